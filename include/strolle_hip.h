@@ -1,0 +1,179 @@
+/* strolle_hip.h — C ABI of libstrolle_hip.so, the MI355X-native replacement for the
+ * per-pixel hot path of Patryk27/strolle.
+ *
+ * Every entry point below replaces one method of the reference's `strolle::Engine<P>`
+ * (reference paths relative to /root/reference). u64 handles stand in for the
+ * `Params` associated handle types (strolle/src/lib.rs:402-409); POD structs stand in
+ * for the Rust value types; `int` status codes stand in for the reference's
+ * panics/asserts. See INTEGRATION.md for the Rust-side FFI stub a maintainer adds.
+ *
+ * Threading: like the reference (`&mut self` everywhere, lib.rs:105-395) an engine is
+ * single-owner; calls on one engine must not overlap. All GPU work is enqueued on the
+ * `hipStream_t` given to st_render_camera (0 = the null stream); st_tick uploads on the
+ * same stream it was given.
+ */
+#ifndef STROLLE_HIP_H
+#define STROLLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct StEngine StEngine;
+typedef uint64_t StHandle;
+
+enum StStatus {
+    ST_OK = 0,
+    ST_ERR_INVALID_ARGUMENT = 1,
+    ST_ERR_NO_DEVICE = 2,        /* engine was created host-only, or HIP is unavailable */
+    ST_ERR_UNKNOWN_CAMERA = 3,   /* reference: panic "camera does not exist" (camera_controllers.rs:21-34) */
+    ST_ERR_EMPTY_MESH = 4,       /* reference: assert "contains no triangles" (triangles.rs:50-53) */
+    ST_ERR_HIP = 5,              /* a HIP runtime call failed; see st_last_error() */
+    ST_ERR_ATLAS_FULL = 6        /* reference: warn + drop (images.rs:71-79) */
+};
+
+/* strolle/src/mesh_triangle.rs:6-33 — object-space triangle */
+typedef struct StMeshTriangle {
+    float positions[3][3];
+    float normals[3][3];
+    float uvs[3][2];
+    float tangents[3][4];
+} StMeshTriangle;
+
+/* strolle/src/material.rs:8-23; texture handles: 0 = None */
+typedef struct StMaterial {
+    float base_color[4];
+    float emissive[4];
+    float perceptual_roughness;
+    float metallic;
+    float reflectance;
+    float ior;
+    StHandle base_color_texture;
+    StHandle emissive_texture;
+    StHandle metallic_roughness_texture;
+    StHandle normal_map_texture;
+    uint32_t alpha_mode; /* 0 = Opaque, 1 = Blend (material.rs:72-91) */
+    uint32_t _pad;
+} StMaterial;
+
+/* strolle/src/light.rs:6-22 */
+enum StLightKind { ST_LIGHT_POINT = 0, ST_LIGHT_SPOT = 1 };
+typedef struct StLight {
+    uint32_t kind;
+    float position[3];
+    float radius;
+    float color[3];
+    float range;
+    float direction[3]; /* spot only */
+    float angle;        /* spot only */
+} StLight;
+
+/* strolle/src/camera.rs:8-14,83-105,170-175. Matrices are column-major (glam Mat4::to_cols_array). */
+enum StCameraMode {
+    ST_MODE_IMAGE = 0, ST_MODE_DI_DIFFUSE = 1, ST_MODE_DI_SPECULAR = 2, ST_MODE_GI_DIFFUSE = 3,
+    ST_MODE_GI_SPECULAR = 4, ST_MODE_BVH_HEATMAP = 5, ST_MODE_REFERENCE = 6
+};
+typedef struct StCamera {
+    uint32_t mode;     /* StCameraMode */
+    uint32_t denoise;  /* CameraMode::{Image,Di*,Gi*}{denoise} */
+    uint32_t depth;    /* CameraMode::Reference{depth} */
+    uint32_t width, height;   /* viewport.size */
+    uint32_t pos_x, pos_y;    /* viewport.position (kept for API parity; the output buffer is viewport-sized) */
+    uint32_t _pad;
+    float transform[16];
+    float projection[16];
+} StCamera;
+
+/* ---- lifecycle: Engine::new (lib.rs:132-158).
+ * device_ordinal >= 0: HIP device; -1: host-only engine (scene stores + BVH build work,
+ * every call that needs the GPU returns ST_ERR_NO_DEVICE — never a CPU fallback). */
+int st_engine_create(int device_ordinal, StEngine** out);
+void st_engine_destroy(StEngine* e);
+const char* st_last_error(void);
+
+/* ---- scene: insert_*/remove_* (lib.rs:161-246) */
+int st_mesh_insert(StEngine* e, StHandle id, const StMeshTriangle* triangles, size_t count);   /* lib.rs:161 */
+int st_mesh_remove(StEngine* e, StHandle id);                                                    /* lib.rs:169 */
+int st_material_insert(StEngine* e, StHandle id, const StMaterial* material);                   /* lib.rs:174 */
+int st_material_has(StEngine* e, StHandle id);                                                   /* lib.rs:184; returns 0/1 */
+int st_material_remove(StEngine* e, StHandle id);                                                /* lib.rs:192 */
+int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t width, uint32_t height, const uint8_t* rgba, int srgb); /* lib.rs:198 */
+int st_image_remove(StEngine* e, StHandle id);                                                   /* lib.rs:211 */
+/* xform: glam Affine3A as 12 floats, column-major (x_axis, y_axis, z_axis, translation) */
+int st_instance_insert(StEngine* e, StHandle id, StHandle mesh, StHandle material, const float xform[12]); /* lib.rs:217 */
+int st_instance_remove(StEngine* e, StHandle id);                                                /* lib.rs:226 */
+int st_light_insert(StEngine* e, StHandle id, const StLight* light);                            /* lib.rs:232 */
+int st_light_remove(StEngine* e, StHandle id);                                                   /* lib.rs:237 */
+int st_sun_update(StEngine* e, float azimuth, float altitude);                                   /* lib.rs:242 */
+
+/* ---- cameras (lib.rs:252-297) */
+int st_camera_create(StEngine* e, const StCamera* camera, StHandle* out_handle);                /* lib.rs:252 */
+int st_camera_update(StEngine* e, StHandle camera, const StCamera* desc);                       /* lib.rs:262 */
+int st_camera_delete(StEngine* e, StHandle camera);                                              /* lib.rs:292 */
+
+/* ---- per frame */
+int st_tick(StEngine* e, void* hip_stream);                                                      /* lib.rs:301 */
+/* Records and launches every pass of CameraController::render (camera_controller.rs:87-174) on
+ * `hip_stream` and writes the composed HDR frame (RGBA32F, width*height*16 B, row-major) to the
+ * DEVICE pointer `out_rgba32f_device` (may be NULL to skip composition). Asynchronous. */
+int st_render_camera(StEngine* e, StHandle camera, void* out_rgba32f_device, void* hip_stream); /* lib.rs:279 */
+
+/* ---- NEW seams (no counterpart in the reference) */
+/* Deterministic seeds: every pass draws seed = pass_seed(base, frame, pass_id) instead of
+ * rand::thread_rng() (camera_controller.rs:189-194; passes/ref_*.rs:49-59). */
+int st_set_seed(StEngine* e, uint64_t base_seed);
+/* Blue-noise texture (256x256 RGBA8), decoded by the caller from strolle/assets/blue-noise.png
+ * (strolle/src/noise.rs:40-50 embeds the PNG; this library carries no image decoder). */
+int st_set_blue_noise(StEngine* e, const uint8_t* rgba_256x256x4, size_t bytes);
+/* Atmosphere LUTs as RGBA32F (transmittance 256x64, sky 256x256); default all-zero == black sky.
+ * LUT generation (strolle-shaders/src/atmosphere/*.rs) is SURVEY.md §8(f) row 1, not built yet. */
+int st_set_atmosphere_luts(StEngine* e, const float* transmittance_256x64x4, const float* sky_256x256x4);
+/* Multi-GPU tiling: restrict every per-pixel launch of this camera to the pixel rows [y0, y1)
+ * of the full viewport (0,0 = whole frame). Pixels keep their absolute coordinates. */
+int st_camera_set_rows(StEngine* e, StHandle camera, uint32_t y0, uint32_t y1);
+
+/* ---- parity / measurement read-back */
+enum StBufferId {
+    ST_BUF_PRIM_GBUFFER_D0_A = 0, ST_BUF_PRIM_GBUFFER_D0_B = 1, ST_BUF_PRIM_GBUFFER_D1_A = 2, ST_BUF_PRIM_GBUFFER_D1_B = 3,
+    ST_BUF_PRIM_SURFACE_MAP_A = 4, ST_BUF_PRIM_SURFACE_MAP_B = 5, ST_BUF_REPROJECTION_MAP = 6, ST_BUF_VELOCITY_MAP = 7,
+    ST_BUF_DI_RESERVOIRS_0 = 8, ST_BUF_DI_RESERVOIRS_1 = 9, ST_BUF_DI_RESERVOIRS_2 = 10,
+    ST_BUF_DI_DIFF_SAMPLES = 11, ST_BUF_DI_DIFF_PREV_COLORS = 12, ST_BUF_DI_DIFF_CURR_COLORS = 13,
+    ST_BUF_DI_DIFF_MOMENTS_A = 14, ST_BUF_DI_DIFF_MOMENTS_B = 15, ST_BUF_DI_DIFF_STASH = 16, ST_BUF_DI_SPEC_SAMPLES = 17,
+    ST_BUF_GI_D0 = 18, ST_BUF_GI_D1 = 19, ST_BUF_GI_D2 = 20,
+    ST_BUF_GI_RESERVOIRS_0 = 21, ST_BUF_GI_RESERVOIRS_1 = 22, ST_BUF_GI_RESERVOIRS_2 = 23, ST_BUF_GI_RESERVOIRS_3 = 24,
+    ST_BUF_GI_DIFF_SAMPLES = 25, ST_BUF_GI_DIFF_PREV_COLORS = 26, ST_BUF_GI_DIFF_CURR_COLORS = 27,
+    ST_BUF_GI_DIFF_MOMENTS_A = 28, ST_BUF_GI_DIFF_MOMENTS_B = 29, ST_BUF_GI_DIFF_STASH = 30, ST_BUF_GI_SPEC_SAMPLES = 31,
+    ST_BUF_REF_HITS = 32, ST_BUF_REF_RAYS = 33, ST_BUF_REF_COLORS = 34,
+    ST_BUF_DBG_USED_MEMORY = 35, /* u32 per pixel: Ray::traverse's `used_memory` of the heatmap pass (ray.rs:125-264) */
+    ST_BUF_COUNT = 36
+};
+/* Synchronises the device, then copies a per-camera buffer (camera_controller/buffers.rs:7-51) to host
+ * memory. out == NULL: only report the size in *written. */
+int st_camera_read_buffer(StEngine* e, StHandle camera, int buffer_id, void* out, size_t capacity, size_t* written);
+/* Rays traced for this camera since the last reset (device counters, closest-hit + any-hit). */
+int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
+/* Host-side copies of what st_tick uploads: what = 0 BVH stream (float4), 1 triangles in the reference's
+ * 144-B layout, 2 lights (112 B), 3 materials (112 B). Works on host-only engines. */
+int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written);
+int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame);
+
+/* Per-kernel timing (HIP events recorded around every launch on the launch stream).
+ * st_profile_read returns, per kernel slot i < *count: name, launches, total milliseconds,
+ * algorithmic bytes per launch (DESIGN.md "bytes per unit" x units launched). */
+enum { ST_PROFILE_MAX_KERNELS = 48 };
+typedef struct StKernelProfile {
+    char name[48];
+    uint32_t launches;
+    float total_ms;
+    double algorithmic_bytes; /* summed over launches */
+} StKernelProfile;
+int st_profile_enable(StEngine* e, int enabled);
+int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* count, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STROLLE_HIP_H */

@@ -1,0 +1,420 @@
+"""Python host-side mirror of `strolle::Engine` over the C ABI of libstrolle_hip.so.
+
+Names, argument meaning and error behaviour follow the reference's public API
+(strolle/src/lib.rs:105-409, camera.rs, light.rs, material.rs, instance.rs,
+mesh_triangle.rs, sun.rs) so tests read like reference usage. This module is a
+thin ctypes binding: all engine logic (scene stores, BVH build, pass graph) is
+C++ inside the shared library, all per-pixel work is HIP. There is no CPU
+fallback: if the library or a GPU is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import enum
+import math
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libstrolle_hip.so")
+
+
+# ----------------------------------------------------------------------------- C structs (include/strolle_hip.h)
+class StMeshTriangle(C.Structure):
+    _fields_ = [("positions", C.c_float * 9), ("normals", C.c_float * 9), ("uvs", C.c_float * 6), ("tangents", C.c_float * 12)]
+
+
+class StMaterial(C.Structure):
+    _fields_ = [
+        ("base_color", C.c_float * 4), ("emissive", C.c_float * 4),
+        ("perceptual_roughness", C.c_float), ("metallic", C.c_float), ("reflectance", C.c_float), ("ior", C.c_float),
+        ("base_color_texture", C.c_uint64), ("emissive_texture", C.c_uint64),
+        ("metallic_roughness_texture", C.c_uint64), ("normal_map_texture", C.c_uint64),
+        ("alpha_mode", C.c_uint32), ("_pad", C.c_uint32),
+    ]
+
+
+class StLight(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("position", C.c_float * 3), ("radius", C.c_float), ("color", C.c_float * 3),
+                ("range", C.c_float), ("direction", C.c_float * 3), ("angle", C.c_float)]
+
+
+class StCamera(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("denoise", C.c_uint32), ("depth", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("pos_x", C.c_uint32), ("pos_y", C.c_uint32), ("_pad", C.c_uint32), ("transform", C.c_float * 16), ("projection", C.c_float * 16)]
+
+
+class StKernelProfile(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_float), ("algorithmic_bytes", C.c_double)]
+
+
+assert C.sizeof(StMeshTriangle) == 144 and C.sizeof(StMaterial) == 88 and C.sizeof(StLight) == 52 and C.sizeof(StCamera) == 160
+
+
+class StrolleError(RuntimeError):
+    pass
+
+
+class Buffer(enum.IntEnum):
+    """Per-camera buffers (strolle/src/camera_controller/buffers.rs:7-51); values == StBufferId."""
+    PRIM_GBUFFER_D0_A = 0; PRIM_GBUFFER_D0_B = 1; PRIM_GBUFFER_D1_A = 2; PRIM_GBUFFER_D1_B = 3
+    PRIM_SURFACE_MAP_A = 4; PRIM_SURFACE_MAP_B = 5; REPROJECTION_MAP = 6; VELOCITY_MAP = 7
+    DI_RESERVOIRS_0 = 8; DI_RESERVOIRS_1 = 9; DI_RESERVOIRS_2 = 10
+    DI_DIFF_SAMPLES = 11; DI_DIFF_PREV_COLORS = 12; DI_DIFF_CURR_COLORS = 13
+    DI_DIFF_MOMENTS_A = 14; DI_DIFF_MOMENTS_B = 15; DI_DIFF_STASH = 16; DI_SPEC_SAMPLES = 17
+    GI_D0 = 18; GI_D1 = 19; GI_D2 = 20
+    GI_RESERVOIRS_0 = 21; GI_RESERVOIRS_1 = 22; GI_RESERVOIRS_2 = 23; GI_RESERVOIRS_3 = 24
+    GI_DIFF_SAMPLES = 25; GI_DIFF_PREV_COLORS = 26; GI_DIFF_CURR_COLORS = 27
+    GI_DIFF_MOMENTS_A = 28; GI_DIFF_MOMENTS_B = 29; GI_DIFF_STASH = 30; GI_SPEC_SAMPLES = 31
+    REF_HITS = 32; REF_RAYS = 33; REF_COLORS = 34; DBG_USED_MEMORY = 35
+
+
+# ----------------------------------------------------------------------------- value types mirroring the reference
+class CameraMode(enum.IntEnum):
+    """strolle/src/camera.rs:83-105"""
+    IMAGE = 0; DI_DIFFUSE = 1; DI_SPECULAR = 2; GI_DIFFUSE = 3; GI_SPECULAR = 4; BVH_HEATMAP = 5; REFERENCE = 6
+
+
+@dataclasses.dataclass
+class Camera:
+    """strolle/src/camera.rs:8-14. `transform`/`projection` are 4x4 numpy arrays in maths layout
+    (m[row, col]); they are handed over column-major like glam's Mat4."""
+    mode: CameraMode = CameraMode.IMAGE
+    denoise: bool = True
+    depth: int = 0
+    size: tuple = (512, 512)
+    position: tuple = (0, 0)
+    transform: np.ndarray = dataclasses.field(default_factory=lambda: np.eye(4, dtype=np.float32))
+    projection: np.ndarray = dataclasses.field(default_factory=lambda: np.eye(4, dtype=np.float32))
+
+    def to_c(self) -> StCamera:
+        c = StCamera()
+        c.mode = int(self.mode); c.denoise = 1 if self.denoise else 0; c.depth = int(self.depth)
+        c.width, c.height = int(self.size[0]), int(self.size[1])
+        c.pos_x, c.pos_y = int(self.position[0]), int(self.position[1])
+        c.transform[:] = np.asarray(self.transform, dtype=np.float32).T.reshape(-1).tolist()
+        c.projection[:] = np.asarray(self.projection, dtype=np.float32).T.reshape(-1).tolist()
+        return c
+
+
+@dataclasses.dataclass
+class Material:
+    """strolle/src/material.rs:8-70 (defaults :53-70)."""
+    base_color: Sequence[float] = (1.0, 1.0, 1.0, 1.0)
+    base_color_texture: Optional[int] = None
+    emissive: Sequence[float] = (0.0, 0.0, 0.0, 0.0)
+    emissive_texture: Optional[int] = None
+    perceptual_roughness: float = 0.5
+    metallic: float = 0.0
+    metallic_roughness_texture: Optional[int] = None
+    reflectance: float = 0.5
+    ior: float = 1.0
+    normal_map_texture: Optional[int] = None
+    alpha_mode: int = 0  # 0 Opaque, 1 Blend
+
+    def to_c(self) -> StMaterial:
+        m = StMaterial()
+        m.base_color[:] = [float(x) for x in self.base_color]
+        m.emissive[:] = [float(x) for x in self.emissive]
+        m.perceptual_roughness = self.perceptual_roughness; m.metallic = self.metallic
+        m.reflectance = self.reflectance; m.ior = self.ior
+        m.base_color_texture = self.base_color_texture or 0
+        m.emissive_texture = self.emissive_texture or 0
+        m.metallic_roughness_texture = self.metallic_roughness_texture or 0
+        m.normal_map_texture = self.normal_map_texture or 0
+        m.alpha_mode = self.alpha_mode
+        return m
+
+
+@dataclasses.dataclass
+class Light:
+    """strolle/src/light.rs:6-22"""
+    kind: int
+    position: Sequence[float]
+    radius: float
+    color: Sequence[float]
+    range: float
+    direction: Sequence[float] = (0.0, 0.0, 0.0)
+    angle: float = 0.0
+
+    @staticmethod
+    def point(position, radius, color, range) -> "Light":
+        return Light(0, position, radius, color, range)
+
+    @staticmethod
+    def spot(position, radius, color, range, direction, angle) -> "Light":
+        return Light(1, position, radius, color, range, direction, angle)
+
+    def to_c(self) -> StLight:
+        l = StLight()
+        l.kind = self.kind; l.position[:] = [float(x) for x in self.position]; l.radius = self.radius
+        l.color[:] = [float(x) for x in self.color]; l.range = self.range
+        l.direction[:] = [float(x) for x in self.direction]; l.angle = self.angle
+        return l
+
+
+@dataclasses.dataclass
+class Sun:
+    """strolle/src/sun.rs:1-14"""
+    azimuth: float = 0.0
+    altitude: float = 0.35
+
+
+class Mesh:
+    """strolle/src/mesh.rs + mesh_triangle.rs: object-space triangles.
+    positions/normals: [n,3,3] float32, uvs: [n,3,2], tangents: [n,3,4] (optional)."""
+
+    def __init__(self, positions, normals, uvs=None, tangents=None):
+        self.positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3, 3)
+        n = len(self.positions)
+        self.normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(n, 3, 3)
+        self.uvs = np.zeros((n, 3, 2), np.float32) if uvs is None else np.ascontiguousarray(uvs, dtype=np.float32).reshape(n, 3, 2)
+        self.tangents = np.zeros((n, 3, 4), np.float32) if tangents is None else np.ascontiguousarray(tangents, dtype=np.float32).reshape(n, 3, 4)
+
+    def pack(self) -> np.ndarray:
+        n = len(self.positions)
+        out = np.concatenate([self.positions.reshape(n, 9), self.normals.reshape(n, 9), self.uvs.reshape(n, 6), self.tangents.reshape(n, 12)], axis=1)
+        return np.ascontiguousarray(out, dtype=np.float32)
+
+
+@dataclasses.dataclass
+class Instance:
+    """strolle/src/instance.rs:16-31. transform: glam Affine3A as a 3x4 numpy array [R | t]."""
+    mesh_handle: int
+    material_handle: int
+    transform: np.ndarray
+
+    def xform12(self):
+        t = np.asarray(self.transform, dtype=np.float32).reshape(3, 4)
+        return np.concatenate([t[:, 0], t[:, 1], t[:, 2], t[:, 3]]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- camera matrices (what Bevy hands to the engine)
+def perspective_infinite_reverse_rh(fov_y: float, aspect: float, z_near: float) -> np.ndarray:
+    """glam Mat4::perspective_infinite_reverse_rh — Bevy's PerspectiveProjection (default fov pi/4, near 0.1)."""
+    f = np.float32(1.0 / math.tan(0.5 * fov_y))
+    m = np.zeros((4, 4), np.float32)
+    m[0, 0] = np.float32(f / np.float32(aspect)); m[1, 1] = f; m[3, 2] = -1.0; m[2, 3] = np.float32(z_near)
+    return m
+
+
+def look_at_transform(eye, target, up=(0.0, 1.0, 0.0)) -> np.ndarray:
+    """World transform of a camera at `eye` looking at `target` (Bevy Transform::looking_at), 4x4."""
+    eye = np.asarray(eye, np.float64); target = np.asarray(target, np.float64); up = np.asarray(up, np.float64)
+    back = eye - target; back /= np.linalg.norm(back)
+    right = np.cross(up, back); right /= np.linalg.norm(right)
+    upv = np.cross(back, right)
+    m = np.eye(4)
+    m[:3, 0] = right; m[:3, 1] = upv; m[:3, 2] = back; m[:3, 3] = eye
+    return m.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- binding
+class _Binding:
+    """Function table over a C library exporting `<prefix>engine_create` etc."""
+
+    def __init__(self, lib: C.CDLL, prefix: str, has_device: bool):
+        self.lib, self.prefix, self.has_device = lib, prefix, has_device
+        u64, vp, i32, u32, sz = C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
+        P = C.POINTER
+
+        def fn(name, args):
+            f = getattr(lib, prefix + name)
+            f.restype = i32
+            f.argtypes = args
+            return f
+
+        self.engine_create = fn("engine_create", [i32, P(vp)] if has_device else [P(vp)])
+        self.engine_destroy = getattr(lib, prefix + "engine_destroy"); self.engine_destroy.restype = None; self.engine_destroy.argtypes = [vp]
+        self.mesh_insert = fn("mesh_insert", [vp, u64, vp, sz]); self.mesh_remove = fn("mesh_remove", [vp, u64])
+        self.material_insert = fn("material_insert", [vp, u64, P(StMaterial)]); self.material_has = fn("material_has", [vp, u64])
+        self.material_remove = fn("material_remove", [vp, u64])
+        self.instance_insert = fn("instance_insert", [vp, u64, u64, u64, P(C.c_float)]); self.instance_remove = fn("instance_remove", [vp, u64])
+        self.light_insert = fn("light_insert", [vp, u64, P(StLight)]); self.light_remove = fn("light_remove", [vp, u64])
+        self.sun_update = fn("sun_update", [vp, C.c_float, C.c_float])
+        self.camera_create = fn("camera_create", [vp, P(StCamera), P(u64)]); self.camera_update = fn("camera_update", [vp, u64, P(StCamera)])
+        self.camera_delete = fn("camera_delete", [vp, u64])
+        self.tick = fn("tick", [vp, vp] if has_device else [vp])
+        self.render_camera = fn("render_camera", [vp, u64, vp, vp] if has_device else [vp, u64, vp])
+        self.set_seed = fn("set_seed", [vp, u64]); self.set_blue_noise = fn("set_blue_noise", [vp, vp, sz])
+        self.set_atmosphere_luts = fn("set_atmosphere_luts", [vp, vp, vp])
+        self.camera_read_buffer = fn("camera_read_buffer", [vp, u64, i32, vp, sz, P(sz)])
+        self.camera_ray_count = fn("camera_ray_count", [vp, u64, P(u64), i32])
+        self.debug_read_scene = fn("debug_read_scene", [vp, i32, vp, sz, P(sz)])
+        self.debug_world = fn("debug_world", [vp, P(u32), P(u32)])
+        if has_device:
+            self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
+            self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
+            self.profile_enable = fn("profile_enable", [vp, i32])
+            self.profile_read = fn("profile_read", [vp, P(StKernelProfile), sz, P(sz), i32])
+            self.last_error = getattr(lib, prefix + "last_error"); self.last_error.restype = C.c_char_p; self.last_error.argtypes = []
+
+
+_STATUS = {1: "invalid argument", 2: "no HIP device (host-only engine or HIP unavailable)", 3: "camera does not exist",
+           4: "mesh contains no triangles", 5: "HIP runtime error", 6: "no more space in the atlas"}
+
+
+class EngineBase:
+    """Shared call sequence; `Engine` binds it to libstrolle_hip.so."""
+
+    def __init__(self, binding: _Binding, device: int = 0):
+        self._b = binding
+        h = C.c_void_p()
+        self._check(binding.engine_create(device, C.byref(h)) if binding.has_device else binding.engine_create(C.byref(h)))
+        self._h = h
+        self._keep = []
+
+    def _check(self, status: int):
+        if status != 0:
+            detail = ""
+            if self._b.has_device:
+                msg = self._b.last_error()
+                detail = f": {msg.decode()}" if msg else ""
+            raise StrolleError(f"{_STATUS.get(status, 'error')} (status {status}){detail}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._b.engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- scene (lib.rs:161-246)
+    def insert_mesh(self, handle: int, mesh: Mesh):
+        data = mesh.pack()
+        self._check(self._b.mesh_insert(self._h, handle, data.ctypes.data, len(data)))
+
+    def remove_mesh(self, handle: int):
+        self._check(self._b.mesh_remove(self._h, handle))
+
+    def insert_material(self, handle: int, material: Material):
+        m = material.to_c()
+        self._check(self._b.material_insert(self._h, handle, C.byref(m)))
+
+    def has_material(self, handle: int) -> bool:
+        return bool(self._b.material_has(self._h, handle))
+
+    def remove_material(self, handle: int):
+        self._check(self._b.material_remove(self._h, handle))
+
+    def insert_image(self, handle: int, rgba: np.ndarray, srgb: bool = True):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        assert rgba.ndim == 3 and rgba.shape[2] == 4
+        self._check(self._b.image_insert_rgba8(self._h, handle, rgba.shape[1], rgba.shape[0], rgba.ctypes.data, 1 if srgb else 0))
+
+    def remove_image(self, handle: int):
+        self._check(self._b.image_remove(self._h, handle))
+
+    def insert_instance(self, handle: int, instance: Instance):
+        x = instance.xform12()
+        self._check(self._b.instance_insert(self._h, handle, instance.mesh_handle, instance.material_handle, x.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def remove_instance(self, handle: int):
+        self._check(self._b.instance_remove(self._h, handle))
+
+    def insert_light(self, handle: int, light: Light):
+        l = light.to_c()
+        self._check(self._b.light_insert(self._h, handle, C.byref(l)))
+
+    def remove_light(self, handle: int):
+        self._check(self._b.light_remove(self._h, handle))
+
+    def update_sun(self, sun: Sun):
+        self._check(self._b.sun_update(self._h, sun.azimuth, sun.altitude))
+
+    # --- cameras (lib.rs:252-297)
+    def create_camera(self, camera: Camera) -> int:
+        c = camera.to_c(); out = C.c_uint64()
+        self._check(self._b.camera_create(self._h, C.byref(c), C.byref(out)))
+        return out.value
+
+    def update_camera(self, handle: int, camera: Camera):
+        c = camera.to_c()
+        self._check(self._b.camera_update(self._h, handle, C.byref(c)))
+
+    def delete_camera(self, handle: int):
+        self._check(self._b.camera_delete(self._h, handle))
+
+    # --- seams
+    def set_seed(self, seed: int):
+        self._check(self._b.set_seed(self._h, seed))
+
+    def set_blue_noise(self, rgba: np.ndarray):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        self._check(self._b.set_blue_noise(self._h, rgba.ctypes.data, rgba.nbytes))
+
+    def set_atmosphere_luts(self, transmittance: np.ndarray, sky: np.ndarray):
+        t = np.ascontiguousarray(transmittance, dtype=np.float32); s = np.ascontiguousarray(sky, dtype=np.float32)
+        assert t.size == 256 * 64 * 4 and s.size == 256 * 256 * 4
+        self._check(self._b.set_atmosphere_luts(self._h, t.ctypes.data, s.ctypes.data))
+
+    # --- read-back
+    def read_buffer(self, camera: int, buffer: Buffer) -> np.ndarray:
+        n = C.c_size_t()
+        self._check(self._b.camera_read_buffer(self._h, camera, int(buffer), None, 0, C.byref(n)))
+        dtype = np.uint32 if int(buffer) == int(Buffer.DBG_USED_MEMORY) else np.float32
+        out = np.empty(n.value // 4, dtype=dtype)
+        self._check(self._b.camera_read_buffer(self._h, camera, int(buffer), out.ctypes.data, out.nbytes, C.byref(n)))
+        return out
+
+    def ray_count(self, camera: int, reset: bool = False) -> int:
+        out = C.c_uint64()
+        self._check(self._b.camera_ray_count(self._h, camera, C.byref(out), 1 if reset else 0))
+        return out.value
+
+    def read_scene(self, what: int) -> np.ndarray:
+        n = C.c_size_t()
+        self._check(self._b.debug_read_scene(self._h, what, None, 0, C.byref(n)))
+        out = np.empty(n.value // 4, dtype=np.float32)
+        if n.value:
+            self._check(self._b.debug_read_scene(self._h, what, out.ctypes.data, out.nbytes, C.byref(n)))
+        return out
+
+    def world(self):
+        lc, fr = C.c_uint32(), C.c_uint32()
+        self._check(self._b.debug_world(self._h, C.byref(lc), C.byref(fr)))
+        return lc.value, fr.value
+
+
+_lib_cache = {}
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    if path not in _lib_cache:
+        if not os.path.exists(path):
+            raise StrolleError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        _lib_cache[path] = C.CDLL(path)
+    return _lib_cache[path]
+
+
+class Engine(EngineBase):
+    """MI355X engine. device >= 0: HIP ordinal; device = -1: host-only (scene + BVH logic, no rendering)."""
+
+    def __init__(self, device: int = 0):
+        super().__init__(_Binding(load_library(), "st_", True), device)
+
+    def tick(self, stream: int = 0):
+        self._check(self._b.tick(self._h, stream))
+
+    def render_camera(self, handle: int, out_device_ptr: int = 0, stream: int = 0):
+        """Enqueue CameraController::render; `out_device_ptr` = device address of a W*H RGBA32F buffer (0 = skip composition)."""
+        self._check(self._b.render_camera(self._h, handle, out_device_ptr, stream))
+
+    def set_camera_rows(self, handle: int, y0: int, y1: int):
+        self._check(self._b.camera_set_rows(self._h, handle, y0, y1))
+
+    def profile_enable(self, enabled: bool):
+        self._check(self._b.profile_enable(self._h, 1 if enabled else 0))
+
+    def profile_read(self, reset: bool = True):
+        arr = (StKernelProfile * 48)(); n = C.c_size_t()
+        self._check(self._b.profile_read(self._h, arr, 48, C.byref(n), 1 if reset else 0))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, algorithmic_bytes=arr[i].algorithmic_bytes)
+                for i in range(n.value)]

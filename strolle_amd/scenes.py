@@ -1,0 +1,113 @@
+"""Benchmark scenes of the reference's examples, rebuilt through the Engine API.
+
+cornell: bevy-strolle/examples/cornell.rs (scene.gltf + one point light, sun below the horizon).
+dungeon: bevy-strolle/examples/demo.rs (level.glb + six point lights; materials forced to
+reflectance 0 / perceptual_roughness 1 by `adjust_materials`, demo.rs:247-260).
+
+Inputs pinned here because Bevy is not available (stated in DESIGN.md): glTF roughnessFactor
+default 1.0 -> perceptual_roughness, StandardMaterial reflectance default 0.5, PointLight
+range default 20.0, PerspectiveProjection fov pi/4 near 0.1 (infinite reverse-Z).
+"""
+import math
+import os
+
+import numpy as np
+
+from .api import Camera, CameraMode, Instance, Light, Material, Mesh, Sun, look_at_transform, perspective_infinite_reverse_rh
+
+ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+
+
+def load_blue_noise() -> np.ndarray:
+    return np.load(os.path.join(ASSETS, "blue_noise.npy"))
+
+
+def _insert_gltf(engine, npz, material_overrides=None, first_handle=1):
+    n_mat = len(npz["material_metallic"])
+    n_img = int(npz["n_images"]) if "n_images" in npz else 0
+    for i in range(n_img):
+        engine.insert_image(1000 + i, npz[f"image_{i}"], srgb=True)
+    for i in range(n_mat):
+        img = int(npz["material_image"][i])
+        kw = dict(
+            base_color=npz["material_base_color"][i].tolist(),
+            emissive=npz["material_emissive"][i].tolist() + [1.0],
+            perceptual_roughness=float(npz["material_perceptual_roughness"][i]),
+            metallic=float(npz["material_metallic"][i]),
+            reflectance=0.5,
+            alpha_mode=int(npz["material_alpha_mode"][i]),
+            base_color_texture=(1000 + img) if img >= 0 else None,
+        )
+        if material_overrides:
+            kw.update(material_overrides)
+        engine.insert_material(first_handle + i, Material(**kw))
+    n = int(npz["n_meshes"])
+    for i in range(n):
+        engine.insert_mesh(first_handle + i, Mesh(npz[f"positions_{i}"], npz[f"normals_{i}"], npz[f"uvs_{i}"]))
+        x = npz[f"xform_{i}"].reshape(4, 3).T  # [x_axis y_axis z_axis t] columns -> 3x4
+        engine.insert_instance(first_handle + i, Instance(first_handle + i, first_handle + int(npz[f"material_{i}"]), x))
+    return n
+
+
+def camera_for(size, eye, target, mode=CameraMode.IMAGE, denoise=True, depth=0) -> Camera:
+    w, h = size
+    return Camera(mode=mode, denoise=denoise, depth=depth, size=(w, h),
+                  transform=look_at_transform(eye, target),
+                  projection=perspective_infinite_reverse_rh(math.pi / 4.0, w / h, 0.1))
+
+
+def build_cornell(engine, t: float = 0.0):
+    """cornell.rs:38-93 at time t (the point light orbits; the benchmark fixes t = 0)."""
+    npz = np.load(os.path.join(ASSETS, "cornell.npz"))
+    engine.set_blue_noise(load_blue_noise())
+    _insert_gltf(engine, npz)
+    intensity = 50.0 / (4.0 * math.pi)  # extract.rs:285-297
+    engine.insert_light(1, Light.point((math.sin(t) / 2.0, 1.5, math.cos(t) / 2.0), 0.15, (intensity,) * 3, 20.0))
+    engine.update_sun(Sun(azimuth=0.0, altitude=-1.0))  # cornell.rs:87
+
+
+def cornell_camera(size, mode=CameraMode.IMAGE, denoise=True, depth=0) -> Camera:
+    return camera_for(size, (0.0, 1.0, 3.2), (0.0, 1.0, 0.0), mode, denoise, depth)  # cornell.rs:76-78
+
+
+def build_dungeon(engine):
+    """demo.rs:155-218 without the three emissive tori (Bevy's shape::Torus tessellation is not available here)."""
+    npz = np.load(os.path.join(ASSETS, "dungeon.npz"))
+    engine.set_blue_noise(load_blue_noise())
+    _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0))
+    intensity = 5000.0 / (4.0 * math.pi)
+    lights = [(-3.0, 0.75, -23.0), (-23.5, 0.75, -31.0), (1.25, 0.75, -10.5), (-3.15, 0.75, 1.25), (-3.25, 0.75, 20.25), (13.25, 0.75, -28.25)]
+    for i, p in enumerate(lights):
+        engine.insert_light(1 + i, Light.point(p, 0.15, (intensity,) * 3, 35.0))
+    engine.update_sun(Sun(azimuth=0.0, altitude=-1.0))
+
+
+def dungeon_camera(size, mode=CameraMode.IMAGE, denoise=True, depth=0) -> Camera:
+    return camera_for(size, (-5.75, 0.5, -16.8), (-5.75, 0.5, -17.0), mode, denoise, depth)  # demo.rs:150-151
+
+
+def build_random_soup(engine, n_triangles: int, seed: int = 0, n_lights: int = 3, blend_fraction: float = 0.0):
+    """Synthetic stress scene for parity tests: a random triangle soup in [-1,1]^3 with a few materials/lights."""
+    rng = np.random.default_rng(seed)
+    engine.set_blue_noise(load_blue_noise())
+    n_mat = 4
+    for i in range(n_mat):
+        engine.insert_material(1 + i, Material(base_color=rng.uniform(0.2, 0.9, 3).tolist() + [1.0], perceptual_roughness=float(rng.uniform(0.2, 1.0)),
+                                               metallic=float(rng.uniform(0.0, 0.8)) if i % 2 else 0.0,
+                                               emissive=(rng.uniform(0, 0.5, 3).tolist() + [1.0]) if i == 3 else (0, 0, 0, 0)))
+    per = max(1, n_triangles // n_mat)
+    for i in range(n_mat):
+        c = rng.uniform(-1, 1, (per, 1, 3)).astype(np.float32)
+        pos = c + rng.uniform(-0.15, 0.15, (per, 3, 3)).astype(np.float32)
+        e1 = pos[:, 1] - pos[:, 0]; e2 = pos[:, 2] - pos[:, 0]
+        nrm = np.cross(e1, e2); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
+        nrm = np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32)
+        uv = rng.uniform(0, 1, (per, 3, 2)).astype(np.float32)
+        engine.insert_mesh(1 + i, Mesh(pos, nrm, uv))
+        ang = float(rng.uniform(0, 1))
+        rot = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]], np.float32)
+        x = np.concatenate([rot * np.float32(1.0 + 0.1 * i), rng.uniform(-0.1, 0.1, (3, 1)).astype(np.float32)], axis=1)
+        engine.insert_instance(1 + i, Instance(1 + i, 1 + i, x))
+    for i in range(n_lights):
+        engine.insert_light(1 + i, Light.point(rng.uniform(-1.5, 1.5, 3).tolist(), 0.1, rng.uniform(0.5, 2.0, 3).tolist(), 20.0))
+    engine.update_sun(Sun(azimuth=0.0, altitude=-1.0))

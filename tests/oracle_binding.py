@@ -1,0 +1,57 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+It reuses the product's struct definitions and call sequence (strolle_amd.api.EngineBase)
+with the `or_` prefix, so the same scene-building code drives oracle and product.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from strolle_amd.api import EngineBase, _Binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+_lib = None
+
+
+def oracle_lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            build_oracle()
+        _lib = C.CDLL(ORACLE_LIB)
+    return _lib
+
+
+class OracleEngine(EngineBase):
+    def __init__(self):
+        super().__init__(_Binding(oracle_lib(), "or_", False))
+        self._sizes = {}
+
+    def create_camera(self, camera):
+        h = super().create_camera(camera)
+        self._sizes[h] = camera.size
+        return h
+
+    def update_camera(self, handle, camera):
+        super().update_camera(handle, camera)
+        self._sizes[handle] = camera.size
+
+    def tick(self):
+        self._check(self._b.tick(self._h))
+
+    def render_camera(self, handle, compose: bool = True):
+        w, h = self._sizes[handle]
+        out = np.zeros((h, w, 4), np.float32) if compose else None
+        self._check(self._b.render_camera(self._h, handle, out.ctypes.data if compose else None))
+        return out
