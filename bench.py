@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mray/s + ms/frame, Cornell box 1920x1080, Image{denoise:true}
+(1 spp ReSTIR DI + GI + SVGF), on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: Engine::tick + CameraController::render (every pass of the pipeline) + composition.
+Scene, buffers and temporal state are resident in HBM before the timed region; the output stays on the device.
+N > 1: weak scaling — the frame grows to N x 1080p pixels (N=4 is BASELINE.json's 3840x2160 4-tile config),
+each rank renders one row band (+ apron) and the bands are all-gathered every frame (the only collective).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def cpu_baseline(args, size):
+    """The CPU oracle ("port": our C++ restatement of the reference; the reference's lavapipe path cannot run here)
+    timed on this host's cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleEngine, oracle_lib
+    from strolle_amd import CameraMode, scenes
+    lib = oracle_lib()
+    cores = int(lib.or_num_threads())
+    e = OracleEngine()
+    scenes.build_cornell(e)
+    e.set_seed(args.seed)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    cam = e.create_camera(desc)
+    warm, timed = 2, 4
+    for _ in range(warm):
+        e.update_camera(cam, desc); e.tick(); e.render_camera(cam)
+    e.ray_count(cam, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        e.update_camera(cam, desc); e.tick(); e.render_camera(cam)
+    dt = time.perf_counter() - t0
+    rays = e.ray_count(cam)
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "ms_per_frame": round(dt / timed * 1e3, 1),
+            "sample": f"{timed} frames (after {warm} warm-up) of the same {size[0]}x{size[1]} Cornell Image workload, OpenMP over {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)  # two full 6-frame GI cycles (strolle-gpu/src/frame.rs:19-21)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--apron", type=int, default=128, help="extra rows rendered around a rank's band in Image mode (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from strolle_amd import CameraMode, Engine, scenes
+    from strolle_amd.distributed import band_for_rank, gather_frame, render_window, weak_scaling_frame
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    base = (args.width, args.height)
+    width, height = weak_scaling_frame(base, world)
+    engine = Engine(device=local_rank)
+    scenes.build_cornell(engine)
+    engine.set_seed(args.seed)
+    desc = scenes.cornell_camera((width, height), CameraMode.IMAGE)
+    cam = engine.create_camera(desc)
+    band = band_for_rank(height, world, rank)
+    if world > 1:
+        y0, y1 = render_window(height, band, args.apron)
+        engine.set_camera_rows(cam, y0, y1)
+    out = torch.zeros((height, width, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        engine.update_camera(cam, desc)   # Bevy calls update_camera every frame (bevy-strolle/src/stages/prepare.rs:300-340)
+        engine.tick(stream)
+        engine.render_camera(cam, out.data_ptr(), stream)
+        if world > 1:
+            return gather_frame(out, height, width, world, rank)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    engine.ray_count(cam, reset=True)
+    if not args.no_profile:
+        engine.profile_enable(True)
+        engine.profile_read(reset=True)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    rays = engine.ray_count(cam)
+    prof = [] if args.no_profile else engine.profile_read(reset=True)
+    engine.profile_enable(False)
+    t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, rays_total = float(tmax[0]), float(tsum[1])
+    else:
+        rays_total = float(rays)
+    finite = bool(torch.isfinite(frame).all())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        result = {
+            "metric": "Mray/s (primary + shadow + GI rays traced per second, whole job)",
+            "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mray/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Cornell box {width}x{height}, CameraMode::Image{{denoise:true}} (1 spp ReSTIR DI+GI + SVGF), static camera, point light at t=0",
+                       "scene": "cornell (32 triangles, 2 light slots)", "width": width, "height": height,
+                       "per_gpu_rows": band[1] - band[0], "apron_rows": args.apron if world > 1 else 0,
+                       "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
+                       "partition": "single GPU" if world == 1 else f"{world} row bands + all-gather of the RGBA32F frame"},
+        }
+        if prof:
+            dom = max(prof, key=lambda p: p["total_ms"])
+            avg_ms = dom["total_ms"] / dom["launches"]
+            achieved = dom["algorithmic_bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(dom["name"], {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            result["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                                  "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": round(dom["algorithmic_bytes"] / dom["launches"]),
+                                  "note": "algorithmic bytes = compulsory screen-space plane bytes + traversal bytes (the reference's used_memory counter); DESIGN.md"}
+            tot = sum(p["total_ms"] for p in prof)
+            result["kernels"] = {p["name"]: {"ms_per_frame": round(p["total_ms"] / args.steps, 5), "launches_per_frame": round(p["launches"] / args.steps, 2),
+                                            "alg_GBps": round(p["algorithmic_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1) if p["total_ms"] > 0 else None}
+                                 for p in sorted(prof, key=lambda p: -p["total_ms"])}
+            result["gpu_kernel_ms_per_frame"] = round(tot / args.steps, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, base)
+            except Exception as ex:  # the baseline must never sink the GPU number
+                result["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,7 +94,7 @@ int st_engine_create(int device_ordinal, StEngine** out);
 void st_engine_destroy(StEngine* e);
 const char* st_last_error(void);
 
-/* ---- scene: insert_*/remove_* (lib.rs:161-246) */
+/* ---- scene: insert_xxx / remove_xxx (lib.rs:161-246) */
 int st_mesh_insert(StEngine* e, StHandle id, const StMeshTriangle* triangles, size_t count);   /* lib.rs:161 */
 int st_mesh_remove(StEngine* e, StHandle id);                                                    /* lib.rs:169 */
 int st_material_insert(StEngine* e, StHandle id, const StMaterial* material);                   /* lib.rs:174 */
@@ -129,7 +129,7 @@ int st_set_seed(StEngine* e, uint64_t base_seed);
  * (strolle/src/noise.rs:40-50 embeds the PNG; this library carries no image decoder). */
 int st_set_blue_noise(StEngine* e, const uint8_t* rgba_256x256x4, size_t bytes);
 /* Atmosphere LUTs as RGBA32F (transmittance 256x64, sky 256x256); default all-zero == black sky.
- * LUT generation (strolle-shaders/src/atmosphere/*.rs) is SURVEY.md §8(f) row 1, not built yet. */
+ * LUT generation (strolle-shaders/src/atmosphere/ *.rs) is SURVEY.md §8(f) row 1, not built yet. */
 int st_set_atmosphere_luts(StEngine* e, const float* transmittance_256x64x4, const float* sky_256x256x4);
 /* Multi-GPU tiling: restrict every per-pixel launch of this camera to the pixel rows [y0, y1)
  * of the full viewport (0,0 = whole frame). Pixels keep their absolute coordinates. */

@@ -277,7 +277,31 @@ struct Engine {
     std::vector<uint8_t> blue_noise;  // 256*256*4
     std::vector<Vec4> transmittance_lut, sky_lut;  // uploaded LUTs (generation is SURVEY §8(f) row 1)
     std::vector<uint8_t> atlas; uint32_t atlas_w = 0, atlas_h = 0;
-    std::map<uint64_t, Vec4> image_rects;
+    // images: one linear RGBA8 atlas, 2048 texels wide, shelf-packed in insertion order and grown in 256-row steps.
+    // (The reference allocates rectangles in an 8192^2 atlas with `guillotiere` 0.6.2, images.rs:54-127 — a crate that is
+    //  not under /root/reference; rectangle placement is therefore this project's own and only the *sampling* result,
+    //  which is placement-independent up to clamp-at-rect-border bleeding, is comparable.)
+    struct ImageRec { uint32_t x, y, w, h; };
+    std::map<uint64_t, ImageRec> images; uint32_t shelf_x = 0, shelf_y = 0, shelf_h = 0;
+    bool insert_image(uint64_t id, uint32_t w, uint32_t h, const uint8_t* rgba) {
+        const uint32_t kAtlasW = 2048, kAtlasMaxH = 8192;
+        if (w > kAtlasW) return false;
+        ImageRec rec;
+        auto it = images.find(id);
+        if (it != images.end() && it->second.w == w && it->second.h == h) rec = it->second;
+        else {
+            if (shelf_x + w > kAtlasW) { shelf_x = 0; shelf_y += shelf_h; shelf_h = 0; }
+            if (shelf_y + h > kAtlasMaxH) return false;
+            rec = ImageRec{shelf_x, shelf_y, w, h};
+            shelf_x += w; shelf_h = std::max(shelf_h, h);
+        }
+        if (atlas_w == 0) atlas_w = kAtlasW;
+        if (rec.y + h > atlas_h) { atlas_h = (rec.y + h + 255u) & ~255u; atlas.resize((size_t)atlas_w * atlas_h * 4, 0); }
+        for (uint32_t y = 0; y < h; y++) std::memcpy(&atlas[((size_t)(rec.y + y) * atlas_w + rec.x) * 4], rgba + (size_t)y * w * 4, (size_t)w * 4);
+        images[id] = rec;
+        materials_dirty = true;
+        return true;
+    }
     std::map<uint64_t, std::unique_ptr<CameraSlot>> cameras; uint64_t next_camera = 0;
 
     Engine() {
@@ -307,7 +331,13 @@ struct Engine {
         material_index.erase(it);
         materials_dirty = true;
     }
-    Vec4 lookup_image(uint64_t h) const { if (!h) return Vec4(); auto it = image_rects.find(h); return it == image_rects.end() ? Vec4() : it->second; }
+    Vec4 lookup_image(uint64_t h) const {
+        if (!h || atlas_w == 0) return Vec4();
+        auto it = images.find(h);
+        if (it == images.end()) return Vec4();
+        const ImageRec& r = it->second;
+        return Vec4((float)r.x / (float)atlas_w, (float)r.y / (float)atlas_h, (float)r.w / (float)atlas_w, (float)r.h / (float)atlas_h);
+    }
     void refresh_materials() {
         gpu_materials.clear();
         for (auto& m : materials) {

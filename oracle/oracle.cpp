@@ -41,6 +41,8 @@ int or_mesh_remove(OrEngine* e, uint64_t id) { E(e)->meshes.erase(id); return 0;
 int or_material_insert(OrEngine* e, uint64_t id, const ApiMaterial* m) { E(e)->insert_material(id, *m); return 0; }
 int or_material_has(OrEngine* e, uint64_t id) { return E(e)->material_index.count(id) ? 1 : 0; }
 int or_material_remove(OrEngine* e, uint64_t id) { E(e)->remove_material(id); return 0; }
+int or_image_insert_rgba8(OrEngine* e, uint64_t id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) { return E(e)->insert_image(id, w, h, rgba) ? 0 : 6; }
+int or_image_remove(OrEngine* e, uint64_t id) { E(e)->images.erase(id); E(e)->materials_dirty = true; return 0; }
 int or_instance_insert(OrEngine* e, uint64_t id, uint64_t mesh, uint64_t material, const float xform[12]) {
     E(e)->insert_instance(id, mesh, material, xform);
     return 0;

@@ -245,8 +245,8 @@ class _Binding:
         self.camera_ray_count = fn("camera_ray_count", [vp, u64, P(u64), i32])
         self.debug_read_scene = fn("debug_read_scene", [vp, i32, vp, sz, P(sz)])
         self.debug_world = fn("debug_world", [vp, P(u32), P(u32)])
+        self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
-            self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
             self.profile_enable = fn("profile_enable", [vp, i32])
             self.profile_read = fn("profile_read", [vp, P(StKernelProfile), sz, P(sz), i32])

@@ -1,0 +1,43 @@
+// k_common.h — per-kernel boilerplate: tile/pixel resolution and launch geometry.
+#pragma once
+#include "st_device.h"
+#include "st_kernels.h"
+
+namespace st {
+
+constexpr int kBlockThreads = 256;               // 4 wavefronts, one 8x8 tile each
+constexpr int kStackWords = 4 * kBvhStackSize * 64;  // 24 KiB of LDS per block for the traversal stacks
+
+struct LaunchDims { uint32_t tiles_x, tile_y0, tile_y1, blocks; };
+inline LaunchDims launch_dims(const KArgs& a, bool half_x) {
+    LaunchDims d;
+    d.tiles_x = (a.width + 7u) / 8u;
+    if (half_x) d.tiles_x /= 2u;  // `(size + 7) / 8 / uvec2(2, 1)` workgroups (passes/*_resampling.rs, gi_sampling.rs)
+    d.tile_y0 = a.row0 / 8u;
+    d.tile_y1 = (a.row1 + 7u) / 8u;
+    const uint32_t groups_x = (d.tiles_x + 3u) / 4u;
+    d.blocks = groups_x * (d.tile_y1 - d.tile_y0);
+    return d;
+}
+
+// Resolves this thread's `global_invocation_id` (gid). Returns false for lanes outside the dispatch.
+ST_D bool resolve_gid(const KArgs& a, bool half_x, U2* gid) {
+    uint32_t tiles_x = (a.width + 7u) >> 3;
+    if (half_x) tiles_x >>= 1;
+    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
+    TileCoord tc = tile_for_thread(tiles_x, ty1 - ty0);
+    if (!tc.valid) return false;
+    tc.y += ty0;
+    *gid = pixel_in_tile(tc);
+    return true;
+}
+// pixel belongs to this launch: inside the viewport (Camera::contains) and inside the row window
+ST_D bool owns_pixel(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.height && p.y >= a.row0 && p.y < a.row1; }
+
+#define ST_LAUNCH(kernel, half, stream, ...)                                                          \
+    do {                                                                                              \
+        const LaunchDims d_ = launch_dims(a, half);                                                   \
+        if (d_.blocks) hipLaunchKernelGGL(kernel, dim3(d_.blocks), dim3(kBlockThreads), 0, stream, __VA_ARGS__); \
+    } while (0)
+
+}  // namespace st

@@ -1,0 +1,193 @@
+// k_di.hip — ReSTIR DI: initial sampling, temporal and spatial resampling, resolving.
+// Behavioural contract: strolle-shaders/src/di_{sampling,temporal_resampling,spatial_resampling,resolving}.rs.
+// Reservoir roles: sampling -> [1]; temporal reads [0], RMW [1]; spatial [1] -> [2]; resolving [2] -> [0]
+// (strolle/src/camera_controller/passes/di_*.rs). Spatial scratch aliases di_diff_samples /
+// di_diff_curr_colors / di_diff_stash (passes/di_spatial_resampling.rs:24-28).
+#include "k_common.h"
+
+namespace st {
+
+// ---------------------------------------------------------------- di_sampling.rs:3-94
+__global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, uint32_t seed) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const uint32_t idx = screen_to_idx(a, pos);
+    WhiteNoise wn = white_noise(seed, pos);
+    const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    if (!hit_some(hit)) return;
+    EphemeralResult res = ephemeral_build(a, wn, hit);
+    DiReservoir out = di_empty();
+    if (res.m > 0.0f) {
+        const float4 bn = blue_noise_read(a, pos);
+        const Ray ray = light_ray_bnoise(light_get(a, res.light_id), v2(bn.x, bn.y), hit.point);
+        const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+        count_rays(a.ray_counter, used_);
+        if (occluded) res.w = 0.0f;
+        out.s.light_id = res.light_id; out.s.light_point = ray.origin; out.s.is_occluded = occluded;
+        out.m = 1.0f; out.w = res.w;
+    }
+    di_write(a.di_res[1], idx, out);
+}
+void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_sampling, false, s, a, seed); }
+
+// ---------------------------------------------------------------- di_temporal_resampling.rs:3-112
+__global__ __launch_bounds__(kBlockThreads) void k_di_temporal(const KArgs a, uint32_t seed) {
+    U2 lhs_pos;
+    if (!resolve_gid(a, false, &lhs_pos) || !owns_pixel(a, lhs_pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
+    WhiteNoise wn = white_noise(seed, lhs_pos);
+    const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
+    if (!hit_some(lhs_hit)) return;
+    DiReservoir lhs = di_read(a.di_res[1], lhs_idx, n);
+    if (lhs.m != 0.0f) lhs.s.pdf = di_pdf_ex(lhs.s, light_get(a, lhs.s.light_id), lhs_hit);
+    DiReservoir rhs = di_empty();
+    Hit rhs_hit = hit_zero();
+    bool rhs_killed = false;
+    const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, lhs_pos));
+    if (rp.confidence > 0.0f) {
+        const U2 rhs_pos = reprojection_prev_round(rp);
+        rhs = di_read(a.di_res[0], screen_to_idx(a, rhs_pos), n);
+        rhs.m = fmin_(rhs.m, 64.0f);
+        if (rhs.m != 0.0f) {
+            const GpuLight rhs_light = light_get(a, rhs.s.light_id);
+            const uint32_t slot = f2b(rhs_light.d3.x);
+            if (slot == 0xcafebabeu) { rhs.w = 0.0f; rhs_killed = true; }
+            else if (slot > 0u) rhs.s.light_id = slot - 1u;
+            rhs_hit = pixel_hit(a, a.prev_cam, a.pg0, a.pg1, rhs_pos);
+        }
+    }
+    Mis mis;
+    mis.lhs_rhs_pdf = ((lhs.m > 0.0f) & hit_some(rhs_hit)) ? di_pdf_ex(lhs.s, light_get_prev(a, lhs.s.light_id), rhs_hit) : 0.0f;
+    mis.rhs_lhs_pdf = ((rhs.m > 0.0f) & !rhs_killed) ? di_pdf_ex(rhs.s, light_get(a, rhs.s.light_id), lhs_hit) : 0.0f;
+    mis.lhs_m = lhs.m; mis.rhs_m = rhs.m; mis.rhs_jacobian = 1.0f; mis.lhs_lhs_pdf = lhs.s.pdf; mis.rhs_rhs_pdf = rhs.s.pdf;
+    const MisResult mr = mis_eval(mis);
+    DiReservoir main_ = di_empty();
+    float main_pdf = 0.0f;
+    if (res_update(main_, wn, lhs.s, mr.lhs_mis * mr.lhs_pdf * lhs.w)) main_pdf = mr.lhs_pdf;
+    if (res_update(main_, wn, rhs.s, mr.rhs_mis * mr.rhs_pdf * rhs.w)) main_pdf = mr.rhs_pdf;
+    main_.m = lhs.m + mr.m;
+    main_.s.pdf = main_pdf;
+    main_.s.confidence = rhs_killed ? 0.0f : 1.0f;
+    res_norm(main_, main_pdf, 1.0f, 1.0f);
+    di_write(a.di_res[1], lhs_idx, main_);
+}
+void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_temporal, false, s, a, seed); }
+
+// ---------------------------------------------------------------- di_spatial_resampling.rs:3-147 (pick)
+__global__ __launch_bounds__(kBlockThreads) void k_di_spatial_pick(const KArgs a, uint32_t seed) {
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    if (!owns_pixel(a, lhs_pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
+    WhiteNoise wn = white_noise(seed, lhs_pos);
+    float4* buf_d0 = a.di_diff_samples; float4* buf_d1 = a.di_diff_curr_colors;
+    const U2 buf_pos_a = u2(gid.x * 2u, gid.y), buf_pos_b = u2(gid.x * 2u + 1u, gid.y);
+    const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
+    if (!hit_some(lhs_hit)) return;
+    const DiReservoir lhs = di_read(a.di_res[1], lhs_idx, n);
+    DiReservoir rhs = di_empty();
+    uint32_t rhs_nth = 0u, rhs_idx = 0u;
+    Hit rhs_hit = hit_zero();
+    float max_radius = 128.0f;
+    while (rhs_nth < 8u) {
+        rhs_nth += 1u;
+        const V2 disk = wn.sample_disk();
+        const U2 rhs_pos = camera_contain(a, as_i2(as_v2(lhs_pos) + disk * max_radius));
+        if (rhs_pos.x == lhs_pos.x && rhs_pos.y == lhs_pos.y) continue;
+        rhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, rhs_pos);
+        if (!hit_some(rhs_hit)) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
+        if (fabsf(rhs_hit.g.depth - lhs_hit.g.depth) > 0.33f * lhs_hit.g.depth) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
+        if (dot(rhs_hit.g.normal, lhs_hit.g.normal) < 0.33f) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
+        rhs_idx = screen_to_idx(a, rhs_pos);
+        rhs = di_read(a.di_res[1], rhs_idx, n);
+        if (rhs.m != 0.0f) break;
+    }
+    if (rhs.m == 0.0f) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return; }
+    const float lhs_rhs_pdf = di_pdf_ex(lhs.s, light_get(a, lhs.s.light_id), rhs_hit);
+    const float rhs_lhs_pdf = di_pdf_ex(rhs.s, light_get(a, rhs.s.light_id), lhs_hit);
+    const Ray ray_a = lhs_rhs_pdf > 0.0f ? di_sample_ray(lhs.s, rhs_hit.point) : zero_ray();
+    const Ray ray_b = rhs_lhs_pdf > 0.0f ? di_sample_ray(rhs.s, lhs_hit.point) : zero_ray();
+    tex_write(buf_d0, a, buf_pos_a, f4(ray_a.origin, ray_a.len));
+    const V2 ea = normal_encode(ray_a.dir);
+    tex_write(buf_d1, a, buf_pos_a, make_float4(ea.x, ea.y, b2f(rhs_idx + 1u), 0.0f));
+    tex_write(buf_d0, a, buf_pos_b, f4(ray_b.origin, ray_b.len));
+    const V2 eb = normal_encode(ray_b.dir);
+    tex_write(buf_d1, a, buf_pos_b, make_float4(eb.x, eb.y, lhs_rhs_pdf, rhs_lhs_pdf));
+}
+void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_spatial_pick, true, s, a, seed); }
+
+// ---------------------------------------------------------------- di_spatial_resampling.rs:211-297 (sample)
+__global__ __launch_bounds__(kBlockThreads) void k_di_spatial_sample(const KArgs a, uint32_t seed) {
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    if (!owns_pixel(a, lhs_pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
+    WhiteNoise wn = white_noise(seed, lhs_pos);
+    const float4* buf_d2 = a.di_diff_stash;
+    const float4* in_res = a.di_res[1];
+    float4* out_res = a.di_res[2];
+    const float4 d0 = tex_read(buf_d2, a, u2(gid.x * 2u, gid.y)), d1 = tex_read(buf_d2, a, u2(gid.x * 2u + 1u, gid.y));
+    const float lhs_rhs_vis = d0.x;
+    const uint32_t rhs_idx = f2b(d0.y);
+    const float rhs_lhs_vis = d1.x, lhs_rhs_pdf = d1.y, rhs_lhs_pdf = d1.z;
+    const DiReservoir lhs = di_read(in_res, lhs_idx, n);
+    if (rhs_idx > 0u) {
+        const DiReservoir rhs = di_read(in_res, rhs_idx - 1u, n);
+        Mis mis;
+        mis.lhs_m = lhs.m; mis.rhs_m = rhs.m; mis.rhs_jacobian = 1.0f; mis.lhs_lhs_pdf = lhs.s.pdf;
+        mis.lhs_rhs_pdf = lhs_rhs_pdf * lhs_rhs_vis; mis.rhs_lhs_pdf = rhs_lhs_pdf * rhs_lhs_vis; mis.rhs_rhs_pdf = rhs.s.pdf;
+        const MisResult mr = mis_eval(mis);
+        DiReservoir main_ = di_empty();
+        float main_pdf = 0.0f;
+        if (res_update(main_, wn, lhs.s, mr.lhs_mis * mr.lhs_pdf * lhs.w)) main_pdf = mr.lhs_pdf;
+        if (res_update(main_, wn, rhs.s, mr.rhs_mis * mr.rhs_pdf * rhs.w)) { main_pdf = mr.rhs_pdf; main_.s.is_occluded = lhs_rhs_vis == 0.0f; }
+        main_.m = lhs.m + mr.m;
+        main_.s.pdf = main_pdf;
+        res_norm(main_, main_pdf, 1.0f, 1.0f);
+        di_write(out_res, lhs_idx, main_);
+    } else di_write(out_res, lhs_idx, lhs);
+    const U2 other = resolve_checkerboard(gid, a.frame / 2u);
+    if (contains_u(a, other)) { const uint32_t oi = screen_to_idx(a, other); di_write(out_res, oi, di_read(in_res, oi, n)); }
+}
+void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_spatial_sample, true, s, a, seed); }
+
+// ---------------------------------------------------------------- di_resolving.rs:3-119
+__global__ __launch_bounds__(kBlockThreads) void k_di_resolving(const KArgs a) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t idx = screen_to_idx(a, pos);
+    const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    DiReservoir res = di_read(a.di_res[2], idx, n);
+    float confidence;
+    V3 radiance, spec_brdf;
+    if (hit_some(hit)) {
+        const bool occluded = trace_any(a, di_sample_ray(res.s, hit.point), lane_stack(lds), &used_);
+        count_rays(a.ray_counter, used_);
+        confidence = (res.s.is_occluded == occluded) ? res.s.confidence : 0.0f;
+        res.s.confidence = 1.0f;
+        res.s.is_occluded = occluded;
+        if (occluded) { radiance = v3s(0.0f); spec_brdf = v3s(0.0f); }
+        else { const LightRadiance lr = light_radiance(light_get(a, res.s.light_id), hit); radiance = lr.radiance * res.w; spec_brdf = lr.spec_brdf; }
+    } else {
+        confidence = 1.0f;
+        radiance = atmosphere_sample(a, hit.dir);
+        spec_brdf = v3s(0.0f);
+    }
+    const float diff_brdf = (1.0f - hit.g.metallic) / kPi;
+    tex_write(a.di_diff_samples, a, pos, f4(radiance * diff_brdf, confidence));
+    tex_write(a.di_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
+    di_write(a.di_res[0], idx, res);
+}
+void launch_di_resolving(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_di_resolving, false, s, a); }
+
+}  // namespace st

@@ -1,0 +1,355 @@
+// k_gi.hip — ReSTIR GI: reprojection, sampling (trace + shade), temporal / spatial / preview resampling, resolving.
+// Behavioural contract: strolle-shaders/src/gi_*.rs. Reservoir roles: reprojection [0] -> [2]; sampling_b -> [1];
+// temporal reads [2], RMW [1]; spatial [1] -> [2]; preview ([1]|[2]) -> [3] -> [0]; resolving reads [0], then copies
+// the frame's source ([1]|[2]) over it (strolle/src/camera_controller/passes/gi_*.rs).
+#include "k_common.h"
+
+namespace st {
+
+// ---------------------------------------------------------------- gi_reprojection.rs:3-51
+__global__ __launch_bounds__(kBlockThreads) void k_gi_reprojection(const KArgs a) {
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const uint32_t n = a.width * a.height;
+    const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    if (!hit_some(hit)) return;
+    const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, pos));
+    GiReservoir res = rp.confidence > 0.0f ? gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n) : gi_empty();
+    res.confidence = 1.0f;
+    res.s.v1_point = hit.point;
+    gi_write(a.gi_res[2], screen_to_idx(a, pos), res);
+}
+void launch_gi_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_gi_reprojection, false, s, a); }
+
+ST_D bool frame_is_gi_tracing(uint32_t frame) { return frame % 6u < 4u; }  // frame.rs:19-21
+
+// ---------------------------------------------------------------- gi_sampling_a.rs:3-122
+__global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_a(const KArgs a, uint32_t seed) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const bool tracing = frame_is_gi_tracing(a.frame);
+    const U2 pos = tracing ? resolve_checkerboard(gid, a.frame / 2u) : resolve_checkerboard(gid, a.frame);
+    if (!owns_pixel(a, pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t idx = screen_to_idx(a, pos);
+    Ray gi_ray; float gi_ray_pdf;
+    if (tracing) {
+        WhiteNoise wn = white_noise(seed, pos);
+        const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+        if (!hit_some(hit)) return;
+        const BrdfSample s = layered_brdf_sample(hit.g, wn, -hit.dir);
+        gi_ray = make_ray(hit.point, s.dir);
+        gi_ray_pdf = s.pdf;
+    } else {
+        const GiReservoir res = gi_read(a.gi_res[2], idx, n);
+        if (res.m == 0.0f) return;
+        gi_ray = make_ray(res.s.v1_point, gi_dir(res.s, res.s.v1_point));
+        gi_ray_pdf = 1.0f;
+    }
+    const TriangleHit gi_hit = trace_closest(a, gi_ray, lane_stack(lds), &used_);
+    count_rays(a.ray_counter, used_);
+    GBuffer gg = gbuffer_zero();
+    if (hit_is_some(gi_hit)) {
+        GpuMaterial m = a.materials[gi_hit.material_id];
+        m.roughness = fmax_(m.roughness, 0.75f * 0.75f);
+        gg.base_color = sample_atlas(a, gi_hit.uv, m.base_color, m.base_color_texture);
+        gg.normal = gi_hit.normal; gg.metallic = m.metallic;
+        gg.emissive = xyz(sample_atlas(a, gi_hit.uv, m.emissive, m.emissive_texture));
+        gg.roughness = m.roughness; gg.reflectance = m.reflectance;
+        gg.depth = distance(gi_ray.origin, gi_hit.point);
+    }
+    float4 p0, p1;
+    gbuffer_pack(gg, &p0, &p1);
+    tex_write(a.gi_d0, a, gid, f4(gi_ray.dir, gi_ray_pdf));  // indexed by the half-resolution gid (gi_sampling_a.rs:117-121)
+    tex_write(a.gi_d1, a, gid, p0);
+    tex_write(a.gi_d2, a, gid, p1);
+}
+void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_sampling_a, true, s, a, seed); }
+
+// ---------------------------------------------------------------- gi_sampling_b.rs:3-235
+__global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_b(const KArgs a, uint32_t seed) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const bool tracing = frame_is_gi_tracing(a.frame);
+    const U2 pos = tracing ? resolve_checkerboard(gid, a.frame / 2u) : resolve_checkerboard(gid, a.frame);
+    if (!owns_pixel(a, pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t idx = screen_to_idx(a, pos);
+    const Hit prim_hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    if (!hit_some(prim_hit)) return;
+    const float4 d0 = tex_read(a.gi_d0, a, gid), d1 = tex_read(a.gi_d1, a, gid), d2 = tex_read(a.gi_d2, a, gid);
+    WhiteNoise wn; Hit gi_hit; float gi_ray_pdf;
+    if (tracing) {
+        wn = white_noise(seed, pos);
+        gi_hit = hit_make(make_ray(prim_hit.point, xyz(d0)), gbuffer_unpack(d1, d2));
+        gi_ray_pdf = d0.w;
+    } else {
+        const GiReservoir res = gi_read(a.gi_res[2], idx, n);
+        if (res.m == 0.0f) return;
+        wn.state = res.s.rng;
+        gi_hit = hit_make(make_ray(res.s.v1_point, xyz(d0)), gbuffer_unpack(d1, d2));
+        gi_ray_pdf = 1.0f;
+    }
+    const uint32_t rng = wn.state;
+    uint32_t light_id; float light_pdf; V3 light_rad; V3 light_dir = v3s(0.0f);
+    if (!hit_some(gi_hit)) {
+        light_id = kLightIdSky; light_pdf = 1.0f;
+        light_rad = atmosphere_sample(a, gi_hit.dir);
+    } else {
+        const float atmosphere_pdf = a.sun_altitude <= -1.0f ? 0.0f : 0.25f;
+        bool pick_sky = a.light_count == 0u;
+        if (!pick_sky) pick_sky = wn.sample() < atmosphere_pdf;  // `||` short-circuits: no sample is drawn when light_count == 0
+        if (pick_sky) {
+            light_id = kLightIdSky; light_pdf = atmosphere_pdf;
+            light_dir = wn.sample_hemisphere(gi_hit.g.normal);
+            light_rad = atmosphere_sample(a, light_dir) * dot(gi_hit.g.normal, light_dir);
+        } else {
+            const EphemeralResult res = ephemeral_build(a, wn, gi_hit);
+            if (res.w > 0.0f) {
+                light_id = res.light_id;
+                light_pdf = (1.0f / res.w) * (1.0f - atmosphere_pdf);
+                light_rad = res.light_rad.radiance * (v3s(1.0f) + res.light_rad.spec_brdf);
+            } else { light_id = 0u; light_pdf = 1.0f; light_rad = v3s(0.0f); }
+        }
+    }
+    V3 radiance;
+    if (light_pdf > 0.0f) {
+        float light_vis;
+        if (hit_some(gi_hit)) {
+            const Ray ray = light_id == kLightIdSky ? make_ray(gi_hit.point, light_dir) : light_ray_wnoise(light_get(a, light_id), wn, gi_hit.point);
+            const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+            count_rays(a.ray_counter, used_);
+            light_vis = occluded ? 0.0f : 1.0f;
+        } else light_vis = 1.0f;
+        radiance = light_rad * light_vis / light_pdf;
+    } else radiance = v3s(0.0f);
+    if (hit_some(gi_hit)) { radiance = radiance * (xyz(gi_hit.g.base_color) / kPi); radiance = radiance + gi_hit.g.emissive; }
+    GiReservoir res = gi_empty();
+    if (gi_ray_pdf > 0.0f) {
+        const V3 v1 = prim_hit.point;
+        V3 v2p, v2n;
+        if (hit_some(gi_hit)) { v2p = gi_hit.point; v2n = gi_hit.g.normal; }
+        else { v2p = v1 + gi_hit.dir * 1000.0f; v2n = -gi_hit.dir; }  // World::SUN_DISTANCE
+        res.s.pdf = 0.0f; res.s.rng = rng; res.s.radiance = radiance; res.s.v1_point = v1; res.s.v2_point = v2p; res.s.v2_normal = v2n;
+        res.m = 1.0f; res.w = 1.0f / gi_ray_pdf;
+        res.s.pdf = gi_pdf(res.s, prim_hit);
+    }
+    gi_write(a.gi_res[1], idx, res);
+}
+void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_sampling_b, true, s, a, seed); }
+
+// ---------------------------------------------------------------- gi_temporal_resampling.rs:3-156
+__global__ __launch_bounds__(kBlockThreads) void k_gi_temporal(const KArgs a, uint32_t seed) {
+    U2 lhs_pos;
+    if (!resolve_gid(a, false, &lhs_pos) || !owns_pixel(a, lhs_pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
+    float4* curr_res = a.gi_res[1];
+    const float4* prev_res = a.gi_res[2];
+    WhiteNoise wn = white_noise(seed, lhs_pos);
+    const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
+    if (!hit_some(lhs_hit)) { gi_write(curr_res, lhs_idx, gi_empty()); return; }
+    const bool tracing = frame_is_gi_tracing(a.frame);
+    const bool got_sample = tracing ? (a.frame % 2u == 0u && got_checkerboard_at(lhs_pos, a.frame / 2u)) : got_checkerboard_at(lhs_pos, a.frame);
+    const GiReservoir lhs = got_sample ? gi_read(curr_res, lhs_idx, n) : gi_empty();
+    GiReservoir rhs = gi_empty();
+    Hit rhs_hit = hit_zero();
+    const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, lhs_pos));
+    if (rp.confidence > 0.0f) {
+        rhs = gi_read(prev_res, lhs_idx, n);
+        rhs.confidence = 1.0f;
+        rhs.m = fmin_(rhs.m, 128.0f);
+        if (!tracing && lhs.m != 0.0f && rhs.m != 0.0f && gi_exists(rhs.s)) {
+            if (distance(lhs.s.radiance, rhs.s.radiance) > 0.33f) rhs.confidence = 0.0f;
+            rhs.s.radiance = lhs.s.radiance;
+            rhs.s.v2_point = lhs.s.v2_point;
+            rhs.s.v2_normal = lhs.s.v2_normal;
+        }
+        if (rhs.m != 0.0f) rhs_hit = pixel_hit(a, a.prev_cam, a.pg0, a.pg1, reprojection_prev_round(rp));
+    }
+    GiReservoir main_ = gi_empty();
+    float main_pdf = 0.0f;
+    if (tracing) {
+        Mis mis;
+        mis.lhs_rhs_pdf = ((lhs.m > 0.0f) & hit_some(rhs_hit)) ? gi_pdf(lhs.s, rhs_hit) : 0.0f;
+        mis.rhs_lhs_pdf = (rhs.m > 0.0f) ? gi_pdf(rhs.s, lhs_hit) : 0.0f;
+        mis.lhs_m = lhs.m; mis.rhs_m = rhs.m; mis.rhs_jacobian = 1.0f; mis.lhs_lhs_pdf = lhs.s.pdf; mis.rhs_rhs_pdf = rhs.s.pdf;
+        const MisResult mr = mis_eval(mis);
+        if (res_update(main_, wn, lhs.s, mr.lhs_mis * mr.lhs_pdf * lhs.w)) main_pdf = mr.lhs_pdf;
+        if (res_update(main_, wn, rhs.s, mr.rhs_mis * mr.rhs_pdf * rhs.w)) main_pdf = mr.rhs_pdf;
+        main_.m = lhs.m + mr.m;
+        main_.confidence = 1.0f;
+        res_norm(main_, main_pdf, 1.0f, 1.0f);
+    } else {
+        if (res_merge(main_, wn, rhs, rhs.s.pdf)) main_pdf = rhs.s.pdf;
+        main_.confidence = rhs.confidence;
+        res_norm(main_, main_pdf, 1.0f, main_.m);
+    }
+    main_.s.pdf = main_pdf;
+    main_.s.v1_point = lhs_hit.point;
+    main_.w = fmin_(main_.w, 5.0f);
+    gi_write(curr_res, lhs_idx, main_);
+}
+void launch_gi_temporal(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_temporal, false, s, a, seed); }
+
+// ---------------------------------------------------------------- gi_spatial_resampling.rs:3-168 (pick)
+__global__ __launch_bounds__(kBlockThreads) void k_gi_spatial_pick(const KArgs a, uint32_t seed) {
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    if (!owns_pixel(a, lhs_pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
+    WhiteNoise wn = white_noise(seed, lhs_pos);
+    float4* buf_d0 = a.gi_d0; float4* buf_d1 = a.gi_d1;
+    const float4* reservoirs = a.gi_res[1];
+    const U2 buf_pos_a = u2(gid.x * 2u, gid.y), buf_pos_b = u2(gid.x * 2u + 1u, gid.y);
+    const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
+    const GiReservoir lhs = gi_read(reservoirs, lhs_idx, n);
+    if (!hit_some(lhs_hit) || lhs.m == 0.0f) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return; }
+    GiReservoir rhs = gi_empty();
+    uint32_t rhs_nth = 0u, rhs_idx = 0u;
+    Hit rhs_hit = hit_zero();
+    float rhs_jacobian = 0.0f;
+    float max_radius = 128.0f;
+    while (rhs_nth < 8u) {
+        rhs_nth += 1u;
+        const V2 disk = wn.sample_disk();
+        const U2 rhs_pos = camera_contain(a, as_i2(as_v2(lhs_pos) + disk * max_radius));
+        if (rhs_pos.x == lhs_pos.x && rhs_pos.y == lhs_pos.y) continue;
+        rhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, rhs_pos);
+        if (!hit_some(rhs_hit)) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
+        if (fabsf(rhs_hit.g.depth - lhs_hit.g.depth) > 0.33f * lhs_hit.g.depth) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
+        if (dot(rhs_hit.g.normal, lhs_hit.g.normal) < 0.33f) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
+        rhs_idx = screen_to_idx(a, rhs_pos);
+        rhs = gi_read(reservoirs, rhs_idx, n);
+        if (rhs.m == 0.0f) continue;
+        rhs_jacobian = gi_jacobian(rhs.s, lhs_hit.point);
+        if (rhs_jacobian < 1.0f / 10.0f || rhs_jacobian > 10.0f) { rhs.m = 0.0f; continue; }
+        rhs_jacobian = clampf(rhs_jacobian, 1.0f / 3.0f, 3.0f);
+        break;
+    }
+    if (rhs.m == 0.0f || !hit_some(rhs_hit)) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return; }
+    const float lhs_rhs_pdf = gi_pdf(lhs.s, rhs_hit);
+    const float rhs_lhs_pdf = gi_pdf(rhs.s, lhs_hit);
+    const Ray ray_a = lhs_rhs_pdf > 0.0f ? gi_sample_ray(lhs.s, rhs_hit.point) : zero_ray();
+    const Ray ray_b = rhs_lhs_pdf > 0.0f ? gi_sample_ray(rhs.s, lhs_hit.point) : zero_ray();
+    tex_write(buf_d0, a, buf_pos_a, f4(ray_a.origin, ray_a.len));
+    const V2 ea = normal_encode(ray_a.dir);
+    tex_write(buf_d1, a, buf_pos_a, make_float4(ea.x, ea.y, b2f(rhs_idx + 1u), rhs_jacobian));
+    tex_write(buf_d0, a, buf_pos_b, f4(ray_b.origin, ray_b.len));
+    const V2 eb = normal_encode(ray_b.dir);
+    tex_write(buf_d1, a, buf_pos_b, make_float4(eb.x, eb.y, lhs_rhs_pdf, rhs_lhs_pdf));
+}
+void launch_gi_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_spatial_pick, true, s, a, seed); }
+
+// ---------------------------------------------------------------- gi_spatial_resampling.rs:232-314 (sample)
+__global__ __launch_bounds__(kBlockThreads) void k_gi_spatial_sample(const KArgs a, uint32_t seed) {
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    if (!owns_pixel(a, pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t idx = screen_to_idx(a, pos);
+    WhiteNoise wn = white_noise(seed, pos);
+    const float4* in_res = a.gi_res[1];
+    float4* out_res = a.gi_res[2];
+    const float4 d0 = tex_read(a.gi_d2, a, u2(gid.x * 2u, gid.y)), d1 = tex_read(a.gi_d2, a, u2(gid.x * 2u + 1u, gid.y));
+    const float lhs_rhs_vis = d0.x;
+    const uint32_t rhs_idx = f2b(d0.y);
+    const float rhs_jacobian = d0.z;
+    const float rhs_lhs_vis = d1.x, lhs_rhs_pdf = d1.y, rhs_lhs_pdf = d1.z;
+    const GiReservoir lhs = gi_read(in_res, idx, n);
+    if (rhs_idx > 0u) {
+        const GiReservoir rhs = gi_read(in_res, rhs_idx - 1u, n);
+        Mis mis;
+        mis.lhs_m = lhs.m; mis.rhs_m = rhs.m; mis.rhs_jacobian = rhs_jacobian; mis.lhs_lhs_pdf = lhs.s.pdf;
+        mis.lhs_rhs_pdf = lhs_rhs_pdf * lhs_rhs_vis; mis.rhs_lhs_pdf = rhs_lhs_pdf * rhs_lhs_vis; mis.rhs_rhs_pdf = rhs.s.pdf;
+        const MisResult mr = mis_eval(mis);
+        GiReservoir main_ = gi_empty();
+        float main_pdf = 0.0f;
+        if (res_update(main_, wn, lhs.s, mr.lhs_mis * mr.lhs_pdf * lhs.w)) main_pdf = mr.lhs_pdf;
+        if (res_update(main_, wn, rhs.s, mr.rhs_mis * mr.rhs_pdf * rhs.w * rhs_jacobian)) main_pdf = mr.rhs_pdf;
+        main_.m = lhs.m + mr.m;
+        main_.confidence = 1.0f;
+        main_.s.pdf = main_pdf;
+        main_.s.v1_point = lhs.s.v1_point;
+        res_norm(main_, main_pdf, 1.0f, 1.0f);
+        main_.w = fmin_(main_.w, 5.0f);
+        gi_write(out_res, idx, main_);
+    } else gi_write(out_res, idx, lhs);
+    const U2 other = resolve_checkerboard(gid, a.frame / 2u);
+    if (contains_u(a, other)) { const uint32_t oi = screen_to_idx(a, other); gi_write(out_res, oi, gi_read(in_res, oi, n)); }
+}
+void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_spatial_sample, true, s, a, seed); }
+
+// ---------------------------------------------------------------- gi_preview_resampling.rs:3-138
+__global__ __launch_bounds__(kBlockThreads) void k_gi_preview(const KArgs a, uint32_t seed, uint32_t nth, const float4* in, float4* out) {
+    U2 center_pos;
+    if (!resolve_gid(a, false, &center_pos) || !owns_pixel(a, center_pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t center_idx = screen_to_idx(a, center_pos);
+    WhiteNoise wn = white_noise(seed, center_pos);
+    const Hit center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
+    if (!hit_some(center_hit)) { gi_write(out, center_idx, gi_empty()); return; }
+    GiReservoir main_ = gi_empty();
+    float main_pdf = 0.0f;
+    const GiReservoir center = gi_read(in, center_idx, n);
+    if (res_merge(main_, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
+    const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main_.m / 8.0f));
+    const float max_radius = nth == 0u ? 128.0f : 64.0f;
+    uint32_t sample_nth = 0u;
+    while (sample_nth < max_samples) {
+        sample_nth += 1u;
+        const V2 disk = wn.sample_disk();
+        const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
+        if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) return;  // sic: `return`, not `continue` (:84-86) — nothing is written
+        const Surface ss = surface_from(tex_read(a.sm, a, sample_pos));
+        if (ss.depth == 0.0f) continue;
+        if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
+        if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
+        const GiReservoir s = gi_read(in, screen_to_idx(a, sample_pos), n);
+        if (s.m == 0.0f) continue;
+        const float sample_pdf = gi_pdf(s.s, center_hit);
+        float sample_jacobian = gi_jacobian(s.s, center_hit.point);
+        if (sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f) continue;
+        sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
+        if (res_merge(main_, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
+    }
+    main_.confidence = center.confidence;
+    main_.s.pdf = main_pdf;
+    main_.s.v1_point = center.s.v1_point;
+    res_norm(main_, main_pdf, 1.0f, main_.m);
+    main_.w = fmin_(main_.w, 5.0f);
+    gi_write(out, center_idx, main_);
+}
+void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s) {
+    ST_LAUNCH(k_gi_preview, false, s, a, seed, nth, in, out);
+}
+
+// ---------------------------------------------------------------- gi_resolving.rs:3-67
+__global__ __launch_bounds__(kBlockThreads) void k_gi_resolving(const KArgs a, uint32_t source) {
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const uint32_t n = a.width * a.height;
+    const uint32_t idx = screen_to_idx(a, pos);
+    const float4* in = source == 0u ? a.gi_res[1] : a.gi_res[2];
+    float4* out = a.gi_res[0];
+    const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    const GiReservoir res = gi_read(out, idx, n);
+    float confidence; V3 radiance;
+    if (hit_some(hit)) { confidence = res.confidence; radiance = res.w * gi_cosine(res.s, hit) * res.s.radiance; }
+    else { confidence = 1.0f; radiance = v3s(0.0f); }
+    const float diff_brdf = (1.0f - hit.g.metallic) / kPi;
+    const V3 spec_brdf = gi_spec_brdf(res.s, hit);
+    tex_write(a.gi_diff_samples, a, pos, f4(radiance * diff_brdf, confidence));
+    tex_write(a.gi_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
+    gi_write(out, idx, gi_read(in, idx, n));
+}
+void launch_gi_resolving(const KArgs& a, uint32_t source, hipStream_t s) { ST_LAUNCH(k_gi_resolving, false, s, a, source); }
+
+}  // namespace st

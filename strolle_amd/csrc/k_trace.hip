@@ -1,0 +1,232 @@
+// k_trace.hip — the ray-tracing kernels that are not tied to a ReSTIR stage: BVH heatmap, the reference
+// path tracer (trace + shade + accumulate), primary visibility (the compute restatement of prim_raster),
+// the shared shadow-ray pass of spatial resampling, and frame composition.
+#include "k_common.h"
+
+namespace st {
+
+// ---------------------------------------------------------------- bvh_heatmap.rs:3-77
+ST_D V3 heatmap_gradient(float progress) {
+    const V3 c0 = v3(0.0f, 0.0f, 1.0f), c1 = v3(0.0f, 1.0f, 0.0f), c2 = v3(1.0f, 0.0f, 0.0f), c3 = v3(0.0f, 0.0f, 0.0f);
+    if (progress <= 0.0f) return c0;
+    const float step = 1.0f / (4.0f - 1.0f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float mn = step * (float)i;
+        const float mx = step * ((float)i + 1.0f);
+        if (progress >= mn && progress <= mx) {
+            const float rhs = (progress - mn) / step;
+            const float lhs = 1.0f - rhs;
+            const V3 a = i == 0 ? c0 : (i == 1 ? c1 : c2), b = i == 0 ? c1 : (i == 1 ? c2 : c3);
+            return lhs * a + rhs * b;
+        }
+    }
+    return c3;
+}
+__global__ __launch_bounds__(kBlockThreads) void k_bvh_heatmap(const KArgs a) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    Candidate c; bool any;
+    const uint32_t used = traverse<false>(a, camera_ray(a.cam, pos), kF32Max, lane_stack(lds), &c, &any);
+    count_rays(a.ray_counter, used);
+    a.dbg_used_memory[screen_to_idx(a, pos)] = used;
+    tex_write(a.ref_colors, a, pos, f4(heatmap_gradient((float)used / 8192.0f), 1.0f));
+}
+void launch_bvh_heatmap(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_bvh_heatmap, false, s, a); }
+
+// ---------------------------------------------------------------- ref_tracing.rs:3-60
+__global__ __launch_bounds__(kBlockThreads) void k_ref_tracing(const KArgs a, uint32_t depth) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const uint32_t idx = screen_to_idx(a, pos);
+    Ray ray;
+    if (depth == 0u) ray = camera_ray(a.cam, pos);
+    else {
+        const float4 d0 = a.ref_rays[3u * idx], d1 = a.ref_rays[3u * idx + 1u];
+        if (is_zero(d1)) return;
+        ray = make_ray(xyz(d0), xyz(d1));
+    }
+    const TriangleHit hit = trace_closest(a, ray, lane_stack(lds), &used_);
+    count_rays(a.ray_counter, used_);
+    float4 h0, h1;
+    hit_pack(hit, &h0, &h1);
+    a.ref_hits[2u * idx] = h0;
+    a.ref_hits[2u * idx + 1u] = h1;
+}
+void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s) { ST_LAUNCH(k_ref_tracing, false, s, a, depth); }
+
+// ---------------------------------------------------------------- ref_shading.rs:3-177
+__global__ __launch_bounds__(kBlockThreads) void k_ref_shading(const KArgs a, uint32_t seed, uint32_t depth) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const uint32_t idx = screen_to_idx(a, pos);
+    WhiteNoise wn = white_noise(seed, pos);
+    if (depth == 255u) {  // accumulate
+        const float4 prev = camera_is_eq(a.cam, a.prev_cam) ? tex_read(a.ref_colors, a, pos) : f4z();
+        const V3 curr = xyz(a.ref_rays[3u * idx + 2u]);
+        tex_write(a.ref_colors, a, pos, prev + f4(curr, 1.0f));
+        return;
+    }
+    Ray ray; V3 color, throughput;
+    if (depth == 0u) { ray = camera_ray(a.cam, pos); color = v3s(0.0f); throughput = v3s(1.0f); }
+    else {
+        const float4 d0 = a.ref_rays[3u * idx], d1 = a.ref_rays[3u * idx + 1u], d2 = a.ref_rays[3u * idx + 2u];
+        ray = make_ray(xyz(d0), xyz(d1));
+        color = xyz(d2);
+        throughput = v3(d0.w, d1.w, d2.w);
+    }
+    const TriangleHit t_hit = hit_unpack(a.ref_hits[2u * idx], a.ref_hits[2u * idx + 1u]);
+    if (!hit_is_some(t_hit)) {
+        color = color + throughput * atmosphere_sample(a, ray.dir);
+        a.ref_rays[3u * idx] = f4z();
+        a.ref_rays[3u * idx + 1u] = f4z();
+        a.ref_rays[3u * idx + 2u] = f4(color, 0.0f);
+        return;
+    }
+    GpuMaterial material = a.materials[t_hit.material_id];
+    if (depth > 0u) material.roughness = fmax_(material.roughness, 0.75f * 0.75f);  // Material::regularize
+    Hit hit;
+    hit.point = t_hit.point + t_hit.normal * kNudgeOffset;
+    hit.origin = ray.origin; hit.dir = ray.dir;
+    hit.g.base_color = sample_atlas(a, t_hit.uv, material.base_color, material.base_color_texture);
+    hit.g.normal = t_hit.normal;
+    hit.g.metallic = material.metallic;
+    hit.g.emissive = xyz(sample_atlas(a, t_hit.uv, material.emissive, material.emissive_texture));
+    hit.g.roughness = material.roughness;
+    hit.g.reflectance = material.reflectance;
+    hit.g.depth = 0.0f;
+
+    color = color + throughput * hit.g.emissive;
+    if (a.light_count > 0u) {
+        const uint32_t light_id = wn.sample_int() % a.light_count;
+        const float light_pdf = 1.0f / (float)a.light_count;
+        const GpuLight light = light_get(a, light_id);
+        const bool occluded = trace_any(a, light_ray_wnoise(light, wn, hit.point), lane_stack(lds), &used_);
+        count_rays(a.ray_counter, used_);
+        if (!occluded) color = color + throughput * radiance_sum(light_radiance(light, hit)) / light_pdf;
+    }
+    const BrdfSample rs = layered_brdf_sample(hit.g, wn, -hit.dir);
+    if (rs.pdf == 0.0f) { a.ref_rays[3u * idx] = f4z(); a.ref_rays[3u * idx + 1u] = f4z(); return; }
+    throughput = throughput * dot(rs.dir, hit.g.normal);
+    throughput = throughput * (rs.radiance / rs.pdf);
+    a.ref_rays[3u * idx] = f4(hit.point, throughput.x);
+    a.ref_rays[3u * idx + 1u] = f4(rs.dir, throughput.y);
+    a.ref_rays[3u * idx + 2u] = f4(color, throughput.z);
+}
+void launch_ref_shading(const KArgs& a, uint32_t seed, uint32_t depth, hipStream_t s) { ST_LAUNCH(k_ref_shading, false, s, a, seed, depth); }
+
+// ---------------------------------------------------------------- primary visibility (prim_raster.rs:40-128 as one closest-hit ray per pixel)
+__global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const Ray ray = camera_ray(a.cam, pos);
+    const TriangleHit hit = trace_closest(a, ray, lane_stack(lds), &used_);
+    count_rays(a.ray_counter, used_);
+    if (!hit_is_some(hit)) {  // LoadOp::Clear(TRANSPARENT)
+        tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z()); tex_write(a.sm, a, pos, f4z()); tex_write(a.velocity, a, pos, f4z());
+        return;
+    }
+    const GpuMaterial material = a.materials[hit.material_id];
+    const float4 mr = sample_atlas(a, hit.uv, make_float4(1.0f, material.roughness, material.metallic, 1.0f), material.metallic_roughness_texture);
+    GBuffer g;
+    g.base_color = sample_atlas(a, hit.uv, material.base_color, material.base_color_texture);
+    g.normal = hit.normal;
+    g.metallic = mr.z;
+    g.emissive = xyz(sample_atlas(a, hit.uv, material.emissive, material.emissive_texture));
+    g.roughness = mr.y;
+    g.reflectance = material.reflectance;
+    g.depth = distance(ray.origin, hit.point);
+    float4 d0, d1;
+    gbuffer_pack(g, &d0, &d1);
+    tex_write(a.g0, a, pos, d0);
+    tex_write(a.g1, a, pos, d1);
+    const V2 en = normal_encode(hit.normal);
+    tex_write(a.sm, a, pos, make_float4(en.x, en.y, g.depth, material.roughness));
+    // static instances: prev_point == point (prev_xform * curr_xform_inv == identity)
+    const V2 velocity = clip_to_screen(a.cam, world_to_clip(a.cam, hit.point)) - clip_to_screen(a.prev_cam, world_to_clip(a.prev_cam, hit.point));
+    tex_write(a.velocity, a, pos, dot(velocity, velocity) >= 0.001f ? make_float4(velocity.x, velocity.y, 0.0f, 0.0f) : f4z());
+}
+void launch_prim_visibility(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_prim_visibility, false, s, a); }
+
+// ---------------------------------------------------------------- frame_reprojection.rs:6-95
+__global__ __launch_bounds__(kBlockThreads) void k_frame_reprojection(const KArgs a) {
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    Reprojection rp; rp.prev_x = 0.0f; rp.prev_y = 0.0f; rp.confidence = 0.0f; rp.validity = 0u;
+    const Surface surface = surface_from(tex_read(a.sm, a, pos));
+    if (surface.depth != 0.0f) {
+        const float4 vel = tex_read(a.velocity, a, pos);
+        const V2 prev_screen_pos = as_v2(pos) - v2(vel.x, vel.y);
+        const V2 rounded = round2(prev_screen_pos);
+        if (contains_f(a, rounded)) {
+            const float confidence = surface_similarity(surface_from(tex_read(a.psm, a, as_u2(rounded))), surface);
+            if (confidence > 0.0f) { rp.prev_x = prev_screen_pos.x; rp.prev_y = prev_screen_pos.y; rp.confidence = confidence; }
+        }
+        if (rp.confidence > 0.0f) {
+            const float fl_x = floorf(rp.prev_x), fl_y = floorf(rp.prev_y), ce_x = ceilf(rp.prev_x), ce_y = ceilf(rp.prev_y);
+            const I2 p[4] = {i2(f2i_sat(fl_x), f2i_sat(fl_y)), i2(f2i_sat(ce_x), f2i_sat(fl_y)), i2(f2i_sat(fl_x), f2i_sat(ce_y)), i2(f2i_sat(ce_x), f2i_sat(ce_y))};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (!contains_i(a, p[i])) continue;
+                if (surface_similarity(surface_from(tex_read(a.psm, a, u2((uint32_t)p[i].x, (uint32_t)p[i].y))), surface) >= 0.25f) rp.validity |= (1u << i);
+            }
+        }
+    }
+    tex_write(a.reprojection, a, pos, make_float4(rp.prev_x, rp.prev_y, rp.confidence, b2f(rp.validity)));
+}
+void launch_frame_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_frame_reprojection, false, s, a); }
+
+// ---------------------------------------------------------------- {di,gi}_spatial_resampling.rs `trace`
+__global__ __launch_bounds__(kBlockThreads) void k_spatial_trace(const KArgs a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2) {
+    __shared__ uint32_t lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const float4 ray_d0 = tex_read(buf_d0, a, pos), ray_d1 = tex_read(buf_d1, a, pos);
+    if (is_zero(ray_d1)) { tex_write(buf_d2, a, pos, f4z()); return; }
+    Ray ray = make_ray(xyz(ray_d0), normal_decode(v2(ray_d1.x, ray_d1.y)));
+    ray.len = ray_d0.w;
+    const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+    count_rays(a.ray_counter, used_);
+    tex_write(buf_d2, a, pos, make_float4(occluded ? 0.0f : 1.0f, ray_d1.z, ray_d1.w, 0.0f));
+}
+void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s) {
+    ST_LAUNCH(k_spatial_trace, false, s, a, buf_d0, buf_d1, buf_d2);
+}
+
+// ---------------------------------------------------------------- frame_composition.rs:18-82 as a compute pass into an RGBA32F buffer
+__global__ __launch_bounds__(kBlockThreads) void k_composition(const KArgs a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out) {
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    V3 color;
+    switch (camera_mode) {
+        case 0: {
+            const GBuffer g = gbuffer_unpack(tex_read(a.g0, a, pos), tex_read(a.g1, a, pos));
+            const V3 dd = xyz(tex_read(di_diff, a, pos)), ds = xyz(tex_read(a.di_spec_samples, a, pos));
+            const V3 gd = xyz(tex_read(gi_diff, a, pos)), gs = xyz(tex_read(a.gi_spec_samples, a, pos));
+            color = g.depth != 0.0f ? g.emissive + (dd + gd) * xyz(g.base_color) + ds + gs : dd;
+            break;
+        }
+        case 1: color = xyz(tex_read(di_diff, a, pos)); break;
+        case 2: color = xyz(tex_read(a.di_spec_samples, a, pos)); break;
+        case 3: color = xyz(tex_read(gi_diff, a, pos)); break;
+        case 4: color = xyz(tex_read(a.gi_spec_samples, a, pos)); break;
+        case 5: color = xyz(tex_read(a.ref_colors, a, pos)); break;
+        case 6: { const float4 c = tex_read(a.ref_colors, a, pos); color = xyz(c) / c.w; break; }
+        default: color = v3s(0.0f);
+    }
+    out[pos.y * a.width + pos.x] = f4(color, 1.0f);
+}
+void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out, hipStream_t s) {
+    ST_LAUNCH(k_composition, false, s, a, camera_mode, di_diff, gi_diff, out);
+}
+
+}  // namespace st

@@ -1,0 +1,148 @@
+// st_bvh.h — host side of the scene -> device-buffer step: world-space triangle baking, the binned-SAH
+// BVH build and its flattening into the float4 stream the traversal kernel walks.
+//
+// Contract (tree shape and stream layout must equal the reference's so that `used_memory` and hit order
+// are identical): strolle/src/bvh/builder.rs (12 centroid bins per axis, sweep costs, `<=` tie-break,
+// swap-to-back partition, breadth-first processing) and strolle/src/bvh/serializer.rs (DFS pre-order,
+// internal = 4 float4 holding both children's bounds + right pointer, leaf entry = 1 float4).
+// Implementation notes: iterative builder over an index-free primitive array; subtree reuse by hash
+// (builder.rs:205-301) is not implemented — every refresh is a fresh build.
+#pragma once
+#include <cstdint>
+#include <deque>
+#include <vector>
+
+#include "st_types.h"
+
+namespace st {
+
+struct Aabb {
+    V3 lo, hi;
+    Aabb() { lo = v3s(kF32Max); hi = v3s(-kF32Max); }
+    V3 extent() const { return hi - lo; }
+    float half_area() const { const V3 e = extent(); return e.x * e.y + e.y * e.z + e.z * e.x; }
+    bool is_set() const { return lo.x != kF32Max; }
+    void grow(V3 p) { lo = vmin(lo, p); hi = vmax(hi, p); }
+    void grow(const Aabb& o) { grow(o.lo); grow(o.hi); }  // utils/bounding_box.rs:83-88: min then max, literally
+};
+
+struct BuildPrim { uint32_t triangle_id, material_id; V3 center; Aabb bounds; };
+
+inline float axis_of(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+class BvhBuild {
+  public:
+    struct Node { bool internal = false; Aabb bounds; uint32_t begin = 0, end = 0, left = 0, right = 0; };
+    std::vector<Node> nodes;
+    std::vector<BuildPrim> prims;
+
+    void run() {
+        nodes.clear();
+        Node root; root.begin = 0; root.end = (uint32_t)prims.size();
+        nodes.push_back(root);
+        std::deque<uint32_t> todo;
+        todo.push_back(0);
+        while (!todo.empty()) {
+            const uint32_t id = todo.front();
+            todo.pop_front();
+            int axis; float split_at, split_cost;
+            if (!best_plane(nodes[id], &axis, &split_at, &split_cost)) continue;
+            const float leaf_cost = (float)(nodes[id].end - nodes[id].begin) * nodes[id].bounds.half_area();
+            if (!(split_cost < leaf_cost)) continue;
+            const uint32_t begin = nodes[id].begin, end = nodes[id].end;
+            int64_t i = 0, j = (int64_t)(end - begin) - 1;
+            Aabb lb, rb;
+            BuildPrim* p = prims.data() + begin;
+            while (i <= j) {
+                const BuildPrim cur = p[i];
+                if (axis_of(cur.center, axis) < split_at) { lb.grow(cur.bounds); i++; }
+                else { const BuildPrim t = p[i]; p[i] = p[j]; p[j] = t; rb.grow(cur.bounds); j--; }
+            }
+            Node l, r;
+            l.bounds = lb; l.begin = begin; l.end = begin + (uint32_t)i;
+            r.bounds = rb; r.begin = begin + (uint32_t)i; r.end = end;
+            const uint32_t li = (uint32_t)nodes.size(); nodes.push_back(l);
+            const uint32_t ri = (uint32_t)nodes.size(); nodes.push_back(r);
+            nodes[id].internal = true; nodes[id].left = li; nodes[id].right = ri;
+            todo.push_back(li); todo.push_back(ri);
+        }
+    }
+
+    // DFS flatten. `blend[m]` != 0 marks AlphaMode::Blend materials (leaf flag bit 1).
+    void flatten(const std::vector<uint8_t>& blend, std::vector<float4>& out) const {
+        out.clear();
+        if (prims.empty()) return;
+        emit(0, blend, out);
+    }
+
+  private:
+    static constexpr int kBins = 12;
+
+    bool best_plane(const Node& node, int* out_axis, float* out_at, float* out_cost) const {
+        const uint32_t n = node.end - node.begin;
+        if (n <= 1) return false;
+        const BuildPrim* p = prims.data() + node.begin;
+        Aabb cb;
+        for (uint32_t i = 0; i < n; i++) cb.grow(p[i].center);
+        Aabb bin_bounds[3][kBins]; uint32_t bin_count[3][kBins] = {};
+        const V3 scale = (float)kBins / cb.extent();
+        for (uint32_t i = 0; i < n; i++) {
+            const V3 f = scale * (p[i].center - cb.lo);
+            const uint32_t b[3] = {f2u_sat(f.x), f2u_sat(f.y), f2u_sat(f.z)};
+            for (int a = 0; a < 3; a++) {
+                const uint32_t k = b[a] < (uint32_t)kBins - 1u ? b[a] : (uint32_t)kBins - 1u;
+                bin_count[a][k] += 1; bin_bounds[a][k].grow(p[i].bounds);
+            }
+        }
+        float la[3][kBins - 1], ra[3][kBins - 1]; uint32_t lc[3][kBins - 1], rc[3][kBins - 1];
+        for (int a = 0; a < 3; a++) {
+            Aabb lbb, rbb; uint32_t lcount = 0, rcount = 0;
+            for (int i = 0; i < kBins - 1; i++) {
+                lcount += bin_count[a][i]; lc[a][i] = lcount;
+                if (bin_bounds[a][i].is_set()) lbb.grow(bin_bounds[a][i]);
+                la[a][i] = lbb.half_area();
+                rcount += bin_count[a][kBins - 1 - i]; rc[a][kBins - 2 - i] = rcount;
+                if (bin_bounds[a][kBins - 1 - i].is_set()) rbb.grow(bin_bounds[a][kBins - 1 - i]);
+                ra[a][kBins - 2 - i] = rbb.half_area();
+            }
+        }
+        bool have = false; float best_cost = 0.0f; int best_axis = 0; float best_at = 0.0f;
+        const V3 width = cb.extent() / (float)kBins;
+        for (int a = 0; a < 3; a++)
+            for (int i = 0; i < kBins - 1; i++) {
+                const float cost = (float)lc[a][i] * la[a][i] + (float)rc[a][i] * ra[a][i];
+                if (!have || cost <= best_cost) {
+                    have = true; best_cost = cost; best_axis = a;
+                    best_at = axis_of(cb.lo, a) + axis_of(width, a) * (float)(i + 1);
+                }
+            }
+        *out_axis = best_axis; *out_at = best_at; *out_cost = best_cost;
+        return have;
+    }
+
+    uint32_t emit(uint32_t id, const std::vector<uint8_t>& blend, std::vector<float4>& out) const {
+        const uint32_t at = (uint32_t)out.size();
+        const Node& n = nodes[id];
+        if (n.internal) {
+            out.resize(out.size() + 4, make_float4(0, 0, 0, 0));
+            const Aabb lb = nodes[n.left].bounds, rb = nodes[n.right].bounds;
+            emit(n.left, blend, out);
+            const uint32_t right_at = emit(n.right, blend, out);
+            out[at] = make_float4(lb.lo.x, lb.lo.y, lb.lo.z, b2f(0u));
+            out[at + 1] = make_float4(lb.hi.x, lb.hi.y, lb.hi.z, b2f(right_at));
+            out[at + 2] = make_float4(rb.lo.x, rb.lo.y, rb.lo.z, 0.0f);
+            out[at + 3] = make_float4(rb.hi.x, rb.hi.y, rb.hi.z, 0.0f);
+        } else {
+            const uint32_t n_entries = n.end - n.begin;
+            for (uint32_t i = 0; i < n_entries; i++) {
+                const BuildPrim& p = prims[n.begin + i];
+                const uint32_t more = i + 1 < n_entries ? 1u : 0u;
+                const uint32_t is_blend = (p.material_id < blend.size() && blend[p.material_id]) ? 2u : 0u;
+                out.push_back(make_float4(b2f(more | is_blend), b2f(p.triangle_id), b2f(p.material_id), b2f(1u)));
+            }
+        }
+        return at;
+    }
+};
+
+}  // namespace st

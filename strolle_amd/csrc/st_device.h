@@ -1,0 +1,719 @@
+// st_device.h — device-side library of the MI355X hot path: primary-ray generation, BVH traversal with a
+// per-wave LDS stack, Möller–Trumbore with deferred attribute fetch, G-buffer / normal / reservoir codecs,
+// BRDFs, lights, MIS, atmosphere lookup. Behavioural contract: strolle-gpu/src/*.rs (cited per block);
+// data layout and control flow are this library's own.
+#pragma once
+#include "st_types.h"
+
+namespace st {
+
+#define ST_D __device__ __forceinline__
+
+// ------------------------------------------------------------------ launch geometry
+// One wavefront == one 8x8 pixel tile (64 lanes); a 256-thread block owns four horizontally adjacent tiles.
+// Blocks are dealt to XCDs round-robin by the hardware (block b -> XCD b % 8); the remap below gives every
+// XCD one contiguous band of tile rows so that neighbour taps (spatial resampling, à-trous) of a tile stay
+// in the same XCD's L2.
+struct TileCoord { uint32_t x, y; bool valid; };
+ST_D TileCoord tile_for_thread(uint32_t tiles_x, uint32_t tiles_y) {
+    const uint32_t groups_x = (tiles_x + 3u) >> 2;              // blocks per tile row
+    const uint32_t n_blocks = groups_x * tiles_y;
+    const uint32_t b = blockIdx.x;
+    const uint32_t q = n_blocks >> 3, r = n_blocks & 7u;        // bijective XCD remap (handles n % 8 != 0)
+    const uint32_t xcd = b & 7u, k = b >> 3;
+    const uint32_t lin = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
+    const uint32_t wave = threadIdx.x >> 6;
+    TileCoord t;
+    t.y = lin / groups_x;
+    t.x = (lin - t.y * groups_x) * 4u + wave;
+    t.valid = t.x < tiles_x && t.y < tiles_y;
+    return t;
+}
+ST_D U2 pixel_in_tile(TileCoord t) {
+    const uint32_t lane = threadIdx.x & 63u;
+    return u2(t.x * 8u + (lane & 7u), t.y * 8u + (lane >> 3));
+}
+ST_D uint32_t* lane_stack(uint32_t* lds) {  // [wave][entry][lane]: consecutive lanes hit consecutive banks
+    return lds + (threadIdx.x >> 6) * (kBvhStackSize * 64) + (threadIdx.x & 63u);
+}
+// Per-kernel counters: [0] rays traced, [1] the reference's `used_memory` bytes (algorithmic traversal traffic).
+// hipcc's atomic optimizer folds these uniform-address adds into one atomic per wavefront.
+ST_D void count_rays(unsigned long long* counter, uint32_t used_memory) {
+    atomicAdd(counter, 1ull);
+    atomicAdd(counter + 1, (unsigned long long)used_memory);
+}
+
+// ------------------------------------------------------------------ small codecs
+ST_D uint32_t u32_from_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return a | (b << 8) | (c << 16) | (d << 24); }
+ST_D U2 resolve_checkerboard(U2 gid, uint32_t frame) { return u2(gid.x * 2u + ((frame + gid.y) % 2u), gid.y); }  // utils.rs:33-35
+ST_D U2 resolve_checkerboard_alt(U2 gid, uint32_t frame) { return resolve_checkerboard(gid, frame + 1u); }
+ST_D bool got_checkerboard_at(U2 p, uint32_t frame) { U2 q = resolve_checkerboard(u2(p.x / 2u, p.y), frame); return q.x == p.x && q.y == p.y; }
+
+ST_D V2 normal_encode(V3 n) {  // normal.rs:9-24
+    n = n / (fabsf(n.x) + fabsf(n.y) + fabsf(n.z));
+    V2 r;
+    if (n.z >= 0.0f) r = v2(n.x, n.y);
+    else { r = v2(copysignf(1.0f - fabsf(n.y), n.x), copysignf(1.0f - fabsf(n.x), n.y)); }
+    return r * 0.5f + 0.5f;
+}
+ST_D V3 normal_decode(V2 e) {  // normal.rs:26-34
+    e = e * 2.0f - 1.0f;
+    V3 n = v3(e.x, e.y, 1.0f - fabsf(e.x) - fabsf(e.y));
+    const float t = fmax_(-n.z, 0.0f);
+    n.x -= copysignf(t, n.x);
+    n.y -= copysignf(t, n.y);
+    return normalize(n);
+}
+
+// ------------------------------------------------------------------ noise (noise/white.rs, noise/blue.rs)
+struct WhiteNoise {
+    uint32_t state;
+    ST_D uint32_t sample_int() {
+        state = state * 747796405u + 2891336453u;
+        const uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+        return (word >> 22) ^ word;
+    }
+    ST_D float sample() { return (float)sample_int() / 4294967296.0f; }
+    ST_D V2 sample_circle() { const float angle = sample() * kPi * 2.0f; float s, c; sincos_(angle, &s, &c); return v2(c, s); }
+    ST_D V2 sample_disk() { const float radius = sqrtf(sample()); return sample_circle() * radius; }
+    ST_D V3 sample_sphere() {
+        const float phi = sample() * 2.0f * kPi;
+        const float cos_theta = sample() * 2.0f - 1.0f;
+        const float u = sample();
+        const float theta = acos_(cos_theta);
+        const float r = sqrtf(u);
+        float st_, ct_, sp_, cp_;
+        sincos_(theta, &st_, &ct_); sincos_(phi, &sp_, &cp_);
+        return v3(r * st_ * cp_, r * st_ * sp_, r * ct_);
+    }
+    ST_D V3 sample_hemisphere(V3 normal) {
+        const float cos_theta = sample();
+        const float sin_theta = sqrtf(1.0f - sqr(cos_theta));
+        const float phi = 2.0f * kPi * sample();
+        V3 t, b;
+        any_orthonormal_pair(normal, &t, &b);
+        float sp_, cp_; sincos_(phi, &sp_, &cp_);
+        return (t * cp_ + b * sp_) * sin_theta + normal * cos_theta;
+    }
+};
+ST_D WhiteNoise white_noise(uint32_t seed, U2 id) { WhiteNoise w; w.state = seed ^ (48619u * id.x) ^ (95461u * id.y); return w; }
+ST_D float4 blue_noise_read(const KArgs& a, U2 id) {
+    const uint32_t ux = (id.x + 71u * a.frame) % 256u, uy = (id.y + 11u * a.frame) % 256u;
+    const uchar4 p = a.blue_noise[uy * 256u + ux];
+    return make_float4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+}
+
+// ------------------------------------------------------------------ rays & camera (ray.rs:14-53, camera.rs:19-150)
+struct Ray { V3 origin, dir, inv_dir; float len; };
+ST_D Ray make_ray(V3 o, V3 d) { Ray r; r.origin = o; r.dir = d; r.inv_dir = 1.0f / d; r.len = kF32Max; return r; }
+ST_D Ray zero_ray() { Ray r; r.origin = v3s(0.0f); r.dir = v3s(0.0f); r.inv_dir = v3s(0.0f); r.len = 0.0f; return r; }  // Ray::default()
+ST_D V3 ray_at(const Ray& r, float t) { return r.origin + r.dir * t; }
+
+ST_D Ray camera_ray(const GpuCamera& c, U2 pos) {
+    const V2 screen_size = v2(c.screen.x, c.screen.y);
+    const V2 sp = as_v2(pos) + v2(0.5f, 0.5f);
+    V2 ndc = sp * 2.0f / screen_size - v2(1.0f, 1.0f);
+    ndc = v2(ndc.x, -ndc.y);
+    const V3 far_plane = project_point3(c.ndc_to_world, v3(ndc.x, ndc.y, kF32Eps));
+    const V3 near_plane = project_point3(c.ndc_to_world, v3(ndc.x, ndc.y, 1.0f));
+    return make_ray(near_plane, normalize(far_plane - near_plane));
+}
+ST_D float4 world_to_clip(const GpuCamera& c, V3 p) { return mul(c.projection_view, f4(p, 1.0f)); }
+ST_D V2 clip_to_screen(const GpuCamera& c, float4 p) {
+    V2 ndc = v2(p.x, p.y) / p.w;
+    ndc = v2(ndc.x, -ndc.y);
+    return (0.5f * ndc + 0.5f) * v2(c.screen.x, c.screen.y);
+}
+ST_D uint32_t screen_to_idx(const KArgs& a, U2 p) { return p.y * a.width + p.x; }
+ST_D U2 camera_contain(const KArgs& a, I2 p) {  // camera.rs:53-75
+    const int32_t sx = (int32_t)a.width, sy = (int32_t)a.height;
+    if (p.x < 0) p.x = -p.x;
+    if (p.y < 0) p.y = -p.y;
+    if (p.x >= sx) p.x = sx - p.x + sx - 1;
+    if (p.y >= sy) p.y = sy - p.y + sy - 1;
+    return u2((uint32_t)p.x, (uint32_t)p.y);
+}
+ST_D bool contains_u(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.height; }
+ST_D bool contains_i(const KArgs& a, I2 p) { return p.x >= 0 && p.y >= 0 && p.x < (int32_t)a.width && p.y < (int32_t)a.height; }
+ST_D bool contains_f(const KArgs& a, V2 p) { return p.x >= 0.0f && p.y >= 0.0f && p.x < (float)a.width && p.y < (float)a.height; }
+ST_D bool camera_is_eq(const GpuCamera& a, const GpuCamera& b) {  // camera.rs:104-107
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float4 x = a.projection_view.c[i], y = b.projection_view.c[i];
+        ok = ok && fabsf(x.x - y.x) <= 0.0025f && fabsf(x.y - y.y) <= 0.0025f && fabsf(x.z - y.z) <= 0.0025f && fabsf(x.w - y.w) <= 0.0025f;
+    }
+    return ok;
+}
+// plane access with storage-image semantics (out-of-range reads are zero, writes are dropped)
+ST_D float4 tex_read(const float4* p, const KArgs& a, U2 pos) { return (pos.x < a.width && pos.y < a.height) ? p[pos.y * a.width + pos.x] : f4z(); }
+ST_D void tex_write(float4* p, const KArgs& a, U2 pos, float4 v) { if (pos.x < a.width && pos.y < a.height) p[pos.y * a.width + pos.x] = v; }
+
+// ------------------------------------------------------------------ materials & atlas (material.rs:25-104)
+ST_D float srgb_to_linear(uint32_t v) {
+    const float c = (float)v / 255.0f;
+    return c <= 0.04045f ? c / 12.92f : pow_((c + 0.055f) / 1.055f, 2.4f);
+}
+ST_D float4 atlas_texel(const KArgs& a, int32_t x, int32_t y) {
+    x = x < 0 ? 0 : (x >= (int32_t)a.atlas_w ? (int32_t)a.atlas_w - 1 : x);
+    y = y < 0 ? 0 : (y >= (int32_t)a.atlas_h ? (int32_t)a.atlas_h - 1 : y);
+    const uchar4 p = a.atlas[(uint32_t)y * a.atlas_w + (uint32_t)x];
+    return make_float4(srgb_to_linear(p.x), srgb_to_linear(p.y), srgb_to_linear(p.z), (float)p.w / 255.0f);
+}
+// gfx950 has no texture unit: bilinear, clamp-to-edge, lod 0, sRGB decode before filtering; NaN coordinates -> 0.
+ST_D float4 atlas_sample(const KArgs& a, V2 uv) {
+    if (a.atlas_w == 0u) return f4z();
+    if (uv.x != uv.x) uv.x = 0.0f;
+    if (uv.y != uv.y) uv.y = 0.0f;
+    const float fx = uv.x * (float)a.atlas_w - 0.5f, fy = uv.y * (float)a.atlas_h - 0.5f;
+    const float x0 = floorf(fx), y0 = floorf(fy);
+    const float tx = fx - x0, ty = fy - y0;
+    const int32_t ix = f2i_sat(x0), iy = f2i_sat(y0);
+    const float4 p00 = atlas_texel(a, ix, iy), p10 = atlas_texel(a, ix + 1, iy), p01 = atlas_texel(a, ix, iy + 1), p11 = atlas_texel(a, ix + 1, iy + 1);
+    const float4 top = p00 + (p10 - p00) * tx;
+    const float4 bot = p01 + (p11 - p01) * tx;
+    return top + (bot - top) * ty;
+}
+ST_D float mat_wrap(float t) { return t > 0.0f ? fmodf(t, 1.0f) : 1.0f - fmodf(-t, 1.0f); }
+ST_D float4 sample_atlas(const KArgs& a, V2 hit_uv, float4 multiplier, float4 texture) {
+    if (is_zero(texture)) return multiplier;
+    hit_uv.x = mat_wrap(hit_uv.x);
+    hit_uv.y = mat_wrap(hit_uv.y);
+    const V2 uv = v2(texture.x, texture.y) + hit_uv * v2(texture.z, texture.w);
+    return multiplier * atlas_sample(a, uv);
+}
+
+// ------------------------------------------------------------------ BVH traversal (ray.rs:114-302, triangle.rs:64-113)
+struct TriangleHit { float distance; V3 point, normal; V2 uv; uint32_t material_id; };
+ST_D bool hit_is_some(const TriangleHit& h) { return h.distance < kF32Max; }
+
+ST_D float intersect_box(const Ray& r, V3 bmin, V3 bmax) {
+    float tmin = 0.0f, tmax = kF32Max;
+    const V3 t1 = (bmin - r.origin) * r.inv_dir;
+    const V3 t2 = (bmax - r.origin) * r.inv_dir;
+    tmin = fmax_(tmin, fmin_(t1.x, t2.x)); tmax = fmin_(tmax, fmax_(t1.x, t2.x));
+    tmin = fmax_(tmin, fmin_(t1.y, t2.y)); tmax = fmin_(tmax, fmax_(t1.y, t2.y));
+    tmin = fmax_(tmin, fmin_(t1.z, t2.z)); tmax = fmin_(tmax, fmax_(t1.z, t2.z));
+    return tmin <= tmax ? tmin : kF32Max;
+}
+ST_D float intersect_sphere(const Ray& r, float radius) {  // ray.rs:304-321
+    const float b = dot(r.origin, r.dir);
+    const float c = dot(r.origin, r.origin) - radius * radius;
+    if (c > 0.0f && b > 0.0f) return -1.0f;
+    const float discr = b * b - c;
+    if (discr < 0.0f) return -1.0f;
+    if (discr > b * b) return -b + sqrtf(discr);
+    return -b - sqrtf(discr);
+}
+
+struct Candidate { float t, u, v, inv_det; uint32_t tri, material; };
+
+ST_D V2 tri_uv(const KArgs& a, uint32_t tri, float u, float v) {
+    const float4 q0 = a.tri_attr[4u * tri], q1 = a.tri_attr[4u * tri + 1u], q2 = a.tri_attr[4u * tri + 2u], q3 = a.tri_attr[4u * tri + 3u];
+    const V2 uv0 = v2(q0.w, q1.w), uv1 = v2(q2.w, q3.x), uv2 = v2(q3.y, q3.z);
+    return uv0 + (uv1 - uv0) * u + (uv2 - uv0) * v;
+}
+// ANY_HIT: Tracing::ReturnFirst. Returns the reference's `used_memory` byte counter.
+// On return `best.t` is the closest accepted distance (or the initial max_t if none).
+template <bool ANY_HIT>
+ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, uint32_t* stack, Candidate* best, bool* found_any) {
+    best->t = max_t; best->tri = 0xffffffffu; best->material = 0u; best->u = 0.0f; best->v = 0.0f; best->inv_det = 1.0f;
+    *found_any = false;
+    if (a.bvh_len == 0u) return 0u;
+    uint32_t used_memory = 0u;
+    uint32_t ptr = 0u;
+    int sp = 0;
+    for (;;) {
+        used_memory += 16u;
+        const float4 d0 = a.bvh[ptr];
+        if (f2b(d0.w) == 0u) {
+            used_memory += 48u;
+            const float4 d1 = a.bvh[ptr + 1u], d2 = a.bvh[ptr + 2u], d3 = a.bvh[ptr + 3u];
+            uint32_t near_ptr = ptr + 4u, far_ptr = f2b(d1.w);
+            float near_d = intersect_box(ray, xyz(d0), xyz(d1));
+            float far_d = intersect_box(ray, xyz(d2), xyz(d3));
+            if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
+            if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = far_ptr; sp++; } }
+            if (near_d < best->t) { ptr = near_ptr; continue; }
+        } else {
+            used_memory += 144u;
+            const uint32_t flags = f2b(d0.x), tri = f2b(d0.y), material = f2b(d0.z);
+            const float4 g0 = a.tri_geo[3u * tri], g1 = a.tri_geo[3u * tri + 1u], g2 = a.tri_geo[3u * tri + 2u];
+            const V3 p0 = xyz(g0), e1 = xyz(g1), e2 = xyz(g2);
+            const V3 pvec = cross(ray.dir, e2);
+            const float det = dot(e1, pvec);
+            bool found = false;
+            if (!(fabsf(det) < kF32Eps)) {
+                const float inv_det = 1.0f / det;
+                const V3 tvec = ray.origin - p0;
+                const float u = dot(tvec, pvec) * inv_det;
+                const V3 qvec = cross(tvec, e1);
+                const float v = dot(ray.dir, qvec) * inv_det;
+                const float t = dot(e2, qvec) * inv_det;
+                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t))) {
+                    found = true;
+                    if (flags & 2u) {  // AlphaMode::Blend: the hit only counts where the base colour is opaque
+                        used_memory += 112u + 16u;
+                        const GpuMaterial m = a.materials[material];
+                        const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
+                        if (bc.w < 1.0f) found = false;
+                    }
+                    if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = tri; best->material = material; *found_any = true; }
+                }
+            }
+            if (found && ANY_HIT) break;
+            if (flags & 1u) { ptr += 1u; continue; }
+        }
+        if (sp > 0) { sp--; ptr = stack[sp * 64]; } else break;
+    }
+    return used_memory;
+}
+// Ray::trace (closest hit) with attributes resolved once, for the winning triangle.
+ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, uint32_t* stack, uint32_t* used_memory) {
+    Candidate c; bool any;
+    *used_memory = traverse<false>(a, ray, kF32Max, stack, &c, &any);
+    TriangleHit h;
+    h.distance = c.t; h.material_id = c.material; h.point = v3s(0.0f); h.normal = v3s(0.0f); h.uv = v2(0.0f, 0.0f);
+    if (any) {
+        const float4 q0 = a.tri_attr[4u * c.tri], q1 = a.tri_attr[4u * c.tri + 1u], q2 = a.tri_attr[4u * c.tri + 2u], q3 = a.tri_attr[4u * c.tri + 3u];
+        V3 n = c.u * xyz(q1) + c.v * xyz(q2) + (1.0f - c.u - c.v) * xyz(q0);
+        h.normal = normalize(n) * copysignf(1.0f, c.inv_det);
+        const V2 uv0 = v2(q0.w, q1.w), uv1 = v2(q2.w, q3.x), uv2 = v2(q3.y, q3.z);
+        h.uv = uv0 + (uv1 - uv0) * c.u + (uv2 - uv0) * c.v;
+    }
+    if (hit_is_some(h)) h.point = ray_at(ray, h.distance);
+    return h;
+}
+// Ray::intersect (shadow ray)
+ST_D bool trace_any(const KArgs& a, const Ray& ray, uint32_t* stack, uint32_t* used_memory) {
+    Candidate c; bool any;
+    *used_memory = traverse<true>(a, ray, ray.len, stack, &c, &any);
+    return c.t < ray.len;
+}
+ST_D void hit_pack(const TriangleHit& h, float4* d0, float4* d1) {  // hit.rs:112-120
+    *d0 = f4(h.point, b2f(h.material_id));
+    const V2 n = normal_encode(h.normal);
+    *d1 = make_float4(n.x, n.y, h.uv.x, h.uv.y);
+}
+ST_D TriangleHit hit_unpack(float4 d0, float4 d1) {  // hit.rs:95-110
+    TriangleHit h;
+    if (is_zero(xyz(d0))) { h.distance = kF32Max; h.point = v3s(0.0f); h.normal = v3s(0.0f); h.uv = v2(0.0f, 0.0f); h.material_id = 0u; return h; }
+    h.distance = 0.0f; h.point = xyz(d0); h.normal = normal_decode(v2(d1.x, d1.y)); h.uv = v2(d1.z, d1.w); h.material_id = f2b(d0.w);
+    return h;
+}
+
+// ------------------------------------------------------------------ G-buffer, surface, hit (gbuffer.rs, surface.rs, hit.rs)
+struct GBuffer { float4 base_color; V3 normal; float metallic; V3 emissive; float roughness, reflectance, depth; };
+ST_D GBuffer gbuffer_zero() { GBuffer g; g.base_color = f4z(); g.normal = v3s(0.0f); g.metallic = 0.0f; g.emissive = v3s(0.0f); g.roughness = 0.0f; g.reflectance = 0.0f; g.depth = 0.0f; return g; }
+ST_D GBuffer gbuffer_unpack(float4 d0, float4 d1) {
+    GBuffer g;
+    g.depth = d0.x;
+    g.normal = normal_decode(v2(d0.y, d0.z));
+    const uint32_t w0 = f2b(d0.w);
+    g.metallic = (float)(w0 & 0xffu) / 255.0f;
+    g.roughness = sqr((float)((w0 >> 8) & 0xffu) / 255.0f);
+    g.reflectance = (float)((w0 >> 16) & 0xffu) / 255.0f;
+    g.emissive = xyz(d1);
+    const uint32_t w1 = f2b(d1.w);
+    g.base_color = make_float4(pow_((float)(w1 & 0xffu) / 255.0f, 2.2f), pow_((float)((w1 >> 8) & 0xffu) / 255.0f, 2.2f),
+                               pow_((float)((w1 >> 16) & 0xffu) / 255.0f, 2.2f), pow_((float)((w1 >> 24) & 0xffu) / 63.0f, 2.2f));
+    return g;
+}
+ST_D void gbuffer_pack(const GBuffer& g, float4* d0, float4* d1) {
+    const V2 n = normal_encode(g.normal);
+    const float m = clampf(g.metallic, 0.0f, 1.0f) * 255.0f;
+    const float r = clampf(sqrtf(g.roughness), 0.0f, 1.0f) * 255.0f;
+    const float rf = clampf(g.reflectance, 0.0f, 1.0f) * 255.0f;
+    *d0 = make_float4(g.depth, n.x, n.y, b2f(u32_from_bytes(f2u_sat(m), f2u_sat(r), f2u_sat(rf), 1u)));
+    const float ig = 1.0f / 2.2f;
+    const float bx = clampf(pow_(g.base_color.x, ig), 0.0f, 1.0f), by = clampf(pow_(g.base_color.y, ig), 0.0f, 1.0f);
+    const float bz = clampf(pow_(g.base_color.z, ig), 0.0f, 1.0f), bw = clampf(pow_(g.base_color.w, ig), 0.0f, 1.0f);
+    *d1 = make_float4(g.emissive.x, g.emissive.y, g.emissive.z,
+                      b2f(u32_from_bytes(f2u_sat(bx * 255.0f), f2u_sat(by * 255.0f), f2u_sat(bz * 255.0f), f2u_sat(bw * 63.0f))));
+}
+ST_D float clamped_roughness(const GBuffer& g) { return clampf(g.roughness, 0.089f * 0.089f, 1.0f); }
+
+struct Surface { V3 normal; float depth, roughness; };
+ST_D Surface surface_from(float4 d) { Surface s; s.normal = normal_decode(v2(d.x, d.y)); s.depth = d.z; s.roughness = d.w; return s; }
+ST_D float surface_similarity(const Surface& self, const Surface& other) {  // surface.rs:21-47
+    if (self.depth == 0.0f || other.depth == 0.0f) return 0.0f;
+    const float d = fmax_(dot(self.normal, other.normal), 0.0f);
+    const float normal_score = d <= 0.5f ? 0.0f : 2.0f * d;
+    const float t = fabsf(self.depth - other.depth);
+    const float depth_score = t >= 0.1f * other.depth ? 0.0f : 1.0f;
+    return normal_score * depth_score;
+}
+
+struct Hit { V3 origin, dir, point; GBuffer g; };
+constexpr float kNudgeOffset = 0.01f;  // hit.rs:19
+ST_D Hit hit_make(const Ray& ray, const GBuffer& g) { Hit h; h.origin = ray.origin; h.dir = ray.dir; h.point = ray_at(ray, g.depth - kNudgeOffset); h.g = g; return h; }
+ST_D Hit hit_zero() { Hit h; h.origin = v3s(0.0f); h.dir = v3s(0.0f); h.point = v3s(0.0f); h.g = gbuffer_zero(); return h; }
+ST_D bool hit_some(const Hit& h) { return h.g.depth != 0.0f; }
+ST_D Hit pixel_hit(const KArgs& a, const GpuCamera& cam, const float4* g0, const float4* g1, U2 pos) {
+    return hit_make(camera_ray(cam, pos), gbuffer_unpack(tex_read(g0, a, pos), tex_read(g1, a, pos)));
+}
+
+// ------------------------------------------------------------------ BRDFs (brdf.rs)
+ST_D float ggx_distribution(float n_dot_h, float roughness) {
+    const float a2 = roughness * roughness;
+    const float d = (n_dot_h * a2 - n_dot_h) * n_dot_h + 1.0f;
+    return a2 / (kPi * d * d);
+}
+ST_D float ggx_schlick_masking_term(float n_dot_l, float n_dot_v, float roughness) {
+    const float k = roughness * roughness / 2.0f;
+    const float g_v = n_dot_v / (n_dot_v * (1.0f - k) + k);
+    const float g_l = n_dot_l / (n_dot_l * (1.0f - k) + k);
+    return g_v * g_l;
+}
+ST_D V3 ggx_schlick_fresnel(V3 f0, float l_dot_h) {
+    const float f90 = saturate(dot(f0, v3s(50.0f * 0.33f)));
+    return f0 + (v3s(f90) - f0) * pow_(fmax_(1.0f - l_dot_h, 0.001f), 5.0f);
+}
+ST_D V3 diffuse_eval(const GBuffer& g) { return xyz(g.base_color) * (1.0f - g.metallic) / kPi; }
+ST_D V3 specular_eval(const GBuffer& g, V3 l, V3 v) {
+    if (g.metallic <= 0.0f) return v3s(0.0f);
+    const float a = clamped_roughness(g);
+    const V3 n = g.normal;
+    const V3 h = normalize(l + v);
+    const float n_dot_l = saturate(dot(n, l)), n_dot_h = saturate(dot(n, h)), l_dot_h = saturate(dot(l, h)), n_dot_v = saturate(dot(n, v));
+    if (n_dot_l <= 0.0f || n_dot_v <= 0.0f) return v3s(0.0f);
+    const float d = ggx_distribution(n_dot_h, a);
+    const float gg = ggx_schlick_masking_term(n_dot_l, n_dot_v, a);
+    const V3 f0 = v3s(0.16f * g.reflectance * g.reflectance * (1.0f - g.metallic)) + xyz(g.base_color) * g.metallic;
+    const V3 f = ggx_schlick_fresnel(f0, l_dot_h);
+    return d * gg * f / (4.0f * n_dot_l * n_dot_v);
+}
+struct BrdfSample { V3 dir; float pdf; V3 radiance; };
+ST_D BrdfSample layered_brdf_sample(const GBuffer& g, WhiteNoise& wn, V3 v) {
+    BrdfSample s;
+    if (wn.sample() < g.metallic) {
+        const float r0 = wn.sample(), r1 = wn.sample();
+        const float a = clamped_roughness(g);
+        const V3 n = g.normal;
+        const float a2 = sqr(a);
+        V3 b, t;
+        any_orthonormal_pair(n, &b, &t);  // brdf.rs:91 `(b, t)`
+        const float cos_theta = sqrtf(fmax_(0.0f, (1.0f - r0) / ((a2 - 1.0f) * r0 + 1.0f)));
+        const float sin_theta = sqrtf(fmax_(0.0f, 1.0f - cos_theta * cos_theta));
+        const float phi = r1 * kPi * 2.0f;
+        float sp_, cp_; sincos_(phi, &sp_, &cp_);
+        const V3 h = t * (sin_theta * cp_) + b * (sin_theta * sp_) + n * cos_theta;
+        const float n_dot_h = saturate(dot(n, h)), h_dot_v = saturate(dot(h, v));
+        s.dir = normalize(2.0f * h_dot_v * h - v);
+        s.pdf = ggx_distribution(n_dot_h, a) * n_dot_h / (4.0f * h_dot_v);
+        s.radiance = specular_eval(g, s.dir, v);
+        s.pdf /= g.metallic;
+    } else {
+        s.dir = wn.sample_hemisphere(g.normal);
+        s.pdf = 1.0f / kPi;
+        s.radiance = diffuse_eval(g);
+        s.pdf /= 1.0f - g.metallic;
+    }
+    return s;
+}
+
+// ------------------------------------------------------------------ lights (light.rs)
+struct LightRadiance { V3 radiance, diff_brdf, spec_brdf; };
+ST_D V3 radiance_sum(const LightRadiance& r) { return r.radiance * (r.diff_brdf + r.spec_brdf); }
+ST_D GpuLight light_zero() { GpuLight l; l.d0 = l.d1 = l.d2 = l.d3 = l.prev_d0 = l.prev_d1 = l.prev_d2 = f4z(); return l; }
+ST_D GpuLight light_get(const KArgs& a, uint32_t id) { return id < a.n_lights_buf ? a.lights[id] : light_zero(); }  // unchecked in the reference
+ST_D GpuLight light_get_prev(const KArgs& a, uint32_t id) { GpuLight l = light_get(a, id); l.d0 = l.prev_d0; l.d1 = l.prev_d1; l.d2 = l.prev_d2; return l; }
+ST_D bool light_is_none(const GpuLight& l) { return f2b(l.d2.x) == 0u; }
+ST_D bool light_contains(const GpuLight& l, V3 p) { return distance(xyz(l.d0), p) <= l.d0.w; }
+
+ST_D LightRadiance light_radiance(const GpuLight& l, const Hit& hit) {  // light.rs:143-207
+    const V3 center = xyz(l.d0);
+    const float radius = l.d0.w, range = l.d1.w;
+    const V3 lv = center - hit.point;
+    float f_angle;
+    if (f2b(l.d2.x) == 1u) f_angle = 1.0f;
+    else {
+        const float angle = angle_between(normal_decode(v2(l.d2.y, l.d2.z)), hit.point - center);
+        f_angle = saturate(1.0f - pow_(angle / l.d2.w, 3.0f));
+    }
+    float f_dist;
+    if (range == INFINITY) f_dist = 1.0f;
+    else {
+        const float l2 = length_squared(lv);
+        const float inv_r2 = 1.0f / sqr(range);
+        const float factor = l2 * inv_r2;
+        const float smooth_factor = saturate(1.0f - factor * factor);
+        const float attenuation = smooth_factor * smooth_factor;
+        f_dist = attenuation / fmax_(l2, 0.0001f);
+    }
+    const float f_cosine = saturate(dot(hit.g.normal, normalize(lv)));
+    LightRadiance out;
+    out.diff_brdf = diffuse_eval(hit.g);
+    {
+        const V3 v = -hit.dir;
+        const V3 n = hit.g.normal;
+        const V3 r = reflect(-v, n);
+        const V3 center_to_ray = dot(lv, r) * r - lv;
+        const float t = radius * inverse_sqrt(dot(center_to_ray, center_to_ray));
+        const V3 closest_point = lv + center_to_ray * saturate(t);
+        const float l_spec_length_inverse = inverse_sqrt(dot(closest_point, closest_point));
+        const float tt = clamped_roughness(hit.g) + radius * 0.5f * l_spec_length_inverse;
+        const float i_roughness = clamped_roughness(hit.g) / saturate(tt);
+        const float intensity = sqr(i_roughness);
+        const V3 ls = closest_point * l_spec_length_inverse;
+        out.spec_brdf = intensity * specular_eval(hit.g, ls, v);
+    }
+    out.radiance = xyz(l.d1) * f_angle * f_dist * f_cosine;
+    return out;
+}
+ST_D Ray light_ray_wnoise(const GpuLight& l, WhiteNoise& wn, V3 hit_point) {  // light.rs:209-215
+    const V3 light_pos = xyz(l.d0) + l.d0.w * wn.sample_sphere();
+    const V3 light_to_hit = hit_point - light_pos;
+    Ray r = make_ray(light_pos, normalize(light_to_hit));
+    r.len = length(light_to_hit);
+    return r;
+}
+ST_D Ray light_ray_bnoise(const GpuLight& l, V2 sample, V3 hit_point) {  // light.rs:217-239
+    const V3 to_light = xyz(l.d0) - hit_point;
+    const V3 light_dir = normalize(to_light);
+    const float light_distance = length(to_light);
+    const float light_radius = l.d0.w / light_distance;
+    V3 lt, lb;
+    any_orthonormal_pair(light_dir, &lt, &lb);
+    const float angle = 2.0f * kPi * sample.x;
+    const float rad = sqrtf(sample.y);
+    float s_, c_; sincos_(angle, &s_, &c_);
+    const V2 disk_point = v2(s_, c_) * rad * light_radius;
+    V3 ray_dir = light_dir + disk_point.x * lt + disk_point.y * lb;
+    ray_dir = normalize(ray_dir);
+    Ray r = make_ray(hit_point + ray_dir * light_distance, -ray_dir);
+    r.len = light_distance;
+    return r;
+}
+
+// ------------------------------------------------------------------ atmosphere lookup (atmosphere.rs:86-205)
+constexpr float kGroundRadiusMm = 6.360f, kAtmosphereRadiusMm = 6.460f, kExposure = 20.0f;
+ST_D float4 lut_texel(const float4* lut, int32_t w, int32_t h, int32_t x, int32_t y) {
+    x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    return lut[y * w + x];
+}
+ST_D float4 lut_sample(const float4* lut, int32_t w, int32_t h, V2 uv) {
+    if (uv.x != uv.x) uv.x = 0.0f;
+    if (uv.y != uv.y) uv.y = 0.0f;
+    const float fx = uv.x * (float)w - 0.5f, fy = uv.y * (float)h - 0.5f;
+    const float x0 = floorf(fx), y0 = floorf(fy);
+    const float tx = fx - x0, ty = fy - y0;
+    const int32_t ix = f2i_sat(x0), iy = f2i_sat(y0);
+    const float4 p00 = lut_texel(lut, w, h, ix, iy), p10 = lut_texel(lut, w, h, ix + 1, iy), p01 = lut_texel(lut, w, h, ix, iy + 1), p11 = lut_texel(lut, w, h, ix + 1, iy + 1);
+    const float4 top = p00 + (p10 - p00) * tx;
+    const float4 bot = p01 + (p11 - p01) * tx;
+    return top + (bot - top) * ty;
+}
+ST_D V3 atmosphere_sample(const KArgs& a, V3 ray_dir) {
+    const V3 sun_dir = v3(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
+    const V3 view_pos = v3(0.0f, kGroundRadiusMm + 0.0002f, 0.0f);
+    // sample_sky_lut
+    V3 lum;
+    {
+        const float height = length(view_pos);
+        const V3 up = view_pos / height;
+        float th = sqr(height) - sqr(kGroundRadiusMm);
+        th = sqrtf(th) / height;
+        const float horizon = acos_(clampf(th, -1.0f, 1.0f));
+        const float altitude = horizon - acos_(dot(ray_dir, up));
+        float azimuth;
+        if (fabsf(altitude) > (0.5f * kPi - 0.0001f)) azimuth = 0.0f;
+        else {
+            const V3 right = cross(sun_dir, up);
+            const V3 forward = cross(up, right);
+            const V3 projected_dir = normalize(ray_dir - up * dot(ray_dir, up));
+            const float sin_theta = dot(projected_dir, right);
+            const float cos_theta = dot(projected_dir, forward);
+            azimuth = atan2_(sin_theta, cos_theta) + kPi;
+        }
+        const float u = azimuth / (2.0f * kPi);
+        const float v = 0.5f + 0.5f * copysignf(sqrtf(fabsf(altitude) * 2.0f / kPi), altitude);
+        lum = xyz(lut_sample(a.sky_lut, 256, 256, v2(u, v)));
+    }
+    // evaluate_bloom + interpolate_bloom
+    V3 sun_lum;
+    {
+        const float sun_solid_angle = 0.53f * kPi / 180.0f;
+        const float min_sun_cos_theta = cos_(sun_solid_angle);
+        const float cos_theta = dot(ray_dir, sun_dir);
+        if (cos_theta >= min_sun_cos_theta) sun_lum = v3s(1.0f);
+        else {
+            const float offset = min_sun_cos_theta - cos_theta;
+            const float gaussian_bloom = exp_(-offset * 50000.0f) * 0.5f;
+            const float inv_bloom = 1.0f / (0.02f + offset * 300.0f) * 0.01f;
+            sun_lum = v3s(gaussian_bloom + inv_bloom);
+        }
+        const V3 t = vclamp((sun_lum - v3s(0.002f)) / (v3s(1.0f) - v3s(0.002f)), v3s(0.0f), v3s(1.0f));
+        sun_lum = t * t * (v3s(3.0f) - 2.0f * t);
+    }
+    if (length_squared(sun_lum) > 0.0f) {
+        const Ray ray = make_ray(view_pos, ray_dir);
+        if (intersect_sphere(ray, kGroundRadiusMm) >= 0.0f) sun_lum = v3s(0.0f);
+        else {
+            const float height = length(view_pos);
+            const V3 up = view_pos / height;
+            const float sun_cos_zenith_angle = dot(sun_dir, up);
+            const float u = saturate(0.5f + 0.5f * sun_cos_zenith_angle);
+            const float v = saturate((height - kGroundRadiusMm) / (kAtmosphereRadiusMm - kGroundRadiusMm));
+            sun_lum = sun_lum * xyz(lut_sample(a.transmittance_lut, 256, 64, v2(u, v)));
+        }
+    }
+    lum = lum + sun_lum;
+    lum = lum * kExposure;
+    return lum;
+}
+
+// ------------------------------------------------------------------ reprojection (reprojection.rs, utils/bilinear_filter.rs)
+struct Reprojection { float prev_x, prev_y, confidence; uint32_t validity; };
+ST_D Reprojection reprojection_read(float4 d) { Reprojection r; r.prev_x = d.x; r.prev_y = d.y; r.confidence = d.z; r.validity = f2b(d.w); return r; }
+ST_D U2 reprojection_prev_round(const Reprojection& r) { return as_u2(round2(v2(r.prev_x, r.prev_y))); }
+ST_D bool reprojection_is_exact(const Reprojection& r) {
+    const float fx = r.prev_x - floorf(r.prev_x), fy = r.prev_y - floorf(r.prev_y);  // glam Vec2::fract
+    return (fx * fx + fy * fy) == 0.0f;
+}
+ST_D float4 bilinear_reproject(const KArgs& a, const Reprojection& r, const float4* plane) {
+    if (reprojection_is_exact(r)) return tex_read(plane, a, reprojection_prev_round(r));
+    const float fl_x = floorf(r.prev_x), fl_y = floorf(r.prev_y), ce_x = ceilf(r.prev_x), ce_y = ceilf(r.prev_y);
+    const I2 p[4] = {i2(f2i_sat(fl_x), f2i_sat(fl_y)), i2(f2i_sat(ce_x), f2i_sat(fl_y)), i2(f2i_sat(fl_x), f2i_sat(ce_y)), i2(f2i_sat(ce_x), f2i_sat(ce_y))};
+    float4 s[4]; float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        s[i] = f4z(); w[i] = 0.0f;
+        if ((r.validity & (1u << i)) > 0u && p[i].x >= 0 && p[i].y >= 0) { s[i] = tex_read(plane, a, u2((uint32_t)p[i].x, (uint32_t)p[i].y)); w[i] = 1.0f; }
+    }
+    const float ux = r.prev_x - truncf(r.prev_x), uy = r.prev_y - truncf(r.prev_y);  // f32::fract
+    const float4 weights = make_float4(w[0], w[1], w[2], w[3]) * make_float4((1.0f - ux) * (1.0f - uy), ux * (1.0f - uy), (1.0f - ux) * uy, ux * uy);
+    const float w_sum = (weights.x * 1.0f) + (weights.y * 1.0f) + (weights.z * 1.0f) + (weights.w * 1.0f);
+    if (w_sum == 0.0f) return f4z();
+    return (s[0] * weights.x + s[1] * weights.y + s[2] * weights.z + s[3] * weights.w) / w_sum;
+}
+
+// ------------------------------------------------------------------ reservoirs (reservoir.rs, reservoir/*.rs)
+struct DiSample { float pdf, confidence; uint32_t light_id; V3 light_point; bool is_occluded; };
+struct DiReservoir { DiSample s; float m, w; };
+ST_D DiReservoir di_empty() { DiReservoir r; r.s.pdf = 0.0f; r.s.confidence = 0.0f; r.s.light_id = 0u; r.s.light_point = v3s(0.0f); r.s.is_occluded = false; r.m = 0.0f; r.w = 0.0f; return r; }
+ST_D DiReservoir di_read(const float4* buf, uint32_t id, uint32_t count) {
+    if (id >= count) return di_empty();
+    const float4 d0 = buf[2u * id], d1 = buf[2u * id + 1u];
+    const uint32_t w = f2b(d0.w);
+    DiReservoir r;
+    r.s.pdf = d0.z; r.s.confidence = (float)((w >> 8) & 0xffu); r.s.light_id = f2b(d1.w); r.s.light_point = xyz(d1); r.s.is_occluded = (w & 0xffu) > 0u;
+    r.m = d0.x; r.w = d0.y;
+    return r;
+}
+ST_D void di_write(float4* buf, uint32_t id, const DiReservoir& r) {
+    buf[2u * id] = make_float4(r.m, r.w, r.s.pdf, b2f(u32_from_bytes(r.s.is_occluded ? 1u : 0u, f2u_sat(r.s.confidence), 0u, 0u)));
+    buf[2u * id + 1u] = f4(r.s.light_point, b2f(r.s.light_id));
+}
+ST_D float di_pdf_ex(const DiSample& s, const GpuLight& l, Hit hit) {  // reservoir/di.rs:105-116
+    hit.g.base_color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (!light_is_none(l) && light_contains(l, s.light_point)) return luma(radiance_sum(light_radiance(l, hit)));
+    return 0.0f;
+}
+ST_D Ray di_sample_ray(const DiSample& s, V3 hit_point) {
+    const V3 dir = hit_point - s.light_point;
+    Ray r = make_ray(s.light_point, normalize(dir));
+    r.len = length(dir);
+    return r;
+}
+
+struct GiSample { float pdf; uint32_t rng; V3 radiance, v1_point, v2_point, v2_normal; };
+struct GiReservoir { GiSample s; float m, w, confidence; };
+ST_D GiReservoir gi_empty() { GiReservoir r; r.s.pdf = 0.0f; r.s.rng = 0u; r.s.radiance = r.s.v1_point = r.s.v2_point = r.s.v2_normal = v3s(0.0f); r.m = 0.0f; r.w = 0.0f; r.confidence = 0.0f; return r; }
+ST_D GiReservoir gi_read(const float4* buf, uint32_t id, uint32_t count) {
+    if (id >= count) return gi_empty();
+    const float4 d0 = buf[4u * id], d1 = buf[4u * id + 1u], d2 = buf[4u * id + 2u], d3 = buf[4u * id + 3u];
+    GiReservoir r;
+    r.s.pdf = d2.w; r.s.rng = f2b(d3.w); r.s.radiance = xyz(d0); r.s.v1_point = xyz(d1); r.s.v2_point = xyz(d2); r.s.v2_normal = normal_decode(v2(d3.x, d3.y));
+    r.m = d0.w; r.w = d1.w; r.confidence = d3.z;
+    return r;
+}
+ST_D void gi_write(float4* buf, uint32_t id, const GiReservoir& r) {
+    buf[4u * id] = f4(r.s.radiance, r.m);
+    buf[4u * id + 1u] = f4(r.s.v1_point, r.w);
+    buf[4u * id + 2u] = f4(r.s.v2_point, r.s.pdf);
+    const V2 n = normal_encode(r.s.v2_normal);
+    buf[4u * id + 3u] = make_float4(n.x, n.y, r.confidence, b2f(r.s.rng));
+}
+ST_D bool gi_exists(const GiSample& s) { return !is_zero(s.v2_point); }
+ST_D V3 gi_dir(const GiSample& s, V3 p) { return normalize(s.v2_point - p); }
+ST_D float gi_cosine(const GiSample& s, const Hit& hit) { return fmax_(dot(gi_dir(s, hit.point), hit.g.normal), 0.0f); }
+ST_D V3 gi_spec_brdf(const GiSample& s, const Hit& hit) { return specular_eval(hit.g, gi_dir(s, hit.point), -hit.dir); }
+ST_D float gi_pdf(const GiSample& s, Hit hit) {  // reservoir/gi.rs:98-112
+    if (!gi_exists(s)) return 0.0f;
+    hit.g.base_color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    const float d = luma(diffuse_eval(hit.g));
+    const float sp = luma(gi_spec_brdf(s, hit));
+    return luma(s.radiance) * gi_cosine(s, hit) * (d + sp);
+}
+ST_D Ray gi_sample_ray(const GiSample& s, V3 hit_point) {
+    Ray r = make_ray(hit_point, gi_dir(s, hit_point));
+    r.len = distance(s.v2_point, hit_point) - 0.01f;
+    return r;
+}
+ST_D void gi_partial_jacobian(const GiSample& s, V3 hit_point, float* dist, float* cosv) {
+    const V3 vec = hit_point - s.v2_point;
+    *dist = length(vec);
+    *cosv = saturate(dot(s.v2_normal, vec / *dist));
+}
+ST_D float gi_jacobian(const GiSample& s, V3 new_hit_point) {
+    if (!gi_exists(s)) return 1.0f;
+    float nd, nc, od, oc;
+    gi_partial_jacobian(s, new_hit_point, &nd, &nc);
+    gi_partial_jacobian(s, s.v1_point, &od, &oc);
+    const float x = nc * od * od, y = oc * nd * nd;
+    return y == 0.0f ? 0.0f : x / y;
+}
+
+// Reservoir<T>::update / merge / norm as free templates (reservoir.rs:24-79)
+template <class R, class S>
+ST_D bool res_update(R& r, WhiteNoise& wn, const S& sample, float weight) {
+    r.m += 1.0f; r.w += weight;
+    if (wn.sample() * r.w < weight) { r.s = sample; return true; }
+    return false;
+}
+template <class R>
+ST_D bool res_merge(R& r, WhiteNoise& wn, const R& other, float pdf) {
+    if (other.m <= 0.0f) return false;
+    r.m += other.m - 1.0f;
+    return res_update(r, wn, other.s, other.w * other.m * pdf);
+}
+template <class R>
+ST_D void res_norm(R& r, float pdf, float num, float denom_) { const float denom = pdf * denom_; r.w = denom == 0.0f ? 0.0f : (r.w * num) / denom; }
+
+// EphemeralReservoir::build (reservoir/ephemeral.rs:14-55): RIS over min(16, light_count) uniformly picked lights
+struct EphemeralResult { uint32_t light_id; LightRadiance light_rad; float m, w; };
+ST_D EphemeralResult ephemeral_build(const KArgs& a, WhiteNoise& wn, const Hit& hit) {
+    EphemeralResult res; res.light_id = 0u; res.light_rad.radiance = res.light_rad.diff_brdf = res.light_rad.spec_brdf = v3s(0.0f); res.m = 0.0f; res.w = 0.0f;
+    float res_pdf = 0.0f;
+    const uint32_t max_samples = a.light_count < 16u ? a.light_count : 16u;
+    const float sample_ipdf = (float)a.light_count;
+    for (uint32_t nth = 0; nth < max_samples; nth++) {
+        const uint32_t light_id = wn.sample_int() % a.light_count;
+        const LightRadiance rad = light_radiance(light_get(a, light_id), hit);
+        const float sample_pdf = sqrtf(luma(rad.radiance));  // perc_luma
+        const float weight = sample_pdf * sample_ipdf;
+        res.m += 1.0f; res.w += weight;
+        if (wn.sample() * res.w < weight) { res.light_id = light_id; res.light_rad = rad; res_pdf = sample_pdf; }
+    }
+    { const float denom = res_pdf * res.m; res.w = denom == 0.0f ? 0.0f : (res.w * 1.0f) / denom; }  // norm_avg
+    return res;
+}
+
+// defensive pairwise MIS (reservoir/mis.rs:96-144)
+struct Mis { float lhs_m, rhs_m, rhs_jacobian, lhs_lhs_pdf, lhs_rhs_pdf, rhs_lhs_pdf, rhs_rhs_pdf; };
+struct MisResult { float m, lhs_pdf, lhs_mis, rhs_pdf, rhs_mis; };
+ST_D float mis2(float x, float y) { const float sum = x + y; return sum == 0.0f ? 0.0f : x / sum; }
+ST_D float mis_mfac(float q0, float q1) { return q0 <= 0.0f ? 1.0f : saturate(pow_(fmin_(q1 / q0, 1.0f), 8.0f)); }
+ST_D MisResult mis_eval(const Mis& s) {
+    MisResult r;
+    r.m = s.rhs_m * fmin_(mis_mfac(s.rhs_rhs_pdf, s.rhs_lhs_pdf), mis_mfac(s.lhs_rhs_pdf, s.lhs_lhs_pdf));
+    const float t = mis2(s.lhs_m, s.rhs_m);
+    r.lhs_mis = t + (1.0f - t) * mis2(s.lhs_m * s.lhs_lhs_pdf, s.rhs_m * s.lhs_rhs_pdf);
+    r.rhs_mis = (1.0f - t) * mis2(s.rhs_m * s.rhs_rhs_pdf * s.rhs_jacobian, s.lhs_m * s.rhs_lhs_pdf);
+    r.lhs_pdf = s.lhs_lhs_pdf; r.rhs_pdf = s.rhs_lhs_pdf;
+    return r;
+}
+
+}  // namespace st

@@ -1,0 +1,888 @@
+// st_engine.cpp — host engine of libstrolle_hip.so: scene stores, world-space baking + BVH refresh, device
+// buffer management, the per-frame pass graph and the C ABI (include/strolle_hip.h).
+//
+// Behavioural contract: strolle/src/lib.rs (Engine), camera_controller.rs (pass order), lights.rs / materials.rs /
+// instances.rs / triangles.rs (stores), camera.rs (camera uniform). The wgpu plumbing of the reference
+// (bind groups, mapped buffers, textures) is replaced by plain device allocations and pointer swaps.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/strolle_hip.h"
+#include "st_bvh.h"
+#include "st_kernels.h"
+
+namespace st {
+
+static thread_local std::string g_last_error;
+static int fail(int status, const std::string& msg) { g_last_error = msg; return status; }
+
+#define ST_HIP(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t err_ = (call);                                                                         \
+        if (err_ != hipSuccess) return fail(ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err_)); \
+    } while (0)
+
+// ------------------------------------------------------------------ host maths (glam order; see st_math.h)
+static M4 m4_from_cols(const float* a) { M4 m; for (int i = 0; i < 4; i++) m.c[i] = make_float4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]); return m; }
+static M4 m4_mul(const M4& a, const M4& b) { M4 r; for (int i = 0; i < 4; i++) r.c[i] = mul(a, b.c[i]); return r; }
+static M4 m4_inverse(const M4& m) {  // glam 0.24 Mat4::inverse, scalar path
+    const float m00 = m.c[0].x, m01 = m.c[0].y, m02 = m.c[0].z, m03 = m.c[0].w;
+    const float m10 = m.c[1].x, m11 = m.c[1].y, m12 = m.c[1].z, m13 = m.c[1].w;
+    const float m20 = m.c[2].x, m21 = m.c[2].y, m22 = m.c[2].z, m23 = m.c[2].w;
+    const float m30 = m.c[3].x, m31 = m.c[3].y, m32 = m.c[3].z, m33 = m.c[3].w;
+    const float c00 = m22 * m33 - m32 * m23, c02 = m12 * m33 - m32 * m13, c03 = m12 * m23 - m22 * m13;
+    const float c04 = m21 * m33 - m31 * m23, c06 = m11 * m33 - m31 * m13, c07 = m11 * m23 - m21 * m13;
+    const float c08 = m21 * m32 - m31 * m22, c10 = m11 * m32 - m31 * m12, c11 = m11 * m22 - m21 * m12;
+    const float c12 = m20 * m33 - m30 * m23, c14 = m10 * m33 - m30 * m13, c15 = m10 * m23 - m20 * m13;
+    const float c16 = m20 * m32 - m30 * m22, c18 = m10 * m32 - m30 * m12, c19 = m10 * m22 - m20 * m12;
+    const float c20 = m20 * m31 - m30 * m21, c22 = m10 * m31 - m30 * m11, c23 = m10 * m21 - m20 * m11;
+    const float4 f0 = make_float4(c00, c00, c02, c03), f1 = make_float4(c04, c04, c06, c07), f2 = make_float4(c08, c08, c10, c11);
+    const float4 f3 = make_float4(c12, c12, c14, c15), f4_ = make_float4(c16, c16, c18, c19), f5 = make_float4(c20, c20, c22, c23);
+    const float4 v0 = make_float4(m10, m00, m00, m00), v1 = make_float4(m11, m01, m01, m01), v2_ = make_float4(m12, m02, m02, m02), v3_ = make_float4(m13, m03, m03, m03);
+    const float4 i0 = (v1 * f0 - v2_ * f1) + v3_ * f2;
+    const float4 i1 = (v0 * f0 - v2_ * f3) + v3_ * f4_;
+    const float4 i2_ = (v0 * f1 - v1 * f3) + v3_ * f5;
+    const float4 i3 = (v0 * f2 - v1 * f4_) + v2_ * f5;
+    const float4 sa = make_float4(1.0f, -1.0f, 1.0f, -1.0f), sb = make_float4(-1.0f, 1.0f, -1.0f, 1.0f);
+    M4 inv;
+    inv.c[0] = i0 * sa; inv.c[1] = i1 * sb; inv.c[2] = i2_ * sa; inv.c[3] = i3 * sb;
+    const float4 col0 = make_float4(inv.c[0].x, inv.c[1].x, inv.c[2].x, inv.c[3].x);
+    const float4 d0 = m.c[0] * col0;
+    const float det = d0.x + d0.y + d0.z + d0.w;
+    const float rcp = 1.0f / det;
+    for (int i = 0; i < 4; i++) inv.c[i] = inv.c[i] * rcp;
+    return inv;
+}
+struct Affine { V3 x, y, z, t; };
+static Affine affine_from12(const float* a) { Affine r; r.x = v3(a[0], a[1], a[2]); r.y = v3(a[3], a[4], a[5]); r.z = v3(a[6], a[7], a[8]); r.t = v3(a[9], a[10], a[11]); return r; }
+static V3 affine_vec(const Affine& a, V3 v) { V3 r = a.x * v.x; r = r + a.y * v.y; r = r + a.z * v.z; return r; }
+static V3 affine_point(const Affine& a, V3 p) { return ((a.x * p.x) + (a.y * p.y) + (a.z * p.z)) + a.t; }
+static Affine affine_inverse(const Affine& a) {  // glam Affine3A::inverse
+    const V3 t0 = cross(a.y, a.z), t1 = cross(a.z, a.x), t2 = cross(a.x, a.y);
+    const float det = dot(a.z, t2);
+    const float inv_det = 1.0f / det;
+    const V3 c0 = t0 * inv_det, c1 = t1 * inv_det, c2 = t2 * inv_det;
+    Affine r;
+    r.x = v3(c0.x, c1.x, c2.x); r.y = v3(c0.y, c1.y, c2.y); r.z = v3(c0.z, c1.z, c2.z);
+    r.t = -affine_vec(r, a.t);
+    return r;
+}
+
+// per-pass seeds (NEW seam): the same definition is stated in DESIGN.md
+static uint32_t seed_hash(uint32_t v) {
+    v = v * 747796405u + 2891336453u;
+    const uint32_t w = ((v >> ((v >> 28) + 4u)) ^ v) * 277803737u;
+    return (w >> 22) ^ w;
+}
+static uint32_t pass_seed(uint64_t base, uint32_t frame, uint32_t pass_id) {
+    return seed_hash((uint32_t)base ^ seed_hash((uint32_t)(base >> 32) ^ seed_hash(frame ^ seed_hash(pass_id))));
+}
+enum PassSeedId { SEED_DI_SAMPLING = 1, SEED_DI_TEMPORAL = 2, SEED_DI_SPATIAL_PICK = 3, SEED_DI_SPATIAL_SAMPLE = 5, SEED_GI_SAMPLING_A = 8,
+                  SEED_GI_SAMPLING_B = 9, SEED_GI_TEMPORAL = 10, SEED_GI_SPATIAL_PICK = 11, SEED_GI_SPATIAL_SAMPLE = 13, SEED_GI_PREVIEW = 14,
+                  SEED_REF_SHADING = 200 };
+
+// sun light colour: atmosphere/generate_transmittance_lut.rs:32-59 evaluated on the host (lights.rs:80-95)
+static V3 sun_transmittance(V3 pos, V3 sun_dir) {
+    auto sphere = [&](float radius) {
+        const float b = dot(pos, sun_dir), c = dot(pos, pos) - radius * radius;
+        if (c > 0.0f && b > 0.0f) return -1.0f;
+        const float discr = b * b - c;
+        if (discr < 0.0f) return -1.0f;
+        return discr > b * b ? -b + sqrtf(discr) : -b - sqrtf(discr);
+    };
+    if (sphere(6.360f) > 0.0f) return v3s(0.0f);
+    const float atmosphere_distance = sphere(6.460f);
+    float t = 0.0f, i = 0.0f;
+    V3 transmittance = v3s(1.0f);
+    while (i < 40.0f) {
+        const float new_t = ((i + 0.3f) / 40.0f) * atmosphere_distance;
+        const float dt = new_t - t;
+        t = new_t;
+        const V3 new_pos = pos + t * sun_dir;
+        const float altitude_km = (length(new_pos) - 6.360f) * 1000.0f;
+        const float rayleigh_density = exp_(-altitude_km / 8.0f), mie_density = exp_(-altitude_km / 1.2f);
+        const V3 rayleigh_scattering = v3(5.802f, 13.558f, 33.1f) * rayleigh_density;
+        const float rayleigh_absorption = 0.0f * rayleigh_density;
+        const float mie_scattering = 3.996f * mie_density, mie_absorption = 4.4f * mie_density;
+        const V3 ozone_absorption = v3(0.650f, 1.881f, 0.085f) * fmax_(1.0f - fabsf(altitude_km - 25.0f) / 15.0f, 0.0f);
+        const V3 extinction = rayleigh_scattering + v3s(rayleigh_absorption) + v3s(mie_scattering) + v3s(mie_absorption) + ozone_absorption;
+        const V3 arg = -dt * extinction;
+        transmittance = transmittance * v3(exp_(arg.x), exp_(arg.y), exp_(arg.z));
+        i += 1.0f;
+    }
+    return transmittance;
+}
+
+// ------------------------------------------------------------------ small containers
+struct SlotRanges {  // utils/allocator.rs
+    std::vector<std::pair<size_t, size_t>> free_; bool unsorted = false;
+    void give(size_t b, size_t e) { if (!free_.empty()) unsorted |= b <= free_.back().second; free_.push_back({b, e}); }
+    bool take(size_t len, size_t* b, size_t* e) {
+        if (unsorted && !free_.empty()) {
+            std::stable_sort(free_.begin(), free_.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
+            for (size_t i = 0; i + 1 < free_.size();) {
+                if (free_[i].second == free_[i + 1].first) { free_[i].second = free_[i + 1].second; free_.erase(free_.begin() + i + 1); }
+                else i++;
+            }
+        }
+        unsorted = false;
+        for (size_t i = 0; i < free_.size(); i++) {
+            const size_t have = free_[i].second - free_[i].first;
+            if (have < len) continue;
+            *b = free_[i].first; *e = *b + len;
+            if (have == len) free_.erase(free_.begin() + i); else free_[i].first += len;
+            return true;
+        }
+        return false;
+    }
+};
+
+struct DeviceArray {
+    void* ptr = nullptr; size_t capacity = 0;
+    int upload(const void* src, size_t bytes, hipStream_t stream) {
+        if (bytes > capacity) {
+            if (ptr) ST_HIP(hipFree(ptr));
+            capacity = std::max<size_t>(bytes * 3 / 2, 4096);
+            ST_HIP(hipMalloc(&ptr, capacity));
+        }
+        if (bytes) ST_HIP(hipMemcpyAsync(ptr, src, bytes, hipMemcpyHostToDevice, stream));
+        return ST_OK;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; capacity = 0; }
+};
+
+// ------------------------------------------------------------------ per-camera state (camera_controller/buffers.rs)
+struct CameraState {
+    StCamera desc{};
+    GpuCamera curr{}, prev{};
+    uint32_t frame = 0, row0 = 0, row1 = 0;
+    void* slab = nullptr; size_t slab_bytes = 0;
+    float4* plane[ST_BUF_COUNT] = {};
+    size_t plane_bytes[ST_BUF_COUNT] = {};
+    unsigned long long* counters = nullptr;  // KS_COUNT x {rays, traversal bytes}
+    unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
+};
+static size_t plane_texels_per_pixel(int id) {
+    if (id >= ST_BUF_DI_RESERVOIRS_0 && id <= ST_BUF_DI_RESERVOIRS_2) return 2;
+    if (id >= ST_BUF_GI_RESERVOIRS_0 && id <= ST_BUF_GI_RESERVOIRS_3) return 4;
+    if (id == ST_BUF_REF_HITS) return 2;
+    if (id == ST_BUF_REF_RAYS) return 3;
+    return 1;
+}
+
+struct ProfileRecord { int slot; hipEvent_t start, stop; double bytes; };
+
+struct Light112 { GpuLight g; };
+
+struct Engine {
+    int device = -1;
+    bool has_device = false;
+    uint64_t base_seed = 0;
+    uint32_t frame = 1;  // lib.rs:152
+
+    // meshes / materials / instances / triangles
+    std::unordered_map<uint64_t, std::vector<StMeshTriangle>> meshes;
+    std::vector<StMaterial> materials; std::unordered_map<uint64_t, uint32_t> material_slot; SlotRanges material_free; bool materials_dirty = false;
+    std::vector<GpuMaterial> gpu_materials;
+    struct InstanceRec { uint64_t id, mesh, material; Affine xform, xform_inv, prev_xform; bool dirty; };
+    std::vector<InstanceRec> instances; bool instances_dirty = false;
+    std::map<uint64_t, std::pair<size_t, size_t>> instance_triangles; SlotRanges triangle_free;
+    std::vector<HostTriangle> triangles; std::vector<BuildPrim> prims; std::vector<uint8_t> prim_alive;
+    std::vector<float4> tri_geo, tri_attr, bvh_stream;
+    BvhBuild bvh;
+    bool scene_uploaded = false;
+
+    // images: a single linear RGBA8 atlas; rect allocation = shelf packing (images.rs uses guillotiere)
+    uint32_t atlas_w = 0, atlas_h = 0; std::vector<uint8_t> atlas; bool atlas_dirty = false;
+    struct ImageRec { uint32_t x, y, w, h; };
+    std::unordered_map<uint64_t, ImageRec> images; uint32_t shelf_x = 0, shelf_y = 0, shelf_h = 0;
+
+    // lights (lights.rs): slot 0 is the sun
+    std::vector<GpuLight> light_buffer; std::map<int64_t, uint32_t> light_slot;
+    std::vector<int64_t> lights_created, lights_updated; std::map<int64_t, uint32_t> lights_remapped; std::vector<uint32_t> lights_killed;
+    uint32_t next_light_id = 1;
+    std::vector<GpuLight> gpu_lights;
+    float sun_azimuth = 0.0f, sun_altitude = 0.35f; bool sun_dirty = true;
+    uint32_t light_count = 0; V3 sun_dir_ = v3s(0.0f);
+
+    std::vector<uint8_t> blue_noise; bool blue_noise_dirty = true;
+    std::vector<float4> transmittance_lut, sky_lut; bool luts_dirty = true;
+
+    DeviceArray d_bvh, d_tri_geo, d_tri_attr, d_materials, d_lights, d_atlas, d_blue_noise, d_transmittance, d_sky;
+
+    std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
+
+    bool profiling = false;
+    std::vector<ProfileRecord> profile_records; std::vector<hipEvent_t> event_pool;
+    StKernelProfile profile_totals[KS_COUNT];
+
+    Engine() {
+        GpuLight sun{};
+        sun.d0 = make_float4(0, 0, 0, 25.0f); sun.d1 = make_float4(0, 0, 0, INFINITY); sun.d2 = make_float4(b2f(1u), 0, 0, 0);
+        light_buffer.push_back(sun);
+        light_slot[-1] = 0;
+        blue_noise.assign(256 * 256 * 4, 0);
+        transmittance_lut.assign(256 * 64, make_float4(0, 0, 0, 0));
+        sky_lut.assign(256 * 256, make_float4(0, 0, 0, 0));
+        reset_profile_totals();
+    }
+    void reset_profile_totals() {
+        for (int i = 0; i < KS_COUNT; i++) {
+            memset(&profile_totals[i], 0, sizeof(StKernelProfile));
+            snprintf(profile_totals[i].name, sizeof(profile_totals[i].name), "%s", kernel_info(i).name);
+        }
+    }
+    ~Engine() {
+        if (!has_device) return;
+        (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        for (auto& kv : cameras) release_camera(*kv.second);
+        for (DeviceArray* d : {&d_bvh, &d_tri_geo, &d_tri_attr, &d_materials, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_sky}) d->release();
+        for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+        for (auto e : event_pool) (void)hipEventDestroy(e);
+    }
+    static void release_camera(CameraState& c) { if (c.slab) (void)hipFree(c.slab); if (c.counters) (void)hipFree(c.counters); c.slab = nullptr; c.counters = nullptr; }
+
+    // ---- materials (materials.rs:33-96, material.rs:29-50)
+    float4 image_rect(uint64_t h) const {
+        if (!h) return make_float4(0, 0, 0, 0);
+        auto it = images.find(h);
+        if (it == images.end() || atlas_w == 0) return make_float4(0, 0, 0, 0);
+        const ImageRec& r = it->second;
+        return make_float4((float)r.x / (float)atlas_w, (float)r.y / (float)atlas_h, (float)r.w / (float)atlas_w, (float)r.h / (float)atlas_h);
+    }
+    void rebuild_gpu_materials() {
+        gpu_materials.resize(materials.size());
+        for (size_t i = 0; i < materials.size(); i++) {
+            const StMaterial& m = materials[i]; GpuMaterial& g = gpu_materials[i];
+            g.base_color = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
+            g.base_color_texture = image_rect(m.base_color_texture);
+            g.emissive = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
+            g.emissive_texture = image_rect(m.emissive_texture);
+            g.roughness = pow_(m.perceptual_roughness, 2.0f);
+            g.metallic = m.metallic; g.reflectance = m.reflectance; g.ior = m.ior;
+            g.metallic_roughness_texture = image_rect(m.metallic_roughness_texture);
+            g.normal_map_texture = image_rect(m.normal_map_texture);
+        }
+    }
+
+    // ---- lights (lights.rs:49-172, light.rs:25-79)
+    static void note(std::vector<int64_t>& v, int64_t k) { if (std::find(v.begin(), v.end(), k) == v.end()) v.push_back(k); }
+    void overwrite_light(uint32_t slot, int64_t key, GpuLight g) {
+        const GpuLight old = light_buffer[slot];
+        g.prev_d0 = old.d0; g.prev_d1 = old.d1; g.prev_d2 = old.d2;
+        note(lights_updated, key);
+        light_buffer[slot] = g;
+    }
+    void insert_light(uint64_t id, const StLight& l) {
+        GpuLight g{};
+        g.d0 = make_float4(l.position[0], l.position[1], l.position[2], l.radius);
+        g.d1 = make_float4(l.color[0], l.color[1], l.color[2], l.range);
+        if (l.kind == ST_LIGHT_POINT) g.d2 = make_float4(b2f(1u), 0, 0, 0);
+        else {
+            V3 n = v3(l.direction[0], l.direction[1], l.direction[2]);  // Normal::encode (normal.rs:9-24)
+            n = n / (fabsf(n.x) + fabsf(n.y) + fabsf(n.z));
+            V2 e = n.z >= 0.0f ? v2(n.x, n.y) : v2(copysignf(1.0f - fabsf(n.y), n.x), copysignf(1.0f - fabsf(n.x), n.y));
+            e = e * 0.5f + 0.5f;
+            g.d2 = make_float4(b2f(2u), e.x, e.y, l.angle);
+        }
+        const int64_t key = (int64_t)id;
+        auto it = light_slot.find(key);
+        if (it != light_slot.end()) { overwrite_light(it->second, key, g); return; }
+        if (next_light_id < light_buffer.size()) { light_buffer[next_light_id] = g; light_slot[key] = next_light_id; }
+        else { light_slot[key] = (uint32_t)light_buffer.size(); light_buffer.push_back(g); }
+        note(lights_created, key);
+        next_light_id += 1;
+    }
+    void remove_light(uint64_t id) {
+        const int64_t key = (int64_t)id;
+        auto it = light_slot.find(key);
+        if (it == light_slot.end()) return;  // silent no-op like the reference
+        const uint32_t slot = it->second;
+        light_slot.erase(it);
+        light_buffer.erase(light_buffer.begin() + slot);
+        light_buffer.push_back(GpuLight{});
+        lights_created.erase(std::remove(lights_created.begin(), lights_created.end(), key), lights_created.end());
+        lights_updated.erase(std::remove(lights_updated.begin(), lights_updated.end(), key), lights_updated.end());
+        lights_remapped.erase(key);
+        if (std::find(lights_killed.begin(), lights_killed.end(), slot) == lights_killed.end()) lights_killed.push_back(slot);
+        next_light_id -= 1;
+        for (auto& kv : light_slot)
+            if (kv.second > slot) { if (!lights_remapped.count(kv.first)) lights_remapped[kv.first] = kv.second; kv.second -= 1; }
+    }
+    void snapshot_lights() {  // lights.rs:128-154: what the device sees this frame, then commit prev_* for the next one
+        for (uint32_t s : lights_killed) light_buffer[s].d3.x = b2f(0xcafebabeu);
+        for (auto& kv : lights_remapped) light_buffer[kv.second].d3.x = b2f(light_slot[kv.first] + 1u);
+        gpu_lights = light_buffer;
+        auto commit = [&](int64_t k) { GpuLight& l = light_buffer[light_slot[k]]; l.prev_d0 = l.d0; l.prev_d1 = l.d1; l.prev_d2 = l.d2; };
+        for (int64_t k : lights_created) commit(k);
+        for (int64_t k : lights_updated) commit(k);
+        for (uint32_t s : lights_killed) light_buffer[s].d3.x = b2f(0u);
+        for (auto& kv : lights_remapped) light_buffer[kv.second].d3.x = b2f(0u);
+        lights_created.clear(); lights_updated.clear(); lights_remapped.clear(); lights_killed.clear();
+    }
+
+    // ---- instances -> world-space triangles (instances.rs:69-139, mesh_triangle.rs:47-86, triangle.rs:16-37)
+    void drop_instance_triangles(uint64_t id) {
+        auto it = instance_triangles.find(id);
+        if (it == instance_triangles.end()) return;
+        triangle_free.give(it->second.first, it->second.second);
+        for (size_t i = it->second.first; i < it->second.second; i++) prim_alive[i] = 0;
+        instance_triangles.erase(it);
+    }
+    void bake(const StMeshTriangle& t, const InstanceRec& inst, uint32_t material, size_t slot) {
+        // normals use transpose(inverse(xform)) (Mat4::transform_vector3 order); tangents follow the forward matrix
+        const Affine& inv = inst.xform_inv;
+        const V3 r0 = v3(inv.x.x, inv.y.x, inv.z.x), r1 = v3(inv.x.y, inv.y.y, inv.z.y), r2 = v3(inv.x.z, inv.y.z, inv.z.z);
+        const float det = dot(inst.xform.z, cross(inst.xform.x, inst.xform.y));
+        const float sign = (f2b(det) >> 31) ? -1.0f : 1.0f;
+        V3 p[3], n[3]; float4 tg[3];
+        for (int i = 0; i < 3; i++) {
+            p[i] = affine_point(inst.xform, v3(t.positions[i][0], t.positions[i][1], t.positions[i][2]));
+            const V3 nn = v3(t.normals[i][0], t.normals[i][1], t.normals[i][2]);
+            // transpose(inverse): columns are the inverse's rows; the 4th row of the transposed matrix carries the
+            // inverse translation in .w only, which transform_vector3 drops
+            V3 acc = r0 * nn.x; acc = r1 * nn.y + acc; acc = r2 * nn.z + acc;
+            n[i] = normalize(acc);
+            const V3 tt = normalize(affine_vec(inst.xform, v3(t.tangents[i][0], t.tangents[i][1], t.tangents[i][2])));
+            tg[i] = make_float4(tt.x, tt.y, tt.z, t.tangents[i][3] * sign);
+        }
+        HostTriangle h;
+        h.d0 = f4(p[0], t.uvs[0][0]); h.d1 = f4(n[0], t.uvs[0][1]); h.d2 = tg[0];
+        h.d3 = f4(p[1], t.uvs[1][0]); h.d4 = f4(n[1], t.uvs[1][1]); h.d5 = tg[1];
+        h.d6 = f4(p[2], t.uvs[2][0]); h.d7 = f4(n[2], t.uvs[2][1]); h.d8 = tg[2];
+        triangles[slot] = h;
+        BuildPrim bp;
+        bp.triangle_id = (uint32_t)slot; bp.material_id = material;
+        bp.center = (((v3s(0.0f) + p[0]) + p[1]) + p[2]) / 3.0f;
+        bp.bounds = Aabb(); bp.bounds.grow(p[0]); bp.bounds.grow(p[1]); bp.bounds.grow(p[2]);
+        prims[slot] = bp; prim_alive[slot] = 1;
+        tri_geo[3 * slot] = f4(p[0], 0.0f); tri_geo[3 * slot + 1] = f4(p[1] - p[0], 0.0f); tri_geo[3 * slot + 2] = f4(p[2] - p[0], 0.0f);
+        tri_attr[4 * slot] = f4(n[0], t.uvs[0][0]); tri_attr[4 * slot + 1] = f4(n[1], t.uvs[0][1]); tri_attr[4 * slot + 2] = f4(n[2], t.uvs[1][0]);
+        tri_attr[4 * slot + 3] = make_float4(t.uvs[1][1], t.uvs[2][0], t.uvs[2][1], 0.0f);
+    }
+    bool refresh_instances() {
+        if (!instances_dirty) return false;
+        instances_dirty = false;
+        for (auto& inst : instances) {
+            if (!inst.dirty) continue;
+            inst.dirty = false;
+            auto mesh = meshes.find(inst.mesh);
+            auto mat = material_slot.find(inst.material);
+            if (mesh == meshes.end() || mat == material_slot.end()) { inst.dirty = true; instances_dirty = true; continue; }  // retry next tick
+            const size_t count = mesh->second.size();
+            auto have = instance_triangles.find(inst.id);
+            if (have != instance_triangles.end() && have->second.second - have->second.first != count) { drop_instance_triangles(inst.id); have = instance_triangles.end(); }
+            size_t b, e;
+            if (have != instance_triangles.end()) { b = have->second.first; e = have->second.second; }
+            else if (!triangle_free.take(count, &b, &e)) {
+                b = triangles.size(); e = b + count;
+                triangles.resize(e); prims.resize(e); prim_alive.resize(e, 0); tri_geo.resize(3 * e); tri_attr.resize(4 * e);
+            }
+            for (size_t i = 0; i < count; i++) bake(mesh->second[i], inst, mat->second, b + i);
+            instance_triangles[inst.id] = {b, e};
+        }
+        return true;
+    }
+
+    // ---- tick (lib.rs:301-395)
+    int tick(hipStream_t stream) {
+        bool scene_changed = false;
+        if (materials_dirty || atlas_dirty) { materials_dirty = false; rebuild_gpu_materials(); scene_changed = true; }
+        if (refresh_instances()) {
+            bvh.prims.clear();
+            for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
+            bvh.run();
+            std::vector<uint8_t> blend(materials.size());
+            for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
+            bvh.flatten(blend, bvh_stream);
+            scene_changed = true;
+        }
+        light_count = next_light_id;
+        {   // World::sun_dir (world.rs:18-24)
+            float sa, ca, sz, cz;
+            sincos_(sun_altitude, &sa, &ca); sincos_(sun_azimuth, &sz, &cz);
+            sun_dir_ = v3(ca * sz, sa, -ca * cz);
+        }
+        if (sun_dirty) {
+            sun_dirty = false;
+            V3 color = sun_transmittance(v3(0.0f, 6.360f + 0.0002f, 0.0f), sun_dir_);
+            color = color * 20.0f * 5.0f;
+            GpuLight sun{};
+            const V3 pos = sun_dir_ * 1000.0f;
+            sun.d0 = f4(pos, 25.0f); sun.d1 = f4(color, INFINITY); sun.d2 = make_float4(b2f(1u), 0, 0, 0);
+            overwrite_light(0, -1, sun);
+        }
+        snapshot_lights();
+        if (has_device) {
+            ST_HIP(hipSetDevice(device));
+            if (scene_changed || !scene_uploaded) {
+                int rc;
+                if ((rc = d_bvh.upload(bvh_stream.data(), bvh_stream.size() * sizeof(float4), stream))) return rc;
+                if ((rc = d_tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), stream))) return rc;
+                if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream))) return rc;
+                if ((rc = d_materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), stream))) return rc;
+                scene_uploaded = true;
+            }
+            if (atlas_dirty) { int rc = d_atlas.upload(atlas.data(), atlas.size(), stream); if (rc) return rc; }
+            if (blue_noise_dirty) { int rc = d_blue_noise.upload(blue_noise.data(), blue_noise.size(), stream); if (rc) return rc; blue_noise_dirty = false; }
+            if (luts_dirty) {
+                int rc;
+                if ((rc = d_transmittance.upload(transmittance_lut.data(), transmittance_lut.size() * sizeof(float4), stream))) return rc;
+                if ((rc = d_sky.upload(sky_lut.data(), sky_lut.size() * sizeof(float4), stream))) return rc;
+                luts_dirty = false;
+            }
+            int rc = d_lights.upload(gpu_lights.data(), gpu_lights.size() * sizeof(GpuLight), stream);
+            if (rc) return rc;
+            // host vectors above may be touched again before the async copies land
+            ST_HIP(hipStreamSynchronize(stream));
+        }
+        atlas_dirty = false;
+        for (auto& kv : cameras) kv.second->frame = frame;  // CameraController::flush
+        frame += 1;
+        return ST_OK;
+    }
+
+    // ---- cameras (camera.rs:50-66, camera_controller.rs:27-86)
+    static GpuCamera serialize_camera(const StCamera& c) {
+        const M4 transform = m4_from_cols(c.transform), projection = m4_from_cols(c.projection);
+        GpuCamera g;
+        g.projection_view = m4_mul(projection, m4_inverse(transform));
+        g.ndc_to_world = m4_mul(transform, m4_inverse(projection));
+        g.origin = make_float4(transform.c[3].x, transform.c[3].y, transform.c[3].z, 0.0f);
+        g.screen = make_float4((float)c.width, (float)c.height, 0.0f, 0.0f);
+        return g;
+    }
+    int allocate_camera(CameraState& c) {
+        c.row0 = 0; c.row1 = c.desc.height;
+        if (!has_device) return ST_OK;
+        ST_HIP(hipSetDevice(device));
+        release_camera(c);
+        const size_t n = (size_t)c.desc.width * c.desc.height;
+        size_t total = 0;
+        for (int i = 0; i < ST_BUF_COUNT; i++) {
+            c.plane_bytes[i] = i == ST_BUF_DBG_USED_MEMORY ? n * 4 : n * 16 * plane_texels_per_pixel(i);
+            total += (c.plane_bytes[i] + 255) & ~size_t(255);
+        }
+        ST_HIP(hipMalloc(&c.slab, total));
+        ST_HIP(hipMemset(c.slab, 0, total));  // wgpu zero-initialises resources; stale-data paths depend on it
+        c.slab_bytes = total;
+        size_t off = 0;
+        for (int i = 0; i < ST_BUF_COUNT; i++) { c.plane[i] = reinterpret_cast<float4*>(static_cast<char*>(c.slab) + off); off += (c.plane_bytes[i] + 255) & ~size_t(255); }
+        ST_HIP(hipMalloc(reinterpret_cast<void**>(&c.counters), sizeof(unsigned long long) * 2 * KS_COUNT));
+        ST_HIP(hipMemset(c.counters, 0, sizeof(unsigned long long) * 2 * KS_COUNT));
+        memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
+        ST_HIP(hipDeviceSynchronize());  // the clears run on the null stream; renders may use any stream
+        return ST_OK;
+    }
+
+    // ---- profiling
+    hipEvent_t take_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    struct Scope {
+        Engine* e; hipStream_t s; int slot; double bytes; hipEvent_t start{}, stop{};
+        Scope(Engine* e_, hipStream_t s_, int slot_, double bytes_) : e(e_), s(s_), slot(slot_), bytes(bytes_) {
+            if (e->profiling) { start = e->take_event(); stop = e->take_event(); (void)hipEventRecord(start, s); }
+        }
+        ~Scope() { if (e->profiling) { (void)hipEventRecord(stop, s); e->profile_records.push_back({slot, start, stop, bytes}); } }
+    };
+    int drain_profile() {
+        for (auto& r : profile_records) {
+            ST_HIP(hipEventSynchronize(r.stop));
+            float ms = 0.0f;
+            ST_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+            profile_totals[r.slot].launches += 1; profile_totals[r.slot].total_ms += ms; profile_totals[r.slot].algorithmic_bytes += r.bytes;
+            event_pool.push_back(r.start); event_pool.push_back(r.stop);
+        }
+        profile_records.clear();
+        return ST_OK;
+    }
+
+    // ---- render (camera_controller.rs:87-174)
+    int render(CameraState& c, float4* out, hipStream_t stream) {
+        if (!has_device) return fail(ST_ERR_NO_DEVICE, "render_camera on a host-only engine");
+        if (!scene_uploaded) return fail(ST_ERR_INVALID_ARGUMENT, "st_tick must precede st_render_camera");
+        ST_HIP(hipSetDevice(device));
+        const bool alt = c.frame % 2u == 1u;
+        KArgs a{};
+        a.cam = c.curr; a.prev_cam = c.prev;
+        a.bvh = static_cast<const float4*>(d_bvh.ptr); a.tri_geo = static_cast<const float4*>(d_tri_geo.ptr); a.tri_attr = static_cast<const float4*>(d_tri_attr.ptr);
+        a.materials = static_cast<const GpuMaterial*>(d_materials.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
+        a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr);
+        a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
+        a.bvh_len = (uint32_t)bvh_stream.size(); a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
+        a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
+        a.sun_dir[0] = sun_dir_.x; a.sun_dir[1] = sun_dir_.y; a.sun_dir[2] = sun_dir_.z;
+        auto P = [&](int id) { return c.plane[id]; };
+        a.g0 = P(alt ? ST_BUF_PRIM_GBUFFER_D0_B : ST_BUF_PRIM_GBUFFER_D0_A); a.pg0 = P(alt ? ST_BUF_PRIM_GBUFFER_D0_A : ST_BUF_PRIM_GBUFFER_D0_B);
+        a.g1 = P(alt ? ST_BUF_PRIM_GBUFFER_D1_B : ST_BUF_PRIM_GBUFFER_D1_A); a.pg1 = P(alt ? ST_BUF_PRIM_GBUFFER_D1_A : ST_BUF_PRIM_GBUFFER_D1_B);
+        a.sm = P(alt ? ST_BUF_PRIM_SURFACE_MAP_B : ST_BUF_PRIM_SURFACE_MAP_A); a.psm = P(alt ? ST_BUF_PRIM_SURFACE_MAP_A : ST_BUF_PRIM_SURFACE_MAP_B);
+        a.reprojection = P(ST_BUF_REPROJECTION_MAP); a.velocity = P(ST_BUF_VELOCITY_MAP);
+        for (int i = 0; i < 3; i++) a.di_res[i] = P(ST_BUF_DI_RESERVOIRS_0 + i);
+        a.di_diff_samples = P(ST_BUF_DI_DIFF_SAMPLES); a.di_diff_prev_colors = P(ST_BUF_DI_DIFF_PREV_COLORS); a.di_diff_curr_colors = P(ST_BUF_DI_DIFF_CURR_COLORS);
+        a.di_diff_moments = P(alt ? ST_BUF_DI_DIFF_MOMENTS_B : ST_BUF_DI_DIFF_MOMENTS_A); a.di_diff_prev_moments = P(alt ? ST_BUF_DI_DIFF_MOMENTS_A : ST_BUF_DI_DIFF_MOMENTS_B);
+        a.di_diff_stash = P(ST_BUF_DI_DIFF_STASH); a.di_spec_samples = P(ST_BUF_DI_SPEC_SAMPLES);
+        a.gi_d0 = P(ST_BUF_GI_D0); a.gi_d1 = P(ST_BUF_GI_D1); a.gi_d2 = P(ST_BUF_GI_D2);
+        for (int i = 0; i < 4; i++) a.gi_res[i] = P(ST_BUF_GI_RESERVOIRS_0 + i);
+        a.gi_diff_samples = P(ST_BUF_GI_DIFF_SAMPLES); a.gi_diff_prev_colors = P(ST_BUF_GI_DIFF_PREV_COLORS); a.gi_diff_curr_colors = P(ST_BUF_GI_DIFF_CURR_COLORS);
+        a.gi_diff_moments = P(alt ? ST_BUF_GI_DIFF_MOMENTS_B : ST_BUF_GI_DIFF_MOMENTS_A); a.gi_diff_prev_moments = P(alt ? ST_BUF_GI_DIFF_MOMENTS_A : ST_BUF_GI_DIFF_MOMENTS_B);
+        a.gi_diff_stash = P(ST_BUF_GI_DIFF_STASH); a.gi_spec_samples = P(ST_BUF_GI_SPEC_SAMPLES);
+        a.ref_hits = P(ST_BUF_REF_HITS); a.ref_rays = P(ST_BUF_REF_RAYS); a.ref_colors = P(ST_BUF_REF_COLORS);
+        a.dbg_used_memory = reinterpret_cast<uint32_t*>(P(ST_BUF_DBG_USED_MEMORY));
+        a.width = c.desc.width; a.height = c.desc.height; a.row0 = c.row0; a.row1 = c.row1;
+        a.frame = c.frame;
+
+        const double rows = (double)(c.row1 - c.row0);
+        auto run = [&](int slot, auto&& launch) {
+            const KernelInfo& ki = kernel_info(slot);
+            const double units = rows * (ki.half ? (double)(((c.desc.width + 7u) / 8u / 2u) * 8u) : (double)c.desc.width);
+            a.ray_counter = c.counters + 2 * slot;
+            Scope scope(this, stream, slot, units * ki.bytes_per_unit);
+            launch();
+        };
+        auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
+        const uint32_t mode = c.desc.mode;
+        if (mode == ST_MODE_BVH_HEATMAP) {
+            run(KS_BVH_HEATMAP, [&] { launch_bvh_heatmap(a, stream); });
+        } else if (mode == ST_MODE_REFERENCE) {
+            for (uint32_t d = 0; d <= c.desc.depth; d++) {
+                run(KS_REF_TRACING, [&] { launch_ref_tracing(a, d, stream); });
+                run(KS_REF_SHADING, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + d), d, stream); });
+            }
+            run(KS_REF_SHADING, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + 255u), 255u, stream); });
+        } else {
+            const bool needs_di = mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE || mode == ST_MODE_DI_SPECULAR;
+            const bool needs_gi = mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE || mode == ST_MODE_GI_SPECULAR;
+            run(KS_PRIM_VISIBILITY, [&] { launch_prim_visibility(a, stream); });
+            if (!instances.empty()) {
+                run(KS_FRAME_REPROJECTION, [&] { launch_frame_reprojection(a, stream); });
+                if (needs_di) {
+                    run(KS_DI_SAMPLING, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), stream); });
+                    run(KS_DI_TEMPORAL, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), stream); });
+                    run(KS_DI_SPATIAL_PICK, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), stream); });
+                    run(KS_DI_SPATIAL_TRACE, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, stream); });
+                    run(KS_DI_SPATIAL_SAMPLE, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), stream); });
+                    run(KS_DI_RESOLVING, [&] { launch_di_resolving(a, stream); });
+                }
+                if (needs_gi) {
+                    uint32_t source;
+                    const bool tracing = c.frame % 6u < 4u;
+                    run(KS_GI_REPROJECTION, [&] { launch_gi_reprojection(a, stream); });
+                    auto sampling = [&] {
+                        run(KS_GI_SAMPLING_A, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), stream); });
+                        run(KS_GI_SAMPLING_B, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), stream); });
+                    };
+                    if (tracing) {
+                        if (c.frame % 2u == 0u) sampling();
+                        run(KS_GI_TEMPORAL, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), stream); });
+                        if (c.frame % 2u == 1u) {
+                            run(KS_GI_SPATIAL_PICK, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), stream); });
+                            run(KS_GI_SPATIAL_TRACE, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, stream); });
+                            run(KS_GI_SPATIAL_SAMPLE, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), stream); });
+                            source = 1;
+                        } else source = 0;
+                    } else {
+                        sampling();
+                        run(KS_GI_TEMPORAL, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), stream); });
+                        source = 0;
+                    }
+                    const uint32_t pseed = seed(SEED_GI_PREVIEW);  // one seed for both preview passes (passes/gi_preview_resampling.rs:60-74)
+                    run(KS_GI_PREVIEW, [&] { launch_gi_preview(a, pseed, 0u, source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], stream); });
+                    run(KS_GI_PREVIEW, [&] { launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], stream); });
+                    run(KS_GI_RESOLVING, [&] { launch_gi_resolving(a, source, stream); });
+                }
+            }
+            if (c.desc.denoise != 0u) {
+                run(KS_DENOISE_REPROJECT, [&] { launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, stream); });
+                run(KS_DENOISE_REPROJECT, [&] { launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, stream); });
+                run(KS_DENOISE_VARIANCE, [&] { launch_denoise_variance(a, stream); });
+                // ping-pong (passes/frame_denoising.rs:87-110): stash -> prev -> stash -> curr -> stash -> curr
+                float4* di[3] = {a.di_diff_stash, a.di_diff_prev_colors, a.di_diff_curr_colors};
+                float4* gi[3] = {a.gi_diff_stash, a.gi_diff_prev_colors, a.gi_diff_curr_colors};
+                const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
+                for (uint32_t nth = 0; nth < 5; nth++)
+                    run(KS_DENOISE_WAVELET, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], stream); });
+            }
+        }
+        if (out) {
+            const bool dn = c.desc.denoise != 0u;
+            const float4* di_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
+            const float4* gi_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
+            run(KS_COMPOSITION, [&] { launch_composition(a, mode, di_diff, gi_diff, out, stream); });
+        }
+        ST_HIP(hipGetLastError());
+        return ST_OK;
+    }
+};
+
+}  // namespace st
+
+using namespace st;
+static Engine* E(StEngine* e) { return reinterpret_cast<Engine*>(e); }
+#define ST_REQUIRE(cond, msg) do { if (!(cond)) return fail(ST_ERR_INVALID_ARGUMENT, msg); } while (0)
+
+extern "C" {
+
+const char* st_last_error(void) { return g_last_error.c_str(); }
+
+int st_engine_create(int device_ordinal, StEngine** out) {
+    ST_REQUIRE(out, "out is NULL");
+    std::unique_ptr<Engine> e(new Engine());
+    if (device_ordinal >= 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= device_ordinal)
+            return fail(ST_ERR_NO_DEVICE, "no HIP device with that ordinal (this library has no CPU rendering path)");
+        ST_HIP(hipSetDevice(device_ordinal));
+        e->device = device_ordinal; e->has_device = true;
+    }
+    *out = reinterpret_cast<StEngine*>(e.release());
+    return ST_OK;
+}
+void st_engine_destroy(StEngine* e) { delete E(e); }
+
+int st_mesh_insert(StEngine* e, StHandle id, const StMeshTriangle* t, size_t count) {
+    ST_REQUIRE(e && (t || count == 0), "null argument");
+    if (count == 0) return fail(ST_ERR_EMPTY_MESH, "mesh contains no triangles");
+    E(e)->meshes[id].assign(t, t + count);
+    return ST_OK;
+}
+int st_mesh_remove(StEngine* e, StHandle id) { ST_REQUIRE(e, "null engine"); E(e)->meshes.erase(id); return ST_OK; }
+
+int st_material_insert(StEngine* e, StHandle id, const StMaterial* m) {
+    ST_REQUIRE(e && m, "null argument");
+    Engine* en = E(e);
+    auto it = en->material_slot.find(id);
+    if (it != en->material_slot.end()) en->materials[it->second] = *m;
+    else {
+        size_t b, end_;
+        uint32_t slot;
+        if (en->material_free.take(1, &b, &end_)) slot = (uint32_t)b;  // materials.rs:48-50 (the slot keeps its previous contents)
+        else { en->materials.push_back(*m); slot = (uint32_t)en->materials.size() - 1u; }
+        en->material_slot[id] = slot;
+    }
+    en->materials_dirty = true;
+    return ST_OK;
+}
+int st_material_has(StEngine* e, StHandle id) { return e && E(e)->material_slot.count(id) ? 1 : 0; }
+int st_material_remove(StEngine* e, StHandle id) {
+    ST_REQUIRE(e, "null engine");
+    Engine* en = E(e);
+    auto it = en->material_slot.find(id);
+    if (it == en->material_slot.end()) return ST_OK;
+    en->material_free.give(it->second, it->second);  // `give(id..id)`: an empty range, as in materials.rs:74
+    en->material_slot.erase(it);
+    en->materials_dirty = true;
+    return ST_OK;
+}
+
+int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) {
+    ST_REQUIRE(e && rgba && w && h && id, "bad image");
+    Engine* en = E(e);
+    const uint32_t kAtlasW = 2048, kAtlasMaxH = 8192;
+    if (w > kAtlasW) return fail(ST_ERR_ATLAS_FULL, "image wider than the atlas");
+    auto it = en->images.find(id);
+    Engine::ImageRec rec;
+    if (it != en->images.end() && it->second.w == w && it->second.h == h) rec = it->second;
+    else {
+        if (en->shelf_x + w > kAtlasW) { en->shelf_x = 0; en->shelf_y += en->shelf_h; en->shelf_h = 0; }
+        if (en->shelf_y + h > kAtlasMaxH) return fail(ST_ERR_ATLAS_FULL, "no more space in the atlas");
+        rec = {en->shelf_x, en->shelf_y, w, h};
+        en->shelf_x += w; en->shelf_h = std::max(en->shelf_h, h);
+    }
+    const uint32_t need_h = rec.y + h;
+    if (en->atlas_w == 0) en->atlas_w = kAtlasW;
+    if (need_h > en->atlas_h) {
+        // grow in 256-row steps; rects are stored in texels, so existing materials stay valid after a rebuild
+        en->atlas_h = (need_h + 255u) & ~255u;
+        en->atlas.resize((size_t)en->atlas_w * en->atlas_h * 4, 0);
+    }
+    for (uint32_t y = 0; y < h; y++) memcpy(&en->atlas[((size_t)(rec.y + y) * en->atlas_w + rec.x) * 4], rgba + (size_t)y * w * 4, (size_t)w * 4);
+    en->images[id] = rec;
+    en->atlas_dirty = true; en->materials_dirty = true;
+    return ST_OK;
+}
+int st_image_remove(StEngine* e, StHandle id) { ST_REQUIRE(e, "null engine"); E(e)->images.erase(id); E(e)->materials_dirty = true; return ST_OK; }
+
+int st_instance_insert(StEngine* e, StHandle id, StHandle mesh, StHandle material, const float xform[12]) {
+    ST_REQUIRE(e && xform, "null argument");
+    Engine* en = E(e);
+    const Affine x = affine_from12(xform);
+    for (auto& r : en->instances)
+        if (r.id == id) { r.prev_xform = r.xform; r.mesh = mesh; r.material = material; r.xform = x; r.xform_inv = affine_inverse(x); r.dirty = true; en->instances_dirty = true; return ST_OK; }
+    en->instances.push_back({id, mesh, material, x, affine_inverse(x), x, true});
+    en->instances_dirty = true;
+    return ST_OK;
+}
+int st_instance_remove(StEngine* e, StHandle id) {
+    ST_REQUIRE(e, "null engine");
+    Engine* en = E(e);
+    for (size_t i = 0; i < en->instances.size(); i++)
+        if (en->instances[i].id == id) { en->instances.erase(en->instances.begin() + i); en->instances_dirty = true; break; }
+    en->drop_instance_triangles(id);
+    return ST_OK;
+}
+int st_light_insert(StEngine* e, StHandle id, const StLight* l) { ST_REQUIRE(e && l, "null argument"); E(e)->insert_light(id, *l); return ST_OK; }
+int st_light_remove(StEngine* e, StHandle id) { ST_REQUIRE(e, "null engine"); E(e)->remove_light(id); return ST_OK; }
+int st_sun_update(StEngine* e, float azimuth, float altitude) { ST_REQUIRE(e, "null engine"); E(e)->sun_azimuth = azimuth; E(e)->sun_altitude = altitude; E(e)->sun_dirty = true; return ST_OK; }
+
+int st_camera_create(StEngine* e, const StCamera* c, StHandle* out) {
+    ST_REQUIRE(e && c && out && c->width && c->height, "bad camera");
+    Engine* en = E(e);
+    std::unique_ptr<CameraState> s(new CameraState());
+    s->desc = *c;
+    s->curr = Engine::serialize_camera(*c); s->prev = s->curr;
+    const int rc = en->allocate_camera(*s);
+    if (rc) return rc;
+    *out = en->next_camera++;
+    en->cameras[*out] = std::move(s);
+    return ST_OK;
+}
+int st_camera_update(StEngine* e, StHandle h, const StCamera* c) {
+    ST_REQUIRE(e && c && c->width && c->height, "bad camera");
+    Engine* en = E(e);
+    auto it = en->cameras.find(h);
+    if (it == en->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    CameraState& s = *it->second;
+    const bool invalidated = s.desc.mode != c->mode || s.desc.denoise != c->denoise || s.desc.depth != c->depth || s.desc.width != c->width || s.desc.height != c->height;
+    s.desc = *c;
+    s.prev = s.curr;
+    s.curr = Engine::serialize_camera(*c);
+    if (invalidated) { if (en->has_device) (void)hipDeviceSynchronize(); return en->allocate_camera(s); }  // camera.rs:17-48: buffers are rebuilt
+    return ST_OK;
+}
+int st_camera_delete(StEngine* e, StHandle h) {
+    ST_REQUIRE(e, "null engine");
+    Engine* en = E(e);
+    auto it = en->cameras.find(h);
+    if (it == en->cameras.end()) return ST_OK;
+    if (en->has_device) { (void)hipDeviceSynchronize(); Engine::release_camera(*it->second); }
+    en->cameras.erase(it);
+    return ST_OK;
+}
+int st_camera_set_rows(StEngine* e, StHandle h, uint32_t y0, uint32_t y1) {
+    ST_REQUIRE(e, "null engine");
+    auto it = E(e)->cameras.find(h);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    CameraState& s = *it->second;
+    if (y0 == 0 && y1 == 0) { y1 = s.desc.height; }
+    ST_REQUIRE(y0 < y1 && y1 <= s.desc.height, "bad row window");
+    s.row0 = y0; s.row1 = y1;
+    return ST_OK;
+}
+
+int st_tick(StEngine* e, void* stream) { ST_REQUIRE(e, "null engine"); return E(e)->tick(static_cast<hipStream_t>(stream)); }
+int st_render_camera(StEngine* e, StHandle h, void* out, void* stream) {
+    ST_REQUIRE(e, "null engine");
+    auto it = E(e)->cameras.find(h);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    return E(e)->render(*it->second, static_cast<float4*>(out), static_cast<hipStream_t>(stream));
+}
+
+int st_set_seed(StEngine* e, uint64_t seed) { ST_REQUIRE(e, "null engine"); E(e)->base_seed = seed; return ST_OK; }
+int st_set_blue_noise(StEngine* e, const uint8_t* rgba, size_t bytes) {
+    ST_REQUIRE(e && rgba && bytes == 256 * 256 * 4, "blue noise must be 256x256 RGBA8");
+    E(e)->blue_noise.assign(rgba, rgba + bytes); E(e)->blue_noise_dirty = true;
+    return ST_OK;
+}
+int st_set_atmosphere_luts(StEngine* e, const float* t, const float* s) {
+    ST_REQUIRE(e && t && s, "null argument");
+    memcpy(E(e)->transmittance_lut.data(), t, sizeof(float4) * 256 * 64);
+    memcpy(E(e)->sky_lut.data(), s, sizeof(float4) * 256 * 256);
+    E(e)->luts_dirty = true;
+    return ST_OK;
+}
+
+int st_camera_read_buffer(StEngine* e, StHandle h, int id, void* out, size_t capacity, size_t* written) {
+    ST_REQUIRE(e && id >= 0 && id < ST_BUF_COUNT, "bad buffer id");
+    Engine* en = E(e);
+    auto it = en->cameras.find(h);
+    if (it == en->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "host-only engine has no camera buffers");
+    CameraState& c = *it->second;
+    if (written) *written = c.plane_bytes[id];
+    if (!out) return ST_OK;
+    ST_REQUIRE(capacity >= c.plane_bytes[id], "buffer too small");
+    ST_HIP(hipSetDevice(en->device));
+    ST_HIP(hipDeviceSynchronize());
+    ST_HIP(hipMemcpy(out, c.plane[id], c.plane_bytes[id], hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+int st_camera_ray_count(StEngine* e, StHandle h, uint64_t* out, int reset) {
+    ST_REQUIRE(e && out, "null argument");
+    Engine* en = E(e);
+    auto it = en->cameras.find(h);
+    if (it == en->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "host-only engine");
+    unsigned long long host[2 * KS_COUNT];
+    ST_HIP(hipSetDevice(en->device));
+    ST_HIP(hipDeviceSynchronize());
+    ST_HIP(hipMemcpy(host, it->second->counters, sizeof(host), hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (int i = 0; i < KS_COUNT; i++) total += host[2 * i];
+    *out = total;
+    if (reset) { ST_HIP(hipMemset(it->second->counters, 0, sizeof(host))); memset(it->second->profiled_traversal_bytes, 0, sizeof(it->second->profiled_traversal_bytes)); ST_HIP(hipDeviceSynchronize()); }
+    return ST_OK;
+}
+int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written) {
+    ST_REQUIRE(e, "null engine");
+    Engine* en = E(e);
+    const void* p; size_t bytes;
+    switch (what) {
+        case 0: p = en->bvh_stream.data(); bytes = en->bvh_stream.size() * sizeof(float4); break;
+        case 1: p = en->triangles.data(); bytes = en->triangles.size() * sizeof(HostTriangle); break;
+        case 2: p = en->gpu_lights.data(); bytes = en->gpu_lights.size() * sizeof(GpuLight); break;
+        case 3: p = en->gpu_materials.data(); bytes = en->gpu_materials.size() * sizeof(GpuMaterial); break;
+        default: return fail(ST_ERR_INVALID_ARGUMENT, "unknown scene buffer");
+    }
+    if (written) *written = bytes;
+    if (!out) return ST_OK;
+    ST_REQUIRE(capacity >= bytes, "buffer too small");
+    if (bytes) memcpy(out, p, bytes);
+    return ST_OK;
+}
+int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame) {
+    ST_REQUIRE(e && light_count && next_frame, "null argument");
+    *light_count = E(e)->light_count; *next_frame = E(e)->frame;
+    return ST_OK;
+}
+
+int st_profile_enable(StEngine* e, int enabled) { ST_REQUIRE(e, "null engine"); E(e)->profiling = enabled != 0; return ST_OK; }
+int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* count, int reset) {
+    ST_REQUIRE(e && out && count, "null argument");
+    Engine* en = E(e);
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "host-only engine");
+    ST_HIP(hipSetDevice(en->device));
+    const int rc = en->drain_profile();
+    if (rc) return rc;
+    // traversal bytes (the reference's used_memory, summed on the device) join the screen-space bytes per kernel
+    ST_HIP(hipDeviceSynchronize());
+    for (auto& kv : en->cameras) {
+        CameraState& c = *kv.second;
+        unsigned long long host[2 * KS_COUNT];
+        ST_HIP(hipMemcpy(host, c.counters, sizeof(host), hipMemcpyDeviceToHost));
+        for (int i = 0; i < KS_COUNT; i++) {
+            const unsigned long long total = host[2 * i + 1];
+            if (total >= c.profiled_traversal_bytes[i]) en->profile_totals[i].algorithmic_bytes += (double)(total - c.profiled_traversal_bytes[i]);
+            c.profiled_traversal_bytes[i] = total;
+        }
+    }
+    size_t n = 0;
+    for (int i = 0; i < KS_COUNT && n < capacity; i++) {
+        if (en->profile_totals[i].launches == 0) continue;
+        out[n] = en->profile_totals[i];
+        n++;
+    }
+    *count = n;
+    if (reset) en->reset_profile_totals();
+    return ST_OK;
+}
+
+}  // extern "C"

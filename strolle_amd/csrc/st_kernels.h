@@ -1,0 +1,65 @@
+// st_kernels.h — launch interface between the host engine (st_engine.cpp) and the HIP kernels.
+// Each launcher enqueues exactly one kernel on `stream`; `KArgs` travels by value in the kernarg segment.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "st_types.h"
+
+namespace st {
+
+// Kernel slots: index into the per-camera counter array (2 x u64 per slot: rays, traversal bytes) and into the
+// profiler's table. `bytes_per_unit` = compulsory screen-space bytes one launch unit (pixel or 2x1 cell) reads +
+// writes through the planes the reference binds for that pass (neighbour taps assumed cache-served).
+enum KernelSlot {
+    KS_BVH_HEATMAP, KS_REF_TRACING, KS_REF_SHADING, KS_PRIM_VISIBILITY, KS_FRAME_REPROJECTION,
+    KS_DI_SAMPLING, KS_DI_TEMPORAL, KS_DI_SPATIAL_PICK, KS_DI_SPATIAL_TRACE, KS_DI_SPATIAL_SAMPLE, KS_DI_RESOLVING,
+    KS_GI_REPROJECTION, KS_GI_SAMPLING_A, KS_GI_SAMPLING_B, KS_GI_TEMPORAL, KS_GI_SPATIAL_PICK, KS_GI_SPATIAL_TRACE,
+    KS_GI_SPATIAL_SAMPLE, KS_GI_PREVIEW, KS_GI_RESOLVING, KS_DENOISE_REPROJECT, KS_DENOISE_VARIANCE, KS_DENOISE_WAVELET,
+    KS_COMPOSITION, KS_COUNT
+};
+struct KernelInfo { const char* name; float bytes_per_unit; bool half; };
+inline const KernelInfo& kernel_info(int slot) {
+    static const KernelInfo k[KS_COUNT] = {
+        {"bvh_heatmap", 16.f, false},        {"ref_tracing", 64.f, false},         {"ref_shading", 128.f, false},
+        {"prim_visibility", 64.f, false},    {"frame_reprojection", 64.f, false},  {"di_sampling", 68.f, false},
+        {"di_temporal", 176.f, false},       {"di_spatial_pick", 128.f, true},     {"di_spatial_trace", 48.f, false},
+        {"di_spatial_sample", 192.f, true},  {"di_resolving", 128.f, false},       {"gi_reprojection", 176.f, false},
+        {"gi_sampling_a", 80.f, true},       {"gi_sampling_b", 144.f, true},       {"gi_temporal", 272.f, false},
+        {"gi_spatial_pick", 160.f, true},    {"gi_spatial_trace", 48.f, false},    {"gi_spatial_sample", 352.f, true},
+        {"gi_preview", 160.f, false},        {"gi_resolving", 256.f, false},       {"denoise_reproject", 112.f, false},
+        {"denoise_variance", 112.f, false},  {"denoise_wavelet", 84.f, false},     {"composition", 112.f, false},
+    };
+    return k[slot];
+}
+
+// ray-tracing passes
+void launch_bvh_heatmap(const KArgs& a, hipStream_t s);
+void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s);
+void launch_ref_shading(const KArgs& a, uint32_t seed, uint32_t depth, hipStream_t s);
+void launch_prim_visibility(const KArgs& a, hipStream_t s);
+void launch_frame_reprojection(const KArgs& a, hipStream_t s);
+// ReSTIR DI
+void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s);
+void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_di_resolving(const KArgs& a, hipStream_t s);
+// ReSTIR GI
+void launch_gi_reprojection(const KArgs& a, hipStream_t s);
+void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_gi_temporal(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_gi_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s);
+void launch_gi_resolving(const KArgs& a, uint32_t source, hipStream_t s);
+// SVGF + composition
+void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const float4* prev_moments, const float4* samples, float4* colors,
+                              float4* moments, hipStream_t s);
+void launch_denoise_variance(const KArgs& a, hipStream_t s);
+void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
+                            float4* gi_out, hipStream_t s);
+void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out, hipStream_t s);
+
+}  // namespace st

@@ -1,0 +1,68 @@
+// st_types.h — PODs shared by the host engine and the kernels (device buffer layouts).
+#pragma once
+#include "st_math.h"
+
+namespace st {
+
+// strolle-gpu/src/camera.rs:9-17 (160 B uniform)
+struct GpuCamera {
+    M4 projection_view;
+    M4 ndc_to_world;
+    float4 origin;
+    float4 screen;
+};
+static_assert(sizeof(GpuCamera) == 160, "Camera uniform is 160 B");
+
+// strolle-gpu/src/material.rs:8-23 (112 B)
+struct GpuMaterial {
+    float4 base_color, base_color_texture, emissive, emissive_texture;
+    float roughness, metallic, reflectance, ior;
+    float4 metallic_roughness_texture, normal_map_texture;
+};
+static_assert(sizeof(GpuMaterial) == 112, "Material is 112 B");
+
+// strolle-gpu/src/light.rs:12-43 (112 B)
+struct GpuLight { float4 d0, d1, d2, d3, prev_d0, prev_d1, prev_d2; };
+static_assert(sizeof(GpuLight) == 112, "Light is 112 B");
+
+// The reference's 144-B AoS triangle (strolle-gpu/src/triangle.rs:9-21), kept on the HOST only (debug
+// read-back + BVH build). The device gets two split arrays instead:
+//   tri_geo [3 float4 / triangle]: (v0.xyz, 0) (v1-v0, 0) (v2-v0, 0)      — all a hit test reads (48 B)
+//   tri_attr[4 float4 / triangle]: (n0, uv0.x) (n1, uv0.y) (n2, uv1.x) (uv1.y, uv2.x, uv2.y, 0)
+// fetched once per ray, for the winning triangle only.
+struct HostTriangle { float4 d0, d1, d2, d3, d4, d5, d6, d7, d8; };
+static_assert(sizeof(HostTriangle) == 144, "Triangle is 144 B");
+
+constexpr int kBvhStackSize = 24;  // strolle-gpu/src/lib.rs:76
+constexpr uint32_t kLightIdSky = 0xffffffffu;
+
+// Everything a per-pixel kernel can touch, passed by value as the kernel argument (scalar loads).
+struct KArgs {
+    GpuCamera cam, prev_cam;
+    // engine-level bindings
+    const float4* bvh; const float4* tri_geo; const float4* tri_attr;
+    const GpuMaterial* materials; const GpuLight* lights;
+    const uchar4* atlas; const uchar4* blue_noise;
+    const float4* transmittance_lut; const float4* sky_lut;
+    uint32_t bvh_len, n_lights_buf, light_count, atlas_w, atlas_h;
+    float sun_altitude;
+    float sun_dir[3];
+    // per-camera planes (A/B resolved for this frame)
+    float4 *g0, *g1, *sm;                // prim_gbuffer_d0/d1, prim_surface_map (curr)
+    const float4 *pg0, *pg1, *psm;       // previous frame's
+    float4 *reprojection, *velocity;
+    float4* di_res[3];
+    float4 *di_diff_samples, *di_diff_prev_colors, *di_diff_curr_colors, *di_diff_moments, *di_diff_stash, *di_spec_samples;
+    const float4* di_diff_prev_moments;
+    float4 *gi_d0, *gi_d1, *gi_d2;
+    float4* gi_res[4];
+    float4 *gi_diff_samples, *gi_diff_prev_colors, *gi_diff_curr_colors, *gi_diff_moments, *gi_diff_stash, *gi_spec_samples;
+    const float4* gi_diff_prev_moments;
+    float4 *ref_hits, *ref_rays, *ref_colors;
+    uint32_t* dbg_used_memory;
+    unsigned long long* ray_counter;
+    uint32_t width, height, row0, row1;  // [row0,row1): rows this launch covers (multi-GPU tiling)
+    uint32_t frame;
+};
+
+}  // namespace st

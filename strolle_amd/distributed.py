@@ -1,0 +1,73 @@
+"""Tile-parallel rendering across the GPUs of one node: one process per GPU, row-band partition of the
+frame, one collective per frame (all-gather of the final HDR buffer over RCCL/xGMI).
+
+The renderer's per-pixel passes are independent across ranks; the only exchange step is the gather of the
+composed RGBA32F bands. The scene is replicated (every rank builds the same engine state deterministically).
+
+Reference / BvhHeatmap modes read nothing outside their own pixel, so a band is bit-identical to the same rows
+of a single-GPU frame (RNG is keyed on absolute pixel coordinates, strolle-gpu/src/noise/white.rs:15-19).
+Image mode has neighbour taps (spatial resampling radius 128 px, wavelets, reprojection); each rank renders
+its band plus `apron` extra rows on both sides so those taps find valid data, and only the band is gathered.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+
+def weak_scaling_frame(base_size: Tuple[int, int], world_size: int) -> Tuple[int, int]:
+    """Frame size whose pixel count is world_size x the single-GPU workload: width doubles from 4 ranks on,
+    height takes the rest (1: 1920x1080, 2: 1920x2160, 4: 3840x2160 — BASELINE.json config 4 —, 8: 3840x4320)."""
+    w, h = base_size
+    wx = 2 if world_size >= 4 and world_size % 2 == 0 else 1
+    return w * wx, h * (world_size // wx)
+
+
+def band_for_rank(height: int, world_size: int, rank: int, align: int = 8) -> Tuple[int, int]:
+    """Rows [y0, y1) owned by `rank`: contiguous bands, multiples of the 8-row tile height except the last."""
+    tiles = (height + align - 1) // align
+    per = tiles // world_size
+    extra = tiles % world_size
+    t0 = rank * per + min(rank, extra)
+    t1 = t0 + per + (1 if rank < extra else 0)
+    return min(t0 * align, height), min(t1 * align, height)
+
+
+def render_window(height: int, band: Tuple[int, int], apron: int) -> Tuple[int, int]:
+    """Rows a rank actually renders: its band widened by `apron` rows (clamped, kept on 8-row tile boundaries)."""
+    y0 = max(0, (band[0] - apron) // 8 * 8)
+    y1 = min(height, (band[1] + apron + 7) // 8 * 8)
+    return y0, y1
+
+
+def gather_frame(local_frame, height: int, width: int, world_size: int, rank: int, group=None):
+    """All-gather the owned band of every rank into a full frame (torch tensors, any backend).
+
+    `local_frame` is the rank's full-size [H, W, 4] float32 tensor of which only its band is meaningful.
+    Bands may differ by one tile row, so they are padded to the largest band for the collective."""
+    import torch
+    import torch.distributed as dist
+
+    bands = [band_for_rank(height, world_size, r) for r in range(world_size)]
+    max_rows = max(b[1] - b[0] for b in bands)
+    y0, y1 = bands[rank]
+    send = torch.zeros((max_rows, width, 4), dtype=local_frame.dtype, device=local_frame.device)
+    send[: y1 - y0] = local_frame[y0:y1]
+    recv = torch.empty((world_size, max_rows, width, 4), dtype=local_frame.dtype, device=local_frame.device)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group) if hasattr(dist, "all_gather_into_tensor") and local_frame.is_cuda \
+        else dist.all_gather(list(recv.unbind(0)), send, group=group)
+    out = torch.empty((height, width, 4), dtype=local_frame.dtype, device=local_frame.device)
+    for r, (b0, b1) in enumerate(bands):
+        out[b0:b1] = recv[r, : b1 - b0]
+    return out
+
+
+def assemble_bands_numpy(bands_data, height: int, width: int) -> np.ndarray:
+    """Host-side reference of gather_frame for tests: bands_data[r] is rank r's full-size frame."""
+    world_size = len(bands_data)
+    out = np.zeros((height, width, 4), np.float32)
+    for r in range(world_size):
+        y0, y1 = band_for_rank(height, world_size, r)
+        out[y0:y1] = bands_data[r][y0:y1]
+    return out

@@ -1,0 +1,163 @@
+"""GPU parity tests: every buffer the HIP path writes must equal the CPU oracle's bit for bit
+(NaN == NaN), frame after frame, through the C ABI. Sizes are chosen so the oracle runs in seconds."""
+import numpy as np
+import pytest
+
+from oracle_binding import OracleEngine
+from parity import assert_bits_equal, bits_equal_mask
+from strolle_amd import Buffer, CameraMode, Engine, scenes
+
+pytestmark = pytest.mark.gpu
+
+ALL_FLOAT_BUFFERS = [b for b in Buffer if b != Buffer.DBG_USED_MEMORY]
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; the product has no CPU fallback"
+    return torch
+
+
+def _pair(build, size, mode, depth=0, denoise=True, seed=11, camera_fn=scenes.cornell_camera):
+    prod, orac = Engine(device=0), OracleEngine()
+    for e in (prod, orac):
+        build(e)
+        e.set_seed(seed)
+    desc = camera_fn(size, mode, denoise=denoise, depth=depth)
+    return prod, orac, desc, prod.create_camera(desc), orac.create_camera(desc)
+
+
+def _step(torch, prod, orac, desc, cp, co, out):
+    prod.update_camera(cp, desc); orac.update_camera(co, desc)
+    prod.tick(); orac.tick()
+    prod.render_camera(cp, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ref = orac.render_camera(co)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), ref
+
+
+def _compare_all(prod, orac, cp, co, frame, buffers=ALL_FLOAT_BUFFERS):
+    for b in buffers:
+        assert_bits_equal(prod.read_buffer(cp, b), orac.read_buffer(co, b), f"frame {frame} buffer {b.name}")
+
+
+@pytest.mark.parametrize("scene,size", [("cornell", (256, 256)), ("cornell", (333, 200)), ("soup", (200, 120)), ("dungeon", (320, 180))])
+def test_bvh_heatmap_used_memory_bit_exact(scene, size):
+    torch = _torch()
+    build = {"cornell": scenes.build_cornell, "soup": lambda e: scenes.build_random_soup(e, 3000, seed=5), "dungeon": scenes.build_dungeon}[scene]
+    cam = scenes.dungeon_camera if scene == "dungeon" else scenes.cornell_camera
+    prod, orac, desc, cp, co = _pair(build, size, CameraMode.BVH_HEATMAP, camera_fn=cam)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    img, ref = _step(torch, prod, orac, desc, cp, co, out)
+    got = prod.read_buffer(cp, Buffer.DBG_USED_MEMORY); want = orac.read_buffer(co, Buffer.DBG_USED_MEMORY)
+    assert np.array_equal(got, want), f"{(got != want).sum()} heatmap integers differ"
+    assert_bits_equal(img, ref, "heatmap colours")
+    assert prod.ray_count(cp) == orac.ray_count(co) == size[0] * size[1]
+
+
+@pytest.mark.parametrize("scene", ["cornell", "soup"])
+def test_reference_mode_bit_exact(scene):
+    torch = _torch()
+    build = scenes.build_cornell if scene == "cornell" else (lambda e: scenes.build_random_soup(e, 2000, seed=9))
+    size = (192, 128)
+    prod, orac, desc, cp, co = _pair(build, size, CameraMode.REFERENCE, depth=2)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(4):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame, [Buffer.REF_HITS, Buffer.REF_RAYS, Buffer.REF_COLORS])
+        assert_bits_equal(img, ref, f"reference frame {frame}")
+    assert prod.ray_count(cp) == orac.ray_count(co)
+
+
+@pytest.mark.parametrize("scene,size,frames", [("cornell", (160, 96), 14), ("cornell", (203, 77), 7), ("soup", (128, 96), 8)])
+def test_image_mode_every_buffer_bit_exact(scene, size, frames):
+    """ReSTIR DI + GI + SVGF over more than two 6-frame GI cycles: all 35 planes after every frame."""
+    torch = _torch()
+    build = scenes.build_cornell if scene == "cornell" else (lambda e: scenes.build_random_soup(e, 1500, seed=2, n_lights=5))
+    prod, orac, desc, cp, co = _pair(build, size, CameraMode.IMAGE)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(frames):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"image frame {frame}")
+    assert prod.ray_count(cp) == orac.ray_count(co)
+
+
+@pytest.mark.parametrize("mode", [CameraMode.DI_DIFFUSE, CameraMode.DI_SPECULAR, CameraMode.GI_DIFFUSE, CameraMode.GI_SPECULAR])
+@pytest.mark.parametrize("denoise", [True, False])
+def test_partial_modes_bit_exact(mode, denoise):
+    torch = _torch()
+    size = (96, 64)
+    prod, orac, desc, cp, co = _pair(lambda e: scenes.build_random_soup(e, 800, seed=4), size, mode, denoise=denoise)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(7):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        assert_bits_equal(img, ref, f"{mode.name} denoise={denoise} frame {frame}")
+
+
+def test_moving_camera_and_light_bit_exact():
+    """Reprojection, velocity and the prev-light path (lights.rs commit/rollback) under motion."""
+    torch = _torch()
+    size = (160, 96)
+    prod, orac = Engine(device=0), OracleEngine()
+    for e in (prod, orac):
+        scenes.build_cornell(e); e.set_seed(3)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    cp, co = prod.create_camera(desc), orac.create_camera(desc)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    from strolle_amd import Light
+    import math
+    for frame in range(9):
+        t = 0.05 * frame
+        desc = scenes.camera_for(size, (0.3 * math.sin(t), 1.0 + 0.1 * t, 3.2 - 0.2 * t), (0.0, 1.0, 0.0))
+        light = Light.point((math.sin(t) / 2.0, 1.5, math.cos(t) / 2.0), 0.15, (50.0 / (4 * math.pi),) * 3, 20.0)
+        for e in (prod, orac):
+            e.insert_light(1, light)
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"moving frame {frame}")
+
+
+def test_full_size_properties_1080p():
+    """BASELINE.json's full size: the oracle is too slow for every frame, so check size-independent
+    properties — determinism (two engines, same seed => identical bits), finiteness, ray budget <= 5N
+     — plus a bit-exact oracle comparison of the first frame's heatmap integers."""
+    torch = _torch()
+    size = (1920, 1080)
+    n = size[0] * size[1]
+    outs = []
+    for rep in range(2):
+        prod = Engine(device=0)
+        scenes.build_cornell(prod); prod.set_seed(5)
+        desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+        cp = prod.create_camera(desc)
+        out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+        for frame in range(8):
+            prod.update_camera(cp, desc); prod.tick()
+            prod.ray_count(cp, reset=True)
+            prod.render_camera(cp, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            rays = prod.ray_count(cp)
+            assert n <= rays <= 5 * n, (frame, rays, n)
+        img = out.cpu().numpy()
+        assert np.isfinite(img).all()
+        outs.append(img)
+        prod.close()
+    assert_bits_equal(outs[0], outs[1], "two identical runs")
+    prod, orac, desc, cp, co = _pair(scenes.build_cornell, size, CameraMode.BVH_HEATMAP)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    _step(torch, prod, orac, desc, cp, co, out)
+    assert np.array_equal(prod.read_buffer(cp, Buffer.DBG_USED_MEMORY), orac.read_buffer(co, Buffer.DBG_USED_MEMORY))
+
+
+def test_errors_are_loud():
+    from strolle_amd import StrolleError
+    prod = Engine(device=0)
+    with pytest.raises(StrolleError):
+        prod.render_camera(12345, 0, 0)       # unknown camera: the reference panics (camera_controllers.rs:21-34)
+    host_only = Engine(device=-1)
+    scenes.build_cornell(host_only)
+    cam = host_only.create_camera(scenes.cornell_camera((64, 64)))
+    host_only.tick()
+    with pytest.raises(StrolleError):
+        host_only.render_camera(cam, 0, 0)    # no device => loud failure, never a CPU path
