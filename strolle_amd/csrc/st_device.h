@@ -36,11 +36,15 @@ ST_D U2 pixel_in_tile(TileCoord t) {
 ST_D uint32_t* lane_stack(uint32_t* lds) {  // [wave][entry][lane]: consecutive lanes hit consecutive banks
     return lds + (threadIdx.x >> 6) * (kBvhStackSize * 64) + (threadIdx.x & 63u);
 }
-// Per-kernel counters: [0] rays traced, [1] the reference's `used_memory` bytes (algorithmic traversal traffic).
-// hipcc's atomic optimizer folds these uniform-address adds into one atomic per wavefront.
+// Per-kernel counters {rays traced, the reference's `used_memory` bytes}. One returning-free atomic pair per
+// wavefront (hipcc's atomic optimizer reduces the uniform-address adds across the wave) lands on one of
+// kCounterLines 64-byte lines picked by block id: a single hot word saturates near 88 atomics/us
+// (MI355X_MICROARCH.md, row "dequeue"), which alone cost 0.7 ms per full-screen launch at 1080p.
+
 ST_D void count_rays(unsigned long long* counter, uint32_t used_memory) {
-    atomicAdd(counter, 1ull);
-    atomicAdd(counter + 1, (unsigned long long)used_memory);
+    unsigned long long* line = counter + (blockIdx.x & (kCounterLines - 1u)) * 8u;
+    atomicAdd(line, 1ull);
+    atomicAdd(line + 1, (unsigned long long)used_memory);
 }
 
 // ------------------------------------------------------------------ small codecs

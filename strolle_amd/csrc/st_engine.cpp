@@ -165,7 +165,7 @@ struct CameraState {
     void* slab = nullptr; size_t slab_bytes = 0;
     float4* plane[ST_BUF_COUNT] = {};
     size_t plane_bytes[ST_BUF_COUNT] = {};
-    unsigned long long* counters = nullptr;  // KS_COUNT x {rays, traversal bytes}
+    unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
 };
 static size_t plane_texels_per_pixel(int id) {
@@ -174,6 +174,21 @@ static size_t plane_texels_per_pixel(int id) {
     if (id == ST_BUF_REF_HITS) return 2;
     if (id == ST_BUF_REF_RAYS) return 3;
     return 1;
+}
+
+constexpr size_t kCounterWordsPerSlot = (size_t)kCounterLines * 8;
+constexpr size_t kCounterBytes = sizeof(unsigned long long) * kCounterWordsPerSlot * KS_COUNT;
+// sums the per-line counters of every kernel slot into host[2*slot + {0: rays, 1: traversal bytes}]
+static int read_counters(const CameraState& c, unsigned long long* host /* 2*KS_COUNT */) {
+    std::vector<unsigned long long> raw(kCounterWordsPerSlot * KS_COUNT);
+    hipError_t err = hipMemcpy(raw.data(), c.counters, kCounterBytes, hipMemcpyDeviceToHost);
+    if (err != hipSuccess) return fail(ST_ERR_HIP, std::string("hipMemcpy(counters): ") + hipGetErrorString(err));
+    for (int s = 0; s < KS_COUNT; s++) {
+        unsigned long long rays = 0, bytes = 0;
+        for (uint32_t l = 0; l < kCounterLines; l++) { rays += raw[(size_t)s * kCounterWordsPerSlot + l * 8]; bytes += raw[(size_t)s * kCounterWordsPerSlot + l * 8 + 1]; }
+        host[2 * s] = rays; host[2 * s + 1] = bytes;
+    }
+    return ST_OK;
 }
 
 struct ProfileRecord { int slot; hipEvent_t start, stop; double bytes; };
@@ -475,8 +490,8 @@ struct Engine {
         c.slab_bytes = total;
         size_t off = 0;
         for (int i = 0; i < ST_BUF_COUNT; i++) { c.plane[i] = reinterpret_cast<float4*>(static_cast<char*>(c.slab) + off); off += (c.plane_bytes[i] + 255) & ~size_t(255); }
-        ST_HIP(hipMalloc(reinterpret_cast<void**>(&c.counters), sizeof(unsigned long long) * 2 * KS_COUNT));
-        ST_HIP(hipMemset(c.counters, 0, sizeof(unsigned long long) * 2 * KS_COUNT));
+        ST_HIP(hipMalloc(reinterpret_cast<void**>(&c.counters), kCounterBytes));
+        ST_HIP(hipMemset(c.counters, 0, kCounterBytes));
         memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
         ST_HIP(hipDeviceSynchronize());  // the clears run on the null stream; renders may use any stream
         return ST_OK;
@@ -544,7 +559,7 @@ struct Engine {
         auto run = [&](int slot, auto&& launch) {
             const KernelInfo& ki = kernel_info(slot);
             const double units = rows * (ki.half ? (double)(((c.desc.width + 7u) / 8u / 2u) * 8u) : (double)c.desc.width);
-            a.ray_counter = c.counters + 2 * slot;
+            a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
             Scope scope(this, stream, slot, units * ki.bytes_per_unit);
             launch();
         };
@@ -824,11 +839,11 @@ int st_camera_ray_count(StEngine* e, StHandle h, uint64_t* out, int reset) {
     unsigned long long host[2 * KS_COUNT];
     ST_HIP(hipSetDevice(en->device));
     ST_HIP(hipDeviceSynchronize());
-    ST_HIP(hipMemcpy(host, it->second->counters, sizeof(host), hipMemcpyDeviceToHost));
+    { const int rc2 = read_counters(*it->second, host); if (rc2) return rc2; }
     uint64_t total = 0;
     for (int i = 0; i < KS_COUNT; i++) total += host[2 * i];
     *out = total;
-    if (reset) { ST_HIP(hipMemset(it->second->counters, 0, sizeof(host))); memset(it->second->profiled_traversal_bytes, 0, sizeof(it->second->profiled_traversal_bytes)); ST_HIP(hipDeviceSynchronize()); }
+    if (reset) { ST_HIP(hipMemset(it->second->counters, 0, kCounterBytes)); memset(it->second->profiled_traversal_bytes, 0, sizeof(it->second->profiled_traversal_bytes)); ST_HIP(hipDeviceSynchronize()); }
     return ST_OK;
 }
 int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written) {
@@ -867,7 +882,7 @@ int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* 
     for (auto& kv : en->cameras) {
         CameraState& c = *kv.second;
         unsigned long long host[2 * KS_COUNT];
-        ST_HIP(hipMemcpy(host, c.counters, sizeof(host), hipMemcpyDeviceToHost));
+        { const int rc2 = read_counters(c, host); if (rc2) return rc2; }
         for (int i = 0; i < KS_COUNT; i++) {
             const unsigned long long total = host[2 * i + 1];
             if (total >= c.profiled_traversal_bytes[i]) en->profile_totals[i].algorithmic_bytes += (double)(total - c.profiled_traversal_bytes[i]);

@@ -35,6 +35,7 @@ static_assert(sizeof(HostTriangle) == 144, "Triangle is 144 B");
 
 constexpr int kBvhStackSize = 24;  // strolle-gpu/src/lib.rs:76
 constexpr uint32_t kLightIdSky = 0xffffffffu;
+constexpr uint32_t kCounterLines = 256;  // ray/byte counters are spread over this many 64-B lines per kernel slot
 
 // Everything a per-pixel kernel can touch, passed by value as the kernel argument (scalar loads).
 struct KArgs {
