@@ -1,0 +1,139 @@
+"""CPU tests of the product's boundary: the C-ABI library loads, exports every symbol include/strolle_hip.h
+declares, and its host logic (scene stores, baking, BVH build/flatten, light table) equals the oracle's bit for bit.
+No compute call is made (there is no GPU here); GPU-requiring calls must fail loudly."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle_binding import OracleEngine
+from parity import assert_bits_equal
+from strolle_amd import Engine, Light, StrolleError, scenes
+from strolle_amd.api import LIB_PATH, load_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "strolle_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(st_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_struct_sizes_match_header():
+    from strolle_amd import api
+    assert (C.sizeof(api.StMeshTriangle), C.sizeof(api.StMaterial), C.sizeof(api.StLight), C.sizeof(api.StCamera)) == (144, 88, 52, 160)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "soup", "dungeon"])
+def test_host_engine_scene_buffers_equal_oracle(scene):
+    build = {"cornell": scenes.build_cornell, "soup": lambda e: scenes.build_random_soup(e, 5000, seed=3), "dungeon": scenes.build_dungeon}[scene]
+    prod, orac = Engine(device=-1), OracleEngine()
+    for e in (prod, orac):
+        build(e)
+        e.tick()
+    names = ["bvh stream", "triangles (144 B)", "lights", "materials"]
+    for what in range(4):
+        assert_bits_equal(prod.read_scene(what), orac.read_scene(what), f"{scene}: {names[what]}")
+    assert prod.world() == orac.world()
+
+
+def test_bvh_stream_contract():
+    """serializer.rs:20-110: root at 0, internal = 4 float4 with w==0 marker and right pointer, leaf flag bits."""
+    prod = Engine(device=-1)
+    scenes.build_cornell(prod); prod.tick()
+    bvh = prod.read_scene(0).reshape(-1, 4)
+    bits = bvh.view(np.uint32)
+    assert bits[0, 3] == 0, "root is an internal node"
+    seen_tris = set()
+    ptr_stack = [0]
+    while ptr_stack:
+        p = ptr_stack.pop()
+        if bits[p, 3] == 0:
+            right = int(bits[p + 1, 3])
+            assert p + 4 < right < len(bvh)
+            ptr_stack += [p + 4, right]
+            assert np.all(bvh[p, :3] <= bvh[p + 1, :3]) and np.all(bvh[p + 2, :3] <= bvh[p + 3, :3])
+        else:
+            while True:
+                assert bits[p, 3] == 1
+                seen_tris.add(int(bits[p, 1]))
+                if bits[p, 0] & 1 == 0:
+                    break
+                p += 1
+    assert seen_tris == set(range(32)), "every Cornell triangle is referenced exactly by the leaves"
+
+
+def test_light_table_remap_and_kill_equal_oracle():
+    """lights.rs:97-154: removing a light shifts later slots, marks the killed slot 0xcafebabe and the remapped ones."""
+    prod, orac = Engine(device=-1), OracleEngine()
+    for e in (prod, orac):
+        scenes.build_cornell(e)
+        for i in range(2, 6):
+            e.insert_light(i, Light.point((i, 1.0, 0.0), 0.1, (1.0, 1.0, 1.0), 10.0))
+        e.tick()
+        e.remove_light(3)
+        e.insert_light(4, Light.spot((4, 2.0, 0.0), 0.2, (2.0, 1.0, 1.0), 10.0, (0.0, -1.0, 0.0), 0.5))
+        e.tick()
+    a, b = prod.read_scene(2), orac.read_scene(2)
+    assert_bits_equal(a, b, "lights after remove/update")
+    lights = a.reshape(-1, 7, 4).view(np.uint32)
+    assert (lights[:, 3, 0] == 0xCAFEBABE).sum() == 1
+    for e in (prod, orac):
+        e.tick()
+    assert_bits_equal(prod.read_scene(2), orac.read_scene(2), "slot flags cleared one frame later")
+    assert prod.world() == orac.world()
+
+
+def test_instance_update_and_removal_equal_oracle():
+    prod, orac = Engine(device=-1), OracleEngine()
+    from strolle_amd import Instance
+    for e in (prod, orac):
+        scenes.build_random_soup(e, 400, seed=8)
+        e.tick()
+        e.remove_instance(2)
+        x = np.concatenate([np.eye(3, dtype=np.float32) * 0.5, np.array([[0.1], [0.2], [0.3]], np.float32)], axis=1)
+        e.insert_instance(1, Instance(1, 3, x))  # same mesh, new material + transform
+        e.tick()
+    for what in range(4):
+        assert_bits_equal(prod.read_scene(what), orac.read_scene(what), f"scene buffer {what} after edits")
+
+
+def test_gpu_calls_fail_loudly_without_a_device():
+    prod = Engine(device=-1)
+    scenes.build_cornell(prod)
+    cam = prod.create_camera(scenes.cornell_camera((64, 64)))
+    prod.tick()
+    with pytest.raises(StrolleError, match="host-only"):
+        prod.render_camera(cam, 0, 0)
+    with pytest.raises(StrolleError):
+        prod.read_buffer(cam, 0)
+    with pytest.raises(StrolleError, match="camera does not exist"):
+        prod.update_camera(999, scenes.cornell_camera((64, 64)))
+    with pytest.raises(StrolleError, match="no triangles"):
+        prod._check(prod._b.mesh_insert(prod._h, 77, None, 0))
+    assert prod.has_material(1) and not prod.has_material(4242)
+    prod.remove_light(4242); prod.remove_instance(4242); prod.remove_mesh(4242)  # unknown removes are silent no-ops
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "strolle_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower() or f in ("api.py",) and "oracle" not in text.replace("no CPU", "").lower(), os.path.join(dirpath, f)
+    import subprocess
+    deps = subprocess.run(["ldd", LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in deps
