@@ -443,7 +443,7 @@ static inline float ggx_schlick_masking_term(float n_dot_l, float n_dot_v, float
     return g_v * g_l;
 }
 static inline Vec3 f_schlick_vec(Vec3 f0, float f90, float v_dot_h) {
-    return f0 + (Vec3::splat(f90) - f0) * stm_pow(fmax_(1.0f - v_dot_h, 0.001f), 5.0f);
+    return f0 + (Vec3::splat(f90) - f0) * stm_pow5(fmax_(1.0f - v_dot_h, 0.001f));
 }
 static inline Vec3 ggx_schlick_fresnel(Vec3 f0, float l_dot_h) {
     float f90 = saturate(dot(f0, Vec3::splat(50.0f * 0.33f)));
@@ -525,7 +525,7 @@ struct Light {
         if (is_point()) f_angle = 1.0f;
         else {
             float angle = angle_between(spot_dir(), hit.point - center());
-            f_angle = saturate(1.0f - stm_pow(angle / spot_angle(), 3.0f));
+            f_angle = saturate(1.0f - stm_pow3(angle / spot_angle()));
         }
         float f_dist;
         if (range() == INFINITY) f_dist = 1.0f;
@@ -842,7 +842,7 @@ struct MisResult { float m, lhs_pdf, lhs_mis, rhs_pdf, rhs_mis; };
 struct Mis {  // reservoir/mis.rs:11-144
     float lhs_m, rhs_m, rhs_jacobian, lhs_lhs_pdf, lhs_rhs_pdf, rhs_lhs_pdf, rhs_rhs_pdf;
     static float mis2(float x, float y) { float sum = x + y; return sum == 0.0f ? 0.0f : x / sum; }
-    static float mfac(float q0, float q1) { return q0 <= 0.0f ? 1.0f : saturate(stm_pow(fmin_(q1 / q0, 1.0f), 8.0f)); }
+    static float mfac(float q0, float q1) { return q0 <= 0.0f ? 1.0f : saturate(stm_pow8(fmin_(q1 / q0, 1.0f))); }
     MisResult eval() const {
         MisResult r;
         r.m = rhs_m * fmin_(mfac(rhs_rhs_pdf, rhs_lhs_pdf), mfac(lhs_rhs_pdf, lhs_lhs_pdf));

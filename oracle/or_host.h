@@ -346,7 +346,7 @@ struct Engine {
             g.base_color_texture = lookup_image(m.base_color_texture);
             g.emissive = Vec4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
             g.emissive_texture = lookup_image(m.emissive_texture);
-            g.roughness = stm_pow(m.perceptual_roughness, 2.0f);
+            g.roughness = stm_pow2(m.perceptual_roughness);
             g.metallic = m.metallic; g.reflectance = m.reflectance; g.ior = m.ior;
             g.metallic_roughness_texture = lookup_image(m.metallic_roughness_texture);
             g.normal_map_texture = lookup_image(m.normal_map_texture);

@@ -161,6 +161,15 @@ static inline float stm_pow(float x, float y) {
     return stm_exp2(y * stm_log2(x));
 }
 
+// Integer-exponent powf calls of the reference (`powf(2.0)`, `3.0`, `5.0`, `8.0`, `64.0`) are evaluated as exact
+// multiplication chains — closer to a correctly rounded pow than exp2(y*log2(x)) and an order of magnitude cheaper
+// (the SVGF edge-stopping weight alone evaluates x^64 sixteen times per pixel per pass).
+static inline float stm_pow2(float x) { return x * x; }
+static inline float stm_pow3(float x) { return x * x * x; }
+static inline float stm_pow5(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+static inline float stm_pow8(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x4; }
+static inline float stm_pow64(float x) { float x2 = x * x; float x4 = x2 * x2; float x8 = x4 * x4; float x16 = x8 * x8; float x32 = x16 * x16; return x32 * x32; }
+
 static inline float stm_atan(float x) {
     float sign = 1.0f;
     if (x < 0.0f) { sign = -1.0f; x = -x; }

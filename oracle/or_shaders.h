@@ -830,7 +830,7 @@ static inline float denoise_sample_weight(float center_luma, const Surface& cs, 
     float leeway = cs.depth * depth_sigma;
     float diff = fabsf(ss.depth - cs.depth);
     float depth_weight = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
-    float normal_weight = stm_pow(fmax_(dot(ss.normal, cs.normal), 0.0f), 64.0f);
+    float normal_weight = stm_pow64(fmax_(dot(ss.normal, cs.normal), 0.0f));
     return stm_exp(-luma_weight) * depth_weight * normal_weight;
 }
 static inline void pass_denoise_reproject(CameraBuffers& b, bool alt, const Plane& prev_colors, const Plane& prev_moments, const Plane& samples,

@@ -25,7 +25,7 @@ ST_D bool resolve_gid(const KArgs& a, bool half_x, U2* gid) {
     uint32_t tiles_x = (a.width + 7u) >> 3;
     if (half_x) tiles_x >>= 1;
     const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
-    TileCoord tc = tile_for_thread(tiles_x, ty1 - ty0);
+    TileCoord tc = tile_for_thread(tiles_x, ty1 - ty0, a.tile_map);
     if (!tc.valid) return false;
     tc.y += ty0;
     *gid = pixel_in_tile(tc);

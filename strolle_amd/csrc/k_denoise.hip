@@ -10,7 +10,7 @@ ST_D float denoise_sample_weight(float center_luma, const Surface& cs, float sam
     const float leeway = cs.depth * depth_sigma;
     const float diff = fabsf(ss.depth - cs.depth);
     const float depth_weight = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
-    const float normal_weight = pow_(fmax_(dot(ss.normal, cs.normal), 0.0f), 64.0f);
+    const float normal_weight = pow64_(fmax_(dot(ss.normal, cs.normal), 0.0f));
     return exp_(-luma_weight) * depth_weight * normal_weight;
 }
 

@@ -15,13 +15,27 @@ namespace st {
 // XCD one contiguous band of tile rows so that neighbour taps (spatial resampling, à-trous) of a tile stay
 // in the same XCD's L2.
 struct TileCoord { uint32_t x, y; bool valid; };
-ST_D TileCoord tile_for_thread(uint32_t tiles_x, uint32_t tiles_y) {
+// map_mode 0: XCD-banded (each XCD owns a contiguous band of tile rows); 1: hardware order (block b -> XCD b % 8,
+// consecutive blocks are horizontal neighbours); 2: XCD-banded in chunks of 4 tile rows (locality for short taps,
+// balance for spatially clustered slow paths).
+ST_D TileCoord tile_for_thread(uint32_t tiles_x, uint32_t tiles_y, uint32_t map_mode) {
     const uint32_t groups_x = (tiles_x + 3u) >> 2;              // blocks per tile row
     const uint32_t n_blocks = groups_x * tiles_y;
     const uint32_t b = blockIdx.x;
-    const uint32_t q = n_blocks >> 3, r = n_blocks & 7u;        // bijective XCD remap (handles n % 8 != 0)
-    const uint32_t xcd = b & 7u, k = b >> 3;
-    const uint32_t lin = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
+    uint32_t lin = b;
+    if (map_mode == 0u) {
+        const uint32_t q = n_blocks >> 3, r = n_blocks & 7u;    // bijective XCD remap (handles n % 8 != 0)
+        const uint32_t xcd = b & 7u, k = b >> 3;
+        lin = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
+    } else if (map_mode == 2u) {
+        const uint32_t chunk = groups_x * 4u * 8u;              // 8 XCDs x 4 tile rows
+        const uint32_t full = (n_blocks / chunk) * chunk;
+        if (b < full) {
+            const uint32_t c = b / chunk, i = b - c * chunk;
+            const uint32_t xcd = i & 7u, k = i >> 3;            // k in [0, groups_x*4)
+            lin = c * chunk + xcd * (groups_x * 4u) + k;
+        }
+    }
     const uint32_t wave = threadIdx.x >> 6;
     TileCoord t;
     t.y = lin / groups_x;
@@ -371,7 +385,7 @@ ST_D float ggx_schlick_masking_term(float n_dot_l, float n_dot_v, float roughnes
 }
 ST_D V3 ggx_schlick_fresnel(V3 f0, float l_dot_h) {
     const float f90 = saturate(dot(f0, v3s(50.0f * 0.33f)));
-    return f0 + (v3s(f90) - f0) * pow_(fmax_(1.0f - l_dot_h, 0.001f), 5.0f);
+    return f0 + (v3s(f90) - f0) * pow5_(fmax_(1.0f - l_dot_h, 0.001f));
 }
 ST_D V3 diffuse_eval(const GBuffer& g) { return xyz(g.base_color) * (1.0f - g.metallic) / kPi; }
 ST_D V3 specular_eval(const GBuffer& g, V3 l, V3 v) {
@@ -433,7 +447,7 @@ ST_D LightRadiance light_radiance(const GpuLight& l, const Hit& hit) {  // light
     if (f2b(l.d2.x) == 1u) f_angle = 1.0f;
     else {
         const float angle = angle_between(normal_decode(v2(l.d2.y, l.d2.z)), hit.point - center);
-        f_angle = saturate(1.0f - pow_(angle / l.d2.w, 3.0f));
+        f_angle = saturate(1.0f - pow3_(angle / l.d2.w));
     }
     float f_dist;
     if (range == INFINITY) f_dist = 1.0f;
@@ -709,7 +723,7 @@ ST_D EphemeralResult ephemeral_build(const KArgs& a, WhiteNoise& wn, const Hit& 
 struct Mis { float lhs_m, rhs_m, rhs_jacobian, lhs_lhs_pdf, lhs_rhs_pdf, rhs_lhs_pdf, rhs_rhs_pdf; };
 struct MisResult { float m, lhs_pdf, lhs_mis, rhs_pdf, rhs_mis; };
 ST_D float mis2(float x, float y) { const float sum = x + y; return sum == 0.0f ? 0.0f : x / sum; }
-ST_D float mis_mfac(float q0, float q1) { return q0 <= 0.0f ? 1.0f : saturate(pow_(fmin_(q1 / q0, 1.0f), 8.0f)); }
+ST_D float mis_mfac(float q0, float q1) { return q0 <= 0.0f ? 1.0f : saturate(pow8_(fmin_(q1 / q0, 1.0f))); }
 ST_D MisResult mis_eval(const Mis& s) {
     MisResult r;
     r.m = s.rhs_m * fmin_(mis_mfac(s.rhs_rhs_pdf, s.rhs_lhs_pdf), mis_mfac(s.lhs_rhs_pdf, s.lhs_lhs_pdf));

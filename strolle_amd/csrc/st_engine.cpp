@@ -222,7 +222,8 @@ struct Engine {
     std::vector<GpuLight> light_buffer; std::map<int64_t, uint32_t> light_slot;
     std::vector<int64_t> lights_created, lights_updated; std::map<int64_t, uint32_t> lights_remapped; std::vector<uint32_t> lights_killed;
     uint32_t next_light_id = 1;
-    std::vector<GpuLight> gpu_lights;
+    std::vector<GpuLight> gpu_lights, uploaded_lights;
+    bool sync_every_tick = false;
     float sun_azimuth = 0.0f, sun_altitude = 0.35f; bool sun_dirty = true;
     uint32_t light_count = 0; V3 sun_dir_ = v3s(0.0f);
 
@@ -233,6 +234,7 @@ struct Engine {
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
+    uint32_t tile_map = 2;  // blockIdx -> tile mapping (st_device.h); 2 measured best on MI355X; ST_TILE_MAP overrides
     bool profiling = false;
     std::vector<ProfileRecord> profile_records; std::vector<hipEvent_t> event_pool;
     StKernelProfile profile_totals[KS_COUNT];
@@ -246,6 +248,7 @@ struct Engine {
         transmittance_lut.assign(256 * 64, make_float4(0, 0, 0, 0));
         sky_lut.assign(256 * 256, make_float4(0, 0, 0, 0));
         reset_profile_totals();
+        if (const char* tm = getenv("ST_TILE_MAP")) tile_map = (uint32_t)atoi(tm);
     }
     void reset_profile_totals() {
         for (int i = 0; i < KS_COUNT; i++) {
@@ -280,7 +283,7 @@ struct Engine {
             g.base_color_texture = image_rect(m.base_color_texture);
             g.emissive = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
             g.emissive_texture = image_rect(m.emissive_texture);
-            g.roughness = pow_(m.perceptual_roughness, 2.0f);
+            g.roughness = pow2_(m.perceptual_roughness);
             g.metallic = m.metallic; g.reflectance = m.reflectance; g.ior = m.ior;
             g.metallic_roughness_texture = image_rect(m.metallic_roughness_texture);
             g.normal_map_texture = image_rect(m.normal_map_texture);
@@ -444,7 +447,9 @@ struct Engine {
                 if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream))) return rc;
                 if ((rc = d_materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), stream))) return rc;
                 scene_uploaded = true;
+                scene_changed = true;  // forces the stream sync below
             }
+            bool misc_uploaded = atlas_dirty || blue_noise_dirty || luts_dirty;
             if (atlas_dirty) { int rc = d_atlas.upload(atlas.data(), atlas.size(), stream); if (rc) return rc; }
             if (blue_noise_dirty) { int rc = d_blue_noise.upload(blue_noise.data(), blue_noise.size(), stream); if (rc) return rc; blue_noise_dirty = false; }
             if (luts_dirty) {
@@ -453,10 +458,17 @@ struct Engine {
                 if ((rc = d_sky.upload(sky_lut.data(), sky_lut.size() * sizeof(float4), stream))) return rc;
                 luts_dirty = false;
             }
-            int rc = d_lights.upload(gpu_lights.data(), gpu_lights.size() * sizeof(GpuLight), stream);
-            if (rc) return rc;
-            // host vectors above may be touched again before the async copies land
-            ST_HIP(hipStreamSynchronize(stream));
+            bool uploaded = scene_changed || misc_uploaded;
+            // lights change rarely; skipping the identical re-upload also skips the stream sync below, so the host can
+            // run a frame ahead of the GPU (the reference re-uploads only dirty buffers too: mapped_storage_buffer.rs:103-121)
+            if (gpu_lights.size() != uploaded_lights.size() || memcmp(gpu_lights.data(), uploaded_lights.data(), gpu_lights.size() * sizeof(GpuLight)) != 0) {
+                int rc = d_lights.upload(gpu_lights.data(), gpu_lights.size() * sizeof(GpuLight), stream);
+                if (rc) return rc;
+                uploaded_lights = gpu_lights;
+                uploaded = true;
+            }
+            // host vectors may be touched again before async copies from pageable memory land
+            if (uploaded || sync_every_tick) ST_HIP(hipStreamSynchronize(stream));
         }
         atlas_dirty = false;
         for (auto& kv : cameras) kv.second->frame = frame;  // CameraController::flush
@@ -554,6 +566,7 @@ struct Engine {
         a.dbg_used_memory = reinterpret_cast<uint32_t*>(P(ST_BUF_DBG_USED_MEMORY));
         a.width = c.desc.width; a.height = c.desc.height; a.row0 = c.row0; a.row1 = c.row1;
         a.frame = c.frame;
+        a.tile_map = tile_map;
 
         const double rows = (double)(c.row1 - c.row0);
         auto run = [&](int slot, auto&& launch) {

@@ -146,6 +146,14 @@ ST_HD float pow_(float x, float y) {  // x >= 0, finite y > 0 (all the path need
     if (x == 1.0f) return 1.0f;
     return exp2_(y * log2_(x));
 }
+// integer-exponent powf calls of the reference as exact multiplication chains (cheaper and closer to a correctly
+// rounded pow than exp2(y*log2(x)); x^64 is evaluated 16x per pixel per wavelet pass)
+ST_HD float pow2_(float x) { return x * x; }
+ST_HD float pow3_(float x) { return x * x * x; }
+ST_HD float pow5_(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x4 * x; }
+ST_HD float pow8_(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x4 * x4; }
+ST_HD float pow64_(float x) { const float x2 = x * x; const float x4 = x2 * x2; const float x8 = x4 * x4; const float x16 = x8 * x8; const float x32 = x16 * x16; return x32 * x32; }
+
 ST_HD float atan_(float x) {
     float sign = 1.0f;
     if (x < 0.0f) { sign = -1.0f; x = -x; }

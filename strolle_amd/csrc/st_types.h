@@ -64,6 +64,7 @@ struct KArgs {
     unsigned long long* ray_counter;
     uint32_t width, height, row0, row1;  // [row0,row1): rows this launch covers (multi-GPU tiling)
     uint32_t frame;
+    uint32_t tile_map;  // blockIdx -> tile mapping (st_device.h tile_for_thread)
 };
 
 }  // namespace st

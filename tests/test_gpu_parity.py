@@ -161,3 +161,71 @@ def test_errors_are_loud():
     host_only.tick()
     with pytest.raises(StrolleError):
         host_only.render_camera(cam, 0, 0)    # no device => loud failure, never a CPU path
+
+
+def test_dungeon_image_mode_bit_exact():
+    """BASELINE.json config 3's scene (level.glb: 8,393 triangles, 45 textured materials): atlas sampling,
+    multi-triangle leaves, six lights through the 16-sample RIS."""
+    torch = _torch()
+    size = (160, 96)
+    prod, orac, desc, cp, co = _pair(scenes.build_dungeon, size, CameraMode.IMAGE, camera_fn=scenes.dungeon_camera)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(8):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"dungeon frame {frame}")
+    assert float(ref[..., :3].mean()) > 0.0
+
+
+def test_dungeon_heatmap_1080p_bit_exact():
+    """Config 3's check at its full size: BVH-heatmap integer counts, bit-exact."""
+    torch = _torch()
+    size = (1920, 1080)
+    prod, orac, desc, cp, co = _pair(scenes.build_dungeon, size, CameraMode.BVH_HEATMAP, camera_fn=scenes.dungeon_camera)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    _step(torch, prod, orac, desc, cp, co, out)
+    assert np.array_equal(prod.read_buffer(cp, Buffer.DBG_USED_MEMORY), orac.read_buffer(co, Buffer.DBG_USED_MEMORY))
+
+
+def _render_bands(torch, build, size, mode, depth, frames, n_bands, apron, camera_fn=scenes.cornell_camera):
+    """Emulates the multi-GPU partition on one GPU: one engine per band, each restricted to its row window."""
+    from strolle_amd.distributed import assemble_bands_numpy, band_for_rank, render_window
+    w, h = size
+    full = []
+    for r in range(n_bands):
+        e = Engine(device=0)
+        build(e); e.set_seed(21)
+        desc = camera_fn(size, mode, depth=depth)
+        cam = e.create_camera(desc)
+        y0, y1 = render_window(h, band_for_rank(h, n_bands, r), apron)
+        e.set_camera_rows(cam, y0, y1)
+        out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+        for _ in range(frames):
+            e.update_camera(cam, desc); e.tick()
+            e.render_camera(cam, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        full.append(out.cpu().numpy())
+        e.close()
+    return assemble_bands_numpy(full, h, w)
+
+
+@pytest.mark.parametrize("mode,depth", [(CameraMode.BVH_HEATMAP, 0), (CameraMode.REFERENCE, 1)])
+def test_row_bands_reproduce_the_single_gpu_frame_exactly(mode, depth):
+    """Reference/Heatmap touch only their own pixel and key the RNG on absolute coordinates: a tiled frame is bit-identical."""
+    torch = _torch()
+    size = (256, 200)
+    single = _render_bands(torch, scenes.build_cornell, size, mode, depth, 3, 1, 0)
+    tiled = _render_bands(torch, scenes.build_cornell, size, mode, depth, 3, 4, 0)
+    assert_bits_equal(tiled, single, "4 row bands vs 1")
+
+
+def test_row_bands_image_mode_seam_psnr():
+    """Image mode has cross-band taps; with an apron the assembled frame must stay close to the single-GPU frame."""
+    from parity import psnr
+    torch = _torch()
+    size = (512, 384)
+    single = _render_bands(torch, scenes.build_cornell, size, CameraMode.IMAGE, 0, 14, 1, 0)
+    tiled = _render_bands(torch, scenes.build_cornell, size, CameraMode.IMAGE, 0, 14, 2, 64)
+    value = psnr(np.clip(tiled[..., :3], 0, 1), np.clip(single[..., :3], 0, 1))
+    print("seam PSNR (2 bands, apron 64) =", value)
+    assert value >= 35.0, value
