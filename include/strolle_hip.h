@@ -128,9 +128,6 @@ int st_set_seed(StEngine* e, uint64_t base_seed);
 /* Blue-noise texture (256x256 RGBA8), decoded by the caller from strolle/assets/blue-noise.png
  * (strolle/src/noise.rs:40-50 embeds the PNG; this library carries no image decoder). */
 int st_set_blue_noise(StEngine* e, const uint8_t* rgba_256x256x4, size_t bytes);
-/* Atmosphere LUTs as RGBA32F (transmittance 256x64, sky 256x256); default all-zero == black sky.
- * LUT generation (strolle-shaders/src/atmosphere/ *.rs) is SURVEY.md §8(f) row 1, not built yet. */
-int st_set_atmosphere_luts(StEngine* e, const float* transmittance_256x64x4, const float* sky_256x256x4);
 /* Multi-GPU tiling: restrict every per-pixel launch of this camera to the pixel rows [y0, y1)
  * of the full viewport (0,0 = whole frame). Pixels keep their absolute coordinates. */
 int st_camera_set_rows(StEngine* e, StHandle camera, uint32_t y0, uint32_t y1);
@@ -159,6 +156,9 @@ int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
  * 144-B layout, 2 lights (112 B), 3 materials (112 B). Works on host-only engines. */
 int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written);
 int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame);
+/* Atmosphere LUTs as generated on the device (strolle-shaders/src/atmosphere): what = 0 transmittance 256x64,
+ * 1 multi-scattering 32x32, 2 sky 256x256; RGBA32F texels holding f16-rounded values (the reference stores Rgba16Float). */
+int st_debug_read_lut(StEngine* e, int what, float* out, size_t capacity_floats, size_t* written_floats);
 
 /* Per-kernel timing (HIP events recorded around every launch on the launch stream).
  * st_profile_read returns, per kernel slot i < *count: name, launches, total milliseconds,

@@ -222,7 +222,7 @@ static inline Vec3 transmittance_eval(Vec3 pos, Vec3 sun_dir) {
         float rayleigh_density = stm_exp(-altitude_km / 8.0f);
         float mie_density = stm_exp(-altitude_km / 1.2f);
         Vec3 rayleigh_scattering = Vec3(5.802f, 13.558f, 33.1f) * rayleigh_density;
-        float rayleigh_absorption = 0.0f * rayleigh_density;
+        float rayleigh_absorption = 0.0f;  // RAYLEIGH_ABSORPTION_BASE (0.0) * density, folded: 0 * inf must not poison the LUT (DESIGN.md deviation 9)
         float mie_scattering = 3.996f * mie_density;
         float mie_absorption = 4.4f * mie_density;
         Vec3 ozone_absorption = Vec3(0.650f, 1.881f, 0.085f) * fmax_(1.0f - fabsf(altitude_km - 25.0f) / 15.0f, 0.0f);
@@ -232,6 +232,154 @@ static inline Vec3 transmittance_eval(Vec3 pos, Vec3 sun_dir) {
         i += 1.0f;
     }
     return transmittance;
+}
+
+// ---------------------------------------------------------------- atmosphere LUT generation (strolle-shaders/src/atmosphere/*.rs)
+// Textures are Rgba16Float in the reference: every texel is rounded through f16 on store (quantize_f16).
+struct ScatteringTerms { Vec3 rayleigh; float mie; Vec3 extinction; };
+static inline ScatteringTerms eval_scattering(Vec3 pos) {  // atmosphere/utils.rs:3-29
+    float altitude_km = (length(pos) - Atmosphere::GROUND_RADIUS_MM) * 1000.0f;
+    float rayleigh_density = stm_exp(-altitude_km / 8.0f);
+    float mie_density = stm_exp(-altitude_km / 1.2f);
+    ScatteringTerms t;
+    t.rayleigh = Vec3(5.802f, 13.558f, 33.1f) * rayleigh_density;
+    float rayleigh_absorption = 0.0f;  // RAYLEIGH_ABSORPTION_BASE (0.0) * density, folded: 0 * inf must not poison the LUT (DESIGN.md deviation 9)
+    t.mie = 3.996f * mie_density;
+    float mie_absorption = 4.4f * mie_density;
+    Vec3 ozone_absorption = Vec3(0.650f, 1.881f, 0.085f) * fmax_(1.0f - fabsf(altitude_km - 25.0f) / 15.0f, 0.0f);
+    t.extinction = t.rayleigh + Vec3::splat(rayleigh_absorption) + Vec3::splat(t.mie) + Vec3::splat(mie_absorption) + ozone_absorption;
+    return t;
+}
+static inline float eval_mie_phase(float cos_theta) {  // atmosphere/utils.rs:31-40
+    const float G = 0.8f;
+    const float SCALE = 3.0f / (8.0f * PI);
+    float num = (1.0f - G * G) * (1.0f + cos_theta * cos_theta);
+    float denom = (2.0f + G * G) * stm_pow(1.0f + G * G - 2.0f * G * cos_theta, 1.5f);
+    return SCALE * num / denom;
+}
+static inline float eval_rayleigh_phase(float cos_theta) { const float K = 3.0f / (16.0f * PI); return K * (1.0f + cos_theta * cos_theta); }
+static inline Vec3 exp3(Vec3 v) { return Vec3(stm_exp(v.x), stm_exp(v.y), stm_exp(v.z)); }
+static inline Vec4 store_f16(Vec3 v) { return Vec4(quantize_f16(v.x), quantize_f16(v.y), quantize_f16(v.z), quantize_f16(1.0f)); }
+
+static inline void generate_transmittance_lut(std::vector<Vec4>& out) {  // generate_transmittance_lut.rs:5-30
+    out.assign(256 * 64, Vec4());
+    for (uint32_t y = 0; y < 64; y++)
+        for (uint32_t x = 0; x < 256; x++) {
+            Vec2 uv = Vec2((float)x, (float)y) / Vec2(256.0f, 64.0f);
+            float sun_cos_theta = 2.0f * uv.x - 1.0f;
+            float sun_theta = stm_acos(clampf(sun_cos_theta, -1.0f, 1.0f));
+            float height = lerpf(Atmosphere::GROUND_RADIUS_MM, Atmosphere::ATMOSPHERE_RADIUS_MM, uv.y);
+            Vec3 pos(0.0f, height, 0.0f);
+            Vec3 sun_dir = normalize(Vec3(0.0f, sun_cos_theta, -stm_sin(sun_theta)));
+            out[y * 256 + x] = store_f16(transmittance_eval(pos, sun_dir));
+        }
+}
+static inline void generate_scattering_lut(const LutTex& transmittance, std::vector<Vec4>& out) {  // generate_scattering_lut.rs
+    out.assign(32 * 32, Vec4());
+    const int SQ = 8;
+    for (uint32_t y = 0; y < 32; y++)
+        for (uint32_t x = 0; x < 32; x++) {
+            Vec2 uv = Vec2((float)x, (float)y) / Vec2(32.0f, 32.0f);
+            float sun_cos_theta = 2.0f * uv.x - 1.0f;
+            float sun_theta = stm_acos(clampf(sun_cos_theta, -1.0f, 1.0f));
+            float height = lerpf(Atmosphere::GROUND_RADIUS_MM, Atmosphere::ATMOSPHERE_RADIUS_MM, fmax_(uv.y, 0.01f));
+            Vec3 pos(0.0f, height, 0.0f);
+            Vec3 sun_dir = normalize(Vec3(0.0f, sun_cos_theta, -stm_sin(sun_theta)));
+            Vec3 lum_total, fms;
+            float inv_samples = 1.0f / (float)(SQ * SQ);
+            for (int i = 0; i < SQ; i++)
+                for (int j = 0; j < SQ; j++) {
+                    float theta = PI * ((float)i + 0.5f) / (float)SQ;
+                    float phi = stm_acos(clampf(1.0f - 2.0f * ((float)j + 0.5f) / (float)SQ, -1.0f, 1.0f));
+                    float cos_phi = stm_cos(phi), sin_phi = stm_sin(phi), cos_theta_d = stm_cos(theta), sin_theta_d = stm_sin(theta);
+                    Vec3 ray_dir(sin_phi * sin_theta_d, cos_phi, sin_phi * cos_theta_d);  // spherical_direction
+                    float atmosphere_distance = Ray::make(pos, ray_dir).intersect_sphere(Atmosphere::ATMOSPHERE_RADIUS_MM);
+                    float ground_distance = Ray::make(pos, ray_dir).intersect_sphere(Atmosphere::GROUND_RADIUS_MM);
+                    float t_max = ground_distance > 0.0f ? ground_distance : atmosphere_distance;
+                    float cos_theta = dot(ray_dir, sun_dir);
+                    float mie_phase_value = eval_mie_phase(cos_theta);
+                    float rayleigh_phase_value = eval_rayleigh_phase(-cos_theta);
+                    Vec3 lum, lum_factor, transmittance_acc = Vec3::splat(1.0f);
+                    float t = 0.0f, step_i = 0.0f;
+                    while (step_i < 20.0f) {
+                        float new_t = ((step_i + 0.3f) / 20.0f) * t_max;
+                        float dt = new_t - t;
+                        t = new_t;
+                        Vec3 new_pos = pos + t * ray_dir;
+                        ScatteringTerms sc = eval_scattering(new_pos);
+                        Vec3 sample_transmittance = exp3(-dt * sc.extinction);
+                        Vec3 scattering_no_phase = sc.rayleigh + Vec3::splat(sc.mie);
+                        Vec3 scattering_f = (scattering_no_phase - scattering_no_phase * sample_transmittance) / sc.extinction;
+                        lum_factor += transmittance_acc * scattering_f;
+                        Vec3 sun_transmittance = Atmosphere::sample_lut(transmittance, new_pos, sun_dir);
+                        Vec3 rayleigh_in = sc.rayleigh * rayleigh_phase_value;
+                        float mie_in = sc.mie * mie_phase_value;
+                        Vec3 in_scattering = (rayleigh_in + Vec3::splat(mie_in)) * sun_transmittance;
+                        Vec3 scattering_integral = (in_scattering - in_scattering * sample_transmittance) / sc.extinction;
+                        lum += scattering_integral * transmittance_acc;
+                        transmittance_acc *= sample_transmittance;
+                        step_i += 1.0f;
+                    }
+                    if (ground_distance > 0.0f) {
+                        Vec3 hit_pos = pos + ground_distance * ray_dir;
+                        if (dot(pos, sun_dir) > 0.0f) {
+                            hit_pos = normalize(hit_pos) * Atmosphere::GROUND_RADIUS_MM;
+                            lum += transmittance_acc * Vec3::splat(0.25f) * Atmosphere::sample_lut(transmittance, hit_pos, sun_dir);
+                        }
+                    }
+                    fms += lum_factor * inv_samples;
+                    lum_total += lum * inv_samples;
+                }
+            Vec3 out_val = lum_total / (Vec3::splat(1.0f) - fms);
+            out[y * 32 + x] = store_f16(out_val);
+        }
+}
+static inline void generate_sky_lut(const LutTex& transmittance, const LutTex& scattering, float sun_altitude, std::vector<Vec4>& out) {  // generate_sky_lut.rs
+    out.assign(256 * 256, Vec4());
+    _Pragma("omp parallel for schedule(dynamic, 4)")
+    for (int32_t y = 0; y < 256; y++)
+        for (uint32_t x = 0; x < 256; x++) {
+            Vec2 uv = Vec2((float)x, (float)y) / Vec2(256.0f, 256.0f);
+            float azimuth = (uv.x - 0.5f) * 2.0f * PI;
+            float v;
+            if (uv.y < 0.5f) { float coord = 1.0f - 2.0f * uv.y; v = -coord * coord; }
+            else { float coord = uv.y * 2.0f - 1.0f; v = coord * coord; }
+            float height = length(Atmosphere::view_pos());
+            float th = sqr(height) - sqr(Atmosphere::GROUND_RADIUS_MM);
+            th = sqrtf(th) / height;
+            float horizon = stm_acos(clampf(th, -1.0f, 1.0f)) - 0.5f * PI;
+            float altitude = v * 0.5f * PI - horizon;
+            Vec3 ray_dir(stm_cos(altitude) * stm_sin(azimuth), stm_sin(altitude), -stm_cos(altitude) * stm_cos(azimuth));
+            float sa = fmodf(sun_altitude, 2.0f * PI);
+            Vec3 sun_dir = sa < 0.5f * PI ? Vec3(0.0f, stm_sin(sa), -stm_cos(sa)) : Vec3(0.0f, stm_sin(sa), stm_cos(sa));
+            Vec3 pos = Atmosphere::view_pos();
+            float atmosphere_distance = Ray::make(pos, ray_dir).intersect_sphere(Atmosphere::ATMOSPHERE_RADIUS_MM);
+            float ground_distance = Ray::make(pos, ray_dir).intersect_sphere(Atmosphere::GROUND_RADIUS_MM);
+            float t_max = ground_distance < 0.0f ? atmosphere_distance : ground_distance;
+            float cos_theta = dot(ray_dir, sun_dir);
+            float mie_phase_value = eval_mie_phase(cos_theta);
+            float rayleigh_phase_value = eval_rayleigh_phase(-cos_theta);
+            Vec3 lum, transmittance_acc = Vec3::splat(1.0f);
+            float t = 0.0f, i = 0.0f;
+            while (i < 32.0f) {
+                float new_t = ((i + 0.3f) / 32.0f) * t_max;
+                float dt = new_t - t;
+                t = new_t;
+                Vec3 new_pos = pos + t * ray_dir;
+                ScatteringTerms sc = eval_scattering(new_pos);
+                Vec3 sample_transmittance = exp3(-dt * sc.extinction);
+                Vec3 sun_transmittance = Atmosphere::sample_lut(transmittance, new_pos, sun_dir);
+                Vec3 psi_ms = Atmosphere::sample_lut(scattering, new_pos, sun_dir);
+                Vec3 rayleigh_in = sc.rayleigh * (rayleigh_phase_value * sun_transmittance + psi_ms);
+                Vec3 mie_in = sc.mie * (mie_phase_value * sun_transmittance + psi_ms);
+                Vec3 in_scattering = rayleigh_in + mie_in;
+                Vec3 scattering_integral = (in_scattering - in_scattering * sample_transmittance) / sc.extinction;
+                lum += scattering_integral * transmittance_acc;
+                transmittance_acc *= sample_transmittance;
+                i += 1.0f;
+            }
+            out[(size_t)y * 256 + x] = store_f16(lum);
+        }
 }
 
 // ---------------------------------------------------------------- Engine (lib.rs:105-395) + CameraController (camera_controller.rs)
@@ -275,7 +423,8 @@ struct Engine {
     uint64_t base_seed = 0;
     BvhBuilder bvh; std::vector<Vec4> bvh_buffer;
     std::vector<uint8_t> blue_noise;  // 256*256*4
-    std::vector<Vec4> transmittance_lut, sky_lut;  // uploaded LUTs (generation is SURVEY §8(f) row 1)
+    std::vector<Vec4> transmittance_lut, scattering_lut, sky_lut;  // passes/atmosphere.rs:78-110
+    bool atmosphere_initialized = false; bool sky_known = false; float known_sun_altitude = 0.0f;
     std::vector<uint8_t> atlas; uint32_t atlas_w = 0, atlas_h = 0;
     // images: one linear RGBA8 atlas, 2048 texels wide, shelf-packed in insertion order and grown in 256-row steps.
     // (The reference allocates rectangles in an 8192^2 atlas with `guillotiere` 0.6.2, images.rs:54-127 — a crate that is
@@ -530,9 +679,21 @@ struct Engine {
         return true;
     }
 
+    void run_atmosphere() {  // passes/atmosphere.rs:78-110
+        if (!atmosphere_initialized) {
+            generate_transmittance_lut(transmittance_lut);
+            generate_scattering_lut(LutTex{transmittance_lut.data(), 256, 64}, scattering_lut);
+            atmosphere_initialized = true;
+        }
+        if (!sky_known || known_sun_altitude != sun_altitude) {
+            generate_sky_lut(LutTex{transmittance_lut.data(), 256, 64}, LutTex{scattering_lut.data(), 32, 32}, world.sun_altitude, sky_lut);
+            sky_known = true; known_sun_altitude = sun_altitude;
+        }
+    }
     bool render_camera(uint64_t h, Vec4* out) {
         auto it = cameras.find(h);
         if (it == cameras.end()) return false;
+        if (it->second->api.mode != 5) run_atmosphere();
         CameraSlot& s = *it->second;
         CameraBuffers& b = s.buffers;
         EngineView e = view();

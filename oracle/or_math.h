@@ -192,6 +192,34 @@ static inline float stm_atan2(float y, float x) {  // Rust f32::atan2(self=y, ot
     return a;
 }
 
+// Rgba16Float storage (atmosphere LUTs): f32 -> f16 (round to nearest even) -> f32, in integer arithmetic so that
+// CPU and GPU agree bit for bit.
+static inline float quantize_f16(float f) {
+    uint32_t u = f2b(f);
+    uint32_t sign = (u >> 16) & 0x8000u;
+    uint32_t a = u & 0x7fffffffu;
+    uint32_t h;
+    if (a >= 0x7f800000u) h = sign | (a > 0x7f800000u ? 0x7e00u : 0x7c00u);
+    else if (a >= 0x477ff000u) h = sign | 0x7c00u;
+    else if (a < 0x38800000u) {
+        if (a < 0x33000000u) h = sign;
+        else {
+            uint32_t m = (a & 0x007fffffu) | 0x00800000u;
+            uint32_t sft = 126u - (a >> 23);
+            uint32_t r = m >> sft, rem = m & ((1u << sft) - 1u), half = 1u << (sft - 1u);
+            if (rem > half || (rem == half && (r & 1u))) r += 1u;
+            h = sign | r;
+        }
+    } else {
+        uint32_t b = a + 0xfffu + ((a >> 13) & 1u);
+        h = sign | ((b - 0x38000000u) >> 13);
+    }
+    uint32_t hs = (h & 0x8000u) << 16, he = (h >> 10) & 0x1fu, hm = h & 0x3ffu;
+    if (he == 0u) { float v = (float)hm * 5.9604644775390625e-8f; return b2f(f2b(v) | hs); }
+    if (he == 31u) return b2f(hs | 0x7f800000u | (hm << 13));
+    return b2f(hs | ((he + 112u) << 23) | (hm << 13));
+}
+
 // -------------------------------------------------------------------- Vec2
 struct Vec2 {
     float x, y;

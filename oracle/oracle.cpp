@@ -28,9 +28,11 @@ int or_set_blue_noise(OrEngine* e, const uint8_t* rgba, size_t n) {
     E(e)->blue_noise.assign(rgba, rgba + n);
     return 0;
 }
-int or_set_atmosphere_luts(OrEngine* e, const float* transmittance_256x64x4, const float* sky_256x256x4) {
-    std::memcpy((void*)E(e)->transmittance_lut.data(), transmittance_256x64x4, sizeof(Vec4) * 256 * 64);
-    std::memcpy((void*)E(e)->sky_lut.data(), sky_256x256x4, sizeof(Vec4) * 256 * 256);
+// what = 0 transmittance (256x64), 1 scattering (32x32), 2 sky (256x256): RGBA32F texels holding f16-rounded values
+int or_debug_read_lut(OrEngine* e, int what, float* out, size_t capacity_floats, size_t* written_floats) {
+    const std::vector<Vec4>* v = what == 0 ? &E(e)->transmittance_lut : (what == 1 ? &E(e)->scattering_lut : &E(e)->sky_lut);
+    if (written_floats) *written_floats = v->size() * 4;
+    if (out) { if (capacity_floats < v->size() * 4) return 1; std::memcpy(out, (const void*)v->data(), v->size() * sizeof(Vec4)); }
     return 0;
 }
 int or_mesh_insert(OrEngine* e, uint64_t id, const ApiMeshTriangle* tris, size_t n) {

@@ -240,7 +240,7 @@ class _Binding:
         self.tick = fn("tick", [vp, vp] if has_device else [vp])
         self.render_camera = fn("render_camera", [vp, u64, vp, vp] if has_device else [vp, u64, vp])
         self.set_seed = fn("set_seed", [vp, u64]); self.set_blue_noise = fn("set_blue_noise", [vp, vp, sz])
-        self.set_atmosphere_luts = fn("set_atmosphere_luts", [vp, vp, vp])
+        self.debug_read_lut = fn("debug_read_lut", [vp, i32, vp, sz, P(sz)])
         self.camera_read_buffer = fn("camera_read_buffer", [vp, u64, i32, vp, sz, P(sz)])
         self.camera_ray_count = fn("camera_ray_count", [vp, u64, P(u64), i32])
         self.debug_read_scene = fn("debug_read_scene", [vp, i32, vp, sz, P(sz)])
@@ -350,11 +350,6 @@ class EngineBase:
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
         self._check(self._b.set_blue_noise(self._h, rgba.ctypes.data, rgba.nbytes))
 
-    def set_atmosphere_luts(self, transmittance: np.ndarray, sky: np.ndarray):
-        t = np.ascontiguousarray(transmittance, dtype=np.float32); s = np.ascontiguousarray(sky, dtype=np.float32)
-        assert t.size == 256 * 64 * 4 and s.size == 256 * 256 * 4
-        self._check(self._b.set_atmosphere_luts(self._h, t.ctypes.data, s.ctypes.data))
-
     # --- read-back
     def read_buffer(self, camera: int, buffer: Buffer) -> np.ndarray:
         n = C.c_size_t()
@@ -376,6 +371,15 @@ class EngineBase:
         if n.value:
             self._check(self._b.debug_read_scene(self._h, what, out.ctypes.data, out.nbytes, C.byref(n)))
         return out
+
+    def read_lut(self, what: int) -> np.ndarray:
+        """Atmosphere LUT (0 transmittance 256x64, 1 scattering 32x32, 2 sky 256x256) as [H, W, 4] float32."""
+        n = C.c_size_t()
+        self._check(self._b.debug_read_lut(self._h, what, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        self._check(self._b.debug_read_lut(self._h, what, out.ctypes.data, out.size, C.byref(n)))
+        w = (256, 32, 256)[what]
+        return out.reshape(-1, w, 4)
 
     def world(self):
         lc, fr = C.c_uint32(), C.c_uint32()

@@ -108,7 +108,7 @@ static V3 sun_transmittance(V3 pos, V3 sun_dir) {
         const float altitude_km = (length(new_pos) - 6.360f) * 1000.0f;
         const float rayleigh_density = exp_(-altitude_km / 8.0f), mie_density = exp_(-altitude_km / 1.2f);
         const V3 rayleigh_scattering = v3(5.802f, 13.558f, 33.1f) * rayleigh_density;
-        const float rayleigh_absorption = 0.0f * rayleigh_density;
+        const float rayleigh_absorption = 0.0f;  // RAYLEIGH_ABSORPTION_BASE (0.0) * density, folded: 0 * inf must not poison the LUT (DESIGN.md deviation 9)
         const float mie_scattering = 3.996f * mie_density, mie_absorption = 4.4f * mie_density;
         const V3 ozone_absorption = v3(0.650f, 1.881f, 0.085f) * fmax_(1.0f - fabsf(altitude_km - 25.0f) / 15.0f, 0.0f);
         const V3 extinction = rayleigh_scattering + v3s(rayleigh_absorption) + v3s(mie_scattering) + v3s(mie_absorption) + ozone_absorption;
@@ -228,9 +228,9 @@ struct Engine {
     uint32_t light_count = 0; V3 sun_dir_ = v3s(0.0f);
 
     std::vector<uint8_t> blue_noise; bool blue_noise_dirty = true;
-    std::vector<float4> transmittance_lut, sky_lut; bool luts_dirty = true;
+    bool atmosphere_initialized = false, sky_known = false; float known_sun_altitude = 0.0f;  // passes/atmosphere.rs:14-15,78-110
 
-    DeviceArray d_bvh, d_tri_geo, d_tri_attr, d_materials, d_lights, d_atlas, d_blue_noise, d_transmittance, d_sky;
+    DeviceArray d_bvh, d_tri_geo, d_tri_attr, d_materials, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
@@ -245,8 +245,6 @@ struct Engine {
         light_buffer.push_back(sun);
         light_slot[-1] = 0;
         blue_noise.assign(256 * 256 * 4, 0);
-        transmittance_lut.assign(256 * 64, make_float4(0, 0, 0, 0));
-        sky_lut.assign(256 * 256, make_float4(0, 0, 0, 0));
         reset_profile_totals();
         if (const char* tm = getenv("ST_TILE_MAP")) tile_map = (uint32_t)atoi(tm);
     }
@@ -261,7 +259,7 @@ struct Engine {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         for (auto& kv : cameras) release_camera(*kv.second);
-        for (DeviceArray* d : {&d_bvh, &d_tri_geo, &d_tri_attr, &d_materials, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_sky}) d->release();
+        for (DeviceArray* d : {&d_bvh, &d_tri_geo, &d_tri_attr, &d_materials, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
         for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
     }
@@ -449,15 +447,9 @@ struct Engine {
                 scene_uploaded = true;
                 scene_changed = true;  // forces the stream sync below
             }
-            bool misc_uploaded = atlas_dirty || blue_noise_dirty || luts_dirty;
+            bool misc_uploaded = atlas_dirty || blue_noise_dirty;
             if (atlas_dirty) { int rc = d_atlas.upload(atlas.data(), atlas.size(), stream); if (rc) return rc; }
             if (blue_noise_dirty) { int rc = d_blue_noise.upload(blue_noise.data(), blue_noise.size(), stream); if (rc) return rc; blue_noise_dirty = false; }
-            if (luts_dirty) {
-                int rc;
-                if ((rc = d_transmittance.upload(transmittance_lut.data(), transmittance_lut.size() * sizeof(float4), stream))) return rc;
-                if ((rc = d_sky.upload(sky_lut.data(), sky_lut.size() * sizeof(float4), stream))) return rc;
-                luts_dirty = false;
-            }
             bool uploaded = scene_changed || misc_uploaded;
             // lights change rarely; skipping the identical re-upload also skips the stream sync below, so the host can
             // run a frame ahead of the GPU (the reference re-uploads only dirty buffers too: mapped_storage_buffer.rs:103-121)
@@ -578,6 +570,17 @@ struct Engine {
         };
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
         const uint32_t mode = c.desc.mode;
+        if (mode != ST_MODE_BVH_HEATMAP) {  // AtmospherePass::run (passes/atmosphere.rs:78-110)
+            if (!atmosphere_initialized) {
+                launch_atmosphere_static(static_cast<float4*>(d_transmittance.ptr), static_cast<float4*>(d_scattering.ptr), stream);
+                atmosphere_initialized = true;
+            }
+            if (!sky_known || known_sun_altitude != sun_altitude) {
+                launch_atmosphere_sky(static_cast<const float4*>(d_transmittance.ptr), static_cast<const float4*>(d_scattering.ptr), sun_altitude,
+                                      static_cast<float4*>(d_sky.ptr), stream);
+                sky_known = true; known_sun_altitude = sun_altitude;
+            }
+        }
         if (mode == ST_MODE_BVH_HEATMAP) {
             run(KS_BVH_HEATMAP, [&] { launch_bvh_heatmap(a, stream); });
         } else if (mode == ST_MODE_REFERENCE) {
@@ -670,6 +673,11 @@ int st_engine_create(int device_ordinal, StEngine** out) {
             return fail(ST_ERR_NO_DEVICE, "no HIP device with that ordinal (this library has no CPU rendering path)");
         ST_HIP(hipSetDevice(device_ordinal));
         e->device = device_ordinal; e->has_device = true;
+        // LUT storage (zero until the first non-heatmap render generates them)
+        const size_t lut_bytes[3] = {sizeof(float4) * 256 * 64, sizeof(float4) * 32 * 32, sizeof(float4) * 256 * 256};
+        DeviceArray* luts[3] = {&e->d_transmittance, &e->d_scattering, &e->d_sky};
+        for (int i = 0; i < 3; i++) { ST_HIP(hipMalloc(&luts[i]->ptr, lut_bytes[i])); luts[i]->capacity = lut_bytes[i]; ST_HIP(hipMemset(luts[i]->ptr, 0, lut_bytes[i])); }
+        ST_HIP(hipDeviceSynchronize());
     }
     *out = reinterpret_cast<StEngine*>(e.release());
     return ST_OK;
@@ -820,11 +828,18 @@ int st_set_blue_noise(StEngine* e, const uint8_t* rgba, size_t bytes) {
     E(e)->blue_noise.assign(rgba, rgba + bytes); E(e)->blue_noise_dirty = true;
     return ST_OK;
 }
-int st_set_atmosphere_luts(StEngine* e, const float* t, const float* s) {
-    ST_REQUIRE(e && t && s, "null argument");
-    memcpy(E(e)->transmittance_lut.data(), t, sizeof(float4) * 256 * 64);
-    memcpy(E(e)->sky_lut.data(), s, sizeof(float4) * 256 * 256);
-    E(e)->luts_dirty = true;
+int st_debug_read_lut(StEngine* e, int what, float* out, size_t capacity_floats, size_t* written_floats) {
+    ST_REQUIRE(e && what >= 0 && what < 3, "bad lut id");
+    Engine* en = E(e);
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "host-only engine has no LUTs");
+    const size_t n[3] = {256 * 64 * 4, 32 * 32 * 4, 256 * 256 * 4};
+    const DeviceArray* src[3] = {&en->d_transmittance, &en->d_scattering, &en->d_sky};
+    if (written_floats) *written_floats = n[what];
+    if (!out) return ST_OK;
+    ST_REQUIRE(capacity_floats >= n[what], "buffer too small");
+    ST_HIP(hipSetDevice(en->device));
+    ST_HIP(hipDeviceSynchronize());
+    ST_HIP(hipMemcpy(out, src[what]->ptr, n[what] * sizeof(float), hipMemcpyDeviceToHost));
     return ST_OK;
 }
 

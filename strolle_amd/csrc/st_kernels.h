@@ -32,6 +32,9 @@ inline const KernelInfo& kernel_info(int slot) {
     return k[slot];
 }
 
+// atmosphere LUTs (passes/atmosphere.rs: transmittance + scattering once, sky on sun-altitude change)
+void launch_atmosphere_static(float4* transmittance_lut, float4* scattering_lut, hipStream_t s);
+void launch_atmosphere_sky(const float4* transmittance_lut, const float4* scattering_lut, float sun_altitude, float4* sky_lut, hipStream_t s);
 // ray-tracing passes
 void launch_bvh_heatmap(const KArgs& a, hipStream_t s);
 void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s);

@@ -229,3 +229,29 @@ def test_row_bands_image_mode_seam_psnr():
     value = psnr(np.clip(tiled[..., :3], 0, 1), np.clip(single[..., :3], 0, 1))
     print("seam PSNR (2 bands, apron 64) =", value)
     assert value >= 35.0, value
+
+
+def test_atmosphere_luts_and_daylight_bit_exact():
+    """the three LUT-generation kernels (transmittance, multi-scattering, sky view) against the
+    oracle, texel for texel (f16-rounded), then a daylight dungeon frame sequence that samples them."""
+    torch = _torch()
+    from strolle_amd import Sun
+    size = (160, 96)
+
+    def build(e):
+        scenes.build_dungeon(e)
+        e.update_sun(Sun(azimuth=0.6, altitude=0.5))
+    prod, orac, desc, cp, co = _pair(build, size, CameraMode.IMAGE, camera_fn=scenes.dungeon_camera)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(7):
+        if frame == 4:  # the sky LUT is regenerated when the sun's altitude changes (passes/atmosphere.rs:98-109)
+            for e in (prod, orac):
+                e.update_sun(Sun(azimuth=0.7, altitude=0.2))
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        if frame in (0, 4):
+            for what, name in enumerate(("transmittance", "scattering", "sky")):
+                lut = orac.read_lut(what)
+                assert np.isfinite(lut).all() and lut[..., :3].max() > 0
+                assert_bits_equal(prod.read_lut(what), lut, f"{name} LUT at frame {frame}")
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"daylight frame {frame}")
