@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_reproject(const KArgs
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const float4 sample = tex_read(samples, a, pos);
-    if (tex_read(a.sm, a, pos).z == 0.0f) { tex_write(colors, a, pos, sample); return; }  // sky
+    if (tex_read(a.sn, a, pos).w == 0.0f) { tex_write(colors, a, pos, sample); return; }  // sky
     const float sample_luma = luma(xyz(sample));
     const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, pos));
     V3 color, moment;
@@ -47,7 +47,7 @@ void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const f
 __global__ __launch_bounds__(kBlockThreads) void k_denoise_variance(const KArgs a) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    const Surface cs = surface_from(tex_read(a.sm, a, pos));
+    const Surface cs = surface_decoded(tex_read(a.sn, a, pos));
     const float4 cdi = tex_read(a.di_diff_curr_colors, a, pos), cdi_m = tex_read(a.di_diff_moments, a, pos);
     const float4 cgi = tex_read(a.gi_diff_curr_colors, a, pos), cgi_m = tex_read(a.gi_diff_moments, a, pos);
     if (cs.depth == 0.0f) { tex_write(a.di_diff_stash, a, pos, cdi); tex_write(a.gi_diff_stash, a, pos, cgi); return; }
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_variance(const KArgs 
             const I2 sp = i2((int32_t)pos.x + ox, (int32_t)pos.y + oy);
             if (contains_i(a, sp)) {
                 const U2 up = u2((uint32_t)sp.x, (uint32_t)sp.y);
-                const Surface ss = surface_from(tex_read(a.sm, a, up));
+                const Surface ss = surface_decoded(tex_read(a.sn, a, up));
                 if (ss.depth != 0.0f) {
                     const float l = luma(xyz(tex_read(a.di_diff_curr_colors, a, up)));
                     const float w = denoise_sample_weight(cdi_luma, cs, l, ss, 1.0f, 0.2f);
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a
                                                                     const float4* gi_in, float4* gi_out) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    const Surface cs = surface_from(tex_read(a.sm, a, pos));
+    const Surface cs = surface_decoded(tex_read(a.sn, a, pos));
     const float4 cdi = tex_read(di_in, a, pos);
     if (cs.depth == 0.0f) { tex_write(di_out, a, pos, cdi); return; }
     const float4 cgi = tex_read(gi_in, a, pos);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a
             const I2 sp = i2((int32_t)pos.x + jitter.x + ox * (int32_t)stride, (int32_t)pos.y + jitter.y + oy * (int32_t)stride);
             if (!contains_i(a, sp)) continue;
             const U2 up = u2((uint32_t)sp.x, (uint32_t)sp.y);
-            const Surface ss = surface_from(tex_read(a.sm, a, up));
+            const Surface ss = surface_decoded(tex_read(a.sn, a, up));
             if (ss.depth == 0.0f) continue;
             const float4 sdi = tex_read(di_in, a, up);
             const float w = denoise_sample_weight(cdi_luma, cs, luma(xyz(sdi)), ss, luma_sigma_di, depth_sigma_di);

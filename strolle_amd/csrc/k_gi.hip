@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_preview(const KArgs a, uin
         const V2 disk = wn.sample_disk();
         const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
         if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) return;  // sic: `return`, not `continue` (:84-86) — nothing is written
-        const Surface ss = surface_from(tex_read(a.sm, a, sample_pos));
+        const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
         if (ss.depth == 0.0f) continue;
         if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
         if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a
     count_rays(a.ray_counter, used_);
     if (!hit_is_some(hit)) {  // LoadOp::Clear(TRANSPARENT)
         tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z()); tex_write(a.sm, a, pos, f4z()); tex_write(a.velocity, a, pos, f4z());
+        tex_write(a.sn, a, pos, f4z());
         return;
     }
     const GpuMaterial material = a.materials[hit.material_id];
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a
     tex_write(a.g1, a, pos, d1);
     const V2 en = normal_encode(hit.normal);
     tex_write(a.sm, a, pos, make_float4(en.x, en.y, g.depth, material.roughness));
+    tex_write(a.sn, a, pos, f4(normal_decode(en), g.depth));
     // static instances: prev_point == point (prev_xform * curr_xform_inv == identity)
     const V2 velocity = clip_to_screen(a.cam, world_to_clip(a.cam, hit.point)) - clip_to_screen(a.prev_cam, world_to_clip(a.prev_cam, hit.point));
     tex_write(a.velocity, a, pos, dot(velocity, velocity) >= 0.001f ? make_float4(velocity.x, velocity.y, 0.0f, 0.0f) : f4z());
@@ -161,13 +163,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_frame_reprojection(const KArg
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     Reprojection rp; rp.prev_x = 0.0f; rp.prev_y = 0.0f; rp.confidence = 0.0f; rp.validity = 0u;
-    const Surface surface = surface_from(tex_read(a.sm, a, pos));
+    const Surface surface = surface_decoded(tex_read(a.sn, a, pos));
     if (surface.depth != 0.0f) {
         const float4 vel = tex_read(a.velocity, a, pos);
         const V2 prev_screen_pos = as_v2(pos) - v2(vel.x, vel.y);
         const V2 rounded = round2(prev_screen_pos);
         if (contains_f(a, rounded)) {
-            const float confidence = surface_similarity(surface_from(tex_read(a.psm, a, as_u2(rounded))), surface);
+            const float confidence = surface_similarity(surface_decoded(tex_read(a.psn, a, as_u2(rounded))), surface);
             if (confidence > 0.0f) { rp.prev_x = prev_screen_pos.x; rp.prev_y = prev_screen_pos.y; rp.confidence = confidence; }
         }
         if (rp.confidence > 0.0f) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_frame_reprojection(const KArg
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (!contains_i(a, p[i])) continue;
-                if (surface_similarity(surface_from(tex_read(a.psm, a, u2((uint32_t)p[i].x, (uint32_t)p[i].y))), surface) >= 0.25f) rp.validity |= (1u << i);
+                if (surface_similarity(surface_decoded(tex_read(a.psn, a, u2((uint32_t)p[i].x, (uint32_t)p[i].y))), surface) >= 0.25f) rp.validity |= (1u << i);
             }
         }
     }

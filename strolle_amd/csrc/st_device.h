@@ -353,6 +353,7 @@ ST_D float clamped_roughness(const GBuffer& g) { return clampf(g.roughness, 0.08
 
 struct Surface { V3 normal; float depth, roughness; };
 ST_D Surface surface_from(float4 d) { Surface s; s.normal = normal_decode(v2(d.x, d.y)); s.depth = d.z; s.roughness = d.w; return s; }
+ST_D Surface surface_decoded(float4 d) { Surface s; s.normal = v3(d.x, d.y, d.z); s.depth = d.w; s.roughness = 0.0f; return s; }  // from KArgs::sn
 ST_D float surface_similarity(const Surface& self, const Surface& other) {  // surface.rs:21-47
     if (self.depth == 0.0f || other.depth == 0.0f) return 0.0f;
     const float d = fmax_(dot(self.normal, other.normal), 0.0f);

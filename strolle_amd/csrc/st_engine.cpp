@@ -163,8 +163,8 @@ struct CameraState {
     GpuCamera curr{}, prev{};
     uint32_t frame = 0, row0 = 0, row1 = 0;
     void* slab = nullptr; size_t slab_bytes = 0;
-    float4* plane[ST_BUF_COUNT] = {};
-    size_t plane_bytes[ST_BUF_COUNT] = {};
+    float4* plane[ST_BUF_COUNT + 2] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
+    size_t plane_bytes[ST_BUF_COUNT + 2] = {};
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
 };
@@ -485,7 +485,7 @@ struct Engine {
         release_camera(c);
         const size_t n = (size_t)c.desc.width * c.desc.height;
         size_t total = 0;
-        for (int i = 0; i < ST_BUF_COUNT; i++) {
+        for (int i = 0; i < ST_BUF_COUNT + 2; i++) {
             c.plane_bytes[i] = i == ST_BUF_DBG_USED_MEMORY ? n * 4 : n * 16 * plane_texels_per_pixel(i);
             total += (c.plane_bytes[i] + 255) & ~size_t(255);
         }
@@ -493,7 +493,7 @@ struct Engine {
         ST_HIP(hipMemset(c.slab, 0, total));  // wgpu zero-initialises resources; stale-data paths depend on it
         c.slab_bytes = total;
         size_t off = 0;
-        for (int i = 0; i < ST_BUF_COUNT; i++) { c.plane[i] = reinterpret_cast<float4*>(static_cast<char*>(c.slab) + off); off += (c.plane_bytes[i] + 255) & ~size_t(255); }
+        for (int i = 0; i < ST_BUF_COUNT + 2; i++) { c.plane[i] = reinterpret_cast<float4*>(static_cast<char*>(c.slab) + off); off += (c.plane_bytes[i] + 255) & ~size_t(255); }
         ST_HIP(hipMalloc(reinterpret_cast<void**>(&c.counters), kCounterBytes));
         ST_HIP(hipMemset(c.counters, 0, kCounterBytes));
         memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
@@ -544,6 +544,7 @@ struct Engine {
         a.g0 = P(alt ? ST_BUF_PRIM_GBUFFER_D0_B : ST_BUF_PRIM_GBUFFER_D0_A); a.pg0 = P(alt ? ST_BUF_PRIM_GBUFFER_D0_A : ST_BUF_PRIM_GBUFFER_D0_B);
         a.g1 = P(alt ? ST_BUF_PRIM_GBUFFER_D1_B : ST_BUF_PRIM_GBUFFER_D1_A); a.pg1 = P(alt ? ST_BUF_PRIM_GBUFFER_D1_A : ST_BUF_PRIM_GBUFFER_D1_B);
         a.sm = P(alt ? ST_BUF_PRIM_SURFACE_MAP_B : ST_BUF_PRIM_SURFACE_MAP_A); a.psm = P(alt ? ST_BUF_PRIM_SURFACE_MAP_A : ST_BUF_PRIM_SURFACE_MAP_B);
+        a.sn = P(ST_BUF_COUNT + (alt ? 1 : 0)); a.psn = P(ST_BUF_COUNT + (alt ? 0 : 1));
         a.reprojection = P(ST_BUF_REPROJECTION_MAP); a.velocity = P(ST_BUF_VELOCITY_MAP);
         for (int i = 0; i < 3; i++) a.di_res[i] = P(ST_BUF_DI_RESERVOIRS_0 + i);
         a.di_diff_samples = P(ST_BUF_DI_DIFF_SAMPLES); a.di_diff_prev_colors = P(ST_BUF_DI_DIFF_PREV_COLORS); a.di_diff_curr_colors = P(ST_BUF_DI_DIFF_CURR_COLORS);

@@ -51,6 +51,10 @@ struct KArgs {
     // per-camera planes (A/B resolved for this frame)
     float4 *g0, *g1, *sm;                // prim_gbuffer_d0/d1, prim_surface_map (curr)
     const float4 *pg0, *pg1, *psm;       // previous frame's
+    // Decoded twin of the surface map: (normal.xyz, depth) per pixel, written by primary visibility. Neighbour-tap loops
+    // (à-trous, variance, preview resampling, reprojection validity) read it instead of re-running the octahedral decode
+    // (a sqrt and a division per tap); the bytes per tap are the same 16. Not part of the reference's buffer set.
+    float4* sn; const float4* psn;
     float4 *reprojection, *velocity;
     float4* di_res[3];
     float4 *di_diff_samples, *di_diff_prev_colors, *di_diff_curr_colors, *di_diff_moments, *di_diff_stash, *di_spec_samples;
