@@ -1,6 +1,7 @@
 // k_common.h — per-kernel boilerplate: tile/pixel resolution and launch geometry.
 #pragma once
 #include "st_device.h"
+#include "st_passes.h"
 #include "st_kernels.h"
 
 namespace st {

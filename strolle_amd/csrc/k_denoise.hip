@@ -19,24 +19,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_reproject(const KArgs
                                                                       const float4* samples, float4* colors, float4* moments) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    const float4 sample = tex_read(samples, a, pos);
-    if (tex_read(a.sn, a, pos).w == 0.0f) { tex_write(colors, a, pos, sample); return; }  // sky
-    const float sample_luma = luma(xyz(sample));
-    const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, pos));
-    V3 color, moment;
-    if (rp.confidence > 0.0f && sample.w > 0.0f) {
-        const float4 pc = bilinear_reproject(a, rp, prev_colors);
-        const float4 pm = bilinear_reproject(a, rp, prev_moments);
-        const float curr_history = fmin_(pm.x + 1.0f, 16.0f);
-        const float alpha = 1.0f / curr_history;
-        color = lerp3(xyz(pc), xyz(sample), alpha);
-        moment = v3(curr_history, lerpf(pm.y, sample_luma, alpha), lerpf(pm.z, sample_luma * sample_luma, alpha));
-    } else {
-        color = xyz(sample);
-        moment = v3(1.0f, sample_luma, sample_luma * sample_luma);
-    }
-    tex_write(colors, a, pos, f4(color, 0.0f));
-    tex_write(moments, a, pos, f4(moment, 0.0f));
+    denoise_reproject_pixel(a, pos, tex_read(samples, a, pos), prev_colors, prev_moments, colors, moments);
 }
 void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const float4* prev_moments, const float4* samples, float4* colors,
                               float4* moments, hipStream_t s) {
@@ -87,13 +70,21 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_variance(const KArgs 
 void launch_denoise_variance(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a); }
 
 // ---------------------------------------------------------------- frame_denoising.rs:219-361
+// COMPOSE: the last wavelet pass also runs frame composition for its pixel (frame_composition.rs) — the composed frame
+// needs only this pixel's denoised colours, which are in registers here.
+template <bool COMPOSE>
 __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out,
-                                                                    const float4* gi_in, float4* gi_out) {
+                                                                    const float4* gi_in, float4* gi_out, uint32_t camera_mode, float4* frame_out) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Surface cs = surface_decoded(tex_read(a.sn, a, pos));
     const float4 cdi = tex_read(di_in, a, pos);
-    if (cs.depth == 0.0f) { tex_write(di_out, a, pos, cdi); return; }
+    if (cs.depth == 0.0f) {
+        tex_write(di_out, a, pos, cdi);
+        // composition reads gi_diff_curr_colors for this pixel, which this pass leaves untouched on sky pixels
+        if (COMPOSE) frame_out[pos.y * a.width + pos.x] = compose_pixel(a, pos, camera_mode, cdi, tex_read(gi_out, a, pos));
+        return;
+    }
     const float4 cgi = tex_read(gi_in, a, pos);
     const float cdi_luma = luma(xyz(cdi)), cgi_luma = luma(xyz(cgi));
     const float luma_sigma_di = lerpf(2.5f, 0.5f, sqrtf(cdi.w));
@@ -122,12 +113,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a
             if (wg > 0.0f) { sum_gi_w += wg; sum_gi_c = sum_gi_c + wg * xyz(sgi); sum_gi_v += sqr(wg) * sgi.w; }
         }
     }
-    tex_write(di_out, a, pos, f4(sum_di_c / sum_di_w, sum_di_v / (sum_di_w * sum_di_w)));
-    tex_write(gi_out, a, pos, f4(sum_gi_c / sum_gi_w, sum_gi_v / (sum_gi_w * sum_gi_w)));
+    const float4 odi = f4(sum_di_c / sum_di_w, sum_di_v / (sum_di_w * sum_di_w));
+    const float4 ogi = f4(sum_gi_c / sum_gi_w, sum_gi_v / (sum_gi_w * sum_gi_w));
+    tex_write(di_out, a, pos, odi);
+    tex_write(gi_out, a, pos, ogi);
+    if (COMPOSE) frame_out[pos.y * a.width + pos.x] = compose_pixel(a, pos, camera_mode, odi, ogi);
 }
 void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
                             float4* gi_out, hipStream_t s) {
-    ST_LAUNCH(k_denoise_wavelet, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out);
+    ST_LAUNCH(k_denoise_wavelet<false>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, 0u, (float4*)nullptr);
+}
+void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
+                                    float4* gi_out, uint32_t camera_mode, float4* frame_out, hipStream_t s) {
+    ST_LAUNCH(k_denoise_wavelet<true>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, camera_mode, frame_out);
 }
 
 }  // namespace st

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_spatial_sample(const KArgs
 void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_spatial_sample, true, s, a, seed); }
 
 // ---------------------------------------------------------------- di_resolving.rs:3-119
+// REPROJECT: the DI half of frame_denoising.rs::reproject is appended (it reads only this pixel's fresh diffuse sample
+// plus previous-frame planes).
+template <bool REPROJECT>
 __global__ __launch_bounds__(kBlockThreads) void k_di_resolving(const KArgs a) {
     __shared__ uint32_t lds[kStackWords];
     uint32_t used_ = 0u;
@@ -184,10 +187,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_resolving(const KArgs a) {
         spec_brdf = v3s(0.0f);
     }
     const float diff_brdf = (1.0f - hit.g.metallic) / kPi;
-    tex_write(a.di_diff_samples, a, pos, f4(radiance * diff_brdf, confidence));
+    const float4 diff = f4(radiance * diff_brdf, confidence);
+    tex_write(a.di_diff_samples, a, pos, diff);
     tex_write(a.di_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
     di_write(a.di_res[0], idx, res);
+    if (REPROJECT) denoise_reproject_pixel(a, pos, diff, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_curr_colors, a.di_diff_moments);
 }
-void launch_di_resolving(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_di_resolving, false, s, a); }
+void launch_di_resolving(const KArgs& a, bool reproject, hipStream_t s) {
+    if (reproject) ST_LAUNCH(k_di_resolving<true>, false, s, a); else ST_LAUNCH(k_di_resolving<false>, false, s, a);
+}
 
 }  // namespace st

@@ -288,47 +288,66 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_spatial_sample(const KArgs
 void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_spatial_sample, true, s, a, seed); }
 
 // ---------------------------------------------------------------- gi_preview_resampling.rs:3-138
-__global__ __launch_bounds__(kBlockThreads) void k_gi_preview(const KArgs a, uint32_t seed, uint32_t nth, const float4* in, float4* out) {
+// RESOLVE (second preview pass only): gi_resolving.rs and, if `reproject`, the GI half of frame_denoising.rs::reproject run
+// for the same pixel right here. Resolving consumes exactly what this pass would have stored at gi_res[0][pixel] — the merged
+// reservoir, an empty one on sky, or (the reference's early `return`, :84-86) whatever gi_res[0] already held — and then
+// overwrites that slot with the frame's source reservoir, so the intermediate store is dropped.
+template <bool RESOLVE>
+__global__ __launch_bounds__(kBlockThreads) void k_gi_preview(const KArgs a, uint32_t seed, uint32_t nth, const float4* in, float4* out, uint32_t source,
+                                                              uint32_t reproject) {
     U2 center_pos;
     if (!resolve_gid(a, false, &center_pos) || !owns_pixel(a, center_pos)) return;
     const uint32_t n = a.width * a.height;
     const uint32_t center_idx = screen_to_idx(a, center_pos);
     WhiteNoise wn = white_noise(seed, center_pos);
     const Hit center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
-    if (!hit_some(center_hit)) { gi_write(out, center_idx, gi_empty()); return; }
     GiReservoir main_ = gi_empty();
-    float main_pdf = 0.0f;
-    const GiReservoir center = gi_read(in, center_idx, n);
-    if (res_merge(main_, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
-    const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main_.m / 8.0f));
-    const float max_radius = nth == 0u ? 128.0f : 64.0f;
-    uint32_t sample_nth = 0u;
-    while (sample_nth < max_samples) {
-        sample_nth += 1u;
-        const V2 disk = wn.sample_disk();
-        const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
-        if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) return;  // sic: `return`, not `continue` (:84-86) — nothing is written
-        const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
-        if (ss.depth == 0.0f) continue;
-        if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
-        if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
-        const GiReservoir s = gi_read(in, screen_to_idx(a, sample_pos), n);
-        if (s.m == 0.0f) continue;
-        const float sample_pdf = gi_pdf(s.s, center_hit);
-        float sample_jacobian = gi_jacobian(s.s, center_hit.point);
-        if (sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f) continue;
-        sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
-        if (res_merge(main_, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
+    bool keep_stored = false;  // the reference's early `return`: the output slot keeps its previous contents
+    if (hit_some(center_hit)) {
+        float main_pdf = 0.0f;
+        const GiReservoir center = gi_read(in, center_idx, n);
+        if (res_merge(main_, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
+        const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main_.m / 8.0f));
+        const float max_radius = nth == 0u ? 128.0f : 64.0f;
+        uint32_t sample_nth = 0u;
+        while (sample_nth < max_samples) {
+            sample_nth += 1u;
+            const V2 disk = wn.sample_disk();
+            const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
+            if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) { keep_stored = true; break; }  // sic: `return`, not `continue`
+            const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
+            if (ss.depth == 0.0f) continue;
+            if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
+            if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
+            const GiReservoir s = gi_read(in, screen_to_idx(a, sample_pos), n);
+            if (s.m == 0.0f) continue;
+            const float sample_pdf = gi_pdf(s.s, center_hit);
+            float sample_jacobian = gi_jacobian(s.s, center_hit.point);
+            if (sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f) continue;
+            sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
+            if (res_merge(main_, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
+        }
+        if (!keep_stored) {
+            main_.confidence = center.confidence;
+            main_.s.pdf = main_pdf;
+            main_.s.v1_point = center.s.v1_point;
+            res_norm(main_, main_pdf, 1.0f, main_.m);
+            main_.w = fmin_(main_.w, 5.0f);
+        }
     }
-    main_.confidence = center.confidence;
-    main_.s.pdf = main_pdf;
-    main_.s.v1_point = center.s.v1_point;
-    res_norm(main_, main_pdf, 1.0f, main_.m);
-    main_.w = fmin_(main_.w, 5.0f);
-    gi_write(out, center_idx, main_);
+    if (!RESOLVE) {
+        if (!keep_stored) gi_write(out, center_idx, main_);
+        return;
+    }
+    if (keep_stored) main_ = gi_read(out, center_idx, n);
+    const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, main_, source);
+    if (reproject) denoise_reproject_pixel(a, center_pos, diff, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_curr_colors, a.gi_diff_moments);
 }
 void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s) {
-    ST_LAUNCH(k_gi_preview, false, s, a, seed, nth, in, out);
+    ST_LAUNCH(k_gi_preview<false>, false, s, a, seed, nth, in, out, 0u, 0u);
+}
+void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, uint32_t source, bool reproject, hipStream_t s) {
+    ST_LAUNCH(k_gi_preview<true>, false, s, a, seed, nth, in, a.gi_res[0], source, reproject ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------- gi_resolving.rs:3-67
@@ -337,18 +356,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_resolving(const KArgs a, u
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const uint32_t n = a.width * a.height;
     const uint32_t idx = screen_to_idx(a, pos);
-    const float4* in = source == 0u ? a.gi_res[1] : a.gi_res[2];
-    float4* out = a.gi_res[0];
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
-    const GiReservoir res = gi_read(out, idx, n);
-    float confidence; V3 radiance;
-    if (hit_some(hit)) { confidence = res.confidence; radiance = res.w * gi_cosine(res.s, hit) * res.s.radiance; }
-    else { confidence = 1.0f; radiance = v3s(0.0f); }
-    const float diff_brdf = (1.0f - hit.g.metallic) / kPi;
-    const V3 spec_brdf = gi_spec_brdf(res.s, hit);
-    tex_write(a.gi_diff_samples, a, pos, f4(radiance * diff_brdf, confidence));
-    tex_write(a.gi_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
-    gi_write(out, idx, gi_read(in, idx, n));
+    gi_resolve_pixel(a, pos, idx, hit, gi_read(a.gi_res[0], idx, n), source);
 }
 void launch_gi_resolving(const KArgs& a, uint32_t source, hipStream_t s) { ST_LAUNCH(k_gi_resolving, false, s, a, source); }
 

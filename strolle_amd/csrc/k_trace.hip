@@ -122,6 +122,32 @@ __global__ __launch_bounds__(kBlockThreads) void k_ref_shading(const KArgs a, ui
 void launch_ref_shading(const KArgs& a, uint32_t seed, uint32_t depth, hipStream_t s) { ST_LAUNCH(k_ref_shading, false, s, a, seed, depth); }
 
 // ---------------------------------------------------------------- primary visibility (prim_raster.rs:40-128 as one closest-hit ray per pixel)
+// frame_reprojection.rs:6-95 for one pixel, given its own fresh surface and velocity
+ST_D void frame_reprojection_pixel(const KArgs& a, U2 pos, const Surface& surface, V2 velocity) {
+    Reprojection rp; rp.prev_x = 0.0f; rp.prev_y = 0.0f; rp.confidence = 0.0f; rp.validity = 0u;
+    if (surface.depth != 0.0f) {
+        const V2 prev_screen_pos = as_v2(pos) - velocity;
+        const V2 rounded = round2(prev_screen_pos);
+        if (contains_f(a, rounded)) {
+            const float confidence = surface_similarity(surface_decoded(tex_read(a.psn, a, as_u2(rounded))), surface);
+            if (confidence > 0.0f) { rp.prev_x = prev_screen_pos.x; rp.prev_y = prev_screen_pos.y; rp.confidence = confidence; }
+        }
+        if (rp.confidence > 0.0f) {
+            const float fl_x = floorf(rp.prev_x), fl_y = floorf(rp.prev_y), ce_x = ceilf(rp.prev_x), ce_y = ceilf(rp.prev_y);
+            const I2 p[4] = {i2(f2i_sat(fl_x), f2i_sat(fl_y)), i2(f2i_sat(ce_x), f2i_sat(fl_y)), i2(f2i_sat(fl_x), f2i_sat(ce_y)), i2(f2i_sat(ce_x), f2i_sat(ce_y))};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (!contains_i(a, p[i])) continue;
+                if (surface_similarity(surface_decoded(tex_read(a.psn, a, u2((uint32_t)p[i].x, (uint32_t)p[i].y))), surface) >= 0.25f) rp.validity |= (1u << i);
+            }
+        }
+    }
+    tex_write(a.reprojection, a, pos, make_float4(rp.prev_x, rp.prev_y, rp.confidence, b2f(rp.validity)));
+}
+
+// REPROJECT: frame_reprojection runs in the same kernel (it needs this pixel's new surface + velocity and the PREVIOUS
+// frame's surfaces only).
+template <bool REPROJECT>
 __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a) {
     __shared__ uint32_t lds[kStackWords];
     uint32_t used_ = 0u;
@@ -133,6 +159,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a
     if (!hit_is_some(hit)) {  // LoadOp::Clear(TRANSPARENT)
         tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z()); tex_write(a.sm, a, pos, f4z()); tex_write(a.velocity, a, pos, f4z());
         tex_write(a.sn, a, pos, f4z());
+        if (REPROJECT) tex_write(a.reprojection, a, pos, f4z());
         return;
     }
     const GpuMaterial material = a.materials[hit.material_id];
@@ -154,35 +181,23 @@ __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a
     tex_write(a.sn, a, pos, f4(normal_decode(en), g.depth));
     // static instances: prev_point == point (prev_xform * curr_xform_inv == identity)
     const V2 velocity = clip_to_screen(a.cam, world_to_clip(a.cam, hit.point)) - clip_to_screen(a.prev_cam, world_to_clip(a.prev_cam, hit.point));
-    tex_write(a.velocity, a, pos, dot(velocity, velocity) >= 0.001f ? make_float4(velocity.x, velocity.y, 0.0f, 0.0f) : f4z());
+    const bool moving = dot(velocity, velocity) >= 0.001f;
+    tex_write(a.velocity, a, pos, moving ? make_float4(velocity.x, velocity.y, 0.0f, 0.0f) : f4z());
+    if (REPROJECT) {
+        Surface surface; surface.normal = normal_decode(en); surface.depth = g.depth; surface.roughness = 0.0f;
+        frame_reprojection_pixel(a, pos, surface, moving ? velocity : v2(0.0f, 0.0f));
+    }
 }
-void launch_prim_visibility(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_prim_visibility, false, s, a); }
+void launch_prim_visibility(const KArgs& a, bool reproject, hipStream_t s) {
+    if (reproject) ST_LAUNCH(k_prim_visibility<true>, false, s, a); else ST_LAUNCH(k_prim_visibility<false>, false, s, a);
+}
 
 // ---------------------------------------------------------------- frame_reprojection.rs:6-95
 __global__ __launch_bounds__(kBlockThreads) void k_frame_reprojection(const KArgs a) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    Reprojection rp; rp.prev_x = 0.0f; rp.prev_y = 0.0f; rp.confidence = 0.0f; rp.validity = 0u;
-    const Surface surface = surface_decoded(tex_read(a.sn, a, pos));
-    if (surface.depth != 0.0f) {
-        const float4 vel = tex_read(a.velocity, a, pos);
-        const V2 prev_screen_pos = as_v2(pos) - v2(vel.x, vel.y);
-        const V2 rounded = round2(prev_screen_pos);
-        if (contains_f(a, rounded)) {
-            const float confidence = surface_similarity(surface_decoded(tex_read(a.psn, a, as_u2(rounded))), surface);
-            if (confidence > 0.0f) { rp.prev_x = prev_screen_pos.x; rp.prev_y = prev_screen_pos.y; rp.confidence = confidence; }
-        }
-        if (rp.confidence > 0.0f) {
-            const float fl_x = floorf(rp.prev_x), fl_y = floorf(rp.prev_y), ce_x = ceilf(rp.prev_x), ce_y = ceilf(rp.prev_y);
-            const I2 p[4] = {i2(f2i_sat(fl_x), f2i_sat(fl_y)), i2(f2i_sat(ce_x), f2i_sat(fl_y)), i2(f2i_sat(fl_x), f2i_sat(ce_y)), i2(f2i_sat(ce_x), f2i_sat(ce_y))};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (!contains_i(a, p[i])) continue;
-                if (surface_similarity(surface_decoded(tex_read(a.psn, a, u2((uint32_t)p[i].x, (uint32_t)p[i].y))), surface) >= 0.25f) rp.validity |= (1u << i);
-            }
-        }
-    }
-    tex_write(a.reprojection, a, pos, make_float4(rp.prev_x, rp.prev_y, rp.confidence, b2f(rp.validity)));
+    const float4 vel = tex_read(a.velocity, a, pos);
+    frame_reprojection_pixel(a, pos, surface_decoded(tex_read(a.sn, a, pos)), v2(vel.x, vel.y));
 }
 void launch_frame_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_frame_reprojection, false, s, a); }
 
@@ -208,24 +223,7 @@ void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* bu
 __global__ __launch_bounds__(kBlockThreads) void k_composition(const KArgs a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    V3 color;
-    switch (camera_mode) {
-        case 0: {
-            const GBuffer g = gbuffer_unpack(tex_read(a.g0, a, pos), tex_read(a.g1, a, pos));
-            const V3 dd = xyz(tex_read(di_diff, a, pos)), ds = xyz(tex_read(a.di_spec_samples, a, pos));
-            const V3 gd = xyz(tex_read(gi_diff, a, pos)), gs = xyz(tex_read(a.gi_spec_samples, a, pos));
-            color = g.depth != 0.0f ? g.emissive + (dd + gd) * xyz(g.base_color) + ds + gs : dd;
-            break;
-        }
-        case 1: color = xyz(tex_read(di_diff, a, pos)); break;
-        case 2: color = xyz(tex_read(a.di_spec_samples, a, pos)); break;
-        case 3: color = xyz(tex_read(gi_diff, a, pos)); break;
-        case 4: color = xyz(tex_read(a.gi_spec_samples, a, pos)); break;
-        case 5: color = xyz(tex_read(a.ref_colors, a, pos)); break;
-        case 6: { const float4 c = tex_read(a.ref_colors, a, pos); color = xyz(c) / c.w; break; }
-        default: color = v3s(0.0f);
-    }
-    out[pos.y * a.width + pos.x] = f4(color, 1.0f);
+    out[pos.y * a.width + pos.x] = compose_pixel(a, pos, camera_mode, tex_read(di_diff, a, pos), tex_read(gi_diff, a, pos));
 }
 void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out, hipStream_t s) {
     ST_LAUNCH(k_composition, false, s, a, camera_mode, di_diff, gi_diff, out);

@@ -234,6 +234,7 @@ struct Engine {
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
+    bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
     uint32_t tile_map = 2;  // blockIdx -> tile mapping (st_device.h); 2 measured best on MI355X; ST_TILE_MAP overrides
     bool profiling = false;
     std::vector<ProfileRecord> profile_records; std::vector<hipEvent_t> event_pool;
@@ -247,6 +248,7 @@ struct Engine {
         blue_noise.assign(256 * 256 * 4, 0);
         reset_profile_totals();
         if (const char* tm = getenv("ST_TILE_MAP")) tile_map = (uint32_t)atoi(tm);
+        if (const char* nf = getenv("ST_NO_FUSE")) fuse = atoi(nf) == 0;
     }
     void reset_profile_totals() {
         for (int i = 0; i < KS_COUNT; i++) {
@@ -562,15 +564,23 @@ struct Engine {
         a.tile_map = tile_map;
 
         const double rows = (double)(c.row1 - c.row0);
-        auto run = [&](int slot, auto&& launch) {
+        auto slot_bytes = [&](int slot) {
             const KernelInfo& ki = kernel_info(slot);
             const double units = rows * (ki.half ? (double)(((c.desc.width + 7u) / 8u / 2u) * 8u) : (double)c.desc.width);
+            return units * ki.bytes_per_unit;
+        };
+        // `fused`: reference passes executed inside this launch. Their (unfused) algorithmic bytes are credited to the
+        // launching slot so that fusion shows up as a gain, not as a moved goalpost.
+        auto run = [&](int slot, std::initializer_list<int> fused, auto&& launch) {
+            double bytes = slot_bytes(slot);
+            for (int f : fused) bytes += slot_bytes(f);
             a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
-            Scope scope(this, stream, slot, units * ki.bytes_per_unit);
+            Scope scope(this, stream, slot, bytes);
             launch();
         };
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
         const uint32_t mode = c.desc.mode;
+        bool di_reprojected = false, gi_reprojected = false, composed = false;
         if (mode != ST_MODE_BVH_HEATMAP) {  // AtmospherePass::run (passes/atmosphere.rs:78-110)
             if (!atmosphere_initialized) {
                 launch_atmosphere_static(static_cast<float4*>(d_transmittance.ptr), static_cast<float4*>(d_scattering.ptr), stream);
@@ -583,72 +593,86 @@ struct Engine {
             }
         }
         if (mode == ST_MODE_BVH_HEATMAP) {
-            run(KS_BVH_HEATMAP, [&] { launch_bvh_heatmap(a, stream); });
+            run(KS_BVH_HEATMAP, {}, [&] { launch_bvh_heatmap(a, stream); });
         } else if (mode == ST_MODE_REFERENCE) {
             for (uint32_t d = 0; d <= c.desc.depth; d++) {
-                run(KS_REF_TRACING, [&] { launch_ref_tracing(a, d, stream); });
-                run(KS_REF_SHADING, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + d), d, stream); });
+                run(KS_REF_TRACING, {}, [&] { launch_ref_tracing(a, d, stream); });
+                run(KS_REF_SHADING, {}, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + d), d, stream); });
             }
-            run(KS_REF_SHADING, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + 255u), 255u, stream); });
+            run(KS_REF_SHADING, {}, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + 255u), 255u, stream); });
         } else {
             const bool needs_di = mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE || mode == ST_MODE_DI_SPECULAR;
             const bool needs_gi = mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE || mode == ST_MODE_GI_SPECULAR;
-            run(KS_PRIM_VISIBILITY, [&] { launch_prim_visibility(a, stream); });
-            if (!instances.empty()) {
-                run(KS_FRAME_REPROJECTION, [&] { launch_frame_reprojection(a, stream); });
+            const bool denoise = c.desc.denoise != 0u;
+            const bool any_objects = !instances.empty();
+            if (fuse && any_objects) run(KS_PRIM_VISIBILITY, {KS_FRAME_REPROJECTION}, [&] { launch_prim_visibility(a, true, stream); });
+            else run(KS_PRIM_VISIBILITY, {}, [&] { launch_prim_visibility(a, false, stream); });
+            if (any_objects) {
+                if (!fuse) run(KS_FRAME_REPROJECTION, {}, [&] { launch_frame_reprojection(a, stream); });
                 if (needs_di) {
-                    run(KS_DI_SAMPLING, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), stream); });
-                    run(KS_DI_TEMPORAL, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), stream); });
-                    run(KS_DI_SPATIAL_PICK, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), stream); });
-                    run(KS_DI_SPATIAL_TRACE, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, stream); });
-                    run(KS_DI_SPATIAL_SAMPLE, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), stream); });
-                    run(KS_DI_RESOLVING, [&] { launch_di_resolving(a, stream); });
+                    run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), stream); });
+                    run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), stream); });
+                    run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), stream); });
+                    run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, stream); });
+                    run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), stream); });
+                    if (fuse && denoise) { run(KS_DI_RESOLVING, {KS_DENOISE_REPROJECT}, [&] { launch_di_resolving(a, true, stream); }); di_reprojected = true; }
+                    else run(KS_DI_RESOLVING, {}, [&] { launch_di_resolving(a, false, stream); });
                 }
                 if (needs_gi) {
                     uint32_t source;
                     const bool tracing = c.frame % 6u < 4u;
-                    run(KS_GI_REPROJECTION, [&] { launch_gi_reprojection(a, stream); });
+                    run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, stream); });
                     auto sampling = [&] {
-                        run(KS_GI_SAMPLING_A, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), stream); });
-                        run(KS_GI_SAMPLING_B, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), stream); });
+                        run(KS_GI_SAMPLING_A, {}, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), stream); });
+                        run(KS_GI_SAMPLING_B, {}, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), stream); });
                     };
                     if (tracing) {
                         if (c.frame % 2u == 0u) sampling();
-                        run(KS_GI_TEMPORAL, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), stream); });
+                        run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), stream); });
                         if (c.frame % 2u == 1u) {
-                            run(KS_GI_SPATIAL_PICK, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), stream); });
-                            run(KS_GI_SPATIAL_TRACE, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, stream); });
-                            run(KS_GI_SPATIAL_SAMPLE, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), stream); });
+                            run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), stream); });
+                            run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, stream); });
+                            run(KS_GI_SPATIAL_SAMPLE, {}, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), stream); });
                             source = 1;
                         } else source = 0;
                     } else {
                         sampling();
-                        run(KS_GI_TEMPORAL, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), stream); });
+                        run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), stream); });
                         source = 0;
                     }
                     const uint32_t pseed = seed(SEED_GI_PREVIEW);  // one seed for both preview passes (passes/gi_preview_resampling.rs:60-74)
-                    run(KS_GI_PREVIEW, [&] { launch_gi_preview(a, pseed, 0u, source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], stream); });
-                    run(KS_GI_PREVIEW, [&] { launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], stream); });
-                    run(KS_GI_RESOLVING, [&] { launch_gi_resolving(a, source, stream); });
+                    run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 0u, source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], stream); });
+                    if (fuse) {
+                        if (denoise) { run(KS_GI_PREVIEW, {KS_GI_RESOLVING, KS_DENOISE_REPROJECT}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], source, true, stream); }); gi_reprojected = true; }
+                        else run(KS_GI_PREVIEW, {KS_GI_RESOLVING}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], source, false, stream); });
+                    } else {
+                        run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], stream); });
+                        run(KS_GI_RESOLVING, {}, [&] { launch_gi_resolving(a, source, stream); });
+                    }
                 }
             }
-            if (c.desc.denoise != 0u) {
-                run(KS_DENOISE_REPROJECT, [&] { launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, stream); });
-                run(KS_DENOISE_REPROJECT, [&] { launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, stream); });
-                run(KS_DENOISE_VARIANCE, [&] { launch_denoise_variance(a, stream); });
+            if (denoise) {
+                if (!di_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, stream); });
+                if (!gi_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, stream); });
+                run(KS_DENOISE_VARIANCE, {}, [&] { launch_denoise_variance(a, stream); });
                 // ping-pong (passes/frame_denoising.rs:87-110): stash -> prev -> stash -> curr -> stash -> curr
                 float4* di[3] = {a.di_diff_stash, a.di_diff_prev_colors, a.di_diff_curr_colors};
                 float4* gi[3] = {a.gi_diff_stash, a.gi_diff_prev_colors, a.gi_diff_curr_colors};
                 const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
-                for (uint32_t nth = 0; nth < 5; nth++)
-                    run(KS_DENOISE_WAVELET, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], stream); });
+                for (uint32_t nth = 0; nth < 5; nth++) {
+                    if (nth == 4 && fuse && out) {
+                        run(KS_DENOISE_WAVELET, {KS_COMPOSITION}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], mode, out, stream); });
+                        composed = true;
+                    } else
+                        run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], stream); });
+                }
             }
         }
-        if (out) {
+        if (out && !composed) {
             const bool dn = c.desc.denoise != 0u;
             const float4* di_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
             const float4* gi_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
-            run(KS_COMPOSITION, [&] { launch_composition(a, mode, di_diff, gi_diff, out, stream); });
+            run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, stream); });
         }
         ST_HIP(hipGetLastError());
         return ST_OK;

@@ -39,7 +39,7 @@ void launch_atmosphere_sky(const float4* transmittance_lut, const float4* scatte
 void launch_bvh_heatmap(const KArgs& a, hipStream_t s);
 void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s);
 void launch_ref_shading(const KArgs& a, uint32_t seed, uint32_t depth, hipStream_t s);
-void launch_prim_visibility(const KArgs& a, hipStream_t s);
+void launch_prim_visibility(const KArgs& a, bool fuse_frame_reprojection, hipStream_t s);
 void launch_frame_reprojection(const KArgs& a, hipStream_t s);
 // ReSTIR DI
 void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s);
@@ -47,7 +47,7 @@ void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s);
 void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_di_resolving(const KArgs& a, hipStream_t s);
+void launch_di_resolving(const KArgs& a, bool fuse_denoise_reproject, hipStream_t s);
 // ReSTIR GI
 void launch_gi_reprojection(const KArgs& a, hipStream_t s);
 void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s);
@@ -57,12 +57,17 @@ void launch_gi_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s);
 void launch_gi_resolving(const KArgs& a, uint32_t source, hipStream_t s);
+// second preview pass + gi_resolving (+ the GI half of denoise reproject) in one launch
+void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, uint32_t source, bool fuse_denoise_reproject, hipStream_t s);
 // SVGF + composition
 void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const float4* prev_moments, const float4* samples, float4* colors,
                               float4* moments, hipStream_t s);
 void launch_denoise_variance(const KArgs& a, hipStream_t s);
 void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
                             float4* gi_out, hipStream_t s);
+// last wavelet pass + frame composition in one launch
+void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
+                                    float4* gi_out, uint32_t camera_mode, float4* frame_out, hipStream_t s);
 void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out, hipStream_t s);
 
 }  // namespace st
