@@ -25,7 +25,11 @@ def weak_scaling_frame(base_size: Tuple[int, int], world_size: int) -> Tuple[int
 
 
 def band_for_rank(height: int, world_size: int, rank: int, align: int = 8) -> Tuple[int, int]:
-    """Rows [y0, y1) owned by `rank`: contiguous bands, multiples of the 8-row tile height except the last."""
+    """Rows [y0, y1) owned by `rank`. Equal bands when the height divides evenly (kernels mask rows outside the window,
+    so bands need not sit on 8-row tile boundaries); otherwise tile-aligned bands that differ by at most one tile row."""
+    if height % world_size == 0:
+        rows = height // world_size
+        return rank * rows, (rank + 1) * rows
     tiles = (height + align - 1) // align
     per = tiles // world_size
     extra = tiles % world_size
@@ -61,6 +65,29 @@ def gather_frame(local_frame, height: int, width: int, world_size: int, rank: in
     for r, (b0, b1) in enumerate(bands):
         out[b0:b1] = recv[r, : b1 - b0]
     return out
+
+
+def gather_bands_to_root(local_frame, full_frame, height: int, world_size: int, rank: int, dst: int = 0, group=None):
+    """The per-frame collective of the tile-parallel path: every rank sends its band, rank `dst` receives each band
+    straight into its place in `full_frame` (no staging copy). With equal bands this is one point-to-point message
+    per xGMI link into the root (RCCL implements gather as grouped send/recv), not a ring.
+    `full_frame` is only used on `dst` and may alias `local_frame` there."""
+    import torch.distributed as dist
+
+    assert height % world_size == 0, "equal bands required; use gather_frame() for ragged partitions"
+    y0, y1 = band_for_rank(height, world_size, rank)
+    send = local_frame[y0:y1]
+    if rank == dst:
+        gather_list = []
+        for r in range(world_size):
+            b0, b1 = band_for_rank(height, world_size, r)
+            gather_list.append(full_frame[b0:b1])
+        if full_frame.data_ptr() == local_frame.data_ptr():
+            send = send.clone()  # in-place: the root's own band must not alias its receive slot
+        dist.gather(send, gather_list, dst=dst, group=group)
+    else:
+        dist.gather(send, None, dst=dst, group=group)
+    return full_frame if rank == dst else None
 
 
 def assemble_bands_numpy(bands_data, height: int, width: int) -> np.ndarray:

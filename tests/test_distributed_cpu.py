@@ -16,7 +16,10 @@ def test_bands_partition_the_frame(height, world):
     for r in range(world):
         y0, y1 = band_for_rank(height, world, r)
         assert 0 <= y0 <= y1 <= height
-        assert y0 % 8 == 0 and (y1 % 8 == 0 or y1 == height)
+        if height % world:  # ragged partitions sit on 8-row tile boundaries; even ones are exactly equal
+            assert y0 % 8 == 0 and (y1 % 8 == 0 or y1 == height)
+        else:
+            assert y1 - y0 == height // world
         rows += list(range(y0, y1))
     assert rows == list(range(height))
 
@@ -31,7 +34,7 @@ def test_weak_scaling_frames():
         assert w * h == n * 1920 * 1080
         for r in range(n):
             y0, y1 = band_for_rank(h, n, r)
-            assert abs((y1 - y0) * w - 1920 * 1080) <= 8 * w  # bands are aligned to 8-row tiles
+            assert (y1 - y0) * w == 1920 * 1080
 
 
 def test_render_window_has_apron_and_stays_on_tiles():
@@ -57,6 +60,23 @@ want = assemble_bands_numpy([frame_of(r) for r in range(world)], H, W)
 assert np.array_equal(full, want), "gathered frame differs"
 y0, y1 = band_for_rank(H, world, rank)
 assert np.array_equal(full[y0:y1], frame_of(rank)[y0:y1])
+# the bench's collective: equal bands gathered straight into rank 0's frame
+from strolle_amd.distributed import gather_bands_to_root
+H2 = 64
+def frame2(r):
+    return np.random.default_rng(200 + r).standard_normal((H2, W, 4)).astype(np.float32)
+local2 = torch.from_numpy(frame2(rank))
+full2 = torch.zeros((H2, W, 4)) if rank == 0 else None
+got = gather_bands_to_root(local2, full2, H2, world, rank)
+if rank == 0:
+    assert np.array_equal(got.numpy(), assemble_bands_numpy([frame2(r) for r in range(world)], H2, W))
+    # in-place variant: the root's render target doubles as the gathered frame
+    inplace = torch.from_numpy(frame2(0))
+    gather_bands_to_root(inplace, inplace, H2, world, rank)
+    assert np.array_equal(inplace.numpy(), assemble_bands_numpy([frame2(r) for r in range(world)], H2, W))
+else:
+    assert got is None
+    gather_bands_to_root(local2, None, H2, world, rank)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

@@ -255,3 +255,17 @@ def test_atmosphere_luts_and_daylight_bit_exact():
                 assert_bits_equal(prod.read_lut(what), lut, f"{name} LUT at frame {frame}")
         _compare_all(prod, orac, cp, co, frame)
         assert_bits_equal(img, ref, f"daylight frame {frame}")
+
+
+def test_cornell_4k_reference_4spp_bit_exact():
+    """BASELINE.json config 4 on one GPU: Cornell 3840x2160, Reference{depth:1}, 4 frames accumulated with a static camera
+    (ref_shading.rs:53-67) — every pixel of the accumulated frame equals the oracle's."""
+    torch = _torch()
+    size = (3840, 2160)
+    prod, orac, desc, cp, co = _pair(scenes.build_cornell, size, CameraMode.REFERENCE, depth=1)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(4):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+    assert_bits_equal(img, ref, "4K reference, 4 spp")
+    assert np.all(prod.read_buffer(cp, Buffer.REF_COLORS).reshape(size[1], size[0], 4)[..., 3] == 4.0)
+    assert prod.ray_count(cp) == orac.ray_count(co)
