@@ -35,6 +35,15 @@ ST_D bool resolve_gid(const KArgs& a, bool half_x, U2* gid) {
 // pixel belongs to this launch: inside the viewport (Camera::contains) and inside the row window
 ST_D bool owns_pixel(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.height && p.y >= a.row0 && p.y < a.row1; }
 
+// tracing kernels are instantiated for 16- and 32-bit stack entries; the BVH stream length picks one
+#define ST_LAUNCH_TRACE(kernel_tmpl, half, stream, ...)                                                             \
+    do {                                                                                                            \
+        if (a.bvh_len < 65536u) ST_LAUNCH(ST_TPL(kernel_tmpl, uint16_t), half, stream, __VA_ARGS__);                \
+        else ST_LAUNCH(ST_TPL(kernel_tmpl, uint32_t), half, stream, __VA_ARGS__);                                   \
+    } while (0)
+#define ST_TPL(k, t) k<t>
+#define ST_TPL2(k, b, t) k<b, t>
+
 #define ST_LAUNCH(kernel, half, stream, ...)                                                          \
     do {                                                                                              \
         const LaunchDims d_ = launch_dims(a, half);                                                   \

@@ -8,8 +8,9 @@
 namespace st {
 
 // ---------------------------------------------------------------- di_sampling.rs:3-94
+template <class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, uint32_t seed) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, ui
     }
     di_write(a.di_res[1], idx, out);
 }
-void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_sampling, false, s, a, seed); }
+void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_di_sampling, false, s, a, seed); }
 
 // ---------------------------------------------------------------- di_temporal_resampling.rs:3-112
 __global__ __launch_bounds__(kBlockThreads) void k_di_temporal(const KArgs a, uint32_t seed) {
@@ -161,9 +162,9 @@ void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST
 // ---------------------------------------------------------------- di_resolving.rs:3-119
 // REPROJECT: the DI half of frame_denoising.rs::reproject is appended (it reads only this pixel's fresh diffuse sample
 // plus previous-frame planes).
-template <bool REPROJECT>
+template <bool REPROJECT, class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_di_resolving(const KArgs a) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -194,7 +195,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_resolving(const KArgs a) {
     if (REPROJECT) denoise_reproject_pixel(a, pos, diff, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_curr_colors, a.di_diff_moments);
 }
 void launch_di_resolving(const KArgs& a, bool reproject, hipStream_t s) {
-    if (reproject) ST_LAUNCH(k_di_resolving<true>, false, s, a); else ST_LAUNCH(k_di_resolving<false>, false, s, a);
+    const bool small = a.bvh_len < 65536u;
+    if (reproject) { if (small) ST_LAUNCH((k_di_resolving<true, uint16_t>), false, s, a); else ST_LAUNCH((k_di_resolving<true, uint32_t>), false, s, a); }
+    else { if (small) ST_LAUNCH((k_di_resolving<false, uint16_t>), false, s, a); else ST_LAUNCH((k_di_resolving<false, uint32_t>), false, s, a); }
 }
 
 }  // namespace st

@@ -24,8 +24,9 @@ void launch_gi_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_gi_repr
 ST_D bool frame_is_gi_tracing(uint32_t frame) { return frame % 6u < 4u; }  // frame.rs:19-21
 
 // ---------------------------------------------------------------- gi_sampling_a.rs:3-122
+template <class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_a(const KArgs a, uint32_t seed) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
@@ -66,11 +67,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_a(const KArgs a, 
     tex_write(a.gi_d1, a, gid, p0);
     tex_write(a.gi_d2, a, gid, p1);
 }
-void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_sampling_a, true, s, a, seed); }
+void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_a, true, s, a, seed); }
 
 // ---------------------------------------------------------------- gi_sampling_b.rs:3-235
+template <class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_b(const KArgs a, uint32_t seed) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_b(const KArgs a, 
     }
     gi_write(a.gi_res[1], idx, res);
 }
-void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_sampling_b, true, s, a, seed); }
+void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_b, true, s, a, seed); }
 
 // ---------------------------------------------------------------- gi_temporal_resampling.rs:3-156
 __global__ __launch_bounds__(kBlockThreads) void k_gi_temporal(const KArgs a, uint32_t seed) {

@@ -23,22 +23,24 @@ ST_D V3 heatmap_gradient(float progress) {
     }
     return c3;
 }
+template <class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_bvh_heatmap(const KArgs a) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     Candidate c; bool any;
-    const uint32_t used = traverse<false>(a, camera_ray(a.cam, pos), kF32Max, lane_stack(lds), &c, &any);
+    const uint32_t used = traverse<false, SE>(a, camera_ray(a.cam, pos), kF32Max, lane_stack(lds), &c, &any);
     count_rays(a.ray_counter, used);
     a.dbg_used_memory[screen_to_idx(a, pos)] = used;
     tex_write(a.ref_colors, a, pos, f4(heatmap_gradient((float)used / 8192.0f), 1.0f));
 }
-void launch_bvh_heatmap(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_bvh_heatmap, false, s, a); }
+void launch_bvh_heatmap(const KArgs& a, hipStream_t s) { ST_LAUNCH_TRACE(k_bvh_heatmap, false, s, a); }
 
 // ---------------------------------------------------------------- ref_tracing.rs:3-60
+template <class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_ref_tracing(const KArgs a, uint32_t depth) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -57,11 +59,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_ref_tracing(const KArgs a, ui
     a.ref_hits[2u * idx] = h0;
     a.ref_hits[2u * idx + 1u] = h1;
 }
-void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s) { ST_LAUNCH(k_ref_tracing, false, s, a, depth); }
+void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s) { ST_LAUNCH_TRACE(k_ref_tracing, false, s, a, depth); }
 
 // ---------------------------------------------------------------- ref_shading.rs:3-177
+template <class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_ref_shading(const KArgs a, uint32_t seed, uint32_t depth) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_ref_shading(const KArgs a, ui
     a.ref_rays[3u * idx + 1u] = f4(rs.dir, throughput.y);
     a.ref_rays[3u * idx + 2u] = f4(color, throughput.z);
 }
-void launch_ref_shading(const KArgs& a, uint32_t seed, uint32_t depth, hipStream_t s) { ST_LAUNCH(k_ref_shading, false, s, a, seed, depth); }
+void launch_ref_shading(const KArgs& a, uint32_t seed, uint32_t depth, hipStream_t s) { ST_LAUNCH_TRACE(k_ref_shading, false, s, a, seed, depth); }
 
 // ---------------------------------------------------------------- primary visibility (prim_raster.rs:40-128 as one closest-hit ray per pixel)
 // frame_reprojection.rs:6-95 for one pixel, given its own fresh surface and velocity
@@ -147,9 +150,9 @@ ST_D void frame_reprojection_pixel(const KArgs& a, U2 pos, const Surface& surfac
 
 // REPROJECT: frame_reprojection runs in the same kernel (it needs this pixel's new surface + velocity and the PREVIOUS
 // frame's surfaces only).
-template <bool REPROJECT>
+template <bool REPROJECT, class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -189,7 +192,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a
     }
 }
 void launch_prim_visibility(const KArgs& a, bool reproject, hipStream_t s) {
-    if (reproject) ST_LAUNCH(k_prim_visibility<true>, false, s, a); else ST_LAUNCH(k_prim_visibility<false>, false, s, a);
+    const bool small = a.bvh_len < 65536u;
+    if (reproject) { if (small) ST_LAUNCH((k_prim_visibility<true, uint16_t>), false, s, a); else ST_LAUNCH((k_prim_visibility<true, uint32_t>), false, s, a); }
+    else { if (small) ST_LAUNCH((k_prim_visibility<false, uint16_t>), false, s, a); else ST_LAUNCH((k_prim_visibility<false, uint32_t>), false, s, a); }
 }
 
 // ---------------------------------------------------------------- frame_reprojection.rs:6-95
@@ -202,8 +207,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_frame_reprojection(const KArg
 void launch_frame_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_frame_reprojection, false, s, a); }
 
 // ---------------------------------------------------------------- {di,gi}_spatial_resampling.rs `trace`
+template <class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_spatial_trace(const KArgs a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2) {
-    __shared__ uint32_t lds[kStackWords];
+    __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_spatial_trace(const KArgs a, 
     tex_write(buf_d2, a, pos, make_float4(occluded ? 0.0f : 1.0f, ray_d1.z, ray_d1.w, 0.0f));
 }
 void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s) {
-    ST_LAUNCH(k_spatial_trace, false, s, a, buf_d0, buf_d1, buf_d2);
+    ST_LAUNCH_TRACE(k_spatial_trace, false, s, a, buf_d0, buf_d1, buf_d2);
 }
 
 // ---------------------------------------------------------------- frame_composition.rs:18-82 as a compute pass into an RGBA32F buffer

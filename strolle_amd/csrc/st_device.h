@@ -47,9 +47,11 @@ ST_D U2 pixel_in_tile(TileCoord t) {
     const uint32_t lane = threadIdx.x & 63u;
     return u2(t.x * 8u + (lane & 7u), t.y * 8u + (lane >> 3));
 }
-ST_D uint32_t* lane_stack(uint32_t* lds) {  // [wave][entry][lane]: consecutive lanes hit consecutive banks
-    return lds + (threadIdx.x >> 6) * (kBvhStackSize * 64) + (threadIdx.x & 63u);
-}
+// Traversal stack in LDS, [wave][entry][lane] (consecutive lanes -> consecutive banks). Entries are BVH stream indices:
+// streams shorter than 65536 float4 (Cornell: 124, dungeon: ~35 k) use 16-bit entries, which halves the LDS footprint
+// (12 KiB per 4-wave block) and lifts the LDS cap on occupancy from 6 to 8 waves per SIMD.
+template <class SE>
+ST_D SE* lane_stack(SE* lds) { return lds + (threadIdx.x >> 6) * (kBvhStackSize * 64) + (threadIdx.x & 63u); }
 // Per-kernel counters {rays traced, the reference's `used_memory` bytes}. One returning-free atomic pair per
 // wavefront (hipcc's atomic optimizer reduces the uniform-address adds across the wave) lands on one of
 // kCounterLines 64-byte lines picked by block id: a single hot word saturates near 88 atomics/us
@@ -233,8 +235,8 @@ ST_D V2 tri_uv(const KArgs& a, uint32_t tri, float u, float v) {
 }
 // ANY_HIT: Tracing::ReturnFirst. Returns the reference's `used_memory` byte counter.
 // On return `best.t` is the closest accepted distance (or the initial max_t if none).
-template <bool ANY_HIT>
-ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, uint32_t* stack, Candidate* best, bool* found_any) {
+template <bool ANY_HIT, class SE>
+ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, Candidate* best, bool* found_any) {
     best->t = max_t; best->tri = 0xffffffffu; best->material = 0u; best->u = 0.0f; best->v = 0.0f; best->inv_det = 1.0f;
     *found_any = false;
     if (a.bvh_len == 0u) return 0u;
@@ -251,7 +253,7 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, uint32_t* st
             float near_d = intersect_box(ray, xyz(d0), xyz(d1));
             float far_d = intersect_box(ray, xyz(d2), xyz(d3));
             if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-            if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = far_ptr; sp++; } }
+            if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)far_ptr; sp++; } }
             if (near_d < best->t) { ptr = near_ptr; continue; }
         } else {
             used_memory += 144u;
@@ -287,7 +289,8 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, uint32_t* st
     return used_memory;
 }
 // Ray::trace (closest hit) with attributes resolved once, for the winning triangle.
-ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, uint32_t* stack, uint32_t* used_memory) {
+template <class SE>
+ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
     Candidate c; bool any;
     *used_memory = traverse<false>(a, ray, kF32Max, stack, &c, &any);
     TriangleHit h;
@@ -303,7 +306,8 @@ ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, uint32_t* stack, 
     return h;
 }
 // Ray::intersect (shadow ray)
-ST_D bool trace_any(const KArgs& a, const Ray& ray, uint32_t* stack, uint32_t* used_memory) {
+template <class SE>
+ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
     Candidate c; bool any;
     *used_memory = traverse<true>(a, ray, ray.len, stack, &c, &any);
     return c.t < ray.len;
