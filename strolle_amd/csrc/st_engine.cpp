@@ -234,6 +234,8 @@ struct Engine {
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
+    bool overlap = true;    // run the DI and GI chains concurrently on two HIP streams (ST_NO_OVERLAP=1 disables)
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
     uint32_t tile_map = 2;  // blockIdx -> tile mapping (st_device.h); 2 measured best on MI355X; ST_TILE_MAP overrides
     bool profiling = false;
@@ -249,6 +251,7 @@ struct Engine {
         reset_profile_totals();
         if (const char* tm = getenv("ST_TILE_MAP")) tile_map = (uint32_t)atoi(tm);
         if (const char* nf = getenv("ST_NO_FUSE")) fuse = atoi(nf) == 0;
+        if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
     }
     void reset_profile_totals() {
         for (int i = 0; i < KS_COUNT; i++) {
@@ -264,6 +267,9 @@ struct Engine {
         for (DeviceArray* d : {&d_bvh, &d_tri_geo, &d_tri_attr, &d_materials, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
         for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
     static void release_camera(CameraState& c) { if (c.slab) (void)hipFree(c.slab); if (c.counters) (void)hipFree(c.counters); c.slab = nullptr; c.counters = nullptr; }
 
@@ -571,11 +577,12 @@ struct Engine {
         };
         // `fused`: reference passes executed inside this launch. Their (unfused) algorithmic bytes are credited to the
         // launching slot so that fusion shows up as a gain, not as a moved goalpost.
+        hipStream_t cur = stream;  // stream the next launches go to (the GI chain may be diverted to side_stream)
         auto run = [&](int slot, std::initializer_list<int> fused, auto&& launch) {
             double bytes = slot_bytes(slot);
             for (int f : fused) bytes += slot_bytes(f);
             a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
-            Scope scope(this, stream, slot, bytes);
+            Scope scope(this, cur, slot, bytes);
             launch();
         };
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
@@ -593,78 +600,88 @@ struct Engine {
             }
         }
         if (mode == ST_MODE_BVH_HEATMAP) {
-            run(KS_BVH_HEATMAP, {}, [&] { launch_bvh_heatmap(a, stream); });
+            run(KS_BVH_HEATMAP, {}, [&] { launch_bvh_heatmap(a, cur); });
         } else if (mode == ST_MODE_REFERENCE) {
             for (uint32_t d = 0; d <= c.desc.depth; d++) {
-                run(KS_REF_TRACING, {}, [&] { launch_ref_tracing(a, d, stream); });
-                run(KS_REF_SHADING, {}, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + d), d, stream); });
+                run(KS_REF_TRACING, {}, [&] { launch_ref_tracing(a, d, cur); });
+                run(KS_REF_SHADING, {}, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + d), d, cur); });
             }
-            run(KS_REF_SHADING, {}, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + 255u), 255u, stream); });
+            run(KS_REF_SHADING, {}, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + 255u), 255u, cur); });
         } else {
             const bool needs_di = mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE || mode == ST_MODE_DI_SPECULAR;
             const bool needs_gi = mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE || mode == ST_MODE_GI_SPECULAR;
             const bool denoise = c.desc.denoise != 0u;
             const bool any_objects = !instances.empty();
-            if (fuse && any_objects) run(KS_PRIM_VISIBILITY, {KS_FRAME_REPROJECTION}, [&] { launch_prim_visibility(a, true, stream); });
-            else run(KS_PRIM_VISIBILITY, {}, [&] { launch_prim_visibility(a, false, stream); });
+            if (fuse && any_objects) run(KS_PRIM_VISIBILITY, {KS_FRAME_REPROJECTION}, [&] { launch_prim_visibility(a, true, cur); });
+            else run(KS_PRIM_VISIBILITY, {}, [&] { launch_prim_visibility(a, false, cur); });
             if (any_objects) {
-                if (!fuse) run(KS_FRAME_REPROJECTION, {}, [&] { launch_frame_reprojection(a, stream); });
+                if (!fuse) run(KS_FRAME_REPROJECTION, {}, [&] { launch_frame_reprojection(a, cur); });
+                // The DI chain and the GI chain touch disjoint planes between primary visibility and the denoiser, so the GI
+                // chain runs on a second stream: its bandwidth-bound reservoir passes overlap DI's latency-bound shadow rays.
+                const bool forked = overlap && needs_di && needs_gi;
+                if (forked) {
+                    if (!side_stream) { ST_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking)); ST_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); ST_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); }
+                    ST_HIP(hipEventRecord(ev_fork, stream));
+                    ST_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+                }
                 if (needs_di) {
-                    run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), stream); });
-                    run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), stream); });
-                    run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), stream); });
-                    run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, stream); });
-                    run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), stream); });
-                    if (fuse && denoise) { run(KS_DI_RESOLVING, {KS_DENOISE_REPROJECT}, [&] { launch_di_resolving(a, true, stream); }); di_reprojected = true; }
-                    else run(KS_DI_RESOLVING, {}, [&] { launch_di_resolving(a, false, stream); });
+                    run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), cur); });
+                    run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), cur); });
+                    run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), cur); });
+                    run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, cur); });
+                    run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), cur); });
+                    if (fuse && denoise) { run(KS_DI_RESOLVING, {KS_DENOISE_REPROJECT}, [&] { launch_di_resolving(a, true, cur); }); di_reprojected = true; }
+                    else run(KS_DI_RESOLVING, {}, [&] { launch_di_resolving(a, false, cur); });
                 }
                 if (needs_gi) {
+                    if (forked) cur = side_stream;
                     uint32_t source;
                     const bool tracing = c.frame % 6u < 4u;
-                    run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, stream); });
+                    run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, cur); });
                     auto sampling = [&] {
-                        run(KS_GI_SAMPLING_A, {}, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), stream); });
-                        run(KS_GI_SAMPLING_B, {}, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), stream); });
+                        run(KS_GI_SAMPLING_A, {}, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), cur); });
+                        run(KS_GI_SAMPLING_B, {}, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), cur); });
                     };
                     if (tracing) {
                         if (c.frame % 2u == 0u) sampling();
-                        run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), stream); });
+                        run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), cur); });
                         if (c.frame % 2u == 1u) {
-                            run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), stream); });
-                            run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, stream); });
-                            run(KS_GI_SPATIAL_SAMPLE, {}, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), stream); });
+                            run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), cur); });
+                            run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, cur); });
+                            run(KS_GI_SPATIAL_SAMPLE, {}, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), cur); });
                             source = 1;
                         } else source = 0;
                     } else {
                         sampling();
-                        run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), stream); });
+                        run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), cur); });
                         source = 0;
                     }
                     const uint32_t pseed = seed(SEED_GI_PREVIEW);  // one seed for both preview passes (passes/gi_preview_resampling.rs:60-74)
-                    run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 0u, source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], stream); });
+                    run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 0u, source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], cur); });
                     if (fuse) {
-                        if (denoise) { run(KS_GI_PREVIEW, {KS_GI_RESOLVING, KS_DENOISE_REPROJECT}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], source, true, stream); }); gi_reprojected = true; }
-                        else run(KS_GI_PREVIEW, {KS_GI_RESOLVING}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], source, false, stream); });
+                        if (denoise) { run(KS_GI_PREVIEW, {KS_GI_RESOLVING, KS_DENOISE_REPROJECT}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], source, true, cur); }); gi_reprojected = true; }
+                        else run(KS_GI_PREVIEW, {KS_GI_RESOLVING}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], source, false, cur); });
                     } else {
-                        run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], stream); });
-                        run(KS_GI_RESOLVING, {}, [&] { launch_gi_resolving(a, source, stream); });
+                        run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], cur); });
+                        run(KS_GI_RESOLVING, {}, [&] { launch_gi_resolving(a, source, cur); });
                     }
+                    if (forked) { ST_HIP(hipEventRecord(ev_join, side_stream)); ST_HIP(hipStreamWaitEvent(stream, ev_join, 0)); cur = stream; }
                 }
             }
             if (denoise) {
-                if (!di_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, stream); });
-                if (!gi_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, stream); });
-                run(KS_DENOISE_VARIANCE, {}, [&] { launch_denoise_variance(a, stream); });
+                if (!di_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, cur); });
+                if (!gi_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, cur); });
+                run(KS_DENOISE_VARIANCE, {}, [&] { launch_denoise_variance(a, cur); });
                 // ping-pong (passes/frame_denoising.rs:87-110): stash -> prev -> stash -> curr -> stash -> curr
                 float4* di[3] = {a.di_diff_stash, a.di_diff_prev_colors, a.di_diff_curr_colors};
                 float4* gi[3] = {a.gi_diff_stash, a.gi_diff_prev_colors, a.gi_diff_curr_colors};
                 const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
                 for (uint32_t nth = 0; nth < 5; nth++) {
                     if (nth == 4 && fuse && out) {
-                        run(KS_DENOISE_WAVELET, {KS_COMPOSITION}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], mode, out, stream); });
+                        run(KS_DENOISE_WAVELET, {KS_COMPOSITION}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], mode, out, cur); });
                         composed = true;
                     } else
-                        run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], stream); });
+                        run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], cur); });
                 }
             }
         }
@@ -672,7 +689,7 @@ struct Engine {
             const bool dn = c.desc.denoise != 0u;
             const float4* di_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
             const float4* gi_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
-            run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, stream); });
+            run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, cur); });
         }
         ST_HIP(hipGetLastError());
         return ST_OK;
