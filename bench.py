@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--apron", type=int, default=32, help="extra rows rendered around a rank's band in Image mode (N > 1)")
+    ap.add_argument("--scene", choices=["cornell", "dungeon"], default="cornell", help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene")
+    ap.add_argument("--mode", choices=["image", "gi_diffuse", "reference", "heatmap"], default="image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
     args = ap.parse_args()
@@ -83,9 +85,14 @@ def main():
     base = (args.width, args.height)
     width, height = weak_scaling_frame(base, world)
     engine = Engine(device=local_rank)
-    scenes.build_cornell(engine)
+    mode = {"image": CameraMode.IMAGE, "gi_diffuse": CameraMode.GI_DIFFUSE, "reference": CameraMode.REFERENCE, "heatmap": CameraMode.BVH_HEATMAP}[args.mode]
+    if args.scene == "cornell":
+        scenes.build_cornell(engine)
+        desc = scenes.cornell_camera((width, height), mode, depth=1)
+    else:
+        scenes.build_dungeon(engine)
+        desc = scenes.dungeon_camera((width, height), mode, depth=1)
     engine.set_seed(args.seed)
-    desc = scenes.cornell_camera((width, height), CameraMode.IMAGE)
     cam = engine.create_camera(desc)
     band = band_for_rank(height, world, rank)
     window = (0, height)
@@ -168,8 +175,10 @@ def main():
             "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Cornell box {width}x{height}, CameraMode::Image{{denoise:true}} (1 spp ReSTIR DI+GI + SVGF), static camera, point light at t=0",
-                       "scene": "cornell (32 triangles, 2 light slots)", "width": width, "height": height,
+            "config": {"workload": (f"Cornell box {width}x{height}, CameraMode::Image{{denoise:true}} (1 spp ReSTIR DI+GI + SVGF), static camera, point light at t=0"
+                                    if (args.scene, args.mode) == ("cornell", "image") else f"{args.scene} {width}x{height}, mode {args.mode} (NOT the headline workload)"),
+                       "scene": "cornell (32 triangles, 2 light slots)" if args.scene == "cornell" else "dungeon level.glb (8,393 triangles, 45 textured materials, 7 light slots)",
+                       "width": width, "height": height,
                        "per_gpu_rows": band[1] - band[0], "apron_rows": args.apron if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
                        "partition": "single GPU" if world == 1 else f"{world} row bands, per-frame RCCL gather of the RGBA32F bands to rank 0 overlapped with the next frame"},
@@ -195,7 +204,7 @@ def main():
                                  for p in sorted(prof, key=lambda p: -p["total_ms"])}
             result["gpu_kernel_ms_per_frame"] = round(tot / args.steps, 4)
             result["ms_per_step_with_event_timing"] = round(profiled_ms, 4)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and (args.scene, args.mode) == ("cornell", "image"):
             try:
                 result["cpu_baseline"] = cpu_baseline(args, base)
             except Exception as ex:  # the baseline must never sink the GPU number

@@ -234,8 +234,11 @@ struct Engine {
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
-    bool overlap = true;    // run the DI and GI chains concurrently on two HIP streams (ST_NO_OVERLAP=1 disables)
-    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_prim = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
+    bool have_prev_frame_events = false;
+    bool fuse_compose = false;  // composition inside the last wavelet launch: measured slower (109 vs 65+36 us), kept for A/B (ST_FUSE_COMPOSE=1)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
     uint32_t tile_map = 2;  // blockIdx -> tile mapping (st_device.h); 2 measured best on MI355X; ST_TILE_MAP overrides
     bool profiling = false;
@@ -252,6 +255,7 @@ struct Engine {
         if (const char* tm = getenv("ST_TILE_MAP")) tile_map = (uint32_t)atoi(tm);
         if (const char* nf = getenv("ST_NO_FUSE")) fuse = atoi(nf) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
+        if (const char* fc = getenv("ST_FUSE_COMPOSE")) fuse_compose = atoi(fc) != 0;
     }
     void reset_profile_totals() {
         for (int i = 0; i < KS_COUNT; i++) {
@@ -268,8 +272,7 @@ struct Engine {
         for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
         if (side_stream) (void)hipStreamDestroy(side_stream);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
+        for (hipEvent_t e : {ev_prim, ev_gi_done, ev_prim_ok, ev_frame_done, ev_setup}) if (e) (void)hipEventDestroy(e);
     }
     static void release_camera(CameraState& c) { if (c.slab) (void)hipFree(c.slab); if (c.counters) (void)hipFree(c.counters); c.slab = nullptr; c.counters = nullptr; }
 
@@ -587,16 +590,16 @@ struct Engine {
         };
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
         const uint32_t mode = c.desc.mode;
-        bool di_reprojected = false, gi_reprojected = false, composed = false;
+        bool di_reprojected = false, gi_reprojected = false, composed = false, luts_generated_now = false;
         if (mode != ST_MODE_BVH_HEATMAP) {  // AtmospherePass::run (passes/atmosphere.rs:78-110)
             if (!atmosphere_initialized) {
                 launch_atmosphere_static(static_cast<float4*>(d_transmittance.ptr), static_cast<float4*>(d_scattering.ptr), stream);
-                atmosphere_initialized = true;
+                atmosphere_initialized = true; luts_generated_now = true;
             }
             if (!sky_known || known_sun_altitude != sun_altitude) {
                 launch_atmosphere_sky(static_cast<const float4*>(d_transmittance.ptr), static_cast<const float4*>(d_scattering.ptr), sun_altitude,
                                       static_cast<float4*>(d_sky.ptr), stream);
-                sky_known = true; known_sun_altitude = sun_altitude;
+                sky_known = true; known_sun_altitude = sun_altitude; luts_generated_now = true;
             }
         }
         if (mode == ST_MODE_BVH_HEATMAP) {
@@ -612,63 +615,57 @@ struct Engine {
             const bool needs_gi = mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE || mode == ST_MODE_GI_SPECULAR;
             const bool denoise = c.desc.denoise != 0u;
             const bool any_objects = !instances.empty();
-            if (fuse && any_objects) run(KS_PRIM_VISIBILITY, {KS_FRAME_REPROJECTION}, [&] { launch_prim_visibility(a, true, cur); });
-            else run(KS_PRIM_VISIBILITY, {}, [&] { launch_prim_visibility(a, false, cur); });
-            if (any_objects) {
-                if (!fuse) run(KS_FRAME_REPROJECTION, {}, [&] { launch_frame_reprojection(a, cur); });
-                // The DI chain and the GI chain touch disjoint planes between primary visibility and the denoiser, so the GI
-                // chain runs on a second stream: its bandwidth-bound reservoir passes overlap DI's latency-bound shadow rays.
-                const bool forked = overlap && needs_di && needs_gi;
-                if (forked) {
-                    if (!side_stream) { ST_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking)); ST_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); ST_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); }
-                    ST_HIP(hipEventRecord(ev_fork, stream));
-                    ST_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
-                }
-                if (needs_di) {
-                    run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), cur); });
-                    run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), cur); });
-                    run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), cur); });
-                    run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, cur); });
-                    run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), cur); });
-                    if (fuse && denoise) { run(KS_DI_RESOLVING, {KS_DENOISE_REPROJECT}, [&] { launch_di_resolving(a, true, cur); }); di_reprojected = true; }
-                    else run(KS_DI_RESOLVING, {}, [&] { launch_di_resolving(a, false, cur); });
-                }
-                if (needs_gi) {
-                    if (forked) cur = side_stream;
-                    uint32_t source;
-                    const bool tracing = c.frame % 6u < 4u;
-                    run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, cur); });
-                    auto sampling = [&] {
-                        run(KS_GI_SAMPLING_A, {}, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), cur); });
-                        run(KS_GI_SAMPLING_B, {}, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), cur); });
-                    };
-                    if (tracing) {
-                        if (c.frame % 2u == 0u) sampling();
-                        run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), cur); });
-                        if (c.frame % 2u == 1u) {
-                            run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), cur); });
-                            run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, cur); });
-                            run(KS_GI_SPATIAL_SAMPLE, {}, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), cur); });
-                            source = 1;
-                        } else source = 0;
-                    } else {
-                        sampling();
-                        run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), cur); });
-                        source = 0;
+            const bool tracing = c.frame % 6u < 4u;
+            const uint32_t gi_source = (tracing && c.frame % 2u == 1u) ? 1u : 0u;
+            const uint32_t pseed = seed(SEED_GI_PREVIEW);  // one seed for both preview passes (passes/gi_preview_resampling.rs:60-74)
+
+            auto do_prim = [&] {
+                if (fuse && any_objects) run(KS_PRIM_VISIBILITY_REPROJECTION, {}, [&] { launch_prim_visibility(a, true, cur); });
+                else run(KS_PRIM_VISIBILITY, {}, [&] { launch_prim_visibility(a, false, cur); });
+                if (any_objects && !fuse) run(KS_FRAME_REPROJECTION, {}, [&] { launch_frame_reprojection(a, cur); });
+            };
+            auto do_di = [&] {
+                run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), cur); });
+                run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), cur); });
+                run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), cur); });
+                run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, cur); });
+                run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), cur); });
+                if (fuse && denoise) { run(KS_DI_RESOLVING_REPROJECT, {}, [&] { launch_di_resolving(a, true, cur); }); di_reprojected = true; }
+                else run(KS_DI_RESOLVING, {}, [&] { launch_di_resolving(a, false, cur); });
+            };
+            // GI up to the first preview pass: touches only reservoirs, gi_d0..2 and read-only frame inputs
+            auto do_gi_head = [&] {
+                run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, cur); });
+                auto sampling = [&] {
+                    run(KS_GI_SAMPLING_A, {}, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), cur); });
+                    run(KS_GI_SAMPLING_B, {}, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), cur); });
+                };
+                if (tracing) {
+                    if (c.frame % 2u == 0u) sampling();
+                    run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), cur); });
+                    if (c.frame % 2u == 1u) {
+                        run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), cur); });
+                        run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, cur); });
+                        run(KS_GI_SPATIAL_SAMPLE, {}, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), cur); });
                     }
-                    const uint32_t pseed = seed(SEED_GI_PREVIEW);  // one seed for both preview passes (passes/gi_preview_resampling.rs:60-74)
-                    run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 0u, source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], cur); });
-                    if (fuse) {
-                        if (denoise) { run(KS_GI_PREVIEW, {KS_GI_RESOLVING, KS_DENOISE_REPROJECT}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], source, true, cur); }); gi_reprojected = true; }
-                        else run(KS_GI_PREVIEW, {KS_GI_RESOLVING}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], source, false, cur); });
-                    } else {
-                        run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], cur); });
-                        run(KS_GI_RESOLVING, {}, [&] { launch_gi_resolving(a, source, cur); });
-                    }
-                    if (forked) { ST_HIP(hipEventRecord(ev_join, side_stream)); ST_HIP(hipStreamWaitEvent(stream, ev_join, 0)); cur = stream; }
+                } else {
+                    sampling();
+                    run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), cur); });
                 }
-            }
-            if (denoise) {
+                run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 0u, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], cur); });
+            };
+            // second preview pass + resolving (+ reproject): the first GI stage that writes planes the denoiser/composition read
+            auto do_gi_tail = [&] {
+                if (fuse) {
+                    if (denoise) { run(KS_GI_PREVIEW_RESOLVE_REPROJECT, {}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, true, cur); }); gi_reprojected = true; }
+                    else run(KS_GI_PREVIEW_RESOLVE, {}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, false, cur); });
+                } else {
+                    run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], cur); });
+                    run(KS_GI_RESOLVING, {}, [&] { launch_gi_resolving(a, gi_source, cur); });
+                }
+            };
+            auto do_denoise = [&] {
+                if (!denoise) return;
                 if (!di_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, cur); });
                 if (!gi_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, cur); });
                 run(KS_DENOISE_VARIANCE, {}, [&] { launch_denoise_variance(a, cur); });
@@ -677,12 +674,67 @@ struct Engine {
                 float4* gi[3] = {a.gi_diff_stash, a.gi_diff_prev_colors, a.gi_diff_curr_colors};
                 const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
                 for (uint32_t nth = 0; nth < 5; nth++) {
-                    if (nth == 4 && fuse && out) {
-                        run(KS_DENOISE_WAVELET, {KS_COMPOSITION}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], mode, out, cur); });
+                    if (nth == 4 && fuse_compose && out) {
+                        run(KS_DENOISE_WAVELET_COMPOSE, {}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], mode, out, cur); });
                         composed = true;
                     } else
                         run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], cur); });
                 }
+            };
+            auto do_compose = [&] {
+                if (!out || composed) return;
+                const float4* di_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
+                const float4* gi_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
+                run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, cur); });
+                composed = true;
+            };
+
+            if (overlap && needs_di && needs_gi && any_objects) {
+                // Two streams, software-pipelined across frames. `side` carries primary visibility and the GI chain, `stream`
+                // carries the DI chain, the denoiser and composition; events express the true data dependencies only, so the
+                // bandwidth-bound reservoir passes of frame N+1 overlap the VALU-bound denoiser of frame N:
+                //   prim(N+1)      after DI(N)            — it overwrites frame N's "previous" G-buffer + the reprojection map
+                //   GI tail(N+1)   after frame N is done  — it writes gi sample/colour/moment planes the denoiser + composition read
+                //   DI(N+1)        after prim(N+1)        (and after frame N's denoiser by stream order: DI scratch aliases its planes)
+                //   denoiser(N+1)  after GI tail(N+1)
+                if (!side_stream) {
+                    ST_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+                    for (hipEvent_t* e : {&ev_prim, &ev_gi_done, &ev_prim_ok, &ev_frame_done, &ev_setup}) ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+                }
+                // LUT generation issued on `stream` in this call must precede the side stream's consumers. (Do NOT do this
+                // unconditionally: an event recorded on `stream` here completes only after frame N's denoiser, which would
+                // serialise prim(N+1) behind it. Uploads in st_tick are followed by a host-side stream sync.)
+                if (luts_generated_now) { ST_HIP(hipEventRecord(ev_setup, stream)); ST_HIP(hipStreamWaitEvent(side_stream, ev_setup, 0)); }
+                if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_prim_ok, 0));
+                cur = side_stream;
+                do_prim();
+                ST_HIP(hipEventRecord(ev_prim, side_stream));
+                do_gi_head();
+                if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_frame_done, 0));
+                do_gi_tail();
+                ST_HIP(hipEventRecord(ev_gi_done, side_stream));
+                cur = stream;
+                ST_HIP(hipStreamWaitEvent(stream, ev_prim, 0));
+                do_di();
+                // stand-alone denoise reprojection kernels (unfused path) still read the reprojection map: prim(N+1) may
+                // only start once they are through
+                const bool reproject_later = denoise && !fuse;
+                if (!reproject_later) ST_HIP(hipEventRecord(ev_prim_ok, stream));
+                ST_HIP(hipStreamWaitEvent(stream, ev_gi_done, 0));
+                do_denoise();
+                if (reproject_later) ST_HIP(hipEventRecord(ev_prim_ok, stream));
+                do_compose();
+                ST_HIP(hipEventRecord(ev_frame_done, stream));
+                have_prev_frame_events = true;
+            } else {
+                do_prim();
+                if (any_objects) {
+                    if (needs_di) do_di();
+                    if (needs_gi) { do_gi_head(); do_gi_tail(); }
+                }
+                do_denoise();
+                do_compose();
+                if (side_stream) { ST_HIP(hipEventRecord(ev_prim_ok, stream)); ST_HIP(hipEventRecord(ev_frame_done, stream)); }
             }
         }
         if (out && !composed) {

@@ -15,7 +15,10 @@ enum KernelSlot {
     KS_DI_SAMPLING, KS_DI_TEMPORAL, KS_DI_SPATIAL_PICK, KS_DI_SPATIAL_TRACE, KS_DI_SPATIAL_SAMPLE, KS_DI_RESOLVING,
     KS_GI_REPROJECTION, KS_GI_SAMPLING_A, KS_GI_SAMPLING_B, KS_GI_TEMPORAL, KS_GI_SPATIAL_PICK, KS_GI_SPATIAL_TRACE,
     KS_GI_SPATIAL_SAMPLE, KS_GI_PREVIEW, KS_GI_RESOLVING, KS_DENOISE_REPROJECT, KS_DENOISE_VARIANCE, KS_DENOISE_WAVELET,
-    KS_COMPOSITION, KS_COUNT
+    KS_COMPOSITION,
+    // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
+    KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_COMPOSE,
+    KS_COUNT
 };
 struct KernelInfo { const char* name; float bytes_per_unit; bool half; };
 inline const KernelInfo& kernel_info(int slot) {
@@ -28,6 +31,11 @@ inline const KernelInfo& kernel_info(int slot) {
         {"gi_spatial_pick", 160.f, true},    {"gi_spatial_trace", 48.f, false},    {"gi_spatial_sample", 352.f, true},
         {"gi_preview", 160.f, false},        {"gi_resolving", 256.f, false},       {"denoise_reproject", 112.f, false},
         {"denoise_variance", 112.f, false},  {"denoise_wavelet", 84.f, false},     {"composition", 112.f, false},
+        {"prim_visibility+frame_reprojection", 64.f + 64.f, false},
+        {"di_resolving+denoise_reproject", 128.f + 112.f, false},
+        {"gi_preview+gi_resolving", 160.f + 256.f, false},
+        {"gi_preview+gi_resolving+denoise_reproject", 160.f + 256.f + 112.f, false},
+        {"denoise_wavelet+composition", 84.f + 112.f, false},
     };
     return k[slot];
 }

@@ -28,8 +28,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name: str) -> str:
-    m = re.match(r"st::k_([a-z_0-9]+)", name)
-    return m.group(1) if m else name
+    """'void st::k_prim_visibility<true, unsigned short>(st::KArgs)' -> 'prim_visibility<true,u16>'"""
+    m = re.search(r"st::k_([a-z_0-9]+)(<[^>]*>)?", name)
+    if not m:
+        return name
+    tpl = (m.group(2) or "").replace("unsigned short", "u16").replace("unsigned int", "u32").replace(" ", "")
+    return m.group(1) + tpl
+
+
+def is_ours(name: str) -> bool:
+    return "st::k_" in name
 
 
 def main():
@@ -43,7 +51,7 @@ def main():
             w = csv.writer(f)
             w.writerow(rows[0])
             for r in rows[1:]:
-                if r and r[0].startswith("st::"):
+                if r and is_ours(r[0]):
                     w.writerow([short(r[0])] + r[1:])
     pmc = defaultdict(lambda: defaultdict(list))
     for kind, counter in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
@@ -51,7 +59,7 @@ def main():
         if not files:
             continue
         for r in csv.DictReader(open(files[-1])):
-            if r["Kernel_Name"].startswith("st::") and r["Counter_Name"] == counter:
+            if is_ours(r["Kernel_Name"]) and r["Counter_Name"] == counter:
                 pmc[short(r["Kernel_Name"])][counter].append(float(r["Counter_Value"]))
     if pmc:
         summary = {}
@@ -64,10 +72,15 @@ def main():
             summary[k] = {"fetch_size_kib": f, "write_size_kib": w,
                           "hbm_bytes_per_launch": None if f is None or w is None else round((2.0 * f + w) * 1024.0),
                           "launches_sampled": len(c.get("FETCH_SIZE", []))}
-        # the shared shadow-ray kernel serves both spatial passes
-        if "spatial_trace" in summary:
-            summary["di_spatial_trace"] = summary["spatial_trace"]
-            summary["gi_spatial_trace"] = summary["spatial_trace"]
+        # aliases under the profiler slot names bench.py uses (st_kernels.h kernel_info)
+        alias = {"di_spatial_trace": "spatial_trace<u16>", "gi_spatial_trace": "spatial_trace<u16>",
+                 "denoise_wavelet": "denoise_wavelet<false>", "denoise_wavelet+composition": "denoise_wavelet<true>",
+                 "prim_visibility+frame_reprojection": "prim_visibility<true,u16>", "di_resolving+denoise_reproject": "di_resolving<true,u16>",
+                 "gi_preview": "gi_preview<false>", "gi_preview+gi_resolving+denoise_reproject": "gi_preview<true>",
+                 "di_sampling": "di_sampling<u16>", "gi_sampling_a": "gi_sampling_a<u16>", "gi_sampling_b": "gi_sampling_b<u16>"}
+        for slot, kernel in alias.items():
+            if kernel in summary:
+                summary[slot] = summary[kernel]
         for name in (f"{tag}_pmc.json", "pmc_latest.json"):
             json.dump(summary, open(os.path.join(out_dir, name), "w"), indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(out_dir)))
