@@ -162,7 +162,9 @@ int st_debug_read_lut(StEngine* e, int what, float* out, size_t capacity_floats,
 
 /* Per-kernel timing (HIP events recorded around every launch on the launch stream).
  * st_profile_read returns, per kernel slot i < *count: name, launches, total milliseconds,
- * algorithmic bytes per launch (DESIGN.md "bytes per unit" x units launched). */
+ * algorithmic bytes per launch (DESIGN.md "bytes per unit" x units launched).
+ * While profiling is enabled the pass graph runs serially on the caller's stream (no two-stream overlap), so that an
+ * event pair times its kernel alone; the rendered bits are the same either way. */
 enum { ST_PROFILE_MAX_KERNELS = 48 };  /* >= the number of kernel slots (st_kernels.h) */
 typedef struct StKernelProfile {
     char name[48];

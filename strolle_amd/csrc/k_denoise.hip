@@ -66,66 +66,122 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_variance(const KArgs 
     gi_var = fmax_(gi_var, 0.0f);
     tex_write(a.di_diff_stash, a, pos, f4(xyz(cdi), di_var));
     tex_write(a.gi_diff_stash, a, pos, f4(xyz(cgi), gi_var));
+    a.sl[0][pos.y * a.width + pos.x] = make_float2(sqrtf(cdi_luma), sqrtf(cgi_luma));  // for the first wavelet pass's taps
 }
 void launch_denoise_variance(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a); }
 
 // ---------------------------------------------------------------- frame_denoising.rs:219-361
+// The pass is VALU-issue-bound (SQ counters: ~100 % VALU busy, 1245 VALU/wave before this layout), so the direct and
+// indirect signals are carried as the two halves of 64-bit packed-f32 operations (v_pk_mul_f32 / v_pk_add_f32): the
+// same IEEE operations in the same order per half, half the issue slots. The weight's shared factors (depth, normal)
+// are evaluated once per tap; a tap whose shared factor is exactly zero is dropped before its colours are loaded —
+// its weight would be 0 or NaN and `w > 0` (frame_denoising.rs:318,340) rejects both.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+ST_D f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+ST_D f2 splat2(float x) { return mk2(x, x); }
+
+// exp_() of both halves. Inside |x| < 87 none of exp_'s range branches fire and scale2() is a single multiplication by
+// 2^n with -126 <= n <= 126, so the straight-line packed evaluation is exp_() operation for operation; anything else
+// (NaN, overflow, the denormal tail) takes the scalar routine.
+ST_D f2 exp_pair(f2 x) {
+    if (!(fabsf(x.x) < 87.0f && fabsf(x.y) < 87.0f)) return mk2(exp_(x.x), exp_(x.y));
+    const f2 z = __builtin_elementwise_floor(1.44269504088896341f * x + 0.5f);
+    x = x - z * 0.693359375f;
+    x = x - z * -2.12194440e-4f;
+    const i2v n = __builtin_convertvector(z, i2v);
+    const f2 zz = x * x;
+    const f2 p = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * zz + x + 1.0f;
+    return p * mk2(b2f((uint32_t)(n.x + 127) << 23), b2f((uint32_t)(n.y + 127) << 23));
+}
+
 // COMPOSE: the last wavelet pass also runs frame composition for its pixel (frame_composition.rs) — the composed frame
 // needs only this pixel's denoised colours, which are in registers here.
 template <bool COMPOSE>
 __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out,
-                                                                    const float4* gi_in, float4* gi_out, uint32_t camera_mode, float4* frame_out) {
+                                                                    const float4* gi_in, float4* gi_out, const float2* sl_in, float2* sl_out,
+                                                                    uint32_t camera_mode, float4* frame_out) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    const Surface cs = surface_decoded(tex_read(a.sn, a, pos));
-    const float4 cdi = tex_read(di_in, a, pos);
-    if (cs.depth == 0.0f) {
-        tex_write(di_out, a, pos, cdi);
+    const uint32_t center = pos.y * a.width + pos.x;
+    const float4 csn = a.sn[center];
+    const float4 cdi = di_in[center];
+    if (csn.w == 0.0f) {  // sky
+        di_out[center] = cdi;
         // composition reads gi_diff_curr_colors for this pixel, which this pass leaves untouched on sky pixels
-        if (COMPOSE) frame_out[pos.y * a.width + pos.x] = compose_pixel(a, pos, camera_mode, cdi, tex_read(gi_out, a, pos));
+        if (COMPOSE) frame_out[center] = compose_pixel(a, pos, camera_mode, cdi, gi_out[center]);
         return;
     }
-    const float4 cgi = tex_read(gi_in, a, pos);
-    const float cdi_luma = luma(xyz(cdi)), cgi_luma = luma(xyz(cgi));
-    const float luma_sigma_di = lerpf(2.5f, 0.5f, sqrtf(cdi.w));
-    const float depth_sigma_di = 0.33f / strength;
-    const float luma_sigma_gi = lerpf(1.0f, 0.0f, sqrtf(cgi.w));
-    const float depth_sigma_gi = 0.33f / strength;
-    const float4 bn = blue_noise_read(a, pos);
-    const I2 jitter = as_i2((v2(bn.z, bn.w) - 0.5f) * ((float)stride - 1.0f) * 0.5f);
-    float sum_di_w = 1.0f; V3 sum_di_c = xyz(cdi); float sum_di_v = cdi.w;
-    float sum_gi_w = 1.0f; V3 sum_gi_c = xyz(cgi); float sum_gi_v = cgi.w;
+    const float4 cgi = gi_in[center];
+    const V3 cn = v3(csn.x, csn.y, csn.z);
+    const float2 csl = sl_in[center];  // == sqrtf(luma(xyz(cdi))), sqrtf(luma(xyz(cgi))): written with the colours
+    const f2 c_sqrt_luma = mk2(csl.x, csl.y);
+    const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, sqrtf(cdi.w)), lerpf(1.0f, 0.0f, sqrtf(cgi.w)));
+    const float leeway = csn.w * (0.33f / strength);  // depth sigma is the same for both signals
+    I2 jitter = i2(0, 0);
+    if (stride != 1u) {  // at stride 1 the jitter is (bn - 0.5) * 0 * 0.5 == 0
+        const float4 bn = blue_noise_read(a, pos);
+        jitter = as_i2((v2(bn.z, bn.w) - 0.5f) * ((float)stride - 1.0f) * 0.5f);
+    }
+    f2 sum_w = splat2(1.0f), sum_r = mk2(cdi.x, cgi.x), sum_g = mk2(cdi.y, cgi.y), sum_b = mk2(cdi.z, cgi.z), sum_v = mk2(cdi.w, cgi.w);
+    // Loads are issued in two unconditional batches (8 surface texels, then the colours of the taps) so that a wave pays
+    // two memory round trips instead of sixteen dependent ones; a tap that is out of bounds reads the centre texel and
+    // is masked out afterwards.
+    uint32_t at[8];
+    float4 ssn[8];
+    bool live[8];
 #pragma unroll
-    for (int oy = -1; oy <= 1; oy++) {
+    for (int t = 0; t < 8; t++) {
+        const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
+        const I2 sp = i2((int32_t)pos.x + jitter.x + ox * (int32_t)stride, (int32_t)pos.y + jitter.y + oy * (int32_t)stride);
+        live[t] = contains_i(a, sp);
+        at[t] = live[t] ? (uint32_t)sp.y * a.width + (uint32_t)sp.x : center;
+        ssn[t] = a.sn[at[t]];
+    }
+    float depth_w[8], normal_w[8];
 #pragma unroll
-        for (int ox = -1; ox <= 1; ox++) {
-            if (ox == 0 && oy == 0) continue;
-            const I2 sp = i2((int32_t)pos.x + jitter.x + ox * (int32_t)stride, (int32_t)pos.y + jitter.y + oy * (int32_t)stride);
-            if (!contains_i(a, sp)) continue;
-            const U2 up = u2((uint32_t)sp.x, (uint32_t)sp.y);
-            const Surface ss = surface_decoded(tex_read(a.sn, a, up));
-            if (ss.depth == 0.0f) continue;
-            const float4 sdi = tex_read(di_in, a, up);
-            const float w = denoise_sample_weight(cdi_luma, cs, luma(xyz(sdi)), ss, luma_sigma_di, depth_sigma_di);
-            if (w > 0.0f) { sum_di_w += w; sum_di_c = sum_di_c + w * xyz(sdi); sum_di_v += sqr(w) * sdi.w; }
-            const float4 sgi = tex_read(gi_in, a, up);
-            const float wg = denoise_sample_weight(cgi_luma, cs, luma(xyz(sgi)), ss, luma_sigma_gi, depth_sigma_gi);
-            if (wg > 0.0f) { sum_gi_w += wg; sum_gi_c = sum_gi_c + wg * xyz(sgi); sum_gi_v += sqr(wg) * sgi.w; }
+    for (int t = 0; t < 8; t++) {
+        const float diff = fabsf(ssn[t].w - csn.w);
+        depth_w[t] = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
+        normal_w[t] = pow64_(fmax_(dot(v3(ssn[t].x, ssn[t].y, ssn[t].z), cn), 0.0f));
+        live[t] = live[t] && ssn[t].w != 0.0f && !(depth_w[t] == 0.0f || normal_w[t] == 0.0f);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        float4 sdi[4], sgi[4]; float2 ssl[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = at[half * 4 + u]; sdi[u] = di_in[i]; sgi[u] = gi_in[i]; ssl[u] = sl_in[i]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = half * 4 + u;
+            if (!live[t]) continue;
+            const f2 r = mk2(sdi[u].x, sgi[u].x), g = mk2(sdi[u].y, sgi[u].y), b = mk2(sdi[u].z, sgi[u].z), v = mk2(sdi[u].w, sgi[u].w);
+            const f2 d = c_sqrt_luma - mk2(ssl[u].x, ssl[u].y);
+            const f2 luma_weight = mk2(fabsf(d.x), fabsf(d.y)) * luma_sigma;
+            const f2 w = exp_pair(-luma_weight) * depth_w[t] * normal_w[t];
+            if (w.x > 0.0f && w.y > 0.0f) {
+                sum_w = sum_w + w; sum_r = sum_r + w * r; sum_g = sum_g + w * g; sum_b = sum_b + w * b; sum_v = sum_v + (w * w) * v;
+            } else {
+                if (w.x > 0.0f) { sum_w.x += w.x; sum_r.x += w.x * r.x; sum_g.x += w.x * g.x; sum_b.x += w.x * b.x; sum_v.x += (w.x * w.x) * v.x; }
+                if (w.y > 0.0f) { sum_w.y += w.y; sum_r.y += w.y * r.y; sum_g.y += w.y * g.y; sum_b.y += w.y * b.y; sum_v.y += (w.y * w.y) * v.y; }
+            }
         }
     }
-    const float4 odi = f4(sum_di_c / sum_di_w, sum_di_v / (sum_di_w * sum_di_w));
-    const float4 ogi = f4(sum_gi_c / sum_gi_w, sum_gi_v / (sum_gi_w * sum_gi_w));
-    tex_write(di_out, a, pos, odi);
-    tex_write(gi_out, a, pos, ogi);
-    if (COMPOSE) frame_out[pos.y * a.width + pos.x] = compose_pixel(a, pos, camera_mode, odi, ogi);
+    const f2 ww = sum_w * sum_w;
+    const float4 odi = make_float4(sum_r.x / sum_w.x, sum_g.x / sum_w.x, sum_b.x / sum_w.x, sum_v.x / ww.x);
+    const float4 ogi = make_float4(sum_r.y / sum_w.y, sum_g.y / sum_w.y, sum_b.y / sum_w.y, sum_v.y / ww.y);
+    di_out[center] = odi;
+    gi_out[center] = ogi;
+    if (sl_out) sl_out[center] = make_float2(sqrtf(luma(xyz(odi))), sqrtf(luma(xyz(ogi))));
+    if (COMPOSE) frame_out[center] = compose_pixel(a, pos, camera_mode, odi, ogi);
 }
 void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
-                            float4* gi_out, hipStream_t s) {
-    ST_LAUNCH(k_denoise_wavelet<false>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, 0u, (float4*)nullptr);
+                            float4* gi_out, const float2* sl_in, float2* sl_out, hipStream_t s) {
+    ST_LAUNCH(k_denoise_wavelet<false>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out, 0u, (float4*)nullptr);
 }
 void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
-                                    float4* gi_out, uint32_t camera_mode, float4* frame_out, hipStream_t s) {
-    ST_LAUNCH(k_denoise_wavelet<true>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, camera_mode, frame_out);
+                                    float4* gi_out, const float2* sl_in, uint32_t camera_mode, float4* frame_out, hipStream_t s) {
+    ST_LAUNCH(k_denoise_wavelet<true>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, sl_in, (float2*)nullptr, camera_mode, frame_out);
 }
 
 }  // namespace st

@@ -158,13 +158,14 @@ struct DeviceArray {
 };
 
 // ------------------------------------------------------------------ per-camera state (camera_controller/buffers.rs)
+constexpr int kInternalPlanes = 3;  // decoded-surface twins A/B (KArgs::sn / psn) + the denoiser's sqrt-luma ping-pong pair (KArgs::sl)
 struct CameraState {
     StCamera desc{};
     GpuCamera curr{}, prev{};
     uint32_t frame = 0, row0 = 0, row1 = 0;
     void* slab = nullptr; size_t slab_bytes = 0;
-    float4* plane[ST_BUF_COUNT + 2] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
-    size_t plane_bytes[ST_BUF_COUNT + 2] = {};
+    float4* plane[ST_BUF_COUNT + kInternalPlanes] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
+    size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
 };
@@ -496,7 +497,7 @@ struct Engine {
         release_camera(c);
         const size_t n = (size_t)c.desc.width * c.desc.height;
         size_t total = 0;
-        for (int i = 0; i < ST_BUF_COUNT + 2; i++) {
+        for (int i = 0; i < ST_BUF_COUNT + kInternalPlanes; i++) {
             c.plane_bytes[i] = i == ST_BUF_DBG_USED_MEMORY ? n * 4 : n * 16 * plane_texels_per_pixel(i);
             total += (c.plane_bytes[i] + 255) & ~size_t(255);
         }
@@ -504,7 +505,7 @@ struct Engine {
         ST_HIP(hipMemset(c.slab, 0, total));  // wgpu zero-initialises resources; stale-data paths depend on it
         c.slab_bytes = total;
         size_t off = 0;
-        for (int i = 0; i < ST_BUF_COUNT + 2; i++) { c.plane[i] = reinterpret_cast<float4*>(static_cast<char*>(c.slab) + off); off += (c.plane_bytes[i] + 255) & ~size_t(255); }
+        for (int i = 0; i < ST_BUF_COUNT + kInternalPlanes; i++) { c.plane[i] = reinterpret_cast<float4*>(static_cast<char*>(c.slab) + off); off += (c.plane_bytes[i] + 255) & ~size_t(255); }
         ST_HIP(hipMalloc(reinterpret_cast<void**>(&c.counters), kCounterBytes));
         ST_HIP(hipMemset(c.counters, 0, kCounterBytes));
         memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
@@ -556,6 +557,7 @@ struct Engine {
         a.g1 = P(alt ? ST_BUF_PRIM_GBUFFER_D1_B : ST_BUF_PRIM_GBUFFER_D1_A); a.pg1 = P(alt ? ST_BUF_PRIM_GBUFFER_D1_A : ST_BUF_PRIM_GBUFFER_D1_B);
         a.sm = P(alt ? ST_BUF_PRIM_SURFACE_MAP_B : ST_BUF_PRIM_SURFACE_MAP_A); a.psm = P(alt ? ST_BUF_PRIM_SURFACE_MAP_A : ST_BUF_PRIM_SURFACE_MAP_B);
         a.sn = P(ST_BUF_COUNT + (alt ? 1 : 0)); a.psn = P(ST_BUF_COUNT + (alt ? 0 : 1));
+        a.sl[0] = reinterpret_cast<float2*>(P(ST_BUF_COUNT + 2)); a.sl[1] = a.sl[0] + (size_t)c.desc.width * c.desc.height;
         a.reprojection = P(ST_BUF_REPROJECTION_MAP); a.velocity = P(ST_BUF_VELOCITY_MAP);
         for (int i = 0; i < 3; i++) a.di_res[i] = P(ST_BUF_DI_RESERVOIRS_0 + i);
         a.di_diff_samples = P(ST_BUF_DI_DIFF_SAMPLES); a.di_diff_prev_colors = P(ST_BUF_DI_DIFF_PREV_COLORS); a.di_diff_curr_colors = P(ST_BUF_DI_DIFF_CURR_COLORS);
@@ -675,10 +677,10 @@ struct Engine {
                 const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
                 for (uint32_t nth = 0; nth < 5; nth++) {
                     if (nth == 4 && fuse_compose && out) {
-                        run(KS_DENOISE_WAVELET_COMPOSE, {}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], mode, out, cur); });
+                        run(KS_DENOISE_WAVELET_COMPOSE, {}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], a.sl[nth & 1u], mode, out, cur); });
                         composed = true;
                     } else
-                        run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], cur); });
+                        run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], a.sl[nth & 1u], nth == 4u ? nullptr : a.sl[(nth & 1u) ^ 1u], cur); });
                 }
             };
             auto do_compose = [&] {
@@ -689,7 +691,9 @@ struct Engine {
                 composed = true;
             };
 
-            if (overlap && needs_di && needs_gi && any_objects) {
+            // per-kernel profiling runs the graph serially on `stream`: a launch's event pair then times that kernel alone,
+            // not the kernels of the other stream it would share the chip with
+            if (overlap && !profiling && needs_di && needs_gi && any_objects) {
                 // Two streams, software-pipelined across frames. `side` carries primary visibility and the GI chain, `stream`
                 // carries the DI chain, the denoiser and composition; events express the true data dependencies only, so the
                 // bandwidth-bound reservoir passes of frame N+1 overlap the VALU-bound denoiser of frame N:

@@ -71,11 +71,12 @@ void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, cons
 void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const float4* prev_moments, const float4* samples, float4* colors,
                               float4* moments, hipStream_t s);
 void launch_denoise_variance(const KArgs& a, hipStream_t s);
+// sl_in / sl_out: sqrt-luma planes of the input / output colour planes (KArgs::sl); sl_out may be null (last pass)
 void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
-                            float4* gi_out, hipStream_t s);
+                            float4* gi_out, const float2* sl_in, float2* sl_out, hipStream_t s);
 // last wavelet pass + frame composition in one launch
 void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
-                                    float4* gi_out, uint32_t camera_mode, float4* frame_out, hipStream_t s);
+                                    float4* gi_out, const float2* sl_in, uint32_t camera_mode, float4* frame_out, hipStream_t s);
 void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out, hipStream_t s);
 
 }  // namespace st
