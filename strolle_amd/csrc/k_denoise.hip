@@ -5,13 +5,28 @@
 
 namespace st {
 
-ST_D float denoise_sample_weight(float center_luma, const Surface& cs, float sample_luma, const Surface& ss, float luma_sigma, float depth_sigma) {
-    const float luma_weight = fabsf(sqrtf(center_luma) - sqrtf(sample_luma)) * luma_sigma;
-    const float leeway = cs.depth * depth_sigma;
-    const float diff = fabsf(ss.depth - cs.depth);
-    const float depth_weight = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
-    const float normal_weight = pow64_(fmax_(dot(ss.normal, cs.normal), 0.0f));
-    return exp_(-luma_weight) * depth_weight * normal_weight;
+// The SVGF sample weight (frame_denoising.rs:363-398) is exp(-|sqrt(luma_c) - sqrt(luma_s)| * luma_sigma) * depth_weight *
+// normal_weight, multiplied in that order; the depth and normal factors do not depend on the signal, so the loops below
+// evaluate them once per tap and the exponential for both signals at once.
+
+// Packed pairs (direct, indirect): v_pk_mul_f32 / v_pk_add_f32 carry both signals through one issue slot each.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+ST_D f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+ST_D f2 splat2(float x) { return mk2(x, x); }
+
+// exp_() of both halves. Inside |x| < 87 none of exp_'s range branches fire and scale2() is a single multiplication by
+// 2^n with -126 <= n <= 126, so the straight-line packed evaluation is exp_() operation for operation; anything else
+// (NaN, overflow, the denormal tail) takes the scalar routine.
+ST_D f2 exp_pair(f2 x) {
+    if (!(fabsf(x.x) < 87.0f && fabsf(x.y) < 87.0f)) return mk2(exp_(x.x), exp_(x.y));
+    const f2 z = __builtin_elementwise_floor(1.44269504088896341f * x + 0.5f);
+    x = x - z * 0.693359375f;
+    x = x - z * -2.12194440e-4f;
+    const i2v n = __builtin_convertvector(z, i2v);
+    const f2 zz = x * x;
+    const f2 p = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * zz + x + 1.0f;
+    return p * mk2(b2f((uint32_t)(n.x + 127) << 23), b2f((uint32_t)(n.y + 127) << 23));
 }
 
 // ---------------------------------------------------------------- frame_denoising.rs:3-78
@@ -40,27 +55,37 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_variance(const KArgs 
         di_var = cdi_m.z - sqr(cdi_m.y);
         gi_var = cgi_m.z - sqr(cgi_m.y);
     } else {
-        V3 sum_di = v3s(0.0f), sum_gi = v3s(0.0f);
-        int ox = -2, oy = -2;
-        for (;;) {  // the reference's 29-tap window (frame_denoising.rs:128,180-189), kept as is
-            const I2 sp = i2((int32_t)pos.x + ox, (int32_t)pos.y + oy);
-            if (contains_i(a, sp)) {
-                const U2 up = u2((uint32_t)sp.x, (uint32_t)sp.y);
-                const Surface ss = surface_decoded(tex_read(a.sn, a, up));
-                if (ss.depth != 0.0f) {
-                    const float l = luma(xyz(tex_read(a.di_diff_curr_colors, a, up)));
-                    const float w = denoise_sample_weight(cdi_luma, cs, l, ss, 1.0f, 0.2f);
-                    sum_di = sum_di + v3(l, l * l, 1.0f) * v3s(w);
-                    const float lg = luma(xyz(tex_read(a.gi_diff_curr_colors, a, up)));
-                    const float wg = denoise_sample_weight(cgi_luma, cs, lg, ss, 1.0f, 0.2f);
-                    sum_gi = sum_gi + v3(lg, lg * lg, 1.0f) * v3s(wg);
-                }
+        // Short history: spatial estimate over the reference's 29-tap window (frame_denoising.rs:128,180-189: the walk
+        // starts at (-2,-2) and every later row starts at -3), kept as is. Only ~15 % of the waves get here, but they
+        // set the kernel's duration, so each window row is fetched as one batch of independent loads (10 memory round
+        // trips per wave instead of 58) and the two signals share packed-f32 arithmetic as in the wavelet pass.
+        const f2 c_sqrt_luma = mk2(sqrtf(cdi_luma), sqrtf(cgi_luma));
+        const float leeway = cs.depth * 0.2f;
+        f2 sum_l = splat2(0.0f), sum_ll = splat2(0.0f), sum_1 = splat2(0.0f);
+        for (int oy = -2; oy <= 2; oy++) {
+            float4 ssn[6], sdi[6], sgi[6];
+            bool live[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const I2 sp = i2((int32_t)pos.x + u - 3, (int32_t)pos.y + oy);
+                live[u] = contains_i(a, sp) && !(u == 0 && oy == -2);
+                const uint32_t at = live[u] ? (uint32_t)sp.y * a.width + (uint32_t)sp.x : pos.y * a.width + pos.x;
+                ssn[u] = a.sn[at]; sdi[u] = a.di_diff_curr_colors[at]; sgi[u] = a.gi_diff_curr_colors[at];
             }
-            ox += 1;
-            if (ox == 3) { ox = -3; oy += 1; if (oy == 3) break; }
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                if (!live[u] || ssn[u].w == 0.0f) continue;
+                const f2 l = (mk2(sdi[u].x, sgi[u].x) * 0.2126f + mk2(sdi[u].y, sgi[u].y) * 0.7152f) + mk2(sdi[u].z, sgi[u].z) * 0.0722f;
+                const f2 d = c_sqrt_luma - mk2(sqrtf(l.x), sqrtf(l.y));
+                const float diff = fabsf(ssn[u].w - cs.depth);
+                const float depth_weight = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
+                const float normal_weight = pow64_(fmax_(dot(v3(ssn[u].x, ssn[u].y, ssn[u].z), cs.normal), 0.0f));
+                const f2 w = exp_pair(-mk2(fabsf(d.x), fabsf(d.y))) * depth_weight * normal_weight;  // luma sigma 1: |d| * 1 == |d|
+                sum_l = sum_l + l * w; sum_ll = sum_ll + (l * l) * w; sum_1 = sum_1 + w;
+            }
         }
-        { const float m1 = sum_di.x / sum_di.z, m2 = sum_di.y / sum_di.z; di_var = fabsf(m2 - m1 * m1) * 4.0f; }
-        { const float m1 = sum_gi.x / sum_gi.z, m2 = sum_gi.y / sum_gi.z; gi_var = fabsf(m2 - m1 * m1) * 4.0f; }
+        { const float m1 = sum_l.x / sum_1.x, m2 = sum_ll.x / sum_1.x; di_var = fabsf(m2 - m1 * m1) * 4.0f; }
+        { const float m1 = sum_l.y / sum_1.y, m2 = sum_ll.y / sum_1.y; gi_var = fabsf(m2 - m1 * m1) * 4.0f; }
     }
     di_var = fmax_(di_var, 0.0f);
     gi_var = fmax_(gi_var, 0.0f);
@@ -76,25 +101,6 @@ void launch_denoise_variance(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_denois
 // same IEEE operations in the same order per half, half the issue slots. The weight's shared factors (depth, normal)
 // are evaluated once per tap; a tap whose shared factor is exactly zero is dropped before its colours are loaded —
 // its weight would be 0 or NaN and `w > 0` (frame_denoising.rs:318,340) rejects both.
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i2v __attribute__((ext_vector_type(2)));
-ST_D f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
-ST_D f2 splat2(float x) { return mk2(x, x); }
-
-// exp_() of both halves. Inside |x| < 87 none of exp_'s range branches fire and scale2() is a single multiplication by
-// 2^n with -126 <= n <= 126, so the straight-line packed evaluation is exp_() operation for operation; anything else
-// (NaN, overflow, the denormal tail) takes the scalar routine.
-ST_D f2 exp_pair(f2 x) {
-    if (!(fabsf(x.x) < 87.0f && fabsf(x.y) < 87.0f)) return mk2(exp_(x.x), exp_(x.y));
-    const f2 z = __builtin_elementwise_floor(1.44269504088896341f * x + 0.5f);
-    x = x - z * 0.693359375f;
-    x = x - z * -2.12194440e-4f;
-    const i2v n = __builtin_convertvector(z, i2v);
-    const f2 zz = x * x;
-    const f2 p = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * zz + x + 1.0f;
-    return p * mk2(b2f((uint32_t)(n.x + 127) << 23), b2f((uint32_t)(n.y + 127) << 23));
-}
-
 // COMPOSE: the last wavelet pass also runs frame composition for its pixel (frame_composition.rs) — the composed frame
 // needs only this pixel's denoised colours, which are in registers here.
 template <bool COMPOSE>
@@ -175,9 +181,90 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a
     if (sl_out) sl_out[center] = make_float2(sqrtf(luma(xyz(odi))), sqrtf(luma(xyz(ogi))));
     if (COMPOSE) frame_out[center] = compose_pixel(a, pos, camera_mode, odi, ogi);
 }
+// ---------------------------------------------------------------- the same pass for strides 1, 2 and 4, staged through LDS
+// At these strides the jitter is identically zero — |(bn - 0.5) * (stride - 1) * 0.5| <= 0.75 truncates to 0
+// (frame_denoising.rs:262-266) — so the taps of a block's 32x8 pixels fall on a fixed (32+2S)x(8+2S) window that the
+// block loads once (1.3-2.5 texels per pixel instead of 9) and then reads from LDS. Texels outside the viewport are
+// staged with depth 0: the tap loop already skips depth-0 (sky) samples, which is what `continue` on an out-of-bounds
+// tap does in the reference. Row pitch 40 texels: 640 B rows put 8-lane row segments of ds_read_b128 on disjoint banks.
+template <int S>
+__global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet_lds(const KArgs a, float strength, const float4* di_in, float4* di_out,
+                                                                        const float4* gi_in, float4* gi_out, const float2* sl_in, float2* sl_out) {
+    constexpr int RW = 32 + 2 * S, RH = 8 + 2 * S, PITCH = 40;
+    __shared__ float4 s_sn[PITCH * RH];
+    __shared__ float4 s_di[PITCH * RH];
+    __shared__ float4 s_gi[PITCH * RH];
+    __shared__ float2 s_sl[PITCH * RH];
+    const uint32_t tiles_x = (a.width + 7u) >> 3;
+    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
+    TileCoord tc = tile_for_thread(tiles_x, ty1 - ty0, a.tile_map);  // tc.y is block-uniform, tc.x = first tile of the block + wave
+    const uint32_t wave = threadIdx.x >> 6;
+    const int32_t bx0 = (int32_t)((tc.x - wave) * 8u) - S, by0 = (int32_t)((tc.y + ty0) * 8u) - S;
+    for (int i = (int)threadIdx.x; i < RW * RH; i += kBlockThreads) {
+        const int ry = i / RW, rx = i - ry * RW;
+        const int32_t gx = bx0 + rx, gy = by0 + ry;
+        const int li = ry * PITCH + rx;
+        if (gx >= 0 && gy >= 0 && gx < (int32_t)a.width && gy < (int32_t)a.height) {
+            const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
+            s_sn[li] = a.sn[at]; s_di[li] = di_in[at]; s_gi[li] = gi_in[at]; s_sl[li] = sl_in[at];
+        } else {
+            s_sn[li] = f4z();
+        }
+    }
+    __syncthreads();
+    if (!tc.valid) return;
+    tc.y += ty0;
+    const U2 pos = pixel_in_tile(tc);
+    if (!owns_pixel(a, pos)) return;
+    const uint32_t center = pos.y * a.width + pos.x;
+    const int lc = ((int)(pos.y & 7u) + S) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + S;
+    const float4 csn = s_sn[lc];
+    const float4 cdi = s_di[lc];
+    if (csn.w == 0.0f) { di_out[center] = cdi; return; }  // sky
+    const float4 cgi = s_gi[lc];
+    const V3 cn = v3(csn.x, csn.y, csn.z);
+    const float2 csl = s_sl[lc];
+    const f2 c_sqrt_luma = mk2(csl.x, csl.y);
+    const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, sqrtf(cdi.w)), lerpf(1.0f, 0.0f, sqrtf(cgi.w)));
+    const float leeway = csn.w * (0.33f / strength);
+    f2 sum_w = splat2(1.0f), sum_r = mk2(cdi.x, cgi.x), sum_g = mk2(cdi.y, cgi.y), sum_b = mk2(cdi.z, cgi.z), sum_v = mk2(cdi.w, cgi.w);
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
+        const int lt = lc + oy * S * PITCH + ox * S;
+        const float4 ssn = s_sn[lt];
+        if (ssn.w == 0.0f) continue;
+        const float diff = fabsf(ssn.w - csn.w);
+        const float depth_weight = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
+        const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
+        if (depth_weight == 0.0f || normal_weight == 0.0f) continue;
+        const float4 sdi = s_di[lt], sgi = s_gi[lt];
+        const float2 ssl = s_sl[lt];
+        const f2 r = mk2(sdi.x, sgi.x), g = mk2(sdi.y, sgi.y), b = mk2(sdi.z, sgi.z), v = mk2(sdi.w, sgi.w);
+        const f2 d = c_sqrt_luma - mk2(ssl.x, ssl.y);
+        const f2 luma_weight = mk2(fabsf(d.x), fabsf(d.y)) * luma_sigma;
+        const f2 w = exp_pair(-luma_weight) * depth_weight * normal_weight;
+        if (w.x > 0.0f && w.y > 0.0f) {
+            sum_w = sum_w + w; sum_r = sum_r + w * r; sum_g = sum_g + w * g; sum_b = sum_b + w * b; sum_v = sum_v + (w * w) * v;
+        } else {
+            if (w.x > 0.0f) { sum_w.x += w.x; sum_r.x += w.x * r.x; sum_g.x += w.x * g.x; sum_b.x += w.x * b.x; sum_v.x += (w.x * w.x) * v.x; }
+            if (w.y > 0.0f) { sum_w.y += w.y; sum_r.y += w.y * r.y; sum_g.y += w.y * g.y; sum_b.y += w.y * b.y; sum_v.y += (w.y * w.y) * v.y; }
+        }
+    }
+    const f2 ww = sum_w * sum_w;
+    const float4 odi = make_float4(sum_r.x / sum_w.x, sum_g.x / sum_w.x, sum_b.x / sum_w.x, sum_v.x / ww.x);
+    const float4 ogi = make_float4(sum_r.y / sum_w.y, sum_g.y / sum_w.y, sum_b.y / sum_w.y, sum_v.y / ww.y);
+    di_out[center] = odi;
+    gi_out[center] = ogi;
+    if (sl_out) sl_out[center] = make_float2(sqrtf(luma(xyz(odi))), sqrtf(luma(xyz(ogi))));
+}
+
 void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
                             float4* gi_out, const float2* sl_in, float2* sl_out, hipStream_t s) {
-    ST_LAUNCH(k_denoise_wavelet<false>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out, 0u, (float4*)nullptr);
+    if (stride == 1u) ST_LAUNCH(k_denoise_wavelet_lds<1>, false, s, a, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out);
+    else if (stride == 2u) ST_LAUNCH(k_denoise_wavelet_lds<2>, false, s, a, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out);
+    else if (stride == 4u) ST_LAUNCH(k_denoise_wavelet_lds<4>, false, s, a, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out);
+    else ST_LAUNCH(k_denoise_wavelet<false>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out, 0u, (float4*)nullptr);
 }
 void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
                                     float4* gi_out, const float2* sl_in, uint32_t camera_mode, float4* frame_out, hipStream_t s) {
