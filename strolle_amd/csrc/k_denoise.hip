@@ -120,8 +120,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a
     }
     const float4 cgi = gi_in[center];
     const V3 cn = v3(csn.x, csn.y, csn.z);
-    const float2 csl = sl_in[center];  // == sqrtf(luma(xyz(cdi))), sqrtf(luma(xyz(cgi))): written with the colours
-    const f2 c_sqrt_luma = mk2(csl.x, csl.y);
+    // sl_in == null: this pass's input has no sqrt-luma plane (the generic kernel serves strides 8 and 16, whose taps
+    // are texture-address-bound — a fourth load per tap costs more there than the two square roots it replaces)
+    f2 c_sqrt_luma;
+    if (sl_in) { const float2 csl = sl_in[center]; c_sqrt_luma = mk2(csl.x, csl.y); }
+    else c_sqrt_luma = mk2(sqrtf(luma(xyz(cdi))), sqrtf(luma(xyz(cgi))));
     const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, sqrtf(cdi.w)), lerpf(1.0f, 0.0f, sqrtf(cgi.w)));
     const float leeway = csn.w * (0.33f / strength);  // depth sigma is the same for both signals
     I2 jitter = i2(0, 0);
@@ -156,13 +159,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a
     for (int half = 0; half < 2; half++) {
         float4 sdi[4], sgi[4]; float2 ssl[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = at[half * 4 + u]; sdi[u] = di_in[i]; sgi[u] = gi_in[i]; ssl[u] = sl_in[i]; }
+        for (int u = 0; u < 4; u++) { const uint32_t i = at[half * 4 + u]; sdi[u] = di_in[i]; sgi[u] = gi_in[i]; if (sl_in) ssl[u] = sl_in[i]; }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = half * 4 + u;
             if (!live[t]) continue;
             const f2 r = mk2(sdi[u].x, sgi[u].x), g = mk2(sdi[u].y, sgi[u].y), b = mk2(sdi[u].z, sgi[u].z), v = mk2(sdi[u].w, sgi[u].w);
-            const f2 d = c_sqrt_luma - mk2(ssl[u].x, ssl[u].y);
+            f2 tap_sqrt_luma;
+            if (sl_in) tap_sqrt_luma = mk2(ssl[u].x, ssl[u].y);
+            else { const f2 l = (r * 0.2126f + g * 0.7152f) + b * 0.0722f; tap_sqrt_luma = mk2(sqrtf(l.x), sqrtf(l.y)); }
+            const f2 d = c_sqrt_luma - tap_sqrt_luma;
             const f2 luma_weight = mk2(fabsf(d.x), fabsf(d.y)) * luma_sigma;
             const f2 w = exp_pair(-luma_weight) * depth_w[t] * normal_w[t];
             if (w.x > 0.0f && w.y > 0.0f) {

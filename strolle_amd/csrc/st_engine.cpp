@@ -677,10 +677,10 @@ struct Engine {
                 const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
                 for (uint32_t nth = 0; nth < 5; nth++) {
                     if (nth == 4 && fuse_compose && out) {
-                        run(KS_DENOISE_WAVELET_COMPOSE, {}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], a.sl[nth & 1u], mode, out, cur); });
+                        run(KS_DENOISE_WAVELET_COMPOSE, {}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nullptr, mode, out, cur); });
                         composed = true;
                     } else
-                        run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], a.sl[nth & 1u], nth == 4u ? nullptr : a.sl[(nth & 1u) ^ 1u], cur); });
+                        run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nth <= 2u ? a.sl[nth & 1u] : nullptr, nth <= 1u ? a.sl[(nth & 1u) ^ 1u] : nullptr, cur); });
                 }
             };
             auto do_compose = [&] {

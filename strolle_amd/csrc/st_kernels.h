@@ -71,7 +71,8 @@ void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, cons
 void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const float4* prev_moments, const float4* samples, float4* colors,
                               float4* moments, hipStream_t s);
 void launch_denoise_variance(const KArgs& a, hipStream_t s);
-// sl_in / sl_out: sqrt-luma planes of the input / output colour planes (KArgs::sl); sl_out may be null (last pass)
+// sl_in / sl_out: sqrt-luma planes of the input / output colour planes (KArgs::sl). The LDS-staged strides (1, 2, 4)
+// require sl_in; strides 8 and 16 take null and derive the values from the colours. sl_out null = not needed downstream.
 void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
                             float4* gi_out, const float2* sl_in, float2* sl_out, hipStream_t s);
 // last wavelet pass + frame composition in one launch

@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 output that a gpurun call left under gpurun_out/ into the small, committed
+"""Turn the rocprofv3 output that `tools/gpu_profile_round.sh` left under gpurun_out/ into the small, committed
 summaries under profiles/.
 
   python tools/summarize_profiles.py r01          # tag for the file names
 
 Inputs (any that exist):
-  gpurun_out/prof_stats/**/*_kernel_stats.csv        rocprofv3 --kernel-trace --stats
-  gpurun_out/prof_fetch/**/*_counter_collection.csv  rocprofv3 --pmc FETCH_SIZE   (separate pass)
-  gpurun_out/prof_write/**/*_counter_collection.csv  rocprofv3 --pmc WRITE_SIZE   (separate pass)
+  gpurun_out/prof_stats/**/*_kernel_stats.csv          rocprofv3 --kernel-trace --stats of the default bench command
+  gpurun_out/prof_stats_serial/**/*_kernel_stats.csv   the same with ST_NO_OVERLAP=1 --no-profile (one kernel at a time)
+  gpurun_out/prof_fetch/**/*_counter_collection.csv    rocprofv3 --pmc FETCH_SIZE   (separate pass)
+  gpurun_out/prof_write/**/*_counter_collection.csv    rocprofv3 --pmc WRITE_SIZE   (separate pass)
+  gpurun_out/prof_sq/**/*_counter_collection.csv       rocprofv3 --pmc SQ_* (8 SQ slots, separate pass)
+  gpurun_out/bench_default.json                        the bench line of the same build
 Outputs:
-  profiles/<tag>_kernel_stats.csv   the st:: kernels' rows of the stats table
-  profiles/<tag>_pmc.json           per kernel: mean FETCH_SIZE / WRITE_SIZE (KiB) and HBM bytes per launch
-  profiles/pmc_latest.json          copy of the above (bench.py reads it for `roofline.traffic`)
+  profiles/<tag>_kernel_stats.csv          st:: rows of the default command's stats table (two-stream region + serial region)
+  profiles/<tag>_kernel_stats_serial.csv   st:: rows of the serial run + the bench slot aggregates (e.g. all 5 wavelet launches)
+  profiles/<tag>_pmc.json                  per kernel: mean FETCH_SIZE / WRITE_SIZE (KiB) and HBM bytes per launch
+  profiles/<tag>_sq.csv                    per kernel: VALU instructions per wave, VALU-busy share, wait shares
+  profiles/pmc_latest.json                 copy of <tag>_pmc.json (bench.py reads it for `roofline.traffic`)
+  profiles/<tag>_bench.json                copy of the bench line
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — on gfx950
 FETCH_SIZE reports half the bytes of wide coalesced reads (every plane access here is a 16-B-per-lane float4),
 WRITE_SIZE is taken as reported (uncalibrated, stated as such).
@@ -21,10 +27,21 @@ import glob
 import json
 import os
 import re
+import shutil
 import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# bench.py profiler slot (st_kernels.h kernel_info) -> the kernel symbols it launches
+SLOT_SYMBOLS = {
+    "denoise_wavelet": ["denoise_wavelet_lds<1>", "denoise_wavelet_lds<2>", "denoise_wavelet_lds<4>", "denoise_wavelet<false>"],
+    "denoise_wavelet+composition": ["denoise_wavelet<true>"],
+    "di_spatial_trace": ["spatial_trace<u16>"], "gi_spatial_trace": ["spatial_trace<u16>"],
+    "prim_visibility+frame_reprojection": ["prim_visibility<true,u16>"], "di_resolving+denoise_reproject": ["di_resolving<true,u16>"],
+    "gi_preview": ["gi_preview<false>"], "gi_preview+gi_resolving+denoise_reproject": ["gi_preview<true>"],
+    "di_sampling": ["di_sampling<u16>"], "gi_sampling_a": ["gi_sampling_a<u16>"], "gi_sampling_b": ["gi_sampling_b<u16>"],
+}
 
 
 def short(name: str) -> str:
@@ -40,49 +57,100 @@ def is_ours(name: str) -> bool:
     return "st::k_" in name
 
 
+def latest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def stats_rows(path):
+    rows = list(csv.DictReader(open(path)))
+    return [dict(r, Name=short(r["Name"])) for r in rows if is_ours(r["Name"])]
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "latest"
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
-    stats = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", "*_kernel_stats.csv"), recursive=True))
-    if stats:
-        rows = list(csv.reader(open(stats[-1])))
-        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
-            w = csv.writer(f)
-            w.writerow(rows[0])
-            for r in rows[1:]:
-                if r and is_ours(r[0]):
-                    w.writerow([short(r[0])] + r[1:])
+
+    f = latest("prof_stats/**/*_kernel_stats.csv")
+    if f:
+        rows = stats_rows(f)
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as o:
+            w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+    f = latest("prof_stats_serial/**/*_kernel_stats.csv")
+    if f:
+        rows = stats_rows(f)
+        by = {r["Name"]: r for r in rows}
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats_serial.csv"), "w", newline="") as o:
+            w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+            # aggregates under the profiler slot names bench.py reports (a slot may launch several symbols)
+            for slot, syms in SLOT_SYMBOLS.items():
+                have = [by[s] for s in syms if s in by]
+                if len(have) < 2:
+                    continue
+                calls = sum(int(r["Calls"]) for r in have)
+                total = sum(float(r["TotalDurationNs"]) for r in have)
+                w.writerow({"Name": f"[slot] {slot}", "Calls": calls, "TotalDurationNs": int(total), "AverageNs": f"{total / calls:.1f}",
+                            "Percentage": f"{sum(float(r['Percentage']) for r in have):.2f}",
+                            "MinNs": min(int(r["MinNs"]) for r in have), "MaxNs": max(int(r["MaxNs"]) for r in have), "StdDev": ""})
+
     pmc = defaultdict(lambda: defaultdict(list))
     for kind, counter in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
-        files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", kind, "**", "*_counter_collection.csv"), recursive=True))
-        if not files:
+        f = latest(f"{kind}/**/*_counter_collection.csv")
+        if not f:
             continue
-        for r in csv.DictReader(open(files[-1])):
+        for r in csv.DictReader(open(f)):
             if is_ours(r["Kernel_Name"]) and r["Counter_Name"] == counter:
                 pmc[short(r["Kernel_Name"])][counter].append(float(r["Counter_Value"]))
     if pmc:
+        def tail(v):  # second half of the launches: warm-up frames have cold history
+            return v[len(v) // 2:] if len(v) > 4 else v
         summary = {}
         for k, c in sorted(pmc.items()):
-            # skip the first 12 launches per kernel where possible (warm-up frames have cold history)
-            def mean(v):
-                v = v[len(v) // 2:] if len(v) > 4 else v
-                return sum(v) / len(v) if v else None
-            f, w = mean(c.get("FETCH_SIZE", [])), mean(c.get("WRITE_SIZE", []))
-            summary[k] = {"fetch_size_kib": f, "write_size_kib": w,
-                          "hbm_bytes_per_launch": None if f is None or w is None else round((2.0 * f + w) * 1024.0),
-                          "launches_sampled": len(c.get("FETCH_SIZE", []))}
-        # aliases under the profiler slot names bench.py uses (st_kernels.h kernel_info)
-        alias = {"di_spatial_trace": "spatial_trace<u16>", "gi_spatial_trace": "spatial_trace<u16>",
-                 "denoise_wavelet": "denoise_wavelet<false>", "denoise_wavelet+composition": "denoise_wavelet<true>",
-                 "prim_visibility+frame_reprojection": "prim_visibility<true,u16>", "di_resolving+denoise_reproject": "di_resolving<true,u16>",
-                 "gi_preview": "gi_preview<false>", "gi_preview+gi_resolving+denoise_reproject": "gi_preview<true>",
-                 "di_sampling": "di_sampling<u16>", "gi_sampling_a": "gi_sampling_a<u16>", "gi_sampling_b": "gi_sampling_b<u16>"}
-        for slot, kernel in alias.items():
-            if kernel in summary:
-                summary[slot] = summary[kernel]
+            fv, wv = tail(c.get("FETCH_SIZE", [])), tail(c.get("WRITE_SIZE", []))
+            fm = sum(fv) / len(fv) if fv else None
+            wm = sum(wv) / len(wv) if wv else None
+            summary[k] = {"fetch_size_kib": fm, "write_size_kib": wm,
+                          "hbm_bytes_per_launch": None if fm is None or wm is None else round((2.0 * fm + wm) * 1024.0),
+                          "launches_sampled": len(fv)}
+        for slot, syms in SLOT_SYMBOLS.items():
+            have = [summary[s] for s in syms if s in summary and summary[s]["hbm_bytes_per_launch"] is not None]
+            if not have:
+                continue
+            n = sum(h["launches_sampled"] for h in have)
+            summary[slot] = {"fetch_size_kib": sum(h["fetch_size_kib"] * h["launches_sampled"] for h in have) / n,
+                             "write_size_kib": sum(h["write_size_kib"] * h["launches_sampled"] for h in have) / n,
+                             "hbm_bytes_per_launch": round(sum(h["hbm_bytes_per_launch"] * h["launches_sampled"] for h in have) / n),
+                             "launches_sampled": n, "symbols": syms}
         for name in (f"{tag}_pmc.json", "pmc_latest.json"):
             json.dump(summary, open(os.path.join(out_dir, name), "w"), indent=1, sort_keys=True)
+
+    f = latest("prof_sq/**/*_counter_collection.csv")
+    if f:
+        sq = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            if is_ours(r["Kernel_Name"]):
+                sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        with open(os.path.join(out_dir, f"{tag}_sq.csv"), "w", newline="") as o:
+            w = csv.writer(o)
+            w.writerow(["kernel", "waves", "valu_insts_per_wave", "valu_cycles_share_of_wave_life", "wait_any_share", "wait_inst_share",
+                        "active_any_share", "valu_floor_us_at_2.4GHz"])
+            rows = []
+            for k, c in sq.items():
+                m = {n: (sum(v[len(v) // 2:]) / max(1, len(v[len(v) // 2:]))) for n, v in c.items()}
+                if not m.get("SQ_WAVES"):
+                    continue
+                wc = m["SQ_WAVE_CYCLES"]
+                # one wave64 VALU op occupies its SIMD for 4 cycles; 1024 SIMDs
+                floor_us = m["SQ_INSTS_VALU"] * 4.0 / 1024.0 / 2400.0
+                rows.append([k, int(m["SQ_WAVES"]), round(m["SQ_INSTS_VALU"] / m["SQ_WAVES"]), round(m["SQ_ACTIVE_INST_VALU"] / wc, 3),
+                             round(m["SQ_WAIT_ANY"] / wc, 3), round(m["SQ_WAIT_INST_ANY"] / wc, 3), round(m["SQ_ACTIVE_INST_ANY"] / wc, 3), round(floor_us, 1)])
+            rows.sort(key=lambda r: -r[-1])
+            w.writerows(rows)
+
+    b = os.path.join(ROOT, "gpurun_out", "bench_default.json")
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(out_dir, f"{tag}_bench.json"))
     print("wrote", sorted(os.listdir(out_dir)))
 
 
