@@ -87,14 +87,24 @@ def dungeon_camera(size, mode=CameraMode.IMAGE, denoise=True, depth=0) -> Camera
 
 
 def build_random_soup(engine, n_triangles: int, seed: int = 0, n_lights: int = 3, blend_fraction: float = 0.0):
-    """Synthetic stress scene for parity tests: a random triangle soup in [-1,1]^3 with a few materials/lights."""
+    """Synthetic stress scene for parity tests: a random triangle soup in [-1,1]^3 with a few materials/lights.
+    blend_fraction > 0 turns that share of the materials into AlphaMode::Blend ones with an RGBA texture whose alpha is
+    0, 0.5 or 1 per texel (traversal's alpha test, ray.rs:184-214); n_lights > 16 exercises the 16-pick RIS over a longer
+    light table (reservoir/ephemeral.rs:14-55)."""
     rng = np.random.default_rng(seed)
     engine.set_blue_noise(load_blue_noise())
     n_mat = 4
+    n_blend = int(round(blend_fraction * n_mat))
+    if n_blend:
+        tex = rng.integers(0, 256, (32, 32, 4), dtype=np.uint8)
+        tex[..., 3] = rng.choice(np.array([0, 128, 255], np.uint8), (32, 32))
+        engine.insert_image(900, tex, srgb=True)
     for i in range(n_mat):
-        engine.insert_material(1 + i, Material(base_color=rng.uniform(0.2, 0.9, 3).tolist() + [1.0], perceptual_roughness=float(rng.uniform(0.2, 1.0)),
+        blend = i < n_blend
+        engine.insert_material(1 + i, Material(base_color=rng.uniform(0.2, 0.9, 3).tolist() + [0.9 if blend else 1.0], perceptual_roughness=float(rng.uniform(0.2, 1.0)),
                                                metallic=float(rng.uniform(0.0, 0.8)) if i % 2 else 0.0,
-                                               emissive=(rng.uniform(0, 0.5, 3).tolist() + [1.0]) if i == 3 else (0, 0, 0, 0)))
+                                               emissive=(rng.uniform(0, 0.5, 3).tolist() + [1.0]) if i == 3 else (0, 0, 0, 0),
+                                               alpha_mode=1 if blend else 0, base_color_texture=900 if blend else None))
     per = max(1, n_triangles // n_mat)
     for i in range(n_mat):
         c = rng.uniform(-1, 1, (per, 1, 3)).astype(np.float32)

@@ -305,3 +305,90 @@ def test_back_to_back_frames_without_sync_bit_exact(scene):
         assert_bits_equal(prod.read_buffer(cp, b), orac.read_buffer(co, b), f"buffer {b.name} after {frames} unsynchronised frames")
     assert_bits_equal(img, ref, "composed frame")
     assert prod.ray_count(cp) == orac.ray_count(co)
+
+
+def test_large_bvh_uses_32bit_stack_entries_bit_exact():
+    """A BVH stream longer than 65,536 float4 switches the traversal kernels to 32-bit LDS stack entries (k_common.h
+    ST_LAUNCH_TRACE): heatmap integers, Reference and Image planes must still equal the oracle."""
+    torch = _torch()
+    size = (160, 96)
+    build = lambda e: scenes.build_random_soup(e, 40000, seed=9)
+    prod, orac, desc, cp, co = _pair(build, size, CameraMode.BVH_HEATMAP)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    img, ref = _step(torch, prod, orac, desc, cp, co, out)
+    n_float4 = prod.read_scene(0).size // 4
+    assert n_float4 > 65536, f"scene too small to leave the 16-bit path: {n_float4} float4"
+    assert np.array_equal(prod.read_buffer(cp, Buffer.DBG_USED_MEMORY), orac.read_buffer(co, Buffer.DBG_USED_MEMORY))
+    assert_bits_equal(img, ref, "heatmap colours (u32 stack)")
+    for mode, frames in ((CameraMode.REFERENCE, 2), (CameraMode.IMAGE, 5)):
+        desc = scenes.cornell_camera(size, mode, depth=1)
+        for frame in range(frames):
+            img, ref = _step(torch, prod, orac, desc, cp, co, out)
+            _compare_all(prod, orac, cp, co, frame)
+            assert_bits_equal(img, ref, f"{mode.name} frame {frame} (u32 stack)")
+
+
+def test_alpha_blend_materials_and_many_lights_bit_exact():
+    """Blend materials with a textured alpha channel (traversal's alpha test and its +128 B of used_memory) and a light
+    table longer than the 16 RIS picks."""
+    torch = _torch()
+    size = (128, 80)
+    build = lambda e: scenes.build_random_soup(e, 1500, seed=21, n_lights=24, blend_fraction=0.5)
+    prod, orac, desc, cp, co = _pair(build, size, CameraMode.BVH_HEATMAP)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    img, ref = _step(torch, prod, orac, desc, cp, co, out)
+    assert np.array_equal(prod.read_buffer(cp, Buffer.DBG_USED_MEMORY), orac.read_buffer(co, Buffer.DBG_USED_MEMORY))
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    for frame in range(7):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"blend+lights frame {frame}")
+
+
+def test_empty_world_bit_exact():
+    """No instances: the BVH is empty, primary visibility clears its targets, the DI/GI chains are skipped
+    (camera_controller.rs:118-143) and composition shows the sky."""
+    torch = _torch()
+    size = (96, 64)
+    def build(e):
+        e.set_blue_noise(scenes.load_blue_noise())
+        from strolle_amd import Sun
+        e.update_sun(Sun(azimuth=0.3, altitude=0.6))
+    for mode in (CameraMode.IMAGE, CameraMode.REFERENCE, CameraMode.BVH_HEATMAP):
+        prod, orac, desc, cp, co = _pair(build, size, mode, depth=1)
+        out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+        for frame in range(3):
+            img, ref = _step(torch, prod, orac, desc, cp, co, out)
+            _compare_all(prod, orac, cp, co, frame)
+            assert_bits_equal(img, ref, f"empty world {mode.name} frame {frame}")
+
+
+def test_scene_edits_between_frames_bit_exact():
+    """The host path under change (Engine::tick, lib.rs:301-395): a light removed (its slot is killed for one frame —
+    the 0xcafebabe marker di_temporal looks for), a light added, an instance removed, a material replaced, the camera
+    resized (buffers are rebuilt, camera.rs:17-48) and its mode switched, all between rendered frames."""
+    torch = _torch()
+    from strolle_amd import Light, Material
+    size = (128, 80)
+    prod, orac = Engine(device=0), OracleEngine()
+    for e in (prod, orac):
+        scenes.build_random_soup(e, 1200, seed=13, n_lights=4); e.set_seed(5)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    cp, co = prod.create_camera(desc), orac.create_camera(desc)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(14):
+        for e in (prod, orac):
+            if frame == 3: e.remove_light(2)
+            if frame == 5: e.insert_light(9, Light.point((0.2, 0.8, 0.4), 0.1, (1.5, 1.2, 0.9), 20.0))
+            if frame == 6: e.remove_instance(3)
+            if frame == 8: e.insert_material(1, Material(base_color=(0.9, 0.2, 0.2, 1.0), perceptual_roughness=0.4, metallic=0.3))
+            if frame == 9: e.remove_light(1)
+        if frame == 10:
+            size = (96, 72)
+            desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+            out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+        if frame == 12:
+            desc = scenes.cornell_camera(size, CameraMode.GI_DIFFUSE)
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"edited scene frame {frame}")
