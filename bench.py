@@ -59,7 +59,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--apron", type=int, default=32, help="extra rows rendered around a rank's band in Image mode (N > 1)")
-    ap.add_argument("--scene", choices=["cornell", "dungeon"], default="cornell", help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene")
+    ap.add_argument("--scene", choices=["cornell", "dungeon", "dungeon134k"], default="cornell",
+                    help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene (level.glb, 8,393 triangles); dungeon134k = the same surface subdivided twice (synthetic ~100k-triangle stand-in)")
     ap.add_argument("--mode", choices=["image", "gi_diffuse", "reference", "heatmap"], default="image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
@@ -90,7 +91,7 @@ def main():
         scenes.build_cornell(engine)
         desc = scenes.cornell_camera((width, height), mode, depth=1)
     else:
-        scenes.build_dungeon(engine)
+        scenes.build_dungeon(engine, subdivide=2 if args.scene == "dungeon134k" else 0)
         desc = scenes.dungeon_camera((width, height), mode, depth=1)
     engine.set_seed(args.seed)
     cam = engine.create_camera(desc)
@@ -177,7 +178,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"Cornell box {width}x{height}, CameraMode::Image{{denoise:true}} (1 spp ReSTIR DI+GI + SVGF), static camera, point light at t=0"
                                     if (args.scene, args.mode) == ("cornell", "image") else f"{args.scene} {width}x{height}, mode {args.mode} (NOT the headline workload)"),
-                       "scene": "cornell (32 triangles, 2 light slots)" if args.scene == "cornell" else "dungeon level.glb (8,393 triangles, 45 textured materials, 7 light slots)",
+                       "scene": {"cornell": "cornell (32 triangles, 2 light slots)", "dungeon": "dungeon level.glb (8,393 triangles, 45 textured materials, 7 light slots)",
+                                 "dungeon134k": "SYNTHETIC: dungeon level.glb with every triangle split into 16 (134,288 triangles), same materials and lights"}[args.scene],
                        "width": width, "height": height,
                        "per_gpu_rows": band[1] - band[0], "apron_rows": args.apron if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,

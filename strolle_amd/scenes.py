@@ -22,7 +22,20 @@ def load_blue_noise() -> np.ndarray:
     return np.load(os.path.join(ASSETS, "blue_noise.npy"))
 
 
-def _insert_gltf(engine, npz, material_overrides=None, first_handle=1):
+def _subdivide(pos, nrm, uv, levels: int):
+    """Midpoint subdivision, 4 triangles per level: the surface, normals and texture mapping are unchanged, only the
+    triangle count (and with it the BVH) grows. float32 midpoints, deterministic."""
+    for _ in range(levels):
+        out = []
+        for a in (pos, nrm, uv):
+            v0, v1, v2 = a[:, 0], a[:, 1], a[:, 2]
+            m01, m12, m20 = (v0 + v1) * np.float32(0.5), (v1 + v2) * np.float32(0.5), (v2 + v0) * np.float32(0.5)
+            out.append(np.concatenate([np.stack([v0, m01, m20], 1), np.stack([m01, v1, m12], 1), np.stack([m20, m12, v2], 1), np.stack([m01, m12, m20], 1)], 0))
+        pos, nrm, uv = out
+    return pos, nrm, uv
+
+
+def _insert_gltf(engine, npz, material_overrides=None, first_handle=1, subdivide: int = 0):
     n_mat = len(npz["material_metallic"])
     n_img = int(npz["n_images"]) if "n_images" in npz else 0
     for i in range(n_img):
@@ -43,7 +56,12 @@ def _insert_gltf(engine, npz, material_overrides=None, first_handle=1):
         engine.insert_material(first_handle + i, Material(**kw))
     n = int(npz["n_meshes"])
     for i in range(n):
-        engine.insert_mesh(first_handle + i, Mesh(npz[f"positions_{i}"], npz[f"normals_{i}"], npz[f"uvs_{i}"]))
+        pos, nrm, uv = npz[f"positions_{i}"], npz[f"normals_{i}"], npz[f"uvs_{i}"]
+        if subdivide:
+            n_tri = len(np.asarray(pos).reshape(-1, 3, 3))
+            pos, nrm, uv = _subdivide(np.asarray(pos, np.float32).reshape(n_tri, 3, 3), np.asarray(nrm, np.float32).reshape(n_tri, 3, 3),
+                                      np.asarray(uv, np.float32).reshape(n_tri, 3, 2), subdivide)
+        engine.insert_mesh(first_handle + i, Mesh(pos, nrm, uv))
         x = npz[f"xform_{i}"].reshape(4, 3).T  # [x_axis y_axis z_axis t] columns -> 3x4
         engine.insert_instance(first_handle + i, Instance(first_handle + i, first_handle + int(npz[f"material_{i}"]), x))
     return n
@@ -70,11 +88,13 @@ def cornell_camera(size, mode=CameraMode.IMAGE, denoise=True, depth=0) -> Camera
     return camera_for(size, (0.0, 1.0, 3.2), (0.0, 1.0, 0.0), mode, denoise, depth)  # cornell.rs:76-78
 
 
-def build_dungeon(engine):
-    """demo.rs:155-218 without the three emissive tori (Bevy's shape::Torus tessellation is not available here)."""
+def build_dungeon(engine, subdivide: int = 0):
+    """demo.rs:155-218 without the three emissive tori (Bevy's shape::Torus tessellation is not available here).
+    subdivide = k splits every triangle into 4^k (SYNTHETIC: k = 2 gives the ~134 k-triangle variant that stands in for
+    BASELINE.json's "~100k tris" dungeon; level.glb itself has 8,393)."""
     npz = np.load(os.path.join(ASSETS, "dungeon.npz"))
     engine.set_blue_noise(load_blue_noise())
-    _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0))
+    _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0), subdivide=subdivide)
     intensity = 5000.0 / (4.0 * math.pi)
     lights = [(-3.0, 0.75, -23.0), (-23.5, 0.75, -31.0), (1.25, 0.75, -10.5), (-3.15, 0.75, 1.25), (-3.25, 0.75, 20.25), (13.25, 0.75, -28.25)]
     for i, p in enumerate(lights):

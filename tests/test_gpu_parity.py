@@ -41,11 +41,12 @@ def _compare_all(prod, orac, cp, co, frame, buffers=ALL_FLOAT_BUFFERS):
         assert_bits_equal(prod.read_buffer(cp, b), orac.read_buffer(co, b), f"frame {frame} buffer {b.name}")
 
 
-@pytest.mark.parametrize("scene,size", [("cornell", (256, 256)), ("cornell", (333, 200)), ("soup", (200, 120)), ("dungeon", (320, 180))])
+@pytest.mark.parametrize("scene,size", [("cornell", (256, 256)), ("cornell", (333, 200)), ("soup", (200, 120)), ("dungeon", (320, 180)), ("dungeon134k", (320, 180))])
 def test_bvh_heatmap_used_memory_bit_exact(scene, size):
     torch = _torch()
-    build = {"cornell": scenes.build_cornell, "soup": lambda e: scenes.build_random_soup(e, 3000, seed=5), "dungeon": scenes.build_dungeon}[scene]
-    cam = scenes.dungeon_camera if scene == "dungeon" else scenes.cornell_camera
+    build = {"cornell": scenes.build_cornell, "soup": lambda e: scenes.build_random_soup(e, 3000, seed=5), "dungeon": scenes.build_dungeon,
+             "dungeon134k": lambda e: scenes.build_dungeon(e, subdivide=2)}[scene]  # synthetic ~100k-triangle stand-in (BASELINE.json config 3)
+    cam = scenes.dungeon_camera if scene.startswith("dungeon") else scenes.cornell_camera
     prod, orac, desc, cp, co = _pair(build, size, CameraMode.BVH_HEATMAP, camera_fn=cam)
     out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
     img, ref = _step(torch, prod, orac, desc, cp, co, out)
