@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--scene", choices=["cornell", "dungeon", "dungeon134k"], default="cornell",
                     help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene (level.glb, 8,393 triangles); dungeon134k = the same surface subdivided twice (synthetic ~100k-triangle stand-in)")
     ap.add_argument("--mode", choices=["image", "gi_diffuse", "reference", "heatmap"], default="image")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last (gathered) frame as .npy — tests compare it with a single-GPU render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
     args = ap.parse_args()
@@ -78,10 +79,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # ST_BENCH_DEBUG_SHARED_GPU=1 (functional check only, never a result): all ranks render on cuda:0 and the gather goes
+    # through gloo + host copies, so that the N > 1 control flow can be exercised on a single-GPU box.
+    debug_shared = os.environ.get("ST_BENCH_DEBUG_SHARED_GPU") == "1"
+    if debug_shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if debug_shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     base = (args.width, args.height)
     width, height = weak_scaling_frame(base, world)
@@ -124,7 +133,14 @@ def main():
         rendered = torch.cuda.Event(); rendered.record(main)
         comm.wait_event(rendered)
         with torch.cuda.stream(comm):
-            gather_bands_to_root(out, full, height, world, rank)   # the only collective: bands -> rank 0 over RCCL
+            if debug_shared:
+                comm.synchronize()
+                host_full = torch.zeros((height, width, 4)) if rank == 0 else None
+                gather_bands_to_root(out.cpu(), host_full, height, world, rank)
+                if rank == 0:
+                    full.copy_(host_full)
+            else:
+                gather_bands_to_root(out, full, height, world, rank)   # the only collective: bands -> rank 0 over RCCL
             done = torch.cuda.Event(); done.record(comm)
         gathered[k] = done
         return full if rank == 0 else out
@@ -160,7 +176,7 @@ def main():
         prof = engine.profile_read(reset=True)
         engine.profile_enable(False)
         profiled_ms = elapsed_p / args.steps * 1e3
-    t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cpu" if debug_shared else f"cuda:{local_rank}")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -168,6 +184,9 @@ def main():
     else:
         rays_total = float(rays)
     finite = bool(torch.isfinite(frame).all())
+    if rank == 0 and args.dump_frame:
+        import numpy as np
+        np.save(args.dump_frame, frame.cpu().numpy())
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -183,6 +202,7 @@ def main():
                        "width": width, "height": height,
                        "per_gpu_rows": band[1] - band[0], "apron_rows": args.apron if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
+                       **({"DEBUG_NOT_A_RESULT": "ranks share cuda:0, gather through gloo + host copies"} if debug_shared else {}),
                        "partition": "single GPU" if world == 1 else f"{world} row bands, per-frame RCCL gather of the RGBA32F bands to rank 0 overlapped with the next frame"},
         }
         if prof:

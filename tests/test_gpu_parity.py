@@ -393,3 +393,35 @@ def test_scene_edits_between_frames_bit_exact():
         img, ref = _step(torch, prod, orac, desc, cp, co, out)
         _compare_all(prod, orac, cp, co, frame)
         assert_bits_equal(img, ref, f"edited scene frame {frame}")
+
+
+def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (row bands, aprons, double-buffered targets, per-frame gather on a side stream, ray
+    accounting, JSON) run as two processes that share cuda:0 and gather through gloo (ST_BENCH_DEBUG_SHARED_GPU=1):
+    a functional check of everything except RCCL itself. In Reference mode the gathered frame must equal a
+    single-process render of the whole frame bit for bit."""
+    import json, os, subprocess, sys
+    torch = _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = tmp_path / "frame.npy"
+    env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--width", "128", "--height", "64", "--mode", "reference",
+           "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["width"] == 128 and out["config"]["height"] == 128 and out["config"]["frame_finite"]
+    assert out["config"]["rays_per_frame"] > 0 and out["value"] > 0
+    got = np.load(dump)
+    # the same 5 frames in one process
+    prod = Engine(device=0)
+    scenes.build_cornell(prod); prod.set_seed(0)
+    desc = scenes.cornell_camera((128, 128), CameraMode.REFERENCE, depth=1)
+    cam = prod.create_camera(desc)
+    frame = torch.zeros((128, 128, 4), dtype=torch.float32, device="cuda:0")
+    for _ in range(5):
+        prod.update_camera(cam, desc); prod.tick(); prod.render_camera(cam, frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert_bits_equal(got, frame.cpu().numpy(), "gathered two-band frame vs single-process frame")
