@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--apron", type=int, default=32, help="extra rows rendered around a rank's band in Image mode (N > 1)")
+    ap.add_argument("--apron", type=int, default=16, help="extra rows rendered around a rank's band in Image mode (N > 1)")
     ap.add_argument("--scene", choices=["cornell", "dungeon", "dungeon134k"], default="cornell",
                     help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene (level.glb, 8,393 triangles); dungeon134k = the same surface subdivided twice (synthetic ~100k-triangle stand-in)")
     ap.add_argument("--mode", choices=["image", "gi_diffuse", "reference", "heatmap"], default="image")
