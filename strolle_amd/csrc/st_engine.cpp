@@ -626,15 +626,21 @@ struct Engine {
                 else run(KS_PRIM_VISIBILITY, {}, [&] { launch_prim_visibility(a, false, cur); });
                 if (any_objects && !fuse) run(KS_FRAME_REPROJECTION, {}, [&] { launch_frame_reprojection(a, cur); });
             };
-            auto do_di = [&] {
+            // DI up to temporal resampling touches only the DI reservoirs and read-only frame inputs ...
+            auto do_di_head = [&] {
                 run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), cur); });
                 run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), cur); });
+            };
+            // ... the spatial passes use the denoiser's planes as scratch (passes/di_spatial_resampling.rs binds
+            // di_diff_samples / curr_colors / stash), and resolving writes the planes the denoiser reads
+            auto do_di_tail = [&] {
                 run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), cur); });
                 run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, cur); });
                 run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), cur); });
                 if (fuse && denoise) { run(KS_DI_RESOLVING_REPROJECT, {}, [&] { launch_di_resolving(a, true, cur); }); di_reprojected = true; }
                 else run(KS_DI_RESOLVING, {}, [&] { launch_di_resolving(a, false, cur); });
             };
+            auto do_di = [&] { do_di_head(); do_di_tail(); };
             // GI up to the first preview pass: touches only reservoirs, gi_d0..2 and read-only frame inputs
             auto do_gi_head = [&] {
                 run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, cur); });
@@ -694,12 +700,14 @@ struct Engine {
             // per-kernel profiling runs the graph serially on `stream`: a launch's event pair then times that kernel alone,
             // not the kernels of the other stream it would share the chip with
             if (overlap && !profiling && needs_di && needs_gi && any_objects) {
-                // Two streams, software-pipelined across frames. `side` carries primary visibility and the GI chain, `stream`
-                // carries the DI chain, the denoiser and composition; events express the true data dependencies only, so the
-                // bandwidth-bound reservoir passes of frame N+1 overlap the VALU-bound denoiser of frame N:
-                //   prim(N+1)      after DI(N)            — it overwrites frame N's "previous" G-buffer + the reprojection map
+                // Two streams, software-pipelined across frames and balanced (≈ 0.7 ms of kernels each at 1080p): `side`
+                // carries primary visibility, DI sampling + temporal resampling and the GI chain; `stream` carries the DI
+                // spatial passes + resolving, the denoiser and composition. Events express the true data dependencies only,
+                // so the reservoir passes of frame N+1 overlap the denoiser of frame N:
+                //   prim(N+1)      after DI tail(N)       — it overwrites frame N's "previous" G-buffer + the reprojection map
                 //   GI tail(N+1)   after frame N is done  — it writes gi sample/colour/moment planes the denoiser + composition read
-                //   DI(N+1)        after prim(N+1)        (and after frame N's denoiser by stream order: DI scratch aliases its planes)
+                //   DI tail(N+1)   after DI head(N+1)     (and after frame N's composition by stream order: its scratch aliases
+                //                                          the denoiser's planes)
                 //   denoiser(N+1)  after GI tail(N+1)
                 if (!side_stream) {
                     ST_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
@@ -712,14 +720,15 @@ struct Engine {
                 if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_prim_ok, 0));
                 cur = side_stream;
                 do_prim();
-                ST_HIP(hipEventRecord(ev_prim, side_stream));
+                do_di_head();
+                ST_HIP(hipEventRecord(ev_prim, side_stream));  // primary visibility + DI head of this frame are through
                 do_gi_head();
                 if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_frame_done, 0));
                 do_gi_tail();
                 ST_HIP(hipEventRecord(ev_gi_done, side_stream));
                 cur = stream;
                 ST_HIP(hipStreamWaitEvent(stream, ev_prim, 0));
-                do_di();
+                do_di_tail();
                 // stand-alone denoise reprojection kernels (unfused path) still read the reprojection map: prim(N+1) may
                 // only start once they are through
                 const bool reproject_later = denoise && !fuse;
