@@ -43,43 +43,70 @@ void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const f
 
 // ---------------------------------------------------------------- frame_denoising.rs:80-217
 __global__ __launch_bounds__(kBlockThreads) void k_denoise_variance(const KArgs a) {
-    U2 pos;
-    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    const Surface cs = surface_decoded(tex_read(a.sn, a, pos));
-    const float4 cdi = tex_read(a.di_diff_curr_colors, a, pos), cdi_m = tex_read(a.di_diff_moments, a, pos);
-    const float4 cgi = tex_read(a.gi_diff_curr_colors, a, pos), cgi_m = tex_read(a.gi_diff_moments, a, pos);
-    if (cs.depth == 0.0f) { tex_write(a.di_diff_stash, a, pos, cdi); tex_write(a.gi_diff_stash, a, pos, cgi); return; }
+    // Window of the short-history estimate, staged per block when any of its pixels needs it: ox in [-3, 2], oy in
+    // [-2, 2] around 32x8 pixels = 38 x 12 texels of (surface, direct colour, indirect colour). Only ~15 % of the waves
+    // take the slow path on Cornell, but with 58 dependent loads each they set the kernel's duration; from LDS the same
+    // 29 taps cost one staging round trip. Texels outside the viewport are staged as depth 0, which the loop skips just
+    // as it skips out-of-bounds and sky taps (frame_denoising.rs:135-140).
+    constexpr int RW = 38, RH = 12, PITCH = 40;
+    __shared__ float4 s_sn[PITCH * RH];
+    __shared__ float4 s_di[PITCH * RH];
+    __shared__ float4 s_gi[PITCH * RH];
+    const uint32_t tiles_x = (a.width + 7u) >> 3;
+    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
+    TileCoord tc = tile_for_thread(tiles_x, ty1 - ty0, a.tile_map);
+    const uint32_t wave = threadIdx.x >> 6;
+    tc.y += ty0;
+    const U2 pos = pixel_in_tile(tc);
+    const bool mine = tc.valid && owns_pixel(a, pos);
+    const uint32_t center = pos.y * a.width + pos.x;
+    float4 csn = f4z(), cdi = f4z(), cdi_m = f4z(), cgi = f4z(), cgi_m = f4z();
+    if (mine) { csn = a.sn[center]; cdi = a.di_diff_curr_colors[center]; cdi_m = a.di_diff_moments[center]; cgi = a.gi_diff_curr_colors[center]; cgi_m = a.gi_diff_moments[center]; }
+    const bool slow = mine && csn.w != 0.0f && !(cdi_m.x >= 4.0f);
+    if (__syncthreads_or(slow ? 1 : 0)) {
+        const int32_t bx0 = (int32_t)((tc.x - wave) * 8u) - 3, by0 = (int32_t)(tc.y * 8u) - 2;
+        for (int i = (int)threadIdx.x; i < RW * RH; i += kBlockThreads) {
+            const int ry = i / RW, rx = i - ry * RW;
+            const int32_t gx = bx0 + rx, gy = by0 + ry;
+            const int li = ry * PITCH + rx;
+            if (gx >= 0 && gy >= 0 && gx < (int32_t)a.width && gy < (int32_t)a.height) {
+                const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
+                s_sn[li] = a.sn[at]; s_di[li] = a.di_diff_curr_colors[at]; s_gi[li] = a.gi_diff_curr_colors[at];
+            } else {
+                s_sn[li] = f4z();
+            }
+        }
+        __syncthreads();
+    }
+    if (!mine) return;
+    if (csn.w == 0.0f) { a.di_diff_stash[center] = cdi; a.gi_diff_stash[center] = cgi; return; }  // sky
     const float cdi_luma = luma(xyz(cdi)), cgi_luma = luma(xyz(cgi));
     float di_var, gi_var;
-    if (cdi_m.x >= 4.0f) {
+    if (!slow) {
         di_var = cdi_m.z - sqr(cdi_m.y);
         gi_var = cgi_m.z - sqr(cgi_m.y);
     } else {
         // Short history: spatial estimate over the reference's 29-tap window (frame_denoising.rs:128,180-189: the walk
-        // starts at (-2,-2) and every later row starts at -3), kept as is. Only ~15 % of the waves get here, but they
-        // set the kernel's duration, so each window row is fetched as one batch of independent loads (10 memory round
-        // trips per wave instead of 58) and the two signals share packed-f32 arithmetic as in the wavelet pass.
+        // starts at (-2,-2) and every later row starts at -3), kept as is; the two signals share packed-f32 arithmetic
+        // as in the wavelet pass.
+        const V3 cn = v3(csn.x, csn.y, csn.z);
         const f2 c_sqrt_luma = mk2(sqrtf(cdi_luma), sqrtf(cgi_luma));
-        const float leeway = cs.depth * 0.2f;
+        const float leeway = csn.w * 0.2f;
+        const int lc = ((int)(pos.y & 7u) + 2) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + 3;
         f2 sum_l = splat2(0.0f), sum_ll = splat2(0.0f), sum_1 = splat2(0.0f);
         for (int oy = -2; oy <= 2; oy++) {
-            float4 ssn[6], sdi[6], sgi[6];
-            bool live[6];
 #pragma unroll
-            for (int u = 0; u < 6; u++) {
-                const I2 sp = i2((int32_t)pos.x + u - 3, (int32_t)pos.y + oy);
-                live[u] = contains_i(a, sp) && !(u == 0 && oy == -2);
-                const uint32_t at = live[u] ? (uint32_t)sp.y * a.width + (uint32_t)sp.x : pos.y * a.width + pos.x;
-                ssn[u] = a.sn[at]; sdi[u] = a.di_diff_curr_colors[at]; sgi[u] = a.gi_diff_curr_colors[at];
-            }
-#pragma unroll
-            for (int u = 0; u < 6; u++) {
-                if (!live[u] || ssn[u].w == 0.0f) continue;
-                const f2 l = (mk2(sdi[u].x, sgi[u].x) * 0.2126f + mk2(sdi[u].y, sgi[u].y) * 0.7152f) + mk2(sdi[u].z, sgi[u].z) * 0.0722f;
+            for (int ox = -3; ox <= 2; ox++) {
+                if (ox == -3 && oy == -2) continue;
+                const int lt = lc + oy * PITCH + ox;
+                const float4 ssn = s_sn[lt];
+                if (ssn.w == 0.0f) continue;
+                const float4 sdi = s_di[lt], sgi = s_gi[lt];
+                const f2 l = (mk2(sdi.x, sgi.x) * 0.2126f + mk2(sdi.y, sgi.y) * 0.7152f) + mk2(sdi.z, sgi.z) * 0.0722f;
                 const f2 d = c_sqrt_luma - mk2(sqrtf(l.x), sqrtf(l.y));
-                const float diff = fabsf(ssn[u].w - cs.depth);
+                const float diff = fabsf(ssn.w - csn.w);
                 const float depth_weight = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
-                const float normal_weight = pow64_(fmax_(dot(v3(ssn[u].x, ssn[u].y, ssn[u].z), cs.normal), 0.0f));
+                const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
                 const f2 w = exp_pair(-mk2(fabsf(d.x), fabsf(d.y))) * depth_weight * normal_weight;  // luma sigma 1: |d| * 1 == |d|
                 sum_l = sum_l + l * w; sum_ll = sum_ll + (l * l) * w; sum_1 = sum_1 + w;
             }
@@ -89,9 +116,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_variance(const KArgs 
     }
     di_var = fmax_(di_var, 0.0f);
     gi_var = fmax_(gi_var, 0.0f);
-    tex_write(a.di_diff_stash, a, pos, f4(xyz(cdi), di_var));
-    tex_write(a.gi_diff_stash, a, pos, f4(xyz(cgi), gi_var));
-    a.sl[0][pos.y * a.width + pos.x] = make_float2(sqrtf(cdi_luma), sqrtf(cgi_luma));  // for the first wavelet pass's taps
+    a.di_diff_stash[center] = f4(xyz(cdi), di_var);
+    a.gi_diff_stash[center] = f4(xyz(cgi), gi_var);
+    a.sl[0][center] = make_float2(sqrtf(cdi_luma), sqrtf(cgi_luma));  // for the first wavelet pass's taps
 }
 void launch_denoise_variance(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a); }
 
