@@ -5,11 +5,16 @@
 // are identical): strolle/src/bvh/builder.rs (12 centroid bins per axis, sweep costs, `<=` tie-break,
 // swap-to-back partition, breadth-first processing) and strolle/src/bvh/serializer.rs (DFS pre-order,
 // internal = 4 float4 holding both children's bounds + right pointer, leaf entry = 1 float4).
-// Implementation notes: iterative builder over an index-free primitive array; subtree reuse by hash
-// (builder.rs:205-301) is not implemented — every refresh is a fresh build.
+// Implementation notes: iterative builder over an index-free primitive array, subtrees built concurrently for large
+// scenes (the result does not depend on the schedule); subtree reuse by hash (builder.rs:205-301) is not implemented —
+// every refresh is a fresh build.
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "st_types.h"
@@ -36,10 +41,121 @@ class BvhBuild {
     std::vector<Node> nodes;
     std::vector<BuildPrim> prims;
 
-    void run() {
+    // Builds the tree over `prims` (reordered in place). The result — node contents, child links, primitive order — is a
+    // function of the primitive array alone: a node's split reads only its own [begin, end) range, which its parent's
+    // partition fixed, so subtrees can be built in any order or concurrently. Large scenes therefore fan the subtrees
+    // out over a few worker threads (the reference builds on a scoped thread too, builder.rs:183-203); only the indices
+    // nodes receive in `nodes` depend on the schedule, and nothing downstream looks at them (flatten follows the links).
+    void run(unsigned max_threads = 0) {
+        const uint32_t n = (uint32_t)prims.size();
         nodes.clear();
-        Node root; root.begin = 0; root.end = (uint32_t)prims.size();
-        nodes.push_back(root);
+        nodes.resize(n > 0 ? 2u * (size_t)n + 1u : 1u);  // a split makes two non-empty children, so <= 2n - 1 nodes
+        nodes[0] = Node(); nodes[0].begin = 0; nodes[0].end = n;
+        next_node.store(1u);
+        overflow.store(false);
+        unsigned threads = max_threads ? max_threads : std::thread::hardware_concurrency();
+        if (threads > 16u) threads = 16u;
+        if (n < kParallelMin || threads < 2u) { std::vector<uint32_t> stack{0u}; build_subtree(stack, nullptr); }
+        else run_parallel(threads);
+        if (overflow.load()) {  // cannot happen for finite inputs; keep the sequential answer if it ever does
+            nodes.clear(); nodes.resize(1); nodes.reserve(4u * (size_t)n + 16u);
+            nodes[0] = Node(); nodes[0].begin = 0; nodes[0].end = n;
+            run_sequential_growing();
+            return;
+        }
+        nodes.resize(next_node.load());
+    }
+
+    // DFS flatten. `blend[m]` != 0 marks AlphaMode::Blend materials (leaf flag bit 1).
+    void flatten(const std::vector<uint8_t>& blend, std::vector<float4>& out) const {
+        out.clear();
+        if (prims.empty()) return;
+        emit(0, blend, out);
+    }
+
+  private:
+    static constexpr int kBins = 12;
+    static constexpr uint32_t kParallelMin = 4096;  // below this a build takes < 3 ms and threads cost more than they save
+    static constexpr uint32_t kSpawnMin = 1024;     // subtrees at least this large are offered to other workers
+    // on their own cache line: workers bump the counter constantly, and the vector headers above are read on every access
+    struct alignas(64) Counters { std::atomic<uint32_t> next{1}; std::atomic<bool> overflow{false}; };
+    Counters counters_;
+    std::atomic<uint32_t>& next_node = counters_.next;
+    std::atomic<bool>& overflow = counters_.overflow;
+
+    // Splits node `id` if the SAH says so (builder.rs:60-181). Returns true and the two children when it did.
+    bool split(uint32_t id, uint32_t* left, uint32_t* right) {
+        int axis; float split_at, split_cost;
+        if (!best_plane(nodes[id], &axis, &split_at, &split_cost)) return false;
+        const float leaf_cost = (float)(nodes[id].end - nodes[id].begin) * nodes[id].bounds.half_area();
+        if (!(split_cost < leaf_cost)) return false;
+        const uint32_t begin = nodes[id].begin, end = nodes[id].end;
+        int64_t i = 0, j = (int64_t)(end - begin) - 1;
+        Aabb lb, rb;
+        BuildPrim* p = prims.data() + begin;
+        while (i <= j) {
+            const BuildPrim cur = p[i];
+            if (axis_of(cur.center, axis) < split_at) { lb.grow(cur.bounds); i++; }
+            else { const BuildPrim t = p[i]; p[i] = p[j]; p[j] = t; rb.grow(cur.bounds); j--; }
+        }
+        const uint32_t li = next_node.fetch_add(2u);
+        if ((size_t)li + 2u > nodes.size()) { overflow.store(true); return false; }
+        const uint32_t ri = li + 1u;
+        Node l, r;
+        l.bounds = lb; l.begin = begin; l.end = begin + (uint32_t)i;
+        r.bounds = rb; r.begin = begin + (uint32_t)i; r.end = end;
+        nodes[li] = l; nodes[ri] = r;
+        nodes[id].internal = true; nodes[id].left = li; nodes[id].right = ri;
+        *left = li; *right = ri;
+        return true;
+    }
+
+    struct Shared { std::mutex m; std::condition_variable cv; std::vector<uint32_t> queue; uint32_t pending = 0; };
+
+    // Builds every node reachable from `stack`; with `shared`, large children are handed to the common queue instead.
+    void build_subtree(std::vector<uint32_t>& stack, Shared* shared) {
+        while (!stack.empty()) {
+            const uint32_t id = stack.back();
+            stack.pop_back();
+            uint32_t c[2];
+            if (!split(id, &c[0], &c[1])) continue;
+            for (int k = 0; k < 2; k++) {
+                if (shared && nodes[c[k]].end - nodes[c[k]].begin >= kSpawnMin) {
+                    { std::lock_guard<std::mutex> lock(shared->m); shared->queue.push_back(c[k]); shared->pending++; }
+                    shared->cv.notify_one();
+                } else stack.push_back(c[k]);
+            }
+        }
+    }
+
+    void run_parallel(unsigned threads) {
+        Shared shared;
+        shared.queue.push_back(0u); shared.pending = 1;
+        auto worker = [&] {
+            std::vector<uint32_t> stack;
+            for (;;) {
+                uint32_t id;
+                {
+                    std::unique_lock<std::mutex> lock(shared.m);
+                    shared.cv.wait(lock, [&] { return !shared.queue.empty() || shared.pending == 0; });
+                    if (shared.queue.empty()) return;  // pending == 0: the tree is complete
+                    id = shared.queue.back(); shared.queue.pop_back();
+                }
+                stack.assign(1, id);
+                build_subtree(stack, &shared);
+                bool done;
+                { std::lock_guard<std::mutex> lock(shared.m); shared.pending--; done = shared.pending == 0; }
+                if (done) shared.cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+    }
+
+    // the original breadth-first loop with a growing node vector (only reached through the overflow guard)
+    void run_sequential_growing() {
         std::deque<uint32_t> todo;
         todo.push_back(0);
         while (!todo.empty()) {
@@ -67,16 +183,6 @@ class BvhBuild {
             todo.push_back(li); todo.push_back(ri);
         }
     }
-
-    // DFS flatten. `blend[m]` != 0 marks AlphaMode::Blend materials (leaf flag bit 1).
-    void flatten(const std::vector<uint8_t>& blend, std::vector<float4>& out) const {
-        out.clear();
-        if (prims.empty()) return;
-        emit(0, blend, out);
-    }
-
-  private:
-    static constexpr int kBins = 12;
 
     bool best_plane(const Node& node, int* out_axis, float* out_at, float* out_cost) const {
         const uint32_t n = node.end - node.begin;
