@@ -76,7 +76,10 @@ class BvhBuild {
   private:
     static constexpr int kBins = 12;
     static constexpr uint32_t kParallelMin = 4096;  // below this a build takes < 3 ms and threads cost more than they save
-    static constexpr uint32_t kSpawnMin = 1024;     // subtrees at least this large are offered to other workers
+#ifndef ST_BVH_SPAWN_MIN
+#define ST_BVH_SPAWN_MIN 256
+#endif
+    static constexpr uint32_t kSpawnMin = ST_BVH_SPAWN_MIN;  // subtrees at least this large are offered to other workers
     // on their own cache line: workers bump the counter constantly, and the vector headers above are read on every access
     struct alignas(64) Counters { std::atomic<uint32_t> next{1}; std::atomic<bool> overflow{false}; };
     Counters counters_;

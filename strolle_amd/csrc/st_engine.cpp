@@ -6,6 +6,7 @@
 // (bind groups, mapped buffers, textures) is replaced by plain device allocations and pointer swaps.
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -243,6 +244,7 @@ struct Engine {
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
     uint32_t tile_map = 2;  // blockIdx -> tile mapping (st_device.h); 2 measured best on MI355X; ST_TILE_MAP overrides
     bool profiling = false;
+    bool tick_timing = false;  // ST_TICK_TIMING=1: print the host-side cost of a scene refresh to stderr
     std::vector<ProfileRecord> profile_records; std::vector<hipEvent_t> event_pool;
     StKernelProfile profile_totals[KS_COUNT];
 
@@ -257,6 +259,7 @@ struct Engine {
         if (const char* nf = getenv("ST_NO_FUSE")) fuse = atoi(nf) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* fc = getenv("ST_FUSE_COMPOSE")) fuse_compose = atoi(fc) != 0;
+        if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
     }
     void reset_profile_totals() {
         for (int i = 0; i < KS_COUNT; i++) {
@@ -423,13 +426,22 @@ struct Engine {
     int tick(hipStream_t stream) {
         bool scene_changed = false;
         if (materials_dirty || atlas_dirty) { materials_dirty = false; rebuild_gpu_materials(); scene_changed = true; }
+        const bool timing = tick_timing;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t0 = now();
         if (refresh_instances()) {
+            const auto t1 = now();
             bvh.prims.clear();
             for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
+            const auto t2 = now();
             bvh.run();
+            const auto t3 = now();
             std::vector<uint8_t> blend(materials.size());
             for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
             bvh.flatten(blend, bvh_stream);
+            const auto t4 = now();
+            if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size());
             scene_changed = true;
         }
         light_count = next_light_id;
