@@ -301,7 +301,7 @@ struct Ray {
     // ray.rs:114-266. The per-thread slice of the workgroup stack is a local array here.
     // Deviation (documented): pushes beyond BVH_STACK_SIZE are dropped instead of
     // corrupting the neighbouring lane's slice (UB in the reference).
-    size_t traverse(const SceneView& s, Tracing tracing, TriangleHit* hit) const {
+    size_t traverse(const SceneView& s, Tracing tracing, TriangleHit* hit, uint32_t* hit_triangle_id = nullptr) const {
         size_t used_memory = 0;
         if (s.bvh_len == 0) return 0;  // deviation: empty world == miss (the reference would read an empty buffer)
         uint32_t bvh_ptr = 0;
@@ -336,6 +336,7 @@ struct Ray {
                 }
                 if (found) {
                     hit->material_id = material_id;
+                    if (hit_triangle_id) *hit_triangle_id = triangle_id;
                     if (tracing == ReturnFirst) break;
                 }
                 if (got_more) { bvh_ptr += 1; continue; }

@@ -399,8 +399,11 @@ struct CameraSlot {
 struct Engine {
     // meshes.rs / materials.rs / instances.rs / triangles.rs / lights.rs (insertion-ordered)
     std::map<uint64_t, std::vector<ApiMeshTriangle>> meshes;
-    struct InstanceEntry { uint64_t id, mesh, material; Affine3 xform, xform_inv, prev_xform; bool dirty; };
+    struct InstanceEntry { uint64_t id, mesh, material; Affine3 xform, xform_inv, prev_xform; bool dirty; uint32_t xslot; };
     std::vector<InstanceEntry> instances;
+    // per-instance transform tables for primary visibility's prev_point (prim_raster.rs push constants), indexed by a
+    // stable slot; triangle_slot[t] = slot of the instance that owns triangle t
+    std::vector<Affine3> xf_curr_inv, xf_prev; std::vector<uint32_t> xslot_free, triangle_slot;
     struct IndexedInstance { size_t start, end; };
     std::map<uint64_t, IndexedInstance> tri_index;
     RangeAllocator tri_alloc;
@@ -561,7 +564,10 @@ struct Engine {
         Affine3 x = Affine3::from_12(xf);
         for (auto& e : instances)
             if (e.id == h) { e.prev_xform = e.xform; e.mesh = mesh; e.material = material; e.xform = x; e.xform_inv = inverse(x); e.dirty = true; instances_dirty = true; return; }
-        instances.push_back({h, mesh, material, x, inverse(x), x, true});
+        uint32_t xslot;
+        if (!xslot_free.empty()) { xslot = xslot_free.back(); xslot_free.pop_back(); }
+        else { xslot = (uint32_t)xf_prev.size(); xf_prev.push_back(Affine3()); xf_curr_inv.push_back(Affine3()); }
+        instances.push_back({h, mesh, material, x, inverse(x), x, true, xslot});
         instances_dirty = true;
     }
     void remove_triangles(uint64_t h) {
@@ -573,7 +579,7 @@ struct Engine {
     }
     void remove_instance(uint64_t h) {
         for (size_t i = 0; i < instances.size(); i++)
-            if (instances[i].id == h) { instances.erase(instances.begin() + i); instances_dirty = true; break; }
+            if (instances[i].id == h) { xslot_free.push_back(instances[i].xslot); instances.erase(instances.begin() + i); instances_dirty = true; break; }
         remove_triangles(h);
     }
     static Triangle bake(const ApiMeshTriangle& t, const Affine3& xform, const Affine3& xform_inv, Vec3* center, BoundingBox* bounds) {
@@ -609,11 +615,12 @@ struct Engine {
             size_t start, end;
             if (ti != tri_index.end()) { start = ti->second.start; end = ti->second.end; }
             else if (tri_alloc.take(mesh.size(), &start, &end)) {}
-            else { start = triangles.size(); end = start + mesh.size(); triangles.resize(end); prims_all.resize(end); }
+            else { start = triangles.size(); end = start + mesh.size(); triangles.resize(end); prims_all.resize(end); triangle_slot.resize(end, 0u); }
             for (size_t i = 0; i < mesh.size(); i++) {
                 BvhPrimitive p; p.triangle_id = (uint32_t)(start + i); p.material_id = mat->second;
                 triangles[start + i] = bake(mesh[i], e.xform, e.xform_inv, &p.center, &p.bounds);
                 prims_all[start + i] = p;
+                triangle_slot[start + i] = e.xslot;
             }
             tri_index[e.id] = {start, end};
         }
@@ -624,6 +631,7 @@ struct Engine {
     void tick() {
         if (materials_dirty) { materials_dirty = false; refresh_materials(); }
         if (refresh_instances()) {
+            for (const auto& e : instances) { xf_curr_inv[e.xslot] = e.xform_inv; xf_prev[e.xslot] = e.prev_xform; }
             bvh.current.clear();
             for (auto& p : prims_all) if (p.is_alive()) bvh.current.push_back(p);
             bvh.build();
@@ -713,7 +721,8 @@ struct Engine {
         } else {
             bool needs_di = mode == 0 || mode == 1 || mode == 2;
             bool needs_gi = mode == 0 || mode == 3 || mode == 4;
-            pass_prim_visibility(e, b, alt, nullptr);
+            const InstanceXforms xf{xf_curr_inv.data(), xf_prev.data(), triangle_slot.data()};
+            pass_prim_visibility(e, b, alt, &xf);
             if (!instances.empty()) {
                 pass_frame_reprojection(b, alt);
                 if (needs_di) {

@@ -203,12 +203,11 @@ static inline void pass_ref_shading(const EngineView& e, CameraBuffers& b, uint3
 // re-projecting the hit point with the instance's previous transform. Alpha-kill
 // (`base_color.w < 0.01 && ior == 1.0`) falls out of traversal for Blend
 // materials; for Opaque materials alpha is forced to 1 (prepare.rs:141).
-// `prev_point` uses per-triangle instance transforms; with static instances
-// prev_point == point (the benchmark scenes are static).
-struct InstanceXforms { const Affine3* curr_inv; const Affine3* prev; const uint32_t* triangle_instance; };
-static inline void pass_prim_visibility(const EngineView& e, CameraBuffers& b, bool alternate, const InstanceXforms* xf,
-                                        const std::vector<uint32_t>* hit_triangle_ids_unused = nullptr) {
-    (void)hit_triangle_ids_unused;
+// `prev_point = prev_xform * (curr_xform_inv * point)` (prim_raster.rs:21-27) uses the transforms of the instance that owns
+// the hit triangle: `triangle_slot[t]` indexes the two tables (the reference passes them as per-draw push constants,
+// passes/prim_raster.rs:196-230).
+struct InstanceXforms { const Affine3* curr_inv; const Affine3* prev; const uint32_t* triangle_slot; };
+static inline void pass_prim_visibility(const EngineView& e, CameraBuffers& b, bool alternate, const InstanceXforms* xf) {
     Plane& g0 = b.prim_gbuffer_d0[alternate], &g1 = b.prim_gbuffer_d1[alternate], &sm = b.prim_surface_map[alternate];
     uint64_t rays = 0;
     _Pragma("omp parallel for schedule(dynamic, 4) reduction(+ : rays)")
@@ -218,7 +217,8 @@ static inline void pass_prim_visibility(const EngineView& e, CameraBuffers& b, b
             Ray ray = b.curr_camera.ray(pos);
             // closest hit with the id of the winning triangle (needed for velocity)
             TriangleHit hit = TriangleHit::none();
-            ray.traverse(e.scene, ReturnClosest, &hit);
+            uint32_t hit_triangle = 0;
+            ray.traverse(e.scene, ReturnClosest, &hit, &hit_triangle);
             rays++;
             if (hit.is_none()) {  // LoadOp::Clear(TRANSPARENT): prim_raster.rs (host) :160-193
                 tex_write(g0, b, pos, Vec4()); tex_write(g1, b, pos, Vec4()); tex_write(sm, b, pos, Vec4()); tex_write(b.velocity_map, b, pos, Vec4());
@@ -237,8 +237,8 @@ static inline void pass_prim_visibility(const EngineView& e, CameraBuffers& b, b
             tex_write(g0, b, pos, out[0]); tex_write(g1, b, pos, out[1]);
             Vec2 en = normal_encode(normal);
             tex_write(sm, b, pos, Vec4(en.x, en.y, depth, material.roughness));
-            Vec3 prev_point = hit.point;
-            (void)xf;  // static instances: prev_xform * curr_xform_inv == identity
+            const uint32_t slot = xf->triangle_slot[hit_triangle];
+            Vec3 prev_point = transform_point3(xf->prev[slot], transform_point3(xf->curr_inv[slot], hit.point));
             Vec2 velocity = b.curr_camera.clip_to_screen(b.curr_camera.world_to_clip(hit.point)) -
                             b.prev_camera.clip_to_screen(b.prev_camera.world_to_clip(prev_point));
             if (length_squared(velocity) >= 0.001f) tex_write(b.velocity_map, b, pos, Vec4(velocity.x, velocity.y, 0, 0));

@@ -182,8 +182,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a
     const V2 en = normal_encode(hit.normal);
     tex_write(a.sm, a, pos, make_float4(en.x, en.y, g.depth, material.roughness));
     tex_write(a.sn, a, pos, f4(normal_decode(en), g.depth));
-    // static instances: prev_point == point (prev_xform * curr_xform_inv == identity)
-    const V2 velocity = clip_to_screen(a.cam, world_to_clip(a.cam, hit.point)) - clip_to_screen(a.prev_cam, world_to_clip(a.prev_cam, hit.point));
+    // prim_raster.rs:21-27: where this surface point was under its instance's previous transform
+    const float4* xf = a.instance_xforms + 8u * hit.xform_slot;
+    const V3 prev_point = affine_point(xf + 4, affine_point(xf, hit.point));
+    const V2 velocity = clip_to_screen(a.cam, world_to_clip(a.cam, hit.point)) - clip_to_screen(a.prev_cam, world_to_clip(a.prev_cam, prev_point));
     const bool moving = dot(velocity, velocity) >= 0.001f;
     tex_write(a.velocity, a, pos, moving ? make_float4(velocity.x, velocity.y, 0.0f, 0.0f) : f4z());
     if (REPROJECT) {

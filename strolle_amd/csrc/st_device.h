@@ -204,7 +204,7 @@ ST_D float4 sample_atlas(const KArgs& a, V2 hit_uv, float4 multiplier, float4 te
 }
 
 // ------------------------------------------------------------------ BVH traversal (ray.rs:114-302, triangle.rs:64-113)
-struct TriangleHit { float distance; V3 point, normal; V2 uv; uint32_t material_id; };
+struct TriangleHit { float distance; V3 point, normal; V2 uv; uint32_t material_id; uint32_t xform_slot; };  // xform_slot: owning instance (trace_closest only)
 ST_D bool hit_is_some(const TriangleHit& h) { return h.distance < kF32Max; }
 
 ST_D float intersect_box(const Ray& r, V3 bmin, V3 bmax) {
@@ -294,17 +294,20 @@ ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32
     Candidate c; bool any;
     *used_memory = traverse<false>(a, ray, kF32Max, stack, &c, &any);
     TriangleHit h;
-    h.distance = c.t; h.material_id = c.material; h.point = v3s(0.0f); h.normal = v3s(0.0f); h.uv = v2(0.0f, 0.0f);
+    h.distance = c.t; h.material_id = c.material; h.point = v3s(0.0f); h.normal = v3s(0.0f); h.uv = v2(0.0f, 0.0f); h.xform_slot = 0u;
     if (any) {
         const float4 q0 = a.tri_attr[4u * c.tri], q1 = a.tri_attr[4u * c.tri + 1u], q2 = a.tri_attr[4u * c.tri + 2u], q3 = a.tri_attr[4u * c.tri + 3u];
         V3 n = c.u * xyz(q1) + c.v * xyz(q2) + (1.0f - c.u - c.v) * xyz(q0);
         h.normal = normalize(n) * copysignf(1.0f, c.inv_det);
         const V2 uv0 = v2(q0.w, q1.w), uv1 = v2(q2.w, q3.x), uv2 = v2(q3.y, q3.z);
         h.uv = uv0 + (uv1 - uv0) * c.u + (uv2 - uv0) * c.v;
+        h.xform_slot = f2b(q3.w);
     }
     if (hit_is_some(h)) h.point = ray_at(ray, h.distance);
     return h;
 }
+// glam Affine3A::transform_point3 with the transform stored as 4 float4 (x, y, z axes, translation)
+ST_D V3 affine_point(const float4* m, V3 p) { return ((xyz(m[0]) * p.x) + (xyz(m[1]) * p.y) + (xyz(m[2]) * p.z)) + xyz(m[3]); }
 // Ray::intersect (shadow ray)
 template <class SE>
 ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
@@ -319,6 +322,7 @@ ST_D void hit_pack(const TriangleHit& h, float4* d0, float4* d1) {  // hit.rs:11
 }
 ST_D TriangleHit hit_unpack(float4 d0, float4 d1) {  // hit.rs:95-110
     TriangleHit h;
+    h.xform_slot = 0u;
     if (is_zero(xyz(d0))) { h.distance = kF32Max; h.point = v3s(0.0f); h.normal = v3s(0.0f); h.uv = v2(0.0f, 0.0f); h.material_id = 0u; return h; }
     h.distance = 0.0f; h.point = xyz(d0); h.normal = normal_decode(v2(d1.x, d1.y)); h.uv = v2(d1.z, d1.w); h.material_id = f2b(d0.w);
     return h;

@@ -207,8 +207,12 @@ struct Engine {
     std::unordered_map<uint64_t, std::vector<StMeshTriangle>> meshes;
     std::vector<StMaterial> materials; std::unordered_map<uint64_t, uint32_t> material_slot; SlotRanges material_free; bool materials_dirty = false;
     std::vector<GpuMaterial> gpu_materials;
-    struct InstanceRec { uint64_t id, mesh, material; Affine xform, xform_inv, prev_xform; bool dirty; };
+    struct InstanceRec { uint64_t id, mesh, material; Affine xform, xform_inv, prev_xform; bool dirty; uint32_t xslot; };
     std::vector<InstanceRec> instances; bool instances_dirty = false;
+    // per-instance transforms for primary visibility's prev_point (the reference's per-draw push constants,
+    // passes/prim_raster.rs:196-230): 8 float4 per stable slot — curr_xform_inv (x, y, z axes, translation), then prev_xform.
+    // tri_attr[4 t + 3].w holds the slot of the instance that owns triangle t.
+    std::vector<float4> instance_xforms; std::vector<uint32_t> xslot_free;
     std::map<uint64_t, std::pair<size_t, size_t>> instance_triangles; SlotRanges triangle_free;
     std::vector<HostTriangle> triangles; std::vector<BuildPrim> prims; std::vector<uint8_t> prim_alive;
     std::vector<float4> tri_geo, tri_attr, bvh_stream;
@@ -232,7 +236,7 @@ struct Engine {
     std::vector<uint8_t> blue_noise; bool blue_noise_dirty = true;
     bool atmosphere_initialized = false, sky_known = false; float known_sun_altitude = 0.0f;  // passes/atmosphere.rs:14-15,78-110
 
-    DeviceArray d_bvh, d_tri_geo, d_tri_attr, d_materials, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
+    DeviceArray d_bvh, d_tri_geo, d_tri_attr, d_instance_xforms, d_materials, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
@@ -396,7 +400,7 @@ struct Engine {
         prims[slot] = bp; prim_alive[slot] = 1;
         tri_geo[3 * slot] = f4(p[0], 0.0f); tri_geo[3 * slot + 1] = f4(p[1] - p[0], 0.0f); tri_geo[3 * slot + 2] = f4(p[2] - p[0], 0.0f);
         tri_attr[4 * slot] = f4(n[0], t.uvs[0][0]); tri_attr[4 * slot + 1] = f4(n[1], t.uvs[0][1]); tri_attr[4 * slot + 2] = f4(n[2], t.uvs[1][0]);
-        tri_attr[4 * slot + 3] = make_float4(t.uvs[1][1], t.uvs[2][0], t.uvs[2][1], 0.0f);
+        tri_attr[4 * slot + 3] = make_float4(t.uvs[1][1], t.uvs[2][0], t.uvs[2][1], b2f(inst.xslot));
     }
     bool refresh_instances() {
         if (!instances_dirty) return false;
@@ -431,6 +435,11 @@ struct Engine {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         const auto t0 = now();
         if (refresh_instances()) {
+            for (const auto& inst : instances) {
+                float4* x = instance_xforms.data() + 8u * inst.xslot;
+                const Affine* src[2] = {&inst.xform_inv, &inst.prev_xform};
+                for (int k = 0; k < 2; k++) { x[4 * k] = f4(src[k]->x, 0.0f); x[4 * k + 1] = f4(src[k]->y, 0.0f); x[4 * k + 2] = f4(src[k]->z, 0.0f); x[4 * k + 3] = f4(src[k]->t, 0.0f); }
+            }
             const auto t1 = now();
             bvh.prims.clear();
             for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
@@ -467,6 +476,7 @@ struct Engine {
                 if ((rc = d_bvh.upload(bvh_stream.data(), bvh_stream.size() * sizeof(float4), stream))) return rc;
                 if ((rc = d_tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), stream))) return rc;
                 if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream))) return rc;
+                if ((rc = d_instance_xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), stream))) return rc;
                 if ((rc = d_materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), stream))) return rc;
                 scene_uploaded = true;
                 scene_changed = true;  // forces the stream sync below
@@ -557,7 +567,7 @@ struct Engine {
         const bool alt = c.frame % 2u == 1u;
         KArgs a{};
         a.cam = c.curr; a.prev_cam = c.prev;
-        a.bvh = static_cast<const float4*>(d_bvh.ptr); a.tri_geo = static_cast<const float4*>(d_tri_geo.ptr); a.tri_attr = static_cast<const float4*>(d_tri_attr.ptr);
+        a.bvh = static_cast<const float4*>(d_bvh.ptr); a.tri_geo = static_cast<const float4*>(d_tri_geo.ptr); a.tri_attr = static_cast<const float4*>(d_tri_attr.ptr); a.instance_xforms = static_cast<const float4*>(d_instance_xforms.ptr);
         a.materials = static_cast<const GpuMaterial*>(d_materials.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
         a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr);
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
@@ -872,7 +882,10 @@ int st_instance_insert(StEngine* e, StHandle id, StHandle mesh, StHandle materia
     const Affine x = affine_from12(xform);
     for (auto& r : en->instances)
         if (r.id == id) { r.prev_xform = r.xform; r.mesh = mesh; r.material = material; r.xform = x; r.xform_inv = affine_inverse(x); r.dirty = true; en->instances_dirty = true; return ST_OK; }
-    en->instances.push_back({id, mesh, material, x, affine_inverse(x), x, true});
+    uint32_t xslot;
+    if (!en->xslot_free.empty()) { xslot = en->xslot_free.back(); en->xslot_free.pop_back(); }
+    else { xslot = (uint32_t)(en->instance_xforms.size() / 8u); en->instance_xforms.resize(en->instance_xforms.size() + 8u, make_float4(0, 0, 0, 0)); }
+    en->instances.push_back({id, mesh, material, x, affine_inverse(x), x, true, xslot});
     en->instances_dirty = true;
     return ST_OK;
 }
@@ -880,7 +893,7 @@ int st_instance_remove(StEngine* e, StHandle id) {
     ST_REQUIRE(e, "null engine");
     Engine* en = E(e);
     for (size_t i = 0; i < en->instances.size(); i++)
-        if (en->instances[i].id == id) { en->instances.erase(en->instances.begin() + i); en->instances_dirty = true; break; }
+        if (en->instances[i].id == id) { en->xslot_free.push_back(en->instances[i].xslot); en->instances.erase(en->instances.begin() + i); en->instances_dirty = true; break; }
     en->drop_instance_triangles(id);
     return ST_OK;
 }

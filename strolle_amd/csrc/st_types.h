@@ -42,6 +42,7 @@ struct KArgs {
     GpuCamera cam, prev_cam;
     // engine-level bindings
     const float4* bvh; const float4* tri_geo; const float4* tri_attr;
+    const float4* instance_xforms;  // 8 float4 per instance slot: curr_xform_inv (3 axes + translation), prev_xform; slot = tri_attr[4 t + 3].w
     const GpuMaterial* materials; const GpuLight* lights;
     const uchar4* atlas; const uchar4* blue_noise;
     const float4* transmittance_lut; const float4* sky_lut;
