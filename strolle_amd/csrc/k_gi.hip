@@ -87,13 +87,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_b(const KArgs a, 
     WhiteNoise wn; Hit gi_hit; float gi_ray_pdf;
     if (tracing) {
         wn = white_noise(seed, pos);
-        gi_hit = hit_make(make_ray(prim_hit.point, xyz(d0)), gbuffer_unpack(d1, d2));
+        gi_hit = hit_make(make_ray(prim_hit.point, xyz(d0)), gbuffer_unpack(a, d1, d2));
         gi_ray_pdf = d0.w;
     } else {
         const GiReservoir res = gi_read(a.gi_res[2], idx, n);
         if (res.m == 0.0f) return;
         wn.state = res.s.rng;
-        gi_hit = hit_make(make_ray(res.s.v1_point, xyz(d0)), gbuffer_unpack(d1, d2));
+        gi_hit = hit_make(make_ray(res.s.v1_point, xyz(d0)), gbuffer_unpack(a, d1, d2));
         gi_ray_pdf = 1.0f;
     }
     const uint32_t rng = wn.state;

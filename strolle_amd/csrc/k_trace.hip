@@ -199,6 +199,16 @@ void launch_prim_visibility(const KArgs& a, bool reproject, hipStream_t s) {
     else { if (small) ST_LAUNCH((k_prim_visibility<false, uint16_t>), false, s, a); else ST_LAUNCH((k_prim_visibility<false, uint32_t>), false, s, a); }
 }
 
+// Tabulates the byte decodes of st_device.h with the routines themselves (one launch at engine creation).
+__global__ void k_build_byte_luts(float* out) {
+    const uint32_t v = threadIdx.x;
+    out[kLutSrgb + v] = srgb_to_linear_eval(v);
+    out[kLutUnorm8 + v] = unorm8_eval(v);
+    out[kLutGamma8 + v] = gamma8_eval(v);
+    out[kLutGamma6 + v] = gamma6_eval(v);
+}
+void launch_build_byte_luts(float* out, hipStream_t s) { hipLaunchKernelGGL(k_build_byte_luts, dim3(1), dim3(256), 0, s, out); }
+
 // ---------------------------------------------------------------- frame_reprojection.rs:6-95
 __global__ __launch_bounds__(kBlockThreads) void k_frame_reprojection(const KArgs a) {
     U2 pos;

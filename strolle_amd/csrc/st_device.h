@@ -170,15 +170,24 @@ ST_D float4 tex_read(const float4* p, const KArgs& a, U2 pos) { return (pos.x < 
 ST_D void tex_write(float4* p, const KArgs& a, U2 pos, float4 v) { if (pos.x < a.width && pos.y < a.height) p[pos.y * a.width + pos.x] = v; }
 
 // ------------------------------------------------------------------ materials & atlas (material.rs:25-104)
-ST_D float srgb_to_linear(uint32_t v) {
+// Byte decodes are pure functions of 256 inputs; the engine tabulates them once on the device with these very routines
+// (k_trace.hip k_build_byte_luts) so that a texel costs four table reads instead of three pow_() + a division — about
+// 250 VALU operations per texel, twelve texels per textured primary hit.
+ST_D float srgb_to_linear_eval(uint32_t v) {
     const float c = (float)v / 255.0f;
     return c <= 0.04045f ? c / 12.92f : pow_((c + 0.055f) / 1.055f, 2.4f);
 }
+ST_D float unorm8_eval(uint32_t v) { return (float)v / 255.0f; }
+constexpr uint32_t kLutSrgb = 0u, kLutUnorm8 = 256u, kLutGamma8 = 512u, kLutGamma6 = 768u, kByteLutFloats = 1024u;  // layout of KArgs::byte_luts
+ST_D float gamma8_eval(uint32_t v) { return pow_((float)v / 255.0f, 2.2f); }  // G-buffer base colour RGB (gbuffer.rs:88-97)
+ST_D float gamma6_eval(uint32_t v) { return pow_((float)v / 63.0f, 2.2f); }   // ... and its 6-bit alpha
+ST_D float srgb_to_linear(const KArgs& a, uint32_t v) { return a.byte_luts[kLutSrgb + v]; }
+ST_D float unorm8(const KArgs& a, uint32_t v) { return a.byte_luts[kLutUnorm8 + v]; }
 ST_D float4 atlas_texel(const KArgs& a, int32_t x, int32_t y) {
     x = x < 0 ? 0 : (x >= (int32_t)a.atlas_w ? (int32_t)a.atlas_w - 1 : x);
     y = y < 0 ? 0 : (y >= (int32_t)a.atlas_h ? (int32_t)a.atlas_h - 1 : y);
     const uchar4 p = a.atlas[(uint32_t)y * a.atlas_w + (uint32_t)x];
-    return make_float4(srgb_to_linear(p.x), srgb_to_linear(p.y), srgb_to_linear(p.z), (float)p.w / 255.0f);
+    return make_float4(srgb_to_linear(a, p.x), srgb_to_linear(a, p.y), srgb_to_linear(a, p.z), unorm8(a, p.w));
 }
 // gfx950 has no texture unit: bilinear, clamp-to-edge, lod 0, sRGB decode before filtering; NaN coordinates -> 0.
 ST_D float4 atlas_sample(const KArgs& a, V2 uv) {
@@ -331,18 +340,19 @@ ST_D TriangleHit hit_unpack(float4 d0, float4 d1) {  // hit.rs:95-110
 // ------------------------------------------------------------------ G-buffer, surface, hit (gbuffer.rs, surface.rs, hit.rs)
 struct GBuffer { float4 base_color; V3 normal; float metallic; V3 emissive; float roughness, reflectance, depth; };
 ST_D GBuffer gbuffer_zero() { GBuffer g; g.base_color = f4z(); g.normal = v3s(0.0f); g.metallic = 0.0f; g.emissive = v3s(0.0f); g.roughness = 0.0f; g.reflectance = 0.0f; g.depth = 0.0f; return g; }
-ST_D GBuffer gbuffer_unpack(float4 d0, float4 d1) {
+ST_D GBuffer gbuffer_unpack(const KArgs& a, float4 d0, float4 d1) {
     GBuffer g;
     g.depth = d0.x;
     g.normal = normal_decode(v2(d0.y, d0.z));
     const uint32_t w0 = f2b(d0.w);
-    g.metallic = (float)(w0 & 0xffu) / 255.0f;
-    g.roughness = sqr((float)((w0 >> 8) & 0xffu) / 255.0f);
-    g.reflectance = (float)((w0 >> 16) & 0xffu) / 255.0f;
+    g.metallic = unorm8(a, w0 & 0xffu);
+    g.roughness = sqr(unorm8(a, (w0 >> 8) & 0xffu));
+    g.reflectance = unorm8(a, (w0 >> 16) & 0xffu);
     g.emissive = xyz(d1);
     const uint32_t w1 = f2b(d1.w);
-    g.base_color = make_float4(pow_((float)(w1 & 0xffu) / 255.0f, 2.2f), pow_((float)((w1 >> 8) & 0xffu) / 255.0f, 2.2f),
-                               pow_((float)((w1 >> 16) & 0xffu) / 255.0f, 2.2f), pow_((float)((w1 >> 24) & 0xffu) / 63.0f, 2.2f));
+    const float* lut = a.byte_luts;
+    g.base_color = make_float4(lut[kLutGamma8 + (w1 & 0xffu)], lut[kLutGamma8 + ((w1 >> 8) & 0xffu)], lut[kLutGamma8 + ((w1 >> 16) & 0xffu)],
+                               lut[kLutGamma6 + ((w1 >> 24) & 0xffu)]);
     return g;
 }
 ST_D void gbuffer_pack(const GBuffer& g, float4* d0, float4* d1) {
@@ -377,7 +387,7 @@ ST_D Hit hit_make(const Ray& ray, const GBuffer& g) { Hit h; h.origin = ray.orig
 ST_D Hit hit_zero() { Hit h; h.origin = v3s(0.0f); h.dir = v3s(0.0f); h.point = v3s(0.0f); h.g = gbuffer_zero(); return h; }
 ST_D bool hit_some(const Hit& h) { return h.g.depth != 0.0f; }
 ST_D Hit pixel_hit(const KArgs& a, const GpuCamera& cam, const float4* g0, const float4* g1, U2 pos) {
-    return hit_make(camera_ray(cam, pos), gbuffer_unpack(tex_read(g0, a, pos), tex_read(g1, a, pos)));
+    return hit_make(camera_ray(cam, pos), gbuffer_unpack(a, tex_read(g0, a, pos), tex_read(g1, a, pos)));
 }
 
 // ------------------------------------------------------------------ BRDFs (brdf.rs)

@@ -236,7 +236,7 @@ struct Engine {
     std::vector<uint8_t> blue_noise; bool blue_noise_dirty = true;
     bool atmosphere_initialized = false, sky_known = false; float known_sun_altitude = 0.0f;  // passes/atmosphere.rs:14-15,78-110
 
-    DeviceArray d_bvh, d_tri_geo, d_tri_attr, d_instance_xforms, d_materials, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
+    DeviceArray d_byte_luts, d_bvh, d_tri_geo, d_tri_attr, d_instance_xforms, d_materials, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
@@ -569,7 +569,7 @@ struct Engine {
         a.cam = c.curr; a.prev_cam = c.prev;
         a.bvh = static_cast<const float4*>(d_bvh.ptr); a.tri_geo = static_cast<const float4*>(d_tri_geo.ptr); a.tri_attr = static_cast<const float4*>(d_tri_attr.ptr); a.instance_xforms = static_cast<const float4*>(d_instance_xforms.ptr);
         a.materials = static_cast<const GpuMaterial*>(d_materials.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
-        a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr);
+        a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr); a.byte_luts = static_cast<const float*>(d_byte_luts.ptr);
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
         a.bvh_len = (uint32_t)bvh_stream.size(); a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
         a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
@@ -806,6 +806,8 @@ int st_engine_create(int device_ordinal, StEngine** out) {
         const size_t lut_bytes[3] = {sizeof(float4) * 256 * 64, sizeof(float4) * 32 * 32, sizeof(float4) * 256 * 256};
         DeviceArray* luts[3] = {&e->d_transmittance, &e->d_scattering, &e->d_sky};
         for (int i = 0; i < 3; i++) { ST_HIP(hipMalloc(&luts[i]->ptr, lut_bytes[i])); luts[i]->capacity = lut_bytes[i]; ST_HIP(hipMemset(luts[i]->ptr, 0, lut_bytes[i])); }
+        ST_HIP(hipMalloc(&e->d_byte_luts.ptr, sizeof(float) * 1024)); e->d_byte_luts.capacity = sizeof(float) * 1024;
+        launch_build_byte_luts(static_cast<float*>(e->d_byte_luts.ptr), nullptr);
         ST_HIP(hipDeviceSynchronize());
     }
     *out = reinterpret_cast<StEngine*>(e.release());

@@ -48,6 +48,7 @@ void launch_bvh_heatmap(const KArgs& a, hipStream_t s);
 void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s);
 void launch_ref_shading(const KArgs& a, uint32_t seed, uint32_t depth, hipStream_t s);
 void launch_prim_visibility(const KArgs& a, bool fuse_frame_reprojection, hipStream_t s);
+void launch_build_byte_luts(float* out /* kByteLutFloats */, hipStream_t s);  // st_device.h byte decode tables
 void launch_frame_reprojection(const KArgs& a, hipStream_t s);
 // ReSTIR DI
 void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s);

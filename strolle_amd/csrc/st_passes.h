@@ -49,7 +49,7 @@ ST_D float4 compose_pixel(const KArgs& a, U2 pos, uint32_t camera_mode, float4 d
     V3 color;
     switch (camera_mode) {
         case 0: {
-            const GBuffer g = gbuffer_unpack(tex_read(a.g0, a, pos), tex_read(a.g1, a, pos));
+            const GBuffer g = gbuffer_unpack(a, tex_read(a.g0, a, pos), tex_read(a.g1, a, pos));
             const V3 dd = xyz(di_diff), ds = xyz(tex_read(a.di_spec_samples, a, pos));
             const V3 gd = xyz(gi_diff), gs = xyz(tex_read(a.gi_spec_samples, a, pos));
             color = g.depth != 0.0f ? g.emissive + (dd + gd) * xyz(g.base_color) + ds + gs : dd;
