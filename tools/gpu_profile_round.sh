@@ -5,6 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_serial gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq
 # the same command as the bench line (region 1 pipelined on two streams, region 2 serial with event pairs)
