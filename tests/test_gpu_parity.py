@@ -458,3 +458,27 @@ def test_moving_instances_velocity_bit_exact():
         assert_bits_equal(img, ref, f"moving instance frame {frame}")
         moved += int(np.count_nonzero(orac.read_buffer(co, Buffer.VELOCITY_MAP)))
     assert moved > 0, "no pixel ever had a velocity: the moving instance was not seen"
+
+
+def test_spot_lights_metallic_surfaces_bit_exact():
+    """Spot lights (angle falloff through angle_between + acos_approx, light.rs:143-160) over a scene with metallic
+    materials (GGX specular lobes in DI and GI), plus a point light with infinite range."""
+    torch = _torch()
+    from strolle_amd import Light
+    size = (128, 80)
+    def build(e):
+        scenes.build_random_soup(e, 1200, seed=31, n_lights=1)
+        e.insert_light(5, Light.spot((0.2, 1.4, 0.9), 0.1, (6.0, 5.0, 4.0), 25.0, (-0.1, -0.9, -0.4), 0.6))
+        e.insert_light(6, Light.spot((-0.8, 0.3, 1.2), 0.05, (2.0, 3.0, 5.0), 15.0, (0.5, -0.2, -0.8), 0.25))
+        e.insert_light(7, Light.point((0.0, 2.5, 0.0), 0.2, (0.8, 0.8, 0.8), float("inf")))
+    prod, orac, desc, cp, co = _pair(build, size, CameraMode.IMAGE)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(8):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"spot lights frame {frame}")
+    desc = scenes.cornell_camera(size, CameraMode.REFERENCE, depth=2)
+    for frame in range(2):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        assert_bits_equal(img, ref, f"spot lights reference frame {frame}")
+    assert float(np.nanmean(ref[..., :3])) > 0.0
