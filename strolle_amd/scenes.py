@@ -119,12 +119,16 @@ def build_random_soup(engine, n_triangles: int, seed: int = 0, n_lights: int = 3
         tex = rng.integers(0, 256, (32, 32, 4), dtype=np.uint8)
         tex[..., 3] = rng.choice(np.array([0, 128, 255], np.uint8), (32, 32))
         engine.insert_image(900, tex, srgb=True)
+        engine.insert_image(901, rng.integers(0, 256, (16, 24, 4), dtype=np.uint8), srgb=False)   # metallic-roughness map
+        engine.insert_image(902, rng.integers(0, 256, (8, 8, 4), dtype=np.uint8), srgb=True)      # emissive map
     for i in range(n_mat):
         blend = i < n_blend
         engine.insert_material(1 + i, Material(base_color=rng.uniform(0.2, 0.9, 3).tolist() + [0.9 if blend else 1.0], perceptual_roughness=float(rng.uniform(0.2, 1.0)),
                                                metallic=float(rng.uniform(0.0, 0.8)) if i % 2 else 0.0,
                                                emissive=(rng.uniform(0, 0.5, 3).tolist() + [1.0]) if i == 3 else (0, 0, 0, 0),
-                                               alpha_mode=1 if blend else 0, base_color_texture=900 if blend else None))
+                                               alpha_mode=1 if blend else 0, base_color_texture=900 if blend else None,
+                                               metallic_roughness_texture=901 if (n_blend and i == 2) else None,
+                                               emissive_texture=902 if (n_blend and i == 3) else None))
     per = max(1, n_triangles // n_mat)
     for i in range(n_mat):
         c = rng.uniform(-1, 1, (per, 1, 3)).astype(np.float32)
