@@ -242,7 +242,7 @@ struct Engine {
 
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
     hipStream_t side_stream = nullptr;
-    hipEvent_t ev_prim = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
+    hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
     bool have_prev_frame_events = false;
     bool fuse_compose = false;  // composition inside the last wavelet launch: measured slower (109 vs 65+36 us), kept for A/B (ST_FUSE_COMPOSE=1)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
@@ -280,7 +280,7 @@ struct Engine {
         for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
         if (side_stream) (void)hipStreamDestroy(side_stream);
-        for (hipEvent_t e : {ev_prim, ev_gi_done, ev_prim_ok, ev_frame_done, ev_setup}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_di_head, ev_gi_done, ev_prim_ok, ev_frame_done, ev_setup}) if (e) (void)hipEventDestroy(e);
     }
     static void release_camera(CameraState& c) { if (c.slab) (void)hipFree(c.slab); if (c.counters) (void)hipFree(c.counters); c.slab = nullptr; c.counters = nullptr; }
 
@@ -733,7 +733,7 @@ struct Engine {
                 //   denoiser(N+1)  after GI tail(N+1)
                 if (!side_stream) {
                     ST_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-                    for (hipEvent_t* e : {&ev_prim, &ev_gi_done, &ev_prim_ok, &ev_frame_done, &ev_setup}) ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+                    for (hipEvent_t* e : {&ev_di_head, &ev_gi_done, &ev_prim_ok, &ev_frame_done, &ev_setup}) ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
                 }
                 // LUT generation issued on `stream` in this call must precede the side stream's consumers. (Do NOT do this
                 // unconditionally: an event recorded on `stream` here completes only after frame N's denoiser, which would
@@ -743,13 +743,13 @@ struct Engine {
                 cur = side_stream;
                 do_prim();
                 do_di_head();
-                ST_HIP(hipEventRecord(ev_prim, side_stream));  // primary visibility + DI head of this frame are through
+                ST_HIP(hipEventRecord(ev_di_head, side_stream));  // primary visibility + DI head of this frame are through
                 do_gi_head();
                 if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_frame_done, 0));
                 do_gi_tail();
                 ST_HIP(hipEventRecord(ev_gi_done, side_stream));
                 cur = stream;
-                ST_HIP(hipStreamWaitEvent(stream, ev_prim, 0));
+                ST_HIP(hipStreamWaitEvent(stream, ev_di_head, 0));
                 do_di_tail();
                 // stand-alone denoise reprojection kernels (unfused path) still read the reprojection map: prim(N+1) may
                 // only start once they are through
