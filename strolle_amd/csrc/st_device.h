@@ -57,6 +57,11 @@ ST_D SE* lane_stack(SE* lds) { return lds + (threadIdx.x >> 6) * (kBvhStackSize 
 // kCounterLines 64-byte lines picked by block id: a single hot word saturates near 88 atomics/us
 // (MI355X_MICROARCH.md, row "dequeue"), which alone cost 0.7 ms per full-screen launch at 1080p.
 
+ST_D void count_rays_n(unsigned long long* counter, uint32_t rays, unsigned long long used_memory) {
+    unsigned long long* line = counter + (blockIdx.x & (kCounterLines - 1u)) * 8u;
+    atomicAdd(line, (unsigned long long)rays);
+    atomicAdd(line + 1, used_memory);
+}
 ST_D void count_rays(unsigned long long* counter, uint32_t used_memory) {
     unsigned long long* line = counter + (blockIdx.x & (kCounterLines - 1u)) * 8u;
     atomicAdd(line, 1ull);
@@ -323,6 +328,56 @@ ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_me
     Candidate c; bool any;
     *used_memory = traverse<true>(a, ray, ray.len, stack, &c, &any);
     return c.t < ray.len;
+}
+// The any-hit traversal as a resumable state machine: any_hit_step() is one iteration of traverse<true>()'s loop for a
+// ray whose cut-off distance stays at ray.len until a hit ends it. Used by the compacted shadow-ray kernel, where a lane
+// that finishes its ray picks up another one instead of idling until the slowest lane of the wave is done.
+struct AnyHitState { uint32_t ptr; int32_t sp; uint32_t used_memory; bool found; };
+ST_D AnyHitState any_hit_begin() { AnyHitState s; s.ptr = 0u; s.sp = 0; s.used_memory = 0u; s.found = false; return s; }
+// returns true when the ray is finished (st.found tells how)
+template <class SE>
+ST_D bool any_hit_step(const KArgs& a, const Ray& ray, SE* stack, AnyHitState& st) {
+    if (a.bvh_len == 0u) return true;
+    st.used_memory += 16u;
+    const float4 d0 = a.bvh[st.ptr];
+    if (f2b(d0.w) == 0u) {
+        st.used_memory += 48u;
+        const float4 d1 = a.bvh[st.ptr + 1u], d2 = a.bvh[st.ptr + 2u], d3 = a.bvh[st.ptr + 3u];
+        uint32_t near_ptr = st.ptr + 4u, far_ptr = f2b(d1.w);
+        float near_d = intersect_box(ray, xyz(d0), xyz(d1));
+        float far_d = intersect_box(ray, xyz(d2), xyz(d3));
+        if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
+        if (far_d < ray.len) { if (st.sp < kBvhStackSize) { stack[st.sp * 64] = (SE)far_ptr; st.sp++; } }
+        if (near_d < ray.len) { st.ptr = near_ptr; return false; }
+    } else {
+        st.used_memory += 144u;
+        const uint32_t flags = f2b(d0.x), tri = f2b(d0.y), material = f2b(d0.z);
+        const float4 g0 = a.tri_geo[3u * tri], g1 = a.tri_geo[3u * tri + 1u], g2 = a.tri_geo[3u * tri + 2u];
+        const V3 p0 = xyz(g0), e1 = xyz(g1), e2 = xyz(g2);
+        const V3 pvec = cross(ray.dir, e2);
+        const float det = dot(e1, pvec);
+        if (!(fabsf(det) < kF32Eps)) {
+            const float inv_det = 1.0f / det;
+            const V3 tvec = ray.origin - p0;
+            const float u = dot(tvec, pvec) * inv_det;
+            const V3 qvec = cross(tvec, e1);
+            const float v = dot(ray.dir, qvec) * inv_det;
+            const float t = dot(e2, qvec) * inv_det;
+            if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= ray.len))) {
+                bool found = true;
+                if (flags & 2u) {
+                    st.used_memory += 112u + 16u;
+                    const GpuMaterial m = a.materials[material];
+                    const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
+                    if (bc.w < 1.0f) found = false;
+                }
+                if (found) { st.found = true; return true; }
+            }
+        }
+        if (flags & 1u) { st.ptr += 1u; return false; }
+    }
+    if (st.sp > 0) { st.sp--; st.ptr = stack[st.sp * 64]; return false; }
+    return true;
 }
 ST_D void hit_pack(const TriangleHit& h, float4* d0, float4* d1) {  // hit.rs:112-120
     *d0 = f4(h.point, b2f(h.material_id));
