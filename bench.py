@@ -90,7 +90,10 @@ def main():
         if debug_shared:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL; binds the communicator to this rank's GPU
+            except TypeError:   # a torch without the device_id keyword
+                dist.init_process_group("nccl")
 
     base = (args.width, args.height)
     width, height = weak_scaling_frame(base, world)
