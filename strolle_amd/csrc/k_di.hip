@@ -172,6 +172,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_resolving(const KArgs a) {
     const uint32_t idx = screen_to_idx(a, pos);
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
     DiReservoir res = di_read(a.di_res[2], idx, n);
+    ReprojectHistory history;  // fetched ahead of the shadow ray (st_passes.h)
+    if (REPROJECT) history = denoise_reproject_prefetch(a, pos, a.di_diff_prev_colors, a.di_diff_prev_moments);
     float confidence;
     V3 radiance, spec_brdf;
     if (hit_some(hit)) {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_resolving(const KArgs a) {
     tex_write(a.di_diff_samples, a, pos, diff);
     tex_write(a.di_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
     di_write(a.di_res[0], idx, res);
-    if (REPROJECT) denoise_reproject_pixel(a, pos, diff, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_curr_colors, a.di_diff_moments);
+    if (REPROJECT) denoise_reproject_finish(a, pos, diff, history, a.di_diff_curr_colors, a.di_diff_moments);
 }
 void launch_di_resolving(const KArgs& a, bool reproject, hipStream_t s) {
     const bool small = a.bvh_len < 65536u;

@@ -304,6 +304,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_preview(const KArgs a, uin
     WhiteNoise wn = white_noise(seed, center_pos);
     const Hit center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
     GiReservoir main_ = gi_empty();
+    ReprojectHistory history;  // fetched ahead of the resampling loop (st_passes.h)
+    if (RESOLVE && reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
     bool keep_stored = false;  // the reference's early `return`: the output slot keeps its previous contents
     if (hit_some(center_hit)) {
         float main_pdf = 0.0f;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_preview(const KArgs a, uin
     }
     if (keep_stored) main_ = gi_read(out, center_idx, n);
     const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, main_, source);
-    if (reproject) denoise_reproject_pixel(a, center_pos, diff, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_curr_colors, a.gi_diff_moments);
+    if (reproject) denoise_reproject_finish(a, center_pos, diff, history, a.gi_diff_curr_colors, a.gi_diff_moments);
 }
 void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s) {
     ST_LAUNCH(k_gi_preview<false>, false, s, a, seed, nth, in, out, 0u, 0u);

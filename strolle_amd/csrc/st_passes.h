@@ -7,14 +7,24 @@
 namespace st {
 
 // frame_denoising.rs:3-78 (reproject) for one pixel; `sample` is this pixel's texel of the samples plane.
-ST_D void denoise_reproject_pixel(const KArgs& a, U2 pos, float4 sample, const float4* prev_colors, const float4* prev_moments, float4* colors, float4* moments) {
-    if (tex_read(a.sn, a, pos).w == 0.0f) { tex_write(colors, a, pos, sample); return; }  // sky
-    const float sample_luma = luma(xyz(sample));
+// Split in two so that a fused producer can issue the history loads (reprojection texel -> previous colour / moment taps,
+// two dependent round trips) BEFORE its own long latency chain (a shadow-ray traversal, a resampling loop) and consume
+// them after it: the loads do not depend on the sample. Fetching history that `sample.w <= 0` then ignores is harmless.
+struct ReprojectHistory { bool sky, have; float4 pc, pm; };
+ST_D ReprojectHistory denoise_reproject_prefetch(const KArgs& a, U2 pos, const float4* prev_colors, const float4* prev_moments) {
+    ReprojectHistory h; h.have = false; h.pc = f4z(); h.pm = f4z();
+    h.sky = tex_read(a.sn, a, pos).w == 0.0f;
+    if (h.sky) return h;
     const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, pos));
+    if (rp.confidence > 0.0f) { h.have = true; h.pc = bilinear_reproject(a, rp, prev_colors); h.pm = bilinear_reproject(a, rp, prev_moments); }
+    return h;
+}
+ST_D void denoise_reproject_finish(const KArgs& a, U2 pos, float4 sample, const ReprojectHistory& h, float4* colors, float4* moments) {
+    if (h.sky) { tex_write(colors, a, pos, sample); return; }
+    const float sample_luma = luma(xyz(sample));
     V3 color, moment;
-    if (rp.confidence > 0.0f && sample.w > 0.0f) {
-        const float4 pc = bilinear_reproject(a, rp, prev_colors);
-        const float4 pm = bilinear_reproject(a, rp, prev_moments);
+    if (h.have && sample.w > 0.0f) {
+        const float4 pc = h.pc, pm = h.pm;
         const float curr_history = fmin_(pm.x + 1.0f, 16.0f);
         const float alpha = 1.0f / curr_history;
         color = lerp3(xyz(pc), xyz(sample), alpha);
@@ -25,6 +35,9 @@ ST_D void denoise_reproject_pixel(const KArgs& a, U2 pos, float4 sample, const f
     }
     tex_write(colors, a, pos, f4(color, 0.0f));
     tex_write(moments, a, pos, f4(moment, 0.0f));
+}
+ST_D void denoise_reproject_pixel(const KArgs& a, U2 pos, float4 sample, const float4* prev_colors, const float4* prev_moments, float4* colors, float4* moments) {
+    denoise_reproject_finish(a, pos, sample, denoise_reproject_prefetch(a, pos, prev_colors, prev_moments), colors, moments);
 }
 
 // gi_resolving.rs:3-67 for one pixel. `res` is what out_reservoirs (gi_res[0]) holds for this pixel when the pass starts.
