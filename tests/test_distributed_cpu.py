@@ -10,6 +10,13 @@ from strolle_amd.distributed import assemble_bands_numpy, band_for_rank, render_
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 @pytest.mark.parametrize("height,world", [(1080, 1), (1080, 2), (2160, 4), (4320, 8), (1083, 4), (77, 3)])
 def test_bands_partition_the_frame(height, world):
     rows = []
@@ -89,7 +96,7 @@ def test_gather_frame_gloo_world_size_2(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(script), ROOT]
+           "--master-port", str(_free_port()), str(script), ROOT]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.count("ok") == 2

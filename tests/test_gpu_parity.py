@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 ALL_FLOAT_BUFFERS = [b for b in Buffer if b != Buffer.DBG_USED_MEMORY]
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _torch():
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU; the product has no CPU fallback"
@@ -405,7 +412,7 @@ def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dump = tmp_path / "frame.npy"
     env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--width", "128", "--height", "64", "--mode", "reference",
            "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
