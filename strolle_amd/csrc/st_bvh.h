@@ -13,8 +13,10 @@
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "st_types.h"
@@ -34,6 +36,64 @@ struct Aabb {
 struct BuildPrim { uint32_t triangle_id, material_id; V3 center; Aabb bounds; };
 
 inline float axis_of(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+// A minimal fork-join pool for the builder: a LIFO queue of closures, `threads - 1` workers plus the calling thread.
+class TaskPool {
+  public:
+    explicit TaskPool(unsigned threads) { for (unsigned t = 1; t < threads; t++) workers_.emplace_back([this] { work(false); }); }
+    ~TaskPool() { finish(); }
+    void push(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lock(m_); queue_.push_back(std::move(f)); pending_++; }
+        cv_.notify_one();
+    }
+    // the calling thread works until every task (including the ones tasks pushed) is done, then the workers are joined
+    void finish() {
+        if (joined_) return;
+        { std::lock_guard<std::mutex> lock(m_); closing_ = true; }
+        cv_.notify_all();
+        work(false);
+        for (auto& t : workers_) t.join();
+        joined_ = true;
+    }
+    // fork-join inside a task: fn(0 .. n-1), chunk 0 on the caller, the rest offered to the pool; the caller helps with
+    // whatever is queued while it waits, so nested use cannot deadlock
+    void parallel_for(uint32_t n, const std::function<void(uint32_t)>& fn) {
+        if (n == 0) return;
+        std::atomic<uint32_t> remaining(n - 1u);
+        for (uint32_t c = 1; c < n; c++) push([&fn, &remaining, c] { fn(c); remaining.fetch_sub(1u); });
+        fn(0u);
+        while (remaining.load() > 0u) { if (!run_one()) std::this_thread::yield(); }
+    }
+
+  private:
+    bool run_one() {
+        std::function<void()> f;
+        { std::lock_guard<std::mutex> lock(m_); if (queue_.empty()) return false; f = std::move(queue_.back()); queue_.pop_back(); }
+        f();
+        bool done;
+        { std::lock_guard<std::mutex> lock(m_); pending_--; done = pending_ == 0; }
+        if (done) cv_.notify_all();
+        return true;
+    }
+    void work(bool) {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [this] { return !queue_.empty() || (closing_ && pending_ == 0); });
+                if (queue_.empty()) return;  // closing and pending == 0: nothing left and nothing running
+                f = std::move(queue_.back()); queue_.pop_back();
+            }
+            f();
+            bool done;
+            { std::lock_guard<std::mutex> lock(m_); pending_--; done = pending_ == 0; }
+            if (done) cv_.notify_all();
+        }
+    }
+    std::mutex m_; std::condition_variable cv_;
+    std::vector<std::function<void()>> queue_; uint32_t pending_ = 0;
+    std::vector<std::thread> workers_; bool joined_ = false, closing_ = false;
+};
 
 class BvhBuild {
   public:
@@ -55,8 +115,14 @@ class BvhBuild {
         overflow.store(false);
         unsigned threads = max_threads ? max_threads : std::thread::hardware_concurrency();
         if (threads > 16u) threads = 16u;
-        if (n < kParallelMin || threads < 2u) { std::vector<uint32_t> stack{0u}; build_subtree(stack, nullptr); }
-        else run_parallel(threads);
+        threads_ = (n < kParallelMin || threads < 2u) ? 1u : threads;
+        spawn_min_ = n / (threads_ * 8u) > kSpawnMin ? n / (threads_ * 8u) : kSpawnMin;  // ~8 tasks per thread and level at the top
+        if (threads_ == 1u) { std::vector<uint32_t> stack{0u}; build_subtree(stack, nullptr); }
+        else {
+            TaskPool pool(threads_);
+            pool.push([this, &pool] { std::vector<uint32_t> stack{0u}; build_subtree(stack, &pool); });
+            pool.finish();
+        }
         if (overflow.load()) {  // cannot happen for finite inputs; keep the sequential answer if it ever does
             nodes.clear(); nodes.resize(1); nodes.reserve(4u * (size_t)n + 16u);
             nodes[0] = Node(); nodes[0].begin = 0; nodes[0].end = n;
@@ -67,14 +133,29 @@ class BvhBuild {
     }
 
     // DFS flatten. `blend[m]` != 0 marks AlphaMode::Blend materials (leaf flag bit 1).
+    // A node's children are always allocated after it (larger index), so one backward sweep yields every subtree's length
+    // in the stream; with the offsets known, large subtrees are written concurrently into their disjoint ranges.
     void flatten(const std::vector<uint8_t>& blend, std::vector<float4>& out) const {
         out.clear();
         if (prims.empty()) return;
-        emit(0, blend, out);
+        std::vector<uint32_t> len(nodes.size());
+        for (size_t i = nodes.size(); i-- > 0;) {
+            const Node& n = nodes[i];
+            len[i] = n.internal ? 4u + len[n.left] + len[n.right] : n.end - n.begin;
+        }
+        out.resize(len[0]);
+        if (threads_ > 1u && prims.size() >= 16u * kParallelMin) {  // below ~64 k primitives one thread is done before a pool has started
+            TaskPool pool(threads_);
+            pool.push([&, this] { emit_at(0u, 0u, blend, len, out, &pool); });
+            pool.finish();
+        } else emit_at(0u, 0u, blend, len, out, nullptr);
     }
 
   private:
     static constexpr int kBins = 12;
+    static constexpr uint32_t kParallelBinMin = 16384;  // nodes at least this large bin their primitives on all threads
+    mutable unsigned threads_ = 1;
+    uint32_t spawn_min_ = kSpawnMin;
     static constexpr uint32_t kParallelMin = 4096;  // below this a build takes < 3 ms and threads cost more than they save
 #ifndef ST_BVH_SPAWN_MIN
 #define ST_BVH_SPAWN_MIN 256
@@ -87,9 +168,9 @@ class BvhBuild {
     std::atomic<bool>& overflow = counters_.overflow;
 
     // Splits node `id` if the SAH says so (builder.rs:60-181). Returns true and the two children when it did.
-    bool split(uint32_t id, uint32_t* left, uint32_t* right) {
+    bool split(uint32_t id, uint32_t* left, uint32_t* right, TaskPool* pool) {
         int axis; float split_at, split_cost;
-        if (!best_plane(nodes[id], &axis, &split_at, &split_cost)) return false;
+        if (!best_plane(nodes[id], &axis, &split_at, &split_cost, pool)) return false;
         const float leaf_cost = (float)(nodes[id].end - nodes[id].begin) * nodes[id].bounds.half_area();
         if (!(split_cost < leaf_cost)) return false;
         const uint32_t begin = nodes[id].begin, end = nodes[id].end;
@@ -113,48 +194,20 @@ class BvhBuild {
         return true;
     }
 
-    struct Shared { std::mutex m; std::condition_variable cv; std::vector<uint32_t> queue; uint32_t pending = 0; };
-
-    // Builds every node reachable from `stack`; with `shared`, large children are handed to the common queue instead.
-    void build_subtree(std::vector<uint32_t>& stack, Shared* shared) {
+    // Builds every node reachable from `stack`; with a pool, large children become tasks of their own.
+    void build_subtree(std::vector<uint32_t>& stack, TaskPool* pool) {
         while (!stack.empty()) {
             const uint32_t id = stack.back();
             stack.pop_back();
             uint32_t c[2];
-            if (!split(id, &c[0], &c[1])) continue;
+            if (!split(id, &c[0], &c[1], pool)) continue;
             for (int k = 0; k < 2; k++) {
-                if (shared && nodes[c[k]].end - nodes[c[k]].begin >= kSpawnMin) {
-                    { std::lock_guard<std::mutex> lock(shared->m); shared->queue.push_back(c[k]); shared->pending++; }
-                    shared->cv.notify_one();
+                if (pool && nodes[c[k]].end - nodes[c[k]].begin >= spawn_min_) {
+                    const uint32_t child = c[k];
+                    pool->push([this, pool, child] { std::vector<uint32_t> st{child}; build_subtree(st, pool); });
                 } else stack.push_back(c[k]);
             }
         }
-    }
-
-    void run_parallel(unsigned threads) {
-        Shared shared;
-        shared.queue.push_back(0u); shared.pending = 1;
-        auto worker = [&] {
-            std::vector<uint32_t> stack;
-            for (;;) {
-                uint32_t id;
-                {
-                    std::unique_lock<std::mutex> lock(shared.m);
-                    shared.cv.wait(lock, [&] { return !shared.queue.empty() || shared.pending == 0; });
-                    if (shared.queue.empty()) return;  // pending == 0: the tree is complete
-                    id = shared.queue.back(); shared.queue.pop_back();
-                }
-                stack.assign(1, id);
-                build_subtree(stack, &shared);
-                bool done;
-                { std::lock_guard<std::mutex> lock(shared.m); shared.pending--; done = shared.pending == 0; }
-                if (done) shared.cv.notify_all();
-            }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < threads; t++) pool.emplace_back(worker);
-        worker();
-        for (auto& t : pool) t.join();
     }
 
     // the original breadth-first loop with a growing node vector (only reached through the overflow guard)
@@ -165,7 +218,7 @@ class BvhBuild {
             const uint32_t id = todo.front();
             todo.pop_front();
             int axis; float split_at, split_cost;
-            if (!best_plane(nodes[id], &axis, &split_at, &split_cost)) continue;
+            if (!best_plane(nodes[id], &axis, &split_at, &split_cost, nullptr)) continue;
             const float leaf_cost = (float)(nodes[id].end - nodes[id].begin) * nodes[id].bounds.half_area();
             if (!(split_cost < leaf_cost)) continue;
             const uint32_t begin = nodes[id].begin, end = nodes[id].end;
@@ -187,22 +240,48 @@ class BvhBuild {
         }
     }
 
-    bool best_plane(const Node& node, int* out_axis, float* out_at, float* out_cost) const {
+    struct Bins { Aabb bounds[3][kBins]; uint32_t count[3][kBins]; Bins() { for (auto& a : count) for (auto& c : a) c = 0; } };
+    static void bin_range(const BuildPrim* p, uint32_t n, const Aabb& cb, V3 scale, Bins& b) {
+        for (uint32_t i = 0; i < n; i++) {
+            const V3 f = scale * (p[i].center - cb.lo);
+            const uint32_t idx[3] = {f2u_sat(f.x), f2u_sat(f.y), f2u_sat(f.z)};
+            for (int a = 0; a < 3; a++) {
+                const uint32_t k = idx[a] < (uint32_t)kBins - 1u ? idx[a] : (uint32_t)kBins - 1u;
+                b.count[a][k] += 1; b.bounds[a][k].grow(p[i].bounds);
+            }
+        }
+    }
+    // Centroid bounds and bin contents are min / max / count reductions: exact in any order, so the few nodes at the top
+    // of a large tree (which would otherwise be the serial critical path of the build) split them over the pool.
+    bool best_plane(const Node& node, int* out_axis, float* out_at, float* out_cost, TaskPool* pool) const {
         const uint32_t n = node.end - node.begin;
         if (n <= 1) return false;
         const BuildPrim* p = prims.data() + node.begin;
         Aabb cb;
-        for (uint32_t i = 0; i < n; i++) cb.grow(p[i].center);
-        Aabb bin_bounds[3][kBins]; uint32_t bin_count[3][kBins] = {};
-        const V3 scale = (float)kBins / cb.extent();
-        for (uint32_t i = 0; i < n; i++) {
-            const V3 f = scale * (p[i].center - cb.lo);
-            const uint32_t b[3] = {f2u_sat(f.x), f2u_sat(f.y), f2u_sat(f.z)};
-            for (int a = 0; a < 3; a++) {
-                const uint32_t k = b[a] < (uint32_t)kBins - 1u ? b[a] : (uint32_t)kBins - 1u;
-                bin_count[a][k] += 1; bin_bounds[a][k].grow(p[i].bounds);
-            }
+        Bins bins;
+        const uint32_t chunks = (pool && n >= kParallelBinMin) ? threads_ : 1u;
+        if (chunks > 1u) {
+            const uint32_t per = (n + chunks - 1u) / chunks;
+            std::vector<Aabb> part_cb(chunks);
+            pool->parallel_for(chunks, [&](uint32_t c) {
+                const uint32_t b = c * per, e = b + per < n ? b + per : n;
+                for (uint32_t i = b; i < e; i++) part_cb[c].grow(p[i].center);
+            });
+            for (const Aabb& a : part_cb) if (a.is_set()) cb.grow(a);
+            const V3 scale = (float)kBins / cb.extent();
+            std::vector<Bins> part(chunks);
+            pool->parallel_for(chunks, [&](uint32_t c) {
+                const uint32_t b = c * per, e = b + per < n ? b + per : n;
+                if (b < e) bin_range(p + b, e - b, cb, scale, part[c]);
+            });
+            for (const Bins& pb : part)
+                for (int a = 0; a < 3; a++)
+                    for (int k = 0; k < kBins; k++) { bins.count[a][k] += pb.count[a][k]; if (pb.bounds[a][k].is_set()) bins.bounds[a][k].grow(pb.bounds[a][k]); }
+        } else {
+            for (uint32_t i = 0; i < n; i++) cb.grow(p[i].center);
+            bin_range(p, n, cb, (float)kBins / cb.extent(), bins);
         }
+        Aabb (&bin_bounds)[3][kBins] = bins.bounds; uint32_t (&bin_count)[3][kBins] = bins.count;
         float la[3][kBins - 1], ra[3][kBins - 1]; uint32_t lc[3][kBins - 1], rc[3][kBins - 1];
         for (int a = 0; a < 3; a++) {
             Aabb lbb, rbb; uint32_t lcount = 0, rcount = 0;
@@ -229,28 +308,36 @@ class BvhBuild {
         return have;
     }
 
-    uint32_t emit(uint32_t id, const std::vector<uint8_t>& blend, std::vector<float4>& out) const {
-        const uint32_t at = (uint32_t)out.size();
-        const Node& n = nodes[id];
-        if (n.internal) {
-            out.resize(out.size() + 4, make_float4(0, 0, 0, 0));
-            const Aabb lb = nodes[n.left].bounds, rb = nodes[n.right].bounds;
-            emit(n.left, blend, out);
-            const uint32_t right_at = emit(n.right, blend, out);
-            out[at] = make_float4(lb.lo.x, lb.lo.y, lb.lo.z, b2f(0u));
-            out[at + 1] = make_float4(lb.hi.x, lb.hi.y, lb.hi.z, b2f(right_at));
-            out[at + 2] = make_float4(rb.lo.x, rb.lo.y, rb.lo.z, 0.0f);
-            out[at + 3] = make_float4(rb.hi.x, rb.hi.y, rb.hi.z, 0.0f);
-        } else {
-            const uint32_t n_entries = n.end - n.begin;
-            for (uint32_t i = 0; i < n_entries; i++) {
-                const BuildPrim& p = prims[n.begin + i];
-                const uint32_t more = i + 1 < n_entries ? 1u : 0u;
-                const uint32_t is_blend = (p.material_id < blend.size() && blend[p.material_id]) ? 2u : 0u;
-                out.push_back(make_float4(b2f(more | is_blend), b2f(p.triangle_id), b2f(p.material_id), b2f(1u)));
+    // writes the subtree of `id` at out[at ...]; explicit stack, right subtrees of large nodes become pool tasks
+    void emit_at(uint32_t root, uint32_t root_at, const std::vector<uint8_t>& blend, const std::vector<uint32_t>& len, std::vector<float4>& out,
+                 TaskPool* pool) const {
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{root, root_at}};
+        while (!stack.empty()) {
+            const uint32_t id = stack.back().first, at = stack.back().second;
+            stack.pop_back();
+            const Node& n = nodes[id];
+            if (n.internal) {
+                const Aabb lb = nodes[n.left].bounds, rb = nodes[n.right].bounds;
+                const uint32_t left_at = at + 4u, right_at = left_at + len[n.left];
+                out[at] = make_float4(lb.lo.x, lb.lo.y, lb.lo.z, b2f(0u));
+                out[at + 1] = make_float4(lb.hi.x, lb.hi.y, lb.hi.z, b2f(right_at));
+                out[at + 2] = make_float4(rb.lo.x, rb.lo.y, rb.lo.z, 0.0f);
+                out[at + 3] = make_float4(rb.hi.x, rb.hi.y, rb.hi.z, 0.0f);
+                if (pool && nodes[n.right].end - nodes[n.right].begin >= 4u * spawn_min_) {
+                    const uint32_t r = n.right;
+                    pool->push([this, r, right_at, &blend, &len, &out, pool] { emit_at(r, right_at, blend, len, out, pool); });
+                } else stack.push_back({n.right, right_at});
+                stack.push_back({n.left, left_at});
+            } else {
+                const uint32_t n_entries = n.end - n.begin;
+                for (uint32_t i = 0; i < n_entries; i++) {
+                    const BuildPrim& p = prims[n.begin + i];
+                    const uint32_t more = i + 1 < n_entries ? 1u : 0u;
+                    const uint32_t is_blend = (p.material_id < blend.size() && blend[p.material_id]) ? 2u : 0u;
+                    out[at + i] = make_float4(b2f(more | is_blend), b2f(p.triangle_id), b2f(p.material_id), b2f(1u));
+                }
             }
         }
-        return at;
     }
 };
 

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Frame time with a scene that changes every frame (stress-bvh.rs style): one dungeon instance is re-inserted with a nudged
+transform before every tick, so each frame pays the host refresh (bake, BVH rebuild, flatten, upload) + the render.
+  python tools/animated_cost.py [--subdivide K] [--frames N]"""
+import argparse, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from strolle_amd import CameraMode, Engine, Instance, scenes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--subdivide", type=int, default=0)
+ap.add_argument("--frames", type=int, default=60)
+args = ap.parse_args()
+e = Engine(device=0)
+scenes.build_dungeon(e, subdivide=args.subdivide)
+size = (1920, 1080)
+desc = scenes.dungeon_camera(size, CameraMode.IMAGE)
+cam = e.create_camera(desc)
+out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+stream = torch.cuda.current_stream().cuda_stream
+npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
+base = npz["xform_0"].reshape(4, 3).T.copy(); mat = 1 + int(npz["material_0"])
+def frame(i, animate):
+    if animate:
+        x = base.copy(); x[0, 3] += 0.0005 * ((i % 20) - 10)
+        e.insert_instance(1, Instance(1, mat, x))
+    e.update_camera(cam, desc); e.tick(stream); e.render_camera(cam, out.data_ptr(), stream)
+for animate in (False, True):
+    for i in range(12): frame(i, animate)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for i in range(args.frames): frame(i, animate)
+    torch.cuda.synchronize()
+    print(f"subdivide={args.subdivide} animate={animate}: {(time.perf_counter() - t) / args.frames * 1e3:.3f} ms/frame")
