@@ -8,9 +8,15 @@
  * panics/asserts. See INTEGRATION.md for the Rust-side FFI stub a maintainer adds.
  *
  * Threading: like the reference (`&mut self` everywhere, lib.rs:105-395) an engine is
- * single-owner; calls on one engine must not overlap. All GPU work is enqueued on the
- * `hipStream_t` given to st_render_camera (0 = the null stream); st_tick uploads on the
- * same stream it was given.
+ * single-owner; calls on one engine must not overlap. Stream contract: everything
+ * st_render_camera enqueues is complete once the `hipStream_t` it was given (0 = the null
+ * stream) has drained — the engine may run part of a frame on an internal side stream, but
+ * joins it into the caller's stream before the frame's last kernel. Frames may be enqueued
+ * back to back without host synchronisation. st_tick uploads on the stream it was given
+ * and returns after they have landed.
+ * Environment switches (read once per engine): ST_NO_OVERLAP=1 single stream, ST_NO_FUSE=1
+ * one launch per reference pass, ST_TILE_MAP=0|1|2 block->tile mapping, ST_FUSE_COMPOSE=1,
+ * ST_COMPACT=1 compacted shadow-ray kernel, ST_TICK_TIMING=1 host refresh timing on stderr.
  */
 #ifndef STROLLE_HIP_H
 #define STROLLE_HIP_H
