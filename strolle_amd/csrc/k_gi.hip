@@ -52,17 +52,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_a(const KArgs a, 
     const TriangleHit gi_hit = trace_closest(a, gi_ray, lane_stack(lds), &used_);
     count_rays(a.ray_counter, used_);
     GBuffer gg = gbuffer_zero();
+    uint32_t base_bits = 0u;  // gbuffer_pack_base_color of the zero colour
     if (hit_is_some(gi_hit)) {
         GpuMaterial m = a.materials[gi_hit.material_id];
         m.roughness = fmax_(m.roughness, 0.75f * 0.75f);
         gg.base_color = sample_atlas(a, gi_hit.uv, m.base_color, m.base_color_texture);
+        base_bits = (a.material_base_packed && is_zero(m.base_color_texture)) ? a.material_base_packed[gi_hit.material_id] : gbuffer_pack_base_color(gg.base_color);
         gg.normal = gi_hit.normal; gg.metallic = m.metallic;
         gg.emissive = xyz(sample_atlas(a, gi_hit.uv, m.emissive, m.emissive_texture));
         gg.roughness = m.roughness; gg.reflectance = m.reflectance;
         gg.depth = distance(gi_ray.origin, gi_hit.point);
     }
     float4 p0, p1;
-    gbuffer_pack(gg, &p0, &p1);
+    gbuffer_pack_bits(gg, base_bits, &p0, &p1);
     tex_write(a.gi_d0, a, gid, f4(gi_ray.dir, gi_ray_pdf));  // indexed by the half-resolution gid (gi_sampling_a.rs:117-121)
     tex_write(a.gi_d1, a, gid, p0);
     tex_write(a.gi_d2, a, gid, p1);

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a
     g.reflectance = material.reflectance;
     g.depth = distance(ray.origin, hit.point);
     float4 d0, d1;
-    gbuffer_pack(g, &d0, &d1);
+    gbuffer_pack_bits(g, (a.material_base_packed && is_zero(material.base_color_texture)) ? a.material_base_packed[hit.material_id] : gbuffer_pack_base_color(g.base_color), &d0, &d1);
     tex_write(a.g0, a, pos, d0);
     tex_write(a.g1, a, pos, d1);
     const V2 en = normal_encode(hit.normal);

@@ -410,18 +410,19 @@ ST_D GBuffer gbuffer_unpack(const KArgs& a, float4 d0, float4 d1) {
                                lut[kLutGamma6 + ((w1 >> 24) & 0xffu)]);
     return g;
 }
-ST_D void gbuffer_pack(const GBuffer& g, float4* d0, float4* d1) {
+// gbuffer.rs:19-50. The base colour's four gamma-encoded bytes (4 pow_ = ~320 VALU operations) depend only on the colour;
+// for a material without a base-colour texture that is a per-material constant, which the host packs once with this very
+// routine (gbuffer_pack_base_color, st_math.h; KArgs::material_base_packed) and primary visibility / GI sampling pass in
+// through `base_bits`.
+ST_D void gbuffer_pack_bits(const GBuffer& g, uint32_t base_bits, float4* d0, float4* d1) {
     const V2 n = normal_encode(g.normal);
     const float m = clampf(g.metallic, 0.0f, 1.0f) * 255.0f;
     const float r = clampf(sqrtf(g.roughness), 0.0f, 1.0f) * 255.0f;
     const float rf = clampf(g.reflectance, 0.0f, 1.0f) * 255.0f;
     *d0 = make_float4(g.depth, n.x, n.y, b2f(u32_from_bytes(f2u_sat(m), f2u_sat(r), f2u_sat(rf), 1u)));
-    const float ig = 1.0f / 2.2f;
-    const float bx = clampf(pow_(g.base_color.x, ig), 0.0f, 1.0f), by = clampf(pow_(g.base_color.y, ig), 0.0f, 1.0f);
-    const float bz = clampf(pow_(g.base_color.z, ig), 0.0f, 1.0f), bw = clampf(pow_(g.base_color.w, ig), 0.0f, 1.0f);
-    *d1 = make_float4(g.emissive.x, g.emissive.y, g.emissive.z,
-                      b2f(u32_from_bytes(f2u_sat(bx * 255.0f), f2u_sat(by * 255.0f), f2u_sat(bz * 255.0f), f2u_sat(bw * 63.0f))));
+    *d1 = make_float4(g.emissive.x, g.emissive.y, g.emissive.z, b2f(base_bits));
 }
+ST_D void gbuffer_pack(const GBuffer& g, float4* d0, float4* d1) { gbuffer_pack_bits(g, gbuffer_pack_base_color(g.base_color), d0, d1); }
 ST_D float clamped_roughness(const GBuffer& g) { return clampf(g.roughness, 0.089f * 0.089f, 1.0f); }
 
 struct Surface { V3 normal; float depth, roughness; };

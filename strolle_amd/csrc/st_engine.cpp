@@ -206,7 +206,7 @@ struct Engine {
     // meshes / materials / instances / triangles
     std::unordered_map<uint64_t, std::vector<StMeshTriangle>> meshes;
     std::vector<StMaterial> materials; std::unordered_map<uint64_t, uint32_t> material_slot; SlotRanges material_free; bool materials_dirty = false;
-    std::vector<GpuMaterial> gpu_materials;
+    std::vector<GpuMaterial> gpu_materials; std::vector<uint32_t> material_base_packed;
     struct InstanceRec { uint64_t id, mesh, material; Affine xform, xform_inv, prev_xform; bool dirty; uint32_t xslot; };
     std::vector<InstanceRec> instances; bool instances_dirty = false;
     // per-instance transforms for primary visibility's prev_point (the reference's per-draw push constants,
@@ -236,7 +236,7 @@ struct Engine {
     std::vector<uint8_t> blue_noise; bool blue_noise_dirty = true;
     bool atmosphere_initialized = false, sky_known = false; float known_sun_altitude = 0.0f;  // passes/atmosphere.rs:14-15,78-110
 
-    DeviceArray d_byte_luts, d_bvh, d_tri_geo, d_tri_attr, d_instance_xforms, d_materials, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
+    DeviceArray d_byte_luts, d_bvh, d_tri_geo, d_tri_attr, d_instance_xforms, d_materials, d_material_base_packed, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
@@ -293,7 +293,7 @@ struct Engine {
         return make_float4((float)r.x / (float)atlas_w, (float)r.y / (float)atlas_h, (float)r.w / (float)atlas_w, (float)r.h / (float)atlas_h);
     }
     void rebuild_gpu_materials() {
-        gpu_materials.resize(materials.size());
+        gpu_materials.resize(materials.size()); material_base_packed.resize(materials.size());
         for (size_t i = 0; i < materials.size(); i++) {
             const StMaterial& m = materials[i]; GpuMaterial& g = gpu_materials[i];
             g.base_color = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
@@ -304,6 +304,7 @@ struct Engine {
             g.metallic = m.metallic; g.reflectance = m.reflectance; g.ior = m.ior;
             g.metallic_roughness_texture = image_rect(m.metallic_roughness_texture);
             g.normal_map_texture = image_rect(m.normal_map_texture);
+            material_base_packed[i] = gbuffer_pack_base_color(g.base_color);  // st_math.h routines are bit-identical on host and device
         }
     }
 
@@ -478,6 +479,7 @@ struct Engine {
                 if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream))) return rc;
                 if ((rc = d_instance_xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), stream))) return rc;
                 if ((rc = d_materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), stream))) return rc;
+                if ((rc = d_material_base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), stream))) return rc;
                 scene_uploaded = true;
                 scene_changed = true;  // forces the stream sync below
             }
@@ -568,7 +570,7 @@ struct Engine {
         KArgs a{};
         a.cam = c.curr; a.prev_cam = c.prev;
         a.bvh = static_cast<const float4*>(d_bvh.ptr); a.tri_geo = static_cast<const float4*>(d_tri_geo.ptr); a.tri_attr = static_cast<const float4*>(d_tri_attr.ptr); a.instance_xforms = static_cast<const float4*>(d_instance_xforms.ptr);
-        a.materials = static_cast<const GpuMaterial*>(d_materials.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
+        a.materials = static_cast<const GpuMaterial*>(d_materials.ptr); a.material_base_packed = getenv("ST_NO_PACKED_BASE") ? nullptr : static_cast<const uint32_t*>(d_material_base_packed.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
         a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr); a.byte_luts = static_cast<const float*>(d_byte_luts.ptr);
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
         a.bvh_len = (uint32_t)bvh_stream.size(); a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;

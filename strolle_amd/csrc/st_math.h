@@ -154,6 +154,14 @@ ST_HD float pow5_(float x) { const float x2 = x * x; const float x4 = x2 * x2; r
 ST_HD float pow8_(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x4 * x4; }
 ST_HD float pow64_(float x) { const float x2 = x * x; const float x4 = x2 * x2; const float x8 = x4 * x4; const float x16 = x8 * x8; const float x32 = x16 * x16; return x32 * x32; }
 
+// the G-buffer's gamma-encoded base colour bytes (gbuffer.rs:37-48): RGB8 + A6. Host and device evaluate it identically.
+ST_HD uint32_t gbuffer_pack_base_color(float4 c) {
+    const float ig = 1.0f / 2.2f;
+    const float bx = clampf(pow_(c.x, ig), 0.0f, 1.0f), by = clampf(pow_(c.y, ig), 0.0f, 1.0f);
+    const float bz = clampf(pow_(c.z, ig), 0.0f, 1.0f), bw = clampf(pow_(c.w, ig), 0.0f, 1.0f);
+    return f2u_sat(bx * 255.0f) | (f2u_sat(by * 255.0f) << 8) | (f2u_sat(bz * 255.0f) << 16) | (f2u_sat(bw * 63.0f) << 24);
+}
+
 ST_HD float atan_(float x) {
     float sign = 1.0f;
     if (x < 0.0f) { sign = -1.0f; x = -x; }

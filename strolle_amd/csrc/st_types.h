@@ -44,6 +44,7 @@ struct KArgs {
     const float4* bvh; const float4* tri_geo; const float4* tri_attr;
     const float4* instance_xforms;  // 8 float4 per instance slot: curr_xform_inv (3 axes + translation), prev_xform; slot = tri_attr[4 t + 3].w
     const GpuMaterial* materials; const GpuLight* lights;
+    const uint32_t* material_base_packed;  // per material: gbuffer_pack_base_color(base_color), valid where it has no base-colour texture
     const uchar4* atlas; const uchar4* blue_noise;
     const float* byte_luts;  // 256 sRGB->linear + 256 unorm8 values (st_device.h kLut*), generated on the device at engine creation
     const float4* transmittance_lut; const float4* sky_lut;
