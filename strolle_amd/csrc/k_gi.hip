@@ -147,6 +147,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_b(const KArgs a, 
 void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_b, true, s, a, seed); }
 
 // ---------------------------------------------------------------- gi_temporal_resampling.rs:3-156
+// REPROJECT: gi_reprojection.rs for the same pixel runs right here (tracing frames only, where this pass is the only reader
+// of the reprojected reservoir): the reservoir fetched from last frame's gi_res[0] is used directly and still stored to
+// gi_res[2], so the plane ends the frame with the reference's contents, but it is not written and read back through HBM
+// by two launches.
+template <bool REPROJECT>
 __global__ __launch_bounds__(kBlockThreads) void k_gi_temporal(const KArgs a, uint32_t seed) {
     U2 lhs_pos;
     if (!resolve_gid(a, false, &lhs_pos) || !owns_pixel(a, lhs_pos)) return;
@@ -163,8 +168,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_temporal(const KArgs a, ui
     GiReservoir rhs = gi_empty();
     Hit rhs_hit = hit_zero();
     const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, lhs_pos));
+    if (REPROJECT) {  // gi_reprojection.rs:3-51 (this pixel has a hit: the early-outs above are the same)
+        GiReservoir res = rp.confidence > 0.0f ? gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n) : gi_empty();
+        res.confidence = 1.0f;
+        res.s.v1_point = lhs_hit.point;
+        gi_write(a.gi_res[2], lhs_idx, res);
+        if (rp.confidence > 0.0f) rhs = gi_after_store(res);
+    }
     if (rp.confidence > 0.0f) {
-        rhs = gi_read(prev_res, lhs_idx, n);
+        if (!REPROJECT) rhs = gi_read(prev_res, lhs_idx, n);
         rhs.confidence = 1.0f;
         rhs.m = fmin_(rhs.m, 128.0f);
         if (!tracing && lhs.m != 0.0f && rhs.m != 0.0f && gi_exists(rhs.s)) {
@@ -198,7 +210,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_temporal(const KArgs a, ui
     main_.w = fmin_(main_.w, 5.0f);
     gi_write(curr_res, lhs_idx, main_);
 }
-void launch_gi_temporal(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_temporal, false, s, a, seed); }
+void launch_gi_temporal(const KArgs& a, uint32_t seed, bool fuse_reprojection, hipStream_t s) {
+    if (fuse_reprojection) ST_LAUNCH(k_gi_temporal<true>, false, s, a, seed); else ST_LAUNCH(k_gi_temporal<false>, false, s, a, seed);
+}
 
 // ---------------------------------------------------------------- gi_spatial_resampling.rs:3-168 (pick)
 __global__ __launch_bounds__(kBlockThreads) void k_gi_spatial_pick(const KArgs a, uint32_t seed) {

@@ -729,6 +729,9 @@ ST_D void gi_write(float4* buf, uint32_t id, const GiReservoir& r) {
     const V2 n = normal_encode(r.s.v2_normal);
     buf[4u * id + 3u] = make_float4(n.x, n.y, r.confidence, b2f(r.s.rng));
 }
+// what gi_read() returns for a reservoir gi_write() just stored: every field is kept bit for bit except the normal, which
+// passes through the octahedral code
+ST_D GiReservoir gi_after_store(GiReservoir r) { r.s.v2_normal = normal_decode(normal_encode(r.s.v2_normal)); return r; }
 ST_D bool gi_exists(const GiSample& s) { return !is_zero(s.v2_point); }
 ST_D V3 gi_dir(const GiSample& s, V3 p) { return normalize(s.v2_point - p); }
 ST_D float gi_cosine(const GiSample& s, const Hit& hit) { return fmax_(dot(gi_dir(s, hit.point), hit.g.normal), 0.0f); }

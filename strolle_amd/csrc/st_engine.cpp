@@ -667,14 +667,20 @@ struct Engine {
             auto do_di = [&] { do_di_head(); do_di_tail(); };
             // GI up to the first preview pass: touches only reservoirs, gi_d0..2 and read-only frame inputs
             auto do_gi_head = [&] {
-                run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, cur); });
+                // on tracing frames gi_temporal is the only reader of the reprojected reservoirs and does the reprojection itself
+                const bool fuse_gi_reprojection = fuse && tracing;
+                auto temporal = [&] {
+                    if (fuse_gi_reprojection) run(KS_GI_REPROJECTION_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), true, cur); });
+                    else run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), false, cur); });
+                };
+                if (!fuse_gi_reprojection) run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, cur); });
                 auto sampling = [&] {
                     run(KS_GI_SAMPLING_A, {}, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), cur); });
                     run(KS_GI_SAMPLING_B, {}, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), cur); });
                 };
                 if (tracing) {
                     if (c.frame % 2u == 0u) sampling();
-                    run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), cur); });
+                    temporal();
                     if (c.frame % 2u == 1u) {
                         run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), cur); });
                         run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, cur); });
@@ -682,7 +688,7 @@ struct Engine {
                     }
                 } else {
                     sampling();
-                    run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), cur); });
+                    temporal();
                 }
                 run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 0u, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], cur); });
             };

@@ -18,6 +18,7 @@ enum KernelSlot {
     KS_COMPOSITION,
     // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
     KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_COMPOSE,
+    KS_GI_REPROJECTION_TEMPORAL,
     KS_COUNT
 };
 struct KernelInfo { const char* name; float bytes_per_unit; bool half; };
@@ -36,6 +37,7 @@ inline const KernelInfo& kernel_info(int slot) {
         {"gi_preview+gi_resolving", 160.f + 256.f, false},
         {"gi_preview+gi_resolving+denoise_reproject", 160.f + 256.f + 112.f, false},
         {"denoise_wavelet+composition", 84.f + 112.f, false},
+        {"gi_reprojection+gi_temporal", 176.f + 272.f, false},
     };
     return k[slot];
 }
@@ -61,7 +63,8 @@ void launch_di_resolving(const KArgs& a, bool fuse_denoise_reproject, hipStream_
 void launch_gi_reprojection(const KArgs& a, hipStream_t s);
 void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_gi_temporal(const KArgs& a, uint32_t seed, hipStream_t s);
+// fuse_reprojection: gi_reprojection.rs runs inside this launch (legal on tracing frames, where nothing else reads gi_res[2] before)
+void launch_gi_temporal(const KArgs& a, uint32_t seed, bool fuse_reprojection, hipStream_t s);
 void launch_gi_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s);
