@@ -8,41 +8,41 @@
 namespace st {
 
 // ---------------------------------------------------------------- di_sampling.rs:3-94
+// the pixel's initial reservoir (RIS over the lights + one shadow ray); `hit` is a surface hit
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, uint32_t seed) {
-    __shared__ SE lds[kStackWords];
+ST_D DiReservoir di_sampling_pixel(const KArgs& a, uint32_t seed, U2 pos, const Hit& hit, SE* stack) {
     uint32_t used_ = 0u;
-    U2 pos;
-    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    const uint32_t idx = screen_to_idx(a, pos);
     WhiteNoise wn = white_noise(seed, pos);
-    const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
-    if (!hit_some(hit)) return;
     EphemeralResult res = ephemeral_build(a, wn, hit);
     DiReservoir out = di_empty();
     if (res.m > 0.0f) {
         const float4 bn = blue_noise_read(a, pos);
         const Ray ray = light_ray_bnoise(light_get(a, res.light_id), v2(bn.x, bn.y), hit.point);
-        const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+        const bool occluded = trace_any(a, ray, stack, &used_);
         count_rays(a.ray_counter, used_);
         if (occluded) res.w = 0.0f;
         out.s.light_id = res.light_id; out.s.light_point = ray.origin; out.s.is_occluded = occluded;
         out.m = 1.0f; out.w = res.w;
     }
-    di_write(a.di_res[1], idx, out);
+    return out;
+}
+template <class SE>
+__global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, uint32_t seed) {
+    __shared__ SE lds[kStackWords];
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    if (!hit_some(hit)) return;
+    di_write(a.di_res[1], screen_to_idx(a, pos), di_sampling_pixel(a, seed, pos, hit, lane_stack(lds)));
 }
 void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_di_sampling, false, s, a, seed); }
 
 // ---------------------------------------------------------------- di_temporal_resampling.rs:3-112
-__global__ __launch_bounds__(kBlockThreads) void k_di_temporal(const KArgs a, uint32_t seed) {
-    U2 lhs_pos;
-    if (!resolve_gid(a, false, &lhs_pos) || !owns_pixel(a, lhs_pos)) return;
+// `lhs` is what di_res[1] holds for this pixel (the sampling pass's reservoir), `lhs_hit` a surface hit
+ST_D void di_temporal_pixel(const KArgs& a, uint32_t seed, U2 lhs_pos, const Hit& lhs_hit, DiReservoir lhs) {
     const uint32_t n = a.width * a.height;
     const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
     WhiteNoise wn = white_noise(seed, lhs_pos);
-    const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
-    if (!hit_some(lhs_hit)) return;
-    DiReservoir lhs = di_read(a.di_res[1], lhs_idx, n);
     if (lhs.m != 0.0f) lhs.s.pdf = di_pdf_ex(lhs.s, light_get(a, lhs.s.light_id), lhs_hit);
     DiReservoir rhs = di_empty();
     Hit rhs_hit = hit_zero();
@@ -75,7 +75,30 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_temporal(const KArgs a, ui
     res_norm(main_, main_pdf, 1.0f, 1.0f);
     di_write(a.di_res[1], lhs_idx, main_);
 }
+__global__ __launch_bounds__(kBlockThreads) void k_di_temporal(const KArgs a, uint32_t seed) {
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    if (!hit_some(hit)) return;
+    di_temporal_pixel(a, seed, pos, hit, di_read(a.di_res[1], screen_to_idx(a, pos), a.width * a.height));
+}
 void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_temporal, false, s, a, seed); }
+
+// di_sampling.rs + di_temporal_resampling.rs in one launch: temporal resampling reads the sampling pass's reservoir only at
+// its own pixel, so it takes it from registers (through the store/load codec, which is not the identity) and the pixel's hit
+// is rebuilt once; di_res[1] ends with the temporal result exactly as it does after the two separate passes.
+template <class SE>
+__global__ __launch_bounds__(kBlockThreads) void k_di_sampling_temporal(const KArgs a, uint32_t seed_sampling, uint32_t seed_temporal) {
+    __shared__ SE lds[kStackWords];
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
+    const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    if (!hit_some(hit)) return;
+    di_temporal_pixel(a, seed_temporal, pos, hit, di_after_store(di_sampling_pixel(a, seed_sampling, pos, hit, lane_stack(lds))));
+}
+void launch_di_sampling_temporal(const KArgs& a, uint32_t seed_sampling, uint32_t seed_temporal, hipStream_t s) {
+    ST_LAUNCH_TRACE(k_di_sampling_temporal, false, s, a, seed_sampling, seed_temporal);
+}
 
 // ---------------------------------------------------------------- di_spatial_resampling.rs:3-147 (pick)
 __global__ __launch_bounds__(kBlockThreads) void k_di_spatial_pick(const KArgs a, uint32_t seed) {

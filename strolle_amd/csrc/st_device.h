@@ -686,19 +686,25 @@ ST_D float4 bilinear_reproject(const KArgs& a, const Reprojection& r, const floa
 struct DiSample { float pdf, confidence; uint32_t light_id; V3 light_point; bool is_occluded; };
 struct DiReservoir { DiSample s; float m, w; };
 ST_D DiReservoir di_empty() { DiReservoir r; r.s.pdf = 0.0f; r.s.confidence = 0.0f; r.s.light_id = 0u; r.s.light_point = v3s(0.0f); r.s.is_occluded = false; r.m = 0.0f; r.w = 0.0f; return r; }
-ST_D DiReservoir di_read(const float4* buf, uint32_t id, uint32_t count) {
-    if (id >= count) return di_empty();
-    const float4 d0 = buf[2u * id], d1 = buf[2u * id + 1u];
+// reservoir/di.rs:17-59: two texels per pixel
+ST_D DiReservoir di_unpack(float4 d0, float4 d1) {
     const uint32_t w = f2b(d0.w);
     DiReservoir r;
     r.s.pdf = d0.z; r.s.confidence = (float)((w >> 8) & 0xffu); r.s.light_id = f2b(d1.w); r.s.light_point = xyz(d1); r.s.is_occluded = (w & 0xffu) > 0u;
     r.m = d0.x; r.w = d0.y;
     return r;
 }
-ST_D void di_write(float4* buf, uint32_t id, const DiReservoir& r) {
-    buf[2u * id] = make_float4(r.m, r.w, r.s.pdf, b2f(u32_from_bytes(r.s.is_occluded ? 1u : 0u, f2u_sat(r.s.confidence), 0u, 0u)));
-    buf[2u * id + 1u] = f4(r.s.light_point, b2f(r.s.light_id));
+ST_D void di_pack(const DiReservoir& r, float4* d0, float4* d1) {
+    *d0 = make_float4(r.m, r.w, r.s.pdf, b2f(u32_from_bytes(r.s.is_occluded ? 1u : 0u, f2u_sat(r.s.confidence), 0u, 0u)));
+    *d1 = f4(r.s.light_point, b2f(r.s.light_id));
 }
+ST_D DiReservoir di_read(const float4* buf, uint32_t id, uint32_t count) {
+    if (id >= count) return di_empty();
+    return di_unpack(buf[2u * id], buf[2u * id + 1u]);
+}
+ST_D void di_write(float4* buf, uint32_t id, const DiReservoir& r) { di_pack(r, &buf[2u * id], &buf[2u * id + 1u]); }
+// what di_read() returns for a reservoir di_write() just stored (the confidence passes through a byte)
+ST_D DiReservoir di_after_store(const DiReservoir& r) { float4 d0, d1; di_pack(r, &d0, &d1); return di_unpack(d0, d1); }
 ST_D float di_pdf_ex(const DiSample& s, const GpuLight& l, Hit hit) {  // reservoir/di.rs:105-116
     hit.g.base_color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     if (!light_is_none(l) && light_contains(l, s.light_point)) return luma(radiance_sum(light_radiance(l, hit)));

@@ -245,6 +245,7 @@ struct Engine {
     hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
     bool have_prev_frame_events = false;
     bool fuse_compose = false;  // composition inside the last wavelet launch: measured slower (109 vs 65+36 us), kept for A/B (ST_FUSE_COMPOSE=1)
+    bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
     uint32_t tile_map = 2;  // blockIdx -> tile mapping (st_device.h); 2 measured best on MI355X; ST_TILE_MAP overrides
     bool profiling = false;
@@ -261,6 +262,8 @@ struct Engine {
         reset_profile_totals();
         if (const char* tm = getenv("ST_TILE_MAP")) tile_map = (uint32_t)atoi(tm);
         if (const char* nf = getenv("ST_NO_FUSE")) fuse = atoi(nf) == 0;
+        if (const char* k = getenv("ST_NO_FUSE_DI_HEAD")) fuse_di_head = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* fc = getenv("ST_FUSE_COMPOSE")) fuse_compose = atoi(fc) != 0;
         if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
@@ -652,8 +655,11 @@ struct Engine {
             };
             // DI up to temporal resampling touches only the DI reservoirs and read-only frame inputs ...
             auto do_di_head = [&] {
-                run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), cur); });
-                run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), cur); });
+                if (fuse && fuse_di_head) run(KS_DI_SAMPLING_TEMPORAL, {}, [&] { launch_di_sampling_temporal(a, seed(SEED_DI_SAMPLING), seed(SEED_DI_TEMPORAL), cur); });
+                else {
+                    run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), cur); });
+                    run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), cur); });
+                }
             };
             // ... the spatial passes use the denoiser's planes as scratch (passes/di_spatial_resampling.rs binds
             // di_diff_samples / curr_colors / stash), and resolving writes the planes the denoiser reads
@@ -668,7 +674,7 @@ struct Engine {
             // GI up to the first preview pass: touches only reservoirs, gi_d0..2 and read-only frame inputs
             auto do_gi_head = [&] {
                 // on tracing frames gi_temporal is the only reader of the reprojected reservoirs and does the reprojection itself
-                const bool fuse_gi_reprojection = fuse && tracing;
+                const bool fuse_gi_reprojection = fuse && fuse_gi_reproj && tracing;
                 auto temporal = [&] {
                     if (fuse_gi_reprojection) run(KS_GI_REPROJECTION_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), true, cur); });
                     else run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), false, cur); });

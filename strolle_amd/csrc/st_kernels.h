@@ -18,7 +18,7 @@ enum KernelSlot {
     KS_COMPOSITION,
     // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
     KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_COMPOSE,
-    KS_GI_REPROJECTION_TEMPORAL,
+    KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL,
     KS_COUNT
 };
 struct KernelInfo { const char* name; float bytes_per_unit; bool half; };
@@ -38,6 +38,7 @@ inline const KernelInfo& kernel_info(int slot) {
         {"gi_preview+gi_resolving+denoise_reproject", 160.f + 256.f + 112.f, false},
         {"denoise_wavelet+composition", 84.f + 112.f, false},
         {"gi_reprojection+gi_temporal", 176.f + 272.f, false},
+        {"di_sampling+di_temporal", 68.f + 176.f, false},
     };
     return k[slot];
 }
@@ -55,6 +56,7 @@ void launch_frame_reprojection(const KArgs& a, hipStream_t s);
 // ReSTIR DI
 void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_di_sampling_temporal(const KArgs& a, uint32_t seed_sampling, uint32_t seed_temporal, hipStream_t s);  // both passes, one launch
 void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s);
 void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
