@@ -8,24 +8,6 @@
 namespace st {
 
 // ---------------------------------------------------------------- di_sampling.rs:3-94
-// the pixel's initial reservoir (RIS over the lights + one shadow ray); `hit` is a surface hit
-template <class SE>
-ST_D DiReservoir di_sampling_pixel(const KArgs& a, uint32_t seed, U2 pos, const Hit& hit, SE* stack) {
-    uint32_t used_ = 0u;
-    WhiteNoise wn = white_noise(seed, pos);
-    EphemeralResult res = ephemeral_build(a, wn, hit);
-    DiReservoir out = di_empty();
-    if (res.m > 0.0f) {
-        const float4 bn = blue_noise_read(a, pos);
-        const Ray ray = light_ray_bnoise(light_get(a, res.light_id), v2(bn.x, bn.y), hit.point);
-        const bool occluded = trace_any(a, ray, stack, &used_);
-        count_rays(a.ray_counter, used_);
-        if (occluded) res.w = 0.0f;
-        out.s.light_id = res.light_id; out.s.light_point = ray.origin; out.s.is_occluded = occluded;
-        out.m = 1.0f; out.w = res.w;
-    }
-    return out;
-}
 template <class SE>
 __global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, uint32_t seed) {
     __shared__ SE lds[kStackWords];
@@ -38,49 +20,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, ui
 void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_di_sampling, false, s, a, seed); }
 
 // ---------------------------------------------------------------- di_temporal_resampling.rs:3-112
-// `lhs` is what di_res[1] holds for this pixel (the sampling pass's reservoir), `lhs_hit` a surface hit
-ST_D void di_temporal_pixel(const KArgs& a, uint32_t seed, U2 lhs_pos, const Hit& lhs_hit, DiReservoir lhs) {
-    const uint32_t n = a.width * a.height;
-    const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
-    WhiteNoise wn = white_noise(seed, lhs_pos);
-    if (lhs.m != 0.0f) lhs.s.pdf = di_pdf_ex(lhs.s, light_get(a, lhs.s.light_id), lhs_hit);
-    DiReservoir rhs = di_empty();
-    Hit rhs_hit = hit_zero();
-    bool rhs_killed = false;
-    const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, lhs_pos));
-    if (rp.confidence > 0.0f) {
-        const U2 rhs_pos = reprojection_prev_round(rp);
-        rhs = di_read(a.di_res[0], screen_to_idx(a, rhs_pos), n);
-        rhs.m = fmin_(rhs.m, 64.0f);
-        if (rhs.m != 0.0f) {
-            const GpuLight rhs_light = light_get(a, rhs.s.light_id);
-            const uint32_t slot = f2b(rhs_light.d3.x);
-            if (slot == 0xcafebabeu) { rhs.w = 0.0f; rhs_killed = true; }
-            else if (slot > 0u) rhs.s.light_id = slot - 1u;
-            rhs_hit = pixel_hit(a, a.prev_cam, a.pg0, a.pg1, rhs_pos);
-        }
-    }
-    Mis mis;
-    mis.lhs_rhs_pdf = ((lhs.m > 0.0f) & hit_some(rhs_hit)) ? di_pdf_ex(lhs.s, light_get_prev(a, lhs.s.light_id), rhs_hit) : 0.0f;
-    mis.rhs_lhs_pdf = ((rhs.m > 0.0f) & !rhs_killed) ? di_pdf_ex(rhs.s, light_get(a, rhs.s.light_id), lhs_hit) : 0.0f;
-    mis.lhs_m = lhs.m; mis.rhs_m = rhs.m; mis.rhs_jacobian = 1.0f; mis.lhs_lhs_pdf = lhs.s.pdf; mis.rhs_rhs_pdf = rhs.s.pdf;
-    const MisResult mr = mis_eval(mis);
-    DiReservoir main_ = di_empty();
-    float main_pdf = 0.0f;
-    if (res_update(main_, wn, lhs.s, mr.lhs_mis * mr.lhs_pdf * lhs.w)) main_pdf = mr.lhs_pdf;
-    if (res_update(main_, wn, rhs.s, mr.rhs_mis * mr.rhs_pdf * rhs.w)) main_pdf = mr.rhs_pdf;
-    main_.m = lhs.m + mr.m;
-    main_.s.pdf = main_pdf;
-    main_.s.confidence = rhs_killed ? 0.0f : 1.0f;
-    res_norm(main_, main_pdf, 1.0f, 1.0f);
-    di_write(a.di_res[1], lhs_idx, main_);
-}
 __global__ __launch_bounds__(kBlockThreads) void k_di_temporal(const KArgs a, uint32_t seed) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
     if (!hit_some(hit)) return;
-    di_temporal_pixel(a, seed, pos, hit, di_read(a.di_res[1], screen_to_idx(a, pos), a.width * a.height));
+    di_temporal_pixel(a, seed, pos, hit, di_read(a.di_res[1], screen_to_idx(a, pos), a.width * a.height), tex_read(a.reprojection, a, pos));
 }
 void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_temporal, false, s, a, seed); }
 
@@ -94,7 +39,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_sampling_temporal(const KA
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
     if (!hit_some(hit)) return;
-    di_temporal_pixel(a, seed_temporal, pos, hit, di_after_store(di_sampling_pixel(a, seed_sampling, pos, hit, lane_stack(lds))));
+    di_temporal_pixel(a, seed_temporal, pos, hit, di_after_store(di_sampling_pixel(a, seed_sampling, pos, hit, lane_stack(lds))), tex_read(a.reprojection, a, pos));
 }
 void launch_di_sampling_temporal(const KArgs& a, uint32_t seed_sampling, uint32_t seed_temporal, hipStream_t s) {
     ST_LAUNCH_TRACE(k_di_sampling_temporal, false, s, a, seed_sampling, seed_temporal);
