@@ -20,6 +20,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libstrolle_hip.so")
+if os.environ.get("STROLLE_HIP_LIB"):  # experiments: an alternative build of the same sources (never a different implementation)
+    LIB_PATH = os.environ["STROLLE_HIP_LIB"]
 
 
 # ----------------------------------------------------------------------------- C structs (include/strolle_hip.h)

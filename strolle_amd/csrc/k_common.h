@@ -7,6 +7,12 @@
 namespace st {
 
 constexpr int kBlockThreads = 256;               // 4 wavefronts, one 8x8 tile each
+// -DST_MIN_WAVES=N (experiments): ask the register allocator for at least N waves per SIMD on every pass kernel
+#ifdef ST_MIN_WAVES
+#define ST_KERNEL_BOUNDS __launch_bounds__(kBlockThreads, ST_MIN_WAVES)
+#else
+#define ST_KERNEL_BOUNDS __launch_bounds__(kBlockThreads)
+#endif
 constexpr int kStackWords = 4 * kBvhStackSize * 64;  // 24 KiB of LDS per block for the traversal stacks
 
 struct LaunchDims { uint32_t tiles_x, tile_y0, tile_y1, blocks; };

@@ -30,7 +30,7 @@ ST_D f2 exp_pair(f2 x) {
 }
 
 // ---------------------------------------------------------------- frame_denoising.rs:3-78
-__global__ __launch_bounds__(kBlockThreads) void k_denoise_reproject(const KArgs a, const float4* prev_colors, const float4* prev_moments,
+__global__ ST_KERNEL_BOUNDS void k_denoise_reproject(const KArgs a, const float4* prev_colors, const float4* prev_moments,
                                                                       const float4* samples, float4* colors, float4* moments) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -42,7 +42,7 @@ void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const f
 }
 
 // ---------------------------------------------------------------- frame_denoising.rs:80-217
-__global__ __launch_bounds__(kBlockThreads) void k_denoise_variance(const KArgs a) {
+__global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a) {
     // Window of the short-history estimate, staged per block when any of its pixels needs it: ox in [-3, 2], oy in
     // [-2, 2] around 32x8 pixels = 38 x 12 texels of (surface, direct colour, indirect colour). Only ~15 % of the waves
     // take the slow path on Cornell, but with 58 dependent loads each they set the kernel's duration; from LDS the same
@@ -131,7 +131,7 @@ void launch_denoise_variance(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_denois
 // COMPOSE: the last wavelet pass also runs frame composition for its pixel (frame_composition.rs) — the composed frame
 // needs only this pixel's denoised colours, which are in registers here.
 template <bool COMPOSE>
-__global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out,
+__global__ ST_KERNEL_BOUNDS void k_denoise_wavelet(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out,
                                                                     const float4* gi_in, float4* gi_out, const float2* sl_in, float2* sl_out,
                                                                     uint32_t camera_mode, float4* frame_out) {
     U2 pos;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet(const KArgs a
 // staged with depth 0: the tap loop already skips depth-0 (sky) samples, which is what `continue` on an out-of-bounds
 // tap does in the reference. Row pitch 40 texels: 640 B rows put 8-lane row segments of ds_read_b128 on disjoint banks.
 template <int S>
-__global__ __launch_bounds__(kBlockThreads) void k_denoise_wavelet_lds(const KArgs a, float strength, const float4* di_in, float4* di_out,
+__global__ ST_KERNEL_BOUNDS void k_denoise_wavelet_lds(const KArgs a, float strength, const float4* di_in, float4* di_out,
                                                                         const float4* gi_in, float4* gi_out, const float2* sl_in, float2* sl_out) {
     constexpr int RW = 32 + 2 * S, RH = 8 + 2 * S, PITCH = 40;
     __shared__ float4 s_sn[PITCH * RH];

@@ -9,7 +9,7 @@ namespace st {
 
 // ---------------------------------------------------------------- di_sampling.rs:3-94
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_di_sampling(const KArgs a, uint32_t seed) {
     __shared__ SE lds[kStackWords];
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_sampling(const KArgs a, ui
 void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_di_sampling, false, s, a, seed); }
 
 // ---------------------------------------------------------------- di_temporal_resampling.rs:3-112
-__global__ __launch_bounds__(kBlockThreads) void k_di_temporal(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_di_temporal(const KArgs a, uint32_t seed) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
@@ -33,7 +33,7 @@ void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNC
 // its own pixel, so it takes it from registers (through the store/load codec, which is not the identity) and the pixel's hit
 // is rebuilt once; di_res[1] ends with the temporal result exactly as it does after the two separate passes.
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_di_sampling_temporal(const KArgs a, uint32_t seed_sampling, uint32_t seed_temporal) {
+__global__ ST_KERNEL_BOUNDS void k_di_sampling_temporal(const KArgs a, uint32_t seed_sampling, uint32_t seed_temporal) {
     __shared__ SE lds[kStackWords];
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -46,7 +46,7 @@ void launch_di_sampling_temporal(const KArgs& a, uint32_t seed_sampling, uint32_
 }
 
 // ---------------------------------------------------------------- di_spatial_resampling.rs:3-147 (pick)
-__global__ __launch_bounds__(kBlockThreads) void k_di_spatial_pick(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_di_spatial_pick(const KArgs a, uint32_t seed) {
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
     const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_di_spatial_pick(const KArgs a
 void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_spatial_pick, true, s, a, seed); }
 
 // ---------------------------------------------------------------- di_spatial_resampling.rs:211-297 (sample)
-__global__ __launch_bounds__(kBlockThreads) void k_di_spatial_sample(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_di_spatial_sample(const KArgs a, uint32_t seed) {
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
     const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
@@ -131,7 +131,7 @@ void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST
 // REPROJECT: the DI half of frame_denoising.rs::reproject is appended (it reads only this pixel's fresh diffuse sample
 // plus previous-frame planes).
 template <bool REPROJECT, class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_di_resolving(const KArgs a) {
+__global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a) {
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;

@@ -7,7 +7,7 @@
 namespace st {
 
 // ---------------------------------------------------------------- gi_reprojection.rs:3-51
-__global__ __launch_bounds__(kBlockThreads) void k_gi_reprojection(const KArgs a) {
+__global__ ST_KERNEL_BOUNDS void k_gi_reprojection(const KArgs a) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const uint32_t n = a.width * a.height;
@@ -25,7 +25,7 @@ ST_D bool frame_is_gi_tracing(uint32_t frame) { return frame % 6u < 4u; }  // fr
 
 // ---------------------------------------------------------------- gi_sampling_a.rs:3-122
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_a(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a, uint32_t seed) {
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 gid;
@@ -73,7 +73,7 @@ void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAU
 
 // ---------------------------------------------------------------- gi_sampling_b.rs:3-235
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_gi_sampling_b(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a, uint32_t seed) {
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 gid;
@@ -152,7 +152,7 @@ void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAU
 // gi_res[2], so the plane ends the frame with the reference's contents, but it is not written and read back through HBM
 // by two launches.
 template <bool REPROJECT>
-__global__ __launch_bounds__(kBlockThreads) void k_gi_temporal(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_gi_temporal(const KArgs a, uint32_t seed) {
     U2 lhs_pos;
     if (!resolve_gid(a, false, &lhs_pos) || !owns_pixel(a, lhs_pos)) return;
     const uint32_t n = a.width * a.height;
@@ -215,7 +215,7 @@ void launch_gi_temporal(const KArgs& a, uint32_t seed, bool fuse_reprojection, h
 }
 
 // ---------------------------------------------------------------- gi_spatial_resampling.rs:3-168 (pick)
-__global__ __launch_bounds__(kBlockThreads) void k_gi_spatial_pick(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_gi_spatial_pick(const KArgs a, uint32_t seed) {
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
     const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gi_spatial_pick(const KArgs a
 void launch_gi_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_spatial_pick, true, s, a, seed); }
 
 // ---------------------------------------------------------------- gi_spatial_resampling.rs:232-314 (sample)
-__global__ __launch_bounds__(kBlockThreads) void k_gi_spatial_sample(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_gi_spatial_sample(const KArgs a, uint32_t seed) {
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
     const U2 pos = resolve_checkerboard_alt(gid, a.frame / 2u);
@@ -311,7 +311,7 @@ void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST
 // reservoir, an empty one on sky, or (the reference's early `return`, :84-86) whatever gi_res[0] already held — and then
 // overwrites that slot with the frame's source reservoir, so the intermediate store is dropped.
 template <bool RESOLVE>
-__global__ __launch_bounds__(kBlockThreads) void k_gi_preview(const KArgs a, uint32_t seed, uint32_t nth, const float4* in, float4* out, uint32_t source,
+__global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint32_t nth, const float4* in, float4* out, uint32_t source,
                                                               uint32_t reproject) {
     U2 center_pos;
     if (!resolve_gid(a, false, &center_pos) || !owns_pixel(a, center_pos)) return;
@@ -371,7 +371,7 @@ void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, cons
 }
 
 // ---------------------------------------------------------------- gi_resolving.rs:3-67
-__global__ __launch_bounds__(kBlockThreads) void k_gi_resolving(const KArgs a, uint32_t source) {
+__global__ ST_KERNEL_BOUNDS void k_gi_resolving(const KArgs a, uint32_t source) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const uint32_t n = a.width * a.height;

@@ -25,7 +25,7 @@ ST_D V3 heatmap_gradient(float progress) {
     return c3;
 }
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_bvh_heatmap(const KArgs a) {
+__global__ ST_KERNEL_BOUNDS void k_bvh_heatmap(const KArgs a) {
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -40,7 +40,7 @@ void launch_bvh_heatmap(const KArgs& a, hipStream_t s) { ST_LAUNCH_TRACE(k_bvh_h
 
 // ---------------------------------------------------------------- ref_tracing.rs:3-60
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_ref_tracing(const KArgs a, uint32_t depth) {
+__global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a, uint32_t depth) {
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -64,7 +64,7 @@ void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s) { ST_LAUN
 
 // ---------------------------------------------------------------- ref_shading.rs:3-177
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_ref_shading(const KArgs a, uint32_t seed, uint32_t depth) {
+__global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a, uint32_t seed, uint32_t depth) {
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -152,7 +152,7 @@ ST_D void frame_reprojection_pixel(const KArgs& a, U2 pos, const Surface& surfac
 // REPROJECT: frame_reprojection runs in the same kernel (it needs this pixel's new surface + velocity and the PREVIOUS
 // frame's surfaces only).
 template <bool REPROJECT, class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_prim_visibility(const KArgs a) {
+__global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a) {
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -211,7 +211,7 @@ __global__ void k_build_byte_luts(float* out) {
 void launch_build_byte_luts(float* out, hipStream_t s) { hipLaunchKernelGGL(k_build_byte_luts, dim3(1), dim3(256), 0, s, out); }
 
 // ---------------------------------------------------------------- frame_reprojection.rs:6-95
-__global__ __launch_bounds__(kBlockThreads) void k_frame_reprojection(const KArgs a) {
+__global__ ST_KERNEL_BOUNDS void k_frame_reprojection(const KArgs a) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const float4 vel = tex_read(a.velocity, a, pos);
@@ -221,7 +221,7 @@ void launch_frame_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_fram
 
 // ---------------------------------------------------------------- {di,gi}_spatial_resampling.rs `trace`
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_spatial_trace(const KArgs a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2) {
+__global__ ST_KERNEL_BOUNDS void k_spatial_trace(const KArgs a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2) {
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_spatial_trace(const KArgs a, 
 // LDS pool (5 instead of 8 waves per SIMD) cost more than the idle lanes did. Kept as the starting point for round 2.
 constexpr uint32_t kGroupsPerBlock = 2u, kPoolRays = kGroupsPerBlock * 256u;
 template <class SE>
-__global__ __launch_bounds__(kBlockThreads) void k_spatial_trace_compact(const KArgs a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2,
+__global__ ST_KERNEL_BOUNDS void k_spatial_trace_compact(const KArgs a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2,
                                                                           uint32_t groups_x, uint32_t tile_y0, uint32_t n_groups) {
     __shared__ SE lds[kStackWords];
     __shared__ float4 pool_d0[kPoolRays];
@@ -326,7 +326,7 @@ void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* bu
 }
 
 // ---------------------------------------------------------------- frame_composition.rs:18-82 as a compute pass into an RGBA32F buffer
-__global__ __launch_bounds__(kBlockThreads) void k_composition(const KArgs a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out) {
+__global__ ST_KERNEL_BOUNDS void k_composition(const KArgs a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     out[pos.y * a.width + pos.x] = compose_pixel(a, pos, camera_mode, tex_read(di_diff, a, pos), tex_read(gi_diff, a, pos));
