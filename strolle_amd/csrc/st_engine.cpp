@@ -247,6 +247,10 @@ struct Engine {
     bool fuse_compose = false;  // composition inside the last wavelet launch: measured slower (109 vs 65+36 us), kept for A/B (ST_FUSE_COMPOSE=1)
     bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
+    // ... and for the SVGF passes (ST_TILE_MAP_DENOISE). Measured on one box: denoiser on mode 2 makes the wavelet launches
+    // 56 instead of 61 us when they run alone (serial profile), but the two-stream frame is 1.373 instead of 1.347 ms —
+    // mode 1 shares every XCD evenly between the two kernels in flight — so the frame time decides.
+    uint32_t tile_map_denoise = 1;
     uint32_t tile_map = 1;  // blockIdx -> tile mapping (st_device.h); 1 measured best on MI355X with the current kernels (2 was, before the LDS-staged denoiser); ST_TILE_MAP overrides
     bool profiling = false;
     bool tick_timing = false;  // ST_TICK_TIMING=1: print the host-side cost of a scene refresh to stderr
@@ -260,7 +264,8 @@ struct Engine {
         light_slot[-1] = 0;
         blue_noise.assign(256 * 256 * 4, 0);
         reset_profile_totals();
-        if (const char* tm = getenv("ST_TILE_MAP")) tile_map = (uint32_t)atoi(tm);
+        if (const char* tm = getenv("ST_TILE_MAP")) tile_map = tile_map_denoise = (uint32_t)atoi(tm);
+        if (const char* tm = getenv("ST_TILE_MAP_DENOISE")) tile_map_denoise = (uint32_t)atoi(tm);
         if (const char* nf = getenv("ST_NO_FUSE")) fuse = atoi(nf) == 0;
         if (const char* k = getenv("ST_NO_FUSE_DI_HEAD")) fuse_di_head = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
@@ -710,6 +715,8 @@ struct Engine {
             };
             auto do_denoise = [&] {
                 if (!denoise) return;
+                // the denoiser can use its own block -> tile mapping (see `tile_map_denoise`)
+                struct MapScope { KArgs& a; uint32_t saved; MapScope(KArgs& a_, uint32_t m) : a(a_), saved(a_.tile_map) { a.tile_map = m; } ~MapScope() { a.tile_map = saved; } } map_scope(a, tile_map_denoise);
                 if (!di_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, cur); });
                 if (!gi_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, cur); });
                 run(KS_DENOISE_VARIANCE, {}, [&] { launch_denoise_variance(a, cur); });
