@@ -247,10 +247,10 @@ struct Engine {
     bool fuse_compose = false;  // composition inside the last wavelet launch: measured slower (109 vs 65+36 us), kept for A/B (ST_FUSE_COMPOSE=1)
     bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
-    // ... and for the SVGF passes (ST_TILE_MAP_DENOISE). Measured on one box: denoiser on mode 2 makes the wavelet launches
-    // 56 instead of 61 us when they run alone (serial profile), but the two-stream frame is 1.373 instead of 1.347 ms —
-    // mode 1 shares every XCD evenly between the two kernels in flight — so the frame time decides.
-    uint32_t tile_map_denoise = 1;
+    // ... and for the SVGF passes (ST_TILE_MAP_DENOISE): mode 2 keeps the halo rows of the LDS windows and the a-trous taps
+    // in one XCD's L2. Measured on one box: with mode 1 the two-stream frame is 1.347 instead of 1.373 ms, but a wavelet
+    // launch moves 340 instead of 205 MB through the fabric (algorithmic: 174 MB) and takes 61 instead of 56 us on its own.
+    uint32_t tile_map_denoise = 2;
     uint32_t tile_map = 1;  // blockIdx -> tile mapping (st_device.h); 1 measured best on MI355X with the current kernels (2 was, before the LDS-staged denoiser); ST_TILE_MAP overrides
     bool profiling = false;
     bool tick_timing = false;  // ST_TICK_TIMING=1: print the host-side cost of a scene refresh to stderr
