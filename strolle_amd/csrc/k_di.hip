@@ -46,18 +46,18 @@ void launch_di_sampling_temporal(const KArgs& a, uint32_t seed_sampling, uint32_
 }
 
 // ---------------------------------------------------------------- di_spatial_resampling.rs:3-147 (pick)
-__global__ ST_KERNEL_BOUNDS void k_di_spatial_pick(const KArgs a, uint32_t seed) {
-    U2 gid;
-    if (!resolve_gid(a, true, &gid)) return;
-    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
-    if (!owns_pixel(a, lhs_pos)) return;
+// What the pick stage left in the scratch planes for its cell's two pixels: `wrote_d1` / `wrote_d0` say which texels are
+// fresh (an early exit on a sky pixel writes nothing and the next stages then see stale plane contents, as in the reference).
+struct SpatialRecords { bool wrote_d0, wrote_d1; float4 a0, a1, b0, b1; };
+ST_D SpatialRecords di_spatial_pick_cell(const KArgs& a, uint32_t seed, U2 gid, U2 lhs_pos) {
+    SpatialRecords out; out.wrote_d0 = false; out.wrote_d1 = false; out.a0 = out.a1 = out.b0 = out.b1 = f4z();
     const uint32_t n = a.width * a.height;
     const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
     WhiteNoise wn = white_noise(seed, lhs_pos);
     float4* buf_d0 = a.di_diff_samples; float4* buf_d1 = a.di_diff_curr_colors;
     const U2 buf_pos_a = u2(gid.x * 2u, gid.y), buf_pos_b = u2(gid.x * 2u + 1u, gid.y);
     const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
-    if (!hit_some(lhs_hit)) return;
+    if (!hit_some(lhs_hit)) return out;
     const DiReservoir lhs = di_read(a.di_res[1], lhs_idx, n);
     DiReservoir rhs = di_empty();
     uint32_t rhs_nth = 0u, rhs_idx = 0u;
@@ -76,33 +76,37 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_pick(const KArgs a, uint32_t seed)
         rhs = di_read(a.di_res[1], rhs_idx, n);
         if (rhs.m != 0.0f) break;
     }
-    if (rhs.m == 0.0f) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return; }
+    out.wrote_d1 = true;
+    if (rhs.m == 0.0f) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return out; }
     const float lhs_rhs_pdf = di_pdf_ex(lhs.s, light_get(a, lhs.s.light_id), rhs_hit);
     const float rhs_lhs_pdf = di_pdf_ex(rhs.s, light_get(a, rhs.s.light_id), lhs_hit);
     const Ray ray_a = lhs_rhs_pdf > 0.0f ? di_sample_ray(lhs.s, rhs_hit.point) : zero_ray();
     const Ray ray_b = rhs_lhs_pdf > 0.0f ? di_sample_ray(rhs.s, lhs_hit.point) : zero_ray();
-    tex_write(buf_d0, a, buf_pos_a, f4(ray_a.origin, ray_a.len));
-    const V2 ea = normal_encode(ray_a.dir);
-    tex_write(buf_d1, a, buf_pos_a, make_float4(ea.x, ea.y, b2f(rhs_idx + 1u), 0.0f));
-    tex_write(buf_d0, a, buf_pos_b, f4(ray_b.origin, ray_b.len));
-    const V2 eb = normal_encode(ray_b.dir);
-    tex_write(buf_d1, a, buf_pos_b, make_float4(eb.x, eb.y, lhs_rhs_pdf, rhs_lhs_pdf));
+    const V2 ea = normal_encode(ray_a.dir), eb = normal_encode(ray_b.dir);
+    out.wrote_d0 = true;
+    out.a0 = f4(ray_a.origin, ray_a.len); out.a1 = make_float4(ea.x, ea.y, b2f(rhs_idx + 1u), 0.0f);
+    out.b0 = f4(ray_b.origin, ray_b.len); out.b1 = make_float4(eb.x, eb.y, lhs_rhs_pdf, rhs_lhs_pdf);
+    tex_write(buf_d0, a, buf_pos_a, out.a0); tex_write(buf_d1, a, buf_pos_a, out.a1);
+    tex_write(buf_d0, a, buf_pos_b, out.b0); tex_write(buf_d1, a, buf_pos_b, out.b1);
+    return out;
 }
-void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_spatial_pick, true, s, a, seed); }
-
-// ---------------------------------------------------------------- di_spatial_resampling.rs:211-297 (sample)
-__global__ ST_KERNEL_BOUNDS void k_di_spatial_sample(const KArgs a, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_di_spatial_pick(const KArgs a, uint32_t seed) {
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
     const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
     if (!owns_pixel(a, lhs_pos)) return;
+    (void)di_spatial_pick_cell(a, seed, gid, lhs_pos);
+}
+void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_spatial_pick, true, s, a, seed); }
+
+// ---------------------------------------------------------------- di_spatial_resampling.rs:211-297 (sample)
+// d0 / d1: the trace stage's texels for the cell's two pixels (di_diff_stash at (2 gid.x, gid.y) and (2 gid.x + 1, gid.y))
+ST_D void di_spatial_sample_cell(const KArgs& a, uint32_t seed, U2 gid, U2 lhs_pos, float4 d0, float4 d1) {
     const uint32_t n = a.width * a.height;
     const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
     WhiteNoise wn = white_noise(seed, lhs_pos);
-    const float4* buf_d2 = a.di_diff_stash;
     const float4* in_res = a.di_res[1];
     float4* out_res = a.di_res[2];
-    const float4 d0 = tex_read(buf_d2, a, u2(gid.x * 2u, gid.y)), d1 = tex_read(buf_d2, a, u2(gid.x * 2u + 1u, gid.y));
     const float lhs_rhs_vis = d0.x;
     const uint32_t rhs_idx = f2b(d0.y);
     const float rhs_lhs_vis = d1.x, lhs_rhs_pdf = d1.y, rhs_lhs_pdf = d1.z;
@@ -124,6 +128,52 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_sample(const KArgs a, uint32_t see
     } else di_write(out_res, lhs_idx, lhs);
     const U2 other = resolve_checkerboard(gid, a.frame / 2u);
     if (contains_u(a, other)) { const uint32_t oi = screen_to_idx(a, other); di_write(out_res, oi, di_read(in_res, oi, n)); }
+}
+__global__ ST_KERNEL_BOUNDS void k_di_spatial_sample(const KArgs a, uint32_t seed) {
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    if (!owns_pixel(a, lhs_pos)) return;
+    di_spatial_sample_cell(a, seed, gid, lhs_pos, tex_read(a.di_diff_stash, a, u2(gid.x * 2u, gid.y)), tex_read(a.di_diff_stash, a, u2(gid.x * 2u + 1u, gid.y)));
+}
+
+// di_spatial_resampling.rs pick + trace + sample for one 2x1 checkerboard cell in one launch. The three passes of a cell talk
+// to each other only through that cell's two texels of the scratch planes, so the records and visibilities travel in
+// registers; they are still stored (later passes, or the next frame's stale reads, must find what the reference leaves
+// there), and a texel the pick stage did not write is read back from the plane, stale contents included.
+template <class SE>
+__global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a, uint32_t seed_pick, uint32_t seed_sample) {
+    __shared__ SE lds[kStackWords];
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    const bool own_lhs = owns_pixel(a, lhs_pos);
+    SpatialRecords rec; rec.wrote_d0 = false; rec.wrote_d1 = false; rec.a0 = rec.a1 = rec.b0 = rec.b1 = f4z();
+    if (own_lhs) rec = di_spatial_pick_cell(a, seed_pick, gid, lhs_pos);
+    float4 vis[2];
+    uint32_t rays = 0u; unsigned long long bytes = 0ull;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const U2 pos = u2(gid.x * 2u + (uint32_t)k, gid.y);
+        if (!owns_pixel(a, pos)) { vis[k] = tex_read(a.di_diff_stash, a, pos); continue; }  // what the sample stage would read there
+        const float4 r0 = rec.wrote_d0 ? (k == 0 ? rec.a0 : rec.b0) : tex_read(a.di_diff_samples, a, pos);
+        const float4 r1 = rec.wrote_d1 ? (k == 0 ? rec.a1 : rec.b1) : tex_read(a.di_diff_curr_colors, a, pos);
+        if (is_zero(r1)) vis[k] = f4z();
+        else {
+            Ray ray = make_ray(xyz(r0), normal_decode(v2(r1.x, r1.y)));
+            ray.len = r0.w;
+            uint32_t used_ = 0u;
+            const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+            rays += 1u; bytes += used_;
+            vis[k] = make_float4(occluded ? 0.0f : 1.0f, r1.z, r1.w, 0.0f);
+        }
+        tex_write(a.di_diff_stash, a, pos, vis[k]);
+    }
+    if (rays) count_rays_n(a.ray_counter, rays, bytes);
+    if (own_lhs) di_spatial_sample_cell(a, seed_sample, gid, lhs_pos, vis[0], vis[1]);
+}
+void launch_di_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_sample, hipStream_t s) {
+    ST_LAUNCH_TRACE(k_di_spatial_fused, true, s, a, seed_pick, seed_sample);
 }
 void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_di_spatial_sample, true, s, a, seed); }
 

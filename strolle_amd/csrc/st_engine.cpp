@@ -245,6 +245,7 @@ struct Engine {
     hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
     bool have_prev_frame_events = false;
     bool fuse_compose = false;  // composition inside the last wavelet launch: measured slower (109 vs 65+36 us), kept for A/B (ST_FUSE_COMPOSE=1)
+    bool fuse_spatial = true;  // ST_NO_FUSE_SPATIAL=1: DI spatial resampling as three launches
     bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
     // ... and for the SVGF passes (ST_TILE_MAP_DENOISE): mode 2 keeps the halo rows of the LDS windows and the a-trous taps
@@ -268,6 +269,7 @@ struct Engine {
         if (const char* tm = getenv("ST_TILE_MAP_DENOISE")) tile_map_denoise = (uint32_t)atoi(tm);
         if (const char* nf = getenv("ST_NO_FUSE")) fuse = atoi(nf) == 0;
         if (const char* k = getenv("ST_NO_FUSE_DI_HEAD")) fuse_di_head = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_FUSE_SPATIAL")) fuse_spatial = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* fc = getenv("ST_FUSE_COMPOSE")) fuse_compose = atoi(fc) != 0;
@@ -669,9 +671,15 @@ struct Engine {
             // ... the spatial passes use the denoiser's planes as scratch (passes/di_spatial_resampling.rs binds
             // di_diff_samples / curr_colors / stash), and resolving writes the planes the denoiser reads
             auto do_di_tail = [&] {
-                run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), cur); });
-                run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, cur); });
-                run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), cur); });
+                // the half-resolution grid drops the last tile column when the tile count is odd (`(size + 7) / 8 / (2, 1)`), while
+                // the stand-alone trace pass still visits those pixels: only an even tile count lets one launch cover all three
+                const bool even_tiles = (((a.width + 7u) / 8u) & 1u) == 0u;
+                if (fuse && fuse_spatial && even_tiles) run(KS_DI_SPATIAL_FUSED, {}, [&] { launch_di_spatial_fused(a, seed(SEED_DI_SPATIAL_PICK), seed(SEED_DI_SPATIAL_SAMPLE), cur); });
+                else {
+                    run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), cur); });
+                    run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, cur); });
+                    run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), cur); });
+                }
                 if (fuse && denoise) { run(KS_DI_RESOLVING_REPROJECT, {}, [&] { launch_di_resolving(a, true, cur); }); di_reprojected = true; }
                 else run(KS_DI_RESOLVING, {}, [&] { launch_di_resolving(a, false, cur); });
             };

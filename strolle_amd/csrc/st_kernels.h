@@ -18,7 +18,7 @@ enum KernelSlot {
     KS_COMPOSITION,
     // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
     KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_COMPOSE,
-    KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL,
+    KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL, KS_DI_SPATIAL_FUSED,
     KS_COUNT
 };
 struct KernelInfo { const char* name; float bytes_per_unit; bool half; };
@@ -39,6 +39,7 @@ inline const KernelInfo& kernel_info(int slot) {
         {"denoise_wavelet+composition", 84.f + 112.f, false},
         {"gi_reprojection+gi_temporal", 176.f + 272.f, false},
         {"di_sampling+di_temporal", 68.f + 176.f, false},
+        {"di_spatial_pick+trace+sample", 128.f + 2.f * 48.f + 192.f, true},  // per cell: the trace pass covers both of its pixels
     };
     return k[slot];
 }
@@ -60,6 +61,7 @@ void launch_di_sampling_temporal(const KArgs& a, uint32_t seed_sampling, uint32_
 void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s);
 void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_di_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_sample, hipStream_t s);  // pick + trace + sample per cell
 void launch_di_resolving(const KArgs& a, bool fuse_denoise_reproject, hipStream_t s);
 // ReSTIR GI
 void launch_gi_reprojection(const KArgs& a, hipStream_t s);
