@@ -215,11 +215,11 @@ void launch_gi_temporal(const KArgs& a, uint32_t seed, bool fuse_reprojection, h
 }
 
 // ---------------------------------------------------------------- gi_spatial_resampling.rs:3-168 (pick)
-__global__ ST_KERNEL_BOUNDS void k_gi_spatial_pick(const KArgs a, uint32_t seed) {
-    U2 gid;
-    if (!resolve_gid(a, true, &gid)) return;
-    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
-    if (!owns_pixel(a, lhs_pos)) return;
+// SpatialRecords as in k_di.hip: what this stage left in the scratch planes (gi_d0 / gi_d1) for the cell's two pixels; every
+// exit of the GI pick stage writes both gi_d1 texels
+struct GiSpatialRecords { bool wrote_d0; float4 a0, a1, b0, b1; };
+ST_D GiSpatialRecords gi_spatial_pick_cell(const KArgs& a, uint32_t seed, U2 gid, U2 lhs_pos) {
+    GiSpatialRecords out; out.wrote_d0 = false; out.a0 = out.a1 = out.b0 = out.b1 = f4z();
     const uint32_t n = a.width * a.height;
     const uint32_t lhs_idx = screen_to_idx(a, lhs_pos);
     WhiteNoise wn = white_noise(seed, lhs_pos);
@@ -228,7 +228,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_spatial_pick(const KArgs a, uint32_t seed)
     const U2 buf_pos_a = u2(gid.x * 2u, gid.y), buf_pos_b = u2(gid.x * 2u + 1u, gid.y);
     const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
     const GiReservoir lhs = gi_read(reservoirs, lhs_idx, n);
-    if (!hit_some(lhs_hit) || lhs.m == 0.0f) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return; }
+    if (!hit_some(lhs_hit) || lhs.m == 0.0f) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return out; }
     GiReservoir rhs = gi_empty();
     uint32_t rhs_nth = 0u, rhs_idx = 0u;
     Hit rhs_hit = hit_zero();
@@ -251,32 +251,36 @@ __global__ ST_KERNEL_BOUNDS void k_gi_spatial_pick(const KArgs a, uint32_t seed)
         rhs_jacobian = clampf(rhs_jacobian, 1.0f / 3.0f, 3.0f);
         break;
     }
-    if (rhs.m == 0.0f || !hit_some(rhs_hit)) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return; }
+    if (rhs.m == 0.0f || !hit_some(rhs_hit)) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return out; }
     const float lhs_rhs_pdf = gi_pdf(lhs.s, rhs_hit);
     const float rhs_lhs_pdf = gi_pdf(rhs.s, lhs_hit);
     const Ray ray_a = lhs_rhs_pdf > 0.0f ? gi_sample_ray(lhs.s, rhs_hit.point) : zero_ray();
     const Ray ray_b = rhs_lhs_pdf > 0.0f ? gi_sample_ray(rhs.s, lhs_hit.point) : zero_ray();
-    tex_write(buf_d0, a, buf_pos_a, f4(ray_a.origin, ray_a.len));
-    const V2 ea = normal_encode(ray_a.dir);
-    tex_write(buf_d1, a, buf_pos_a, make_float4(ea.x, ea.y, b2f(rhs_idx + 1u), rhs_jacobian));
-    tex_write(buf_d0, a, buf_pos_b, f4(ray_b.origin, ray_b.len));
-    const V2 eb = normal_encode(ray_b.dir);
-    tex_write(buf_d1, a, buf_pos_b, make_float4(eb.x, eb.y, lhs_rhs_pdf, rhs_lhs_pdf));
+    const V2 ea = normal_encode(ray_a.dir), eb = normal_encode(ray_b.dir);
+    out.wrote_d0 = true;
+    out.a0 = f4(ray_a.origin, ray_a.len); out.a1 = make_float4(ea.x, ea.y, b2f(rhs_idx + 1u), rhs_jacobian);
+    out.b0 = f4(ray_b.origin, ray_b.len); out.b1 = make_float4(eb.x, eb.y, lhs_rhs_pdf, rhs_lhs_pdf);
+    tex_write(buf_d0, a, buf_pos_a, out.a0); tex_write(buf_d1, a, buf_pos_a, out.a1);
+    tex_write(buf_d0, a, buf_pos_b, out.b0); tex_write(buf_d1, a, buf_pos_b, out.b1);
+    return out;
+}
+__global__ ST_KERNEL_BOUNDS void k_gi_spatial_pick(const KArgs a, uint32_t seed) {
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    if (!owns_pixel(a, lhs_pos)) return;
+    (void)gi_spatial_pick_cell(a, seed, gid, lhs_pos);
 }
 void launch_gi_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_spatial_pick, true, s, a, seed); }
 
 // ---------------------------------------------------------------- gi_spatial_resampling.rs:232-314 (sample)
-__global__ ST_KERNEL_BOUNDS void k_gi_spatial_sample(const KArgs a, uint32_t seed) {
-    U2 gid;
-    if (!resolve_gid(a, true, &gid)) return;
-    const U2 pos = resolve_checkerboard_alt(gid, a.frame / 2u);
-    if (!owns_pixel(a, pos)) return;
+// d0 / d1: the trace stage's texels (gi_d2) for the cell's two pixels
+ST_D void gi_spatial_sample_cell(const KArgs& a, uint32_t seed, U2 gid, U2 pos, float4 d0, float4 d1) {
     const uint32_t n = a.width * a.height;
     const uint32_t idx = screen_to_idx(a, pos);
     WhiteNoise wn = white_noise(seed, pos);
     const float4* in_res = a.gi_res[1];
     float4* out_res = a.gi_res[2];
-    const float4 d0 = tex_read(a.gi_d2, a, u2(gid.x * 2u, gid.y)), d1 = tex_read(a.gi_d2, a, u2(gid.x * 2u + 1u, gid.y));
     const float lhs_rhs_vis = d0.x;
     const uint32_t rhs_idx = f2b(d0.y);
     const float rhs_jacobian = d0.z;
@@ -303,7 +307,50 @@ __global__ ST_KERNEL_BOUNDS void k_gi_spatial_sample(const KArgs a, uint32_t see
     const U2 other = resolve_checkerboard(gid, a.frame / 2u);
     if (contains_u(a, other)) { const uint32_t oi = screen_to_idx(a, other); gi_write(out_res, oi, gi_read(in_res, oi, n)); }
 }
+__global__ ST_KERNEL_BOUNDS void k_gi_spatial_sample(const KArgs a, uint32_t seed) {
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    if (!owns_pixel(a, pos)) return;
+    gi_spatial_sample_cell(a, seed, gid, pos, tex_read(a.gi_d2, a, u2(gid.x * 2u, gid.y)), tex_read(a.gi_d2, a, u2(gid.x * 2u + 1u, gid.y)));
+}
 void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_spatial_sample, true, s, a, seed); }
+
+// gi_spatial_resampling.rs pick + trace + sample for one 2x1 cell in one launch (see k_di_spatial_fused, k_di.hip)
+template <class SE>
+__global__ ST_KERNEL_BOUNDS void k_gi_spatial_fused(const KArgs a, uint32_t seed_pick, uint32_t seed_sample) {
+    __shared__ SE lds[kStackWords];
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
+    const bool own_lhs = owns_pixel(a, lhs_pos);
+    GiSpatialRecords rec; rec.wrote_d0 = false; rec.a0 = rec.a1 = rec.b0 = rec.b1 = f4z();
+    if (own_lhs) rec = gi_spatial_pick_cell(a, seed_pick, gid, lhs_pos);  // writes both gi_d1 texels on every path
+    float4 vis[2];
+    uint32_t rays = 0u; unsigned long long bytes = 0ull;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const U2 pos = u2(gid.x * 2u + (uint32_t)k, gid.y);
+        if (!owns_pixel(a, pos)) { vis[k] = tex_read(a.gi_d2, a, pos); continue; }
+        const float4 r1 = own_lhs ? (k == 0 ? rec.a1 : rec.b1) : tex_read(a.gi_d1, a, pos);
+        if (is_zero(r1)) vis[k] = f4z();
+        else {
+            const float4 r0 = rec.wrote_d0 ? (k == 0 ? rec.a0 : rec.b0) : tex_read(a.gi_d0, a, pos);
+            Ray ray = make_ray(xyz(r0), normal_decode(v2(r1.x, r1.y)));
+            ray.len = r0.w;
+            uint32_t used_ = 0u;
+            const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+            rays += 1u; bytes += used_;
+            vis[k] = make_float4(occluded ? 0.0f : 1.0f, r1.z, r1.w, 0.0f);
+        }
+        tex_write(a.gi_d2, a, pos, vis[k]);
+    }
+    if (rays) count_rays_n(a.ray_counter, rays, bytes);
+    if (own_lhs) gi_spatial_sample_cell(a, seed_sample, gid, lhs_pos, vis[0], vis[1]);
+}
+void launch_gi_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_sample, hipStream_t s) {
+    ST_LAUNCH_TRACE(k_gi_spatial_fused, true, s, a, seed_pick, seed_sample);
+}
 
 // ---------------------------------------------------------------- gi_preview_resampling.rs:3-138
 // RESOLVE (second preview pass only): gi_resolving.rs and, if `reproject`, the GI half of frame_denoising.rs::reproject run

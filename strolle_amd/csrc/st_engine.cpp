@@ -701,9 +701,13 @@ struct Engine {
                     if (c.frame % 2u == 0u) sampling();
                     temporal();
                     if (c.frame % 2u == 1u) {
-                        run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), cur); });
-                        run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, cur); });
-                        run(KS_GI_SPATIAL_SAMPLE, {}, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), cur); });
+                        if (fuse && fuse_spatial && ((((a.width + 7u) / 8u) & 1u) == 0u))
+                            run(KS_GI_SPATIAL_FUSED, {}, [&] { launch_gi_spatial_fused(a, seed(SEED_GI_SPATIAL_PICK), seed(SEED_GI_SPATIAL_SAMPLE), cur); });
+                        else {
+                            run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), cur); });
+                            run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, cur); });
+                            run(KS_GI_SPATIAL_SAMPLE, {}, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), cur); });
+                        }
                     }
                 } else {
                     sampling();

@@ -18,7 +18,7 @@ enum KernelSlot {
     KS_COMPOSITION,
     // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
     KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_COMPOSE,
-    KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL, KS_DI_SPATIAL_FUSED,
+    KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL, KS_DI_SPATIAL_FUSED, KS_GI_SPATIAL_FUSED,
     KS_COUNT
 };
 struct KernelInfo { const char* name; float bytes_per_unit; bool half; };
@@ -40,6 +40,7 @@ inline const KernelInfo& kernel_info(int slot) {
         {"gi_reprojection+gi_temporal", 176.f + 272.f, false},
         {"di_sampling+di_temporal", 68.f + 176.f, false},
         {"di_spatial_pick+trace+sample", 128.f + 2.f * 48.f + 192.f, true},  // per cell: the trace pass covers both of its pixels
+        {"gi_spatial_pick+trace+sample", 160.f + 2.f * 48.f + 352.f, true},
     };
     return k[slot];
 }
@@ -71,6 +72,7 @@ void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_gi_temporal(const KArgs& a, uint32_t seed, bool fuse_reprojection, hipStream_t s);
 void launch_gi_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
 void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
+void launch_gi_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_sample, hipStream_t s);  // pick + trace + sample per cell
 void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s);
 void launch_gi_resolving(const KArgs& a, uint32_t source, hipStream_t s);
 // second preview pass + gi_resolving (+ the GI half of denoise reproject) in one launch
