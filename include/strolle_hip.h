@@ -176,7 +176,8 @@ typedef struct StKernelProfile {
     char name[48];
     uint32_t launches;
     float total_ms;
-    double algorithmic_bytes; /* summed over launches */
+    double algorithmic_bytes; /* summed over launches: screen-space bytes (B) + traversal bytes (A), SURVEY.md 8(d) */
+    double traversal_bytes;   /* the A part alone: the reference's used_memory counter summed over the kernel's rays */
 } StKernelProfile;
 int st_profile_enable(StEngine* e, int enabled);
 int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* count, int reset);

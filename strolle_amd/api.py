@@ -50,7 +50,7 @@ class StCamera(C.Structure):
 
 
 class StKernelProfile(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_float), ("algorithmic_bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_float), ("algorithmic_bytes", C.c_double), ("traversal_bytes", C.c_double)]
 
 
 assert C.sizeof(StMeshTriangle) == 144 and C.sizeof(StMaterial) == 88 and C.sizeof(StLight) == 52 and C.sizeof(StCamera) == 160
@@ -422,5 +422,5 @@ class Engine(EngineBase):
     def profile_read(self, reset: bool = True):
         arr = (StKernelProfile * 48)(); n = C.c_size_t()
         self._check(self._b.profile_read(self._h, arr, 48, C.byref(n), 1 if reset else 0))
-        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, algorithmic_bytes=arr[i].algorithmic_bytes)
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, algorithmic_bytes=arr[i].algorithmic_bytes, traversal_bytes=arr[i].traversal_bytes)
                 for i in range(n.value)]

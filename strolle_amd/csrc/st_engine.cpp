@@ -1080,7 +1080,10 @@ int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* 
         { const int rc2 = read_counters(c, host); if (rc2) return rc2; }
         for (int i = 0; i < KS_COUNT; i++) {
             const unsigned long long total = host[2 * i + 1];
-            if (total >= c.profiled_traversal_bytes[i]) en->profile_totals[i].algorithmic_bytes += (double)(total - c.profiled_traversal_bytes[i]);
+            if (total >= c.profiled_traversal_bytes[i]) {
+                en->profile_totals[i].algorithmic_bytes += (double)(total - c.profiled_traversal_bytes[i]);
+                en->profile_totals[i].traversal_bytes += (double)(total - c.profiled_traversal_bytes[i]);
+            }
             c.profiled_traversal_bytes[i] = total;
         }
     }
