@@ -429,14 +429,14 @@ struct Engine {
     std::vector<Vec4> transmittance_lut, scattering_lut, sky_lut;  // passes/atmosphere.rs:78-110
     bool atmosphere_initialized = false; bool sky_known = false; float known_sun_altitude = 0.0f;
     std::vector<uint8_t> atlas; uint32_t atlas_w = 0, atlas_h = 0;
-    // images: one linear RGBA8 atlas, 2048 texels wide, shelf-packed in insertion order and grown in 256-row steps.
+    // images: one linear RGBA8 atlas, 8192 texels wide (the reference's extent), shelf-packed in insertion order and grown in 256-row steps.
     // (The reference allocates rectangles in an 8192^2 atlas with `guillotiere` 0.6.2, images.rs:54-127 — a crate that is
     //  not under /root/reference; rectangle placement is therefore this project's own and only the *sampling* result,
     //  which is placement-independent up to clamp-at-rect-border bleeding, is comparable.)
     struct ImageRec { uint32_t x, y, w, h; };
     std::map<uint64_t, ImageRec> images; uint32_t shelf_x = 0, shelf_y = 0, shelf_h = 0;
     bool insert_image(uint64_t id, uint32_t w, uint32_t h, const uint8_t* rgba) {
-        const uint32_t kAtlasW = 2048, kAtlasMaxH = 8192;
+        const uint32_t kAtlasW = 8192, kAtlasMaxH = 8192;
         if (w > kAtlasW) return false;
         ImageRec rec;
         auto it = images.find(id);

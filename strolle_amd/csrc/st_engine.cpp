@@ -886,7 +886,7 @@ int st_material_remove(StEngine* e, StHandle id) {
 int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) {
     ST_REQUIRE(e && rgba && w && h && id, "bad image");
     Engine* en = E(e);
-    const uint32_t kAtlasW = 2048, kAtlasMaxH = 8192;
+    const uint32_t kAtlasW = 8192, kAtlasMaxH = 8192;  // the reference's atlas extent (images.rs:54-60)
     if (w > kAtlasW) return fail(ST_ERR_ATLAS_FULL, "image wider than the atlas");
     auto it = en->images.find(id);
     Engine::ImageRec rec;
