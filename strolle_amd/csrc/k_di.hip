@@ -8,8 +8,9 @@
 namespace st {
 
 // ---------------------------------------------------------------- di_sampling.rs:3-94
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_di_sampling(const KArgs a, uint32_t seed) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_di_sampling(const KArgs a_in, uint32_t seed) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -32,8 +33,9 @@ void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNC
 // di_sampling.rs + di_temporal_resampling.rs in one launch: temporal resampling reads the sampling pass's reservoir only at
 // its own pixel, so it takes it from registers (through the store/load codec, which is not the identity) and the pixel's hit
 // is rebuilt once; di_res[1] ends with the temporal result exactly as it does after the two separate passes.
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_di_sampling_temporal(const KArgs a, uint32_t seed_sampling, uint32_t seed_temporal) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_di_sampling_temporal(const KArgs a_in, uint32_t seed_sampling, uint32_t seed_temporal) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -141,8 +143,9 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_sample(const KArgs a, uint32_t see
 // to each other only through that cell's two texels of the scratch planes, so the records and visibilities travel in
 // registers; they are still stored (later passes, or the next frame's stale reads, must find what the reference leaves
 // there), and a texel the pick stage did not write is read back from the plane, stale contents included.
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a, uint32_t seed_pick, uint32_t seed_sample) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a_in, uint32_t seed_pick, uint32_t seed_sample) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
@@ -180,8 +183,9 @@ void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST
 // ---------------------------------------------------------------- di_resolving.rs:3-119
 // REPROJECT: the DI half of frame_denoising.rs::reproject is appended (it reads only this pixel's fresh diffuse sample
 // plus previous-frame planes).
-template <bool REPROJECT, class SE>
-__global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a) {
+template <bool LDS_SCENE, bool REPROJECT, class SE>
+__global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -215,9 +219,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a) {
     if (REPROJECT) denoise_reproject_finish(a, pos, diff, history, a.di_diff_curr_colors, a.di_diff_moments);
 }
 void launch_di_resolving(const KArgs& a, bool reproject, hipStream_t s) {
-    const bool small = a.bvh_len < 65536u;
-    if (reproject) { if (small) ST_LAUNCH((k_di_resolving<true, uint16_t>), false, s, a); else ST_LAUNCH((k_di_resolving<true, uint32_t>), false, s, a); }
-    else { if (small) ST_LAUNCH((k_di_resolving<false, uint16_t>), false, s, a); else ST_LAUNCH((k_di_resolving<false, uint32_t>), false, s, a); }
+    if (reproject) ST_LAUNCH_TRACE_B(k_di_resolving, true, false, s, a); else ST_LAUNCH_TRACE_B(k_di_resolving, false, false, s, a);
 }
 
 }  // namespace st

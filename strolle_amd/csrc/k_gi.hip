@@ -24,8 +24,9 @@ void launch_gi_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_gi_repr
 ST_D bool frame_is_gi_tracing(uint32_t frame) { return frame % 6u < 4u; }  // frame.rs:19-21
 
 // ---------------------------------------------------------------- gi_sampling_a.rs:3-122
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a, uint32_t seed) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a_in, uint32_t seed) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 gid;
@@ -72,8 +73,9 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a, uint32_t seed) {
 void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_a, true, s, a, seed); }
 
 // ---------------------------------------------------------------- gi_sampling_b.rs:3-235
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a, uint32_t seed) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 gid;
@@ -317,8 +319,9 @@ __global__ ST_KERNEL_BOUNDS void k_gi_spatial_sample(const KArgs a, uint32_t see
 void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_spatial_sample, true, s, a, seed); }
 
 // gi_spatial_resampling.rs pick + trace + sample for one 2x1 cell in one launch (see k_di_spatial_fused, k_di.hip)
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_gi_spatial_fused(const KArgs a, uint32_t seed_pick, uint32_t seed_sample) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_gi_spatial_fused(const KArgs a_in, uint32_t seed_pick, uint32_t seed_sample) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;

@@ -24,8 +24,9 @@ ST_D V3 heatmap_gradient(float progress) {
     }
     return c3;
 }
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_bvh_heatmap(const KArgs a) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_bvh_heatmap(const KArgs a_in) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -39,8 +40,9 @@ __global__ ST_KERNEL_BOUNDS void k_bvh_heatmap(const KArgs a) {
 void launch_bvh_heatmap(const KArgs& a, hipStream_t s) { ST_LAUNCH_TRACE(k_bvh_heatmap, false, s, a); }
 
 // ---------------------------------------------------------------- ref_tracing.rs:3-60
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a, uint32_t depth) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a_in, uint32_t depth) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -63,8 +65,9 @@ __global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a, uint32_t depth) {
 void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s) { ST_LAUNCH_TRACE(k_ref_tracing, false, s, a, depth); }
 
 // ---------------------------------------------------------------- ref_shading.rs:3-177
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a, uint32_t seed, uint32_t depth) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, uint32_t depth) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -151,8 +154,9 @@ ST_D void frame_reprojection_pixel(const KArgs& a, U2 pos, const Surface& surfac
 
 // REPROJECT: frame_reprojection runs in the same kernel (it needs this pixel's new surface + velocity and the PREVIOUS
 // frame's surfaces only).
-template <bool REPROJECT, class SE>
-__global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a) {
+template <bool LDS_SCENE, bool REPROJECT, class SE>
+__global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;
@@ -195,9 +199,7 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a) {
     }
 }
 void launch_prim_visibility(const KArgs& a, bool reproject, hipStream_t s) {
-    const bool small = a.bvh_len < 65536u;
-    if (reproject) { if (small) ST_LAUNCH((k_prim_visibility<true, uint16_t>), false, s, a); else ST_LAUNCH((k_prim_visibility<true, uint32_t>), false, s, a); }
-    else { if (small) ST_LAUNCH((k_prim_visibility<false, uint16_t>), false, s, a); else ST_LAUNCH((k_prim_visibility<false, uint32_t>), false, s, a); }
+    if (reproject) ST_LAUNCH_TRACE_B(k_prim_visibility, true, false, s, a); else ST_LAUNCH_TRACE_B(k_prim_visibility, false, false, s, a);
 }
 
 // Tabulates the byte decodes of st_device.h with the routines themselves (one launch at engine creation).
@@ -220,8 +222,9 @@ __global__ ST_KERNEL_BOUNDS void k_frame_reprojection(const KArgs a) {
 void launch_frame_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_frame_reprojection, false, s, a); }
 
 // ---------------------------------------------------------------- {di,gi}_spatial_resampling.rs `trace`
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_spatial_trace(const KArgs a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2) {
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_spatial_trace(const KArgs a_in, const float4* buf_d0, const float4* buf_d1, float4* buf_d2) {
+    ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
     U2 pos;

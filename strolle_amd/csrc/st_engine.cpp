@@ -583,6 +583,7 @@ struct Engine {
         a.materials = static_cast<const GpuMaterial*>(d_materials.ptr); a.material_base_packed = getenv("ST_NO_PACKED_BASE") ? nullptr : static_cast<const uint32_t*>(d_material_base_packed.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
         a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr); a.byte_luts = static_cast<const float*>(d_byte_luts.ptr);
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
+        a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
         a.bvh_len = (uint32_t)bvh_stream.size(); a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
         a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
         a.sun_dir[0] = sun_dir_.x; a.sun_dir[1] = sun_dir_.y; a.sun_dir[2] = sun_dir_.z;
