@@ -37,10 +37,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SLOT_SYMBOLS = {
     "denoise_wavelet": ["denoise_wavelet_lds<1>", "denoise_wavelet_lds<2>", "denoise_wavelet_lds<4>", "denoise_wavelet<false>"],
     "denoise_wavelet+composition": ["denoise_wavelet<true>"],
-    "di_spatial_trace": ["spatial_trace<u16>"], "gi_spatial_trace": ["spatial_trace<u16>"],
-    "prim_visibility+frame_reprojection": ["prim_visibility<true,u16>"], "di_resolving+denoise_reproject": ["di_resolving<true,u16>"],
+    # tracing kernels: <LDS scene, [REPROJECT,] stack entry>; whichever instance the scene selected
+    "prim_visibility+frame_reprojection": ["prim_visibility<true,true,u16>", "prim_visibility<false,true,u16>", "prim_visibility<false,true,u32>"],
+    "di_sampling+di_temporal": ["di_sampling_temporal<true,u16>", "di_sampling_temporal<false,u16>", "di_sampling_temporal<false,u32>"],
+    "di_spatial_pick+trace+sample": ["di_spatial_fused<true,u16>", "di_spatial_fused<false,u16>", "di_spatial_fused<false,u32>"],
+    "di_resolving+denoise_reproject": ["di_resolving<true,true,u16>", "di_resolving<false,true,u16>", "di_resolving<false,true,u32>"],
+    "gi_spatial_pick+trace+sample": ["gi_spatial_fused<true,u16>", "gi_spatial_fused<false,u16>", "gi_spatial_fused<false,u32>"],
+    "gi_sampling_a": ["gi_sampling_a<true,u16>", "gi_sampling_a<false,u16>", "gi_sampling_a<false,u32>"],
+    "gi_sampling_b": ["gi_sampling_b<true,u16>", "gi_sampling_b<false,u16>", "gi_sampling_b<false,u32>"],
+    "gi_reprojection+gi_temporal": ["gi_temporal<true>"], "gi_temporal": ["gi_temporal<false>"],
     "gi_preview": ["gi_preview<false>"], "gi_preview+gi_resolving+denoise_reproject": ["gi_preview<true>"],
-    "di_sampling": ["di_sampling<u16>"], "gi_sampling_a": ["gi_sampling_a<u16>"], "gi_sampling_b": ["gi_sampling_b<u16>"],
 }
 
 
@@ -86,7 +92,7 @@ def main():
             # aggregates under the profiler slot names bench.py reports (a slot may launch several symbols)
             for slot, syms in SLOT_SYMBOLS.items():
                 have = [by[s] for s in syms if s in by]
-                if len(have) < 2:
+                if len(have) < 1 or (len(have) == 1 and len(syms) == 1):
                     continue
                 calls = sum(int(r["Calls"]) for r in have)
                 total = sum(float(r["TotalDurationNs"]) for r in have)
