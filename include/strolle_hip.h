@@ -14,9 +14,11 @@
  * joins it into the caller's stream before the frame's last kernel. Frames may be enqueued
  * back to back without host synchronisation. st_tick uploads on the stream it was given
  * and returns after they have landed.
- * Environment switches (read once per engine): ST_NO_OVERLAP=1 single stream, ST_NO_FUSE=1
- * one launch per reference pass, ST_TILE_MAP=0|1|2 block->tile mapping, ST_FUSE_COMPOSE=1,
- * ST_COMPACT=1 compacted shadow-ray kernel, ST_TICK_TIMING=1 host refresh timing on stderr.
+ * Environment switches (read once per engine; every combination renders the same bits): ST_NO_OVERLAP=1
+ * single stream; ST_NO_FUSE=1 one launch per reference pass (ST_NO_FUSE_SPATIAL / _DI_HEAD /
+ * _GI_REPROJECTION=1 undo one fusion); ST_TILE_MAP=0|1|2 and ST_TILE_MAP_DENOISE block->tile mapping;
+ * ST_FUSE_COMPOSE=1; ST_COMPACT=1 compacted shadow-ray kernel; ST_NO_PACKED_BASE=1; ST_TICK_TIMING=1
+ * host refresh timing on stderr.
  */
 #ifndef STROLLE_HIP_H
 #define STROLLE_HIP_H
