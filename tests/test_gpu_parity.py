@@ -523,3 +523,50 @@ print("compact ok")
 """ % (root, os.path.join(root, "tests"))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, ST_COMPACT="1"))
     assert res.returncode == 0 and "compact ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+def test_random_edit_history_renders_bit_exact(seed):
+    """Random scene edits between frames (instances moved / removed / re-added, lights added / removed, materials
+    replaced) with every plane compared after every frame: the temporal passes meet killed and remapped light slots, fresh
+    and vanished geometry, reused triangle and transform slots."""
+    torch = _torch()
+    from strolle_amd import Instance, Light, Material
+    rng = np.random.default_rng(seed)
+    size = (112, 72)
+    prod, orac = Engine(device=0), OracleEngine()
+    for e in (prod, orac):
+        scenes.build_random_soup(e, 900, seed=seed, n_lights=3); e.set_seed(seed)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    cp, co = prod.create_camera(desc), orac.create_camera(desc)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    lights = {1, 2, 3}; present = {1, 2, 3, 4}
+
+    def xform():
+        a = float(rng.uniform(0, 1.0))
+        r = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32) * np.float32(rng.uniform(0.8, 1.2))
+        return np.concatenate([r, rng.uniform(-0.2, 0.2, (3, 1)).astype(np.float32)], axis=1)
+
+    for frame in range(16):
+        for _ in range(int(rng.integers(0, 3))):
+            op = int(rng.integers(0, 5))
+            if op == 0:
+                h = int(rng.integers(1, 5)); inst = Instance(h, int(rng.integers(1, 5)), xform()); present.add(h)
+                for e in (prod, orac): e.insert_instance(h, inst)
+            elif op == 1 and len(present) > 1:
+                h = int(rng.choice(sorted(present))); present.discard(h)
+                for e in (prod, orac): e.remove_instance(h)
+            elif op == 2:
+                h = int(rng.integers(1, 7)); lights.add(h)
+                l = Light.point(rng.uniform(-1.5, 1.5, 3).tolist(), 0.1, rng.uniform(0.3, 2.0, 3).tolist(), 20.0)
+                for e in (prod, orac): e.insert_light(h, l)
+            elif op == 3 and len(lights) > 1:
+                h = int(rng.choice(sorted(lights))); lights.discard(h)
+                for e in (prod, orac): e.remove_light(h)
+            elif op == 4:
+                h = int(rng.integers(1, 5))
+                m = Material(base_color=rng.uniform(0.1, 0.9, 3).tolist() + [1.0], perceptual_roughness=float(rng.uniform(0.2, 1.0)), metallic=float(rng.uniform(0, 0.9)))
+                for e in (prod, orac): e.insert_material(h, m)
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"seed {seed} frame {frame}")
