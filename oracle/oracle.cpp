@@ -163,6 +163,33 @@ void or_probe_math(int op, const float* x, const float* y, float* out, size_t n)
         }
     }
 }
+// GGX normal distribution D(n.h, roughness) and the specular sampler's (direction, pdf) for unit-test integration
+float or_probe_ggx_d(float n_dot_h, float roughness) { return ggx_distribution(n_dot_h, roughness); }
+// samples the layered BRDF n times for a surface with normal +Y, view direction v3: out = n x {dir.xyz, pdf, radiance.xyz}
+void or_probe_brdf_samples(uint32_t seed, float metallic, float roughness, const float* base3, const float* v3, float* out7, size_t n) {
+    GBufferEntry g;
+    g.base_color = Vec4(base3[0], base3[1], base3[2], 1.0f); g.normal = Vec3(0.0f, 1.0f, 0.0f); g.metallic = metallic; g.emissive = Vec3();
+    g.roughness = roughness; g.reflectance = 0.5f; g.depth = 1.0f;
+    WhiteNoise wn{seed};
+    const Vec3 v(v3[0], v3[1], v3[2]);
+    for (size_t i = 0; i < n; i++) {
+        const BrdfSample s = layered_brdf_sample(g, wn, v);
+        float* o = out7 + 7 * i;
+        o[0] = s.dir.x; o[1] = s.dir.y; o[2] = s.dir.z; o[3] = s.pdf; o[4] = s.radiance.x; o[5] = s.radiance.y; o[6] = s.radiance.z;
+    }
+}
+// weighted reservoir sampling (reservoir.rs:24-45): streams `k` candidates with the given weights through Reservoir::update
+// `trials` times (one RNG stream) and counts which candidate each trial keeps; also returns the last trial's (m, w)
+void or_probe_reservoir_counts(uint32_t seed, const float* weights, uint32_t k, uint32_t trials, uint32_t* counts, float* m_w) {
+    WhiteNoise wn{seed};
+    for (uint32_t i = 0; i < k; i++) counts[i] = 0;
+    for (uint32_t t = 0; t < trials; t++) {
+        Reservoir<uint32_t> r; r.sample = 0xffffffffu;
+        for (uint32_t i = 0; i < k; i++) r.update(wn, i, weights[i]);
+        if (r.sample < k) counts[r.sample]++;
+        m_w[0] = r.m; m_w[1] = r.w;
+    }
+}
 uint32_t or_probe_pass_seed(uint64_t base, uint32_t frame, uint32_t pass_id) { return pass_seed(base, frame, pass_id); }
 // white noise stream: n samples of sample_int() for (seed, x, y)
 void or_probe_white_noise(uint32_t seed, uint32_t x, uint32_t y, uint32_t* out, size_t n) {
