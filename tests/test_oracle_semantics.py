@@ -188,3 +188,32 @@ def test_weighted_reservoir_sampling_proportions():
     sigma = np.sqrt(p * (1 - p) / trials)
     assert (np.abs(counts / trials - p) <= 5 * sigma + 1e-9).all(), (counts / trials, p)
     assert mw[0] == len(w) and abs(mw[1] - w.sum()) < 1e-5
+
+
+def test_octahedral_normal_codec_round_trip():
+    """normal.rs:9-34: decode(encode(n)) returns n (to float32 rounding) for unit vectors in every octant, and the encoded
+    pair stays inside [0, 1]^2."""
+    lib = oracle_lib()
+    lib.or_probe_normal_codec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    n = rng.standard_normal((2000, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.concatenate([n, np.eye(3, dtype=np.float32), -np.eye(3, dtype=np.float32)])
+    worst = 0.0
+    for v in n:
+        v = np.ascontiguousarray(v); enc = np.zeros(2, np.float32); dec = np.zeros(3, np.float32)
+        lib.or_probe_normal_codec(v.ctypes.data, enc.ctypes.data, dec.ctypes.data)
+        assert (enc >= 0).all() and (enc <= 1).all()
+        worst = max(worst, float(np.abs(dec - v).max()))
+        assert abs(np.linalg.norm(dec) - 1.0) < 1e-5
+    assert worst < 2e-6, worst
+
+
+def test_pass_seeds_are_distinct_and_stable():
+    """The seam that replaces thread_rng (DESIGN.md deviation 1): per-(frame, pass) seeds from one base seed."""
+    lib = oracle_lib()
+    lib.or_probe_pass_seed.restype = C.c_uint32
+    lib.or_probe_pass_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    seen = {lib.or_probe_pass_seed(0, f, p) for f in range(64) for p in range(24)}
+    assert len(seen) == 64 * 24, "collisions among the first 64 frames x 24 passes"
+    assert lib.or_probe_pass_seed(0, 3, 5) == lib.or_probe_pass_seed(0, 3, 5) != lib.or_probe_pass_seed(1, 3, 5)
