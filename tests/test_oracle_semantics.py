@@ -164,7 +164,8 @@ def test_brdf_sampler_pdfs_match_the_sampled_distribution():
     lib.or_probe_brdf_samples(9, 1.0, 0.4, base.ctypes.data, v.ctypes.data, out.ctypes.data, n)
     d, pdf = out[:, :3].astype(np.float64), out[:, 3].astype(np.float64)
     ok = pdf > 0
-    h = d + v[None, :].astype(np.float64); h /= np.linalg.norm(h, axis=1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        h = d + v[None, :].astype(np.float64); h /= np.linalg.norm(h, axis=1, keepdims=True)
     # E over samples of [ 1/pdf * D(n.h) (n.h) / (4 h.v) ] restricted to reflected directions == measure of the sampled set of h == 1
     lib.or_probe_ggx_d.restype = C.c_float; lib.or_probe_ggx_d.argtypes = [C.c_float, C.c_float]
     a = max(0.4, 0.089 * 0.089)
