@@ -164,6 +164,10 @@ int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
  * 144-B layout, 2 lights (112 B), 3 materials (112 B). Works on host-only engines. */
 int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written);
 int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame);
+/* The last BVH refresh (strolle/src/bvh/builder.rs:35-124 reuses subtrees whose primitives did not change): how many
+ * primitives the tree holds and how many of them came over inside subtrees copied from the previous tree. The
+ * uploaded stream is the one a from-scratch build of the same primitives gives, reuse or not. */
+int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused);
 /* Atmosphere LUTs as generated on the device (strolle-shaders/src/atmosphere): what = 0 transmittance 256x64,
  * 1 multi-scattering 32x32, 2 sky 256x256; RGBA32F texels holding f16-rounded values (the reference stores Rgba16Float). */
 int st_debug_read_lut(StEngine* e, int what, float* out, size_t capacity_floats, size_t* written_floats);

@@ -250,6 +250,7 @@ class _Binding:
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
+            self.debug_bvh_refresh = fn("debug_bvh_refresh", [vp, P(u64), P(u64)])
             self.profile_enable = fn("profile_enable", [vp, i32])
             self.profile_read = fn("profile_read", [vp, P(StKernelProfile), sz, P(sz), i32])
             self.last_error = getattr(lib, prefix + "last_error"); self.last_error.restype = C.c_char_p; self.last_error.argtypes = []
@@ -387,6 +388,12 @@ class EngineBase:
         lc, fr = C.c_uint32(), C.c_uint32()
         self._check(self._b.debug_world(self._h, C.byref(lc), C.byref(fr)))
         return lc.value, fr.value
+
+    def bvh_refresh(self):
+        """(primitives in the tree, primitives that arrived inside subtrees reused from the previous tree)."""
+        n, r = C.c_uint64(), C.c_uint64()
+        self._check(self._b.debug_bvh_refresh(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
 
 _lib_cache = {}

@@ -33,7 +33,7 @@ struct Aabb {
     void grow(const Aabb& o) { grow(o.lo); grow(o.hi); }  // utils/bounding_box.rs:83-88: min then max, literally
 };
 
-struct BuildPrim { uint32_t triangle_id, material_id; V3 center; Aabb bounds; };
+struct BuildPrim { uint32_t triangle_id, material_id; V3 center; Aabb bounds; uint64_t key = 0; };  // key: hash of the other fields (BvhBuild::run)
 
 inline float axis_of(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 
@@ -97,9 +97,17 @@ class TaskPool {
 
 class BvhBuild {
   public:
-    struct Node { bool internal = false; Aabb bounds; uint32_t begin = 0, end = 0, left = 0, right = 0; };
+    // lhash / rhash: order-sensitive hashes of the primitives the split sent left / right, in the order the partition examined
+    // them (as builder.rs:205-232 hashes them) — equal hashes mean the child received the same primitives in the same order,
+    // hence would be rebuilt into the same subtree. count: nodes in this subtree (set by finish_counts()).
+    struct Node { bool internal = false; Aabb bounds; uint32_t begin = 0, end = 0, left = 0, right = 0; uint64_t lhash = 0, rhash = 0; uint32_t count = 1; };
     std::vector<Node> nodes;
     std::vector<BuildPrim> prims;
+
+    // Call before refilling `prims` for the next build: keeps the finished tree and its primitive order so that subtrees whose
+    // input did not change are copied instead of rebuilt (builder.rs:233-301). The outcome equals a fresh build.
+    void begin_refresh() { prev_nodes_.swap(nodes); prev_prims_.swap(prims); nodes.clear(); prims.clear(); }
+    size_t reused_primitives() const { return reused_.load(); }
 
     // Builds the tree over `prims` (reordered in place). The result — node contents, child links, primitive order — is a
     // function of the primitive array alone: a node's split reads only its own [begin, end) range, which its parent's
@@ -113,23 +121,28 @@ class BvhBuild {
         nodes[0] = Node(); nodes[0].begin = 0; nodes[0].end = n;
         next_node.store(1u);
         overflow.store(false);
+        reused_.store(0);
+        for (uint32_t i = 0; i < n; i++) prims[i].key = prim_key(prims[i]);
+        const uint32_t root_ghost = (!prev_nodes_.empty() && !prev_prims_.empty() && prev_nodes_[0].internal) ? 0u : kNoGhost;
         unsigned threads = max_threads ? max_threads : std::thread::hardware_concurrency();
         if (threads > 16u) threads = 16u;
         threads_ = (n < kParallelMin || threads < 2u) ? 1u : threads;
         spawn_min_ = n / (threads_ * 8u) > kSpawnMin ? n / (threads_ * 8u) : kSpawnMin;  // ~8 tasks per thread and level at the top
-        if (threads_ == 1u) { std::vector<uint32_t> stack{0u}; build_subtree(stack, nullptr); }
+        if (threads_ == 1u) { std::vector<Work> stack{{0u, root_ghost}}; build_subtree(stack, nullptr); }
         else {
             TaskPool pool(threads_);
-            pool.push([this, &pool] { std::vector<uint32_t> stack{0u}; build_subtree(stack, &pool); });
+            pool.push([this, &pool, root_ghost] { std::vector<Work> stack{{0u, root_ghost}}; build_subtree(stack, &pool); });
             pool.finish();
         }
         if (overflow.load()) {  // cannot happen for finite inputs; keep the sequential answer if it ever does
             nodes.clear(); nodes.resize(1); nodes.reserve(4u * (size_t)n + 16u);
             nodes[0] = Node(); nodes[0].begin = 0; nodes[0].end = n;
             run_sequential_growing();
+            finish_counts();
             return;
         }
         nodes.resize(next_node.load());
+        finish_counts();
     }
 
     // DFS flatten. `blend[m]` != 0 marks AlphaMode::Blend materials (leaf flag bit 1).
@@ -155,6 +168,8 @@ class BvhBuild {
     static constexpr int kBins = 12;
     static constexpr uint32_t kParallelBinMin = 16384;  // nodes at least this large bin their primitives on all threads
     mutable unsigned threads_ = 1;
+    std::vector<Node> prev_nodes_; std::vector<BuildPrim> prev_prims_;  // the previous build (begin_refresh)
+    std::atomic<size_t> reused_{0};
     uint32_t spawn_min_ = kSpawnMin;
     static constexpr uint32_t kParallelMin = 4096;  // below this a build takes < 3 ms and threads cost more than they save
 #ifndef ST_BVH_SPAWN_MIN
@@ -168,45 +183,116 @@ class BvhBuild {
     std::atomic<bool>& overflow = counters_.overflow;
 
     // Splits node `id` if the SAH says so (builder.rs:60-181). Returns true and the two children when it did.
-    bool split(uint32_t id, uint32_t* left, uint32_t* right, TaskPool* pool) {
+    static constexpr uint32_t kNoGhost = 0xffffffffu;
+    struct Work { uint32_t id, ghost; };  // ghost: the node that stood at this place in the previous tree, if any
+    static uint64_t prim_key(const BuildPrim& p) {
+        uint64_t h = 1469598103934665603ull;
+        const uint32_t w[11] = {p.triangle_id, p.material_id, f2b(p.center.x), f2b(p.center.y), f2b(p.center.z), f2b(p.bounds.lo.x), f2b(p.bounds.lo.y),
+                                f2b(p.bounds.lo.z), f2b(p.bounds.hi.x), f2b(p.bounds.hi.y), f2b(p.bounds.hi.z)};
+        for (uint32_t x : w) { h ^= x; h *= 1099511628211ull; }
+        return h;
+    }
+    static uint64_t mix(uint64_t h, uint64_t key) { return (h ^ key) * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull; }
+
+    // Copies the previous tree's subtree `old_id` (and the final order of its primitives) to the range starting at `begin`.
+    uint32_t copy_subtree(uint32_t old_id, uint32_t begin) {
+        const Node& old_root = prev_nodes_[old_id];
+        const uint32_t cnt = old_root.count, n_prims = old_root.end - old_root.begin;
+        const uint32_t base = next_node.fetch_add(cnt);
+        if ((size_t)base + cnt > nodes.size()) { overflow.store(true); return kNoGhost; }
+        for (uint32_t i = 0; i < n_prims; i++) prims[begin + i] = prev_prims_[old_root.begin + i];
+        const int64_t shift = (int64_t)begin - (int64_t)old_root.begin;
+        uint32_t next = base;
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{old_id, next++}};  // (old node, its new index)
+        while (!stack.empty()) {
+            const uint32_t o = stack.back().first, nw = stack.back().second;
+            stack.pop_back();
+            Node c = prev_nodes_[o];
+            c.begin = (uint32_t)((int64_t)c.begin + shift); c.end = (uint32_t)((int64_t)c.end + shift);
+            if (c.internal) {
+                const uint32_t l = next++, r = next++;
+                stack.push_back({c.right, r}); stack.push_back({c.left, l});
+                c.left = l; c.right = r;
+            }
+            nodes[nw] = c;
+        }
+        reused_.fetch_add(n_prims);
+        return base;
+    }
+
+    // Splits node `w.id` if the SAH says so (builder.rs:60-181). Children whose primitives (and their order) equal those of the
+    // previous tree's child at the same place are copied from it; the others are returned as further work.
+    int split(Work w, Work* out, TaskPool* pool) {
+        const uint32_t id = w.id;
         int axis; float split_at, split_cost;
-        if (!best_plane(nodes[id], &axis, &split_at, &split_cost, pool)) return false;
+        if (!best_plane(nodes[id], &axis, &split_at, &split_cost, pool)) return 0;
         const float leaf_cost = (float)(nodes[id].end - nodes[id].begin) * nodes[id].bounds.half_area();
-        if (!(split_cost < leaf_cost)) return false;
+        if (!(split_cost < leaf_cost)) return 0;
         const uint32_t begin = nodes[id].begin, end = nodes[id].end;
         int64_t i = 0, j = (int64_t)(end - begin) - 1;
         Aabb lb, rb;
+        uint64_t lh = 0x243f6a8885a308d3ull, rh = 0x13198a2e03707344ull;
         BuildPrim* p = prims.data() + begin;
         while (i <= j) {
             const BuildPrim cur = p[i];
-            if (axis_of(cur.center, axis) < split_at) { lb.grow(cur.bounds); i++; }
-            else { const BuildPrim t = p[i]; p[i] = p[j]; p[j] = t; rb.grow(cur.bounds); j--; }
+            if (axis_of(cur.center, axis) < split_at) { lb.grow(cur.bounds); lh = mix(lh, cur.key); i++; }
+            else { const BuildPrim t = p[i]; p[i] = p[j]; p[j] = t; rb.grow(cur.bounds); rh = mix(rh, cur.key); j--; }
         }
-        const uint32_t li = next_node.fetch_add(2u);
-        if ((size_t)li + 2u > nodes.size()) { overflow.store(true); return false; }
-        const uint32_t ri = li + 1u;
-        Node l, r;
-        l.bounds = lb; l.begin = begin; l.end = begin + (uint32_t)i;
-        r.bounds = rb; r.begin = begin + (uint32_t)i; r.end = end;
-        nodes[li] = l; nodes[ri] = r;
-        nodes[id].internal = true; nodes[id].left = li; nodes[id].right = ri;
-        *left = li; *right = ri;
-        return true;
+        const uint32_t pivot = begin + (uint32_t)i;
+        const Node* ghost = (w.ghost != kNoGhost && prev_nodes_[w.ghost].internal) ? &prev_nodes_[w.ghost] : nullptr;
+        uint32_t child[2]; bool reused[2] = {false, false};
+        const uint32_t cb[2] = {begin, pivot}, ce[2] = {pivot, end};
+        const uint64_t hs[2] = {lh, rh};
+        for (int k = 0; k < 2; k++) {
+            if (!ghost) continue;
+            const uint32_t g = k == 0 ? ghost->left : ghost->right;
+            const uint64_t gh = k == 0 ? ghost->lhash : ghost->rhash;
+            if (gh == hs[k] && prev_nodes_[g].end - prev_nodes_[g].begin == ce[k] - cb[k]) {
+                const uint32_t at = copy_subtree(g, cb[k]);
+                if (at == kNoGhost) return 0;
+                child[k] = at; reused[k] = true;
+            }
+        }
+        uint32_t fresh = 0;
+        for (int k = 0; k < 2; k++) fresh += reused[k] ? 0u : 1u;
+        uint32_t li = 0;
+        if (fresh) {
+            li = next_node.fetch_add(fresh);
+            if ((size_t)li + fresh > nodes.size()) { overflow.store(true); return 0; }
+        }
+        int n_out = 0;
+        for (int k = 0; k < 2; k++) {
+            if (reused[k]) continue;
+            Node c; c.bounds = k == 0 ? lb : rb; c.begin = cb[k]; c.end = ce[k];
+            child[k] = li++;
+            nodes[child[k]] = c;
+            out[n_out++] = Work{child[k], ghost ? (k == 0 ? ghost->left : ghost->right) : kNoGhost};
+        }
+        Node& me = nodes[id];
+        me.internal = true; me.left = child[0]; me.right = child[1]; me.lhash = lh; me.rhash = rh;
+        return n_out;
     }
 
     // Builds every node reachable from `stack`; with a pool, large children become tasks of their own.
-    void build_subtree(std::vector<uint32_t>& stack, TaskPool* pool) {
+    void build_subtree(std::vector<Work>& stack, TaskPool* pool) {
         while (!stack.empty()) {
-            const uint32_t id = stack.back();
+            const Work w = stack.back();
             stack.pop_back();
-            uint32_t c[2];
-            if (!split(id, &c[0], &c[1], pool)) continue;
-            for (int k = 0; k < 2; k++) {
-                if (pool && nodes[c[k]].end - nodes[c[k]].begin >= spawn_min_) {
-                    const uint32_t child = c[k];
-                    pool->push([this, pool, child] { std::vector<uint32_t> st{child}; build_subtree(st, pool); });
+            Work c[2];
+            const int n = split(w, c, pool);
+            for (int k = 0; k < n; k++) {
+                if (pool && nodes[c[k].id].end - nodes[c[k].id].begin >= spawn_min_) {
+                    const Work child = c[k];
+                    pool->push([this, pool, child] { std::vector<Work> st{child}; build_subtree(st, pool); });
                 } else stack.push_back(c[k]);
             }
+        }
+    }
+    // subtree sizes (children always have larger indices than their parent)
+    void finish_counts() {
+        for (size_t i = nodes.size(); i-- > 0;) {
+            Node& n = nodes[i];
+            n.count = n.internal ? 1u + nodes[n.left].count + nodes[n.right].count : 1u;
         }
     }
 

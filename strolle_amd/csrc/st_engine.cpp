@@ -452,7 +452,7 @@ struct Engine {
                 for (int k = 0; k < 2; k++) { x[4 * k] = f4(src[k]->x, 0.0f); x[4 * k + 1] = f4(src[k]->y, 0.0f); x[4 * k + 2] = f4(src[k]->z, 0.0f); x[4 * k + 3] = f4(src[k]->t, 0.0f); }
             }
             const auto t1 = now();
-            bvh.prims.clear();
+            bvh.begin_refresh();  // keeps the previous tree: unchanged subtrees are copied, not rebuilt (same result as a fresh build)
             for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
             const auto t2 = now();
             bvh.run();
@@ -461,7 +461,7 @@ struct Engine {
             for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
             bvh.flatten(blend, bvh_stream);
             const auto t4 = now();
-            if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size());
+            if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles, %zu reused)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size(), bvh.reused_primitives());
             scene_changed = true;
         }
         light_count = next_light_id;
@@ -1062,6 +1062,12 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
 int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame) {
     ST_REQUIRE(e && light_count && next_frame, "null argument");
     *light_count = E(e)->light_count; *next_frame = E(e)->frame;
+    return ST_OK;
+}
+
+int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused) {
+    ST_REQUIRE(e && primitives && reused, "null argument");
+    *primitives = E(e)->bvh.prims.size(); *reused = E(e)->bvh.reused_primitives();
     return ST_OK;
 }
 

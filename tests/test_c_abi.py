@@ -109,6 +109,37 @@ def test_instance_update_and_removal_equal_oracle():
         assert_bits_equal(prod.read_scene(what), orac.read_scene(what), f"scene buffer {what} after edits")
 
 
+def test_bvh_refresh_reuses_unchanged_subtrees_and_equals_a_fresh_build():
+    """strolle/src/bvh/builder.rs:35-124: a refresh keeps the subtrees whose primitives did not change. Here the reused tree
+    must be the tree a from-scratch build gives (the oracle engine rebuilds from scratch every tick), and moving one small
+    instance of the dungeon must leave most primitives inside reused subtrees."""
+    from strolle_amd import Instance
+    npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
+    moved = 8                                  # dungeon mesh/instance handle 1+7: six triangles
+    material = 1 + int(npz["material_7"])
+    x = np.ascontiguousarray(npz["xform_7"].reshape(4, 3).T, np.float32)
+    prod, orac = Engine(device=-1), OracleEngine()
+    for e in (prod, orac):
+        scenes.build_dungeon(e)
+        e.tick()
+    n0, r0 = prod.bvh_refresh()
+    assert n0 == 8393 and r0 == 0, "the first build has nothing to reuse"
+    for k in range(3):
+        x = x.copy(); x[1, 3] += np.float32(0.125)
+        for e in (prod, orac):
+            e.insert_instance(moved, Instance(moved, material, x))
+            e.tick()
+        assert_bits_equal(prod.read_scene(0), orac.read_scene(0), f"BVH stream after move {k}")
+        n, r = prod.bvh_refresh()
+        assert n == n0 and r > n // 2, f"move {k}: {r} of {n} primitives reused"
+    for e in (prod, orac):                     # removing it: fewer primitives, the rest still largely reusable
+        e.remove_instance(moved)
+        e.tick()
+    assert_bits_equal(prod.read_scene(0), orac.read_scene(0), "BVH stream after the removal")
+    n, r = prod.bvh_refresh()
+    assert n == n0 - 6 and r > n // 2
+
+
 def test_gpu_calls_fail_loudly_without_a_device():
     prod = Engine(device=-1)
     scenes.build_cornell(prod)
