@@ -40,7 +40,10 @@ enum StStatus {
     ST_ERR_UNKNOWN_CAMERA = 3,   /* reference: panic "camera does not exist" (camera_controllers.rs:21-34) */
     ST_ERR_EMPTY_MESH = 4,       /* reference: assert "contains no triangles" (triangles.rs:50-53) */
     ST_ERR_HIP = 5,              /* a HIP runtime call failed; see st_last_error() */
-    ST_ERR_ATLAS_FULL = 6        /* reference: warn + drop (images.rs:71-79) */
+    ST_ERR_ATLAS_FULL = 6,       /* reference: warn + drop (images.rs:71-79) */
+    ST_ERR_IO = 7,               /* scene ingest: a file could not be read */
+    ST_ERR_PARSE = 8,            /* scene ingest: malformed glTF / GLB / PNG; st_last_error() says where */
+    ST_ERR_UNSUPPORTED = 9       /* scene ingest: valid file using something this loader does not read (JPEG, Draco, ...) */
 };
 
 /* strolle/src/mesh_triangle.rs:6-33 — object-space triangle */
@@ -171,6 +174,35 @@ int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused);
 /* Atmosphere LUTs as generated on the device (strolle-shaders/src/atmosphere): what = 0 transmittance 256x64,
  * 1 multi-scattering 32x32, 2 sky 256x256; RGBA32F texels holding f16-rounded values (the reference stores Rgba16Float). */
 int st_debug_read_lut(StEngine* e, int what, float* out, size_t capacity_floats, size_t* written_floats);
+
+/* ---- scene ingest. In the reference this step is Bevy's glTF loader plus bevy-strolle's
+ * stages (bevy-strolle/src/stages/prepare.rs:20-122 meshes, :124-180 materials, :182-260 images; extract.rs instances);
+ * here it is a convenience layered on the entry points above and nothing else. One mesh + instance per triangle-list
+ * primitive of the default scene, numbered in depth-first node order: mesh / instance handle = first_handle + i,
+ * material handle = first_handle + material index, image handle = first_image_handle + image index. Materials follow
+ * prepare.rs:132-175 (Opaque forces alpha 1, Mask becomes Blend with alpha 0/1, reflectance 0.5, ior 1). PNG textures
+ * are decoded here (all colour types and bit depths, Adam7 too); JPEG, Draco and sparse accessors give
+ * ST_ERR_UNSUPPORTED. Host-only work: valid on host-only engines. */
+enum { ST_GLTF_OVERRIDE_REFLECTANCE = 1, ST_GLTF_OVERRIDE_PERCEPTUAL_ROUGHNESS = 2 };
+typedef struct StGltfOptions {
+    StHandle first_handle;        /* default 1 */
+    StHandle first_image_handle;  /* default 1000 */
+    uint32_t override_mask;       /* ST_GLTF_OVERRIDE_*: replace that field of every material (demo.rs:254-258 does this) */
+    float reflectance;
+    float perceptual_roughness;
+    uint32_t subdivide;           /* k: every triangle is split into 4^k by midpoint subdivision (synthetic scaling), k <= 6 */
+} StGltfOptions;
+typedef struct StGltfSummary {
+    uint32_t meshes, triangles, materials, images;
+    uint32_t images_dropped;      /* did not fit the atlas: the reference warns and drops them (images.rs:71-79) */
+    uint32_t primitives_skipped;  /* points, lines, strips, fans, or primitives without a single triangle */
+} StGltfSummary;
+/* options == NULL: the defaults above; summary may be NULL. External buffers / images are read relative to the file. */
+int st_scene_load_gltf(StEngine* e, const char* path, const StGltfOptions* options, StGltfSummary* summary);
+int st_scene_load_gltf_memory(StEngine* e, const void* bytes, size_t size, const char* base_dir, const StGltfOptions* options, StGltfSummary* summary);
+/* PNG -> RGBA8 (straight alpha; 16-bit samples keep their high byte), the decoder the loader uses. out_rgba == NULL
+ * only reports the size. */
+int st_decode_png(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height);
 
 /* Per-kernel timing (HIP events recorded around every launch on the launch stream).
  * st_profile_read returns, per kernel slot i < *count: name, launches, total milliseconds,

@@ -53,6 +53,16 @@ class StKernelProfile(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_float), ("algorithmic_bytes", C.c_double), ("traversal_bytes", C.c_double)]
 
 
+class StGltfOptions(C.Structure):
+    _fields_ = [("first_handle", C.c_uint64), ("first_image_handle", C.c_uint64), ("override_mask", C.c_uint32), ("reflectance", C.c_float),
+                ("perceptual_roughness", C.c_float), ("subdivide", C.c_uint32)]
+
+
+class StGltfSummary(C.Structure):
+    _fields_ = [("meshes", C.c_uint32), ("triangles", C.c_uint32), ("materials", C.c_uint32), ("images", C.c_uint32), ("images_dropped", C.c_uint32),
+                ("primitives_skipped", C.c_uint32)]
+
+
 assert C.sizeof(StMeshTriangle) == 144 and C.sizeof(StMaterial) == 88 and C.sizeof(StLight) == 52 and C.sizeof(StCamera) == 160
 
 
@@ -251,13 +261,17 @@ class _Binding:
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
             self.debug_bvh_refresh = fn("debug_bvh_refresh", [vp, P(u64), P(u64)])
+            self.scene_load_gltf = fn("scene_load_gltf", [vp, C.c_char_p, P(StGltfOptions), P(StGltfSummary)])
+            self.scene_load_gltf_memory = fn("scene_load_gltf_memory", [vp, vp, sz, C.c_char_p, P(StGltfOptions), P(StGltfSummary)])
+            self.decode_png = fn("decode_png", [vp, sz, vp, sz, P(u32), P(u32)])
             self.profile_enable = fn("profile_enable", [vp, i32])
             self.profile_read = fn("profile_read", [vp, P(StKernelProfile), sz, P(sz), i32])
             self.last_error = getattr(lib, prefix + "last_error"); self.last_error.restype = C.c_char_p; self.last_error.argtypes = []
 
 
 _STATUS = {1: "invalid argument", 2: "no HIP device (host-only engine or HIP unavailable)", 3: "camera does not exist",
-           4: "mesh contains no triangles", 5: "HIP runtime error", 6: "no more space in the atlas"}
+           4: "mesh contains no triangles", 5: "HIP runtime error", 6: "no more space in the atlas", 7: "file could not be read",
+           8: "malformed scene file", 9: "unsupported scene file feature"}
 
 
 class EngineBase:
@@ -275,7 +289,7 @@ class EngineBase:
             detail = ""
             if self._b.has_device:
                 msg = self._b.last_error()
-                detail = f": {msg.decode()}" if msg else ""
+                detail = f": {msg.decode(errors='replace')}" if msg else ""
             raise StrolleError(f"{_STATUS.get(status, 'error')} (status {status}){detail}")
 
     def close(self):
@@ -423,6 +437,23 @@ class Engine(EngineBase):
     def set_camera_rows(self, handle: int, y0: int, y1: int):
         self._check(self._b.camera_set_rows(self._h, handle, y0, y1))
 
+    def load_gltf(self, source, base_dir: Optional[str] = None, first_handle: int = 1, first_image_handle: int = 1000,
+                  reflectance: Optional[float] = None, perceptual_roughness: Optional[float] = None, subdivide: int = 0) -> dict:
+        """st_scene_load_gltf: `source` is a path to a .gltf / .glb file, or the file's bytes (external buffers and images
+        are then read relative to `base_dir`). Returns the loader's summary."""
+        opt = StGltfOptions(first_handle, first_image_handle, 0, 0.0, 0.0, subdivide)
+        if reflectance is not None:
+            opt.override_mask |= 1; opt.reflectance = reflectance
+        if perceptual_roughness is not None:
+            opt.override_mask |= 2; opt.perceptual_roughness = perceptual_roughness
+        out = StGltfSummary()
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            data = bytes(source)
+            self._check(self._b.scene_load_gltf_memory(self._h, data, len(data), base_dir.encode() if base_dir else None, C.byref(opt), C.byref(out)))
+        else:
+            self._check(self._b.scene_load_gltf(self._h, os.fsencode(source), C.byref(opt), C.byref(out)))
+        return {name: getattr(out, name) for name, _ in StGltfSummary._fields_}
+
     def profile_enable(self, enabled: bool):
         self._check(self._b.profile_enable(self._h, 1 if enabled else 0))
 
@@ -431,3 +462,21 @@ class Engine(EngineBase):
         self._check(self._b.profile_read(self._h, arr, 48, C.byref(n), 1 if reset else 0))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, algorithmic_bytes=arr[i].algorithmic_bytes, traversal_bytes=arr[i].traversal_bytes)
                 for i in range(n.value)]
+
+
+def decode_png(data: bytes) -> np.ndarray:
+    """st_decode_png: PNG bytes -> [h, w, 4] uint8 (the decoder st_scene_load_gltf uses for textures)."""
+    lib = load_library()
+    fn = lib.st_decode_png
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    w, h = C.c_uint32(), C.c_uint32()
+    data = bytes(data)
+    status = fn(data, len(data), None, 0, C.byref(w), C.byref(h))
+    if status == 0:
+        out = np.empty((h.value, w.value, 4), np.uint8)
+        status = fn(data, len(data), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h))
+    if status != 0:
+        lib.st_last_error.restype = C.c_char_p
+        raise StrolleError(f"{_STATUS.get(status, 'error')} (status {status}): {lib.st_last_error().decode(errors='replace')}")
+    return out

@@ -826,6 +826,8 @@ static Engine* E(StEngine* e) { return reinterpret_cast<Engine*>(e); }
 extern "C" {
 
 const char* st_last_error(void) { return g_last_error.c_str(); }
+// st_gltf.cpp reports through the same thread-local message
+extern "C" int st_internal_fail(int status, const char* message) { return fail(status, message ? message : ""); }
 
 int st_engine_create(int device_ordinal, StEngine** out) {
     ST_REQUIRE(out, "out is NULL");
