@@ -167,6 +167,8 @@ int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
  * 144-B layout, 2 lights (112 B), 3 materials (112 B). Works on host-only engines. */
 int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written);
 int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame);
+/* Where an image sits in the 8192-wide atlas: x, y, width, height in texels (images.rs:115-124 `lookup`). */
+int st_debug_image_rect(StEngine* e, StHandle id, uint32_t out_xywh[4]);
 /* The last BVH refresh (strolle/src/bvh/builder.rs:35-124 reuses subtrees whose primitives did not change): how many
  * primitives the tree holds and how many of them came over inside subtrees copied from the previous tree. The
  * uploaded stream is the one a from-scratch build of the same primitives gives, reuse or not. */

@@ -429,30 +429,82 @@ struct Engine {
     std::vector<Vec4> transmittance_lut, scattering_lut, sky_lut;  // passes/atmosphere.rs:78-110
     bool atmosphere_initialized = false; bool sky_known = false; float known_sun_altitude = 0.0f;
     std::vector<uint8_t> atlas; uint32_t atlas_w = 0, atlas_h = 0;
-    // images: one linear RGBA8 atlas, 8192 texels wide (the reference's extent), shelf-packed in insertion order and grown in 256-row steps.
-    // (The reference allocates rectangles in an 8192^2 atlas with `guillotiere` 0.6.2, images.rs:54-127 — a crate that is
-    //  not under /root/reference; rectangle placement is therefore this project's own and only the *sampling* result,
-    //  which is placement-independent up to clamp-at-rect-border bleeding, is comparable.)
+    // images: one linear RGBA8 atlas of the reference's extent (8192 x 8192, images.rs:28-29), grown in 256-row steps.
+    // (The reference places rectangles with `guillotiere` 0.6.2, images.rs:54-127 — a crate that is not under
+    //  /root/reference; rectangle placement is therefore this project's own policy, restated here independently of the
+    //  product's st_atlas.h: shelves stacked bottom to top; a request goes to the closed shelf of least height that has a
+    //  wide enough free span (leftmost such span), else to the top shelf, which may still grow taller, else to a new shelf
+    //  on top; released spans merge with free neighbours and empty top shelves disappear. Only the *sampling* result, which
+    //  does not depend on placement up to clamp-at-rect-border bleeding, is comparable with the reference.)
     struct ImageRec { uint32_t x, y, w, h; };
-    std::map<uint64_t, ImageRec> images; uint32_t shelf_x = 0, shelf_y = 0, shelf_h = 0;
+    struct AtlasPacker {
+        struct Row { uint32_t y, h; std::map<uint32_t, uint32_t> holes; /* x0 -> x1 */ };
+        std::vector<Row> rows;
+        static constexpr uint32_t W = 8192, H = 8192;
+        static bool hole_for(const Row& r, uint32_t w, uint32_t* x0) {
+            for (auto& kv : r.holes) if (kv.second - kv.first >= w) { *x0 = kv.first; return true; }
+            return false;
+        }
+        static void carve(Row& r, uint32_t x0, uint32_t w) {
+            const uint32_t x1 = r.holes[x0];
+            r.holes.erase(x0);
+            if (x0 + w < x1) r.holes[x0 + w] = x1;
+        }
+        bool place(uint32_t w, uint32_t h, ImageRec* out) {
+            if (!w || !h || w > W || h > H) return false;
+            Row* chosen = nullptr; uint32_t x0 = 0, x = 0;
+            for (size_t i = 0; i + 1 < rows.size(); i++)
+                if (rows[i].h >= h && (!chosen || rows[i].h < chosen->h) && hole_for(rows[i], w, &x)) { chosen = &rows[i]; x0 = x; }
+            if (!chosen && !rows.empty() && hole_for(rows.back(), w, &x) && rows.back().y + std::max(rows.back().h, h) <= H) {
+                chosen = &rows.back(); x0 = x; chosen->h = std::max(chosen->h, h);
+            }
+            if (!chosen) {
+                const uint64_t y = rows.empty() ? 0 : (uint64_t)rows.back().y + rows.back().h;
+                if (y + h > H) return false;
+                rows.push_back(Row{(uint32_t)y, h, {{0u, W}}});
+                chosen = &rows.back(); x0 = 0;
+            }
+            carve(*chosen, x0, w);
+            *out = ImageRec{x0, chosen->y, w, h};
+            return true;
+        }
+        void give_back(const ImageRec& r) {
+            for (Row& row : rows) {
+                if (row.y != r.y) continue;
+                uint32_t a = r.x, b = r.x + r.w;
+                auto next = row.holes.find(b);
+                if (next != row.holes.end()) { b = next->second; row.holes.erase(next); }
+                for (auto it = row.holes.begin(); it != row.holes.end(); ++it)
+                    if (it->second == a) { a = it->first; row.holes.erase(it); break; }
+                row.holes[a] = b;
+                break;
+            }
+            while (!rows.empty() && rows.back().holes.size() == 1 && rows.back().holes.begin()->first == 0 && rows.back().holes.begin()->second == W) rows.pop_back();
+        }
+    };
+    std::map<uint64_t, ImageRec> images; AtlasPacker packer;
     bool insert_image(uint64_t id, uint32_t w, uint32_t h, const uint8_t* rgba) {
-        const uint32_t kAtlasW = 8192, kAtlasMaxH = 8192;
-        if (w > kAtlasW) return false;
+        if (w > AtlasPacker::W) return false;
         ImageRec rec;
         auto it = images.find(id);
-        if (it != images.end() && it->second.w == w && it->second.h == h) rec = it->second;
+        if (it != images.end() && it->second.w == w && it->second.h == h) rec = it->second;  // images.rs:61-63
         else {
-            if (shelf_x + w > kAtlasW) { shelf_x = 0; shelf_y += shelf_h; shelf_h = 0; }
-            if (shelf_y + h > kAtlasMaxH) return false;
-            rec = ImageRec{shelf_x, shelf_y, w, h};
-            shelf_x += w; shelf_h = std::max(shelf_h, h);
+            if (it != images.end()) { packer.give_back(it->second); images.erase(it); materials_dirty = true; }  // images.rs:64-66
+            if (!packer.place(w, h, &rec)) return false;  // images.rs:71-79: warn and drop
         }
-        if (atlas_w == 0) atlas_w = kAtlasW;
+        if (atlas_w == 0) atlas_w = AtlasPacker::W;
         if (rec.y + h > atlas_h) { atlas_h = (rec.y + h + 255u) & ~255u; atlas.resize((size_t)atlas_w * atlas_h * 4, 0); }
         for (uint32_t y = 0; y < h; y++) std::memcpy(&atlas[((size_t)(rec.y + y) * atlas_w + rec.x) * 4], rgba + (size_t)y * w * 4, (size_t)w * 4);
         images[id] = rec;
         materials_dirty = true;
         return true;
+    }
+    void remove_image(uint64_t id) {  // images.rs:107-113
+        auto it = images.find(id);
+        if (it == images.end()) return;
+        packer.give_back(it->second);
+        images.erase(it);
+        materials_dirty = true;
     }
     std::map<uint64_t, std::unique_ptr<CameraSlot>> cameras; uint64_t next_camera = 0;
 

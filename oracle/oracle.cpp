@@ -44,7 +44,13 @@ int or_material_insert(OrEngine* e, uint64_t id, const ApiMaterial* m) { E(e)->i
 int or_material_has(OrEngine* e, uint64_t id) { return E(e)->material_index.count(id) ? 1 : 0; }
 int or_material_remove(OrEngine* e, uint64_t id) { E(e)->remove_material(id); return 0; }
 int or_image_insert_rgba8(OrEngine* e, uint64_t id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) { return E(e)->insert_image(id, w, h, rgba) ? 0 : 6; }
-int or_image_remove(OrEngine* e, uint64_t id) { E(e)->images.erase(id); E(e)->materials_dirty = true; return 0; }
+int or_image_remove(OrEngine* e, uint64_t id) { E(e)->remove_image(id); return 0; }
+int or_debug_image_rect(OrEngine* e, uint64_t id, uint32_t out[4]) {
+    auto it = E(e)->images.find(id);
+    if (it == E(e)->images.end()) return 1;
+    out[0] = it->second.x; out[1] = it->second.y; out[2] = it->second.w; out[3] = it->second.h;
+    return 0;
+}
 int or_instance_insert(OrEngine* e, uint64_t id, uint64_t mesh, uint64_t material, const float xform[12]) {
     E(e)->insert_instance(id, mesh, material, xform);
     return 0;

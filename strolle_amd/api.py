@@ -257,6 +257,7 @@ class _Binding:
         self.camera_ray_count = fn("camera_ray_count", [vp, u64, P(u64), i32])
         self.debug_read_scene = fn("debug_read_scene", [vp, i32, vp, sz, P(sz)])
         self.debug_world = fn("debug_world", [vp, P(u32), P(u32)])
+        self.debug_image_rect = fn("debug_image_rect", [vp, u64, P(u32)])
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
@@ -402,6 +403,12 @@ class EngineBase:
         lc, fr = C.c_uint32(), C.c_uint32()
         self._check(self._b.debug_world(self._h, C.byref(lc), C.byref(fr)))
         return lc.value, fr.value
+
+    def image_rect(self, handle: int):
+        """(x, y, w, h) of an image in the atlas, in texels."""
+        r = (C.c_uint32 * 4)()
+        self._check(self._b.debug_image_rect(self._h, handle, r))
+        return tuple(r)
 
     def bvh_refresh(self):
         """(primitives in the tree, primitives that arrived inside subtrees reused from the previous tree)."""

@@ -195,29 +195,40 @@ class BvhBuild {
     static uint64_t mix(uint64_t h, uint64_t key) { return (h ^ key) * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull; }
 
     // Copies the previous tree's subtree `old_id` (and the final order of its primitives) to the range starting at `begin`.
-    uint32_t copy_subtree(uint32_t old_id, uint32_t begin) {
+    // The copy is laid out in pre-order — a node, its left subtree, its right subtree — so every node's place follows from
+    // the subtree sizes alone and large subtrees can be copied by other workers at the same time.
+    uint32_t copy_subtree(uint32_t old_id, uint32_t begin, TaskPool* pool) {
         const Node& old_root = prev_nodes_[old_id];
         const uint32_t cnt = old_root.count, n_prims = old_root.end - old_root.begin;
         const uint32_t base = next_node.fetch_add(cnt);
         if ((size_t)base + cnt > nodes.size()) { overflow.store(true); return kNoGhost; }
-        for (uint32_t i = 0; i < n_prims; i++) prims[begin + i] = prev_prims_[old_root.begin + i];
-        const int64_t shift = (int64_t)begin - (int64_t)old_root.begin;
-        uint32_t next = base;
-        std::vector<std::pair<uint32_t, uint32_t>> stack{{old_id, next++}};  // (old node, its new index)
+        reused_.fetch_add(n_prims);
+        copy_nodes(old_id, base, (int64_t)begin - (int64_t)old_root.begin, pool);
+        return base;
+    }
+    void copy_nodes(uint32_t old_id, uint32_t at, int64_t shift, TaskPool* pool) {
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{old_id, at}};  // (old node, its new index)
+        bool first = true;
         while (!stack.empty()) {
             const uint32_t o = stack.back().first, nw = stack.back().second;
             stack.pop_back();
-            Node c = prev_nodes_[o];
+            const Node& src = prev_nodes_[o];
+            if (pool && !first && src.end - src.begin >= spawn_min_) {
+                pool->push([this, o, nw, shift, pool] { copy_nodes(o, nw, shift, pool); });
+                continue;
+            }
+            first = false;
+            Node c = src;
             c.begin = (uint32_t)((int64_t)c.begin + shift); c.end = (uint32_t)((int64_t)c.end + shift);
             if (c.internal) {
-                const uint32_t l = next++, r = next++;
-                stack.push_back({c.right, r}); stack.push_back({c.left, l});
+                const uint32_t l = nw + 1u, r = l + prev_nodes_[src.left].count;
+                stack.push_back({src.right, r}); stack.push_back({src.left, l});
                 c.left = l; c.right = r;
+            } else {
+                for (uint32_t i = src.begin; i < src.end; i++) prims[(uint32_t)((int64_t)i + shift)] = prev_prims_[i];
             }
             nodes[nw] = c;
         }
-        reused_.fetch_add(n_prims);
-        return base;
     }
 
     // Splits node `w.id` if the SAH says so (builder.rs:60-181). Children whose primitives (and their order) equal those of the
@@ -248,7 +259,7 @@ class BvhBuild {
             const uint32_t g = k == 0 ? ghost->left : ghost->right;
             const uint64_t gh = k == 0 ? ghost->lhash : ghost->rhash;
             if (gh == hs[k] && prev_nodes_[g].end - prev_nodes_[g].begin == ce[k] - cb[k]) {
-                const uint32_t at = copy_subtree(g, cb[k]);
+                const uint32_t at = copy_subtree(g, cb[k], pool);
                 if (at == kNoGhost) return 0;
                 child[k] = at; reused[k] = true;
             }

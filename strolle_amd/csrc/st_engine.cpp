@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/strolle_hip.h"
+#include "st_atlas.h"
 #include "st_bvh.h"
 #include "st_kernels.h"
 
@@ -219,10 +220,11 @@ struct Engine {
     BvhBuild bvh;
     bool scene_uploaded = false;
 
-    // images: a single linear RGBA8 atlas; rect allocation = shelf packing (images.rs uses guillotiere)
+    // images: a single linear RGBA8 atlas of the reference's extent (images.rs:28-29); rectangles from st_atlas.h
+    static constexpr uint32_t kAtlasW = 8192, kAtlasMaxH = 8192;
     uint32_t atlas_w = 0, atlas_h = 0; std::vector<uint8_t> atlas; bool atlas_dirty = false;
     struct ImageRec { uint32_t x, y, w, h; };
-    std::unordered_map<uint64_t, ImageRec> images; uint32_t shelf_x = 0, shelf_y = 0, shelf_h = 0;
+    std::unordered_map<uint64_t, ImageRec> images; AtlasShelves atlas_rects{kAtlasW, kAtlasMaxH};
 
     // lights (lights.rs): slot 0 is the sun
     std::vector<GpuLight> light_buffer; std::map<int64_t, uint32_t> light_slot;
@@ -889,16 +891,19 @@ int st_material_remove(StEngine* e, StHandle id) {
 int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) {
     ST_REQUIRE(e && rgba && w && h && id, "bad image");
     Engine* en = E(e);
-    const uint32_t kAtlasW = 8192, kAtlasMaxH = 8192;  // the reference's atlas extent (images.rs:54-60)
+    constexpr uint32_t kAtlasW = Engine::kAtlasW;
     if (w > kAtlasW) return fail(ST_ERR_ATLAS_FULL, "image wider than the atlas");
     auto it = en->images.find(id);
     Engine::ImageRec rec;
-    if (it != en->images.end() && it->second.w == w && it->second.h == h) rec = it->second;
+    if (it != en->images.end() && it->second.w == w && it->second.h == h) rec = it->second;  // same size: rewritten in place (images.rs:61-63)
     else {
-        if (en->shelf_x + w > kAtlasW) { en->shelf_x = 0; en->shelf_y += en->shelf_h; en->shelf_h = 0; }
-        if (en->shelf_y + h > kAtlasMaxH) return fail(ST_ERR_ATLAS_FULL, "no more space in the atlas");
-        rec = {en->shelf_x, en->shelf_y, w, h};
-        en->shelf_x += w; en->shelf_h = std::max(en->shelf_h, h);
+        if (it != en->images.end()) {  // another size: the old rectangle is given back first (images.rs:64-66)
+            en->atlas_rects.release(it->second.x, it->second.y, it->second.w);
+            en->images.erase(it);
+            en->materials_dirty = true;
+        }
+        rec = {0, 0, w, h};
+        if (!en->atlas_rects.allocate(w, h, &rec.x, &rec.y)) return fail(ST_ERR_ATLAS_FULL, "no more space in the atlas");
     }
     const uint32_t need_h = rec.y + h;
     if (en->atlas_w == 0) en->atlas_w = kAtlasW;
@@ -912,7 +917,23 @@ int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, cons
     en->atlas_dirty = true; en->materials_dirty = true;
     return ST_OK;
 }
-int st_image_remove(StEngine* e, StHandle id) { ST_REQUIRE(e, "null engine"); E(e)->images.erase(id); E(e)->materials_dirty = true; return ST_OK; }
+int st_image_remove(StEngine* e, StHandle id) {  // images.rs:107-113
+    ST_REQUIRE(e, "null engine");
+    Engine* en = E(e);
+    auto it = en->images.find(id);
+    if (it == en->images.end()) return ST_OK;
+    en->atlas_rects.release(it->second.x, it->second.y, it->second.w);
+    en->images.erase(it);
+    en->materials_dirty = true;
+    return ST_OK;
+}
+int st_debug_image_rect(StEngine* e, StHandle id, uint32_t out_xywh[4]) {
+    ST_REQUIRE(e && out_xywh, "null argument");
+    auto it = E(e)->images.find(id);
+    if (it == E(e)->images.end()) return fail(ST_ERR_INVALID_ARGUMENT, "no such image");
+    out_xywh[0] = it->second.x; out_xywh[1] = it->second.y; out_xywh[2] = it->second.w; out_xywh[3] = it->second.h;
+    return ST_OK;
+}
 
 int st_instance_insert(StEngine* e, StHandle id, StHandle mesh, StHandle material, const float xform[12]) {
     ST_REQUIRE(e && xform, "null argument");

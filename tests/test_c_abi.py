@@ -140,6 +140,51 @@ def test_bvh_refresh_reuses_unchanged_subtrees_and_equals_a_fresh_build():
     assert n == n0 - 6 and r > n // 2
 
 
+def test_atlas_rectangles_are_released_and_reused():
+    """images.rs:54-113: an image that is removed, or comes back with another size, gives its rectangle back. Rectangles of
+    live images never overlap, stay inside the 8192 x 8192 atlas, and churn far beyond the atlas area never runs out of
+    space while little is live. Placement is this project's policy (the reference's comes from the guillotiere crate), so
+    the product is checked against the oracle's independent restatement of that policy."""
+    rng = np.random.default_rng(11)
+    prod, orac = Engine(device=-1), OracleEngine()
+    live = {}
+    inserted_area = 0
+    for step in range(1200):
+        if live and (len(live) >= 40 or rng.random() < 0.35):
+            h = int(rng.choice(sorted(live)))
+            del live[h]
+            for e in (prod, orac): e.remove_image(h)
+        else:
+            h = int(rng.integers(1, 60))     # an id that is live: same size rewrites in place, another size re-allocates
+            w, hh = (int(v) for v in rng.choice([64, 200, 512, 1024], 2))
+            if h in live and rng.random() < 0.5:
+                w, hh = live[h]
+            img = np.full((hh, w, 4), step % 251, np.uint8)
+            for e in (prod, orac): e.insert_image(h, img)
+            live[h] = (w, hh)
+            inserted_area += w * hh
+        if step % 50 == 49 or step == 1199:
+            rects = {h: prod.image_rect(h) for h in live}
+            assert rects == {h: orac.image_rect(h) for h in live}, f"step {step}: product and oracle place images differently"
+            for h, (x, y, w, hh) in rects.items():
+                assert (w, hh) == live[h] and x + w <= 8192 and y + hh <= 8192
+            items = sorted(rects.values())
+            for i, a in enumerate(items):
+                for b in items[i + 1:]:
+                    assert a[0] + a[2] <= b[0] or b[0] + b[2] <= a[0] or a[1] + a[3] <= b[1] or b[1] + b[3] <= a[1], f"step {step}: {a} overlaps {b}"
+    assert inserted_area > 8192 * 8192, "the churn has to exceed what a never-freeing allocator could hold"
+    # a full atlas is reported (the reference warns and drops the image), and space comes back when images go away
+    big = np.zeros((4096, 8192, 4), np.uint8)
+    for h in list(live):
+        for e in (prod, orac): e.remove_image(h)
+    prod.insert_image(1, big); prod.insert_image(2, big)
+    with pytest.raises(StrolleError, match="no more space in the atlas"):
+        prod.insert_image(3, np.zeros((1, 1, 4), np.uint8))
+    prod.remove_image(1)
+    prod.insert_image(3, np.zeros((16, 16, 4), np.uint8))
+    assert prod.image_rect(3) == (0, 0, 16, 16)
+
+
 def test_gpu_calls_fail_loudly_without_a_device():
     prod = Engine(device=-1)
     scenes.build_cornell(prod)
