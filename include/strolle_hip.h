@@ -113,6 +113,12 @@ int st_material_has(StEngine* e, StHandle id);                                  
 int st_material_remove(StEngine* e, StHandle id);                                                /* lib.rs:192 */
 int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t width, uint32_t height, const uint8_t* rgba, int srgb); /* lib.rs:198 */
 int st_image_remove(StEngine* e, StHandle id);                                                   /* lib.rs:211 */
+/* lib.rs:198 with ImageData::Texture{texture, is_dynamic} (image.rs:46-59): the pixels are RGBA8 in device memory,
+ * rows `row_pitch_bytes` apart. Static images are copied into the atlas once, by the next st_tick; dynamic ones by every
+ * st_tick (images.rs:187-213) on the stream st_tick is given — the caller keeps the buffer alive and orders its writes
+ * before that tick. Needs a device engine. */
+int st_image_insert_device_rgba8(StEngine* e, StHandle id, uint32_t width, uint32_t height, const void* device_rgba,
+                                 size_t row_pitch_bytes, int is_dynamic);
 /* xform: glam Affine3A as 12 floats, column-major (x_axis, y_axis, z_axis, translation) */
 int st_instance_insert(StEngine* e, StHandle id, StHandle mesh, StHandle material, const float xform[12]); /* lib.rs:217 */
 int st_instance_remove(StEngine* e, StHandle id);                                                /* lib.rs:226 */

@@ -261,6 +261,7 @@ class _Binding:
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
+            self.image_insert_device_rgba8 = fn("image_insert_device_rgba8", [vp, u64, u32, u32, vp, sz, i32])
             self.debug_bvh_refresh = fn("debug_bvh_refresh", [vp, P(u64), P(u64)])
             self.scene_load_gltf = fn("scene_load_gltf", [vp, C.c_char_p, P(StGltfOptions), P(StGltfSummary)])
             self.scene_load_gltf_memory = fn("scene_load_gltf_memory", [vp, vp, sz, C.c_char_p, P(StGltfOptions), P(StGltfSummary)])
@@ -443,6 +444,10 @@ class Engine(EngineBase):
 
     def set_camera_rows(self, handle: int, y0: int, y1: int):
         self._check(self._b.camera_set_rows(self._h, handle, y0, y1))
+
+    def insert_device_image(self, handle: int, device_ptr: int, width: int, height: int, row_pitch_bytes: int = 0, dynamic: bool = False):
+        """ImageData::Texture: RGBA8 pixels in device memory (e.g. `tensor.data_ptr()` of a [h, w, 4] uint8 CUDA tensor)."""
+        self._check(self._b.image_insert_device_rgba8(self._h, handle, width, height, device_ptr, row_pitch_bytes or width * 4, 1 if dynamic else 0))
 
     def load_gltf(self, source, base_dir: Optional[str] = None, first_handle: int = 1, first_image_handle: int = 1000,
                   reflectance: Optional[float] = None, perceptual_roughness: Optional[float] = None, subdivide: int = 0) -> dict:

@@ -225,6 +225,12 @@ struct Engine {
     uint32_t atlas_w = 0, atlas_h = 0; std::vector<uint8_t> atlas; bool atlas_dirty = false;
     struct ImageRec { uint32_t x, y, w, h; };
     std::unordered_map<uint64_t, ImageRec> images; AtlasShelves atlas_rects{kAtlasW, kAtlasMaxH};
+    // ImageData::Texture (image.rs:46-59): pixels that live in device memory. Static ones are copied into the atlas once
+    // (and mirrored into the host copy, which stays the source of every later re-upload); dynamic ones at every tick
+    // (images.rs:187-213). std::map: copies are issued in handle order.
+    struct DeviceImage { const void* pixels; size_t pitch; bool dynamic, pending; };
+    std::map<uint64_t, DeviceImage> device_images;
+    bool atlas_copy_in_flight = false;  // a tick queued device-to-device atlas copies that the next frame's side stream must wait for
 
     // lights (lights.rs): slot 0 is the sun
     std::vector<GpuLight> light_buffer; std::map<int64_t, uint32_t> light_slot;
@@ -497,6 +503,19 @@ struct Engine {
             }
             bool misc_uploaded = atlas_dirty || blue_noise_dirty;
             if (atlas_dirty) { int rc = d_atlas.upload(atlas.data(), atlas.size(), stream); if (rc) return rc; }
+            for (auto& kv : device_images) {
+                DeviceImage& di = kv.second;
+                if (!di.pending && !di.dynamic) continue;
+                const ImageRec& r = images.at(kv.first);
+                uint8_t* dst = static_cast<uint8_t*>(d_atlas.ptr) + ((size_t)r.y * atlas_w + r.x) * 4;
+                ST_HIP(hipMemcpy2DAsync(dst, (size_t)atlas_w * 4, di.pixels, di.pitch, (size_t)r.w * 4, r.h, hipMemcpyDeviceToDevice, stream));
+                if (!di.dynamic) {  // keep the host copy complete: it is what a later full upload sends
+                    ST_HIP(hipMemcpy2DAsync(&atlas[((size_t)r.y * atlas_w + r.x) * 4], (size_t)atlas_w * 4, di.pixels, di.pitch, (size_t)r.w * 4, r.h, hipMemcpyDeviceToHost, stream));
+                    misc_uploaded = true;  // joins the stream below before the host copy is read again
+                }
+                di.pending = false;
+                atlas_copy_in_flight = true;
+            }
             if (blue_noise_dirty) { int rc = d_blue_noise.upload(blue_noise.data(), blue_noise.size(), stream); if (rc) return rc; blue_noise_dirty = false; }
             bool uploaded = scene_changed || misc_uploaded;
             // lights change rarely; skipping the identical re-upload also skips the stream sync below, so the host can
@@ -774,7 +793,8 @@ struct Engine {
                 // LUT generation issued on `stream` in this call must precede the side stream's consumers. (Do NOT do this
                 // unconditionally: an event recorded on `stream` here completes only after frame N's denoiser, which would
                 // serialise prim(N+1) behind it. Uploads in st_tick are followed by a host-side stream sync.)
-                if (luts_generated_now) { ST_HIP(hipEventRecord(ev_setup, stream)); ST_HIP(hipStreamWaitEvent(side_stream, ev_setup, 0)); }
+                if (luts_generated_now || atlas_copy_in_flight) { ST_HIP(hipEventRecord(ev_setup, stream)); ST_HIP(hipStreamWaitEvent(side_stream, ev_setup, 0)); }
+                atlas_copy_in_flight = false;  // dynamic images (copied by st_tick without a host sync) cost the prim(N+1) / denoiser(N) overlap
                 if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_prim_ok, 0));
                 cur = side_stream;
                 do_prim();
@@ -888,9 +908,8 @@ int st_material_remove(StEngine* e, StHandle id) {
     return ST_OK;
 }
 
-int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) {
-    ST_REQUIRE(e && rgba && w && h && id, "bad image");
-    Engine* en = E(e);
+// Images::insert (images.rs:54-105): finds the rectangle for image `id` and makes the host copy of the atlas tall enough.
+static int place_image(Engine* en, StHandle id, uint32_t w, uint32_t h, Engine::ImageRec* out) {
     constexpr uint32_t kAtlasW = Engine::kAtlasW;
     if (w > kAtlasW) return fail(ST_ERR_ATLAS_FULL, "image wider than the atlas");
     auto it = en->images.find(id);
@@ -900,6 +919,7 @@ int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, cons
         if (it != en->images.end()) {  // another size: the old rectangle is given back first (images.rs:64-66)
             en->atlas_rects.release(it->second.x, it->second.y, it->second.w);
             en->images.erase(it);
+            en->device_images.erase(id);
             en->materials_dirty = true;
         }
         rec = {0, 0, w, h};
@@ -912,9 +932,29 @@ int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, cons
         en->atlas_h = (need_h + 255u) & ~255u;
         en->atlas.resize((size_t)en->atlas_w * en->atlas_h * 4, 0);
     }
-    for (uint32_t y = 0; y < h; y++) memcpy(&en->atlas[((size_t)(rec.y + y) * en->atlas_w + rec.x) * 4], rgba + (size_t)y * w * 4, (size_t)w * 4);
     en->images[id] = rec;
     en->atlas_dirty = true; en->materials_dirty = true;
+    *out = rec;
+    return ST_OK;
+}
+
+int st_image_insert_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) {
+    ST_REQUIRE(e && rgba && w && h && id, "bad image");
+    Engine* en = E(e);
+    Engine::ImageRec rec;
+    if (int rc = place_image(en, id, w, h, &rec)) return rc;
+    en->device_images.erase(id);
+    for (uint32_t y = 0; y < h; y++) memcpy(&en->atlas[((size_t)(rec.y + y) * en->atlas_w + rec.x) * 4], rgba + (size_t)y * w * 4, (size_t)w * 4);
+    return ST_OK;
+}
+int st_image_insert_device_rgba8(StEngine* e, StHandle id, uint32_t w, uint32_t h, const void* device_rgba, size_t row_pitch_bytes, int is_dynamic) {
+    ST_REQUIRE(e && device_rgba && w && h && id, "bad image");
+    ST_REQUIRE(row_pitch_bytes >= (size_t)w * 4, "row pitch smaller than a row");
+    Engine* en = E(e);
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "device images need a device engine");
+    Engine::ImageRec rec;
+    if (int rc = place_image(en, id, w, h, &rec)) return rc;
+    en->device_images[id] = Engine::DeviceImage{device_rgba, row_pitch_bytes, is_dynamic != 0, true};
     return ST_OK;
 }
 int st_image_remove(StEngine* e, StHandle id) {  // images.rs:107-113
@@ -924,6 +964,7 @@ int st_image_remove(StEngine* e, StHandle id) {  // images.rs:107-113
     if (it == en->images.end()) return ST_OK;
     en->atlas_rects.release(it->second.x, it->second.y, it->second.w);
     en->images.erase(it);
+    en->device_images.erase(id);
     en->materials_dirty = true;
     return ST_OK;
 }

@@ -570,3 +570,56 @@ def test_random_edit_history_renders_bit_exact(seed):
         img, ref = _step(torch, prod, orac, desc, cp, co, out)
         _compare_all(prod, orac, cp, co, frame)
         assert_bits_equal(img, ref, f"seed {seed} frame {frame}")
+
+
+@pytest.mark.gpu
+def test_device_resident_and_dynamic_images_bit_exact():
+    """ImageData::Texture (image.rs:46-59, images.rs:160-213): pixels that already live in device memory — copied into the
+    atlas once (static) or at every tick (dynamic) — must render exactly as the same pixels handed over as raw bytes,
+    which is all the oracle knows. The dynamic texture changes every frame; frames are enqueued without host syncs in
+    between, so the per-tick copy has to be ordered against both streams of the frame graph."""
+    from strolle_amd import StrolleError
+    torch = _torch()
+    size = (128, 80)
+    build = lambda e: scenes.build_random_soup(e, 1200, seed=33, n_lights=5, blend_fraction=0.5)
+    prod, orac, desc, cp, co = _pair(build, size, CameraMode.IMAGE)
+    rng = np.random.default_rng(5)
+    # the soup's textures again, this time from device memory: 900 (alpha-tested base colour) becomes dynamic, 902 (emissive)
+    # static with padded rows; 901 stays raw. Same sizes, so the rectangles stay where they are in both engines.
+    base = rng.integers(0, 256, (32, 32, 4), dtype=np.uint8); base[..., 3] = rng.choice(np.array([0, 128, 255], np.uint8), (32, 32))
+    emissive = rng.integers(0, 256, (8, 8, 4), dtype=np.uint8)
+    d_base = torch.from_numpy(base).cuda()
+    d_emissive = torch.zeros((8, 16, 4), dtype=torch.uint8, device="cuda:0")   # pitch 64 B, rows of 32 B
+    d_emissive[:, :8] = torch.from_numpy(emissive).cuda()
+    torch.cuda.synchronize()
+    prod.insert_device_image(900, d_base.data_ptr(), 32, 32, dynamic=True)
+    prod.insert_device_image(902, d_emissive.data_ptr(), 8, 8, row_pitch_bytes=64, dynamic=False)
+    orac.insert_image(900, base); orac.insert_image(902, emissive)
+    assert prod.image_rect(900) == orac.image_rect(900) and prod.image_rect(902) == orac.image_rect(902)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = [torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0") for _ in range(6)]
+    refs = []
+    for frame in range(6):
+        if frame:
+            base = base.copy(); base[..., :3] = (base[..., :3].astype(np.int32) + 37 * frame) % 256
+            if frame == 3:
+                base[..., 3] = 255 - base[..., 3]     # the alpha test flips: traversal itself changes
+            d_base.copy_(torch.from_numpy(base), non_blocking=False)   # same stream as the tick: ordered before its copy
+            orac.insert_image(900, base)
+        prod.update_camera(cp, desc); orac.update_camera(co, desc)
+        prod.tick(stream); orac.tick()
+        prod.render_camera(cp, outs[frame].data_ptr(), stream)
+        refs.append(orac.render_camera(co))
+    torch.cuda.synchronize()
+    for frame in range(6):
+        assert_bits_equal(outs[frame].cpu().numpy(), refs[frame], f"device images frame {frame}")
+    _compare_all(prod, orac, cp, co, 5)
+    # a later raw re-upload of the whole atlas must not lose the static device image (its host mirror is complete)
+    extra = rng.integers(0, 256, (4, 4, 4), dtype=np.uint8)
+    prod.insert_image(950, extra); orac.insert_image(950, extra)
+    out = outs[0]
+    img, ref = _step(torch, prod, orac, desc, cp, co, out)
+    assert_bits_equal(img, ref, "frame after a full atlas re-upload")
+    # host-only engines say so instead of pretending
+    with pytest.raises(StrolleError, match="device"):
+        Engine(device=-1).insert_device_image(1, d_base.data_ptr(), 32, 32)
