@@ -135,8 +135,9 @@ int st_camera_delete(StEngine* e, StHandle camera);                             
 int st_tick(StEngine* e, void* hip_stream);                                                      /* lib.rs:301 */
 /* Records and launches every pass of CameraController::render (camera_controller.rs:87-174) on
  * `hip_stream` and writes the composed HDR frame (RGBA32F, width*height*16 B, row-major) to the
- * DEVICE pointer `out_rgba32f_device` (may be NULL to skip composition). Asynchronous. */
-int st_render_camera(StEngine* e, StHandle camera, void* out_rgba32f_device, void* hip_stream); /* lib.rs:279 */
+ * DEVICE pointer `out_device` (width x height pixels of the camera's output format, RGBA32F unless
+ * st_camera_set_output_format said otherwise; may be NULL to skip composition). Asynchronous. */
+int st_render_camera(StEngine* e, StHandle camera, void* out_device, void* hip_stream); /* lib.rs:279 */
 
 /* ---- NEW seams (no counterpart in the reference) */
 /* Deterministic seeds: every pass draws seed = pass_seed(base, frame, pass_id) instead of
@@ -148,6 +149,12 @@ int st_set_blue_noise(StEngine* e, const uint8_t* rgba_256x256x4, size_t bytes);
 /* Multi-GPU tiling: restrict every per-pixel launch of this camera to the pixel rows [y0, y1)
  * of the full viewport (0,0 = whole frame). Pixels keep their absolute coordinates. */
 int st_camera_set_rows(StEngine* e, StHandle camera, uint32_t y0, uint32_t y1);
+/* camera.rs:170-175 `viewport.format`: the reference renders into a texture view of that format and the hardware converts
+ * on store; here the composition kernel does. RGBA32F (default, 16 B/pixel), RGBA16F (8 B, round to nearest even),
+ * RGBA8 / BGRA8 sRGB (4 B: clamp, IEC 61966-2-1 encode, round to nearest; alpha 255). The buffer handed to
+ * st_render_camera must hold width x height pixels of the chosen format. */
+enum StOutputFormat { ST_FORMAT_RGBA32F = 0, ST_FORMAT_RGBA16F = 1, ST_FORMAT_RGBA8_UNORM_SRGB = 2, ST_FORMAT_BGRA8_UNORM_SRGB = 3 };
+int st_camera_set_output_format(StEngine* e, StHandle camera, int format);
 
 /* ---- parity / measurement read-back */
 enum StBufferId {

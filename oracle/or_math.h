@@ -194,7 +194,8 @@ static inline float stm_atan2(float y, float x) {  // Rust f32::atan2(self=y, ot
 
 // Rgba16Float storage (atmosphere LUTs): f32 -> f16 (round to nearest even) -> f32, in integer arithmetic so that
 // CPU and GPU agree bit for bit.
-static inline float quantize_f16(float f) {
+// f32 -> f16 bit pattern, round to nearest even (IEEE 754-2008 binary16; what a store to an Rgba16Float texel does)
+static inline uint32_t f16_bits(float f) {
     uint32_t u = f2b(f);
     uint32_t sign = (u >> 16) & 0x8000u;
     uint32_t a = u & 0x7fffffffu;
@@ -214,6 +215,10 @@ static inline float quantize_f16(float f) {
         uint32_t b = a + 0xfffu + ((a >> 13) & 1u);
         h = sign | ((b - 0x38000000u) >> 13);
     }
+    return h;
+}
+static inline float quantize_f16(float f) {
+    uint32_t h = f16_bits(f);
     uint32_t hs = (h & 0x8000u) << 16, he = (h >> 10) & 0x1fu, hm = h & 0x3ffu;
     if (he == 0u) { float v = (float)hm * 5.9604644775390625e-8f; return b2f(f2b(v) | hs); }
     if (he == 31u) return b2f(hs | 0x7f800000u | (hm << 13));

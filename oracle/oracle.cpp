@@ -63,6 +63,32 @@ int or_camera_create(OrEngine* e, const ApiCamera* c, uint64_t* out) { *out = E(
 int or_camera_update(OrEngine* e, uint64_t h, const ApiCamera* c) { return E(e)->update_camera(h, *c) ? 0 : 3; }
 int or_camera_delete(OrEngine* e, uint64_t h) { E(e)->cameras.erase(h); return 0; }
 int or_tick(OrEngine* e) { E(e)->tick(); return 0; }
+// What the render target's format does to the composed RGBA32F frame (camera.rs:170-175 `viewport.format`; the conversion
+// itself is the GPU's store path, specified by the Khronos Data Format Specification 1.3, sections 10.1 "16-bit floating
+// point" and 13.3 "sRGB transfer functions"): format 1 = Rgba16Float (round to nearest even), 2 = Rgba8UnormSrgb,
+// 3 = Bgra8UnormSrgb (clamp to [0, 1], encode, scale by 255, round to nearest; alpha is linear and always 1 here).
+static uint32_t srgb8(float x) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 1.0f) return 255u;
+    float y = x <= 0.0031308f ? x * 12.92f : 1.055f * stm_pow(x, 1.0f / 2.4f) - 0.055f;
+    return (uint32_t)(y * 255.0f + 0.5f);
+}
+int or_encode_output(const float* rgba32f, size_t pixels, int format, void* out) {
+    if (format == 1) {
+        uint16_t* o = static_cast<uint16_t*>(out);
+        for (size_t i = 0; i < pixels * 4; i++) o[i] = (uint16_t)f16_bits(rgba32f[i]);
+        return 0;
+    }
+    if (format == 2 || format == 3) {
+        uint8_t* o = static_cast<uint8_t*>(out);
+        for (size_t i = 0; i < pixels; i++) {
+            const uint32_t r = srgb8(rgba32f[4 * i]), g = srgb8(rgba32f[4 * i + 1]), b = srgb8(rgba32f[4 * i + 2]);
+            o[4 * i] = (uint8_t)(format == 2 ? r : b); o[4 * i + 1] = (uint8_t)g; o[4 * i + 2] = (uint8_t)(format == 2 ? b : r); o[4 * i + 3] = 255;
+        }
+        return 0;
+    }
+    return 1;
+}
 int or_render_camera(OrEngine* e, uint64_t h, float* out_rgba32f) { return E(e)->render_camera(h, reinterpret_cast<Vec4*>(out_rgba32f)) ? 0 : 3; }
 
 // ---- debug / parity read-back (buffer ids shared with include/strolle_hip.h ST_BUF_*)

@@ -70,6 +70,14 @@ class StrolleError(RuntimeError):
     pass
 
 
+class OutputFormat(enum.IntEnum):
+    """StOutputFormat"""
+    RGBA32F = 0
+    RGBA16F = 1
+    RGBA8_UNORM_SRGB = 2
+    BGRA8_UNORM_SRGB = 3
+
+
 class Buffer(enum.IntEnum):
     """Per-camera buffers (strolle/src/camera_controller/buffers.rs:7-51); values == StBufferId."""
     PRIM_GBUFFER_D0_A = 0; PRIM_GBUFFER_D0_B = 1; PRIM_GBUFFER_D1_A = 2; PRIM_GBUFFER_D1_B = 3
@@ -261,6 +269,7 @@ class _Binding:
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
+            self.camera_set_output_format = fn("camera_set_output_format", [vp, u64, i32])
             self.image_insert_device_rgba8 = fn("image_insert_device_rgba8", [vp, u64, u32, u32, vp, sz, i32])
             self.debug_bvh_refresh = fn("debug_bvh_refresh", [vp, P(u64), P(u64)])
             self.scene_load_gltf = fn("scene_load_gltf", [vp, C.c_char_p, P(StGltfOptions), P(StGltfSummary)])
@@ -441,6 +450,10 @@ class Engine(EngineBase):
     def render_camera(self, handle: int, out_device_ptr: int = 0, stream: int = 0):
         """Enqueue CameraController::render; `out_device_ptr` = device address of a W*H RGBA32F buffer (0 = skip composition)."""
         self._check(self._b.render_camera(self._h, handle, out_device_ptr, stream))
+
+    def set_output_format(self, handle: int, fmt: "OutputFormat"):
+        """viewport.format (camera.rs:170-175): what st_render_camera writes into its output buffer."""
+        self._check(self._b.camera_set_output_format(self._h, handle, int(fmt)))
 
     def set_camera_rows(self, handle: int, y0: int, y1: int):
         self._check(self._b.camera_set_rows(self._h, handle, y0, y1))

@@ -8,26 +8,7 @@
 namespace st {
 
 ST_D float quantize_f16(float f) {
-    const uint32_t u = f2b(f);
-    const uint32_t sign = (u >> 16) & 0x8000u;
-    const uint32_t a = u & 0x7fffffffu;
-    uint32_t h;
-    if (a >= 0x7f800000u) h = sign | (a > 0x7f800000u ? 0x7e00u : 0x7c00u);
-    else if (a >= 0x477ff000u) h = sign | 0x7c00u;
-    else if (a < 0x38800000u) {
-        if (a < 0x33000000u) h = sign;
-        else {
-            const uint32_t m = (a & 0x007fffffu) | 0x00800000u;
-            const uint32_t sft = 126u - (a >> 23);
-            uint32_t r = m >> sft;
-            const uint32_t rem = m & ((1u << sft) - 1u), half = 1u << (sft - 1u);
-            if (rem > half || (rem == half && (r & 1u))) r += 1u;
-            h = sign | r;
-        }
-    } else {
-        const uint32_t b = a + 0xfffu + ((a >> 13) & 1u);
-        h = sign | ((b - 0x38000000u) >> 13);
-    }
+    const uint32_t h = f16_bits(f);
     const uint32_t hs = (h & 0x8000u) << 16, he = (h >> 10) & 0x1fu, hm = h & 0x3ffu;
     if (he == 0u) { const float v = (float)hm * 5.9604644775390625e-8f; return b2f(f2b(v) | hs); }
     if (he == 31u) return b2f(hs | 0x7f800000u | (hm << 13));

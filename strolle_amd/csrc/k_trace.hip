@@ -329,13 +329,21 @@ void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* bu
 }
 
 // ---------------------------------------------------------------- frame_composition.rs:18-82 as a compute pass into an RGBA32F buffer
-__global__ ST_KERNEL_BOUNDS void k_composition(const KArgs a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out) {
+// `format` (StOutputFormat) is what the reference leaves to the render target's format (camera.rs:170-175 viewport.format).
+__global__ ST_KERNEL_BOUNDS void k_composition(const KArgs a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, void* out, uint32_t format) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
-    out[pos.y * a.width + pos.x] = compose_pixel(a, pos, camera_mode, tex_read(di_diff, a, pos), tex_read(gi_diff, a, pos));
+    const float4 c = compose_pixel(a, pos, camera_mode, tex_read(di_diff, a, pos), tex_read(gi_diff, a, pos));
+    const uint32_t at = pos.y * a.width + pos.x;
+    if (format == 0u) static_cast<float4*>(out)[at] = c;
+    else if (format == 1u) static_cast<uint2*>(out)[at] = make_uint2(f16_bits(c.x) | (f16_bits(c.y) << 16), f16_bits(c.z) | (f16_bits(c.w) << 16));
+    else {
+        const uint32_t r = srgb8_encode(c.x), g = srgb8_encode(c.y), b = srgb8_encode(c.z);
+        static_cast<uint32_t*>(out)[at] = format == 2u ? (r | (g << 8) | (b << 16) | 0xff000000u) : (b | (g << 8) | (r << 16) | 0xff000000u);
+    }
 }
-void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out, hipStream_t s) {
-    ST_LAUNCH(k_composition, false, s, a, camera_mode, di_diff, gi_diff, out);
+void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, void* out, uint32_t format, hipStream_t s) {
+    ST_LAUNCH(k_composition, false, s, a, camera_mode, di_diff, gi_diff, out, format);
 }
 
 }  // namespace st

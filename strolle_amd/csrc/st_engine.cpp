@@ -165,6 +165,7 @@ struct CameraState {
     StCamera desc{};
     GpuCamera curr{}, prev{};
     uint32_t frame = 0, row0 = 0, row1 = 0;
+    uint32_t out_format = 0;  // StOutputFormat (camera.rs:170-175 viewport.format)
     void* slab = nullptr; size_t slab_bytes = 0;
     float4* plane[ST_BUF_COUNT + kInternalPlanes] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
     size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
@@ -593,7 +594,7 @@ struct Engine {
     }
 
     // ---- render (camera_controller.rs:87-174)
-    int render(CameraState& c, float4* out, hipStream_t stream) {
+    int render(CameraState& c, void* out, hipStream_t stream) {
         if (!has_device) return fail(ST_ERR_NO_DEVICE, "render_camera on a host-only engine");
         if (!scene_uploaded) return fail(ST_ERR_INVALID_ARGUMENT, "st_tick must precede st_render_camera");
         ST_HIP(hipSetDevice(device));
@@ -759,8 +760,8 @@ struct Engine {
                 float4* gi[3] = {a.gi_diff_stash, a.gi_diff_prev_colors, a.gi_diff_curr_colors};
                 const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
                 for (uint32_t nth = 0; nth < 5; nth++) {
-                    if (nth == 4 && fuse_compose && out) {
-                        run(KS_DENOISE_WAVELET_COMPOSE, {}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nullptr, mode, out, cur); });
+                    if (nth == 4 && fuse_compose && out && c.out_format == 0u) {
+                        run(KS_DENOISE_WAVELET_COMPOSE, {}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nullptr, mode, static_cast<float4*>(out), cur); });
                         composed = true;
                     } else
                         run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nth <= 2u ? a.sl[nth & 1u] : nullptr, nth <= 1u ? a.sl[(nth & 1u) ^ 1u] : nullptr, cur); });
@@ -770,7 +771,7 @@ struct Engine {
                 if (!out || composed) return;
                 const float4* di_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
                 const float4* gi_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
-                run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, cur); });
+                run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
                 composed = true;
             };
 
@@ -832,7 +833,7 @@ struct Engine {
             const bool dn = c.desc.denoise != 0u;
             const float4* di_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
             const float4* gi_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
-            run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, cur); });
+            run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
         }
         ST_HIP(hipGetLastError());
         return ST_OK;
@@ -1046,12 +1047,21 @@ int st_camera_set_rows(StEngine* e, StHandle h, uint32_t y0, uint32_t y1) {
     return ST_OK;
 }
 
+int st_camera_set_output_format(StEngine* e, StHandle h, int format) {
+    ST_REQUIRE(e, "null engine");
+    auto it = E(e)->cameras.find(h);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    ST_REQUIRE(format >= ST_FORMAT_RGBA32F && format <= ST_FORMAT_BGRA8_UNORM_SRGB, "unknown output format");
+    it->second->out_format = (uint32_t)format;
+    return ST_OK;
+}
+
 int st_tick(StEngine* e, void* stream) { ST_REQUIRE(e, "null engine"); return E(e)->tick(static_cast<hipStream_t>(stream)); }
 int st_render_camera(StEngine* e, StHandle h, void* out, void* stream) {
     ST_REQUIRE(e, "null engine");
     auto it = E(e)->cameras.find(h);
     if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
-    return E(e)->render(*it->second, static_cast<float4*>(out), static_cast<hipStream_t>(stream));
+    return E(e)->render(*it->second, out, static_cast<hipStream_t>(stream));
 }
 
 int st_set_seed(StEngine* e, uint64_t seed) { ST_REQUIRE(e, "null engine"); E(e)->base_seed = seed; return ST_OK; }

@@ -88,6 +88,6 @@ void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, con
 // last wavelet pass + frame composition in one launch
 void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
                                     float4* gi_out, const float2* sl_in, uint32_t camera_mode, float4* frame_out, hipStream_t s);
-void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, float4* out, hipStream_t s);
+void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, void* out, uint32_t format, hipStream_t s);
 
 }  // namespace st

@@ -154,6 +154,34 @@ ST_HD float pow5_(float x) { const float x2 = x * x; const float x4 = x2 * x2; r
 ST_HD float pow8_(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x4 * x4; }
 ST_HD float pow64_(float x) { const float x2 = x * x; const float x4 = x2 * x2; const float x8 = x4 * x4; const float x16 = x8 * x8; const float x32 = x16 * x16; return x32 * x32; }
 
+// f32 -> f16 bits, round to nearest even, in integer arithmetic (what a store to an Rgba16Float texel does)
+ST_HD uint32_t f16_bits(float f) {
+    const uint32_t u = f2b(f);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return sign | (a > 0x7f800000u ? 0x7e00u : 0x7c00u);
+    if (a >= 0x477ff000u) return sign | 0x7c00u;
+    if (a < 0x38800000u) {
+        if (a < 0x33000000u) return sign;
+        const uint32_t m = (a & 0x007fffffu) | 0x00800000u;
+        const uint32_t sft = 126u - (a >> 23);
+        uint32_t r = m >> sft;
+        const uint32_t rem = m & ((1u << sft) - 1u), half = 1u << (sft - 1u);
+        if (rem > half || (rem == half && (r & 1u))) r += 1u;
+        return sign | r;
+    }
+    const uint32_t b = a + 0xfffu + ((a >> 13) & 1u);
+    return sign | ((b - 0x38000000u) >> 13);
+}
+// linear -> 8-bit sRGB (the store to an Rgba8UnormSrgb / Bgra8UnormSrgb render target: clamp, IEC 61966-2-1 transfer
+// function, round to nearest). NaN and negatives give 0.
+ST_HD uint32_t srgb8_encode(float x) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 1.0f) return 255u;
+    const float y = x <= 0.0031308f ? x * 12.92f : 1.055f * pow_(x, 1.0f / 2.4f) - 0.055f;
+    return (uint32_t)(y * 255.0f + 0.5f);
+}
+
 // the G-buffer's gamma-encoded base colour bytes (gbuffer.rs:37-48): RGB8 + A6. Host and device evaluate it identically.
 ST_HD uint32_t gbuffer_pack_base_color(float4 c) {
     const float ig = 1.0f / 2.2f;

@@ -33,6 +33,18 @@ def oracle_lib() -> C.CDLL:
     return _lib
 
 
+def encode_output(frame: np.ndarray, fmt: int) -> np.ndarray:
+    """or_encode_output: the composed RGBA32F frame as a render target of format `fmt` (StOutputFormat) would hold it."""
+    frame = np.ascontiguousarray(frame, np.float32)
+    pixels = frame.size // 4
+    out = np.zeros(frame.shape, np.uint16 if fmt == 1 else np.uint8)
+    fn = oracle_lib().or_encode_output
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    assert fn(frame.ctypes.data, pixels, int(fmt), out.ctypes.data) == 0
+    return out
+
+
 class OracleEngine(EngineBase):
     def __init__(self):
         super().__init__(_Binding(oracle_lib(), "or_", False))

@@ -623,3 +623,32 @@ def test_device_resident_and_dynamic_images_bit_exact():
     # host-only engines say so instead of pretending
     with pytest.raises(StrolleError, match="device"):
         Engine(device=-1).insert_device_image(1, d_base.data_ptr(), 32, 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+def test_output_formats_bit_exact(fmt):
+    """camera.rs:170-175 viewport.format: Rgba16Float and the two 8-bit sRGB swap-chain formats, written by the composition
+    kernel, against the oracle's RGBA32F frame pushed through or_encode_output."""
+    from oracle_binding import encode_output
+    from strolle_amd import OutputFormat
+    torch = _torch()
+    size = (160, 96)
+    prod, orac, desc, cp, co = _pair(scenes.build_cornell, size, CameraMode.IMAGE)
+    prod.set_output_format(cp, OutputFormat(fmt))
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float16 if fmt == 1 else torch.uint8, device="cuda:0")
+    for frame in range(4):
+        prod.update_camera(cp, desc); orac.update_camera(co, desc)
+        prod.tick(); orac.tick()
+        prod.render_camera(cp, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        ref = orac.render_camera(co)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        got = got.view(np.uint16) if fmt == 1 else got
+        assert np.array_equal(got, encode_output(ref, fmt)), f"format {fmt} frame {frame}"
+    assert len(np.unique(got[..., :3])) > 50, "a frame with this little variety would not test the encoders"
+    # the default goes back to RGBA32F
+    prod.set_output_format(cp, OutputFormat.RGBA32F)
+    out32 = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    img, ref = _step(torch, prod, orac, desc, cp, co, out32)
+    assert_bits_equal(img, ref, "RGBA32F after switching back")

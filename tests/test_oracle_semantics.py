@@ -218,3 +218,31 @@ def test_pass_seeds_are_distinct_and_stable():
     seen = {lib.or_probe_pass_seed(0, f, p) for f in range(64) for p in range(24)}
     assert len(seen) == 64 * 24, "collisions among the first 64 frames x 24 passes"
     assert lib.or_probe_pass_seed(0, 3, 5) == lib.or_probe_pass_seed(0, 3, 5) != lib.or_probe_pass_seed(1, 3, 5)
+
+
+def test_output_format_encoders_against_numpy():
+    """or_encode_output pins what st_camera_set_output_format promises: Rgba16Float = IEEE round-to-nearest-even (numpy's
+    float16 cast is that), sRGB8 = round(255 * oetf(clamp(x))) — checked against the transfer function in float64, where
+    the deterministic powf of the oracle may move a value sitting on a rounding boundary by one code at most."""
+    from oracle_binding import encode_output
+    rng = np.random.default_rng(2)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e9, np.inf, -np.inf, np.nan, 5.96e-8, 2.98e-8, 2.9802325e-8, 6.1e-5, 6.097555e-5,
+                        1.0009765625, 1.00048828125, 1.000488281251, 0.333333, 1e-10, 0.0031308, 0.00313081, 0.5, 0.2, 0.9999, 1.00001], np.float32)
+    vals = np.concatenate([special, rng.standard_normal(4000).astype(np.float32) * 10, np.exp(rng.uniform(-30, 12, 4000)).astype(np.float32),
+                           rng.uniform(0, 1, 4000).astype(np.float32)])
+    vals = np.resize(vals, (len(vals) + 3) // 4 * 4).reshape(-1, 1, 4)
+    half = encode_output(vals, 1)
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    nan = np.isnan(vals)
+    assert np.array_equal(half[~nan], want[~nan])
+    assert np.all((half[nan] & 0x7c00) == 0x7c00) and np.all((half[nan] & 0x3ff) != 0)
+    for fmt in (2, 3):
+        got = encode_output(vals, fmt).astype(np.int32)
+        x = np.nan_to_num(np.clip(vals.astype(np.float64), 0.0, 1.0), nan=0.0)
+        y = np.where(x <= 0.0031308, x * 12.92, 1.055 * np.power(x, 1 / 2.4) - 0.055)
+        ideal = np.floor(y * 255.0 + 0.5).astype(np.int32)
+        rgb = got[..., [0, 1, 2]] if fmt == 2 else got[..., [2, 1, 0]]
+        assert np.abs(rgb - ideal[..., :3]).max() <= 1
+        assert (rgb == ideal[..., :3]).mean() > 0.999
+        assert np.all(got[..., 3] == 255)
