@@ -140,6 +140,16 @@ int st_tick(StEngine* e, void* hip_stream);                                     
 int st_render_camera(StEngine* e, StHandle camera, void* out_device, void* hip_stream); /* lib.rs:279 */
 
 /* ---- NEW seams (no counterpart in the reference) */
+/* BVH refresh policy for scenes that change every frame (examples/stress-bvh.rs).
+ * ST_BVH_REBUILD (default) is the reference's behaviour: every change rebuilds the tree — with unchanged subtrees
+ * reused, builder.rs:183-301 — and the result is the tree a from-scratch build gives. ST_BVH_REFIT keeps the tree
+ * while instances only move (same triangles, same materials, same Blend flags) and recomputes its boxes bottom-up,
+ * which costs a fraction of a rebuild; traversal stays correct, `used_memory` and the tree's quality follow the old
+ * topology until something other than a transform changes (or the mode is set again), which rebuilds. */
+enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1 };
+int st_set_bvh_refresh(StEngine* e, int mode);
+int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits);
+
 /* Deterministic seeds: every pass draws seed = pass_seed(base, frame, pass_id) instead of
  * rand::thread_rng() (camera_controller.rs:189-194; passes/ref_*.rs:49-59). */
 int st_set_seed(StEngine* e, uint64_t base_seed);

@@ -144,6 +144,21 @@ struct BvhBuilder {
         }
     }
 
+    // Refit (not in the reference; the product's ST_BVH_REFIT policy restated on the tree instead of on the flat stream):
+    // the topology and the order of the primitives stay, every node's box becomes the union of what is below it.
+    BoundingBox refit(uint32_t id, const std::vector<BvhPrimitive>& all) {
+        BvhNode& n = nodes[id];
+        BoundingBox box;
+        if (n.internal) { box.add(refit(n.left, all)); box.add(refit(n.right, all)); }
+        else
+            for (uint32_t i = n.prim_start; i < n.prim_end; i++) {
+                current[i].bounds = all[current[i].triangle_id].bounds; current[i].center = all[current[i].triangle_id].center;
+                box.add(current[i].bounds);
+            }
+        n.bounds = box;
+        return box;
+    }
+
     // bvh/serializer.rs:20-110
     uint32_t serialize(uint32_t id, const std::vector<uint8_t>& material_is_blend, std::vector<Vec4>& buffer) const {
         uint32_t ptr = (uint32_t)buffer.size();
@@ -425,6 +440,8 @@ struct Engine {
     uint32_t frame = 1;  // lib.rs:152
     uint64_t base_seed = 0;
     BvhBuilder bvh; std::vector<Vec4> bvh_buffer;
+    bool bvh_refit_mode = false, built_with_refit_mode = false; uint64_t rebuilds = 0, refits = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> built_leaves; std::vector<uint8_t> built_blend;
     std::vector<uint8_t> blue_noise;  // 256*256*4
     std::vector<Vec4> transmittance_lut, scattering_lut, sky_lut;  // passes/atmosphere.rs:78-110
     bool atmosphere_initialized = false; bool sky_known = false; float known_sun_altitude = 0.0f;
@@ -684,11 +701,22 @@ struct Engine {
         if (materials_dirty) { materials_dirty = false; refresh_materials(); }
         if (refresh_instances()) {
             for (const auto& e : instances) { xf_curr_inv[e.xslot] = e.xform_inv; xf_prev[e.xslot] = e.prev_xform; }
-            bvh.current.clear();
-            for (auto& p : prims_all) if (p.is_alive()) bvh.current.push_back(p);
-            bvh.build();
             std::vector<uint8_t> blend(materials.size() + 1, 0);
             for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1;
+            // what the leaves refer to: live (triangle slot, material) pairs; refit mode keeps the tree while this and the
+            // Blend flags stay what the last build saw
+            std::vector<std::pair<uint32_t, uint32_t>> leaves;
+            for (auto& p : prims_all) if (p.is_alive()) leaves.push_back({p.triangle_id, p.material_id});
+            if (bvh_refit_mode && built_with_refit_mode && leaves == built_leaves && blend == built_blend && !bvh.nodes.empty()) {
+                bvh.refit(0, prims_all);
+                refits += 1;
+            } else {
+                bvh.current.clear();
+                for (auto& p : prims_all) if (p.is_alive()) bvh.current.push_back(p);
+                bvh.build();
+                built_leaves = leaves; built_blend = blend; built_with_refit_mode = bvh_refit_mode;
+                rebuilds += 1;
+            }
             bvh_buffer.clear();
             bvh.serialize(0, blend, bvh_buffer);
         }

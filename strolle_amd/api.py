@@ -266,6 +266,7 @@ class _Binding:
         self.debug_read_scene = fn("debug_read_scene", [vp, i32, vp, sz, P(sz)])
         self.debug_world = fn("debug_world", [vp, P(u32), P(u32)])
         self.debug_image_rect = fn("debug_image_rect", [vp, u64, P(u32)])
+        self.set_bvh_refresh = fn("set_bvh_refresh", [vp, i32]); self.debug_bvh_refits = fn("debug_bvh_refits", [vp, P(u64), P(u64)])
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
@@ -413,6 +414,16 @@ class EngineBase:
         lc, fr = C.c_uint32(), C.c_uint32()
         self._check(self._b.debug_world(self._h, C.byref(lc), C.byref(fr)))
         return lc.value, fr.value
+
+    def set_bvh_refresh(self, refit: bool):
+        """st_set_bvh_refresh: False = rebuild on every change (the reference's behaviour), True = refit while instances only move."""
+        self._check(self._b.set_bvh_refresh(self._h, 1 if refit else 0))
+
+    def bvh_refits(self):
+        """(rebuilds, refits) so far."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._b.debug_bvh_refits(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def image_rect(self, handle: int):
         """(x, y, w, h) of an image in the atlas, in texels."""

@@ -156,6 +156,11 @@ struct DeviceArray {
         if (bytes) ST_HIP(hipMemcpyAsync(ptr, src, bytes, hipMemcpyHostToDevice, stream));
         return ST_OK;
     }
+    // part of an array that is already on the device: bytes [offset, offset + bytes) of `base`
+    int upload_range(const void* base, size_t offset, size_t bytes, hipStream_t stream) {
+        if (bytes) ST_HIP(hipMemcpyAsync(static_cast<char*>(ptr) + offset, static_cast<const char*>(base) + offset, bytes, hipMemcpyHostToDevice, stream));
+        return ST_OK;
+    }
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; capacity = 0; }
 };
 
@@ -220,6 +225,14 @@ struct Engine {
     std::vector<float4> tri_geo, tri_attr, bvh_stream;
     BvhBuild bvh;
     bool scene_uploaded = false;
+    // BVH refresh policy (st_set_bvh_refresh). Refit: while the set of (triangle slot, material) pairs and the Blend flags
+    // are what the last build saw — i.e. instances only moved — keep the tree and recompute the boxes bottom-up.
+    int bvh_refresh_mode = ST_BVH_REBUILD;
+    bool have_topology = false; uint64_t topology_signature = 0;
+    std::vector<uint32_t> internal_positions;  // stream offsets of the internal nodes, ascending (parents before children)
+    uint64_t refits = 0, rebuilds = 0;
+    // triangle slots baked since the last upload: only that range of tri_geo / tri_attr has to travel
+    size_t dirty_lo = SIZE_MAX, dirty_hi = 0; bool tri_arrays_resized = false;
 
     // images: a single linear RGBA8 atlas of the reference's extent (images.rs:28-29); rectangles from st_atlas.h
     static constexpr uint32_t kAtlasW = 8192, kAtlasMaxH = 8192;
@@ -439,11 +452,59 @@ struct Engine {
             else if (!triangle_free.take(count, &b, &e)) {
                 b = triangles.size(); e = b + count;
                 triangles.resize(e); prims.resize(e); prim_alive.resize(e, 0); tri_geo.resize(3 * e); tri_attr.resize(4 * e);
+                tri_arrays_resized = true;
             }
             for (size_t i = 0; i < count; i++) bake(mesh->second[i], inst, mat->second, b + i);
+            dirty_lo = std::min(dirty_lo, b); dirty_hi = std::max(dirty_hi, e);
             instance_triangles[inst.id] = {b, e};
         }
         return true;
+    }
+
+    // ---- BVH refit (the alternative to a rebuild when instances only move)
+    // What the leaves of the current tree refer to: every live (triangle slot, material) pair, plus the Blend flags baked into
+    // the leaf entries. Equal signatures mean the stream's topology and leaf entries are still right; only boxes moved.
+    uint64_t topology_of(const std::vector<uint8_t>& blend) const {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+        auto mix = [&h](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; h ^= h >> 29; };
+        for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) mix(((uint64_t)i << 32) | prims[i].material_id);
+        mix(0xffffffffffffffffull);
+        for (uint8_t b : blend) mix(b);
+        return h;
+    }
+    // offsets of the internal nodes of bvh_stream, in stream order (serializer.rs:20-110: a node is internal when d0.w == 0)
+    void index_stream() {
+        internal_positions.clear();
+        for (size_t p = 0; p < bvh_stream.size();) {
+            if (f2b(bvh_stream[p].w) == 0u) { internal_positions.push_back((uint32_t)p); p += 4; }
+            else p += 1;
+        }
+    }
+    // box of the subtree that starts at stream offset p: a run of leaf entries (triangle bounds as baked) or an internal node
+    // (union of the two child boxes it stores)
+    Aabb subtree_box(size_t p) const {
+        Aabb box;
+        if (f2b(bvh_stream[p].w) == 0u) {
+            box.grow(v3(bvh_stream[p].x, bvh_stream[p].y, bvh_stream[p].z)); box.grow(v3(bvh_stream[p + 1].x, bvh_stream[p + 1].y, bvh_stream[p + 1].z));
+            box.grow(v3(bvh_stream[p + 2].x, bvh_stream[p + 2].y, bvh_stream[p + 2].z)); box.grow(v3(bvh_stream[p + 3].x, bvh_stream[p + 3].y, bvh_stream[p + 3].z));
+            return box;
+        }
+        for (;; p++) {
+            const Aabb& b = prims[f2b(bvh_stream[p].y)].bounds;
+            box.grow(b.lo); box.grow(b.hi);
+            if (!(f2b(bvh_stream[p].x) & 1u)) return box;
+        }
+    }
+    // children sit behind their parent in the stream, so one backward sweep over the internal nodes sees finished children
+    void refit_stream() {
+        for (size_t i = internal_positions.size(); i-- > 0;) {
+            const size_t p = internal_positions[i];
+            const Aabb l = subtree_box(p + 4), r = subtree_box(f2b(bvh_stream[p + 1].w));
+            bvh_stream[p] = make_float4(l.lo.x, l.lo.y, l.lo.z, bvh_stream[p].w);
+            bvh_stream[p + 1] = make_float4(l.hi.x, l.hi.y, l.hi.z, bvh_stream[p + 1].w);
+            bvh_stream[p + 2] = make_float4(r.lo.x, r.lo.y, r.lo.z, bvh_stream[p + 2].w);
+            bvh_stream[p + 3] = make_float4(r.hi.x, r.hi.y, r.hi.z, bvh_stream[p + 3].w);
+        }
     }
 
     // ---- tick (lib.rs:301-395)
@@ -461,16 +522,26 @@ struct Engine {
                 for (int k = 0; k < 2; k++) { x[4 * k] = f4(src[k]->x, 0.0f); x[4 * k + 1] = f4(src[k]->y, 0.0f); x[4 * k + 2] = f4(src[k]->z, 0.0f); x[4 * k + 3] = f4(src[k]->t, 0.0f); }
             }
             const auto t1 = now();
-            bvh.begin_refresh();  // keeps the previous tree: unchanged subtrees are copied, not rebuilt (same result as a fresh build)
-            for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
-            const auto t2 = now();
-            bvh.run();
-            const auto t3 = now();
             std::vector<uint8_t> blend(materials.size());
             for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
-            bvh.flatten(blend, bvh_stream);
-            const auto t4 = now();
-            if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles, %zu reused)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size(), bvh.reused_primitives());
+            const uint64_t signature = bvh_refresh_mode == ST_BVH_REFIT ? topology_of(blend) : 0;
+            if (bvh_refresh_mode == ST_BVH_REFIT && have_topology && signature == topology_signature) {
+                refit_stream();
+                refits++;
+                if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, refit %.2f ms (%zu internal nodes)\n", ms(t0, t1), ms(t1, now()), internal_positions.size());
+            } else {
+                bvh.begin_refresh();  // keeps the previous tree: unchanged subtrees are copied, not rebuilt (same result as a fresh build)
+                for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
+                const auto t2 = now();
+                bvh.run();
+                const auto t3 = now();
+                bvh.flatten(blend, bvh_stream);
+                const auto t4 = now();
+                rebuilds++;
+                have_topology = false;
+                if (bvh_refresh_mode == ST_BVH_REFIT) { index_stream(); topology_signature = signature; have_topology = true; }
+                if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles, %zu reused)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size(), bvh.reused_primitives());
+            }
             scene_changed = true;
         }
         light_count = next_light_id;
@@ -494,8 +565,16 @@ struct Engine {
             if (scene_changed || !scene_uploaded) {
                 int rc;
                 if ((rc = d_bvh.upload(bvh_stream.data(), bvh_stream.size() * sizeof(float4), stream))) return rc;
-                if ((rc = d_tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), stream))) return rc;
-                if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream))) return rc;
+                // triangle arrays: whole on the first upload or after they grew, otherwise only the slots baked since
+                const bool partial = scene_uploaded && !tri_arrays_resized && d_tri_geo.capacity >= tri_geo.size() * sizeof(float4) && d_tri_attr.capacity >= tri_attr.size() * sizeof(float4);
+                if (!partial) {
+                    if ((rc = d_tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), stream))) return rc;
+                    if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream))) return rc;
+                } else if (dirty_lo < dirty_hi) {
+                    if ((rc = d_tri_geo.upload_range(tri_geo.data(), 3 * dirty_lo * sizeof(float4), 3 * (dirty_hi - dirty_lo) * sizeof(float4), stream))) return rc;
+                    if ((rc = d_tri_attr.upload_range(tri_attr.data(), 4 * dirty_lo * sizeof(float4), 4 * (dirty_hi - dirty_lo) * sizeof(float4), stream))) return rc;
+                }
+                dirty_lo = SIZE_MAX; dirty_hi = 0; tri_arrays_resized = false;
                 if ((rc = d_instance_xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), stream))) return rc;
                 if ((rc = d_materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), stream))) return rc;
                 if ((rc = d_material_base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), stream))) return rc;
@@ -1139,6 +1218,18 @@ int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame) {
     return ST_OK;
 }
 
+int st_set_bvh_refresh(StEngine* e, int mode) {
+    ST_REQUIRE(e, "null engine");
+    ST_REQUIRE(mode == ST_BVH_REBUILD || mode == ST_BVH_REFIT, "unknown refresh mode");
+    Engine* en = E(e);
+    if (en->bvh_refresh_mode != mode) { en->bvh_refresh_mode = mode; en->have_topology = false; }
+    return ST_OK;
+}
+int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits) {
+    ST_REQUIRE(e && rebuilds && refits, "null argument");
+    *rebuilds = E(e)->rebuilds; *refits = E(e)->refits;
+    return ST_OK;
+}
 int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused) {
     ST_REQUIRE(e && primitives && reused, "null argument");
     *primitives = E(e)->bvh.prims.size(); *reused = E(e)->bvh.reused_primitives();

@@ -140,6 +140,81 @@ def test_bvh_refresh_reuses_unchanged_subtrees_and_equals_a_fresh_build():
     assert n == n0 - 6 and r > n // 2
 
 
+def test_bvh_refit_mode_keeps_the_tree_while_instances_only_move():
+    """ST_BVH_REFIT (SURVEY 8(f).2's alternative to rebuilding): moves refit the boxes of the existing tree, anything else
+    rebuilds. The product refits the flat stream, the oracle its node tree; both must give the same stream, the boxes must
+    contain their triangles, and the tree must be the old topology (a fresh build of the moved scene differs)."""
+    from strolle_amd import Instance
+    npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
+    prod, orac, fresh = Engine(device=-1), OracleEngine(), Engine(device=-1)
+    for e in (prod, orac, fresh):
+        scenes.build_dungeon(e)
+    for e in (prod, orac):
+        e.set_bvh_refresh(True)
+    for e in (prod, orac, fresh):
+        e.tick()
+    assert prod.bvh_refits() == orac.bvh_refits() == (1, 0)
+    topology = prod.read_scene(0).reshape(-1, 4).view(np.uint32)[:, 3].copy()    # .w: node kind, right pointers, leaf markers
+    moved = [(8, 7), (1, 0), (17, 16)]
+    for k in range(4):
+        for handle, i in moved:
+            x = np.ascontiguousarray(npz[f"xform_{i}"].reshape(4, 3).T, np.float32)
+            x[:, 3] += np.float32(0.05 * (k + 1)) * np.array([1.0, 0.5, -0.25], np.float32)
+            for e in (prod, orac, fresh):
+                e.insert_instance(handle, Instance(handle, 1 + int(npz[f"material_{i}"]), x))
+        for e in (prod, orac, fresh):
+            e.tick()
+        stream = prod.read_scene(0)
+        assert_bits_equal(stream, orac.read_scene(0), f"refit {k}: BVH stream")
+        assert_bits_equal(prod.read_scene(1), fresh.read_scene(1), f"refit {k}: triangles")
+        assert np.array_equal(stream.reshape(-1, 4).view(np.uint32)[:, 3], topology), "a refit must not touch topology or leaf entries"
+        assert not np.array_equal(stream, fresh.read_scene(0)), "the rebuilt tree of the moved scene is a different one"
+        assert prod.bvh_refits() == orac.bvh_refits() == (1, k + 1)
+    # every box contains the triangles below it: walk the stream
+    s4 = prod.read_scene(0).reshape(-1, 4)
+    tri = prod.read_scene(1).reshape(-1, 9, 4)
+    def box_of(p):
+        if s4[p].view(np.uint32)[3] == 0:
+            lo_l, hi_l = box_of(p + 4); lo_r, hi_r = box_of(int(s4[p + 1].view(np.uint32)[3]))
+            for (lo, hi), (blo, bhi) in (((lo_l, hi_l), (s4[p][:3], s4[p + 1][:3])), ((lo_r, hi_r), (s4[p + 2][:3], s4[p + 3][:3]))):
+                assert np.all(blo <= lo) and np.all(bhi >= hi) and np.array_equal(blo, lo) and np.array_equal(bhi, hi), f"node {p}: box is not the tight union"
+            return np.minimum(lo_l, lo_r), np.maximum(hi_l, hi_r)
+        lo, hi = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+        while True:
+            e = s4[p].view(np.uint32)
+            v = tri[e[1]][[0, 3, 6], :3]
+            lo, hi = np.minimum(lo, v.min(0)), np.maximum(hi, v.max(0))
+            if not e[0] & 1:
+                return lo, hi
+            p += 1
+    import sys
+    sys.setrecursionlimit(10000)
+    box_of(0)
+    # anything but a move rebuilds: a material turning Blend changes leaf flags, a removed instance changes the leaves
+    from strolle_amd import Material
+    for e in (prod, orac):
+        e.insert_material(1, Material(base_color=[1, 1, 1, 0.5], alpha_mode=1))
+        e.insert_instance(8, Instance(8, 1 + int(npz["material_7"]), np.ascontiguousarray(npz["xform_7"].reshape(4, 3).T, np.float32)))
+        e.tick()
+    assert_bits_equal(prod.read_scene(0), orac.read_scene(0), "after a material change")
+    assert prod.bvh_refits() == orac.bvh_refits() == (2, 4)
+    for e in (prod, orac):
+        e.remove_instance(8)
+        e.tick()
+    assert_bits_equal(prod.read_scene(0), orac.read_scene(0), "after a removal")
+    assert prod.bvh_refits() == orac.bvh_refits() == (3, 4)
+    # back in rebuild mode every change builds the tree a from-scratch build gives
+    x = np.ascontiguousarray(npz["xform_0"].reshape(4, 3).T, np.float32)
+    for e in (prod, orac, fresh):
+        e.set_bvh_refresh(False) if e is not fresh else None
+        e.remove_instance(8)
+        e.insert_material(1, Material(base_color=[1, 1, 1, 0.5], alpha_mode=1))
+        e.insert_instance(1, Instance(1, 1 + int(npz["material_0"]), x))
+        e.tick()
+    assert_bits_equal(prod.read_scene(0), fresh.read_scene(0), "rebuild mode again: product vs an engine that never refitted")
+    assert_bits_equal(prod.read_scene(0), orac.read_scene(0), "rebuild mode again: product vs oracle")
+
+
 def test_atlas_rectangles_are_released_and_reused():
     """images.rs:54-113: an image that is removed, or comes back with another size, gives its rectangle back. Rectangles of
     live images never overlap, stay inside the 8192 x 8192 atlas, and churn far beyond the atlas area never runs out of

@@ -652,3 +652,42 @@ def test_output_formats_bit_exact(fmt):
     out32 = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
     img, ref = _step(torch, prod, orac, desc, cp, co, out32)
     assert_bits_equal(img, ref, "RGBA32F after switching back")
+
+
+@pytest.mark.gpu
+def test_bvh_refit_mode_renders_bit_exact():
+    """ST_BVH_REFIT with instances moving every frame: the tree of frame 0 is refitted, never rebuilt, and only the moved
+    triangles travel to the device — heatmap integers, every Image-mode plane and the frame must still equal the oracle's,
+    which refits its own tree. A removal then forces a rebuild, after which refitting resumes."""
+    torch = _torch()
+    import math
+    from strolle_amd import Instance
+    size = (144, 96)
+    prod, orac = Engine(device=0), OracleEngine()
+    for e in (prod, orac):
+        scenes.build_random_soup(e, 2400, seed=23, n_lights=3); e.set_seed(4); e.set_bvh_refresh(True)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    heat = scenes.cornell_camera(size, CameraMode.BVH_HEATMAP)
+    cp, co = prod.create_camera(desc), orac.create_camera(desc)
+    hp, ho = prod.create_camera(heat), orac.create_camera(heat)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    out_h = torch.zeros_like(out)
+    stream = torch.cuda.current_stream().cuda_stream
+    for frame in range(8):
+        ang = 0.05 * frame
+        rot = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]], np.float32)
+        for e in (prod, orac):
+            if frame >= 1:
+                e.insert_instance(2, Instance(2, 2, np.concatenate([rot * np.float32(1.1), np.array([[0.03 * frame], [0.0], [0.01 * frame]], np.float32)], axis=1)))
+                e.insert_instance(3, Instance(3, 3, np.concatenate([rot.T * np.float32(1.2), np.array([[0.0], [0.02 * frame], [0.0]], np.float32)], axis=1)))
+            if frame == 5:
+                e.remove_instance(4)
+        prod.update_camera(cp, desc); orac.update_camera(co, desc)
+        prod.tick(stream); orac.tick()
+        prod.render_camera(cp, out.data_ptr(), stream); prod.render_camera(hp, out_h.data_ptr(), stream)
+        ref = orac.render_camera(co); orac.render_camera(ho)
+        torch.cuda.synchronize()
+        assert np.array_equal(prod.read_buffer(hp, Buffer.DBG_USED_MEMORY), orac.read_buffer(ho, Buffer.DBG_USED_MEMORY)), f"refit frame {frame}: used_memory"
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(out.cpu().numpy(), ref, f"refit frame {frame}")
+    assert prod.bvh_refits() == orac.bvh_refits() == (2, 6)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Frame time with a scene that changes every frame (stress-bvh.rs style): one dungeon instance is re-inserted with a nudged
 transform before every tick, so each frame pays the host refresh (bake, BVH rebuild, flatten, upload) + the render.
-  python tools/animated_cost.py [--subdivide K] [--frames N]"""
+  python tools/animated_cost.py [--subdivide K] [--frames N] [--refit]"""
 import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,9 +11,11 @@ from strolle_amd import CameraMode, Engine, Instance, scenes
 ap = argparse.ArgumentParser()
 ap.add_argument("--subdivide", type=int, default=0)
 ap.add_argument("--frames", type=int, default=60)
+ap.add_argument("--refit", action="store_true", help="ST_BVH_REFIT: refit the tree instead of rebuilding it")
 args = ap.parse_args()
 e = Engine(device=0)
 scenes.build_dungeon(e, subdivide=args.subdivide)
+e.set_bvh_refresh(args.refit)
 size = (1920, 1080)
 desc = scenes.dungeon_camera(size, CameraMode.IMAGE)
 cam = e.create_camera(desc)
@@ -31,4 +33,4 @@ for animate in (False, True):
     torch.cuda.synchronize(); t = time.perf_counter()
     for i in range(args.frames): frame(i, animate)
     torch.cuda.synchronize()
-    print(f"subdivide={args.subdivide} animate={animate}: {(time.perf_counter() - t) / args.frames * 1e3:.3f} ms/frame")
+    print(f"subdivide={args.subdivide} refit={args.refit} animate={animate}: {(time.perf_counter() - t) / args.frames * 1e3:.3f} ms/frame")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host cost of Engine::tick when the scene changes every frame (the stress-bvh.rs situation): one instance of the
 dungeon is nudged per tick, which re-bakes it and rebuilds + re-flattens + re-uploads the BVH.
-  python tools/tick_cost.py [--device 0|-1] [--subdivide K]"""
+  python tools/tick_cost.py [--device 0|-1] [--subdivide K] [--refit]   (--refit: ST_BVH_REFIT, boxes refitted instead of a rebuild)"""
 import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,9 +11,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--device", type=int, default=-1)
 ap.add_argument("--subdivide", type=int, default=0)
 ap.add_argument("--ticks", type=int, default=20)
+ap.add_argument("--refit", action="store_true")
 args = ap.parse_args()
 e = Engine(device=args.device)
 scenes.build_dungeon(e, subdivide=args.subdivide)
+e.set_bvh_refresh(args.refit)
 e.tick()
 npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
 base = npz["xform_0"].reshape(4, 3).T.copy()
@@ -24,4 +26,4 @@ for i in range(args.ticks):
     e.insert_instance(1, Instance(1, mat, x))
     t = time.perf_counter(); e.tick(); ts.append(time.perf_counter() - t)
 tris = e.read_scene(1).nbytes // 144
-print(f"device={args.device} triangles={tris}: tick with one moved instance: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms")
+print(f"device={args.device} triangles={tris} refit={args.refit} (rebuilds, refits)={e.bvh_refits()}: tick with one moved instance: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms")
