@@ -360,3 +360,22 @@ def test_random_edit_sequences_keep_host_state_equal_to_oracle(seed):
             for what, name in enumerate(["bvh stream", "triangles", "lights", "materials"]):
                 assert_bits_equal(prod.read_scene(what), orac.read_scene(what), f"seed {seed} step {step}: {name}")
             assert prod.world() == orac.world(), f"seed {seed} step {step}: world"
+
+
+def _compile_example(out_path):
+    import subprocess
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "examples", "render_gltf.c"), "-L", os.path.dirname(LIB_PATH), "-lstrolle_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + os.path.dirname(LIB_PATH), "-o", out_path]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
+def test_header_is_c99_and_the_c_example_links(tmp_path):
+    """include/strolle_hip.h is a C header (the cgo / bindgen / ctypes side reads it as C): a strict C99 translation unit
+    that includes it, and the C example that drives the whole ABI, must compile without warnings and link."""
+    import subprocess
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "strolle_hip.h"\nint main(void) { StCamera c; StGltfOptions o; (void)c; (void)o; return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(probe), "-o", str(tmp_path / "probe.o")],
+                   check=True, capture_output=True, text=True)
+    _compile_example(str(tmp_path / "render_gltf"))
