@@ -12,13 +12,13 @@
  * st_render_camera enqueues is complete once the `hipStream_t` it was given (0 = the null
  * stream) has drained — the engine may run part of a frame on an internal side stream, but
  * joins it into the caller's stream before the frame's last kernel. Frames may be enqueued
- * back to back without host synchronisation. st_tick uploads on the stream it was given
- * and returns after they have landed.
+ * back to back without host synchronisation. st_tick queues its uploads on the stream it was given (from
+ * page-locked copies, so the scene may be edited again as soon as it returns); st_render_camera orders itself behind them.
  * Environment switches (read once per engine; every combination renders the same bits): ST_NO_OVERLAP=1
  * single stream; ST_NO_FUSE=1 one launch per reference pass (ST_NO_FUSE_SPATIAL / _DI_HEAD /
  * _GI_REPROJECTION=1 undo one fusion); ST_TILE_MAP=0|1|2 and ST_TILE_MAP_DENOISE block->tile mapping;
- * ST_FUSE_COMPOSE=1; ST_COMPACT=1 compacted shadow-ray kernel; ST_NO_PACKED_BASE=1; ST_TICK_TIMING=1
- * host refresh timing on stderr.
+ * ST_FUSE_COMPOSE=1; ST_COMPACT=1 compacted shadow-ray kernel; ST_NO_PACKED_BASE=1; ST_NO_STAGING=1 st_tick uploads from
+ * pageable memory and joins its stream; ST_TICK_TIMING=1 host refresh timing on stderr.
  */
 #ifndef STROLLE_HIP_H
 #define STROLLE_HIP_H

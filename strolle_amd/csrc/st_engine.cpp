@@ -145,20 +145,84 @@ struct SlotRanges {  // utils/allocator.rs
     }
 };
 
+// Pinned staging for the uploads of st_tick: what a tick sends is copied into one slot of page-locked memory and goes to
+// the device from there, so st_tick does not have to wait for the stream before the caller may touch the scene again —
+// with a scene that changes every frame the host then runs a frame ahead of the GPU instead of in lock-step with it.
+// Three slots: a slot is reused only after the copies issued from it have finished (its event).
+struct StagingRing {
+    static constexpr int kSlots = 3;
+    static constexpr size_t kMaxSlotBytes = (size_t)256 << 20;  // larger ticks go from pageable memory and join the stream
+    struct Slot { char* mem = nullptr; size_t capacity = 0, used = 0; hipEvent_t done = nullptr; bool pending = false; };
+    Slot slots[kSlots];
+    int cur = 0;
+    size_t wanted = 0;   // bytes the last tick asked for: the next slot is grown to hold that much
+    bool enabled = true;
+
+    void begin_tick() {
+        if (!enabled) return;
+        cur = (cur + 1) % kSlots;
+        Slot& s = slots[cur];
+        if (s.pending) { (void)hipEventSynchronize(s.done); s.pending = false; }
+        s.used = 0;
+        const size_t want = std::min(kMaxSlotBytes, std::max<size_t>(wanted + wanted / 4, (size_t)1 << 20));
+        if (s.capacity < want) {
+            if (s.mem) (void)hipHostFree(s.mem);
+            s.mem = nullptr; s.capacity = 0;
+            void* m = nullptr;
+            if (hipHostMalloc(&m, want, hipHostMallocDefault) == hipSuccess) { s.mem = static_cast<char*>(m); s.capacity = want; }
+            else (void)hipGetLastError();
+        }
+        wanted = 0;
+    }
+    // a page-locked copy of [src, src + bytes), or nullptr when the slot cannot take it (the caller then uploads from `src`
+    // and joins the stream)
+    const void* stage(const void* src, size_t bytes) {
+        wanted += (bytes + 255) & ~(size_t)255;
+        if (!enabled) return nullptr;
+        Slot& s = slots[cur];
+        const size_t at = (s.used + 255) & ~(size_t)255;
+        if (!s.mem || at + bytes > s.capacity) return nullptr;
+        memcpy(s.mem + at, src, bytes);
+        s.used = at + bytes;
+        return s.mem + at;
+    }
+    int end_tick(hipStream_t stream) {
+        if (!enabled) return ST_OK;
+        Slot& s = slots[cur];
+        if (s.used == 0) return ST_OK;
+        if (!s.done) ST_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        ST_HIP(hipEventRecord(s.done, stream));
+        s.pending = true;
+        return ST_OK;
+    }
+    void release() {
+        for (Slot& s : slots) {
+            if (s.pending) (void)hipEventSynchronize(s.done);
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.mem) (void)hipHostFree(s.mem);
+            s = Slot();
+        }
+    }
+};
+
 struct DeviceArray {
     void* ptr = nullptr; size_t capacity = 0;
-    int upload(const void* src, size_t bytes, hipStream_t stream) {
+    // `pageable` is set when the copy had to be issued straight from `src`: the caller joins the stream before `src` changes
+    int upload(const void* src, size_t bytes, hipStream_t stream, StagingRing& ring, bool* pageable) {
         if (bytes > capacity) {
             if (ptr) ST_HIP(hipFree(ptr));
             capacity = std::max<size_t>(bytes * 3 / 2, 4096);
             ST_HIP(hipMalloc(&ptr, capacity));
         }
-        if (bytes) ST_HIP(hipMemcpyAsync(ptr, src, bytes, hipMemcpyHostToDevice, stream));
-        return ST_OK;
+        return upload_range(src, 0, bytes, stream, ring, pageable);
     }
     // part of an array that is already on the device: bytes [offset, offset + bytes) of `base`
-    int upload_range(const void* base, size_t offset, size_t bytes, hipStream_t stream) {
-        if (bytes) ST_HIP(hipMemcpyAsync(static_cast<char*>(ptr) + offset, static_cast<const char*>(base) + offset, bytes, hipMemcpyHostToDevice, stream));
+    int upload_range(const void* base, size_t offset, size_t bytes, hipStream_t stream, StagingRing& ring, bool* pageable) {
+        if (!bytes) return ST_OK;
+        const void* src = static_cast<const char*>(base) + offset;
+        const void* staged = ring.stage(src, bytes);
+        if (!staged) *pageable = true;
+        ST_HIP(hipMemcpyAsync(static_cast<char*>(ptr) + offset, staged ? staged : src, bytes, hipMemcpyHostToDevice, stream));
         return ST_OK;
     }
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; capacity = 0; }
@@ -244,7 +308,9 @@ struct Engine {
     // (images.rs:187-213). std::map: copies are issued in handle order.
     struct DeviceImage { const void* pixels; size_t pitch; bool dynamic, pending; };
     std::map<uint64_t, DeviceImage> device_images;
-    bool atlas_copy_in_flight = false;  // a tick queued device-to-device atlas copies that the next frame's side stream must wait for
+    StagingRing staging;
+    // a tick queued copies without joining the stream: ev_tick marks their end, the next frame's streams wait for it
+    bool tick_work_in_flight = false; hipEvent_t ev_tick = nullptr;
 
     // lights (lights.rs): slot 0 is the sun
     std::vector<GpuLight> light_buffer; std::map<int64_t, uint32_t> light_slot;
@@ -295,6 +361,7 @@ struct Engine {
         if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* fc = getenv("ST_FUSE_COMPOSE")) fuse_compose = atoi(fc) != 0;
+        if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
         if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
     }
     void reset_profile_totals() {
@@ -308,11 +375,12 @@ struct Engine {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         for (auto& kv : cameras) release_camera(*kv.second);
-        for (DeviceArray* d : {&d_bvh, &d_tri_geo, &d_tri_attr, &d_materials, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
+        for (DeviceArray* d : {&d_byte_luts, &d_bvh, &d_tri_geo, &d_tri_attr, &d_instance_xforms, &d_materials, &d_material_base_packed, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
         for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
         if (side_stream) (void)hipStreamDestroy(side_stream);
-        for (hipEvent_t e : {ev_di_head, ev_gi_done, ev_prim_ok, ev_frame_done, ev_setup}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_di_head, ev_gi_done, ev_prim_ok, ev_frame_done, ev_setup, ev_tick}) if (e) (void)hipEventDestroy(e);
+        staging.release();
     }
     static void release_camera(CameraState& c) { if (c.slab) (void)hipFree(c.slab); if (c.counters) (void)hipFree(c.counters); c.slab = nullptr; c.counters = nullptr; }
 
@@ -562,27 +630,30 @@ struct Engine {
         snapshot_lights();
         if (has_device) {
             ST_HIP(hipSetDevice(device));
+            tick_work_in_flight = false;
+            bool pageable = false;  // some copy of this tick reads pageable host memory (or writes it): join the stream before returning
+            staging.begin_tick();
             if (scene_changed || !scene_uploaded) {
                 int rc;
-                if ((rc = d_bvh.upload(bvh_stream.data(), bvh_stream.size() * sizeof(float4), stream))) return rc;
+                if ((rc = d_bvh.upload(bvh_stream.data(), bvh_stream.size() * sizeof(float4), stream, staging, &pageable))) return rc;
                 // triangle arrays: whole on the first upload or after they grew, otherwise only the slots baked since
                 const bool partial = scene_uploaded && !tri_arrays_resized && d_tri_geo.capacity >= tri_geo.size() * sizeof(float4) && d_tri_attr.capacity >= tri_attr.size() * sizeof(float4);
                 if (!partial) {
-                    if ((rc = d_tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), stream))) return rc;
-                    if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream))) return rc;
+                    if ((rc = d_tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), stream, staging, &pageable))) return rc;
+                    if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream, staging, &pageable))) return rc;
                 } else if (dirty_lo < dirty_hi) {
-                    if ((rc = d_tri_geo.upload_range(tri_geo.data(), 3 * dirty_lo * sizeof(float4), 3 * (dirty_hi - dirty_lo) * sizeof(float4), stream))) return rc;
-                    if ((rc = d_tri_attr.upload_range(tri_attr.data(), 4 * dirty_lo * sizeof(float4), 4 * (dirty_hi - dirty_lo) * sizeof(float4), stream))) return rc;
+                    if ((rc = d_tri_geo.upload_range(tri_geo.data(), 3 * dirty_lo * sizeof(float4), 3 * (dirty_hi - dirty_lo) * sizeof(float4), stream, staging, &pageable))) return rc;
+                    if ((rc = d_tri_attr.upload_range(tri_attr.data(), 4 * dirty_lo * sizeof(float4), 4 * (dirty_hi - dirty_lo) * sizeof(float4), stream, staging, &pageable))) return rc;
                 }
                 dirty_lo = SIZE_MAX; dirty_hi = 0; tri_arrays_resized = false;
-                if ((rc = d_instance_xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), stream))) return rc;
-                if ((rc = d_materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), stream))) return rc;
-                if ((rc = d_material_base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), stream))) return rc;
+                if ((rc = d_instance_xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), stream, staging, &pageable))) return rc;
+                if ((rc = d_materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), stream, staging, &pageable))) return rc;
+                if ((rc = d_material_base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), stream, staging, &pageable))) return rc;
                 scene_uploaded = true;
                 scene_changed = true;  // forces the stream sync below
             }
-            bool misc_uploaded = atlas_dirty || blue_noise_dirty;
-            if (atlas_dirty) { int rc = d_atlas.upload(atlas.data(), atlas.size(), stream); if (rc) return rc; }
+            bool misc_uploaded = atlas_dirty || blue_noise_dirty, uploaded_device_images = false;
+            if (atlas_dirty) { int rc = d_atlas.upload(atlas.data(), atlas.size(), stream, staging, &pageable); if (rc) return rc; }
             for (auto& kv : device_images) {
                 DeviceImage& di = kv.second;
                 if (!di.pending && !di.dynamic) continue;
@@ -591,23 +662,31 @@ struct Engine {
                 ST_HIP(hipMemcpy2DAsync(dst, (size_t)atlas_w * 4, di.pixels, di.pitch, (size_t)r.w * 4, r.h, hipMemcpyDeviceToDevice, stream));
                 if (!di.dynamic) {  // keep the host copy complete: it is what a later full upload sends
                     ST_HIP(hipMemcpy2DAsync(&atlas[((size_t)r.y * atlas_w + r.x) * 4], (size_t)atlas_w * 4, di.pixels, di.pitch, (size_t)r.w * 4, r.h, hipMemcpyDeviceToHost, stream));
-                    misc_uploaded = true;  // joins the stream below before the host copy is read again
+                    misc_uploaded = true; pageable = true;  // joins the stream below before the host copy is read again
                 }
                 di.pending = false;
-                atlas_copy_in_flight = true;
+                uploaded_device_images = true;
             }
-            if (blue_noise_dirty) { int rc = d_blue_noise.upload(blue_noise.data(), blue_noise.size(), stream); if (rc) return rc; blue_noise_dirty = false; }
-            bool uploaded = scene_changed || misc_uploaded;
+            if (blue_noise_dirty) { int rc = d_blue_noise.upload(blue_noise.data(), blue_noise.size(), stream, staging, &pageable); if (rc) return rc; blue_noise_dirty = false; }
+            bool uploaded = scene_changed || misc_uploaded || uploaded_device_images;
             // lights change rarely; skipping the identical re-upload also skips the stream sync below, so the host can
             // run a frame ahead of the GPU (the reference re-uploads only dirty buffers too: mapped_storage_buffer.rs:103-121)
             if (gpu_lights.size() != uploaded_lights.size() || memcmp(gpu_lights.data(), uploaded_lights.data(), gpu_lights.size() * sizeof(GpuLight)) != 0) {
-                int rc = d_lights.upload(gpu_lights.data(), gpu_lights.size() * sizeof(GpuLight), stream);
+                int rc = d_lights.upload(gpu_lights.data(), gpu_lights.size() * sizeof(GpuLight), stream, staging, &pageable);
                 if (rc) return rc;
                 uploaded_lights = gpu_lights;
                 uploaded = true;
             }
-            // host vectors may be touched again before async copies from pageable memory land
-            if (uploaded || sync_every_tick) ST_HIP(hipStreamSynchronize(stream));
+            if (int rc = staging.end_tick(stream)) return rc;
+            // What was uploaded went through page-locked staging, so the caller may change the scene again at once; the next
+            // frame's side stream is ordered behind these copies by an event (render). Only copies that touch pageable
+            // host memory directly (staging full or disabled) make the tick wait for the stream.
+            if (uploaded) {
+                if (!ev_tick) ST_HIP(hipEventCreateWithFlags(&ev_tick, hipEventDisableTiming));
+                ST_HIP(hipEventRecord(ev_tick, stream));
+                tick_work_in_flight = true;
+            }
+            if ((uploaded && pageable) || sync_every_tick) ST_HIP(hipStreamSynchronize(stream));
         }
         atlas_dirty = false;
         for (auto& kv : cameras) kv.second->frame = frame;  // CameraController::flush
@@ -677,6 +756,7 @@ struct Engine {
         if (!has_device) return fail(ST_ERR_NO_DEVICE, "render_camera on a host-only engine");
         if (!scene_uploaded) return fail(ST_ERR_INVALID_ARGUMENT, "st_tick must precede st_render_camera");
         ST_HIP(hipSetDevice(device));
+        if (tick_work_in_flight) ST_HIP(hipStreamWaitEvent(stream, ev_tick, 0));  // a no-op when st_tick ran on this stream
         const bool alt = c.frame % 2u == 1u;
         KArgs a{};
         a.cam = c.curr; a.prev_cam = c.prev;
@@ -873,8 +953,10 @@ struct Engine {
                 // LUT generation issued on `stream` in this call must precede the side stream's consumers. (Do NOT do this
                 // unconditionally: an event recorded on `stream` here completes only after frame N's denoiser, which would
                 // serialise prim(N+1) behind it. Uploads in st_tick are followed by a host-side stream sync.)
-                if (luts_generated_now || atlas_copy_in_flight) { ST_HIP(hipEventRecord(ev_setup, stream)); ST_HIP(hipStreamWaitEvent(side_stream, ev_setup, 0)); }
-                atlas_copy_in_flight = false;  // dynamic images (copied by st_tick without a host sync) cost the prim(N+1) / denoiser(N) overlap
+                if (luts_generated_now) { ST_HIP(hipEventRecord(ev_setup, stream)); ST_HIP(hipStreamWaitEvent(side_stream, ev_setup, 0)); }
+                // copies st_tick queued without joining the stream (staged uploads, dynamic images): they sit behind frame N on
+                // the tick's stream, so a frame that follows a scene change gives up the prim(N+1) / denoiser(N) overlap
+                if (tick_work_in_flight) ST_HIP(hipStreamWaitEvent(side_stream, ev_tick, 0));
                 if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_prim_ok, 0));
                 cur = side_stream;
                 do_prim();

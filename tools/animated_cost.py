@@ -23,14 +23,17 @@ out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
 stream = torch.cuda.current_stream().cuda_stream
 npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
 base = npz["xform_0"].reshape(4, 3).T.copy(); mat = 1 + int(npz["material_0"])
+in_tick = [0.0]
 def frame(i, animate):
     if animate:
         x = base.copy(); x[0, 3] += 0.0005 * ((i % 20) - 10)
         e.insert_instance(1, Instance(1, mat, x))
-    e.update_camera(cam, desc); e.tick(stream); e.render_camera(cam, out.data_ptr(), stream)
+    e.update_camera(cam, desc)
+    t = time.perf_counter(); e.tick(stream); in_tick[0] += time.perf_counter() - t
+    e.render_camera(cam, out.data_ptr(), stream)
 for animate in (False, True):
     for i in range(12): frame(i, animate)
-    torch.cuda.synchronize(); t = time.perf_counter()
+    torch.cuda.synchronize(); t = time.perf_counter(); in_tick[0] = 0.0
     for i in range(args.frames): frame(i, animate)
     torch.cuda.synchronize()
-    print(f"subdivide={args.subdivide} refit={args.refit} animate={animate}: {(time.perf_counter() - t) / args.frames * 1e3:.3f} ms/frame")
+    print(f"subdivide={args.subdivide} refit={args.refit} animate={animate}: {(time.perf_counter() - t) / args.frames * 1e3:.3f} ms/frame, of which the host spends {in_tick[0] / args.frames * 1e3:.3f} ms inside st_tick")
