@@ -295,8 +295,6 @@ struct Engine {
     bool have_topology = false; uint64_t topology_signature = 0;
     std::vector<uint32_t> internal_positions;  // stream offsets of the internal nodes, ascending (parents before children)
     uint64_t refits = 0, rebuilds = 0;
-    // triangle slots baked since the last upload: only that range of tri_geo / tri_attr has to travel
-    size_t dirty_lo = SIZE_MAX, dirty_hi = 0; bool tri_arrays_resized = false;
 
     // images: a single linear RGBA8 atlas of the reference's extent (images.rs:28-29); rectangles from st_atlas.h
     static constexpr uint32_t kAtlasW = 8192, kAtlasMaxH = 8192;
@@ -324,7 +322,19 @@ struct Engine {
     std::vector<uint8_t> blue_noise; bool blue_noise_dirty = true;
     bool atmosphere_initialized = false, sky_known = false; float known_sun_altitude = 0.0f;  // passes/atmosphere.rs:14-15,78-110
 
-    DeviceArray d_byte_luts, d_bvh, d_tri_geo, d_tri_attr, d_instance_xforms, d_materials, d_material_base_packed, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
+    DeviceArray d_byte_luts, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
+    // The arrays a scene change rewrites exist twice. A tick that changes the scene fills the copy no frame in flight reads,
+    // on a stream of its own, while the previous frame still renders from the other one; the next frame switches over.
+    // (Updating in place would have to wait for the previous frame, and the next frame's primary rays with it.)
+    struct SceneSet {
+        DeviceArray bvh, tri_geo, tri_attr, xforms, materials, base_packed;
+        size_t dirty_lo = SIZE_MAX, dirty_hi = 0; bool tri_full = true;  // what this copy lacks of the host's triangle arrays
+        hipEvent_t free_ev = nullptr; bool busy = false;  // busy: frames reading this copy were enqueued since it was written; free_ev ends the last
+        bool valid = false;
+    };
+    SceneSet sets[2]; int live = 0;
+    bool double_buffer = true, alternating = false, mixed_render_streams = false;
+    hipStream_t copy_stream = nullptr, last_render_stream = nullptr; hipEvent_t ev_copy = nullptr; bool copy_in_flight = false;
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
@@ -362,6 +372,7 @@ struct Engine {
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* fc = getenv("ST_FUSE_COMPOSE")) fuse_compose = atoi(fc) != 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
+        if (const char* nd = getenv("ST_NO_DOUBLE_BUFFER")) double_buffer = atoi(nd) == 0;
         if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
     }
     void reset_profile_totals() {
@@ -375,7 +386,13 @@ struct Engine {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         for (auto& kv : cameras) release_camera(*kv.second);
-        for (DeviceArray* d : {&d_byte_luts, &d_bvh, &d_tri_geo, &d_tri_attr, &d_instance_xforms, &d_materials, &d_material_base_packed, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
+        for (DeviceArray* d : {&d_byte_luts, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
+        for (SceneSet& t : sets) {
+            for (DeviceArray* d : {&t.bvh, &t.tri_geo, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed}) d->release();
+            if (t.free_ev) (void)hipEventDestroy(t.free_ev);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (ev_copy) (void)hipEventDestroy(ev_copy);
         for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
         if (side_stream) (void)hipStreamDestroy(side_stream);
@@ -520,10 +537,10 @@ struct Engine {
             else if (!triangle_free.take(count, &b, &e)) {
                 b = triangles.size(); e = b + count;
                 triangles.resize(e); prims.resize(e); prim_alive.resize(e, 0); tri_geo.resize(3 * e); tri_attr.resize(4 * e);
-                tri_arrays_resized = true;
+                for (SceneSet& t : sets) t.tri_full = true;
             }
             for (size_t i = 0; i < count; i++) bake(mesh->second[i], inst, mat->second, b + i);
-            dirty_lo = std::min(dirty_lo, b); dirty_hi = std::max(dirty_hi, e);
+            for (SceneSet& t : sets) { t.dirty_lo = std::min(t.dirty_lo, b); t.dirty_hi = std::max(t.dirty_hi, e); }  // slots each device copy still has to receive
             instance_triangles[inst.id] = {b, e};
         }
         return true;
@@ -630,27 +647,49 @@ struct Engine {
         snapshot_lights();
         if (has_device) {
             ST_HIP(hipSetDevice(device));
-            tick_work_in_flight = false;
+            tick_work_in_flight = false; copy_in_flight = false;
             bool pageable = false;  // some copy of this tick reads pageable host memory (or writes it): join the stream before returning
             staging.begin_tick();
+            bool pageable_copy = false;
             if (scene_changed || !scene_uploaded) {
                 int rc;
-                if ((rc = d_bvh.upload(bvh_stream.data(), bvh_stream.size() * sizeof(float4), stream, staging, &pageable))) return rc;
-                // triangle arrays: whole on the first upload or after they grew, otherwise only the slots baked since
-                const bool partial = scene_uploaded && !tri_arrays_resized && d_tri_geo.capacity >= tri_geo.size() * sizeof(float4) && d_tri_attr.capacity >= tri_attr.size() * sizeof(float4);
+                // which copy, on which stream: the first upload and ST_NO_DOUBLE_BUFFER=1 write the live copy in place on the
+                // caller's stream (behind the frames queued there); every later change goes to the other copy on copy_stream
+                int target = live; hipStream_t up = stream; bool* flag = &pageable; bool other_copy = false;
+                if (double_buffer && scene_uploaded && !mixed_render_streams) {
+                    if (!copy_stream) { ST_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); ST_HIP(hipEventCreateWithFlags(&ev_copy, hipEventDisableTiming)); }
+                    if (!alternating) {  // frames enqueued so far read the live copy without marking their end: mark it now, behind them
+                        alternating = true;
+                        SceneSet& l = sets[live];
+                        if (!l.free_ev) ST_HIP(hipEventCreateWithFlags(&l.free_ev, hipEventDisableTiming));
+                        ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
+                    }
+                    target = live ^ 1; up = copy_stream; flag = &pageable_copy; other_copy = true;
+                    if (sets[target].busy) { ST_HIP(hipStreamWaitEvent(copy_stream, sets[target].free_ev, 0)); sets[target].busy = false; }
+                } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
+                SceneSet& t = sets[target];
+                if ((rc = t.bvh.upload(bvh_stream.data(), bvh_stream.size() * sizeof(float4), up, staging, flag))) return rc;
+                // triangle arrays: whole the first time or after they grew, otherwise only the slots baked since this copy was written
+                const bool partial = t.valid && !t.tri_full && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4) && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
                 if (!partial) {
-                    if ((rc = d_tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), stream, staging, &pageable))) return rc;
-                    if ((rc = d_tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), stream, staging, &pageable))) return rc;
-                } else if (dirty_lo < dirty_hi) {
-                    if ((rc = d_tri_geo.upload_range(tri_geo.data(), 3 * dirty_lo * sizeof(float4), 3 * (dirty_hi - dirty_lo) * sizeof(float4), stream, staging, &pageable))) return rc;
-                    if ((rc = d_tri_attr.upload_range(tri_attr.data(), 4 * dirty_lo * sizeof(float4), 4 * (dirty_hi - dirty_lo) * sizeof(float4), stream, staging, &pageable))) return rc;
+                    if ((rc = t.tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), up, staging, flag))) return rc;
+                    if ((rc = t.tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), up, staging, flag))) return rc;
+                } else if (t.dirty_lo < t.dirty_hi) {
+                    if ((rc = t.tri_geo.upload_range(tri_geo.data(), 3 * t.dirty_lo * sizeof(float4), 3 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
+                    if ((rc = t.tri_attr.upload_range(tri_attr.data(), 4 * t.dirty_lo * sizeof(float4), 4 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
                 }
-                dirty_lo = SIZE_MAX; dirty_hi = 0; tri_arrays_resized = false;
-                if ((rc = d_instance_xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), stream, staging, &pageable))) return rc;
-                if ((rc = d_materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), stream, staging, &pageable))) return rc;
-                if ((rc = d_material_base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), stream, staging, &pageable))) return rc;
+                t.dirty_lo = SIZE_MAX; t.dirty_hi = 0; t.tri_full = false; t.valid = true;
+                if ((rc = t.xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), up, staging, flag))) return rc;
+                if ((rc = t.materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), up, staging, flag))) return rc;
+                if ((rc = t.base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                if (other_copy) {
+                    ST_HIP(hipEventRecord(ev_copy, copy_stream));
+                    ST_HIP(hipStreamWaitEvent(stream, ev_copy, 0));  // the caller's stream: the next frame's kernels (and the staging slot's event) come after the copy
+                    copy_in_flight = true;
+                }
+                live = target;
                 scene_uploaded = true;
-                scene_changed = true;  // forces the stream sync below
+                scene_changed = !other_copy;  // in-place uploads count as work on the caller's stream below
             }
             bool misc_uploaded = atlas_dirty || blue_noise_dirty, uploaded_device_images = false;
             if (atlas_dirty) { int rc = d_atlas.upload(atlas.data(), atlas.size(), stream, staging, &pageable); if (rc) return rc; }
@@ -686,6 +725,7 @@ struct Engine {
                 ST_HIP(hipEventRecord(ev_tick, stream));
                 tick_work_in_flight = true;
             }
+            if (pageable_copy) ST_HIP(hipStreamSynchronize(copy_stream));
             if ((uploaded && pageable) || sync_every_tick) ST_HIP(hipStreamSynchronize(stream));
         }
         atlas_dirty = false;
@@ -757,11 +797,15 @@ struct Engine {
         if (!scene_uploaded) return fail(ST_ERR_INVALID_ARGUMENT, "st_tick must precede st_render_camera");
         ST_HIP(hipSetDevice(device));
         if (tick_work_in_flight) ST_HIP(hipStreamWaitEvent(stream, ev_tick, 0));  // a no-op when st_tick ran on this stream
+        if (copy_in_flight) ST_HIP(hipStreamWaitEvent(stream, ev_copy, 0));       // likewise (st_tick already queued this wait on its own stream)
+        if (last_render_stream && last_render_stream != stream) mixed_render_streams = true;
+        last_render_stream = stream;
         const bool alt = c.frame % 2u == 1u;
         KArgs a{};
         a.cam = c.curr; a.prev_cam = c.prev;
-        a.bvh = static_cast<const float4*>(d_bvh.ptr); a.tri_geo = static_cast<const float4*>(d_tri_geo.ptr); a.tri_attr = static_cast<const float4*>(d_tri_attr.ptr); a.instance_xforms = static_cast<const float4*>(d_instance_xforms.ptr);
-        a.materials = static_cast<const GpuMaterial*>(d_materials.ptr); a.material_base_packed = getenv("ST_NO_PACKED_BASE") ? nullptr : static_cast<const uint32_t*>(d_material_base_packed.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
+        const SceneSet& scene = sets[live];
+        a.bvh = static_cast<const float4*>(scene.bvh.ptr); a.tri_geo = static_cast<const float4*>(scene.tri_geo.ptr); a.tri_attr = static_cast<const float4*>(scene.tri_attr.ptr); a.instance_xforms = static_cast<const float4*>(scene.xforms.ptr);
+        a.materials = static_cast<const GpuMaterial*>(scene.materials.ptr); a.material_base_packed = getenv("ST_NO_PACKED_BASE") ? nullptr : static_cast<const uint32_t*>(scene.base_packed.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
         a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr); a.byte_luts = static_cast<const float*>(d_byte_luts.ptr);
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
         a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
@@ -957,6 +1001,7 @@ struct Engine {
                 // copies st_tick queued without joining the stream (staged uploads, dynamic images): they sit behind frame N on
                 // the tick's stream, so a frame that follows a scene change gives up the prim(N+1) / denoiser(N) overlap
                 if (tick_work_in_flight) ST_HIP(hipStreamWaitEvent(side_stream, ev_tick, 0));
+                if (copy_in_flight) ST_HIP(hipStreamWaitEvent(side_stream, ev_copy, 0));  // independent of frame N: the overlap stays
                 if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_prim_ok, 0));
                 cur = side_stream;
                 do_prim();
@@ -995,6 +1040,11 @@ struct Engine {
             const float4* di_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
             const float4* gi_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
             run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
+        }
+        if (alternating) {  // the end of the last frame that reads this copy of the scene
+            SceneSet& l = sets[live];
+            if (!l.free_ev) ST_HIP(hipEventCreateWithFlags(&l.free_ev, hipEventDisableTiming));
+            ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
         }
         ST_HIP(hipGetLastError());
         return ST_OK;
