@@ -616,6 +616,10 @@ static inline void pass_gi_sampling_b(const EngineView& e, CameraBuffers& b, boo
     b.ray_count += rays;
 }
 
+// Test-only knob (tests/test_oracle_semantics.py): the most neighbours the GI spatial and preview passes may merge. 8 is the
+// reference's constant; 0 leaves the sampling + temporal estimate untouched, which isolates the bias the neighbour merges add.
+static uint32_t g_debug_gi_neighbours = 8;
+
 // ---------------------------------------------------------------- gi_temporal_resampling.rs:3-156
 static inline void pass_gi_temporal_resampling(CameraBuffers& b, bool alt, uint32_t seed, Frame frame) {
     const Plane &cg0 = b.prim_gbuffer_d0[alt], &cg1 = b.prim_gbuffer_d1[alt], &pg0 = b.prim_gbuffer_d0[!alt], &pg1 = b.prim_gbuffer_d1[!alt];
@@ -686,7 +690,7 @@ static inline void pass_gi_spatial_pick(CameraBuffers& b, bool alt, uint32_t see
         GiReservoir lhs = GiReservoir::read(reservoirs, lhs_idx, n);
         if (lhs_hit.is_none() || lhs.is_empty()) { tex_write(buf_d1, b, buf_pos_a, Vec4()); tex_write(buf_d1, b, buf_pos_b, Vec4()); continue; }
         GiReservoir rhs; uint32_t rhs_nth = 0; size_t rhs_idx = 0; Hit rhs_hit; float rhs_jacobian = 0.0f;
-        const uint32_t max_samples = 8; float max_radius = 128.0f;
+        const uint32_t max_samples = g_debug_gi_neighbours < 8u ? g_debug_gi_neighbours : 8u; float max_radius = 128.0f;
         while (rhs_nth < max_samples) {
             rhs_nth += 1;
             UVec2 rhs_pos = b.curr_camera.contain(as_ivec2(as_vec2(lhs_pos) + wn.sample_disk() * max_radius));
@@ -773,6 +777,7 @@ static inline void pass_gi_preview_resampling(CameraBuffers& b, bool alt, uint32
         GiReservoir center = GiReservoir::read(in, center_idx, n);
         if (main.merge(wn, center, center.sample.pdf)) main_pdf = center.sample.pdf;
         uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main.m / 8.0f));
+        if (max_samples > g_debug_gi_neighbours) max_samples = g_debug_gi_neighbours;
         float max_radius = nth == 0 ? 128.0f : 64.0f;
         uint32_t sample_nth = 0;
         bool bail = false;

@@ -45,6 +45,7 @@ int or_material_has(OrEngine* e, uint64_t id) { return E(e)->material_index.coun
 int or_material_remove(OrEngine* e, uint64_t id) { E(e)->remove_material(id); return 0; }
 int or_image_insert_rgba8(OrEngine* e, uint64_t id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) { return E(e)->insert_image(id, w, h, rgba) ? 0 : 6; }
 int or_image_remove(OrEngine* e, uint64_t id) { E(e)->remove_image(id); return 0; }
+int or_debug_set_gi_neighbours(uint32_t n) { g_debug_gi_neighbours = n; return 0; }  // test-only, process-wide
 int or_set_bvh_refresh(OrEngine* e, int mode) { E(e)->bvh_refit_mode = mode == 1; return (mode == 0 || mode == 1) ? 0 : 1; }
 int or_debug_bvh_refits(OrEngine* e, uint64_t* rebuilds, uint64_t* refits) { *rebuilds = E(e)->rebuilds; *refits = E(e)->refits; return 0; }
 int or_debug_image_rect(OrEngine* e, uint64_t id, uint32_t out[4]) {

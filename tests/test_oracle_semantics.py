@@ -301,8 +301,8 @@ def test_direct_and_indirect_light_separately_against_the_path_tracer():
     materials are non-metallic, so both specular outputs are exactly zero: brdf.rs:47-49). Direct light is unbiased in the
     reference and lands within 1-2 %. ReSTIR GI is biased by construction — neighbours are merged without a visibility test
     in the spatial and preview passes, Jacobians and weights are clamped (gi_spatial_resampling.rs, gi_preview_resampling.rs:
-    `clamp(1/3, 3)`, `w.min(5)`) — and comes out 4-10 % brighter than one path-traced bounce; the bound below is what that
-    leaves room for, not more."""
+    `clamp(1/3, 3)`, `w.min(5)`) — and comes out 4-10 % brighter than one path-traced bounce; with those merges switched off
+    the same pipeline is within 3 % of it."""
     from oracle_binding import OracleEngine
     size = (96, 64)
 
@@ -334,6 +334,18 @@ def test_direct_and_indirect_light_separately_against_the_path_tracer():
     lum = lambda x: 0.2126 * x[..., 0] + 0.7152 * x[..., 1] + 0.0722 * x[..., 2]
     regions = lum(direct).reshape(4, 16, 4, 24).mean((1, 3)) / lum(depth0).reshape(4, 16, 4, 24).mean((1, 3))
     assert np.abs(regions - 1.0).max() < 0.12 and np.median(np.abs(regions - 1.0)) < 0.03, regions
-    indirect = gi_diffuse * albedo
-    ratio = indirect.mean((0, 1)) / (depth1 - depth0).mean((0, 1))
-    assert np.all(ratio > 0.95) and np.all(ratio < 1.2), f"one bounce, ReSTIR GI / path tracer: {ratio}"
+    bounce = (depth1 - depth0).mean((0, 1))
+    with_neighbours = (gi_diffuse * albedo).mean((0, 1)) / bounce
+    assert np.all(with_neighbours > 0.95) and np.all(with_neighbours < 1.2), f"one bounce, ReSTIR GI / path tracer: {with_neighbours}"
+    # where the excess comes from: with the neighbour merges of the spatial and preview passes switched off (an oracle-only
+    # test knob), what is left is candidate generation + temporal resampling, and that lands within a few percent
+    import ctypes
+    knob = oracle_lib().or_debug_set_gi_neighbours
+    try:
+        knob(ctypes.c_uint32(0))
+        alone, _ = run(CameraMode.GI_DIFFUSE, 96, 24)
+    finally:
+        knob(ctypes.c_uint32(8))
+    without_neighbours = (alone * albedo).mean((0, 1)) / bounce
+    assert np.all(np.abs(without_neighbours - 0.975) < 0.045), f"one bounce, sampling + temporal only / path tracer: {without_neighbours}"
+    assert np.all(with_neighbours > without_neighbours)
