@@ -322,7 +322,7 @@ struct Engine {
     std::vector<uint8_t> blue_noise; bool blue_noise_dirty = true;
     bool atmosphere_initialized = false, sky_known = false; float known_sun_altitude = 0.0f;  // passes/atmosphere.rs:14-15,78-110
 
-    DeviceArray d_byte_luts, d_lights, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
+    DeviceArray d_byte_luts, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
     // The arrays a scene change rewrites exist twice. A tick that changes the scene fills the copy no frame in flight reads,
     // on a stream of its own, while the previous frame still renders from the other one; the next frame switches over.
     // (Updating in place would have to wait for the previous frame, and the next frame's primary rays with it.)
@@ -333,6 +333,9 @@ struct Engine {
         bool valid = false;
     };
     SceneSet sets[2]; int live = 0;
+    // the light table alternates the same way, on its own schedule (a light that moves every frame does not resend the scene)
+    struct LightSet { DeviceArray buf; hipEvent_t free_ev = nullptr; bool busy = false; };
+    LightSet light_sets[2]; int live_lights = 0; bool lights_uploaded = false, lights_alternating = false;
     bool double_buffer = true, alternating = false, mixed_render_streams = false;
     hipStream_t copy_stream = nullptr, last_render_stream = nullptr; hipEvent_t ev_copy = nullptr; bool copy_in_flight = false;
 
@@ -386,7 +389,8 @@ struct Engine {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         for (auto& kv : cameras) release_camera(*kv.second);
-        for (DeviceArray* d : {&d_byte_luts, &d_lights, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
+        for (DeviceArray* d : {&d_byte_luts, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
+        for (LightSet& l : light_sets) { l.buf.release(); if (l.free_ev) (void)hipEventDestroy(l.free_ev); }
         for (SceneSet& t : sets) {
             for (DeviceArray* d : {&t.bvh, &t.tri_geo, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed}) d->release();
             if (t.free_ev) (void)hipEventDestroy(t.free_ev);
@@ -682,11 +686,7 @@ struct Engine {
                 if ((rc = t.xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), up, staging, flag))) return rc;
                 if ((rc = t.materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), up, staging, flag))) return rc;
                 if ((rc = t.base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), up, staging, flag))) return rc;
-                if (other_copy) {
-                    ST_HIP(hipEventRecord(ev_copy, copy_stream));
-                    ST_HIP(hipStreamWaitEvent(stream, ev_copy, 0));  // the caller's stream: the next frame's kernels (and the staging slot's event) come after the copy
-                    copy_in_flight = true;
-                }
+                if (other_copy) copy_in_flight = true;
                 live = target;
                 scene_uploaded = true;
                 scene_changed = !other_copy;  // in-place uploads count as work on the caller's stream below
@@ -711,10 +711,27 @@ struct Engine {
             // lights change rarely; skipping the identical re-upload also skips the stream sync below, so the host can
             // run a frame ahead of the GPU (the reference re-uploads only dirty buffers too: mapped_storage_buffer.rs:103-121)
             if (gpu_lights.size() != uploaded_lights.size() || memcmp(gpu_lights.data(), uploaded_lights.data(), gpu_lights.size() * sizeof(GpuLight)) != 0) {
-                int rc = d_lights.upload(gpu_lights.data(), gpu_lights.size() * sizeof(GpuLight), stream, staging, &pageable);
+                int target = live_lights; hipStream_t up = stream; bool* flag = &pageable; bool other_copy = false;
+                if (double_buffer && lights_uploaded && !mixed_render_streams) {
+                    if (!copy_stream) { ST_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); ST_HIP(hipEventCreateWithFlags(&ev_copy, hipEventDisableTiming)); }
+                    if (!lights_alternating) {  // as for the scene: the frames queued so far end here
+                        lights_alternating = true;
+                        LightSet& l = light_sets[live_lights];
+                        if (!l.free_ev) ST_HIP(hipEventCreateWithFlags(&l.free_ev, hipEventDisableTiming));
+                        ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
+                    }
+                    target = live_lights ^ 1; up = copy_stream; flag = &pageable_copy; other_copy = true;
+                    if (light_sets[target].busy) { ST_HIP(hipStreamWaitEvent(copy_stream, light_sets[target].free_ev, 0)); light_sets[target].busy = false; }
+                } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());
+                int rc = light_sets[target].buf.upload(gpu_lights.data(), gpu_lights.size() * sizeof(GpuLight), up, staging, flag);
                 if (rc) return rc;
+                live_lights = target; lights_uploaded = true;
                 uploaded_lights = gpu_lights;
-                uploaded = true;
+                if (other_copy) copy_in_flight = true; else uploaded = true;
+            }
+            if (copy_in_flight) {
+                ST_HIP(hipEventRecord(ev_copy, copy_stream));
+                ST_HIP(hipStreamWaitEvent(stream, ev_copy, 0));  // the caller's stream: the next frame's kernels (and the staging slot's event) come after the copies
             }
             if (int rc = staging.end_tick(stream)) return rc;
             // What was uploaded went through page-locked staging, so the caller may change the scene again at once; the next
@@ -805,7 +822,7 @@ struct Engine {
         a.cam = c.curr; a.prev_cam = c.prev;
         const SceneSet& scene = sets[live];
         a.bvh = static_cast<const float4*>(scene.bvh.ptr); a.tri_geo = static_cast<const float4*>(scene.tri_geo.ptr); a.tri_attr = static_cast<const float4*>(scene.tri_attr.ptr); a.instance_xforms = static_cast<const float4*>(scene.xforms.ptr);
-        a.materials = static_cast<const GpuMaterial*>(scene.materials.ptr); a.material_base_packed = getenv("ST_NO_PACKED_BASE") ? nullptr : static_cast<const uint32_t*>(scene.base_packed.ptr); a.lights = static_cast<const GpuLight*>(d_lights.ptr);
+        a.materials = static_cast<const GpuMaterial*>(scene.materials.ptr); a.material_base_packed = getenv("ST_NO_PACKED_BASE") ? nullptr : static_cast<const uint32_t*>(scene.base_packed.ptr); a.lights = static_cast<const GpuLight*>(light_sets[live_lights].buf.ptr);
         a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr); a.byte_luts = static_cast<const float*>(d_byte_luts.ptr);
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
         a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
@@ -1043,6 +1060,11 @@ struct Engine {
         }
         if (alternating) {  // the end of the last frame that reads this copy of the scene
             SceneSet& l = sets[live];
+            if (!l.free_ev) ST_HIP(hipEventCreateWithFlags(&l.free_ev, hipEventDisableTiming));
+            ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
+        }
+        if (lights_alternating) {
+            LightSet& l = light_sets[live_lights];
             if (!l.free_ev) ST_HIP(hipEventCreateWithFlags(&l.free_ev, hipEventDisableTiming));
             ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
         }

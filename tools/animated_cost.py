@@ -11,13 +11,15 @@ from strolle_amd import CameraMode, Engine, Instance, scenes
 ap = argparse.ArgumentParser()
 ap.add_argument("--subdivide", type=int, default=0)
 ap.add_argument("--frames", type=int, default=60)
+ap.add_argument("--light", action="store_true", help="move a light every frame instead of an instance (cornell.rs animates its light)")
+ap.add_argument("--cornell", action="store_true")
 ap.add_argument("--refit", action="store_true", help="ST_BVH_REFIT: refit the tree instead of rebuilding it")
 args = ap.parse_args()
 e = Engine(device=0)
-scenes.build_dungeon(e, subdivide=args.subdivide)
+scenes.build_cornell(e) if args.cornell else scenes.build_dungeon(e, subdivide=args.subdivide)
 e.set_bvh_refresh(args.refit)
 size = (1920, 1080)
-desc = scenes.dungeon_camera(size, CameraMode.IMAGE)
+desc = (scenes.cornell_camera if args.cornell else scenes.dungeon_camera)(size, CameraMode.IMAGE)
 cam = e.create_camera(desc)
 out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
 stream = torch.cuda.current_stream().cuda_stream
@@ -25,7 +27,12 @@ npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
 base = npz["xform_0"].reshape(4, 3).T.copy(); mat = 1 + int(npz["material_0"])
 in_tick = [0.0]
 def frame(i, animate):
-    if animate:
+    if animate and args.light:
+        import math
+        from strolle_amd import Light
+        t = 0.05 * i
+        e.insert_light(1, Light.point((math.sin(t) / 2, 1.5, math.cos(t) / 2) if args.cornell else (-3.0 + 0.2 * math.sin(t), 0.75, -23.0), 0.15, (50.0 / (4 * math.pi),) * 3 if args.cornell else (5000.0 / (4 * math.pi),) * 3, 20.0 if args.cornell else 35.0))
+    elif animate:
         x = base.copy(); x[0, 3] += 0.0005 * ((i % 20) - 10)
         e.insert_instance(1, Instance(1, mat, x))
     e.update_camera(cam, desc)
@@ -36,4 +43,4 @@ for animate in (False, True):
     torch.cuda.synchronize(); t = time.perf_counter(); in_tick[0] = 0.0
     for i in range(args.frames): frame(i, animate)
     torch.cuda.synchronize()
-    print(f"subdivide={args.subdivide} refit={args.refit} animate={animate}: {(time.perf_counter() - t) / args.frames * 1e3:.3f} ms/frame, of which the host spends {in_tick[0] / args.frames * 1e3:.3f} ms inside st_tick")
+    print(f"{'cornell' if args.cornell else 'dungeon'} subdivide={args.subdivide} refit={args.refit} animate={('light' if args.light else 'instance') if animate else False}: {(time.perf_counter() - t) / args.frames * 1e3:.3f} ms/frame, of which the host spends {in_tick[0] / args.frames * 1e3:.3f} ms inside st_tick")
