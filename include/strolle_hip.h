@@ -205,8 +205,8 @@ int st_debug_read_lut(StEngine* e, int what, float* out, size_t capacity_floats,
  * here it is a convenience layered on the entry points above and nothing else. One mesh + instance per triangle-list
  * primitive of the default scene, numbered in depth-first node order: mesh / instance handle = first_handle + i,
  * material handle = first_handle + material index, image handle = first_image_handle + image index. Materials follow
- * prepare.rs:132-175 (Opaque forces alpha 1, Mask becomes Blend with alpha 0/1, reflectance 0.5, ior 1). PNG textures
- * are decoded here (all colour types and bit depths, Adam7 too); JPEG, Draco and sparse accessors give
+ * prepare.rs:132-175 (Opaque forces alpha 1, Mask becomes Blend with alpha 0/1, reflectance 0.5, ior 1). PNG (all colour
+ * types and bit depths, Adam7 too) and JPEG textures are decoded here; KTX2 / WebP, Draco and sparse accessors give
  * ST_ERR_UNSUPPORTED. Host-only work: valid on host-only engines. */
 enum { ST_GLTF_OVERRIDE_REFLECTANCE = 1, ST_GLTF_OVERRIDE_PERCEPTUAL_ROUGHNESS = 2 };
 typedef struct StGltfOptions {
@@ -228,6 +228,9 @@ int st_scene_load_gltf_memory(StEngine* e, const void* bytes, size_t size, const
 /* PNG -> RGBA8 (straight alpha; 16-bit samples keep their high byte), the decoder the loader uses. out_rgba == NULL
  * only reports the size. */
 int st_decode_png(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height);
+/* The same for either of glTF's two image formats, told apart by signature: PNG, or JPEG (baseline, extended and
+ * progressive DCT; 8-bit; grey or three components). */
+int st_decode_image(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height);
 
 /* Per-kernel timing (HIP events recorded around every launch on the launch stream).
  * st_profile_read returns, per kernel slot i < *count: name, launches, total milliseconds,

@@ -502,8 +502,17 @@ class Engine(EngineBase):
 
 def decode_png(data: bytes) -> np.ndarray:
     """st_decode_png: PNG bytes -> [h, w, 4] uint8 (the decoder st_scene_load_gltf uses for textures)."""
+    return _decode(data, "st_decode_png")
+
+
+def decode_image(data: bytes) -> np.ndarray:
+    """st_decode_image: PNG or JPEG bytes -> [h, w, 4] uint8."""
+    return _decode(data, "st_decode_image")
+
+
+def _decode(data: bytes, symbol: str) -> np.ndarray:
     lib = load_library()
-    fn = lib.st_decode_png
+    fn = getattr(lib, symbol)
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     w, h = C.c_uint32(), C.c_uint32()

@@ -17,8 +17,8 @@
 //     reflectance 0.5 and ior 1 are Bevy's StandardMaterial defaults, emissive alpha 1;
 //   * missing normals become flat normals (bevy_gltf computes flat normals for such meshes); missing UVs / tangents
 //     are zero (prepare.rs:104-110 `unwrap_or_default`); tangents are not generated.
-// Not supported (reported as ST_ERR_UNSUPPORTED, never skipped silently): JPEG/KTX textures, sparse accessors, Draco /
-// meshopt compression. Point / line / strip / fan primitives are skipped and counted, as strolle only takes triangles.
+// Textures: PNG (decoder below) and JPEG (st_jpeg.h). Not supported (reported as ST_ERR_UNSUPPORTED, never skipped
+// silently): KTX2 / WebP textures, sparse accessors, Draco / meshopt compression. Point / line / strip / fan primitives are skipped and counted, as strolle only takes triangles.
 #include <charconv>
 #include <cmath>
 #include <cstdarg>
@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/strolle_hip.h"
+#include "st_jpeg.h"
 
 extern "C" int st_internal_fail(int status, const char* message);  // st_engine.cpp: records st_last_error()
 
@@ -614,6 +615,22 @@ Picture decode_png(const uint8_t* p, size_t n) {
     return pic;
 }
 
+// PNG or JPEG, by signature (glTF 2.0 allows exactly these two, section 3.8.3)
+Picture decode_image(const uint8_t* p, size_t n, const char* what) {
+    if (n >= 3 && p[0] == 0xFF && p[1] == 0xD8) {
+        try {
+            st_jpeg::Image j = st_jpeg::Decoder(p, n, kMaxImageSide).decode();
+            Picture pic;
+            pic.width = j.width; pic.height = j.height; pic.rgba.swap(j.rgba);
+            return pic;
+        } catch (const st_jpeg::Error& e) {
+            bad(e.unsupported ? ST_ERR_UNSUPPORTED : ST_ERR_PARSE, "%s: %s", what, e.message);
+        }
+    }
+    if (n >= 8 && p[0] == 0x89 && p[1] == 'P') return decode_png(p, n);
+    bad(ST_ERR_UNSUPPORTED, "%s: neither a PNG nor a JPEG (KTX2 / WebP / DDS textures are not read)", what);
+}
+
 // ------------------------------------------------------------------------------------------------ glTF
 struct Mat4d {
     double m[4][4];  // row-major, m[row][col]
@@ -886,8 +903,9 @@ struct Loader {
             }
         for (size_t i = 0; i < imgs->size(); i++) {
             const Bytes raw = image_bytes(doc, imgs->arr[i], i);
-            if (raw.size() >= 3 && raw[0] == 0xFF && raw[1] == 0xD8) bad(ST_ERR_UNSUPPORTED, "glTF: image %zu is a JPEG; only PNG is decoded here", i);
-            const Picture pic = decode_png(raw.data(), raw.size());
+            char what[32];
+            snprintf(what, sizeof what, "glTF image %zu", i);
+            const Picture pic = decode_image(raw.data(), raw.size(), what);
             const int srgb = (data_use[i] && !colour_use[i]) ? 0 : 1;
             const int rc = st_image_insert_rgba8(engine, opt.first_image_handle + i, pic.width, pic.height, pic.rgba.data(), srgb);
             if (rc == ST_ERR_ATLAS_FULL) { sum.images_dropped++; continue; }  // the reference warns and drops (images.rs:71-79)
@@ -1076,10 +1094,10 @@ int st_scene_load_gltf_memory(StEngine* e, const void* bytes, size_t size, const
     return load(e, (const uint8_t*)bytes, size, base_dir ? base_dir : "", options, summary);
 }
 
-int st_decode_png(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height) {
+static int decode_to(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height, bool png_only) {
     if (!bytes || !width || !height) return st_internal_fail(ST_ERR_INVALID_ARGUMENT, "null argument");
     try {
-        const Picture pic = decode_png((const uint8_t*)bytes, size);
+        const Picture pic = png_only ? decode_png((const uint8_t*)bytes, size) : decode_image((const uint8_t*)bytes, size, "image");
         *width = pic.width;
         *height = pic.height;
         if (!out_rgba) return ST_OK;  // size query
@@ -1089,8 +1107,14 @@ int st_decode_png(const void* bytes, size_t size, uint8_t* out_rgba, size_t capa
     } catch (const IngestError& err) {
         return st_internal_fail(err.status, err.message.c_str());
     } catch (const std::bad_alloc&) {
-        return st_internal_fail(ST_ERR_PARSE, "out of memory while decoding the PNG");
+        return st_internal_fail(ST_ERR_PARSE, "out of memory while decoding the image");
     }
+}
+int st_decode_png(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height) {
+    return decode_to(bytes, size, out_rgba, capacity, width, height, true);
+}
+int st_decode_image(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height) {
+    return decode_to(bytes, size, out_rgba, capacity, width, height, false);
 }
 
 }  // extern "C"

@@ -422,11 +422,14 @@ def test_loader_reports_errors_instead_of_guessing(tmp_path):
     doc["buffers"] = [{"byteLength": len(scene.bin), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(scene.bin)).decode()}]
     with pytest.raises(StrolleError, match="out of range"):
         e.load_gltf(json.dumps(doc).encode())
-    # JPEG textures are named, not skipped
+    # texture formats the loader does not read are named, not skipped
     doc = json.loads(json.dumps(scene.doc))
     doc["buffers"] = [{"byteLength": len(scene.bin), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(scene.bin)).decode()}]
-    doc["images"][1] = {"uri": "data:image/jpeg;base64," + base64.b64encode(b"\xff\xd8\xff\xe0" + bytes(32)).decode()}
-    with pytest.raises(StrolleError, match="status 9.*JPEG"):
+    doc["images"][1] = {"uri": "data:image/webp;base64," + base64.b64encode(b"RIFF\x24\x00\x00\x00WEBPVP8 " + bytes(24)).decode()}
+    with pytest.raises(StrolleError, match="status 9.*glTF image 1.*neither a PNG nor a JPEG"):
+        e.load_gltf(json.dumps(doc).encode())
+    doc["images"][1] = {"uri": "data:image/jpeg;base64," + base64.b64encode(b"\xff\xd8\xff\xe0" + bytes(32)).decode()}   # a JPEG in name only
+    with pytest.raises(StrolleError, match="status 8.*JPEG"):
         e.load_gltf(json.dumps(doc).encode())
     doc = json.loads(json.dumps(scene.doc))
     doc["extensionsRequired"] = ["KHR_draco_mesh_compression"]
@@ -494,3 +497,99 @@ def test_reference_assets_load_to_the_committed_conversions(tmp_path, name):
             view = doc["bufferViews"][image["bufferView"]]
             png = binary[view.get("byteOffset", 0): view.get("byteOffset", 0) + view["byteLength"]]
             assert np.array_equal(decode_png(png), converted[f"image_{i}"]), f"texture {i}"
+
+
+# ------------------------------------------------------------------------------------------------ JPEG
+def _test_picture(rng, w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 5.0), 128 + 90 * np.cos(x / 3.0 + y / 11.0), (x * 3 + y * 5) % 256], -1) + rng.normal(0, 12, (h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("progressive", [False, True])
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+def test_jpeg_decoder_matches_libjpeg_bit_for_bit(subsampling, progressive):
+    """st_jpeg.h follows the arithmetic every mainstream decoder shares (13-bit integer IDCT, triangle-filter chroma
+    upsampling, 16-bit fixed-point YCbCr -> RGB), so its output can be compared with libjpeg(-turbo) through PIL exactly:
+    baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0, optimised and default Huffman tables, restart intervals, sizes that
+    are not multiples of the MCU, single-pixel rows and columns, greyscale."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from strolle_amd.api import decode_image
+    rng = np.random.default_rng(10 * subsampling + progressive)
+    for (w, h) in ((64, 64), (33, 17), (1, 1), (7, 50), (200, 123), (3, 3), (2, 9), (17, 1)):
+        for quality, extra in ((30, {}), (92, dict(optimize=True)), (75, dict(restart_marker_blocks=2))):
+            for grey in (False, True):
+                a = _test_picture(rng, w, h)
+                img = Image.fromarray(a[..., 0] if grey else a)
+                kw = dict(quality=quality, progressive=progressive, **extra)
+                if not grey:
+                    kw["subsampling"] = subsampling
+                buf = io.BytesIO()
+                try:
+                    img.save(buf, "JPEG", **kw)
+                except TypeError:       # an older Pillow without restart_marker_blocks
+                    kw.pop("restart_marker_blocks", None); buf = io.BytesIO(); img.save(buf, "JPEG", **kw)
+                want = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGBA"), np.uint8)
+                got = decode_image(buf.getvalue())
+                assert np.array_equal(got, want), f"{w}x{h} q{quality} {extra} grey={grey}"
+
+
+def test_jpeg_textures_load_through_the_gltf_loader(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(8)
+    scene = SyntheticScene(seed=12)
+    jpegs = []
+    for i, (w, h) in enumerate(((24, 16), (9, 31))):
+        buf = io.BytesIO()
+        Image.fromarray(_test_picture(rng, w, h)).save(buf, "JPEG", quality=80, progressive=bool(i), subsampling=2 - i)
+        jpegs.append(buf.getvalue())
+        scene.textures_rgba[i] = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGBA"), np.uint8)
+    doc = scene.doc
+    view = doc["bufferViews"][doc["images"][0]["bufferView"]]
+    while len(scene.bin) % 4:
+        scene.bin.append(0)
+    view["byteOffset"], view["byteLength"] = len(scene.bin), len(jpegs[0])
+    scene.bin += jpegs[0]
+    doc["images"][0]["mimeType"] = "image/jpeg"
+    doc["images"][1] = {"uri": "data:image/jpeg;base64," + base64.b64encode(jpegs[1]).decode()}
+    path, _ = scene.write(str(tmp_path), glb=True)
+    a, b = Engine(device=-1), Engine(device=-1)
+    assert a.load_gltf(path)["images"] == 2
+    scene.insert_expected(b)
+    for e in (a, b):
+        e.tick()
+    for what in range(4):
+        assert_bits_equal(a.read_scene(what), b.read_scene(what), f"scene buffer {what}")
+    assert a.image_rect(1000) == (0, 0, 24, 16) and a.image_rect(1001)[2:] == (9, 31)
+
+
+def test_jpeg_decoder_rejects_what_it_does_not_read_and_survives_damage():
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from strolle_amd.api import decode_image
+    rng = np.random.default_rng(6)
+    a = _test_picture(rng, 40, 30)
+    buf = io.BytesIO(); Image.fromarray(a).convert("CMYK").save(buf, "JPEG")
+    with pytest.raises(StrolleError, match="status 9.*four-component"):
+        decode_image(buf.getvalue())
+    with pytest.raises(StrolleError, match="status 9.*neither"):
+        decode_image(b"RIFF\x00\x00\x00\x00WEBPVP8 ")
+    good = io.BytesIO(); Image.fromarray(a).save(good, "JPEG", quality=70, progressive=True)
+    good = good.getvalue()
+    with pytest.raises(StrolleError):
+        decode_image(good[:200])
+    arithmetic = bytearray(good); arithmetic[good.index(b"\xff\xc2") + 1] = 0xCA
+    with pytest.raises(StrolleError, match="status 9.*arithmetic"):
+        decode_image(bytes(arithmetic))
+    outcomes = [0, 0]
+    for i in range(400):
+        d = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            d[int(rng.integers(2, len(d)))] = int(rng.integers(0, 256))
+        try:
+            decode_image(bytes(d)); outcomes[0] += 1
+        except StrolleError:
+            outcomes[1] += 1
+    assert outcomes[0] and outcomes[1], outcomes
