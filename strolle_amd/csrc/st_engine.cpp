@@ -524,9 +524,23 @@ struct Engine {
         tri_attr[4 * slot] = f4(n[0], t.uvs[0][0]); tri_attr[4 * slot + 1] = f4(n[1], t.uvs[0][1]); tri_attr[4 * slot + 2] = f4(n[2], t.uvs[1][0]);
         tri_attr[4 * slot + 3] = make_float4(t.uvs[1][1], t.uvs[2][0], t.uvs[2][1], b2f(inst.xslot));
     }
+    struct BakeJob { const std::vector<StMeshTriangle>* mesh; const InstanceRec* inst; uint32_t material; size_t first, count; };
     bool refresh_instances() {
         if (!instances_dirty) return false;
         instances_dirty = false;
+        std::vector<BakeJob> jobs; size_t total = 0;
+        {   // one reallocation at most for everything this refresh appends (a scene load appends every instance)
+            size_t fresh = 0;
+            for (const auto& inst : instances) {
+                if (!inst.dirty || instance_triangles.count(inst.id)) continue;
+                auto mesh = meshes.find(inst.mesh);
+                if (mesh != meshes.end()) fresh += mesh->second.size();
+            }
+            if (fresh) {
+                const size_t want = triangles.size() + fresh;
+                triangles.reserve(want); prims.reserve(want); prim_alive.reserve(want); tri_geo.reserve(3 * want); tri_attr.reserve(4 * want);
+            }
+        }
         for (auto& inst : instances) {
             if (!inst.dirty) continue;
             inst.dirty = false;
@@ -543,10 +557,30 @@ struct Engine {
                 triangles.resize(e); prims.resize(e); prim_alive.resize(e, 0); tri_geo.resize(3 * e); tri_attr.resize(4 * e);
                 for (SceneSet& t : sets) t.tri_full = true;
             }
-            for (size_t i = 0; i < count; i++) bake(mesh->second[i], inst, mat->second, b + i);
+            jobs.push_back({&mesh->second, &inst, mat->second, b, count});
+            total += count;
             for (SceneSet& t : sets) { t.dirty_lo = std::min(t.dirty_lo, b); t.dirty_hi = std::max(t.dirty_hi, e); }  // slots each device copy still has to receive
             instance_triangles[inst.id] = {b, e};
         }
+        // Baking (instances.rs:100-139) writes disjoint slots and reads nothing it writes, so once every range is assigned —
+        // the arrays do not move any more — large refreshes are spread over the BVH builder's worker pool in chunks.
+        const auto tb0 = std::chrono::steady_clock::now();
+        constexpr size_t kChunk = 2048, kParallelFrom = 16384;
+        unsigned threads = std::thread::hardware_concurrency();
+        if (threads > 16u) threads = 16u;
+        if (total < kParallelFrom || threads < 2u) {
+            for (const BakeJob& j : jobs)
+                for (size_t i = 0; i < j.count; i++) bake((*j.mesh)[i], *j.inst, j.material, j.first + i);
+        } else {
+            TaskPool pool(threads);
+            for (const BakeJob& j : jobs)
+                for (size_t at = 0; at < j.count; at += kChunk) {
+                    const size_t end = std::min(j.count, at + kChunk);
+                    pool.push([this, j, at, end] { for (size_t i = at; i < end; i++) bake((*j.mesh)[i], *j.inst, j.material, j.first + i); });
+                }
+            pool.finish();
+        }
+        if (tick_timing) fprintf(stderr, "[bake] %zu triangles in %zu jobs: %.2f ms\n", total, jobs.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
         return true;
     }
 

@@ -12,6 +12,7 @@ ap.add_argument("--device", type=int, default=-1)
 ap.add_argument("--subdivide", type=int, default=0)
 ap.add_argument("--ticks", type=int, default=20)
 ap.add_argument("--refit", action="store_true")
+ap.add_argument("--all", action="store_true", help="move every instance per tick, not just one (stress-bvh.rs: many bodies under physics)")
 args = ap.parse_args()
 e = Engine(device=args.device)
 scenes.build_dungeon(e, subdivide=args.subdivide)
@@ -22,8 +23,9 @@ base = npz["xform_0"].reshape(4, 3).T.copy()
 mat = 1 + int(npz["material_0"])
 ts = []
 for i in range(args.ticks):
-    x = base.copy(); x[0, 3] += 0.001 * (i + 1)
-    e.insert_instance(1, Instance(1, mat, x))
+    for k in (range(int(npz["n_meshes"])) if args.all else (0,)):
+        x = npz[f"xform_{k}"].reshape(4, 3).T.copy(); x[0, 3] += 0.001 * (i + 1)
+        e.insert_instance(1 + k, Instance(1 + k, 1 + int(npz[f"material_{k}"]), x))
     t = time.perf_counter(); e.tick(); ts.append(time.perf_counter() - t)
 tris = e.read_scene(1).nbytes // 144
-print(f"device={args.device} triangles={tris} refit={args.refit} (rebuilds, refits)={e.bvh_refits()}: tick with one moved instance: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms")
+print(f"device={args.device} triangles={tris} refit={args.refit} (rebuilds, refits)={e.bvh_refits()}: tick with {'every' if args.all else 'one'} instance moved: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms")
