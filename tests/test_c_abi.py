@@ -35,9 +35,11 @@ def test_struct_sizes_match_header():
     assert (C.sizeof(api.StMeshTriangle), C.sizeof(api.StMaterial), C.sizeof(api.StLight), C.sizeof(api.StCamera)) == (144, 88, 52, 160)
 
 
-@pytest.mark.parametrize("scene", ["cornell", "soup", "dungeon"])
+@pytest.mark.parametrize("scene", ["cornell", "soup", "dungeon", "dungeon33k"])
 def test_host_engine_scene_buffers_equal_oracle(scene):
-    build = {"cornell": scenes.build_cornell, "soup": lambda e: scenes.build_random_soup(e, 5000, seed=3), "dungeon": scenes.build_dungeon}[scene]
+    # dungeon33k (every triangle split in four) is past the sizes at which baking and the BVH build go to the worker pool
+    build = {"cornell": scenes.build_cornell, "soup": lambda e: scenes.build_random_soup(e, 5000, seed=3), "dungeon": scenes.build_dungeon,
+             "dungeon33k": lambda e: scenes.build_dungeon(e, subdivide=1)}[scene]
     prod, orac = Engine(device=-1), OracleEngine()
     for e in (prod, orac):
         build(e)
@@ -213,6 +215,31 @@ def test_bvh_refit_mode_keeps_the_tree_while_instances_only_move():
         e.tick()
     assert_bits_equal(prod.read_scene(0), fresh.read_scene(0), "rebuild mode again: product vs an engine that never refitted")
     assert_bits_equal(prod.read_scene(0), orac.read_scene(0), "rebuild mode again: product vs oracle")
+
+
+@pytest.mark.parametrize("refit", [False, True])
+def test_every_instance_moving_at_pool_size_equals_oracle(refit):
+    """stress-bvh.rs in miniature, at a size where a refresh is baked on the worker pool (>= 16 k triangles): all instances
+    of the 33 k-triangle dungeon move every tick; triangles, BVH stream and materials must stay equal to the oracle's, which
+    bakes and builds on one thread."""
+    from strolle_amd import Instance
+    npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
+    prod, orac = Engine(device=-1), OracleEngine()
+    for e in (prod, orac):
+        scenes.build_dungeon(e, subdivide=1)
+        e.set_bvh_refresh(refit)
+        e.tick()
+    for k in range(3):
+        for i in range(int(npz["n_meshes"])):
+            x = np.ascontiguousarray(npz[f"xform_{i}"].reshape(4, 3).T, np.float32)
+            x[:, 3] += np.float32(0.01 * (k + 1) * (1 + i % 3))
+            for e in (prod, orac):
+                e.insert_instance(1 + i, Instance(1 + i, 1 + int(npz[f"material_{i}"]), x))
+        for e in (prod, orac):
+            e.tick()
+        for what, name in enumerate(("BVH stream", "triangles", "lights", "materials")):
+            assert_bits_equal(prod.read_scene(what), orac.read_scene(what), f"tick {k}: {name}")
+    assert prod.bvh_refits() == orac.bvh_refits() == ((1, 3) if refit else (4, 0))
 
 
 def test_atlas_rectangles_are_released_and_reused():
