@@ -3,8 +3,10 @@ reference's code): the reference has no golden vectors for traversal or camera r
 these pin the semantics instead — the BVH + traversal must return what a brute-force closest-hit search returns, and a
 camera ray must be the unprojection of its pixel centre."""
 import ctypes as C
+import os
 
 import numpy as np
+import pytest
 
 from oracle_binding import OracleEngine, oracle_lib
 from strolle_amd import Buffer, CameraMode, scenes
@@ -349,3 +351,65 @@ def test_direct_and_indirect_light_separately_against_the_path_tracer():
     without_neighbours = (alone * albedo).mean((0, 1)) / bounce
     assert np.all(np.abs(without_neighbours - 0.975) < 0.045), f"one bounce, sampling + temporal only / path tracer: {without_neighbours}"
     assert np.all(with_neighbours > without_neighbours)
+
+
+def test_history_follows_the_camera():
+    """Reprojection (frame_reprojection.rs, the reservoirs' temporal passes, frame_denoising.rs:3-78) has no golden vectors
+    either; what can be checked is its purpose. After 30 frames at one pose the camera jumps to another. The first frame at
+    the new pose, rendered with the reprojected history, must be much closer to the converged picture of the new pose than
+    (a) a first frame without any history and (b) the old pose's picture, which is what a history that does not move with
+    the camera would keep showing. A flipped motion vector, a wrong previous-camera matrix or a broken validity mask fails
+    this by a wide margin."""
+    from oracle_binding import OracleEngine
+    size = (96, 64)
+    pose_a, pose_b = ((0.0, 1.0, 3.2), (0.0, 1.0, 0.0)), ((0.25, 1.1, 3.0), (0.05, 1.0, 0.0))
+    cam = lambda p: scenes.camera_for(size, p[0], p[1], CameraMode.IMAGE, True, 0)
+
+    def frames(poses):
+        e = OracleEngine(); scenes.build_cornell(e); e.set_seed(3)
+        c = e.create_camera(cam(poses[0]))
+        out = []
+        for p in poses:
+            e.update_camera(c, cam(p)); e.tick()
+            out.append(e.render_camera(c)[..., :3].astype(np.float64))
+        return out
+
+    lum = lambda x: 0.2126 * x[..., 0] + 0.7152 * x[..., 1] + 0.0722 * x[..., 2]
+    converged = np.mean(frames([pose_b] * 60)[24:], axis=0)
+    rmse = lambda a: float(np.sqrt(np.mean((lum(a) - lum(converged)) ** 2)))
+    moved = frames([pose_a] * 30 + [pose_b])
+    with_history, old_pose, cold = rmse(moved[30]), rmse(moved[29]), rmse(frames([pose_b])[0])
+    assert with_history < 0.65 * cold, (with_history, cold)
+    assert with_history < 0.35 * old_pose, (with_history, old_pose)
+
+
+@pytest.mark.parametrize("which", [6, 7])
+def test_history_follows_a_moving_instance(which):
+    """The same for object motion: primary visibility derives the motion vector from the owning instance's previous and
+    current transforms (prim_raster.rs:21-27). One of the two Cornell boxes jumps a quarter of a metre sideways after 30
+    frames; the first frame afterwards must be closer to the converged picture of the new arrangement than a frame without
+    history, and far closer than the old arrangement's picture."""
+    from oracle_binding import OracleEngine
+    from strolle_amd import Instance
+    size = (96, 64)
+    npz = np.load(os.path.join(scenes.ASSETS, "cornell.npz"))
+
+    def frames(offsets):
+        e = OracleEngine(); scenes.build_cornell(e); e.set_seed(3)
+        d = scenes.cornell_camera(size, CameraMode.IMAGE)
+        c = e.create_camera(d)
+        out = []
+        for dx in offsets:
+            x = np.ascontiguousarray(npz[f"xform_{which}"].reshape(4, 3).T, np.float32).copy(); x[0, 3] += np.float32(dx)
+            e.insert_instance(1 + which, Instance(1 + which, 1 + int(npz[f"material_{which}"]), x))
+            e.update_camera(c, d); e.tick()
+            out.append(e.render_camera(c)[..., :3].astype(np.float64))
+        return out
+
+    lum = lambda x: 0.2126 * x[..., 0] + 0.7152 * x[..., 1] + 0.0722 * x[..., 2]
+    converged = np.mean(frames([0.25] * 60)[24:], axis=0)
+    rmse = lambda a: float(np.sqrt(np.mean((lum(a) - lum(converged)) ** 2)))
+    moved = frames([0.0] * 30 + [0.25])
+    with_history, old_place, cold = rmse(moved[30]), rmse(moved[29]), rmse(frames([0.25])[0])
+    assert with_history < 0.65 * cold, (with_history, cold)
+    assert with_history < 0.6 * old_place, (with_history, old_place)
