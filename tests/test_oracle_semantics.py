@@ -413,3 +413,32 @@ def test_history_follows_a_moving_instance(which):
     with_history, old_place, cold = rmse(moved[30]), rmse(moved[29]), rmse(frames([0.25])[0])
     assert with_history < 0.65 * cold, (with_history, cold)
     assert with_history < 0.6 * old_place, (with_history, old_place)
+
+
+def test_denoiser_stabilises_and_its_footprint_is_in_pixels():
+    """SVGF (frame_denoising.rs) by its purpose: the filter's reach is fixed in pixels (five a-trous passes, strides 1..16),
+    so against the time-averaged raw picture its blur must shrink as the resolution grows, and at a resolution where the
+    footprint is small against the scene's features the denoised frames must flicker less than the raw ones. (Energy
+    conservation is checked next to the path-tracer comparison above.)"""
+    from oracle_binding import OracleEngine
+
+    def run(size, denoise, n, keep):
+        e = OracleEngine(); scenes.build_cornell(e); e.set_seed(3)
+        d = scenes.cornell_camera(size, CameraMode.IMAGE, denoise=denoise)
+        c = e.create_camera(d)
+        out = []
+        for f in range(n):
+            e.update_camera(c, d); e.tick()
+            img = e.render_camera(c)
+            if f >= n - keep:
+                out.append(0.2126 * img[..., 0] + 0.7152 * img[..., 1] + 0.0722 * img[..., 2])
+        return np.asarray(out, np.float64)
+
+    blur = {}
+    for size in ((96, 64), (288, 192)):
+        raw, den = run(size, False, 48, 24), run(size, True, 48, 24)
+        truth = raw.mean(0)
+        blur[size] = float(np.sqrt(np.mean((den.mean(0) - truth) ** 2)) / truth.mean())
+        if size[0] == 288:
+            assert raw.std(0).mean() > 1.5 * den.std(0).mean(), (raw.std(0).mean(), den.std(0).mean())
+    assert blur[(288, 192)] < 0.6 * blur[(96, 64)], blur
