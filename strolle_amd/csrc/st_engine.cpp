@@ -337,7 +337,7 @@ struct Engine {
     struct LightSet { DeviceArray buf; hipEvent_t free_ev = nullptr; bool busy = false; };
     LightSet light_sets[2]; int live_lights = 0; bool lights_uploaded = false, lights_alternating = false;
     bool double_buffer = true, alternating = false, mixed_render_streams = false;
-    hipStream_t copy_stream = nullptr, last_render_stream = nullptr; hipEvent_t ev_copy = nullptr; bool copy_in_flight = false;
+    hipStream_t copy_stream = nullptr, last_render_stream = nullptr; bool rendered_before = false; hipEvent_t ev_copy = nullptr; bool copy_in_flight = false;
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
@@ -854,8 +854,8 @@ struct Engine {
         ST_HIP(hipSetDevice(device));
         if (tick_work_in_flight) ST_HIP(hipStreamWaitEvent(stream, ev_tick, 0));  // a no-op when st_tick ran on this stream
         if (copy_in_flight) ST_HIP(hipStreamWaitEvent(stream, ev_copy, 0));       // likewise (st_tick already queued this wait on its own stream)
-        if (last_render_stream && last_render_stream != stream) mixed_render_streams = true;
-        last_render_stream = stream;
+        if (rendered_before && last_render_stream != stream) mixed_render_streams = true;  // the null stream is a stream too
+        last_render_stream = stream; rendered_before = true;
         const bool alt = c.frame % 2u == 1u;
         KArgs a{};
         a.cam = c.curr; a.prev_cam = c.prev;
