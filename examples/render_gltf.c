@@ -58,18 +58,22 @@ int main(int argc, char** argv) {
     StEngine* engine = NULL;
     CHECK(st_engine_create(0, &engine));
 
+    StGltfOptions options;
+    memset(&options, 0, sizeof options);
+    options.first_handle = 1; options.first_image_handle = 1000;
+    options.light_radius = 0.15f;                                                       /* cornell.rs:45-54 */
     StGltfSummary scene;
-    CHECK(st_scene_load_gltf(engine, argv[1], NULL, &scene));
-    fprintf(stderr, "%u meshes, %u triangles, %u materials, %u images (%u dropped, %u primitives skipped)\n", scene.meshes, scene.triangles,
-            scene.materials, scene.images, scene.images_dropped, scene.primitives_skipped);
+    CHECK(st_scene_load_gltf(engine, argv[1], &options, &scene));
+    fprintf(stderr, "%u meshes, %u triangles, %u materials, %u images (%u dropped, %u primitives skipped), %u lights\n", scene.meshes,
+            scene.triangles, scene.materials, scene.images, scene.images_dropped, scene.primitives_skipped, scene.lights);
 
-    StLight light;
+    StLight light;                                                                      /* the example's own lamp, on top of the file's */
     memset(&light, 0, sizeof light);
     light.kind = ST_LIGHT_POINT;
     light.position[0] = 0.0f; light.position[1] = 1.5f; light.position[2] = 0.5f;
     light.radius = 0.15f; light.range = 35.0f;
     light.color[0] = light.color[1] = light.color[2] = 50.0f / (4.0f * 3.14159265f);   /* cornell.rs:45-54 */
-    CHECK(st_light_insert(engine, 1, &light));
+    CHECK(st_light_insert(engine, 1 + scene.lights, &light));
     CHECK(st_sun_update(engine, 0.0f, -1.0f));                                          /* night: cornell.rs:87 */
 
     StCamera camera;

@@ -204,7 +204,9 @@ int st_debug_read_lut(StEngine* e, int what, float* out, size_t capacity_floats,
  * stages (bevy-strolle/src/stages/prepare.rs:20-122 meshes, :124-180 materials, :182-260 images; extract.rs instances);
  * here it is a convenience layered on the entry points above and nothing else. One mesh + instance per triangle-list
  * primitive of the default scene, numbered in depth-first node order: mesh / instance handle = first_handle + i,
- * material handle = first_handle + material index, image handle = first_image_handle + image index. Materials follow
+ * material handle = first_handle + material index, image handle = first_image_handle + image index; KHR_lights_punctual
+ * point and spot lights become lights the way bevy_gltf + bevy-strolle's extract stage would make them
+ * (extract.rs:283-327), light handle = first_handle + k. Materials follow
  * prepare.rs:132-175 (Opaque forces alpha 1, Mask becomes Blend with alpha 0/1, reflectance 0.5, ior 1). PNG (all colour
  * types and bit depths, Adam7 too) and JPEG textures are decoded here; KTX2 / WebP, Draco and sparse accessors give
  * ST_ERR_UNSUPPORTED. Host-only work: valid on host-only engines. */
@@ -216,11 +218,18 @@ typedef struct StGltfOptions {
     float reflectance;
     float perceptual_roughness;
     uint32_t subdivide;           /* k: every triangle is split into 4^k by midpoint subdivision (synthetic scaling), k <= 6 */
+    float light_radius;           /* radius given to KHR_lights_punctual lights, which have none. 0 is what arrives through Bevy
+                                   * (PointLight::radius defaults to 0) — but the reference's ReSTIR loses about half of a
+                                   * zero-radius light's energy (reservoir/di.rs:105-116 tests `light.contains(point)`), which is
+                                   * why its own examples set 0.15 (cornell.rs:45-54, demo.rs:169-191) */
+    uint32_t _pad;
 } StGltfOptions;
 typedef struct StGltfSummary {
     uint32_t meshes, triangles, materials, images;
     uint32_t images_dropped;      /* did not fit the atlas: the reference warns and drops them (images.rs:71-79) */
     uint32_t primitives_skipped;  /* points, lines, strips, fans, or primitives without a single triangle */
+    uint32_t lights;              /* KHR_lights_punctual point / spot lights inserted, handles first_handle + k in node order */
+    uint32_t lights_skipped;      /* directional ones (strolle's sun is st_sun_update) and ones fainter than 0.0001 cd */
 } StGltfSummary;
 /* options == NULL: the defaults above; summary may be NULL. External buffers / images are read relative to the file. */
 int st_scene_load_gltf(StEngine* e, const char* path, const StGltfOptions* options, StGltfSummary* summary);

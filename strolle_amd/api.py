@@ -55,12 +55,12 @@ class StKernelProfile(C.Structure):
 
 class StGltfOptions(C.Structure):
     _fields_ = [("first_handle", C.c_uint64), ("first_image_handle", C.c_uint64), ("override_mask", C.c_uint32), ("reflectance", C.c_float),
-                ("perceptual_roughness", C.c_float), ("subdivide", C.c_uint32)]
+                ("perceptual_roughness", C.c_float), ("subdivide", C.c_uint32), ("light_radius", C.c_float), ("_pad", C.c_uint32)]
 
 
 class StGltfSummary(C.Structure):
     _fields_ = [("meshes", C.c_uint32), ("triangles", C.c_uint32), ("materials", C.c_uint32), ("images", C.c_uint32), ("images_dropped", C.c_uint32),
-                ("primitives_skipped", C.c_uint32)]
+                ("primitives_skipped", C.c_uint32), ("lights", C.c_uint32), ("lights_skipped", C.c_uint32)]
 
 
 assert C.sizeof(StMeshTriangle) == 144 and C.sizeof(StMaterial) == 88 and C.sizeof(StLight) == 52 and C.sizeof(StCamera) == 160
@@ -474,10 +474,10 @@ class Engine(EngineBase):
         self._check(self._b.image_insert_device_rgba8(self._h, handle, width, height, device_ptr, row_pitch_bytes or width * 4, 1 if dynamic else 0))
 
     def load_gltf(self, source, base_dir: Optional[str] = None, first_handle: int = 1, first_image_handle: int = 1000,
-                  reflectance: Optional[float] = None, perceptual_roughness: Optional[float] = None, subdivide: int = 0) -> dict:
+                  reflectance: Optional[float] = None, perceptual_roughness: Optional[float] = None, subdivide: int = 0, light_radius: float = 0.0) -> dict:
         """st_scene_load_gltf: `source` is a path to a .gltf / .glb file, or the file's bytes (external buffers and images
         are then read relative to `base_dir`). Returns the loader's summary."""
-        opt = StGltfOptions(first_handle, first_image_handle, 0, 0.0, 0.0, subdivide)
+        opt = StGltfOptions(first_handle, first_image_handle, 0, 0.0, 0.0, subdivide, light_radius, 0)
         if reflectance is not None:
             opt.override_mask |= 1; opt.reflectance = reflectance
         if perceptual_roughness is not None:

@@ -15,6 +15,7 @@
 //   * vertices are stored object-space, de-indexed, three per triangle (prepare.rs:92-118);
 //   * materials follow prepare.rs:132-175: Opaque forces alpha 1, Mask(c) turns alpha into 0/1 and becomes Blend,
 //     reflectance 0.5 and ior 1 are Bevy's StandardMaterial defaults, emissive alpha 1;
+//   * KHR_lights_punctual point and spot lights become lights (see Loader::light); directional ones are skipped;
 //   * missing normals become flat normals (bevy_gltf computes flat normals for such meshes); missing UVs / tangents
 //     are zero (prepare.rs:104-110 `unwrap_or_default`); tangents are not generated.
 // Textures: PNG (decoder below) and JPEG (st_jpeg.h). Not supported (reported as ST_ERR_UNSUPPORTED, never skipped
@@ -1037,8 +1038,50 @@ struct Loader {
             const Json& mesh = doc.root.at("meshes").at(mj->index("node.mesh"), "mesh");
             for (auto& prim : mesh.at("primitives").arr) primitive(prim, world);
         }
+        if (const Json* ext = n.find("extensions"))
+            if (const Json* lp = ext->find("KHR_lights_punctual"))
+                if (const Json* li = lp->find("light")) light(li->index("node light"), world);
         if (const Json* kids = n.find("children"))
             for (auto& k : kids->arr) node(k.index("node child"), world, depth + 1);
+    }
+
+    // KHR_lights_punctual -> Light (light.rs:6-22) the way it would arrive through Bevy: bevy_gltf turns a point or spot light's
+    // candela into lumens (x 4 pi) and leaves PointLight::radius at its default 0; bevy-strolle's extract stage turns lumens
+    // back into colour x lumens / (4 pi), takes the position from the node's world transform and, for spots, the direction
+    // -(rotation x Z) and the outer cone angle (bevy-strolle/src/stages/extract.rs:283-327), dropping lights fainter than
+    // 0.0001. A range the file does not give is Bevy's default 20. Directional lights have no counterpart: strolle's sun is
+    // a resource of its own (st_sun_update), so they are counted and skipped.
+    void light(size_t index, const Mat4d& world) {
+        const Json* ext = doc.root.find("extensions");
+        const Json* lp = ext ? ext->find("KHR_lights_punctual") : nullptr;
+        if (!lp) PARSE_FAIL("glTF: a node names a light but the document has no KHR_lights_punctual");
+        const Json& l = lp->at("lights").at(index, "light");
+        const std::string type = l.string_or("type", "");
+        if (type == "directional") { sum.lights_skipped++; return; }
+        if (type != "point" && type != "spot") PARSE_FAIL("glTF: light type \"%s\"", type.c_str());
+        double color[3] = {1, 1, 1};
+        if (const Json* c = l.find("color")) {
+            if (c->size() != 3) PARSE_FAIL("glTF: light colour needs 3 numbers");
+            for (int i = 0; i < 3; i++) color[i] = c->arr[(size_t)i].number("light colour");
+        }
+        const float candela = (float)l.number_or("intensity", 1.0);
+        if (candela < 0.0001f) { sum.lights_skipped++; return; }  // extract.rs:287-290
+        StLight out;
+        memset(&out, 0, sizeof out);
+        out.kind = type == "spot" ? ST_LIGHT_SPOT : ST_LIGHT_POINT;
+        for (int i = 0; i < 3; i++) { out.position[i] = (float)world.m[i][3]; out.color[i] = (float)color[i] * candela; }
+        out.radius = opt.light_radius;
+        out.range = (float)l.number_or("range", 20.0);
+        if (out.kind == ST_LIGHT_SPOT) {
+            double d[3] = {-world.m[0][2], -world.m[1][2], -world.m[2][2]};  // the node's -Z axis in world space
+            const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            if (!(len > 0.0)) PARSE_FAIL("glTF: spot light on a node with a degenerate transform");
+            for (int i = 0; i < 3; i++) out.direction[i] = (float)(d[i] / len);
+            const Json* spot = l.find("spot");
+            out.angle = (float)(spot ? spot->number_or("outerConeAngle", 0.7853981633974483) : 0.7853981633974483);
+        }
+        check(st_light_insert(engine, opt.first_handle + sum.lights, &out), "st_light_insert");
+        sum.lights++;
     }
 
     void run() {

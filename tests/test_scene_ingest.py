@@ -307,14 +307,23 @@ class SyntheticScene:
             {"children": [1, 3], "matrix": [1.0, 0.0, 0.0, 0.0, 0.0, 2.220446049250313e-16, -1.0, 0.0, 0.0, 1.0, 2.220446049250313e-16, 0.0, 0.5, -0.25, 3.0, 1.0]},
             {"children": [2], "rotation": _quat([1, 2, 3], 0.7), "scale": [0.04, 1.5, 2.0], "translation": [-2.47702, -14.1602, 0.02125]},
             {"mesh": 0, "rotation": _quat([0, 1, 0], -1.1), "translation": [0.1, 0.2, 0.3]},
-            {"mesh": 1, "scale": [2.0, 2.0, 2.0]},
-            {"mesh": 1, "translation": [9.0, 9.0, 9.0]},   # not reachable from the scene: must not be loaded
+            {"mesh": 1, "scale": [2.0, 2.0, 2.0], "children": [5, 6, 7, 8]},
+            {"mesh": 1, "translation": [9.0, 9.0, 9.0], "extensions": {"KHR_lights_punctual": {"light": 0}}},   # not reachable from the scene: must not be loaded
+            {"translation": [0.5, 2.0, -1.0], "extensions": {"KHR_lights_punctual": {"light": 0}}},
+            {"translation": [-1.0, 3.0, 0.25], "rotation": _quat([1, 0.2, 0], 1.1), "extensions": {"KHR_lights_punctual": {"light": 1}}},
+            {"extensions": {"KHR_lights_punctual": {"light": 2}}},                                           # directional: skipped
+            {"translation": [1.0, 1.0, 1.0], "extensions": {"KHR_lights_punctual": {"light": 3}}},          # too faint: skipped
         ]
+        self.lights = [{"type": "point", "color": [1.0, 0.5, 0.25], "intensity": 40.0, "range": 12.5},
+                       {"type": "spot", "intensity": 300.0, "spot": {"innerConeAngle": 0.2, "outerConeAngle": 0.6}},
+                       {"type": "directional", "intensity": 3.0},
+                       {"type": "point", "intensity": 0.00005}]
         self.doc = {
             "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": self.nodes,
             "meshes": [{"primitives": [prim0, prim1, prim_lines]}, {"primitives": [prim2, prim3]}],
             "materials": self.materials, "accessors": self.accessors, "bufferViews": self.views,
             "textures": [{"source": 0}, {"source": 1}],
+            "extensionsUsed": ["KHR_lights_punctual"], "extensions": {"KHR_lights_punctual": {"lights": self.lights}},
             "images": [{"bufferView": v_img0, "mimeType": "image/png"}, {"uri": "data:image/png;base64," + base64.b64encode(self.pngs[1]).decode()}],
         }
         # ---- what the loader is expected to hand to the engine
@@ -364,6 +373,19 @@ class SyntheticScene:
         ]
         for i, m in enumerate(mats):
             engine.insert_material(first_handle + i, m)
+        from strolle_amd import Light
+        chain_to = {5: [0, 3, 5], 6: [0, 3, 6]}
+        for k, (node, light) in enumerate(((5, self.lights[0]), (6, self.lights[1]))):
+            world = np.eye(4)
+            for n in chain_to[node]:
+                world = _matmul(world, _node_matrix(self.nodes[n]))
+            position = [float(np.float32(world[i, 3])) for i in range(3)]
+            color = [float(np.float32(np.float32(c) * np.float32(light["intensity"]))) for c in light.get("color", [1.0, 1.0, 1.0])]
+            if light["type"] == "point":
+                engine.insert_light(first_handle + k, Light.point(position, 0.0, color, light.get("range", 20.0)))
+            else:
+                d = -world[:3, 2]; d = d / np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+                engine.insert_light(first_handle + k, Light.spot(position, 0.0, color, light.get("range", 20.0), [float(np.float32(v)) for v in d], light["spot"]["outerConeAngle"]))
         for i, (mesh, material, chain) in enumerate(self.expected_meshes):
             world = np.eye(4)
             for n in chain:
@@ -381,7 +403,7 @@ def test_loader_equals_the_same_scene_inserted_through_the_api(tmp_path, contain
     path, data = scene.write(str(tmp_path), glb=container != "gltf")
     a, b = Engine(device=-1), Engine(device=-1)
     summary = a.load_gltf(data if container == "memory" else path, first_handle=7, first_image_handle=300)
-    assert summary == dict(meshes=4, triangles=8 + 2 + 4 + 3, materials=4, images=2, images_dropped=0, primitives_skipped=1)
+    assert summary == dict(meshes=4, triangles=8 + 2 + 4 + 3, materials=4, images=2, images_dropped=0, primitives_skipped=1, lights=2, lights_skipped=2)
     scene.insert_expected(b, first_handle=7, first_image=300)
     for e in (a, b):
         e.tick()
