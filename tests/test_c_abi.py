@@ -406,3 +406,22 @@ def test_header_is_c99_and_the_c_example_links(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(probe), "-o", str(tmp_path / "probe.o")],
                    check=True, capture_output=True, text=True)
     _compile_example(str(tmp_path / "render_gltf"))
+
+
+def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):
+    """The Python mirror declares every struct of the header by hand; a C program that includes the header says what the
+    sizes and a few telling offsets really are."""
+    import subprocess
+    from strolle_amd import api
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "strolle_hip.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu ", sizeof(StMeshTriangle), sizeof(StMaterial), sizeof(StLight), sizeof(StCamera), sizeof(StGltfOptions), sizeof(StGltfSummary), sizeof(StKernelProfile));\n'
+                   '  printf("%zu %zu %zu %zu\\n", offsetof(StMaterial, base_color_texture), offsetof(StCamera, transform), offsetof(StGltfOptions, light_radius), offsetof(StKernelProfile, algorithmic_bytes));\n'
+                   '  return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True, text=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(api.StMeshTriangle), C.sizeof(api.StMaterial), C.sizeof(api.StLight), C.sizeof(api.StCamera), C.sizeof(api.StGltfOptions), C.sizeof(api.StGltfSummary),
+            C.sizeof(api.StKernelProfile), api.StMaterial.base_color_texture.offset, api.StCamera.transform.offset, api.StGltfOptions.light_radius.offset,
+            api.StKernelProfile.algorithmic_bytes.offset]
+    assert got == want, (got, want)
