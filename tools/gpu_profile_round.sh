@@ -16,3 +16,7 @@ ST_NO_OVERLAP=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d
 ST_NO_OVERLAP=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_write -- python bench.py --steps 12 --warmup 12 --no-cpu-baseline --no-profile > gpurun_out/prof_write.log 2>&1
 ST_NO_OVERLAP=1 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/prof_sq -- python bench.py --steps 12 --warmup 12 --no-cpu-baseline --no-profile > gpurun_out/prof_sq.log 2>&1
 cat gpurun_out/bench_default.json | head -c 600
+echo
+# the changing-scene numbers DESIGN.md quotes (host refresh + render; not part of the bench line)
+{ python tools/tick_cost.py --device -1 --subdivide 2; python tools/tick_cost.py --device -1 --subdivide 2 --refit; python tools/tick_cost.py --device -1 --subdivide 2 --refit --all;
+  python tools/animated_cost.py --subdivide 2 --refit | tail -1; python tools/animated_cost.py --cornell --light | tail -1; } > gpurun_out/animated.log 2>&1; cat gpurun_out/animated.log
