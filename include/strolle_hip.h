@@ -166,6 +166,20 @@ int st_camera_set_rows(StEngine* e, StHandle camera, uint32_t y0, uint32_t y1);
 enum StOutputFormat { ST_FORMAT_RGBA32F = 0, ST_FORMAT_RGBA16F = 1, ST_FORMAT_RGBA8_UNORM_SRGB = 2, ST_FORMAT_BGRA8_UNORM_SRGB = 3 };
 int st_camera_set_output_format(StEngine* e, StHandle camera, int format);
 
+/* Arithmetic of the per-pixel kernels. Both builds of every kernel live in the library (csrc/Makefile):
+ * ST_ARITH_FAST (default) uses the hardware's reciprocal / square root / exp2 / log2 / sin / cos (1 ulp each) and lets the
+ * compiler contract a*b+c into FMAs, everywhere except the ray-generation + BVH-traversal compare chain (Camera::ray,
+ * Ray::traverse, intersect_box, Triangle::hit: strolle-gpu/src/camera.rs:32-51, ray.rs:114-302, triangle.rs:64-113),
+ * which stays IEEE-exact so that BVH-heatmap integers are bit-identical to the reference restatement. The reference itself
+ * leaves these functions to the SPIR-V driver's precision. Output is checked against the oracle within the per-plane
+ * tolerances stated in tests/test_gpu_fast_tolerance.py.
+ * ST_ARITH_EXACT evaluates everything with correctly rounded + - * / sqrt, no contraction and fixed polynomial
+ * transcendentals: every buffer of every pass is then bit-identical to the CPU oracle (tests/test_gpu_parity.py).
+ * ST_EXACT=1 in the environment makes new engines start in the exact build. Switching keeps all camera state. */
+enum StArithmetic { ST_ARITH_FAST = 0, ST_ARITH_EXACT = 1 };
+int st_engine_set_arithmetic(StEngine* e, int arithmetic);
+int st_engine_get_arithmetic(StEngine* e, int* out);
+
 /* ---- parity / measurement read-back */
 enum StBufferId {
     ST_BUF_PRIM_GBUFFER_D0_A = 0, ST_BUF_PRIM_GBUFFER_D0_B = 1, ST_BUF_PRIM_GBUFFER_D1_A = 2, ST_BUF_PRIM_GBUFFER_D1_B = 3,
@@ -184,6 +198,29 @@ enum StBufferId {
 /* Synchronises the device, then copies a per-camera buffer (camera_controller/buffers.rs:7-51) to host
  * memory. out == NULL: only report the size in *written. */
 int st_camera_read_buffer(StEngine* e, StHandle camera, int buffer_id, void* out, size_t capacity, size_t* written);
+/* The inverse of st_camera_read_buffer: overwrite a per-camera buffer with host data (`bytes` must be the buffer's size).
+ * With st_debug_set_pass_mask this lets a test hand one launch exactly the inputs the oracle's pass saw, so the fast
+ * build is compared pass by pass instead of through ReSTIR's chaotic temporal feedback. Planes this library derives from
+ * the reference's (decoded surface twins, sqrt-luma planes) are regenerated before the next render. Synchronises. */
+int st_camera_write_buffer(StEngine* e, StHandle camera, int buffer_id, const void* data, size_t bytes);
+/* One bit per reference pass (strolle/src/camera_controller.rs:87-174 order). st_render_camera executes a launch only when
+ * ALL the passes it covers are in the mask (a fused launch covers several); a mask that splits a fused launch is an
+ * ST_ERR_INVALID_ARGUMENT. Default: all ones. Frame counters, seeds and plane ping-pong are unaffected. */
+enum StPassBit {
+    ST_PASS_PRIM_VISIBILITY = 1u << 0, ST_PASS_FRAME_REPROJECTION = 1u << 1,
+    ST_PASS_DI_SAMPLING = 1u << 2, ST_PASS_DI_TEMPORAL = 1u << 3, ST_PASS_DI_SPATIAL_PICK = 1u << 4, ST_PASS_DI_SPATIAL_TRACE = 1u << 5,
+    ST_PASS_DI_SPATIAL_SAMPLE = 1u << 6, ST_PASS_DI_RESOLVING = 1u << 7,
+    ST_PASS_GI_REPROJECTION = 1u << 8, ST_PASS_GI_SAMPLING_A = 1u << 9, ST_PASS_GI_SAMPLING_B = 1u << 10, ST_PASS_GI_TEMPORAL = 1u << 11,
+    ST_PASS_GI_SPATIAL_PICK = 1u << 12, ST_PASS_GI_SPATIAL_TRACE = 1u << 13, ST_PASS_GI_SPATIAL_SAMPLE = 1u << 14,
+    ST_PASS_GI_PREVIEW_0 = 1u << 15, ST_PASS_GI_PREVIEW_1 = 1u << 16, ST_PASS_GI_RESOLVING = 1u << 17,
+    ST_PASS_DENOISE_REPROJECT_DI = 1u << 18, ST_PASS_DENOISE_REPROJECT_GI = 1u << 19, ST_PASS_DENOISE_VARIANCE = 1u << 20,
+    ST_PASS_DENOISE_WAVELET_0 = 1u << 21, /* ... wavelet pass n = ST_PASS_DENOISE_WAVELET_0 << n, n < 5 */
+    ST_PASS_COMPOSITION = 1u << 26, ST_PASS_BVH_HEATMAP = 1u << 27, ST_PASS_REF_TRACING = 1u << 28, ST_PASS_REF_SHADING = 1u << 29
+};
+int st_debug_set_pass_mask(StEngine* e, uint64_t mask);
+/* The pass bits of every launch the last st_render_camera considered, in launch order (executed or not): lets a test walk
+ * the shipped launch structure without knowing it. Returns the count; writes at most `capacity` entries. */
+int st_debug_last_launches(StEngine* e, uint64_t* out_bits, size_t capacity, size_t* count);
 /* Rays traced for this camera since the last reset (device counters, closest-hit + any-hit). */
 int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
 /* Host-side copies of what st_tick uploads: what = 0 BVH stream (float4), 1 triangles in the reference's

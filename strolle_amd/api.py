@@ -92,6 +92,18 @@ class Buffer(enum.IntEnum):
     REF_HITS = 32; REF_RAYS = 33; REF_COLORS = 34; DBG_USED_MEMORY = 35
 
 
+class PassBit(enum.IntFlag):
+    """StPassBit: one bit per reference pass (camera_controller.rs:87-174 order)."""
+    PRIM_VISIBILITY = 1 << 0; FRAME_REPROJECTION = 1 << 1
+    DI_SAMPLING = 1 << 2; DI_TEMPORAL = 1 << 3; DI_SPATIAL_PICK = 1 << 4; DI_SPATIAL_TRACE = 1 << 5; DI_SPATIAL_SAMPLE = 1 << 6; DI_RESOLVING = 1 << 7
+    GI_REPROJECTION = 1 << 8; GI_SAMPLING_A = 1 << 9; GI_SAMPLING_B = 1 << 10; GI_TEMPORAL = 1 << 11
+    GI_SPATIAL_PICK = 1 << 12; GI_SPATIAL_TRACE = 1 << 13; GI_SPATIAL_SAMPLE = 1 << 14
+    GI_PREVIEW_0 = 1 << 15; GI_PREVIEW_1 = 1 << 16; GI_RESOLVING = 1 << 17
+    DENOISE_REPROJECT_DI = 1 << 18; DENOISE_REPROJECT_GI = 1 << 19; DENOISE_VARIANCE = 1 << 20
+    DENOISE_WAVELET_0 = 1 << 21; DENOISE_WAVELET_1 = 1 << 22; DENOISE_WAVELET_2 = 1 << 23; DENOISE_WAVELET_3 = 1 << 24; DENOISE_WAVELET_4 = 1 << 25
+    COMPOSITION = 1 << 26; BVH_HEATMAP = 1 << 27; REF_TRACING = 1 << 28; REF_SHADING = 1 << 29
+
+
 # ----------------------------------------------------------------------------- value types mirroring the reference
 class CameraMode(enum.IntEnum):
     """strolle/src/camera.rs:83-105"""
@@ -276,6 +288,9 @@ class _Binding:
             self.scene_load_gltf = fn("scene_load_gltf", [vp, C.c_char_p, P(StGltfOptions), P(StGltfSummary)])
             self.scene_load_gltf_memory = fn("scene_load_gltf_memory", [vp, vp, sz, C.c_char_p, P(StGltfOptions), P(StGltfSummary)])
             self.decode_png = fn("decode_png", [vp, sz, vp, sz, P(u32), P(u32)])
+            self.engine_set_arithmetic = fn("engine_set_arithmetic", [vp, i32]); self.engine_get_arithmetic = fn("engine_get_arithmetic", [vp, P(i32)])
+            self.camera_write_buffer = fn("camera_write_buffer", [vp, u64, i32, vp, sz])
+            self.debug_set_pass_mask = fn("debug_set_pass_mask", [vp, u64]); self.debug_last_launches = fn("debug_last_launches", [vp, P(u64), sz, P(sz)])
             self.profile_enable = fn("profile_enable", [vp, i32])
             self.profile_read = fn("profile_read", [vp, P(StKernelProfile), sz, P(sz), i32])
             self.last_error = getattr(lib, prefix + "last_error"); self.last_error.restype = C.c_char_p; self.last_error.argtypes = []
@@ -452,8 +467,36 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
 class Engine(EngineBase):
     """MI355X engine. device >= 0: HIP ordinal; device = -1: host-only (scene + BVH logic, no rendering)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, exact: Optional[bool] = None):
+        """exact=None: the library default (fast arithmetic unless ST_EXACT=1 is set); True / False: st_engine_set_arithmetic."""
         super().__init__(_Binding(load_library(), "st_", True), device)
+        if exact is not None:
+            self.set_exact(exact)
+
+    def set_exact(self, exact: bool):
+        """st_engine_set_arithmetic: True = the bit-exact build of the kernels, False = the fast (default) build."""
+        self._check(self._b.engine_set_arithmetic(self._h, 1 if exact else 0))
+
+    @property
+    def exact(self) -> bool:
+        out = C.c_int()
+        self._check(self._b.engine_get_arithmetic(self._h, C.byref(out)))
+        return out.value == 1
+
+    def write_buffer(self, camera: int, buffer: "Buffer", data: np.ndarray):
+        """st_camera_write_buffer: the inverse of read_buffer (parity tests hand a launch the oracle's input planes)."""
+        data = np.ascontiguousarray(data)
+        self._check(self._b.camera_write_buffer(self._h, camera, int(buffer), data.ctypes.data, data.nbytes))
+
+    def set_pass_mask(self, mask: int):
+        """st_debug_set_pass_mask: bit set = that reference pass runs (PassBit)."""
+        self._check(self._b.debug_set_pass_mask(self._h, mask & 0xFFFFFFFFFFFFFFFF))
+
+    def last_launches(self):
+        """Pass bits of every launch the last render_camera considered, in launch order."""
+        arr = (C.c_uint64 * 64)(); n = C.c_size_t()
+        self._check(self._b.debug_last_launches(self._h, arr, 64, C.byref(n)))
+        return [arr[i] for i in range(min(n.value, 64))]
 
     def tick(self, stream: int = 0):
         self._check(self._b.tick(self._h, stream))

@@ -6,6 +6,7 @@
 #include "k_common.h"
 
 namespace st {
+namespace ST_KNS {
 
 ST_D float quantize_f16(float f) {
     const uint32_t h = f16_bits(f);
@@ -194,4 +195,5 @@ void launch_atmosphere_sky(const float4* transmittance_lut, const float4* scatte
     hipLaunchKernelGGL(k_atmosphere_sky, dim3(32, 32), dim3(64), 0, s, transmittance_lut, scattering_lut, sun_altitude, sky_lut);
 }
 
+}  // namespace ST_KNS
 }  // namespace st

@@ -4,6 +4,7 @@
 #include "k_common.h"
 
 namespace st {
+namespace ST_KNS {
 
 // The SVGF sample weight (frame_denoising.rs:363-398) is exp(-|sqrt(luma_c) - sqrt(luma_s)| * luma_sigma) * depth_weight *
 // normal_weight, multiplied in that order; the depth and normal factors do not depend on the signal, so the loops below
@@ -304,4 +305,21 @@ void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float stren
     ST_LAUNCH(k_denoise_wavelet<true>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, sl_in, (float2*)nullptr, camera_mode, frame_out);
 }
 
+// ---------------------------------------------------------------- st_camera_write_buffer support
+__global__ ST_KERNEL_BOUNDS void k_refresh_internal_planes(const KArgs a, float4* psn_out) {
+    U2 pos;
+    if (!resolve_gid(a, false, &pos) || !contains_u(a, pos)) return;
+    const uint32_t i = pos.y * a.width + pos.x;
+    const float4 sm = a.sm[i], psm = a.psm[i];
+    a.sn[i] = sm.z == 0.0f ? f4z() : f4(normal_decode(v2(sm.x, sm.y)), sm.z);   // what primary visibility writes beside the surface map
+    psn_out[i] = psm.z == 0.0f ? f4z() : f4(normal_decode(v2(psm.x, psm.y)), psm.z);
+    a.sl[0][i] = make_float2(sqrtf(luma(xyz(a.di_diff_stash[i]))), sqrtf(luma(xyz(a.gi_diff_stash[i]))));
+    a.sl[1][i] = make_float2(sqrtf(luma(xyz(a.di_diff_prev_colors[i]))), sqrtf(luma(xyz(a.gi_diff_prev_colors[i]))));
+}
+void launch_refresh_internal_planes(const KArgs& a_in, hipStream_t s) {
+    KArgs a = a_in; a.row0 = 0; a.row1 = a.height;
+    ST_LAUNCH(k_refresh_internal_planes, false, s, a, const_cast<float4*>(a.psn));
+}
+
+}  // namespace ST_KNS
 }  // namespace st

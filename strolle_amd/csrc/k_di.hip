@@ -6,6 +6,7 @@
 #include "k_common.h"
 
 namespace st {
+namespace ST_KNS {
 
 // ---------------------------------------------------------------- di_sampling.rs:3-94
 template <bool LDS_SCENE, class SE>
@@ -222,4 +223,5 @@ void launch_di_resolving(const KArgs& a, bool reproject, hipStream_t s) {
     if (reproject) ST_LAUNCH_TRACE_B(k_di_resolving, true, false, s, a); else ST_LAUNCH_TRACE_B(k_di_resolving, false, false, s, a);
 }
 
+}  // namespace ST_KNS
 }  // namespace st

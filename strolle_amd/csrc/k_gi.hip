@@ -5,6 +5,7 @@
 #include "k_common.h"
 
 namespace st {
+namespace ST_KNS {
 
 // ---------------------------------------------------------------- gi_reprojection.rs:3-51
 __global__ ST_KERNEL_BOUNDS void k_gi_reprojection(const KArgs a) {
@@ -431,4 +432,5 @@ __global__ ST_KERNEL_BOUNDS void k_gi_resolving(const KArgs a, uint32_t source) 
 }
 void launch_gi_resolving(const KArgs& a, uint32_t source, hipStream_t s) { ST_LAUNCH(k_gi_resolving, false, s, a, source); }
 
+}  // namespace ST_KNS
 }  // namespace st

@@ -5,6 +5,7 @@
 #include "k_common.h"
 
 namespace st {
+namespace ST_KNS {
 
 // ---------------------------------------------------------------- bvh_heatmap.rs:3-77
 ST_D V3 heatmap_gradient(float progress) {
@@ -346,4 +347,5 @@ void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_d
     ST_LAUNCH(k_composition, false, s, a, camera_mode, di_diff, gi_diff, out, format);
 }
 
+}  // namespace ST_KNS
 }  // namespace st

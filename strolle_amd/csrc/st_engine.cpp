@@ -240,6 +240,7 @@ struct CameraState {
     size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
+    bool internal_dirty = false;  // st_camera_write_buffer replaced a plane the internal planes derive from: regenerate them before the next frame
 };
 static size_t plane_texels_per_pixel(int id) {
     if (id >= ST_BUF_DI_RESERVOIRS_0 && id <= ST_BUF_DI_RESERVOIRS_2) return 2;
@@ -341,6 +342,12 @@ struct Engine {
 
     std::unordered_map<uint64_t, std::unique_ptr<CameraState>> cameras; uint64_t next_camera = 0;
 
+    // Which build of the kernels this engine launches (st_kernels.h): fast arithmetic by default, the bit-exact build on request
+    // (st_engine_set_arithmetic, or ST_EXACT=1 in the environment when the engine is created).
+    int arithmetic = ST_ARITH_FAST;
+    Launchers L = launchers_fast();
+    std::vector<uint64_t> last_launches;  // pass bits of every launch the last render considered (st_debug_last_launches)
+    uint64_t pass_mask = ~0ull;  // st_debug_set_pass_mask: which reference passes a render executes (parity tests run one launch at a time)
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
@@ -377,6 +384,7 @@ struct Engine {
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
         if (const char* nd = getenv("ST_NO_DOUBLE_BUFFER")) double_buffer = atoi(nd) == 0;
         if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
+        if (const char* ex = getenv("ST_EXACT")) if (atoi(ex) != 0) { arithmetic = ST_ARITH_EXACT; L = launchers_exact(); }
     }
     void reset_profile_totals() {
         for (int i = 0; i < KS_COUNT; i++) {
@@ -896,12 +904,15 @@ struct Engine {
             const double units = rows * (ki.half ? (double)(((c.desc.width + 7u) / 8u / 2u) * 8u) : (double)c.desc.width);
             return units * ki.bytes_per_unit;
         };
-        // `fused`: reference passes executed inside this launch. Their (unfused) algorithmic bytes are credited to the
-        // launching slot so that fusion shows up as a gain, not as a moved goalpost.
         hipStream_t cur = stream;  // stream the next launches go to (the GI chain may be diverted to side_stream)
-        auto run = [&](int slot, std::initializer_list<int> fused, auto&& launch) {
-            double bytes = slot_bytes(slot);
-            for (int f : fused) bytes += slot_bytes(f);
+        // `bits`: the reference passes this launch executes (StPassBit). Their unfused algorithmic bytes are what
+        // kernel_info(slot) credits to the launch, so fusion shows up as a gain, not as a moved goalpost.
+        last_launches.clear();
+        bool mask_split = false;
+        auto run = [&](int slot, uint64_t bits, auto&& launch) {
+            last_launches.push_back(bits);
+            if ((bits & pass_mask) != bits) { mask_split |= (bits & pass_mask) != 0; return; }
+            const double bytes = slot_bytes(slot);
             a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
             Scope scope(this, cur, slot, bytes);
             launch();
@@ -909,25 +920,26 @@ struct Engine {
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
         const uint32_t mode = c.desc.mode;
         bool di_reprojected = false, gi_reprojected = false, composed = false, luts_generated_now = false;
+        if (c.internal_dirty) { L.launch_refresh_internal_planes(a, stream); c.internal_dirty = false; luts_generated_now = true; }  // ordered before the side stream like the LUTs
         if (mode != ST_MODE_BVH_HEATMAP) {  // AtmospherePass::run (passes/atmosphere.rs:78-110)
             if (!atmosphere_initialized) {
-                launch_atmosphere_static(static_cast<float4*>(d_transmittance.ptr), static_cast<float4*>(d_scattering.ptr), stream);
+                L.launch_atmosphere_static(static_cast<float4*>(d_transmittance.ptr), static_cast<float4*>(d_scattering.ptr), stream);
                 atmosphere_initialized = true; luts_generated_now = true;
             }
             if (!sky_known || known_sun_altitude != sun_altitude) {
-                launch_atmosphere_sky(static_cast<const float4*>(d_transmittance.ptr), static_cast<const float4*>(d_scattering.ptr), sun_altitude,
+                L.launch_atmosphere_sky(static_cast<const float4*>(d_transmittance.ptr), static_cast<const float4*>(d_scattering.ptr), sun_altitude,
                                       static_cast<float4*>(d_sky.ptr), stream);
                 sky_known = true; known_sun_altitude = sun_altitude; luts_generated_now = true;
             }
         }
         if (mode == ST_MODE_BVH_HEATMAP) {
-            run(KS_BVH_HEATMAP, {}, [&] { launch_bvh_heatmap(a, cur); });
+            run(KS_BVH_HEATMAP, ST_PASS_BVH_HEATMAP, [&] { L.launch_bvh_heatmap(a, cur); });
         } else if (mode == ST_MODE_REFERENCE) {
             for (uint32_t d = 0; d <= c.desc.depth; d++) {
-                run(KS_REF_TRACING, {}, [&] { launch_ref_tracing(a, d, cur); });
-                run(KS_REF_SHADING, {}, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + d), d, cur); });
+                run(KS_REF_TRACING, ST_PASS_REF_TRACING, [&] { L.launch_ref_tracing(a, d, cur); });
+                run(KS_REF_SHADING, ST_PASS_REF_SHADING, [&] { L.launch_ref_shading(a, seed(SEED_REF_SHADING + d), d, cur); });
             }
-            run(KS_REF_SHADING, {}, [&] { launch_ref_shading(a, seed(SEED_REF_SHADING + 255u), 255u, cur); });
+            run(KS_REF_SHADING, ST_PASS_REF_SHADING, [&] { L.launch_ref_shading(a, seed(SEED_REF_SHADING + 255u), 255u, cur); });
         } else {
             const bool needs_di = mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE || mode == ST_MODE_DI_SPECULAR;
             const bool needs_gi = mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE || mode == ST_MODE_GI_SPECULAR;
@@ -938,16 +950,16 @@ struct Engine {
             const uint32_t pseed = seed(SEED_GI_PREVIEW);  // one seed for both preview passes (passes/gi_preview_resampling.rs:60-74)
 
             auto do_prim = [&] {
-                if (fuse && any_objects) run(KS_PRIM_VISIBILITY_REPROJECTION, {}, [&] { launch_prim_visibility(a, true, cur); });
-                else run(KS_PRIM_VISIBILITY, {}, [&] { launch_prim_visibility(a, false, cur); });
-                if (any_objects && !fuse) run(KS_FRAME_REPROJECTION, {}, [&] { launch_frame_reprojection(a, cur); });
+                if (fuse && any_objects) run(KS_PRIM_VISIBILITY_REPROJECTION, ST_PASS_PRIM_VISIBILITY | ST_PASS_FRAME_REPROJECTION, [&] { L.launch_prim_visibility(a, true, cur); });
+                else run(KS_PRIM_VISIBILITY, ST_PASS_PRIM_VISIBILITY, [&] { L.launch_prim_visibility(a, false, cur); });
+                if (any_objects && !fuse) run(KS_FRAME_REPROJECTION, ST_PASS_FRAME_REPROJECTION, [&] { L.launch_frame_reprojection(a, cur); });
             };
             // DI up to temporal resampling touches only the DI reservoirs and read-only frame inputs ...
             auto do_di_head = [&] {
-                if (fuse && fuse_di_head) run(KS_DI_SAMPLING_TEMPORAL, {}, [&] { launch_di_sampling_temporal(a, seed(SEED_DI_SAMPLING), seed(SEED_DI_TEMPORAL), cur); });
+                if (fuse && fuse_di_head) run(KS_DI_SAMPLING_TEMPORAL, ST_PASS_DI_SAMPLING | ST_PASS_DI_TEMPORAL, [&] { L.launch_di_sampling_temporal(a, seed(SEED_DI_SAMPLING), seed(SEED_DI_TEMPORAL), cur); });
                 else {
-                    run(KS_DI_SAMPLING, {}, [&] { launch_di_sampling(a, seed(SEED_DI_SAMPLING), cur); });
-                    run(KS_DI_TEMPORAL, {}, [&] { launch_di_temporal(a, seed(SEED_DI_TEMPORAL), cur); });
+                    run(KS_DI_SAMPLING, ST_PASS_DI_SAMPLING, [&] { L.launch_di_sampling(a, seed(SEED_DI_SAMPLING), cur); });
+                    run(KS_DI_TEMPORAL, ST_PASS_DI_TEMPORAL, [&] { L.launch_di_temporal(a, seed(SEED_DI_TEMPORAL), cur); });
                 }
             };
             // ... the spatial passes use the denoiser's planes as scratch (passes/di_spatial_resampling.rs binds
@@ -956,14 +968,14 @@ struct Engine {
                 // the half-resolution grid drops the last tile column when the tile count is odd (`(size + 7) / 8 / (2, 1)`), while
                 // the stand-alone trace pass still visits those pixels: only an even tile count lets one launch cover all three
                 const bool even_tiles = (((a.width + 7u) / 8u) & 1u) == 0u;
-                if (fuse && fuse_spatial && even_tiles) run(KS_DI_SPATIAL_FUSED, {}, [&] { launch_di_spatial_fused(a, seed(SEED_DI_SPATIAL_PICK), seed(SEED_DI_SPATIAL_SAMPLE), cur); });
+                if (fuse && fuse_spatial && even_tiles) run(KS_DI_SPATIAL_FUSED, ST_PASS_DI_SPATIAL_PICK | ST_PASS_DI_SPATIAL_TRACE | ST_PASS_DI_SPATIAL_SAMPLE, [&] { L.launch_di_spatial_fused(a, seed(SEED_DI_SPATIAL_PICK), seed(SEED_DI_SPATIAL_SAMPLE), cur); });
                 else {
-                    run(KS_DI_SPATIAL_PICK, {}, [&] { launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), cur); });
-                    run(KS_DI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, cur); });
-                    run(KS_DI_SPATIAL_SAMPLE, {}, [&] { launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), cur); });
+                    run(KS_DI_SPATIAL_PICK, ST_PASS_DI_SPATIAL_PICK, [&] { L.launch_di_spatial_pick(a, seed(SEED_DI_SPATIAL_PICK), cur); });
+                    run(KS_DI_SPATIAL_TRACE, ST_PASS_DI_SPATIAL_TRACE, [&] { L.launch_spatial_trace(a, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_stash, cur); });
+                    run(KS_DI_SPATIAL_SAMPLE, ST_PASS_DI_SPATIAL_SAMPLE, [&] { L.launch_di_spatial_sample(a, seed(SEED_DI_SPATIAL_SAMPLE), cur); });
                 }
-                if (fuse && denoise) { run(KS_DI_RESOLVING_REPROJECT, {}, [&] { launch_di_resolving(a, true, cur); }); di_reprojected = true; }
-                else run(KS_DI_RESOLVING, {}, [&] { launch_di_resolving(a, false, cur); });
+                if (fuse && denoise) { run(KS_DI_RESOLVING_REPROJECT, ST_PASS_DI_RESOLVING | ST_PASS_DENOISE_REPROJECT_DI, [&] { L.launch_di_resolving(a, true, cur); }); di_reprojected = true; }
+                else run(KS_DI_RESOLVING, ST_PASS_DI_RESOLVING, [&] { L.launch_di_resolving(a, false, cur); });
             };
             auto do_di = [&] { do_di_head(); do_di_tail(); };
             // GI up to the first preview pass: touches only reservoirs, gi_d0..2 and read-only frame inputs
@@ -971,66 +983,66 @@ struct Engine {
                 // on tracing frames gi_temporal is the only reader of the reprojected reservoirs and does the reprojection itself
                 const bool fuse_gi_reprojection = fuse && fuse_gi_reproj && tracing;
                 auto temporal = [&] {
-                    if (fuse_gi_reprojection) run(KS_GI_REPROJECTION_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), true, cur); });
-                    else run(KS_GI_TEMPORAL, {}, [&] { launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), false, cur); });
+                    if (fuse_gi_reprojection) run(KS_GI_REPROJECTION_TEMPORAL, ST_PASS_GI_REPROJECTION | ST_PASS_GI_TEMPORAL, [&] { L.launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), true, cur); });
+                    else run(KS_GI_TEMPORAL, ST_PASS_GI_TEMPORAL, [&] { L.launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), false, cur); });
                 };
-                if (!fuse_gi_reprojection) run(KS_GI_REPROJECTION, {}, [&] { launch_gi_reprojection(a, cur); });
+                if (!fuse_gi_reprojection) run(KS_GI_REPROJECTION, ST_PASS_GI_REPROJECTION, [&] { L.launch_gi_reprojection(a, cur); });
                 auto sampling = [&] {
-                    run(KS_GI_SAMPLING_A, {}, [&] { launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), cur); });
-                    run(KS_GI_SAMPLING_B, {}, [&] { launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), cur); });
+                    run(KS_GI_SAMPLING_A, ST_PASS_GI_SAMPLING_A, [&] { L.launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), cur); });
+                    run(KS_GI_SAMPLING_B, ST_PASS_GI_SAMPLING_B, [&] { L.launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), cur); });
                 };
                 if (tracing) {
                     if (c.frame % 2u == 0u) sampling();
                     temporal();
                     if (c.frame % 2u == 1u) {
                         if (fuse && fuse_spatial && ((((a.width + 7u) / 8u) & 1u) == 0u))
-                            run(KS_GI_SPATIAL_FUSED, {}, [&] { launch_gi_spatial_fused(a, seed(SEED_GI_SPATIAL_PICK), seed(SEED_GI_SPATIAL_SAMPLE), cur); });
+                            run(KS_GI_SPATIAL_FUSED, ST_PASS_GI_SPATIAL_PICK | ST_PASS_GI_SPATIAL_TRACE | ST_PASS_GI_SPATIAL_SAMPLE, [&] { L.launch_gi_spatial_fused(a, seed(SEED_GI_SPATIAL_PICK), seed(SEED_GI_SPATIAL_SAMPLE), cur); });
                         else {
-                            run(KS_GI_SPATIAL_PICK, {}, [&] { launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), cur); });
-                            run(KS_GI_SPATIAL_TRACE, {}, [&] { launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, cur); });
-                            run(KS_GI_SPATIAL_SAMPLE, {}, [&] { launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), cur); });
+                            run(KS_GI_SPATIAL_PICK, ST_PASS_GI_SPATIAL_PICK, [&] { L.launch_gi_spatial_pick(a, seed(SEED_GI_SPATIAL_PICK), cur); });
+                            run(KS_GI_SPATIAL_TRACE, ST_PASS_GI_SPATIAL_TRACE, [&] { L.launch_spatial_trace(a, a.gi_d0, a.gi_d1, a.gi_d2, cur); });
+                            run(KS_GI_SPATIAL_SAMPLE, ST_PASS_GI_SPATIAL_SAMPLE, [&] { L.launch_gi_spatial_sample(a, seed(SEED_GI_SPATIAL_SAMPLE), cur); });
                         }
                     }
                 } else {
                     sampling();
                     temporal();
                 }
-                run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 0u, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], cur); });
+                run(KS_GI_PREVIEW, ST_PASS_GI_PREVIEW_0, [&] { L.launch_gi_preview(a, pseed, 0u, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], cur); });
             };
             // second preview pass + resolving (+ reproject): the first GI stage that writes planes the denoiser/composition read
             auto do_gi_tail = [&] {
                 if (fuse) {
-                    if (denoise) { run(KS_GI_PREVIEW_RESOLVE_REPROJECT, {}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, true, cur); }); gi_reprojected = true; }
-                    else run(KS_GI_PREVIEW_RESOLVE, {}, [&] { launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, false, cur); });
+                    if (denoise) { run(KS_GI_PREVIEW_RESOLVE_REPROJECT, ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING | ST_PASS_DENOISE_REPROJECT_GI, [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, true, cur); }); gi_reprojected = true; }
+                    else run(KS_GI_PREVIEW_RESOLVE, ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING, [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, false, cur); });
                 } else {
-                    run(KS_GI_PREVIEW, {}, [&] { launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], cur); });
-                    run(KS_GI_RESOLVING, {}, [&] { launch_gi_resolving(a, gi_source, cur); });
+                    run(KS_GI_PREVIEW, ST_PASS_GI_PREVIEW_1, [&] { L.launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], cur); });
+                    run(KS_GI_RESOLVING, ST_PASS_GI_RESOLVING, [&] { L.launch_gi_resolving(a, gi_source, cur); });
                 }
             };
             auto do_denoise = [&] {
                 if (!denoise) return;
                 // the denoiser can use its own block -> tile mapping (see `tile_map_denoise`)
                 struct MapScope { KArgs& a; uint32_t saved; MapScope(KArgs& a_, uint32_t m) : a(a_), saved(a_.tile_map) { a.tile_map = m; } ~MapScope() { a.tile_map = saved; } } map_scope(a, tile_map_denoise);
-                if (!di_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, cur); });
-                if (!gi_reprojected) run(KS_DENOISE_REPROJECT, {}, [&] { launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, cur); });
-                run(KS_DENOISE_VARIANCE, {}, [&] { launch_denoise_variance(a, cur); });
+                if (!di_reprojected) run(KS_DENOISE_REPROJECT, ST_PASS_DENOISE_REPROJECT_DI, [&] { L.launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, cur); });
+                if (!gi_reprojected) run(KS_DENOISE_REPROJECT, ST_PASS_DENOISE_REPROJECT_GI, [&] { L.launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, cur); });
+                run(KS_DENOISE_VARIANCE, ST_PASS_DENOISE_VARIANCE, [&] { L.launch_denoise_variance(a, cur); });
                 // ping-pong (passes/frame_denoising.rs:87-110): stash -> prev -> stash -> curr -> stash -> curr
                 float4* di[3] = {a.di_diff_stash, a.di_diff_prev_colors, a.di_diff_curr_colors};
                 float4* gi[3] = {a.gi_diff_stash, a.gi_diff_prev_colors, a.gi_diff_curr_colors};
                 const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
                 for (uint32_t nth = 0; nth < 5; nth++) {
                     if (nth == 4 && fuse_compose && out && c.out_format == 0u) {
-                        run(KS_DENOISE_WAVELET_COMPOSE, {}, [&] { launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nullptr, mode, static_cast<float4*>(out), cur); });
+                        run(KS_DENOISE_WAVELET_COMPOSE, ((uint64_t)ST_PASS_DENOISE_WAVELET_0 << nth) | ST_PASS_COMPOSITION, [&] { L.launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nullptr, mode, static_cast<float4*>(out), cur); });
                         composed = true;
                     } else
-                        run(KS_DENOISE_WAVELET, {}, [&] { launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nth <= 2u ? a.sl[nth & 1u] : nullptr, nth <= 1u ? a.sl[(nth & 1u) ^ 1u] : nullptr, cur); });
+                        run(KS_DENOISE_WAVELET, (uint64_t)ST_PASS_DENOISE_WAVELET_0 << nth, [&] { L.launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nth <= 2u ? a.sl[nth & 1u] : nullptr, nth <= 1u ? a.sl[(nth & 1u) ^ 1u] : nullptr, cur); });
                 }
             };
             auto do_compose = [&] {
                 if (!out || composed) return;
                 const float4* di_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
                 const float4* gi_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
-                run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
+                run(KS_COMPOSITION, ST_PASS_COMPOSITION, [&] { L.launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
                 composed = true;
             };
 
@@ -1095,7 +1107,7 @@ struct Engine {
             const bool dn = c.desc.denoise != 0u;
             const float4* di_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
             const float4* gi_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
-            run(KS_COMPOSITION, {}, [&] { launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
+            run(KS_COMPOSITION, ST_PASS_COMPOSITION, [&] { L.launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
         }
         if (alternating) {  // the end of the last frame that reads this copy of the scene
             SceneSet& l = sets[live];
@@ -1108,6 +1120,7 @@ struct Engine {
             ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
         }
         ST_HIP(hipGetLastError());
+        if (mask_split) return fail(ST_ERR_INVALID_ARGUMENT, "the pass mask splits a fused launch (st_debug_last_launches lists the launch groups)");
         return ST_OK;
     }
 };
@@ -1138,7 +1151,7 @@ int st_engine_create(int device_ordinal, StEngine** out) {
         DeviceArray* luts[3] = {&e->d_transmittance, &e->d_scattering, &e->d_sky};
         for (int i = 0; i < 3; i++) { ST_HIP(hipMalloc(&luts[i]->ptr, lut_bytes[i])); luts[i]->capacity = lut_bytes[i]; ST_HIP(hipMemset(luts[i]->ptr, 0, lut_bytes[i])); }
         ST_HIP(hipMalloc(&e->d_byte_luts.ptr, sizeof(float) * 1024)); e->d_byte_luts.capacity = sizeof(float) * 1024;
-        launch_build_byte_luts(static_cast<float*>(e->d_byte_luts.ptr), nullptr);
+        e->L.launch_build_byte_luts(static_cast<float*>(e->d_byte_luts.ptr), nullptr);
         ST_HIP(hipDeviceSynchronize());
     }
     *out = reinterpret_cast<StEngine*>(e.release());
@@ -1372,6 +1385,46 @@ int st_camera_read_buffer(StEngine* e, StHandle h, int id, void* out, size_t cap
     ST_HIP(hipMemcpy(out, c.plane[id], c.plane_bytes[id], hipMemcpyDeviceToHost));
     return ST_OK;
 }
+int st_camera_write_buffer(StEngine* e, StHandle h, int id, const void* data, size_t bytes) {
+    ST_REQUIRE(e && data && id >= 0 && id < ST_BUF_COUNT, "bad buffer id");
+    Engine* en = E(e);
+    auto it = en->cameras.find(h);
+    if (it == en->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "host-only engine has no camera buffers");
+    CameraState& c = *it->second;
+    ST_REQUIRE(bytes == c.plane_bytes[id], "size does not match the buffer");
+    ST_HIP(hipSetDevice(en->device));
+    ST_HIP(hipDeviceSynchronize());
+    ST_HIP(hipMemcpy(c.plane[id], data, bytes, hipMemcpyHostToDevice));
+    c.internal_dirty = true;
+    return ST_OK;
+}
+int st_debug_set_pass_mask(StEngine* e, uint64_t mask) { ST_REQUIRE(e, "null engine"); E(e)->pass_mask = mask; return ST_OK; }
+int st_debug_last_launches(StEngine* e, uint64_t* out_bits, size_t capacity, size_t* count) {
+    ST_REQUIRE(e && count, "null argument");
+    const std::vector<uint64_t>& v = E(e)->last_launches;
+    *count = v.size();
+    for (size_t i = 0; i < v.size() && i < capacity && out_bits; i++) out_bits[i] = v[i];
+    return ST_OK;
+}
+int st_engine_set_arithmetic(StEngine* e, int arithmetic) {
+    ST_REQUIRE(e, "null engine");
+    ST_REQUIRE(arithmetic == ST_ARITH_FAST || arithmetic == ST_ARITH_EXACT, "unknown arithmetic");
+    Engine* en = E(e);
+    if (en->arithmetic == arithmetic) return ST_OK;
+    en->arithmetic = arithmetic;
+    en->L = arithmetic == ST_ARITH_EXACT ? launchers_exact() : launchers_fast();
+    if (en->has_device) {  // frames in flight finish with the tables they were launched with; the byte tables follow the build
+        ST_HIP(hipSetDevice(en->device));
+        ST_HIP(hipDeviceSynchronize());
+        en->L.launch_build_byte_luts(static_cast<float*>(en->d_byte_luts.ptr), nullptr);
+        ST_HIP(hipDeviceSynchronize());
+        // the atmosphere LUTs are regenerated by the next render with the new build's routines
+        en->atmosphere_initialized = false; en->sky_known = false;
+    }
+    return ST_OK;
+}
+int st_engine_get_arithmetic(StEngine* e, int* out) { ST_REQUIRE(e && out, "null argument"); *out = E(e)->arithmetic; return ST_OK; }
 int st_camera_ray_count(StEngine* e, StHandle h, uint64_t* out, int reset) {
     ST_REQUIRE(e && out, "null argument");
     Engine* en = E(e);

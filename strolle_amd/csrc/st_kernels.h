@@ -45,49 +45,34 @@ inline const KernelInfo& kernel_info(int slot) {
     return k[slot];
 }
 
-// atmosphere LUTs (passes/atmosphere.rs: transmittance + scattering once, sky on sun-altitude change)
-void launch_atmosphere_static(float4* transmittance_lut, float4* scattering_lut, hipStream_t s);
-void launch_atmosphere_sky(const float4* transmittance_lut, const float4* scattering_lut, float sun_altitude, float4* sky_lut, hipStream_t s);
-// ray-tracing passes
-void launch_bvh_heatmap(const KArgs& a, hipStream_t s);
-void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s);
-void launch_ref_shading(const KArgs& a, uint32_t seed, uint32_t depth, hipStream_t s);
-void launch_prim_visibility(const KArgs& a, bool fuse_frame_reprojection, hipStream_t s);
-void launch_build_byte_luts(float* out /* kByteLutFloats */, hipStream_t s);  // st_device.h byte decode tables
-void launch_frame_reprojection(const KArgs& a, hipStream_t s);
-// ReSTIR DI
-void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_di_sampling_temporal(const KArgs& a, uint32_t seed_sampling, uint32_t seed_temporal, hipStream_t s);  // both passes, one launch
-void launch_di_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s);
-void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_di_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_sample, hipStream_t s);  // pick + trace + sample per cell
-void launch_di_resolving(const KArgs& a, bool fuse_denoise_reproject, hipStream_t s);
-// ReSTIR GI
-void launch_gi_reprojection(const KArgs& a, hipStream_t s);
-void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s);
-// fuse_reprojection: gi_reprojection.rs runs inside this launch (legal on tracing frames, where nothing else reads gi_res[2] before)
-void launch_gi_temporal(const KArgs& a, uint32_t seed, bool fuse_reprojection, hipStream_t s);
-void launch_gi_spatial_pick(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s);
-void launch_gi_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_sample, hipStream_t s);  // pick + trace + sample per cell
-void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s);
-void launch_gi_resolving(const KArgs& a, uint32_t source, hipStream_t s);
-// second preview pass + gi_resolving (+ the GI half of denoise reproject) in one launch
-void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, uint32_t source, bool fuse_denoise_reproject, hipStream_t s);
-// SVGF + composition
-void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const float4* prev_moments, const float4* samples, float4* colors,
-                              float4* moments, hipStream_t s);
-void launch_denoise_variance(const KArgs& a, hipStream_t s);
-// sl_in / sl_out: sqrt-luma planes of the input / output colour planes (KArgs::sl). The LDS-staged strides (1, 2, 4)
-// require sl_in; strides 8 and 16 take null and derive the values from the colours. sl_out null = not needed downstream.
-void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
-                            float4* gi_out, const float2* sl_in, float2* sl_out, hipStream_t s);
-// last wavelet pass + frame composition in one launch
-void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
-                                    float4* gi_out, const float2* sl_in, uint32_t camera_mode, float4* frame_out, hipStream_t s);
-void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, void* out, uint32_t format, hipStream_t s);
+// The launchers exist twice, in namespaces st::exact and st::fast (the two arithmetic builds of the kernel files, Makefile);
+// the engine calls them through a table picked per engine (st_engine_set_arithmetic).
+#define ST_LAUNCHER(name, args) void name args;
+namespace exact {
+#include "st_launchers.inc"
+}
+namespace fast {
+#include "st_launchers.inc"
+}
+#undef ST_LAUNCHER
+struct Launchers {
+#define ST_LAUNCHER(name, args) void (*name) args;
+#include "st_launchers.inc"
+#undef ST_LAUNCHER
+};
+inline Launchers launchers_exact() {
+    Launchers t;
+#define ST_LAUNCHER(name, args) t.name = &exact::name;
+#include "st_launchers.inc"
+#undef ST_LAUNCHER
+    return t;
+}
+inline Launchers launchers_fast() {
+    Launchers t;
+#define ST_LAUNCHER(name, args) t.name = &fast::name;
+#include "st_launchers.inc"
+#undef ST_LAUNCHER
+    return t;
+}
 
 }  // namespace st

@@ -28,7 +28,7 @@ def _torch():
 
 
 def _pair(build, size, mode, depth=0, denoise=True, seed=11, camera_fn=scenes.cornell_camera):
-    prod, orac = Engine(device=0), OracleEngine()
+    prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
         build(e)
         e.set_seed(seed)
@@ -109,7 +109,7 @@ def test_moving_camera_and_light_bit_exact():
     """Reprojection, velocity and the prev-light path (lights.rs commit/rollback) under motion."""
     torch = _torch()
     size = (160, 96)
-    prod, orac = Engine(device=0), OracleEngine()
+    prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
         scenes.build_cornell(e); e.set_seed(3)
     desc = scenes.cornell_camera(size, CameraMode.IMAGE)
@@ -128,10 +128,42 @@ def test_moving_camera_and_light_bit_exact():
         assert_bits_equal(img, ref, f"moving frame {frame}")
 
 
-def test_full_size_properties_1080p():
-    """BASELINE.json's full size: the oracle is too slow for every frame, so check size-independent
-    properties — determinism (two engines, same seed => identical bits), finiteness, ray budget <= 5N
-     — plus a bit-exact oracle comparison of the first frame's heatmap integers."""
+def _full_size_run(torch, build, camera_fn, size, mode, frames, all_planes_at, seed=5):
+    """Exact build vs oracle at a BASELINE.json configuration's stated size: the composed frame after every frame, every
+    per-camera plane at the frames listed in `all_planes_at` (the last one included: it carries the whole temporal state —
+    reservoirs, history colours, moments — so a divergence in any earlier frame would show there), and the ray counts."""
+    prod, orac, desc, cp, co = _pair(build, size, mode, seed=seed, camera_fn=camera_fn)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(frames):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        assert_bits_equal(img, ref, f"{size[0]}x{size[1]} {mode.name} frame {frame}")
+        if frame in all_planes_at:
+            _compare_all(prod, orac, cp, co, frame, list(Buffer))
+    assert prod.ray_count(cp) == orac.ray_count(co)
+    prod.close(); orac.close()
+
+
+def test_config2_cornell_1080p_image_14_frames_bit_exact():
+    """BASELINE.json config 2 at its stated size — Cornell 1920x1080, Image{denoise:true} (camera_controller.rs:113-172, the
+    headline configuration) — over 14 frames (more than two 6-frame GI cycles, frame.rs:19-21)."""
+    _full_size_run(_torch(), scenes.build_cornell, scenes.cornell_camera, (1920, 1080), CameraMode.IMAGE, 14, {5, 13})
+
+
+def test_config3_dungeon_1080p_gi_diffuse_8_frames_bit_exact():
+    """BASELINE.json config 3 at its stated size — dungeon 1920x1080, GiDiffuse{denoise:true}; its BVH-heatmap check is
+    test_dungeon_heatmap_1080p_bit_exact."""
+    _full_size_run(_torch(), scenes.build_dungeon, scenes.dungeon_camera, (1920, 1080), CameraMode.GI_DIFFUSE, 8, {7})
+
+
+def test_config5_dungeon_4k_image_4_frames_bit_exact():
+    """BASELINE.json config 5's per-frame work at its stated size — dungeon 3840x2160, Image{denoise:true} — on one GPU
+    (the 8-way split of the same frame is test_row_bands_*)."""
+    _full_size_run(_torch(), scenes.build_dungeon, scenes.dungeon_camera, (3840, 2160), CameraMode.IMAGE, 4, {3})
+
+
+def test_full_size_ray_budget_and_determinism_1080p():
+    """Size-independent properties at the headline size, in the DEFAULT (fast) build: two engines with the same seed give
+    identical bits, every frame is finite, and the ray budget is N <= rays <= 5N per frame."""
     torch = _torch()
     size = (1920, 1080)
     n = size[0] * size[1]
@@ -162,7 +194,7 @@ def test_full_size_properties_1080p():
 
 def test_errors_are_loud():
     from strolle_amd import StrolleError
-    prod = Engine(device=0)
+    prod = Engine(device=0, exact=True)
     with pytest.raises(StrolleError):
         prod.render_camera(12345, 0, 0)       # unknown camera: the reference panics (camera_controllers.rs:21-34)
     host_only = Engine(device=-1)
@@ -203,7 +235,7 @@ def _render_bands(torch, build, size, mode, depth, frames, n_bands, apron, camer
     w, h = size
     full = []
     for r in range(n_bands):
-        e = Engine(device=0)
+        e = Engine(device=0, exact=True)
         build(e); e.set_seed(21)
         desc = camera_fn(size, mode, depth=depth)
         cam = e.create_camera(desc)
@@ -293,7 +325,7 @@ def test_back_to_back_frames_without_sync_bit_exact(scene):
     cam_fn = scenes.cornell_camera if scene == "cornell" else scenes.dungeon_camera
     finals = []
     for rep in range(2):
-        prod = Engine(device=0)
+        prod = Engine(device=0, exact=True)
         build(prod); prod.set_seed(31)
         desc = cam_fn(size, CameraMode.IMAGE)
         cp = prod.create_camera(desc)
@@ -380,7 +412,7 @@ def test_scene_edits_between_frames_bit_exact():
     torch = _torch()
     from strolle_amd import Light, Material
     size = (128, 80)
-    prod, orac = Engine(device=0), OracleEngine()
+    prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
         scenes.build_random_soup(e, 1200, seed=13, n_lights=4); e.set_seed(5)
     desc = scenes.cornell_camera(size, CameraMode.IMAGE)
@@ -413,7 +445,7 @@ def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
     torch = _torch()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dump = tmp_path / "frame.npy"
-    env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", ST_EXACT="1")  # exact build: the bit-compare below needs it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--width", "128", "--height", "64", "--mode", "reference",
            "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
@@ -425,7 +457,7 @@ def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
     assert out["config"]["rays_per_frame"] > 0 and out["value"] > 0
     got = np.load(dump)
     # the same 5 frames in one process
-    prod = Engine(device=0)
+    prod = Engine(device=0, exact=True)
     scenes.build_cornell(prod); prod.set_seed(0)
     desc = scenes.cornell_camera((128, 128), CameraMode.REFERENCE, depth=1)
     cam = prod.create_camera(desc)
@@ -444,7 +476,7 @@ def test_moving_instances_velocity_bit_exact():
     import math
     from strolle_amd import Instance
     size = (144, 96)
-    prod, orac = Engine(device=0), OracleEngine()
+    prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
         scenes.build_random_soup(e, 1600, seed=17, n_lights=3); e.set_seed(9)
     desc = scenes.cornell_camera(size, CameraMode.IMAGE)
@@ -506,7 +538,7 @@ from oracle_binding import OracleEngine
 from parity import assert_bits_equal
 from strolle_amd import Buffer, CameraMode, Engine, scenes
 for build, cam_fn in ((scenes.build_cornell, scenes.cornell_camera), (scenes.build_dungeon, scenes.dungeon_camera)):
-    prod, orac = Engine(device=0), OracleEngine()
+    prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
         build(e); e.set_seed(4)
     size = (136, 88)
@@ -536,7 +568,7 @@ def test_random_edit_history_renders_bit_exact(seed):
     from strolle_amd import Instance, Light, Material
     rng = np.random.default_rng(seed)
     size = (112, 72)
-    prod, orac = Engine(device=0), OracleEngine()
+    prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
         scenes.build_random_soup(e, 900, seed=seed, n_lights=3); e.set_seed(seed)
     desc = scenes.cornell_camera(size, CameraMode.IMAGE)
@@ -665,7 +697,7 @@ def test_bvh_refit_mode_renders_bit_exact():
     import math
     from strolle_amd import Instance
     size = (144, 96)
-    prod, orac = Engine(device=0), OracleEngine()
+    prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
         scenes.build_random_soup(e, 2400, seed=23, n_lights=3); e.set_seed(4); e.set_bvh_refresh(True)
     desc = scenes.cornell_camera(size, CameraMode.IMAGE)
