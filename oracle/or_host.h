@@ -778,6 +778,7 @@ struct Engine {
             sky_known = true; known_sun_altitude = sun_altitude;
         }
     }
+    uint64_t pass_mask = ~0ull;  // which reference passes render_camera executes (parity tests step through a frame one launch at a time)
     bool render_camera(uint64_t h, Vec4* out) {
         auto it = cameras.find(h);
         if (it == cameras.end()) return false;
@@ -790,61 +791,62 @@ struct Engine {
         uint32_t mode = s.api.mode;
         bool denoise = s.api.denoise != 0 && mode <= 4;
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, frame.id, pass); };
+        auto on = [&](uint32_t bit) { return (pass_mask >> bit) & 1ull; };  // or_debug_set_pass_mask: bit numbers = include/strolle_hip.h StPassBit
         if (mode == 5) {
-            pass_bvh_heatmap(e, b);
+            if (on(27)) pass_bvh_heatmap(e, b);
         } else if (mode == 6) {
             for (uint32_t d = 0; d <= s.api.depth; d++) {
-                pass_ref_tracing(e, b, d);
-                pass_ref_shading(e, b, seed(PASS_REF_SHADING + d), d);
+                if (on(28)) pass_ref_tracing(e, b, d);
+                if (on(29)) pass_ref_shading(e, b, seed(PASS_REF_SHADING + d), d);
             }
-            pass_ref_shading(e, b, seed(PASS_REF_SHADING + 255), 255);
+            if (on(29)) pass_ref_shading(e, b, seed(PASS_REF_SHADING + 255), 255);
         } else {
             bool needs_di = mode == 0 || mode == 1 || mode == 2;
             bool needs_gi = mode == 0 || mode == 3 || mode == 4;
             const InstanceXforms xf{xf_curr_inv.data(), xf_prev.data(), triangle_slot.data()};
-            pass_prim_visibility(e, b, alt, &xf);
+            if (on(0)) pass_prim_visibility(e, b, alt, &xf);
             if (!instances.empty()) {
-                pass_frame_reprojection(b, alt);
+                if (on(1)) pass_frame_reprojection(b, alt);
                 if (needs_di) {
-                    pass_di_sampling(e, b, alt, seed(PASS_DI_SAMPLING), frame);
-                    pass_di_temporal_resampling(e, b, alt, seed(PASS_DI_TEMPORAL));
-                    pass_di_spatial_pick(e, b, alt, seed(PASS_DI_SPATIAL_PICK), frame);
-                    pass_spatial_trace(e, b, b.di_diff_samples, b.di_diff_curr_colors, b.di_diff_stash);
-                    pass_di_spatial_sample(b, seed(PASS_DI_SPATIAL_SAMPLE), frame);
-                    pass_di_resolving(e, b, alt);
+                    if (on(2)) pass_di_sampling(e, b, alt, seed(PASS_DI_SAMPLING), frame);
+                    if (on(3)) pass_di_temporal_resampling(e, b, alt, seed(PASS_DI_TEMPORAL));
+                    if (on(4)) pass_di_spatial_pick(e, b, alt, seed(PASS_DI_SPATIAL_PICK), frame);
+                    if (on(5)) pass_spatial_trace(e, b, b.di_diff_samples, b.di_diff_curr_colors, b.di_diff_stash);
+                    if (on(6)) pass_di_spatial_sample(b, seed(PASS_DI_SPATIAL_SAMPLE), frame);
+                    if (on(7)) pass_di_resolving(e, b, alt);
                 }
                 if (needs_gi) {
                     uint32_t source;
-                    pass_gi_reprojection(b, alt);
+                    if (on(8)) pass_gi_reprojection(b, alt);
                     if (frame.is_gi_tracing()) {
                         if (frame.id % 2 == 0) {
-                            pass_gi_sampling_a(e, b, alt, seed(PASS_GI_SAMPLING_A), frame);
-                            pass_gi_sampling_b(e, b, alt, seed(PASS_GI_SAMPLING_B), frame);
+                            if (on(9)) pass_gi_sampling_a(e, b, alt, seed(PASS_GI_SAMPLING_A), frame);
+                            if (on(10)) pass_gi_sampling_b(e, b, alt, seed(PASS_GI_SAMPLING_B), frame);
                         }
-                        pass_gi_temporal_resampling(b, alt, seed(PASS_GI_TEMPORAL), frame);
+                        if (on(11)) pass_gi_temporal_resampling(b, alt, seed(PASS_GI_TEMPORAL), frame);
                         if (frame.id % 2 == 1) {
-                            pass_gi_spatial_pick(b, alt, seed(PASS_GI_SPATIAL_PICK), frame);
-                            pass_spatial_trace(e, b, b.gi_d0, b.gi_d1, b.gi_d2);
-                            pass_gi_spatial_sample(b, seed(PASS_GI_SPATIAL_SAMPLE), frame);
+                            if (on(12)) pass_gi_spatial_pick(b, alt, seed(PASS_GI_SPATIAL_PICK), frame);
+                            if (on(13)) pass_spatial_trace(e, b, b.gi_d0, b.gi_d1, b.gi_d2);
+                            if (on(14)) pass_gi_spatial_sample(b, seed(PASS_GI_SPATIAL_SAMPLE), frame);
                             source = 1;
                         } else source = 0;
                     } else {
-                        pass_gi_sampling_a(e, b, alt, seed(PASS_GI_SAMPLING_A), frame);
-                        pass_gi_sampling_b(e, b, alt, seed(PASS_GI_SAMPLING_B), frame);
-                        pass_gi_temporal_resampling(b, alt, seed(PASS_GI_TEMPORAL), frame);
+                        if (on(9)) pass_gi_sampling_a(e, b, alt, seed(PASS_GI_SAMPLING_A), frame);
+                        if (on(10)) pass_gi_sampling_b(e, b, alt, seed(PASS_GI_SAMPLING_B), frame);
+                        if (on(11)) pass_gi_temporal_resampling(b, alt, seed(PASS_GI_TEMPORAL), frame);
                         source = 0;
                     }
                     // gi_preview_resampling (host :60-74): pass 1 reads [1] or [2] -> [3]; pass 2 reads [3] (source forced to 1) -> [0]
                     uint32_t pseed = seed(PASS_GI_PREVIEW);
-                    pass_gi_preview_resampling(b, alt, pseed, source, 0, b.gi_reservoirs[1], b.gi_reservoirs[2], b.gi_reservoirs[3]);
-                    pass_gi_preview_resampling(b, alt, pseed, 1, 1, b.gi_reservoirs[1], b.gi_reservoirs[3], b.gi_reservoirs[0]);
-                    pass_gi_resolving(b, alt, source);
+                    if (on(15)) pass_gi_preview_resampling(b, alt, pseed, source, 0, b.gi_reservoirs[1], b.gi_reservoirs[2], b.gi_reservoirs[3]);
+                    if (on(16)) pass_gi_preview_resampling(b, alt, pseed, 1, 1, b.gi_reservoirs[1], b.gi_reservoirs[3], b.gi_reservoirs[0]);
+                    if (on(17)) pass_gi_resolving(b, alt, source);
                 }
             }
             if (denoise) {
-                pass_denoise_reproject(b, alt, b.di_diff_prev_colors, b.di_diff_moments[!alt], b.di_diff_samples, b.di_diff_curr_colors, b.di_diff_moments[alt]);
-                pass_denoise_reproject(b, alt, b.gi_diff_prev_colors, b.gi_diff_moments[!alt], b.gi_diff_samples, b.gi_diff_curr_colors, b.gi_diff_moments[alt]);
-                pass_denoise_estimate_variance(b, alt);
+                if (on(18)) pass_denoise_reproject(b, alt, b.di_diff_prev_colors, b.di_diff_moments[!alt], b.di_diff_samples, b.di_diff_curr_colors, b.di_diff_moments[alt]);
+                if (on(19)) pass_denoise_reproject(b, alt, b.gi_diff_prev_colors, b.gi_diff_moments[!alt], b.gi_diff_samples, b.gi_diff_curr_colors, b.gi_diff_moments[alt]);
+                if (on(20)) pass_denoise_estimate_variance(b, alt);
                 struct WP { Plane *di_in, *di_out, *gi_in, *gi_out; };
                 WP wp[5] = {{&b.di_diff_stash, &b.di_diff_prev_colors, &b.gi_diff_stash, &b.gi_diff_prev_colors},
                             {&b.di_diff_prev_colors, &b.di_diff_stash, &b.gi_diff_prev_colors, &b.gi_diff_stash},
@@ -852,12 +854,12 @@ struct Engine {
                             {&b.di_diff_curr_colors, &b.di_diff_stash, &b.gi_diff_curr_colors, &b.gi_diff_stash},
                             {&b.di_diff_stash, &b.di_diff_curr_colors, &b.gi_diff_stash, &b.gi_diff_curr_colors}};
                 for (uint32_t nth = 0; nth < 5; nth++)
-                    pass_denoise_wavelet(e, b, alt, frame, 1u << nth, (float)(1 + nth), *wp[nth].di_in, *wp[nth].di_out, *wp[nth].gi_in, *wp[nth].gi_out);
+                    if (on(21 + nth)) pass_denoise_wavelet(e, b, alt, frame, 1u << nth, (float)(1 + nth), *wp[nth].di_in, *wp[nth].di_out, *wp[nth].gi_in, *wp[nth].gi_out);
             }
         }
         if (out) {
             bool dn = s.api.denoise != 0;
-            pass_frame_composition(b, alt, mode, dn && (mode == 0 || mode == 1), dn && (mode == 0 || mode == 3), out);
+            if (on(26)) pass_frame_composition(b, alt, mode, dn && (mode == 0 || mode == 1), dn && (mode == 0 || mode == 3), out);
         }
         return true;
     }

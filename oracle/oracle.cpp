@@ -92,6 +92,8 @@ int or_encode_output(const float* rgba32f, size_t pixels, int format, void* out)
     }
     return 1;
 }
+int or_debug_set_pass_mask(OrEngine* e, uint64_t mask) { E(e)->pass_mask = mask; return 0; }
+int or_camera_write_buffer(OrEngine* e, uint64_t h, int buffer_id, const void* data, size_t bytes);
 int or_render_camera(OrEngine* e, uint64_t h, float* out_rgba32f) { return E(e)->render_camera(h, reinterpret_cast<Vec4*>(out_rgba32f)) ? 0 : 3; }
 
 // ---- debug / parity read-back (buffer ids shared with include/strolle_hip.h ST_BUF_*)
@@ -126,6 +128,15 @@ int or_camera_read_buffer(OrEngine* e, uint64_t h, int buffer_id, void* out, siz
     if (!p) return 1;
     if (written) *written = bytes;
     if (out) { if (capacity < bytes) return 1; std::memcpy(out, p, bytes); }
+    return 0;
+}
+int or_camera_write_buffer(OrEngine* e, uint64_t h, int buffer_id, const void* data, size_t bytes) {
+    auto it = E(e)->cameras.find(h);
+    if (it == E(e)->cameras.end()) return 3;
+    size_t have = 0;
+    const void* p = buffer_ptr(it->second->buffers, buffer_id, &have);
+    if (!p || have != bytes) return 1;
+    std::memcpy(const_cast<void*>(p), data, bytes);
     return 0;
 }
 int or_camera_ray_count(OrEngine* e, uint64_t h, uint64_t* out, int reset) {

@@ -15,11 +15,33 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef int i2v __attribute__((ext_vector_type(2)));
 ST_D f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
 ST_D f2 splat2(float x) { return mk2(x, x); }
+ST_D f2 sqrt2(f2 x) { return mk2(fsqrt(x.x), fsqrt(x.y)); }
+// x / d where 1 / d may be precomputed: the exact build divides, the fast build multiplies by the hoisted reciprocal
+ST_D float div_by(float x, float d, float inv_d) {
+#if ST_FAST_DEVICE
+    return x * inv_d;
+#else
+    return x / d;
+#endif
+}
+// frame_denoising.rs:343-358: colour sums / weight sum, variance sum / weight sum squared
+ST_D float4 wavelet_resolve(float r, float g, float b, float v, float w, float ww) {
+#if ST_FAST_DEVICE
+    const float iw = frcp(w);
+    return make_float4(r * iw, g * iw, b * iw, v * (iw * iw));
+#else
+    return make_float4(r / w, g / w, b / w, v / ww);
+#endif
+}
 
 // exp_() of both halves. Inside |x| < 87 none of exp_'s range branches fire and scale2() is a single multiplication by
 // 2^n with -126 <= n <= 126, so the straight-line packed evaluation is exp_() operation for operation; anything else
 // (NaN, overflow, the denormal tail) takes the scalar routine.
 ST_D f2 exp_pair(f2 x) {
+#if ST_FAST_DEVICE
+    x = x * 1.44269504088896341f;
+    return mk2(__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y));
+#endif
     if (!(fabsf(x.x) < 87.0f && fabsf(x.y) < 87.0f)) return mk2(exp_(x.x), exp_(x.y));
     const f2 z = __builtin_elementwise_floor(1.44269504088896341f * x + 0.5f);
     x = x - z * 0.693359375f;
@@ -91,8 +113,8 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a) {
         // starts at (-2,-2) and every later row starts at -3), kept as is; the two signals share packed-f32 arithmetic
         // as in the wavelet pass.
         const V3 cn = v3(csn.x, csn.y, csn.z);
-        const f2 c_sqrt_luma = mk2(sqrtf(cdi_luma), sqrtf(cgi_luma));
-        const float leeway = csn.w * 0.2f;
+        const f2 c_sqrt_luma = mk2(fsqrt(cdi_luma), fsqrt(cgi_luma));
+        const float leeway = csn.w * 0.2f, inv_leeway = frcp(leeway);
         const int lc = ((int)(pos.y & 7u) + 2) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + 3;
         f2 sum_l = splat2(0.0f), sum_ll = splat2(0.0f), sum_1 = splat2(0.0f);
         for (int oy = -2; oy <= 2; oy++) {
@@ -104,22 +126,22 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a) {
                 if (ssn.w == 0.0f) continue;
                 const float4 sdi = s_di[lt], sgi = s_gi[lt];
                 const f2 l = (mk2(sdi.x, sgi.x) * 0.2126f + mk2(sdi.y, sgi.y) * 0.7152f) + mk2(sdi.z, sgi.z) * 0.0722f;
-                const f2 d = c_sqrt_luma - mk2(sqrtf(l.x), sqrtf(l.y));
+                const f2 d = c_sqrt_luma - sqrt2(l);
                 const float diff = fabsf(ssn.w - csn.w);
-                const float depth_weight = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
+                const float depth_weight = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
                 const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
                 const f2 w = exp_pair(-mk2(fabsf(d.x), fabsf(d.y))) * depth_weight * normal_weight;  // luma sigma 1: |d| * 1 == |d|
                 sum_l = sum_l + l * w; sum_ll = sum_ll + (l * l) * w; sum_1 = sum_1 + w;
             }
         }
-        { const float m1 = sum_l.x / sum_1.x, m2 = sum_ll.x / sum_1.x; di_var = fabsf(m2 - m1 * m1) * 4.0f; }
-        { const float m1 = sum_l.y / sum_1.y, m2 = sum_ll.y / sum_1.y; gi_var = fabsf(m2 - m1 * m1) * 4.0f; }
+        { const float m1 = fdiv(sum_l.x, sum_1.x), m2 = fdiv(sum_ll.x, sum_1.x); di_var = fabsf(m2 - m1 * m1) * 4.0f; }
+        { const float m1 = fdiv(sum_l.y, sum_1.y), m2 = fdiv(sum_ll.y, sum_1.y); gi_var = fabsf(m2 - m1 * m1) * 4.0f; }
     }
     di_var = fmax_(di_var, 0.0f);
     gi_var = fmax_(gi_var, 0.0f);
     a.di_diff_stash[center] = f4(xyz(cdi), di_var);
     a.gi_diff_stash[center] = f4(xyz(cgi), gi_var);
-    a.sl[0][center] = make_float2(sqrtf(cdi_luma), sqrtf(cgi_luma));  // for the first wavelet pass's taps
+    a.sl[0][center] = make_float2(fsqrt(cdi_luma), fsqrt(cgi_luma));  // for the first wavelet pass's taps
 }
 void launch_denoise_variance(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a); }
 
@@ -152,9 +174,9 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_wavelet(const KArgs a, uint32_t strid
     // are texture-address-bound — a fourth load per tap costs more there than the two square roots it replaces)
     f2 c_sqrt_luma;
     if (sl_in) { const float2 csl = sl_in[center]; c_sqrt_luma = mk2(csl.x, csl.y); }
-    else c_sqrt_luma = mk2(sqrtf(luma(xyz(cdi))), sqrtf(luma(xyz(cgi))));
-    const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, sqrtf(cdi.w)), lerpf(1.0f, 0.0f, sqrtf(cgi.w)));
-    const float leeway = csn.w * (0.33f / strength);  // depth sigma is the same for both signals
+    else c_sqrt_luma = mk2(fsqrt(luma(xyz(cdi))), fsqrt(luma(xyz(cgi))));
+    const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, fsqrt(cdi.w)), lerpf(1.0f, 0.0f, fsqrt(cgi.w)));
+    const float leeway = csn.w * (0.33f / strength), inv_leeway = frcp(leeway);  // depth sigma is the same for both signals
     I2 jitter = i2(0, 0);
     if (stride != 1u) {  // at stride 1 the jitter is (bn - 0.5) * 0 * 0.5 == 0
         const float4 bn = blue_noise_read(a, pos);
@@ -179,7 +201,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_wavelet(const KArgs a, uint32_t strid
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const float diff = fabsf(ssn[t].w - csn.w);
-        depth_w[t] = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
+        depth_w[t] = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
         normal_w[t] = pow64_(fmax_(dot(v3(ssn[t].x, ssn[t].y, ssn[t].z), cn), 0.0f));
         live[t] = live[t] && ssn[t].w != 0.0f && !(depth_w[t] == 0.0f || normal_w[t] == 0.0f);
     }
@@ -195,7 +217,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_wavelet(const KArgs a, uint32_t strid
             const f2 r = mk2(sdi[u].x, sgi[u].x), g = mk2(sdi[u].y, sgi[u].y), b = mk2(sdi[u].z, sgi[u].z), v = mk2(sdi[u].w, sgi[u].w);
             f2 tap_sqrt_luma;
             if (sl_in) tap_sqrt_luma = mk2(ssl[u].x, ssl[u].y);
-            else { const f2 l = (r * 0.2126f + g * 0.7152f) + b * 0.0722f; tap_sqrt_luma = mk2(sqrtf(l.x), sqrtf(l.y)); }
+            else { const f2 l = (r * 0.2126f + g * 0.7152f) + b * 0.0722f; tap_sqrt_luma = sqrt2(l); }
             const f2 d = c_sqrt_luma - tap_sqrt_luma;
             const f2 luma_weight = mk2(fabsf(d.x), fabsf(d.y)) * luma_sigma;
             const f2 w = exp_pair(-luma_weight) * depth_w[t] * normal_w[t];
@@ -208,11 +230,11 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_wavelet(const KArgs a, uint32_t strid
         }
     }
     const f2 ww = sum_w * sum_w;
-    const float4 odi = make_float4(sum_r.x / sum_w.x, sum_g.x / sum_w.x, sum_b.x / sum_w.x, sum_v.x / ww.x);
-    const float4 ogi = make_float4(sum_r.y / sum_w.y, sum_g.y / sum_w.y, sum_b.y / sum_w.y, sum_v.y / ww.y);
+    const float4 odi = wavelet_resolve(sum_r.x, sum_g.x, sum_b.x, sum_v.x, sum_w.x, ww.x);
+    const float4 ogi = wavelet_resolve(sum_r.y, sum_g.y, sum_b.y, sum_v.y, sum_w.y, ww.y);
     di_out[center] = odi;
     gi_out[center] = ogi;
-    if (sl_out) sl_out[center] = make_float2(sqrtf(luma(xyz(odi))), sqrtf(luma(xyz(ogi))));
+    if (sl_out) sl_out[center] = make_float2(fsqrt(luma(xyz(odi))), fsqrt(luma(xyz(ogi))));
     if (COMPOSE) frame_out[center] = compose_pixel(a, pos, camera_mode, odi, ogi);
 }
 // ---------------------------------------------------------------- the same pass for strides 1, 2 and 4, staged through LDS
@@ -259,8 +281,8 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_wavelet_lds(const KArgs a, float stre
     const V3 cn = v3(csn.x, csn.y, csn.z);
     const float2 csl = s_sl[lc];
     const f2 c_sqrt_luma = mk2(csl.x, csl.y);
-    const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, sqrtf(cdi.w)), lerpf(1.0f, 0.0f, sqrtf(cgi.w)));
-    const float leeway = csn.w * (0.33f / strength);
+    const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, fsqrt(cdi.w)), lerpf(1.0f, 0.0f, fsqrt(cgi.w)));
+    const float leeway = csn.w * (0.33f / strength), inv_leeway = frcp(leeway);
     f2 sum_w = splat2(1.0f), sum_r = mk2(cdi.x, cgi.x), sum_g = mk2(cdi.y, cgi.y), sum_b = mk2(cdi.z, cgi.z), sum_v = mk2(cdi.w, cgi.w);
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -269,7 +291,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_wavelet_lds(const KArgs a, float stre
         const float4 ssn = s_sn[lt];
         if (ssn.w == 0.0f) continue;
         const float diff = fabsf(ssn.w - csn.w);
-        const float depth_weight = diff >= leeway ? 0.0f : 1.0f - diff / leeway;
+        const float depth_weight = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
         const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
         if (depth_weight == 0.0f || normal_weight == 0.0f) continue;
         const float4 sdi = s_di[lt], sgi = s_gi[lt];
@@ -286,11 +308,11 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_wavelet_lds(const KArgs a, float stre
         }
     }
     const f2 ww = sum_w * sum_w;
-    const float4 odi = make_float4(sum_r.x / sum_w.x, sum_g.x / sum_w.x, sum_b.x / sum_w.x, sum_v.x / ww.x);
-    const float4 ogi = make_float4(sum_r.y / sum_w.y, sum_g.y / sum_w.y, sum_b.y / sum_w.y, sum_v.y / ww.y);
+    const float4 odi = wavelet_resolve(sum_r.x, sum_g.x, sum_b.x, sum_v.x, sum_w.x, ww.x);
+    const float4 ogi = wavelet_resolve(sum_r.y, sum_g.y, sum_b.y, sum_v.y, sum_w.y, ww.y);
     di_out[center] = odi;
     gi_out[center] = ogi;
-    if (sl_out) sl_out[center] = make_float2(sqrtf(luma(xyz(odi))), sqrtf(luma(xyz(ogi))));
+    if (sl_out) sl_out[center] = make_float2(fsqrt(luma(xyz(odi))), fsqrt(luma(xyz(ogi))));
 }
 
 void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
@@ -313,8 +335,8 @@ __global__ ST_KERNEL_BOUNDS void k_refresh_internal_planes(const KArgs a, float4
     const float4 sm = a.sm[i], psm = a.psm[i];
     a.sn[i] = sm.z == 0.0f ? f4z() : f4(normal_decode(v2(sm.x, sm.y)), sm.z);   // what primary visibility writes beside the surface map
     psn_out[i] = psm.z == 0.0f ? f4z() : f4(normal_decode(v2(psm.x, psm.y)), psm.z);
-    a.sl[0][i] = make_float2(sqrtf(luma(xyz(a.di_diff_stash[i]))), sqrtf(luma(xyz(a.gi_diff_stash[i]))));
-    a.sl[1][i] = make_float2(sqrtf(luma(xyz(a.di_diff_prev_colors[i]))), sqrtf(luma(xyz(a.gi_diff_prev_colors[i]))));
+    a.sl[0][i] = make_float2(fsqrt(luma(xyz(a.di_diff_stash[i]))), fsqrt(luma(xyz(a.gi_diff_stash[i]))));
+    a.sl[1][i] = make_float2(fsqrt(luma(xyz(a.di_diff_prev_colors[i]))), fsqrt(luma(xyz(a.gi_diff_prev_colors[i]))));
 }
 void launch_refresh_internal_planes(const KArgs& a_in, hipStream_t s) {
     KArgs a = a_in; a.row0 = 0; a.row1 = a.height;

@@ -212,7 +212,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
         radiance = atmosphere_sample(a, hit.dir);
         spec_brdf = v3s(0.0f);
     }
-    const float diff_brdf = (1.0f - hit.g.metallic) / kPi;
+    const float diff_brdf = fdivc(1.0f - hit.g.metallic, kPi);
     const float4 diff = f4(radiance * diff_brdf, confidence);
     tex_write(a.di_diff_samples, a, pos, diff);
     tex_write(a.di_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));

@@ -118,7 +118,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed
             const EphemeralResult res = ephemeral_build(a, wn, gi_hit);
             if (res.w > 0.0f) {
                 light_id = res.light_id;
-                light_pdf = (1.0f / res.w) * (1.0f - atmosphere_pdf);
+                light_pdf = frcp(res.w) * (1.0f - atmosphere_pdf);
                 light_rad = res.light_rad.radiance * (v3s(1.0f) + res.light_rad.spec_brdf);
             } else { light_id = 0u; light_pdf = 1.0f; light_rad = v3s(0.0f); }
         }
@@ -134,7 +134,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed
         } else light_vis = 1.0f;
         radiance = light_rad * light_vis / light_pdf;
     } else radiance = v3s(0.0f);
-    if (hit_some(gi_hit)) { radiance = radiance * (xyz(gi_hit.g.base_color) / kPi); radiance = radiance + gi_hit.g.emissive; }
+    if (hit_some(gi_hit)) { radiance = radiance * divc3(xyz(gi_hit.g.base_color), kPi); radiance = radiance + gi_hit.g.emissive; }
     GiReservoir res = gi_empty();
     if (gi_ray_pdf > 0.0f) {
         const V3 v1 = prim_hit.point;
@@ -142,7 +142,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed
         if (hit_some(gi_hit)) { v2p = gi_hit.point; v2n = gi_hit.g.normal; }
         else { v2p = v1 + gi_hit.dir * 1000.0f; v2n = -gi_hit.dir; }  // World::SUN_DISTANCE
         res.s.pdf = 0.0f; res.s.rng = rng; res.s.radiance = radiance; res.s.v1_point = v1; res.s.v2_point = v2p; res.s.v2_normal = v2n;
-        res.m = 1.0f; res.w = 1.0f / gi_ray_pdf;
+        res.m = 1.0f; res.w = frcp(gi_ray_pdf);
         res.s.pdf = gi_pdf(res.s, prim_hit);
     }
     gi_write(a.gi_res[1], idx, res);
@@ -378,7 +378,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
         float main_pdf = 0.0f;
         const GiReservoir center = gi_read(in, center_idx, n);
         if (res_merge(main_, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
-        const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main_.m / 8.0f));
+        const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main_.m * 0.125f));
         const float max_radius = nth == 0u ? 128.0f : 64.0f;
         uint32_t sample_nth = 0u;
         while (sample_nth < max_samples) {

@@ -17,7 +17,7 @@ ST_D V3 heatmap_gradient(float progress) {
         const float mn = step * (float)i;
         const float mx = step * ((float)i + 1.0f);
         if (progress >= mn && progress <= mx) {
-            const float rhs = (progress - mn) / step;
+            const float rhs = fdivc(progress - mn, step);
             const float lhs = 1.0f - rhs;
             const V3 a = i == 0 ? c0 : (i == 1 ? c1 : c2), b = i == 0 ? c1 : (i == 1 ? c2 : c3);
             return lhs * a + rhs * b;
@@ -113,7 +113,7 @@ __global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, 
     color = color + throughput * hit.g.emissive;
     if (a.light_count > 0u) {
         const uint32_t light_id = wn.sample_int() % a.light_count;
-        const float light_pdf = 1.0f / (float)a.light_count;
+        const float light_pdf = frcp((float)a.light_count);
         const GpuLight light = light_get(a, light_id);
         const bool occluded = trace_any(a, light_ray_wnoise(light, wn, hit.point), lane_stack(lds), &used_);
         count_rays(a.ray_counter, used_);

@@ -75,7 +75,7 @@ ST_D U2 resolve_checkerboard_alt(U2 gid, uint32_t frame) { return resolve_checke
 ST_D bool got_checkerboard_at(U2 p, uint32_t frame) { U2 q = resolve_checkerboard(u2(p.x / 2u, p.y), frame); return q.x == p.x && q.y == p.y; }
 
 ST_D V2 normal_encode(V3 n) {  // normal.rs:9-24
-    n = n / (fabsf(n.x) + fabsf(n.y) + fabsf(n.z));
+    n = n / (fabsf(n.x) + fabsf(n.y) + fabsf(n.z));  // V3 / float: one reciprocal in the fast build
     V2 r;
     if (n.z >= 0.0f) r = v2(n.x, n.y);
     else { r = v2(copysignf(1.0f - fabsf(n.y), n.x), copysignf(1.0f - fabsf(n.x), n.y)); }
@@ -98,22 +98,22 @@ struct WhiteNoise {
         const uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
         return (word >> 22) ^ word;
     }
-    ST_D float sample() { return (float)sample_int() / 4294967296.0f; }
+    ST_D float sample() { return (float)sample_int() * 2.3283064365386963e-10f; }  // / 2^32: a power of two, exact either way
     ST_D V2 sample_circle() { const float angle = sample() * kPi * 2.0f; float s, c; sincos_(angle, &s, &c); return v2(c, s); }
-    ST_D V2 sample_disk() { const float radius = sqrtf(sample()); return sample_circle() * radius; }
+    ST_D V2 sample_disk() { const float radius = fsqrt(sample()); return sample_circle() * radius; }
     ST_D V3 sample_sphere() {
         const float phi = sample() * 2.0f * kPi;
         const float cos_theta = sample() * 2.0f - 1.0f;
         const float u = sample();
         const float theta = acos_(cos_theta);
-        const float r = sqrtf(u);
+        const float r = fsqrt(u);
         float st_, ct_, sp_, cp_;
         sincos_(theta, &st_, &ct_); sincos_(phi, &sp_, &cp_);
         return v3(r * st_ * cp_, r * st_ * sp_, r * ct_);
     }
     ST_D V3 sample_hemisphere(V3 normal) {
         const float cos_theta = sample();
-        const float sin_theta = sqrtf(1.0f - sqr(cos_theta));
+        const float sin_theta = fsqrt(1.0f - sqr(cos_theta));
         const float phi = 2.0f * kPi * sample();
         V3 t, b;
         any_orthonormal_pair(normal, &t, &b);
@@ -125,24 +125,57 @@ ST_D WhiteNoise white_noise(uint32_t seed, U2 id) { WhiteNoise w; w.state = seed
 ST_D float4 blue_noise_read(const KArgs& a, U2 id) {
     const uint32_t ux = (id.x + 71u * a.frame) % 256u, uy = (id.y + 11u * a.frame) % 256u;
     const uchar4 p = a.blue_noise[uy * 256u + ux];
-    return make_float4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+    return make_float4(fdivc((float)p.x, 255.0f), fdivc((float)p.y, 255.0f), fdivc((float)p.z, 255.0f), fdivc((float)p.w, 255.0f));
 }
 
 // ------------------------------------------------------------------ rays & camera (ray.rs:14-53, camera.rs:19-150)
 struct Ray { V3 origin, dir, inv_dir; float len; };
-ST_D Ray make_ray(V3 o, V3 d) { Ray r; r.origin = o; r.dir = d; r.inv_dir = 1.0f / d; r.len = kF32Max; return r; }
+
+// ================================================================== exact island (1/3): ray generation
+// Everything between the `contract(off)` pragmas is the same arithmetic in both builds of the kernels: correctly rounded
+// + - * / sqrt, never contracted, no hardware approximations. It covers what decides which BVH nodes and triangles a ray
+// visits — Camera::ray, the ray's reciprocal direction, intersect_box, Triangle::hit, the alpha test's texture fetch — so
+// that the reference's `used_memory` counter (the BVH heatmap's integers) is bit-identical to the CPU restatement whichever
+// build runs. Helpers used in here are defined in here (xe::): an inlined helper from outside would bring its own
+// contraction setting with it.
+#pragma clang fp contract(off)
+namespace xe {
+ST_D V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+ST_D V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+ST_D V3 mul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+ST_D V3 scale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+ST_D float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+ST_D V3 cross(V3 a, V3 b) { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+ST_D V3 normalize(V3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
+ST_D float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+ST_D float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+ST_D float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+ST_D float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+ST_D V3 project_point3(const M4& m, V3 p) {  // glam Mat4::project_point3
+    float4 r = scale4(m.c[0], p.x);
+    r = add4(scale4(m.c[1], p.y), r);
+    r = add4(scale4(m.c[2], p.z), r);
+    r = add4(m.c[3], r);
+    const float rw = 1.0f / r.w;
+    return v3(r.x * rw, r.y * rw, r.z * rw);
+}
+}  // namespace xe
+ST_D Ray make_ray(V3 o, V3 d) { Ray r; r.origin = o; r.dir = d; r.inv_dir = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); r.len = kF32Max; return r; }
 ST_D Ray zero_ray() { Ray r; r.origin = v3s(0.0f); r.dir = v3s(0.0f); r.inv_dir = v3s(0.0f); r.len = 0.0f; return r; }  // Ray::default()
 ST_D V3 ray_at(const Ray& r, float t) { return r.origin + r.dir * t; }
 
 ST_D Ray camera_ray(const GpuCamera& c, U2 pos) {
-    const V2 screen_size = v2(c.screen.x, c.screen.y);
-    const V2 sp = as_v2(pos) + v2(0.5f, 0.5f);
-    V2 ndc = sp * 2.0f / screen_size - v2(1.0f, 1.0f);
-    ndc = v2(ndc.x, -ndc.y);
-    const V3 far_plane = project_point3(c.ndc_to_world, v3(ndc.x, ndc.y, kF32Eps));
-    const V3 near_plane = project_point3(c.ndc_to_world, v3(ndc.x, ndc.y, 1.0f));
-    return make_ray(near_plane, normalize(far_plane - near_plane));
+    const float spx = (float)pos.x + 0.5f, spy = (float)pos.y + 0.5f;
+    const float ndc_x = spx * 2.0f / c.screen.x - 1.0f;
+    const float ndc_y = -(spy * 2.0f / c.screen.y - 1.0f);
+    const V3 far_plane = xe::project_point3(c.ndc_to_world, v3(ndc_x, ndc_y, kF32Eps));
+    const V3 near_plane = xe::project_point3(c.ndc_to_world, v3(ndc_x, ndc_y, 1.0f));
+    return make_ray(near_plane, xe::normalize(xe::sub(far_plane, near_plane)));
 }
+#if defined(ST_FAST_MATH)
+#pragma clang fp contract(fast)
+#endif
+// ================================================================== end of exact island (1/3)
 ST_D float4 world_to_clip(const GpuCamera& c, V3 p) { return mul(c.projection_view, f4(p, 1.0f)); }
 ST_D V2 clip_to_screen(const GpuCamera& c, float4 p) {
     V2 ndc = v2(p.x, p.y) / p.w;
@@ -178,14 +211,18 @@ ST_D void tex_write(float4* p, const KArgs& a, U2 pos, float4 v) { if (pos.x < a
 // Byte decodes are pure functions of 256 inputs; the engine tabulates them once on the device with these very routines
 // (k_trace.hip k_build_byte_luts) so that a texel costs four table reads instead of three pow_() + a division — about
 // 250 VALU operations per texel, twelve texels per textured primary hit.
+// ================================================================== exact island (2/3): byte tables and atlas sampling
+// The tables are built once per engine with the polynomial pow (identical in both builds); the bilinear fetch is what the
+// traversal's alpha test reads (Triangle::hit's `base_color.w < 1`, ray.rs:184-214).
+#pragma clang fp contract(off)
 ST_D float srgb_to_linear_eval(uint32_t v) {
     const float c = (float)v / 255.0f;
-    return c <= 0.04045f ? c / 12.92f : pow_((c + 0.055f) / 1.055f, 2.4f);
+    return c <= 0.04045f ? c / 12.92f : pow_poly_((c + 0.055f) / 1.055f, 2.4f);
 }
 ST_D float unorm8_eval(uint32_t v) { return (float)v / 255.0f; }
 constexpr uint32_t kLutSrgb = 0u, kLutUnorm8 = 256u, kLutGamma8 = 512u, kLutGamma6 = 768u, kByteLutFloats = 1024u;  // layout of KArgs::byte_luts
-ST_D float gamma8_eval(uint32_t v) { return pow_((float)v / 255.0f, 2.2f); }  // G-buffer base colour RGB (gbuffer.rs:88-97)
-ST_D float gamma6_eval(uint32_t v) { return pow_((float)v / 63.0f, 2.2f); }   // ... and its 6-bit alpha
+ST_D float gamma8_eval(uint32_t v) { return pow_poly_((float)v / 255.0f, 2.2f); }  // G-buffer base colour RGB (gbuffer.rs:88-97)
+ST_D float gamma6_eval(uint32_t v) { return pow_poly_((float)v / 63.0f, 2.2f); }   // ... and its 6-bit alpha
 ST_D float srgb_to_linear(const KArgs& a, uint32_t v) { return a.byte_luts[kLutSrgb + v]; }
 ST_D float unorm8(const KArgs& a, uint32_t v) { return a.byte_luts[kLutUnorm8 + v]; }
 ST_D float4 atlas_texel(const KArgs& a, int32_t x, int32_t y) {
@@ -204,27 +241,33 @@ ST_D float4 atlas_sample(const KArgs& a, V2 uv) {
     const float tx = fx - x0, ty = fy - y0;
     const int32_t ix = f2i_sat(x0), iy = f2i_sat(y0);
     const float4 p00 = atlas_texel(a, ix, iy), p10 = atlas_texel(a, ix + 1, iy), p01 = atlas_texel(a, ix, iy + 1), p11 = atlas_texel(a, ix + 1, iy + 1);
-    const float4 top = p00 + (p10 - p00) * tx;
-    const float4 bot = p01 + (p11 - p01) * tx;
-    return top + (bot - top) * ty;
+    const float4 top = xe::add4(p00, xe::scale4(xe::sub4(p10, p00), tx));
+    const float4 bot = xe::add4(p01, xe::scale4(xe::sub4(p11, p01), tx));
+    return xe::add4(top, xe::scale4(xe::sub4(bot, top), ty));
 }
 ST_D float mat_wrap(float t) { return t > 0.0f ? fmodf(t, 1.0f) : 1.0f - fmodf(-t, 1.0f); }
 ST_D float4 sample_atlas(const KArgs& a, V2 hit_uv, float4 multiplier, float4 texture) {
     if (is_zero(texture)) return multiplier;
     hit_uv.x = mat_wrap(hit_uv.x);
     hit_uv.y = mat_wrap(hit_uv.y);
-    const V2 uv = v2(texture.x, texture.y) + hit_uv * v2(texture.z, texture.w);
-    return multiplier * atlas_sample(a, uv);
+    const V2 uv = v2(texture.x + hit_uv.x * texture.z, texture.y + hit_uv.y * texture.w);
+    return xe::mul4(multiplier, atlas_sample(a, uv));
 }
+#if defined(ST_FAST_MATH)
+#pragma clang fp contract(fast)
+#endif
+// ================================================================== end of exact island (2/3)
 
 // ------------------------------------------------------------------ BVH traversal (ray.rs:114-302, triangle.rs:64-113)
 struct TriangleHit { float distance; V3 point, normal; V2 uv; uint32_t material_id; uint32_t xform_slot; };  // xform_slot: owning instance (trace_closest only)
 ST_D bool hit_is_some(const TriangleHit& h) { return h.distance < kF32Max; }
 
+// ================================================================== exact island (3/3): traversal
+#pragma clang fp contract(off)
 ST_D float intersect_box(const Ray& r, V3 bmin, V3 bmax) {
     float tmin = 0.0f, tmax = kF32Max;
-    const V3 t1 = (bmin - r.origin) * r.inv_dir;
-    const V3 t2 = (bmax - r.origin) * r.inv_dir;
+    const V3 t1 = xe::mul(xe::sub(bmin, r.origin), r.inv_dir);
+    const V3 t2 = xe::mul(xe::sub(bmax, r.origin), r.inv_dir);
     tmin = fmax_(tmin, fmin_(t1.x, t2.x)); tmax = fmin_(tmax, fmax_(t1.x, t2.x));
     tmin = fmax_(tmin, fmin_(t1.y, t2.y)); tmax = fmin_(tmax, fmax_(t1.y, t2.y));
     tmin = fmax_(tmin, fmin_(t1.z, t2.z)); tmax = fmin_(tmax, fmax_(t1.z, t2.z));
@@ -236,8 +279,8 @@ ST_D float intersect_sphere(const Ray& r, float radius) {  // ray.rs:304-321
     if (c > 0.0f && b > 0.0f) return -1.0f;
     const float discr = b * b - c;
     if (discr < 0.0f) return -1.0f;
-    if (discr > b * b) return -b + sqrtf(discr);
-    return -b - sqrtf(discr);
+    if (discr > b * b) return -b + fsqrt(discr);
+    return -b - fsqrt(discr);
 }
 
 struct Candidate { float t, u, v, inv_det; uint32_t tri, material; };
@@ -245,7 +288,7 @@ struct Candidate { float t, u, v, inv_det; uint32_t tri, material; };
 ST_D V2 tri_uv(const KArgs& a, uint32_t tri, float u, float v) {
     const float4 q0 = a.tri_attr[4u * tri], q1 = a.tri_attr[4u * tri + 1u], q2 = a.tri_attr[4u * tri + 2u], q3 = a.tri_attr[4u * tri + 3u];
     const V2 uv0 = v2(q0.w, q1.w), uv1 = v2(q2.w, q3.x), uv2 = v2(q3.y, q3.z);
-    return uv0 + (uv1 - uv0) * u + (uv2 - uv0) * v;
+    return v2((uv0.x + (uv1.x - uv0.x) * u) + (uv2.x - uv0.x) * v, (uv0.y + (uv1.y - uv0.y) * u) + (uv2.y - uv0.y) * v);
 }
 // ANY_HIT: Tracing::ReturnFirst. Returns the reference's `used_memory` byte counter.
 // On return `best.t` is the closest accepted distance (or the initial max_t if none).
@@ -274,16 +317,16 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, C
             const uint32_t flags = f2b(d0.x), tri = f2b(d0.y), material = f2b(d0.z);
             const float4 g0 = a.tri_geo[3u * tri], g1 = a.tri_geo[3u * tri + 1u], g2 = a.tri_geo[3u * tri + 2u];
             const V3 p0 = xyz(g0), e1 = xyz(g1), e2 = xyz(g2);
-            const V3 pvec = cross(ray.dir, e2);
-            const float det = dot(e1, pvec);
+            const V3 pvec = xe::cross(ray.dir, e2);
+            const float det = xe::dot(e1, pvec);
             bool found = false;
             if (!(fabsf(det) < kF32Eps)) {
                 const float inv_det = 1.0f / det;
-                const V3 tvec = ray.origin - p0;
-                const float u = dot(tvec, pvec) * inv_det;
-                const V3 qvec = cross(tvec, e1);
-                const float v = dot(ray.dir, qvec) * inv_det;
-                const float t = dot(e2, qvec) * inv_det;
+                const V3 tvec = xe::sub(ray.origin, p0);
+                const float u = xe::dot(tvec, pvec) * inv_det;
+                const V3 qvec = xe::cross(tvec, e1);
+                const float v = xe::dot(ray.dir, qvec) * inv_det;
+                const float t = xe::dot(e2, qvec) * inv_det;
                 if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t))) {
                     found = true;
                     if (flags & 2u) {  // AlphaMode::Blend: the hit only counts where the base colour is opaque
@@ -354,15 +397,15 @@ ST_D bool any_hit_step(const KArgs& a, const Ray& ray, SE* stack, AnyHitState& s
         const uint32_t flags = f2b(d0.x), tri = f2b(d0.y), material = f2b(d0.z);
         const float4 g0 = a.tri_geo[3u * tri], g1 = a.tri_geo[3u * tri + 1u], g2 = a.tri_geo[3u * tri + 2u];
         const V3 p0 = xyz(g0), e1 = xyz(g1), e2 = xyz(g2);
-        const V3 pvec = cross(ray.dir, e2);
-        const float det = dot(e1, pvec);
+        const V3 pvec = xe::cross(ray.dir, e2);
+        const float det = xe::dot(e1, pvec);
         if (!(fabsf(det) < kF32Eps)) {
             const float inv_det = 1.0f / det;
-            const V3 tvec = ray.origin - p0;
-            const float u = dot(tvec, pvec) * inv_det;
-            const V3 qvec = cross(tvec, e1);
-            const float v = dot(ray.dir, qvec) * inv_det;
-            const float t = dot(e2, qvec) * inv_det;
+            const V3 tvec = xe::sub(ray.origin, p0);
+            const float u = xe::dot(tvec, pvec) * inv_det;
+            const V3 qvec = xe::cross(tvec, e1);
+            const float v = xe::dot(ray.dir, qvec) * inv_det;
+            const float t = xe::dot(e2, qvec) * inv_det;
             if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= ray.len))) {
                 bool found = true;
                 if (flags & 2u) {
@@ -379,6 +422,10 @@ ST_D bool any_hit_step(const KArgs& a, const Ray& ray, SE* stack, AnyHitState& s
     if (st.sp > 0) { st.sp--; st.ptr = stack[st.sp * 64]; return false; }
     return true;
 }
+#if defined(ST_FAST_MATH)
+#pragma clang fp contract(fast)
+#endif
+// ================================================================== end of exact island (3/3)
 ST_D void hit_pack(const TriangleHit& h, float4* d0, float4* d1) {  // hit.rs:112-120
     *d0 = f4(h.point, b2f(h.material_id));
     const V2 n = normal_encode(h.normal);
@@ -417,7 +464,7 @@ ST_D GBuffer gbuffer_unpack(const KArgs& a, float4 d0, float4 d1) {
 ST_D void gbuffer_pack_bits(const GBuffer& g, uint32_t base_bits, float4* d0, float4* d1) {
     const V2 n = normal_encode(g.normal);
     const float m = clampf(g.metallic, 0.0f, 1.0f) * 255.0f;
-    const float r = clampf(sqrtf(g.roughness), 0.0f, 1.0f) * 255.0f;
+    const float r = clampf(fsqrt(g.roughness), 0.0f, 1.0f) * 255.0f;
     const float rf = clampf(g.reflectance, 0.0f, 1.0f) * 255.0f;
     *d0 = make_float4(g.depth, n.x, n.y, b2f(u32_from_bytes(f2u_sat(m), f2u_sat(r), f2u_sat(rf), 1u)));
     *d1 = make_float4(g.emissive.x, g.emissive.y, g.emissive.z, b2f(base_bits));
@@ -450,19 +497,19 @@ ST_D Hit pixel_hit(const KArgs& a, const GpuCamera& cam, const float4* g0, const
 ST_D float ggx_distribution(float n_dot_h, float roughness) {
     const float a2 = roughness * roughness;
     const float d = (n_dot_h * a2 - n_dot_h) * n_dot_h + 1.0f;
-    return a2 / (kPi * d * d);
+    return fdiv(a2, kPi * d * d);
 }
 ST_D float ggx_schlick_masking_term(float n_dot_l, float n_dot_v, float roughness) {
     const float k = roughness * roughness / 2.0f;
-    const float g_v = n_dot_v / (n_dot_v * (1.0f - k) + k);
-    const float g_l = n_dot_l / (n_dot_l * (1.0f - k) + k);
+    const float g_v = fdiv(n_dot_v, n_dot_v * (1.0f - k) + k);
+    const float g_l = fdiv(n_dot_l, n_dot_l * (1.0f - k) + k);
     return g_v * g_l;
 }
 ST_D V3 ggx_schlick_fresnel(V3 f0, float l_dot_h) {
     const float f90 = saturate(dot(f0, v3s(50.0f * 0.33f)));
     return f0 + (v3s(f90) - f0) * pow5_(fmax_(1.0f - l_dot_h, 0.001f));
 }
-ST_D V3 diffuse_eval(const GBuffer& g) { return xyz(g.base_color) * (1.0f - g.metallic) / kPi; }
+ST_D V3 diffuse_eval(const GBuffer& g) { return divc3(xyz(g.base_color) * (1.0f - g.metallic), kPi); }
 ST_D V3 specular_eval(const GBuffer& g, V3 l, V3 v) {
     if (g.metallic <= 0.0f) return v3s(0.0f);
     const float a = clamped_roughness(g);
@@ -486,21 +533,21 @@ ST_D BrdfSample layered_brdf_sample(const GBuffer& g, WhiteNoise& wn, V3 v) {
         const float a2 = sqr(a);
         V3 b, t;
         any_orthonormal_pair(n, &b, &t);  // brdf.rs:91 `(b, t)`
-        const float cos_theta = sqrtf(fmax_(0.0f, (1.0f - r0) / ((a2 - 1.0f) * r0 + 1.0f)));
-        const float sin_theta = sqrtf(fmax_(0.0f, 1.0f - cos_theta * cos_theta));
+        const float cos_theta = fsqrt(fmax_(0.0f, fdiv(1.0f - r0, (a2 - 1.0f) * r0 + 1.0f)));
+        const float sin_theta = fsqrt(fmax_(0.0f, 1.0f - cos_theta * cos_theta));
         const float phi = r1 * kPi * 2.0f;
         float sp_, cp_; sincos_(phi, &sp_, &cp_);
         const V3 h = t * (sin_theta * cp_) + b * (sin_theta * sp_) + n * cos_theta;
         const float n_dot_h = saturate(dot(n, h)), h_dot_v = saturate(dot(h, v));
         s.dir = normalize(2.0f * h_dot_v * h - v);
-        s.pdf = ggx_distribution(n_dot_h, a) * n_dot_h / (4.0f * h_dot_v);
+        s.pdf = fdiv(ggx_distribution(n_dot_h, a) * n_dot_h, 4.0f * h_dot_v);
         s.radiance = specular_eval(g, s.dir, v);
-        s.pdf /= g.metallic;
+        s.pdf = fdiv(s.pdf, g.metallic);
     } else {
         s.dir = wn.sample_hemisphere(g.normal);
         s.pdf = 1.0f / kPi;
         s.radiance = diffuse_eval(g);
-        s.pdf /= 1.0f - g.metallic;
+        s.pdf = fdiv(s.pdf, 1.0f - g.metallic);
     }
     return s;
 }
@@ -522,17 +569,17 @@ ST_D LightRadiance light_radiance(const GpuLight& l, const Hit& hit) {  // light
     if (f2b(l.d2.x) == 1u) f_angle = 1.0f;
     else {
         const float angle = angle_between(normal_decode(v2(l.d2.y, l.d2.z)), hit.point - center);
-        f_angle = saturate(1.0f - pow3_(angle / l.d2.w));
+        f_angle = saturate(1.0f - pow3_(fdiv(angle, l.d2.w)));
     }
     float f_dist;
     if (range == INFINITY) f_dist = 1.0f;
     else {
         const float l2 = length_squared(lv);
-        const float inv_r2 = 1.0f / sqr(range);
+        const float inv_r2 = frcp(sqr(range));
         const float factor = l2 * inv_r2;
         const float smooth_factor = saturate(1.0f - factor * factor);
         const float attenuation = smooth_factor * smooth_factor;
-        f_dist = attenuation / fmax_(l2, 0.0001f);
+        f_dist = fdiv(attenuation, fmax_(l2, 0.0001f));
     }
     const float f_cosine = saturate(dot(hit.g.normal, normalize(lv)));
     LightRadiance out;
@@ -546,7 +593,7 @@ ST_D LightRadiance light_radiance(const GpuLight& l, const Hit& hit) {  // light
         const V3 closest_point = lv + center_to_ray * saturate(t);
         const float l_spec_length_inverse = inverse_sqrt(dot(closest_point, closest_point));
         const float tt = clamped_roughness(hit.g) + radius * 0.5f * l_spec_length_inverse;
-        const float i_roughness = clamped_roughness(hit.g) / saturate(tt);
+        const float i_roughness = fdiv(clamped_roughness(hit.g), saturate(tt));
         const float intensity = sqr(i_roughness);
         const V3 ls = closest_point * l_spec_length_inverse;
         out.spec_brdf = intensity * specular_eval(hit.g, ls, v);
@@ -565,11 +612,11 @@ ST_D Ray light_ray_bnoise(const GpuLight& l, V2 sample, V3 hit_point) {  // ligh
     const V3 to_light = xyz(l.d0) - hit_point;
     const V3 light_dir = normalize(to_light);
     const float light_distance = length(to_light);
-    const float light_radius = l.d0.w / light_distance;
+    const float light_radius = fdiv(l.d0.w, light_distance);
     V3 lt, lb;
     any_orthonormal_pair(light_dir, &lt, &lb);
     const float angle = 2.0f * kPi * sample.x;
-    const float rad = sqrtf(sample.y);
+    const float rad = fsqrt(sample.y);
     float s_, c_; sincos_(angle, &s_, &c_);
     const V2 disk_point = v2(s_, c_) * rad * light_radius;
     V3 ray_dir = light_dir + disk_point.x * lt + disk_point.y * lb;
@@ -607,7 +654,7 @@ ST_D V3 atmosphere_sample(const KArgs& a, V3 ray_dir) {
         const float height = length(view_pos);
         const V3 up = view_pos / height;
         float th = sqr(height) - sqr(kGroundRadiusMm);
-        th = sqrtf(th) / height;
+        th = fdiv(fsqrt(th), height);
         const float horizon = acos_(clampf(th, -1.0f, 1.0f));
         const float altitude = horizon - acos_(dot(ray_dir, up));
         float azimuth;
@@ -620,8 +667,8 @@ ST_D V3 atmosphere_sample(const KArgs& a, V3 ray_dir) {
             const float cos_theta = dot(projected_dir, forward);
             azimuth = atan2_(sin_theta, cos_theta) + kPi;
         }
-        const float u = azimuth / (2.0f * kPi);
-        const float v = 0.5f + 0.5f * copysignf(sqrtf(fabsf(altitude) * 2.0f / kPi), altitude);
+        const float u = fdivc(azimuth, 2.0f * kPi);
+        const float v = 0.5f + 0.5f * copysignf(fsqrt(fdivc(fabsf(altitude) * 2.0f, kPi)), altitude);
         lum = xyz(lut_sample(a.sky_lut, 256, 256, v2(u, v)));
     }
     // evaluate_bloom + interpolate_bloom
@@ -634,7 +681,7 @@ ST_D V3 atmosphere_sample(const KArgs& a, V3 ray_dir) {
         else {
             const float offset = min_sun_cos_theta - cos_theta;
             const float gaussian_bloom = exp_(-offset * 50000.0f) * 0.5f;
-            const float inv_bloom = 1.0f / (0.02f + offset * 300.0f) * 0.01f;
+            const float inv_bloom = frcp(0.02f + offset * 300.0f) * 0.01f;
             sun_lum = v3s(gaussian_bloom + inv_bloom);
         }
         const V3 t = vclamp((sun_lum - v3s(0.002f)) / (v3s(1.0f) - v3s(0.002f)), v3s(0.0f), v3s(1.0f));
@@ -648,7 +695,7 @@ ST_D V3 atmosphere_sample(const KArgs& a, V3 ray_dir) {
             const V3 up = view_pos / height;
             const float sun_cos_zenith_angle = dot(sun_dir, up);
             const float u = saturate(0.5f + 0.5f * sun_cos_zenith_angle);
-            const float v = saturate((height - kGroundRadiusMm) / (kAtmosphereRadiusMm - kGroundRadiusMm));
+            const float v = saturate(fdivc(height - kGroundRadiusMm, kAtmosphereRadiusMm - kGroundRadiusMm));
             sun_lum = sun_lum * xyz(lut_sample(a.transmittance_lut, 256, 64, v2(u, v)));
         }
     }
@@ -679,7 +726,7 @@ ST_D float4 bilinear_reproject(const KArgs& a, const Reprojection& r, const floa
     const float4 weights = make_float4(w[0], w[1], w[2], w[3]) * make_float4((1.0f - ux) * (1.0f - uy), ux * (1.0f - uy), (1.0f - ux) * uy, ux * uy);
     const float w_sum = (weights.x * 1.0f) + (weights.y * 1.0f) + (weights.z * 1.0f) + (weights.w * 1.0f);
     if (w_sum == 0.0f) return f4z();
-    return (s[0] * weights.x + s[1] * weights.y + s[2] * weights.z + s[3] * weights.w) / w_sum;
+    return div4(s[0] * weights.x + s[1] * weights.y + s[2] * weights.z + s[3] * weights.w, w_sum);
 }
 
 // ------------------------------------------------------------------ reservoirs (reservoir.rs, reservoir/*.rs)
@@ -765,7 +812,7 @@ ST_D float gi_jacobian(const GiSample& s, V3 new_hit_point) {
     gi_partial_jacobian(s, new_hit_point, &nd, &nc);
     gi_partial_jacobian(s, s.v1_point, &od, &oc);
     const float x = nc * od * od, y = oc * nd * nd;
-    return y == 0.0f ? 0.0f : x / y;
+    return y == 0.0f ? 0.0f : fdiv(x, y);
 }
 
 // Reservoir<T>::update / merge / norm as free templates (reservoir.rs:24-79)
@@ -782,7 +829,7 @@ ST_D bool res_merge(R& r, WhiteNoise& wn, const R& other, float pdf) {
     return res_update(r, wn, other.s, other.w * other.m * pdf);
 }
 template <class R>
-ST_D void res_norm(R& r, float pdf, float num, float denom_) { const float denom = pdf * denom_; r.w = denom == 0.0f ? 0.0f : (r.w * num) / denom; }
+ST_D void res_norm(R& r, float pdf, float num, float denom_) { const float denom = pdf * denom_; r.w = denom == 0.0f ? 0.0f : fdiv(r.w * num, denom); }
 
 // EphemeralReservoir::build (reservoir/ephemeral.rs:14-55): RIS over min(16, light_count) uniformly picked lights
 struct EphemeralResult { uint32_t light_id; LightRadiance light_rad; float m, w; };
@@ -794,20 +841,20 @@ ST_D EphemeralResult ephemeral_build(const KArgs& a, WhiteNoise& wn, const Hit& 
     for (uint32_t nth = 0; nth < max_samples; nth++) {
         const uint32_t light_id = wn.sample_int() % a.light_count;
         const LightRadiance rad = light_radiance(light_get(a, light_id), hit);
-        const float sample_pdf = sqrtf(luma(rad.radiance));  // perc_luma
+        const float sample_pdf = fsqrt(luma(rad.radiance));  // perc_luma
         const float weight = sample_pdf * sample_ipdf;
         res.m += 1.0f; res.w += weight;
         if (wn.sample() * res.w < weight) { res.light_id = light_id; res.light_rad = rad; res_pdf = sample_pdf; }
     }
-    { const float denom = res_pdf * res.m; res.w = denom == 0.0f ? 0.0f : (res.w * 1.0f) / denom; }  // norm_avg
+    { const float denom = res_pdf * res.m; res.w = denom == 0.0f ? 0.0f : fdiv(res.w * 1.0f, denom); }  // norm_avg
     return res;
 }
 
 // defensive pairwise MIS (reservoir/mis.rs:96-144)
 struct Mis { float lhs_m, rhs_m, rhs_jacobian, lhs_lhs_pdf, lhs_rhs_pdf, rhs_lhs_pdf, rhs_rhs_pdf; };
 struct MisResult { float m, lhs_pdf, lhs_mis, rhs_pdf, rhs_mis; };
-ST_D float mis2(float x, float y) { const float sum = x + y; return sum == 0.0f ? 0.0f : x / sum; }
-ST_D float mis_mfac(float q0, float q1) { return q0 <= 0.0f ? 1.0f : saturate(pow8_(fmin_(q1 / q0, 1.0f))); }
+ST_D float mis2(float x, float y) { const float sum = x + y; return sum == 0.0f ? 0.0f : fdiv(x, sum); }
+ST_D float mis_mfac(float q0, float q1) { return q0 <= 0.0f ? 1.0f : saturate(pow8_(fmin_(fdiv(q1, q0), 1.0f))); }
 ST_D MisResult mis_eval(const Mis& s) {
     MisResult r;
     r.m = s.rhs_m * fmin_(mis_mfac(s.rhs_rhs_pdf, s.rhs_lhs_pdf), mis_mfac(s.lhs_rhs_pdf, s.lhs_lhs_pdf));

@@ -1,7 +1,7 @@
 // st_math.h — scalar/vector maths shared by the HIP kernels and the C++ host engine.
 //
-// Two rules make every result bit-identical on gfx950 and on x86-64 (which is what lets the
-// parity tests demand exact equality instead of tolerances):
+// The kernels are built twice (Makefile). In the EXACT build — and always on the host — two rules make every result
+// bit-identical on gfx950 and on x86-64 (which is what lets the parity tests demand exact equality instead of tolerances):
 //   1. only +, -, *, / and sqrt are used (correctly rounded on both; hipcc's default
 //      -fhip-fp32-correctly-rounded-divide-sqrt is relied upon) and everything is compiled with
 //      -ffp-contract=off, so no FMA is formed outside the IEEE division/sqrt expansions;
@@ -9,6 +9,13 @@
 //      `spirv_std::num_traits::Float`) are evaluated by the fixed polynomial kernels below
 //      (Cephes-style single precision, a few ulp — well inside Vulkan's GLSL.std.450 envelope).
 // Vector operation order follows glam 0.24 scalar maths (the reference's vector library).
+//
+// In the FAST build (-DST_FAST_MATH=1, device code only) division, square root and the transcendentals go to the hardware
+// (v_rcp_f32, v_sqrt_f32, v_rsq_f32, v_exp_f32, v_log_f32, v_sin_f32, v_cos_f32: 1 ulp each) through the helpers below
+// (fdiv, frcp, fsqrt, ...), and the compiler may contract a*b+c into FMAs (-ffp-contract=fast-honor-pragmas). The reference
+// itself leaves all of these to the SPIR-V driver's precision. What must stay exact in both builds — ray generation and the
+// BVH traversal compare chain, whose `used_memory` integers are compared bit for bit — is written with plain `/`, sqrtf
+// and its own helpers inside `#pragma clang fp contract(off)` regions ("exact island", st_device.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -16,6 +23,11 @@
 #include <string.h>
 
 #define ST_HD __host__ __device__ __forceinline__
+#if defined(ST_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#define ST_FAST_DEVICE 1
+#else
+#define ST_FAST_DEVICE 0
+#endif
 
 namespace st {
 
@@ -55,16 +67,32 @@ ST_HD float fmax_(float a, float b) { return fmaxf(a, b); }
 ST_HD float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }  // Rust f32::clamp
 ST_HD float saturate(float x) { return clampf(x, 0.0f, 1.0f); }
 ST_HD float sqr(float x) { return x * x; }
+// division, reciprocal, square root: correctly rounded in the exact build, one hardware instruction each in the fast build
+#if ST_FAST_DEVICE
+ST_HD float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+ST_HD float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+ST_HD float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+ST_HD float inverse_sqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+ST_HD float fdivc(float x, float c) { return x * (1.0f / c); }  // division by a compile-time constant: its reciprocal is folded
+#else
+ST_HD float frcp(float x) { return 1.0f / x; }
+ST_HD float fdiv(float a, float b) { return a / b; }
+ST_HD float fsqrt(float x) { return sqrtf(x); }
 ST_HD float inverse_sqrt(float x) { return 1.0f / sqrtf(x); }
+ST_HD float fdivc(float x, float c) { return x / c; }
+#endif
 ST_HD float signum(float x) { return x != x ? x : copysignf(1.0f, x); }
 
 // ------------------------------------------------------------------ deterministic transcendentals
+// (exact island: these polynomial kernels are never contracted, so the byte tables and the host's uses of them are the
+// same bits whichever build of the kernels runs)
+#pragma clang fp contract(off)
 ST_HD float scale2(float z, int n) {
     if (n > 127) { z *= b2f(0x7f000000u); n -= 127; if (n > 127) n = 127; }
     if (n < -126) { z *= b2f(0x00800000u); n += 126; if (n < -126) n = -126; }
     return z * b2f((uint32_t)(n + 127) << 23);
 }
-ST_HD void sincos_(float x, float* s_out, float* c_out) {
+ST_HD void sincos_poly_(float x, float* s_out, float* c_out) {
     const float ax = fabsf(x);
     int j = (int)(ax * 1.27323954473516f);
     float y = (float)j;
@@ -82,23 +110,31 @@ ST_HD void sincos_(float x, float* s_out, float* c_out) {
     if (x < 0.0f) s = -s;
     *s_out = s; *c_out = c;
 }
+ST_HD void sincos_(float x, float* s_out, float* c_out) {
+#if ST_FAST_DEVICE
+    const float turns = x * 0.15915494309189535f;  // v_sin_f32 / v_cos_f32 take revolutions (valid to +-256 turns)
+    *s_out = __builtin_amdgcn_sinf(turns); *c_out = __builtin_amdgcn_cosf(turns);
+#else
+    sincos_poly_(x, s_out, c_out);
+#endif
+}
 ST_HD float sin_(float x) { float s, c; sincos_(x, &s, &c); return s; }
 ST_HD float cos_(float x) { float s, c; sincos_(x, &s, &c); return c; }
 ST_HD float asin_pos_(float a) {
     float x, z; const bool flag = a > 0.5f;
-    if (flag) { z = 0.5f * (1.0f - a); x = sqrtf(z); } else { x = a; z = x * x; }
+    if (flag) { z = 0.5f * (1.0f - a); x = fsqrt(z); } else { x = a; z = x * x; }
     float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
     if (flag) { p = p + p; p = kHalfPi - p; }
     return p;
 }
 ST_HD float acos_(float x) {
-    if (x < -0.5f) return kPi - 2.0f * asin_pos_(sqrtf(0.5f * (1.0f + x)));
-    if (x > 0.5f) return 2.0f * asin_pos_(sqrtf(0.5f * (1.0f - x)));
+    if (x < -0.5f) return kPi - 2.0f * asin_pos_(fsqrt(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin_pos_(fsqrt(0.5f * (1.0f - x)));
     float s = asin_pos_(fabsf(x));
     if (x < 0.0f) s = -s;
     return kHalfPi - s;
 }
-ST_HD float exp_(float x) {
+ST_HD float exp_poly_(float x) {
     if (x != x) return x;
     if (x > 88.72283905206835f) return INFINITY;
     if (x < -103.278929903431851103f) return 0.0f;
@@ -110,7 +146,7 @@ ST_HD float exp_(float x) {
     const float p = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * zz + x + 1.0f;
     return scale2(p, n);
 }
-ST_HD float log2_(float x) {
+ST_HD float log2_poly_(float x) {
     uint32_t b = f2b(x);
     int e = 0;
     if ((b & 0x7f800000u) == 0) { x *= 8388608.0f; b = f2b(x); e = -23; }
@@ -127,7 +163,7 @@ ST_HD float log2_(float x) {
     r += (float)e;
     return r;
 }
-ST_HD float exp2_(float x) {
+ST_HD float exp2_poly_(float x) {
     if (x != x) return x;
     if (x > 127.999f) return INFINITY;
     if (x < -150.0f) return 0.0f;
@@ -138,14 +174,29 @@ ST_HD float exp2_(float x) {
     const float p = (((((1.535336188319500e-4f * x + 1.339887440266574e-3f) * x + 9.618437357674640e-3f) * x + 5.550332471162809e-2f) * x + 2.402264791363012e-1f) * x + 6.931472028550421e-1f) * x + 1.0f;
     return scale2(p, i0);
 }
-ST_HD float pow_(float x, float y) {  // x >= 0, finite y > 0 (all the path needs)
+ST_HD float pow_poly_(float x, float y) {  // x >= 0, finite y > 0 (all the path needs)
     if (x != x || y != y) return x + y;
     if (x < 0.0f) return NAN;
     if (x == 0.0f) return 0.0f;
     if (x == INFINITY) return INFINITY;
     if (x == 1.0f) return 1.0f;
-    return exp2_(y * log2_(x));
+    return exp2_poly_(y * log2_poly_(x));
 }
+#if defined(ST_FAST_MATH)
+#pragma clang fp contract(fast)
+#endif
+// the names the passes call: the fixed polynomials above in the exact build and on the host, the hardware in the fast build
+#if ST_FAST_DEVICE
+ST_HD float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+ST_HD float log2_(float x) { return __builtin_amdgcn_logf(x); }
+ST_HD float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
+ST_HD float pow_(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }  // 0 -> exp2(-inf) = 0, 1 -> 1, inf -> inf, negative / NaN -> NaN
+#else
+ST_HD float exp_(float x) { return exp_poly_(x); }
+ST_HD float log2_(float x) { return log2_poly_(x); }
+ST_HD float exp2_(float x) { return exp2_poly_(x); }
+ST_HD float pow_(float x, float y) { return pow_poly_(x, y); }
+#endif
 // integer-exponent powf calls of the reference as exact multiplication chains (cheaper and closer to a correctly
 // rounded pow than exp2(y*log2(x)); x^64 is evaluated 16x per pixel per wavelet pass)
 ST_HD float pow2_(float x) { return x * x; }
@@ -194,8 +245,8 @@ ST_HD float atan_(float x) {
     float sign = 1.0f;
     if (x < 0.0f) { sign = -1.0f; x = -x; }
     float y;
-    if (x > 2.414213562373095f) { y = kHalfPi; x = -(1.0f / x); }
-    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    if (x > 2.414213562373095f) { y = kHalfPi; x = -frcp(x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = fdiv(x - 1.0f, x + 1.0f); }
     else y = 0.0f;
     const float z = x * x;
     y += (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
@@ -207,7 +258,7 @@ ST_HD float atan2_(float y, float x) {
         if (y == 0.0f) return copysignf((f2b(x) >> 31) ? kPi : 0.0f, y);
         return y > 0.0f ? kHalfPi : -kHalfPi;
     }
-    float a = atan_(y / x);
+    float a = atan_(fdiv(y, x));
     if (x < 0.0f) a = (y < 0.0f || (y == 0.0f && (f2b(y) >> 31))) ? a - kPi : a + kPi;
     return a;
 }
@@ -230,10 +281,14 @@ ST_HD U2 u2(uint32_t x, uint32_t y) { U2 r; r.x = x; r.y = y; return r; }
 ST_HD V2 operator+(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
 ST_HD V2 operator-(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
 ST_HD V2 operator*(V2 a, V2 b) { return v2(a.x * b.x, a.y * b.y); }
-ST_HD V2 operator/(V2 a, V2 b) { return v2(a.x / b.x, a.y / b.y); }
+ST_HD V2 operator/(V2 a, V2 b) { return v2(fdiv(a.x, b.x), fdiv(a.y, b.y)); }
 ST_HD V2 operator*(V2 a, float s) { return v2(a.x * s, a.y * s); }
 ST_HD V2 operator*(float s, V2 a) { return v2(s * a.x, s * a.y); }
+#if ST_FAST_DEVICE
+ST_HD V2 operator/(V2 a, float s) { const float r = frcp(s); return v2(a.x * r, a.y * r); }
+#else
 ST_HD V2 operator/(V2 a, float s) { return v2(a.x / s, a.y / s); }
+#endif
 ST_HD V2 operator+(V2 a, float s) { return v2(a.x + s, a.y + s); }
 ST_HD V2 operator-(V2 a, float s) { return v2(a.x - s, a.y - s); }
 ST_HD float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
@@ -245,19 +300,28 @@ ST_HD I2 as_i2(V2 a) { return i2(f2i_sat(a.x), f2i_sat(a.y)); }
 ST_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 ST_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 ST_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
-ST_HD V3 operator/(V3 a, V3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
+ST_HD V3 operator/(V3 a, V3 b) { return v3(fdiv(a.x, b.x), fdiv(a.y, b.y), fdiv(a.z, b.z)); }
 ST_HD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 ST_HD V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+#if ST_FAST_DEVICE
+ST_HD V3 operator/(V3 a, float s) { const float r = frcp(s); return v3(a.x * r, a.y * r, a.z * r); }
+#else
 ST_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
-ST_HD V3 operator/(float s, V3 a) { return v3(s / a.x, s / a.y, s / a.z); }
+#endif
+ST_HD V3 operator/(float s, V3 a) { return v3(fdiv(s, a.x), fdiv(s, a.y), fdiv(s, a.z)); }
+ST_HD V3 divc3(V3 a, float c) { return v3(fdivc(a.x, c), fdivc(a.y, c), fdivc(a.z, c)); }
 ST_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 ST_HD bool is_zero(V3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
 ST_HD bool is_zero(float4 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f && a.w == 0.0f; }
 ST_HD float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
 ST_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 ST_HD float length_squared(V3 a) { return dot(a, a); }
-ST_HD float length(V3 a) { return sqrtf(dot(a, a)); }
+ST_HD float length(V3 a) { return fsqrt(dot(a, a)); }
+#if ST_FAST_DEVICE
+ST_HD V3 normalize(V3 a) { return a * inverse_sqrt(dot(a, a)); }
+#else
 ST_HD V3 normalize(V3 a) { return a * (1.0f / length(a)); }
+#endif
 ST_HD float distance(V3 a, V3 b) { return length(a - b); }
 ST_HD V3 vmin(V3 a, V3 b) { return v3(fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)); }
 ST_HD V3 vmax(V3 a, V3 b) { return v3(fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)); }
@@ -268,7 +332,7 @@ ST_HD float lerpf(float a, float b, float t) { return a + (b - a) * clampf(t, 0.
 ST_HD V3 lerp3(V3 a, V3 b, float t) { return a + (b - a) * clampf(t, 0.0f, 1.0f); }
 ST_HD void any_orthonormal_pair(V3 n, V3* t, V3* b) {  // glam Vec3::any_orthonormal_pair
     const float sign = signum(n.z);
-    const float a = -1.0f / (sign + n.z);
+    const float a = -frcp(sign + n.z);
     const float bb = n.x * n.y * a;
     *t = v3(1.0f + sign * n.x * n.x * a, sign * bb, -sign * n.x);
     *b = v3(bb, sign + n.y * n.y * a, -n.y);
@@ -278,14 +342,19 @@ ST_HD float glam_acos_approx(float v) {  // glam 0.24 math::acos_approx, behind 
     const float x = fabsf(v);
     float omx = 1.0f - x;
     if (omx < 0.0f) omx = 0.0f;
-    const float root = sqrtf(omx);
+    const float root = fsqrt(omx);
     float r = ((((((-0.0012624911f * x + 0.0066700901f) * x - 0.0170881256f) * x + 0.0308918810f) * x - 0.0501743046f) * x + 0.0889789874f) * x - 0.2145988016f) * x + 1.5707963050f;
     r *= root;
     return nonnegative ? r : kPi - r;
 }
-ST_HD float angle_between(V3 a, V3 b) { return glam_acos_approx(dot(a, b) / sqrtf(length_squared(a) * length_squared(b))); }
+ST_HD float angle_between(V3 a, V3 b) { return glam_acos_approx(fdiv(dot(a, b), fsqrt(length_squared(a) * length_squared(b)))); }
 
 // float4 arithmetic uses HIP's own component-wise operators (amd_hip_vector_types.h): +, -, * and / by scalar.
+#if ST_FAST_DEVICE
+ST_HD float4 div4(float4 v, float s) { return v * frcp(s); }
+#else
+ST_HD float4 div4(float4 v, float s) { return v / s; }
+#endif
 
 // ------------------------------------------------------------------ 4x4 / affine (column-major, glam order)
 struct M4 { float4 c[4]; };
@@ -301,7 +370,7 @@ ST_HD V3 project_point3(const M4& m, V3 p) {
     r = m.c[1] * p.y + r;
     r = m.c[2] * p.z + r;
     r = m.c[3] + r;
-    const float rw = 1.0f / r.w;
+    const float rw = frcp(r.w);
     return v3(r.x * rw, r.y * rw, r.z * rw);
 }
 

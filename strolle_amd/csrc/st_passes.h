@@ -26,7 +26,7 @@ ST_D void denoise_reproject_finish(const KArgs& a, U2 pos, float4 sample, const 
     if (h.have && sample.w > 0.0f) {
         const float4 pc = h.pc, pm = h.pm;
         const float curr_history = fmin_(pm.x + 1.0f, 16.0f);
-        const float alpha = 1.0f / curr_history;
+        const float alpha = frcp(curr_history);
         color = lerp3(xyz(pc), xyz(sample), alpha);
         moment = v3(curr_history, lerpf(pm.y, sample_luma, alpha), lerpf(pm.z, sample_luma * sample_luma, alpha));
     } else {
@@ -47,7 +47,7 @@ ST_D float4 gi_resolve_pixel(const KArgs& a, U2 pos, uint32_t idx, const Hit& hi
     float confidence; V3 radiance;
     if (hit_some(hit)) { confidence = res.confidence; radiance = res.w * gi_cosine(res.s, hit) * res.s.radiance; }
     else { confidence = 1.0f; radiance = v3s(0.0f); }
-    const float diff_brdf = (1.0f - hit.g.metallic) / kPi;
+    const float diff_brdf = fdivc(1.0f - hit.g.metallic, kPi);
     const V3 spec_brdf = gi_spec_brdf(res.s, hit);
     const float4 diff = f4(radiance * diff_brdf, confidence);
     tex_write(a.gi_diff_samples, a, pos, diff);

@@ -62,6 +62,18 @@ class OracleEngine(EngineBase):
     def tick(self):
         self._check(self._b.tick(self._h))
 
+    def set_pass_mask(self, mask: int):
+        """or_debug_set_pass_mask: which reference passes render_camera executes (bit numbers = StPassBit)."""
+        fn = self._b.lib.or_debug_set_pass_mask
+        fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_uint64]
+        self._check(fn(self._h, mask & 0xFFFFFFFFFFFFFFFF))
+
+    def write_buffer(self, camera: int, buffer, data: np.ndarray):
+        fn = self._b.lib.or_camera_write_buffer
+        fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
+        data = np.ascontiguousarray(data)
+        self._check(fn(self._h, camera, int(buffer), data.ctypes.data, data.nbytes))
+
     def render_camera(self, handle, compose: bool = True):
         w, h = self._sizes[handle]
         out = np.zeros((h, w, 4), np.float32) if compose else None
