@@ -460,6 +460,13 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     if path not in _lib_cache:
         if not os.path.exists(path):
             raise StrolleError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64. If this library were loaded first it would bring
+        # in /opt/rocm's copy, torch would then load its bundled one beside it, and device enumeration fails in whichever
+        # comes second. Loading torch first makes both share torch's runtime (this library only needs the HIP API).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib_cache[path] = C.CDLL(path)
     return _lib_cache[path]
 
