@@ -7,8 +7,13 @@
 
 A "step" is one frame: Engine::tick + CameraController::render (every pass of the pipeline) + composition.
 Scene, buffers and temporal state are resident in HBM before the timed region; the output stays on the device.
-N > 1: weak scaling — the frame grows to N x 1080p pixels (N=4 is BASELINE.json's 3840x2160 4-tile config),
-each rank renders one row band (+ apron) and the bands are all-gathered every frame (the only collective).
+The kernels run in the library's default (fast-arithmetic) build; --exact selects the bit-exact build.
+
+N > 1, --scaling weak (default): the frame grows to N x (width x height) pixels (N=4 is BASELINE.json's 3840x2160 4-tile
+config), each rank renders one row band (+ apron) and the bands are gathered to rank 0 every frame (the only collective).
+--scaling strong: the frame stays width x height and is split into N row bands — BASELINE.json configs 4 and 5 as written:
+  ... bench.py --gpus 4 --scaling strong --width 3840 --height 2160 --scene cornell --mode reference     (config 4)
+  ... bench.py --gpus 8 --scaling strong --width 3840 --height 2160 --scene dungeon --mode image         (config 5; N = 1, 2, 4, 8)
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -20,7 +25,28 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
+# profiler slots (st_kernels.h kernel_info names) that implement the reference's five `frame_denoising::wavelet` passes:
+# name -> reference passes executed per launch
+WAVELET_SLOTS = {"denoise_wavelet": 1, "denoise_wavelet x2 (strides 1+2)": 2}
+WAVELET_SYMBOLS = ["denoise_wavelet_12", "denoise_wavelet_lds<1>", "denoise_wavelet_lds<2>", "denoise_wavelet_lds<4>", "denoise_wavelet_far"]
+
+
+def measure_copy_ceiling(torch, dev):
+    """Device-to-device copy of 1 GiB on this box: (bytes read + bytes written) / time, best of 6 (SURVEY.md 8d asks for the
+    measured ceiling beside the 8 TB/s spec figure)."""
+    n = (1 << 30) // 4
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    best = None
+    for _ in range(6):
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record(); dst.copy_(src); t1.record(); t1.synchronize()
+        ms = t0.elapsed_time(t1)
+        best = ms if best is None else min(best, ms)
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * (1 << 30) / (best * 1e-3) / 1e9
 
 
 def cpu_baseline(args, size):
@@ -53,6 +79,25 @@ def cpu_baseline(args, size):
             "sample": f"best of {timed} frames (after {warm} warm-up) of the same {size[0]}x{size[1]} Cornell Image workload, OpenMP over {cores} threads"}
 
 
+def static_traffic(symbols):
+    """HBM bytes per launch of the given kernel symbols from the committed rocprofv3 counter passes (profiles/pmc_latest.json:
+    separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench command, tools/gpu_profile_quick.sh). Not measured by
+    this process: hardware counters need the profiler."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return None, None
+    total, n = 0.0, 0
+    for s in symbols:
+        e = pmc.get(s)
+        if e and e.get("hbm_bytes_per_launch") is not None:
+            total += e["hbm_bytes_per_launch"] * e["launches_sampled"]; n += e["launches_sampled"]
+    return (round(total / n) if n else None), "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; (2 x FETCH_SIZE + WRITE_SIZE) x 1024, calibration in profiles/README.md)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,8 +108,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--apron", type=int, default=16, help="extra rows rendered around a rank's band in Image mode (N > 1)")
     ap.add_argument("--scene", choices=["cornell", "dungeon", "dungeon134k"], default="cornell",
-                    help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene (level.glb, 8,393 triangles); dungeon134k = the same surface subdivided twice (synthetic ~100k-triangle stand-in)")
+                    help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene (level.glb + the demo's three tori); dungeon134k = the same surface subdivided twice (synthetic ~100k-triangle stand-in)")
     ap.add_argument("--mode", choices=["image", "gi_diffuse", "reference", "heatmap"], default="image")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak = the frame grows with N (per-GPU work fixed), strong = the frame stays --width x --height")
+    ap.add_argument("--exact", action="store_true", help="run the bit-exact build of the kernels (ST_ARITH_EXACT) instead of the default fast build")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last (gathered) frame as .npy — tests compare it with a single-GPU render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
@@ -99,8 +146,8 @@ def main():
                 dist.init_process_group("nccl")
 
     base = (args.width, args.height)
-    width, height = weak_scaling_frame(base, world)
-    engine = Engine(device=local_rank)
+    width, height = weak_scaling_frame(base, world) if args.scaling == "weak" else base
+    engine = Engine(device=local_rank, exact=True if args.exact else None)
     mode = {"image": CameraMode.IMAGE, "gi_diffuse": CameraMode.GI_DIFFUSE, "reference": CameraMode.REFERENCE, "heatmap": CameraMode.BVH_HEATMAP}[args.mode]
     if args.scene == "cornell":
         scenes.build_cornell(engine)
@@ -112,8 +159,9 @@ def main():
     cam = engine.create_camera(desc)
     band = band_for_rank(height, world, rank)
     window = (0, height)
+    needs_apron = args.mode in ("image", "gi_diffuse")   # Reference / heatmap pixels read nothing but their own
     if world > 1:
-        window = render_window(height, band, args.apron)
+        window = render_window(height, band, args.apron if needs_apron else 0)
         engine.set_camera_rows(cam, *window)
     dev = f"cuda:{local_rank}"
     # double-buffered render targets: frame i is gathered on `comm` while frame i+1 renders on `main`
@@ -122,6 +170,7 @@ def main():
     main = torch.cuda.current_stream()
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
     gathered = [None, None]  # events: gather that read outs[k] has finished
+    gather_events = []       # (start, stop) of every gather on the comm stream
     stream = main.cuda_stream
     frame_no = [0]
 
@@ -139,6 +188,7 @@ def main():
         rendered = torch.cuda.Event(); rendered.record(main)
         comm.wait_event(rendered)
         with torch.cuda.stream(comm):
+            g0 = torch.cuda.Event(enable_timing=True); g0.record(comm)
             if debug_shared:
                 comm.synchronize()
                 host_full = torch.zeros((height, width, 4)) if rank == 0 else None
@@ -147,7 +197,8 @@ def main():
                     full.copy_(host_full)
             else:
                 gather_bands_to_root(out, full, height, world, rank)   # the only collective: bands -> rank 0 over RCCL
-            done = torch.cuda.Event(); done.record(comm)
+            done = torch.cuda.Event(enable_timing=True); done.record(comm)
+        gather_events.append((g0, done))
         gathered[k] = done
         return full if rank == 0 else out
 
@@ -155,6 +206,7 @@ def main():
         step()
     torch.cuda.synchronize()
     engine.ray_count(cam, reset=True)
+    gather_events.clear()
 
     def timed_region():
         if world > 1:
@@ -172,8 +224,9 @@ def main():
     # region 1: EXACTLY K steps, no instrumentation -> value / ms_per_step
     elapsed, frame = timed_region()
     rays = engine.ray_count(cam) * (band[1] - band[0]) / (window[1] - window[0])   # apron rows are redundant work: not counted
-    # region 2: the same K steps again with a HIP-event pair around every kernel launch (on the launch stream) -> per-kernel
-    # average durations for the roofline object. Kept out of region 1 because the ~60 event records per frame cost ~10 %.
+    gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events)) if gather_events else None
+    # region 2: the same K steps again with HIP events around every run of same-slot launches (on the launch stream, pass
+    # graph serial) -> per-kernel average durations for the roofline object. Kept out of region 1: it costs ~10 %.
     prof, profiled_ms = [], None
     if not args.no_profile:
         engine.profile_enable(True)
@@ -182,10 +235,15 @@ def main():
         prof = engine.profile_read(reset=True)
         engine.profile_enable(False)
         profiled_ms = elapsed_p / args.steps * 1e3
-    t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cpu" if debug_shared else f"cuda:{local_rank}")
+    on_cpu = "cpu" if debug_shared else f"cuda:{local_rank}"
+    t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=on_cpu)
+    per_rank_ms = None
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        each = [torch.zeros(1, dtype=torch.float64, device=on_cpu) for _ in range(world)]
+        dist.all_gather(each, torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=on_cpu))
+        per_rank_ms = [round(float(x[0]), 4) for x in each]
         elapsed, rays_total = float(tmax[0]), float(tsum[1])
     else:
         rays_total = float(rays)
@@ -193,55 +251,74 @@ def main():
     if rank == 0 and args.dump_frame:
         import numpy as np
         np.save(args.dump_frame, frame.cpu().numpy())
+    copy_ceiling = measure_copy_ceiling(torch, dev) if (rank == 0 and not debug_shared) else None
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        headline = (args.scene, args.mode) == ("cornell", "image")
         result = {
             "metric": "Mray/s (primary + shadow + GI rays traced per second, whole job)",
             "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"Cornell box {width}x{height}, CameraMode::Image{{denoise:true}} (1 spp ReSTIR DI+GI + SVGF), static camera, point light at t=0"
-                                    if (args.scene, args.mode) == ("cornell", "image") else f"{args.scene} {width}x{height}, mode {args.mode} (NOT the headline workload)"),
-                       "scene": {"cornell": "cornell (32 triangles, 2 light slots)", "dungeon": "dungeon level.glb (8,393 triangles, 45 textured materials, 7 light slots)",
-                                 "dungeon134k": "SYNTHETIC: dungeon level.glb with every triangle split into 16 (134,288 triangles), same materials and lights"}[args.scene],
+                                    if headline else f"{args.scene} {width}x{height}, mode {args.mode} (NOT the headline workload)"),
+                       "scene": {"cornell": "cornell (32 triangles, 2 light slots)", "dungeon": scenes.DUNGEON_DESCRIPTION,
+                                 "dungeon134k": "SYNTHETIC: the dungeon with every triangle split into 16, same materials and lights"}[args.scene],
+                       "arithmetic": "exact (bit-identical to the CPU oracle)" if engine.exact else "fast (hardware rcp/sqrt/exp/log, FMA contraction; traversal exact; tolerances in tests/test_gpu_fast_tolerance.py)",
                        "width": width, "height": height,
-                       "per_gpu_rows": band[1] - band[0], "apron_rows": args.apron if world > 1 else 0,
+                       "per_gpu_rows": band[1] - band[0], "apron_rows": (args.apron if needs_apron else 0) if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
                        **({"DEBUG_NOT_A_RESULT": "ranks share cuda:0, gather through gloo + host copies"} if debug_shared else {}),
                        "partition": "single GPU" if world == 1 else f"{world} row bands, per-frame RCCL gather of the RGBA32F bands to rank 0 overlapped with the next frame"},
         }
+        if world > 1:
+            result["multi_gpu"] = {"rccl_ranks": world, "per_rank_ms_per_step": per_rank_ms, "gather_ms_on_comm_stream_rank0": None if gather_ms is None else round(gather_ms, 4),
+                                   "gathered_bytes_per_frame": (height - (band[1] - band[0])) * width * 16}
+        if copy_ceiling is not None:
+            result["hbm_copy_ceiling_GBps_measured"] = round(copy_ceiling, 1)
         if prof:
-            dom = max(prof, key=lambda p: p["total_ms"])
-            avg_ms = dom["total_ms"] / dom["launches"]
-            achieved = dom["algorithmic_bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get(dom["name"], {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            result["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                                  "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": round(dom["algorithmic_bytes"] / dom["launches"]),
-                                  "screen_space_bytes_B": round((dom["algorithmic_bytes"] - dom["traversal_bytes"]) / dom["launches"]),
-                                  "traversal_bytes_A": round(dom["traversal_bytes"] / dom["launches"]),
-                                  "note": "HIP events on the launch stream over a second region of the same K steps; algorithmic bytes = compulsory screen-space plane bytes + traversal bytes (the reference's used_memory counter); DESIGN.md"}
+            by = {p["name"]: p for p in prof}
+            # the dominant kernel: the slot — or, for the a-trous passes, the family of slots — with the largest total time
+            fam = [by[n] for n in WAVELET_SLOTS if n in by]
+            fam_ms = sum(p["total_ms"] for p in fam)
+            top = max(prof, key=lambda p: p["total_ms"])
+            if fam and fam_ms >= max(p["total_ms"] for p in prof if p["name"] not in WAVELET_SLOTS):
+                launches = sum(p["launches"] for p in fam)
+                passes = sum(p["launches"] * WAVELET_SLOTS[p["name"]] for p in fam)
+                alg = sum(p["algorithmic_bytes"] for p in fam)
+                trav = sum(p["traversal_bytes"] for p in fam)
+                name = f"denoise_wavelet ({passes // args.steps} a-trous passes per frame in {launches // args.steps} launches)"
+                tot_ms, symbols = fam_ms, WAVELET_SYMBOLS
+            else:
+                launches, alg, trav, tot_ms, name, symbols = top["launches"], top["algorithmic_bytes"], top["traversal_bytes"], top["total_ms"], top["name"], [top["name"]]
+            avg_ms = tot_ms / launches
+            b_bytes = (alg - trav) / launches
+            achieved = b_bytes / (avg_ms * 1e-3) / 1e9   # screen-space (HBM) bytes only: traversal bytes are cache- / LDS-served
+            traffic, source = static_traffic(symbols)
+            result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
+                                  "frac_of_measured_copy_ceiling": None if not copy_ceiling else round(achieved / copy_ceiling, 5),
+                                  "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": round(b_bytes),
+                                  "traversal_bytes_per_launch_not_hbm": round(trav / launches),
+                                  "note": "HIP events on the launch stream around each run of back-to-back launches of the slot, over a second region of the same K steps; algorithmic bytes = compulsory screen-space plane bytes of the reference passes the launches execute (SURVEY.md 8d / DESIGN.md section 4)"}
             tot = sum(p["total_ms"] for p in prof)
             result["kernels"] = {p["name"]: {"ms_per_frame": round(p["total_ms"] / args.steps, 5), "launches_per_frame": round(p["launches"] / args.steps, 2),
-                                            "alg_GBps": round(p["algorithmic_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1) if p["total_ms"] > 0 else None}
+                                            "us_per_launch": round(p["total_ms"] / p["launches"] * 1e3, 2),
+                                            "B_only_GBps": round((p["algorithmic_bytes"] - p["traversal_bytes"]) / (p["total_ms"] * 1e-3) / 1e9, 1) if p["total_ms"] > 0 else None,
+                                            "traversal_GBps_cache_served": round(p["traversal_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1) if p["total_ms"] > 0 and p["traversal_bytes"] else 0.0}
                                  for p in sorted(prof, key=lambda p: -p["total_ms"])}
             result["gpu_kernel_ms_per_frame"] = round(tot / args.steps, 4)
             # both components of the algorithmic bytes for the whole frame, against the unprofiled frame time
             a_bytes = sum(p["traversal_bytes"] for p in prof) / args.steps
             b_bytes = sum(p["algorithmic_bytes"] - p["traversal_bytes"] for p in prof) / args.steps
             result["frame_bytes"] = {"screen_space_B": round(b_bytes), "traversal_A": round(a_bytes),
-                                     "B_GBps": round(b_bytes / (ms * 1e-3) / 1e9, 1), "A_plus_B_GBps": round((a_bytes + b_bytes) / (ms * 1e-3) / 1e9, 1),
+                                     "B_GBps": round(b_bytes / (ms * 1e-3) / 1e9, 1),
                                      "B_frac_of_peak": round(b_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "note": "B = compulsory screen-space plane bytes of the reference's passes (unfused accounting), A = the reference's used_memory traversal bytes (cache-served on these scenes)"}
+                                     "B_frac_of_measured_copy_ceiling": None if not copy_ceiling else round(b_bytes / (ms * 1e-3) / 1e9 / copy_ceiling, 4),
+                                     "note": "B = compulsory screen-space plane bytes of the reference's passes (unfused accounting; HBM), A = the reference's used_memory traversal bytes (cache- or LDS-served on these scenes: not HBM traffic, not added to B)"}
             result["ms_per_step_with_event_timing"] = round(profiled_ms, 4)
-        if world == 1 and not args.no_cpu_baseline and (args.scene, args.mode) == ("cornell", "image"):
+        if world == 1 and not args.no_cpu_baseline and headline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, base)
             except Exception as ex:  # the baseline must never sink the GPU number

@@ -17,7 +17,7 @@
  * Environment switches (read once per engine; every combination renders the same bits): ST_NO_OVERLAP=1
  * single stream; ST_NO_FUSE=1 one launch per reference pass (ST_NO_FUSE_SPATIAL / _DI_HEAD /
  * _GI_REPROJECTION=1 undo one fusion); ST_TILE_MAP=0|1|2 and ST_TILE_MAP_DENOISE block->tile mapping;
- * ST_FUSE_COMPOSE=1; ST_COMPACT=1 compacted shadow-ray kernel; ST_NO_PACKED_BASE=1; ST_NO_STAGING=1 st_tick uploads from
+ * ST_NO_FUSE_WAVELET=1 strides 1 and 2 of the a-trous chain as two launches; ST_COMPACT=1 compacted shadow-ray kernel; ST_NO_PACKED_BASE=1; ST_NO_STAGING=1 st_tick uploads from
  * pageable memory and joins its stream; ST_NO_DOUBLE_BUFFER=1 scene changes update the device arrays in place; ST_TICK_TIMING=1 host refresh timing on stderr.
  */
 #ifndef STROLLE_HIP_H

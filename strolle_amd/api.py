@@ -491,7 +491,7 @@ class Engine(EngineBase):
         return out.value == 1
 
     def write_buffer(self, camera: int, buffer: "Buffer", data: np.ndarray):
-        """st_camera_write_buffer: the inverse of read_buffer (parity tests hand a launch the oracle's input planes)."""
+        """st_camera_write_buffer: the inverse of read_buffer (parity tests hand a launch its reference input planes)."""
         data = np.ascontiguousarray(data)
         self._check(self._b.camera_write_buffer(self._h, camera, int(buffer), data.ctypes.data, data.nbytes))
 

@@ -65,7 +65,7 @@ void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const f
 }
 
 // ---------------------------------------------------------------- frame_denoising.rs:80-217
-__global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a) {
+__global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_out, float4* gi_out) {
     // Window of the short-history estimate, staged per block when any of its pixels needs it: ox in [-3, 2], oy in
     // [-2, 2] around 32x8 pixels = 38 x 12 texels of (surface, direct colour, indirect colour). Only ~15 % of the waves
     // take the slow path on Cornell, but with 58 dependent loads each they set the kernel's duration; from LDS the same
@@ -102,7 +102,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a) {
         __syncthreads();
     }
     if (!mine) return;
-    if (csn.w == 0.0f) { a.di_diff_stash[center] = cdi; a.gi_diff_stash[center] = cgi; return; }  // sky
+    if (csn.w == 0.0f) { di_out[center] = cdi; gi_out[center] = cgi; return; }  // sky
     const float cdi_luma = luma(xyz(cdi)), cgi_luma = luma(xyz(cgi));
     float di_var, gi_var;
     if (!slow) {
@@ -139,192 +139,286 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a) {
     }
     di_var = fmax_(di_var, 0.0f);
     gi_var = fmax_(gi_var, 0.0f);
-    a.di_diff_stash[center] = f4(xyz(cdi), di_var);
-    a.gi_diff_stash[center] = f4(xyz(cgi), gi_var);
-    a.sl[0][center] = make_float2(fsqrt(cdi_luma), fsqrt(cgi_luma));  // for the first wavelet pass's taps
+    di_out[center] = f4(xyz(cdi), di_var);
+    gi_out[center] = f4(xyz(cgi), gi_var);
 }
-void launch_denoise_variance(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a); }
+void launch_denoise_variance(const KArgs& a, float4* di_out, float4* gi_out, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a, di_out, gi_out); }
 
-// ---------------------------------------------------------------- frame_denoising.rs:219-361
-// The pass is VALU-issue-bound (SQ counters: ~100 % VALU busy, 1245 VALU/wave before this layout), so the direct and
-// indirect signals are carried as the two halves of 64-bit packed-f32 operations (v_pk_mul_f32 / v_pk_add_f32): the
-// same IEEE operations in the same order per half, half the issue slots. The weight's shared factors (depth, normal)
-// are evaluated once per tap; a tap whose shared factor is exactly zero is dropped before its colours are loaded —
+// ---------------------------------------------------------------- frame_denoising.rs:219-361 (five à-trous passes)
+// Measured (rocprofv3, MI355X): these passes are bound by the bytes they move, not by arithmetic — in the fast build a wave
+// spends under 10 % of its life issuing VALU work. So the layout below is about traffic:
+//   * strides 1 and 2 run as ONE launch (k_denoise_wavelet_12): a block stages the (32+6) x (16+6) window of its 32x16
+//     pixels once, runs the stride-1 pass for the (32+4) x (16+4) pixels the stride-2 taps will touch, keeps those results
+//     in LDS, and runs the stride-2 pass from there. Both outputs are stored (the first pass's output is next frame's colour
+//     history, the second feeds the stride-4 pass): 48 B x 1.63 read + 64 B written per pixel for two passes, against
+//     2 x (48 B x 1.33 + 32 B) for two separate 32x8-tiled launches.
+//   * stride 4 (jitter still truncates to 0, frame_denoising.rs:262-266) stages a (32+8) x (16+8) window.
+//   * strides 8 and 16 have per-pixel jitter and no reuse to stage; they gather through L2 (k_denoise_wavelet_far).
+// sqrt(luma) of a tap (frame_denoising.rs:370-372) is recomputed from the staged colours: it costs two hardware square
+// roots per tap and saves an 8-B plane that had to be written by every pass and read back, halo included, by the next.
+// The weight is exp(-|sqrt(luma_c) - sqrt(luma_s)| * luma_sigma) * depth_weight * normal_weight, multiplied in that order
+// (frame_denoising.rs:363-398); depth and normal factors are shared by the direct and the indirect signal, which ride the
+// two halves of packed-f32 operations. A tap whose shared factor is exactly zero is dropped before its colours are read:
 // its weight would be 0 or NaN and `w > 0` (frame_denoising.rs:318,340) rejects both.
-// COMPOSE: the last wavelet pass also runs frame composition for its pixel (frame_composition.rs) — the composed frame
-// needs only this pixel's denoised colours, which are in registers here.
-template <bool COMPOSE>
-__global__ ST_KERNEL_BOUNDS void k_denoise_wavelet(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out,
-                                                                    const float4* gi_in, float4* gi_out, const float2* sl_in, float2* sl_out,
-                                                                    uint32_t camera_mode, float4* frame_out) {
+struct WaveletCenter {
+    float4 sn; V3 n; f2 sqrt_luma, luma_sigma; float leeway, inv_leeway;
+    f2 sum_w, sum_r, sum_g, sum_b, sum_v;
+};
+ST_D f2 sqrt_luma2(float4 di, float4 gi) { return sqrt2((mk2(di.x, gi.x) * 0.2126f + mk2(di.y, gi.y) * 0.7152f) + mk2(di.z, gi.z) * 0.0722f); }
+ST_D WaveletCenter wavelet_begin(float4 csn, float4 cdi, float4 cgi, float strength) {
+    WaveletCenter c;
+    c.sn = csn; c.n = v3(csn.x, csn.y, csn.z);
+    c.sqrt_luma = sqrt_luma2(cdi, cgi);
+    c.luma_sigma = mk2(lerpf(2.5f, 0.5f, fsqrt(cdi.w)), lerpf(1.0f, 0.0f, fsqrt(cgi.w)));
+    c.leeway = csn.w * (0.33f / strength); c.inv_leeway = frcp(c.leeway);  // depth sigma is the same for both signals
+    c.sum_w = splat2(1.0f); c.sum_r = mk2(cdi.x, cgi.x); c.sum_g = mk2(cdi.y, cgi.y); c.sum_b = mk2(cdi.z, cgi.z); c.sum_v = mk2(cdi.w, cgi.w);
+    return c;
+}
+// depth_weight * ... and normal_weight of a tap's surface; false = the tap contributes nothing
+ST_D bool wavelet_shared(const WaveletCenter& c, float4 ssn, float* depth_weight, float* normal_weight) {
+    if (ssn.w == 0.0f) return false;
+    const float diff = fabsf(ssn.w - c.sn.w);
+    *depth_weight = diff >= c.leeway ? 0.0f : 1.0f - div_by(diff, c.leeway, c.inv_leeway);
+    *normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), c.n), 0.0f));
+    return !(*depth_weight == 0.0f || *normal_weight == 0.0f);
+}
+ST_D void wavelet_tap(WaveletCenter& c, float4 sdi, float4 sgi, float depth_weight, float normal_weight) {
+    const f2 r = mk2(sdi.x, sgi.x), g = mk2(sdi.y, sgi.y), b = mk2(sdi.z, sgi.z), v = mk2(sdi.w, sgi.w);
+    const f2 d = c.sqrt_luma - sqrt2((r * 0.2126f + g * 0.7152f) + b * 0.0722f);
+    const f2 luma_weight = mk2(fabsf(d.x), fabsf(d.y)) * c.luma_sigma;
+    const f2 w = exp_pair(-luma_weight) * depth_weight * normal_weight;
+    if (w.x > 0.0f && w.y > 0.0f) {
+        c.sum_w = c.sum_w + w; c.sum_r = c.sum_r + w * r; c.sum_g = c.sum_g + w * g; c.sum_b = c.sum_b + w * b; c.sum_v = c.sum_v + (w * w) * v;
+    } else {
+        if (w.x > 0.0f) { c.sum_w.x += w.x; c.sum_r.x += w.x * r.x; c.sum_g.x += w.x * g.x; c.sum_b.x += w.x * b.x; c.sum_v.x += (w.x * w.x) * v.x; }
+        if (w.y > 0.0f) { c.sum_w.y += w.y; c.sum_r.y += w.y * r.y; c.sum_g.y += w.y * g.y; c.sum_b.y += w.y * b.y; c.sum_v.y += (w.y * w.y) * v.y; }
+    }
+}
+struct WaveletOut { float4 di, gi; bool lit; };  // lit == false: sky pixel — `di` is the copied direct colour, the indirect output is left alone
+ST_D WaveletOut wavelet_end(const WaveletCenter& c) {
+    const f2 ww = c.sum_w * c.sum_w;
+    WaveletOut o;
+    o.di = wavelet_resolve(c.sum_r.x, c.sum_g.x, c.sum_b.x, c.sum_v.x, c.sum_w.x, ww.x);
+    o.gi = wavelet_resolve(c.sum_r.y, c.sum_g.y, c.sum_b.y, c.sum_v.y, c.sum_w.y, ww.y);
+    o.lit = true;
+    return o;
+}
+// one pixel of a zero-jitter pass whose window is in LDS: `lc` = the pixel's texel, taps at +-S texels / rows (pitch P).
+// Texels outside the viewport were staged with depth 0, which is skipped like an out-of-bounds or sky tap. Returns false
+// for a sky pixel (the reference copies the direct colour and leaves the indirect output alone).
+template <int S, int P>
+ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const float4* s_gi, int lc, float strength) {
+    const float4 csn = s_sn[lc], cdi = s_di[lc], cgi = s_gi[lc];
+    if (csn.w == 0.0f) { WaveletOut o; o.di = cdi; o.gi = cgi; o.lit = false; return o; }
+    WaveletCenter c = wavelet_begin(csn, cdi, cgi, strength);
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
+        const int lt = lc + oy * S * P + ox * S;
+        float dw, nw;
+        if (!wavelet_shared(c, s_sn[lt], &dw, &nw)) continue;
+        wavelet_tap(c, s_di[lt], s_gi[lt], dw, nw);
+    }
+    return wavelet_end(c);
+}
+
+// Block geometry of the LDS-staged passes: 32 x 16 pixels, 512 threads, thread t -> pixel (t % 32, t / 32), so a wave
+// reads two 32-texel row segments from LDS (conflict-free ds_read_b128 with a row pitch = 8 mod 16 texels) and stores two
+// 512-B runs per plane. Blocks are dealt to XCDs like the 32x8 tiling does (st_device.h tile_for_thread): mode 2 keeps
+// two block rows (32 pixel rows) per XCD chunk so the halo rows a block shares with its vertical neighbour stay in one L2.
+constexpr int kWvW = 32, kWvH = 16, kWvThreads = kWvW * kWvH;
+struct WaveletBlock { int32_t x0, y0; bool valid; };
+ST_D WaveletBlock wavelet_block(const KArgs& a) {
+    const uint32_t groups_x = (a.width + kWvW - 1u) / kWvW;
+    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
+    const uint32_t rows = ((ty1 - ty0) * 8u + kWvH - 1u) / kWvH;
+    const uint32_t n_blocks = groups_x * rows, b = blockIdx.x;
+    uint32_t lin = b;
+    if (a.tile_map == 0u) {
+        const uint32_t q = n_blocks >> 3, r = n_blocks & 7u, xcd = b & 7u, k = b >> 3;
+        lin = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
+    } else if (a.tile_map == 2u) {
+        const uint32_t chunk = groups_x * 2u * 8u, full = (n_blocks / chunk) * chunk;
+        if (b < full) { const uint32_t c = b / chunk, i = b - c * chunk; lin = c * chunk + (i & 7u) * (groups_x * 2u) + (i >> 3); }
+    }
+    WaveletBlock w;
+    const uint32_t gy = lin / groups_x, gx = lin - gy * groups_x;
+    w.x0 = (int32_t)(gx * kWvW); w.y0 = (int32_t)(ty0 * 8u + gy * kWvH);
+    w.valid = gy < rows;
+    return w;
+}
+inline uint32_t wavelet_blocks(const KArgs& a) {
+    const uint32_t groups_x = (a.width + kWvW - 1u) / kWvW, ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
+    return groups_x * (((ty1 - ty0) * 8u + kWvH - 1u) / kWvH);
+}
+// stages the (kWvW + 2 HALO) x (kWvH + 2 HALO) window around the block into LDS (row pitch P texels)
+template <int HALO, int P>
+ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* di_in, const float4* gi_in, float4* s_sn, float4* s_di, float4* s_gi) {
+    constexpr int WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO;
+    for (int i = (int)threadIdx.x; i < WW * WH; i += kWvThreads) {
+        const int ry = i / WW, rx = i - ry * WW;
+        const int32_t gx = blk.x0 - HALO + rx, gy = blk.y0 - HALO + ry;
+        const int li = ry * P + rx;
+        if (gx >= 0 && gy >= 0 && gx < (int32_t)a.width && gy < (int32_t)a.height) {
+            const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
+            s_sn[li] = a.sn[at]; s_di[li] = di_in[at]; s_gi[li] = gi_in[at];
+        } else {
+            s_sn[li] = f4z();
+        }
+    }
+}
+
+// ---- strides 1 + 2 in one launch. di_in / gi_in: the variance pass's output; di_mid / gi_mid: the stride-1 pass's output
+// (prev_colors planes: next frame's history); di_out / gi_out: the stride-2 pass's output (stash planes). In the reference
+// the variance pass writes the stash planes too (stash -> prev -> stash); here a block would then read halo texels that a
+// neighbouring block has already overwritten with its stride-2 results, so the variance pass of this launch group writes
+// an internal pair of planes instead (st_engine.cpp) and the stash planes first receive the stride-2 output.
+__global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out,
+                                                                   const float4* gi_in, float4* gi_mid, float4* gi_out) {
+    constexpr int HALO = 3, WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO, P = 40;  // 38 x 22 texels, pitch 40 = 8 mod 16
+    constexpr int RW = kWvW + 4, RH = kWvH + 4;                                   // 36 x 20: where the stride-1 pass must run
+    __shared__ float4 s_sn[P * WH];
+    __shared__ float4 s_di[P * WH];
+    __shared__ float4 s_gi[P * WH];
+    const WaveletBlock blk = wavelet_block(a);
+    if (!blk.valid) return;
+    wavelet_stage<HALO, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi);
+    __syncthreads();
+    // stride-1 pass over the 36 x 20 region (row-major over the threads: 1.4 pixels each)
+    float4 r_di[2], r_gi[2]; int r_at[2];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int idx = (int)threadIdx.x + it * kWvThreads;
+        r_at[it] = -1;
+        if (idx >= RW * RH) continue;
+        const int ry = idx / RW, rx = idx - ry * RW;
+        const int lc = (ry + 1) * P + rx + 1;
+        r_at[it] = lc;
+        const WaveletOut o = wavelet_pixel_lds<1, P>(s_sn, s_di, s_gi, lc, strength0);
+        r_di[it] = o.di; r_gi[it] = o.gi;  // sky (or outside the viewport): the indirect colour is never read, as a tap or as a centre
+        const bool lit = o.lit;
+        // the block's own pixels: this is what the stand-alone stride-1 pass stores
+        const int32_t px = blk.x0 - 2 + rx, py = blk.y0 - 2 + ry;
+        if (rx >= 2 && rx < 2 + kWvW && ry >= 2 && ry < 2 + kWvH && px < (int32_t)a.width && py < (int32_t)a.height && (uint32_t)py >= a.row0 && (uint32_t)py < a.row1) {
+            const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
+            di_mid[center] = r_di[it];
+            if (lit) gi_mid[center] = r_gi[it];
+        }
+    }
+    __syncthreads();  // every stride-1 read of the staged colours is done: replace them by the stride-1 results
+#pragma unroll
+    for (int it = 0; it < 2; it++) if (r_at[it] >= 0) { s_di[r_at[it]] = r_di[it]; s_gi[r_at[it]] = r_gi[it]; }
+    __syncthreads();
+    // stride-2 pass for the block's own pixels
+    const int x = (int)(threadIdx.x & 31u), y = (int)(threadIdx.x >> 5);
+    const int32_t px = blk.x0 + x, py = blk.y0 + y;
+    if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) return;
+    const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
+    const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, (y + HALO) * P + x + HALO, strength1);
+    di_out[center] = o.di;
+    if (o.lit) gi_out[center] = o.gi;
+}
+
+// ---- a single zero-jitter pass staged through LDS (stride 4; also strides 1 and 2 when run unfused)
+template <int S>
+__global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_lds(const KArgs a, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out) {
+    constexpr int WH = kWvH + 2 * S, P = (kWvW + 2 * S + 15) / 16 * 16 + 8;  // pitch = 8 mod 16 texels
+    __shared__ float4 s_sn[P * WH];
+    __shared__ float4 s_di[P * WH];
+    __shared__ float4 s_gi[P * WH];
+    const WaveletBlock blk = wavelet_block(a);
+    if (!blk.valid) return;
+    wavelet_stage<S, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi);
+    __syncthreads();
+    const int x = (int)(threadIdx.x & 31u), y = (int)(threadIdx.x >> 5);
+    const int32_t px = blk.x0 + x, py = blk.y0 + y;
+    if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) return;
+    const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
+    const WaveletOut o = wavelet_pixel_lds<S, P>(s_sn, s_di, s_gi, (y + S) * P + x + S, strength);
+    di_out[center] = o.di;
+    if (o.lit) gi_out[center] = o.gi;
+}
+
+// ---- strides 8 and 16: jittered taps, gathered through L2. Three dependent rounds of eight independent loads each
+// (surfaces, direct colours, indirect colours) with scheduling barriers between them: the shared depth / normal factors are
+// reduced to two floats per tap before the colours are requested and the direct signal is finished before the indirect one
+// is loaded, so that at most eight texels are live at a time (6 waves per SIMD cover the gather latency; with all 24 loads
+// hoisted the kernel ran at 4). One signal at a time means scalar instead of packed arithmetic — the same IEEE operations.
+struct WaveletSignal { float sqrt_luma, sigma, sw, sr, sg, sb, sv; };
+ST_D WaveletSignal signal_begin(float4 c, float sigma_hi, float sigma_lo) {
+    WaveletSignal s;
+    s.sqrt_luma = fsqrt(luma(xyz(c))); s.sigma = lerpf(sigma_hi, sigma_lo, fsqrt(c.w));
+    s.sw = 1.0f; s.sr = c.x; s.sg = c.y; s.sb = c.z; s.sv = c.w;
+    return s;
+}
+ST_D void signal_tap(WaveletSignal& s, float4 t, float depth_weight, float normal_weight) {
+    const float d = s.sqrt_luma - fsqrt(luma(xyz(t)));
+    const float w = exp_(-(fabsf(d) * s.sigma)) * depth_weight * normal_weight;
+    if (w > 0.0f) { s.sw += w; s.sr += w * t.x; s.sg += w * t.y; s.sb += w * t.z; s.sv += (w * w) * t.w; }
+}
+ST_D float4 signal_end(const WaveletSignal& s) { return wavelet_resolve(s.sr, s.sg, s.sb, s.sv, s.sw, s.sw * s.sw); }
+__global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const uint32_t center = pos.y * a.width + pos.x;
     const float4 csn = a.sn[center];
     const float4 cdi = di_in[center];
-    if (csn.w == 0.0f) {  // sky
-        di_out[center] = cdi;
-        // composition reads gi_diff_curr_colors for this pixel, which this pass leaves untouched on sky pixels
-        if (COMPOSE) frame_out[center] = compose_pixel(a, pos, camera_mode, cdi, gi_out[center]);
-        return;
-    }
-    const float4 cgi = gi_in[center];
-    const V3 cn = v3(csn.x, csn.y, csn.z);
-    // sl_in == null: this pass's input has no sqrt-luma plane (the generic kernel serves strides 8 and 16, whose taps
-    // are texture-address-bound — a fourth load per tap costs more there than the two square roots it replaces)
-    f2 c_sqrt_luma;
-    if (sl_in) { const float2 csl = sl_in[center]; c_sqrt_luma = mk2(csl.x, csl.y); }
-    else c_sqrt_luma = mk2(fsqrt(luma(xyz(cdi))), fsqrt(luma(xyz(cgi))));
-    const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, fsqrt(cdi.w)), lerpf(1.0f, 0.0f, fsqrt(cgi.w)));
-    const float leeway = csn.w * (0.33f / strength), inv_leeway = frcp(leeway);  // depth sigma is the same for both signals
-    I2 jitter = i2(0, 0);
-    if (stride != 1u) {  // at stride 1 the jitter is (bn - 0.5) * 0 * 0.5 == 0
-        const float4 bn = blue_noise_read(a, pos);
-        jitter = as_i2((v2(bn.z, bn.w) - 0.5f) * ((float)stride - 1.0f) * 0.5f);
-    }
-    f2 sum_w = splat2(1.0f), sum_r = mk2(cdi.x, cgi.x), sum_g = mk2(cdi.y, cgi.y), sum_b = mk2(cdi.z, cgi.z), sum_v = mk2(cdi.w, cgi.w);
-    // Loads are issued in two unconditional batches (8 surface texels, then the colours of the taps) so that a wave pays
-    // two memory round trips instead of sixteen dependent ones; a tap that is out of bounds reads the centre texel and
-    // is masked out afterwards.
-    uint32_t at[8];
-    float4 ssn[8];
-    bool live[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
-        const I2 sp = i2((int32_t)pos.x + jitter.x + ox * (int32_t)stride, (int32_t)pos.y + jitter.y + oy * (int32_t)stride);
-        live[t] = contains_i(a, sp);
-        at[t] = live[t] ? (uint32_t)sp.y * a.width + (uint32_t)sp.x : center;
-        ssn[t] = a.sn[at[t]];
-    }
-    float depth_w[8], normal_w[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const float diff = fabsf(ssn[t].w - csn.w);
-        depth_w[t] = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
-        normal_w[t] = pow64_(fmax_(dot(v3(ssn[t].x, ssn[t].y, ssn[t].z), cn), 0.0f));
-        live[t] = live[t] && ssn[t].w != 0.0f && !(depth_w[t] == 0.0f || normal_w[t] == 0.0f);
-    }
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        float4 sdi[4], sgi[4]; float2 ssl[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = at[half * 4 + u]; sdi[u] = di_in[i]; sgi[u] = gi_in[i]; if (sl_in) ssl[u] = sl_in[i]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = half * 4 + u;
-            if (!live[t]) continue;
-            const f2 r = mk2(sdi[u].x, sgi[u].x), g = mk2(sdi[u].y, sgi[u].y), b = mk2(sdi[u].z, sgi[u].z), v = mk2(sdi[u].w, sgi[u].w);
-            f2 tap_sqrt_luma;
-            if (sl_in) tap_sqrt_luma = mk2(ssl[u].x, ssl[u].y);
-            else { const f2 l = (r * 0.2126f + g * 0.7152f) + b * 0.0722f; tap_sqrt_luma = sqrt2(l); }
-            const f2 d = c_sqrt_luma - tap_sqrt_luma;
-            const f2 luma_weight = mk2(fabsf(d.x), fabsf(d.y)) * luma_sigma;
-            const f2 w = exp_pair(-luma_weight) * depth_w[t] * normal_w[t];
-            if (w.x > 0.0f && w.y > 0.0f) {
-                sum_w = sum_w + w; sum_r = sum_r + w * r; sum_g = sum_g + w * g; sum_b = sum_b + w * b; sum_v = sum_v + (w * w) * v;
-            } else {
-                if (w.x > 0.0f) { sum_w.x += w.x; sum_r.x += w.x * r.x; sum_g.x += w.x * g.x; sum_b.x += w.x * b.x; sum_v.x += (w.x * w.x) * v.x; }
-                if (w.y > 0.0f) { sum_w.y += w.y; sum_r.y += w.y * r.y; sum_g.y += w.y * g.y; sum_b.y += w.y * b.y; sum_v.y += (w.y * w.y) * v.y; }
-            }
-        }
-    }
-    const f2 ww = sum_w * sum_w;
-    const float4 odi = wavelet_resolve(sum_r.x, sum_g.x, sum_b.x, sum_v.x, sum_w.x, ww.x);
-    const float4 ogi = wavelet_resolve(sum_r.y, sum_g.y, sum_b.y, sum_v.y, sum_w.y, ww.y);
-    di_out[center] = odi;
-    gi_out[center] = ogi;
-    if (sl_out) sl_out[center] = make_float2(fsqrt(luma(xyz(odi))), fsqrt(luma(xyz(ogi))));
-    if (COMPOSE) frame_out[center] = compose_pixel(a, pos, camera_mode, odi, ogi);
-}
-// ---------------------------------------------------------------- the same pass for strides 1, 2 and 4, staged through LDS
-// At these strides the jitter is identically zero — |(bn - 0.5) * (stride - 1) * 0.5| <= 0.75 truncates to 0
-// (frame_denoising.rs:262-266) — so the taps of a block's 32x8 pixels fall on a fixed (32+2S)x(8+2S) window that the
-// block loads once (1.3-2.5 texels per pixel instead of 9) and then reads from LDS. Texels outside the viewport are
-// staged with depth 0: the tap loop already skips depth-0 (sky) samples, which is what `continue` on an out-of-bounds
-// tap does in the reference. Row pitch 40 texels: 640 B rows put 8-lane row segments of ds_read_b128 on disjoint banks.
-template <int S>
-__global__ ST_KERNEL_BOUNDS void k_denoise_wavelet_lds(const KArgs a, float strength, const float4* di_in, float4* di_out,
-                                                                        const float4* gi_in, float4* gi_out, const float2* sl_in, float2* sl_out) {
-    constexpr int RW = 32 + 2 * S, RH = 8 + 2 * S, PITCH = 40;
-    __shared__ float4 s_sn[PITCH * RH];
-    __shared__ float4 s_di[PITCH * RH];
-    __shared__ float4 s_gi[PITCH * RH];
-    __shared__ float2 s_sl[PITCH * RH];
-    const uint32_t tiles_x = (a.width + 7u) >> 3;
-    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
-    TileCoord tc = tile_for_thread(tiles_x, ty1 - ty0, a.tile_map);  // tc.y is block-uniform, tc.x = first tile of the block + wave
-    const uint32_t wave = threadIdx.x >> 6;
-    const int32_t bx0 = (int32_t)((tc.x - wave) * 8u) - S, by0 = (int32_t)((tc.y + ty0) * 8u) - S;
-    for (int i = (int)threadIdx.x; i < RW * RH; i += kBlockThreads) {
-        const int ry = i / RW, rx = i - ry * RW;
-        const int32_t gx = bx0 + rx, gy = by0 + ry;
-        const int li = ry * PITCH + rx;
-        if (gx >= 0 && gy >= 0 && gx < (int32_t)a.width && gy < (int32_t)a.height) {
-            const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
-            s_sn[li] = a.sn[at]; s_di[li] = di_in[at]; s_gi[li] = gi_in[at]; s_sl[li] = sl_in[at];
-        } else {
-            s_sn[li] = f4z();
-        }
-    }
-    __syncthreads();
-    if (!tc.valid) return;
-    tc.y += ty0;
-    const U2 pos = pixel_in_tile(tc);
-    if (!owns_pixel(a, pos)) return;
-    const uint32_t center = pos.y * a.width + pos.x;
-    const int lc = ((int)(pos.y & 7u) + S) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + S;
-    const float4 csn = s_sn[lc];
-    const float4 cdi = s_di[lc];
     if (csn.w == 0.0f) { di_out[center] = cdi; return; }  // sky
-    const float4 cgi = s_gi[lc];
-    const V3 cn = v3(csn.x, csn.y, csn.z);
-    const float2 csl = s_sl[lc];
-    const f2 c_sqrt_luma = mk2(csl.x, csl.y);
-    const f2 luma_sigma = mk2(lerpf(2.5f, 0.5f, fsqrt(cdi.w)), lerpf(1.0f, 0.0f, fsqrt(cgi.w)));
-    const float leeway = csn.w * (0.33f / strength), inv_leeway = frcp(leeway);
-    f2 sum_w = splat2(1.0f), sum_r = mk2(cdi.x, cgi.x), sum_g = mk2(cdi.y, cgi.y), sum_b = mk2(cdi.z, cgi.z), sum_v = mk2(cdi.w, cgi.w);
+    const float4 bn = blue_noise_read(a, pos);
+    const I2 jitter = as_i2((v2(bn.z, bn.w) - 0.5f) * ((float)stride - 1.0f) * 0.5f);
+    uint32_t at[8];
+    float dw[8], nw[8];
+    {
+        WaveletCenter c; c.sn = csn; c.n = v3(csn.x, csn.y, csn.z);
+        c.leeway = csn.w * (0.33f / strength); c.inv_leeway = frcp(c.leeway);
+        float4 ssn[8];
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
-        const int lt = lc + oy * S * PITCH + ox * S;
-        const float4 ssn = s_sn[lt];
-        if (ssn.w == 0.0f) continue;
-        const float diff = fabsf(ssn.w - csn.w);
-        const float depth_weight = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
-        const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
-        if (depth_weight == 0.0f || normal_weight == 0.0f) continue;
-        const float4 sdi = s_di[lt], sgi = s_gi[lt];
-        const float2 ssl = s_sl[lt];
-        const f2 r = mk2(sdi.x, sgi.x), g = mk2(sdi.y, sgi.y), b = mk2(sdi.z, sgi.z), v = mk2(sdi.w, sgi.w);
-        const f2 d = c_sqrt_luma - mk2(ssl.x, ssl.y);
-        const f2 luma_weight = mk2(fabsf(d.x), fabsf(d.y)) * luma_sigma;
-        const f2 w = exp_pair(-luma_weight) * depth_weight * normal_weight;
-        if (w.x > 0.0f && w.y > 0.0f) {
-            sum_w = sum_w + w; sum_r = sum_r + w * r; sum_g = sum_g + w * g; sum_b = sum_b + w * b; sum_v = sum_v + (w * w) * v;
-        } else {
-            if (w.x > 0.0f) { sum_w.x += w.x; sum_r.x += w.x * r.x; sum_g.x += w.x * g.x; sum_b.x += w.x * b.x; sum_v.x += (w.x * w.x) * v.x; }
-            if (w.y > 0.0f) { sum_w.y += w.y; sum_r.y += w.y * r.y; sum_g.y += w.y * g.y; sum_b.y += w.y * b.y; sum_v.y += (w.y * w.y) * v.y; }
+        for (int t = 0; t < 8; t++) {
+            const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
+            const I2 sp = i2((int32_t)pos.x + jitter.x + ox * (int32_t)stride, (int32_t)pos.y + jitter.y + oy * (int32_t)stride);
+            const bool inside = contains_i(a, sp);
+            at[t] = inside ? (uint32_t)sp.y * a.width + (uint32_t)sp.x : center;  // an out-of-bounds tap reads the centre and is masked below
+            ssn[t] = a.sn[at[t]];
+            if (!inside) ssn[t].w = 0.0f;
         }
+#pragma unroll
+        for (int t = 0; t < 8; t++) if (!wavelet_shared(c, ssn[t], &dw[t], &nw[t])) { dw[t] = 0.0f; nw[t] = 0.0f; at[t] = center; }  // a dead tap re-reads the centre's line
     }
-    const f2 ww = sum_w * sum_w;
-    const float4 odi = wavelet_resolve(sum_r.x, sum_g.x, sum_b.x, sum_v.x, sum_w.x, ww.x);
-    const float4 ogi = wavelet_resolve(sum_r.y, sum_g.y, sum_b.y, sum_v.y, sum_w.y, ww.y);
-    di_out[center] = odi;
-    gi_out[center] = ogi;
-    if (sl_out) sl_out[center] = make_float2(fsqrt(luma(xyz(odi))), fsqrt(luma(xyz(ogi))));
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        WaveletSignal sg = signal_begin(cdi, 2.5f, 0.5f);
+        float4 tap[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) tap[t] = di_in[at[t]];
+#pragma unroll
+        for (int t = 0; t < 8; t++) if (dw[t] != 0.0f) signal_tap(sg, tap[t], dw[t], nw[t]);
+        di_out[center] = signal_end(sg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        WaveletSignal sg = signal_begin(gi_in[center], 1.0f, 0.0f);
+        float4 tap[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) tap[t] = gi_in[at[t]];
+#pragma unroll
+        for (int t = 0; t < 8; t++) if (dw[t] != 0.0f) signal_tap(sg, tap[t], dw[t], nw[t]);
+        gi_out[center] = signal_end(sg);
+    }
 }
 
 void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
-                            float4* gi_out, const float2* sl_in, float2* sl_out, hipStream_t s) {
-    if (stride == 1u) ST_LAUNCH(k_denoise_wavelet_lds<1>, false, s, a, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out);
-    else if (stride == 2u) ST_LAUNCH(k_denoise_wavelet_lds<2>, false, s, a, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out);
-    else if (stride == 4u) ST_LAUNCH(k_denoise_wavelet_lds<4>, false, s, a, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out);
-    else ST_LAUNCH(k_denoise_wavelet<false>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, sl_in, sl_out, 0u, (float4*)nullptr);
+                            float4* gi_out, hipStream_t s) {
+    const uint32_t blocks = wavelet_blocks(a);
+    if (!blocks) return;
+    if (stride == 1u) hipLaunchKernelGGL(k_denoise_wavelet_lds<1>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
+    else if (stride == 2u) hipLaunchKernelGGL(k_denoise_wavelet_lds<2>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
+    else if (stride == 4u) hipLaunchKernelGGL(k_denoise_wavelet_lds<4>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
+    else ST_LAUNCH(k_denoise_wavelet_far, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out);
 }
-void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in,
-                                    float4* gi_out, const float2* sl_in, uint32_t camera_mode, float4* frame_out, hipStream_t s) {
-    ST_LAUNCH(k_denoise_wavelet<true>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, sl_in, (float2*)nullptr, camera_mode, frame_out);
+void launch_denoise_wavelet_12(const KArgs& a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out, const float4* gi_in,
+                               float4* gi_mid, float4* gi_out, hipStream_t s) {
+    const uint32_t blocks = wavelet_blocks(a);
+    if (blocks) hipLaunchKernelGGL(k_denoise_wavelet_12, dim3(blocks), dim3(kWvThreads), 0, s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
 }
 
 // ---------------------------------------------------------------- st_camera_write_buffer support
@@ -335,8 +429,6 @@ __global__ ST_KERNEL_BOUNDS void k_refresh_internal_planes(const KArgs a, float4
     const float4 sm = a.sm[i], psm = a.psm[i];
     a.sn[i] = sm.z == 0.0f ? f4z() : f4(normal_decode(v2(sm.x, sm.y)), sm.z);   // what primary visibility writes beside the surface map
     psn_out[i] = psm.z == 0.0f ? f4z() : f4(normal_decode(v2(psm.x, psm.y)), psm.z);
-    a.sl[0][i] = make_float2(fsqrt(luma(xyz(a.di_diff_stash[i]))), fsqrt(luma(xyz(a.gi_diff_stash[i]))));
-    a.sl[1][i] = make_float2(fsqrt(luma(xyz(a.di_diff_prev_colors[i]))), fsqrt(luma(xyz(a.gi_diff_prev_colors[i]))));
 }
 void launch_refresh_internal_planes(const KArgs& a_in, hipStream_t s) {
     KArgs a = a_in; a.row0 = 0; a.row1 = a.height;

@@ -229,7 +229,7 @@ struct DeviceArray {
 };
 
 // ------------------------------------------------------------------ per-camera state (camera_controller/buffers.rs)
-constexpr int kInternalPlanes = 3;  // decoded-surface twins A/B (KArgs::sn / psn) + the denoiser's sqrt-luma ping-pong pair (KArgs::sl)
+constexpr int kInternalPlanes = 4;  // decoded-surface twins A/B (KArgs::sn / psn) + the pair the variance pass writes ahead of the strides-1+2 wavelet launch
 struct CameraState {
     StCamera desc{};
     GpuCamera curr{}, prev{};
@@ -265,7 +265,7 @@ static int read_counters(const CameraState& c, unsigned long long* host /* 2*KS_
     return ST_OK;
 }
 
-struct ProfileRecord { int slot; hipEvent_t start, stop; double bytes; };
+struct ProfileRecord { int slot; hipEvent_t start, stop; double bytes; uint32_t launches; };
 
 struct Light112 { GpuLight g; };
 
@@ -352,7 +352,7 @@ struct Engine {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
     bool have_prev_frame_events = false;
-    bool fuse_compose = false;  // composition inside the last wavelet launch: measured slower (109 vs 65+36 us), kept for A/B (ST_FUSE_COMPOSE=1)
+    bool fuse_wavelet = true;  // ST_NO_FUSE_WAVELET=1: strides 1 and 2 of the a-trous chain as two launches
     bool fuse_spatial = true;  // ST_NO_FUSE_SPATIAL=1: DI spatial resampling as three launches
     bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
@@ -380,7 +380,7 @@ struct Engine {
         if (const char* k = getenv("ST_NO_FUSE_SPATIAL")) fuse_spatial = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
-        if (const char* fc = getenv("ST_FUSE_COMPOSE")) fuse_compose = atoi(fc) != 0;
+        if (const char* k = getenv("ST_NO_FUSE_WAVELET")) fuse_wavelet = atoi(k) == 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
         if (const char* nd = getenv("ST_NO_DOUBLE_BUFFER")) double_buffer = atoi(nd) == 0;
         if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
@@ -836,19 +836,31 @@ struct Engine {
         if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
-    struct Scope {
-        Engine* e; hipStream_t s; int slot; double bytes; hipEvent_t start{}, stop{};
-        Scope(Engine* e_, hipStream_t s_, int slot_, double bytes_) : e(e_), s(s_), slot(slot_), bytes(bytes_) {
-            if (e->profiling) { start = e->take_event(); stop = e->take_event(); (void)hipEventRecord(start, s); }
-        }
-        ~Scope() { if (e->profiling) { (void)hipEventRecord(stop, s); e->profile_records.push_back({slot, start, stop, bytes}); } }
-    };
+    // One event pair per RUN of consecutive launches of the same slot on the same stream (the five a-trous launches, say):
+    // an event between two kernels makes the second wait for a barrier packet, which adds microseconds to every launch
+    // it brackets, so back-to-back launches of one slot are timed as one interval and divided by their count.
+    struct OpenScope { int slot = -1; hipStream_t stream = nullptr; hipEvent_t start{}; double bytes = 0; uint32_t launches = 0; } open_scope;
+    void profile_begin(int slot, hipStream_t s, double bytes) {
+        if (!profiling) return;
+        if (open_scope.slot == slot && open_scope.stream == s) { open_scope.bytes += bytes; open_scope.launches += 1; return; }
+        profile_close();
+        open_scope.slot = slot; open_scope.stream = s; open_scope.bytes = bytes; open_scope.launches = 1;
+        open_scope.start = take_event();
+        (void)hipEventRecord(open_scope.start, s);
+    }
+    void profile_close() {
+        if (open_scope.slot < 0) return;
+        hipEvent_t stop = take_event();
+        (void)hipEventRecord(stop, open_scope.stream);
+        profile_records.push_back({open_scope.slot, open_scope.start, stop, open_scope.bytes, open_scope.launches});
+        open_scope.slot = -1;
+    }
     int drain_profile() {
         for (auto& r : profile_records) {
             ST_HIP(hipEventSynchronize(r.stop));
             float ms = 0.0f;
             ST_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
-            profile_totals[r.slot].launches += 1; profile_totals[r.slot].total_ms += ms; profile_totals[r.slot].algorithmic_bytes += r.bytes;
+            profile_totals[r.slot].launches += r.launches; profile_totals[r.slot].total_ms += ms; profile_totals[r.slot].algorithmic_bytes += r.bytes;
             event_pool.push_back(r.start); event_pool.push_back(r.stop);
         }
         profile_records.clear();
@@ -881,7 +893,6 @@ struct Engine {
         a.g1 = P(alt ? ST_BUF_PRIM_GBUFFER_D1_B : ST_BUF_PRIM_GBUFFER_D1_A); a.pg1 = P(alt ? ST_BUF_PRIM_GBUFFER_D1_A : ST_BUF_PRIM_GBUFFER_D1_B);
         a.sm = P(alt ? ST_BUF_PRIM_SURFACE_MAP_B : ST_BUF_PRIM_SURFACE_MAP_A); a.psm = P(alt ? ST_BUF_PRIM_SURFACE_MAP_A : ST_BUF_PRIM_SURFACE_MAP_B);
         a.sn = P(ST_BUF_COUNT + (alt ? 1 : 0)); a.psn = P(ST_BUF_COUNT + (alt ? 0 : 1));
-        a.sl[0] = reinterpret_cast<float2*>(P(ST_BUF_COUNT + 2)); a.sl[1] = a.sl[0] + (size_t)c.desc.width * c.desc.height;
         a.reprojection = P(ST_BUF_REPROJECTION_MAP); a.velocity = P(ST_BUF_VELOCITY_MAP);
         for (int i = 0; i < 3; i++) a.di_res[i] = P(ST_BUF_DI_RESERVOIRS_0 + i);
         a.di_diff_samples = P(ST_BUF_DI_DIFF_SAMPLES); a.di_diff_prev_colors = P(ST_BUF_DI_DIFF_PREV_COLORS); a.di_diff_curr_colors = P(ST_BUF_DI_DIFF_CURR_COLORS);
@@ -910,11 +921,11 @@ struct Engine {
         last_launches.clear();
         bool mask_split = false;
         auto run = [&](int slot, uint64_t bits, auto&& launch) {
-            last_launches.push_back(bits);
+            if (last_launches.empty() || last_launches.back() != bits) last_launches.push_back(bits);  // a launch group is reported once
             if ((bits & pass_mask) != bits) { mask_split |= (bits & pass_mask) != 0; return; }
             const double bytes = slot_bytes(slot);
             a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
-            Scope scope(this, cur, slot, bytes);
+            profile_begin(slot, cur, bytes);
             launch();
         };
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
@@ -1025,18 +1036,23 @@ struct Engine {
                 struct MapScope { KArgs& a; uint32_t saved; MapScope(KArgs& a_, uint32_t m) : a(a_), saved(a_.tile_map) { a.tile_map = m; } ~MapScope() { a.tile_map = saved; } } map_scope(a, tile_map_denoise);
                 if (!di_reprojected) run(KS_DENOISE_REPROJECT, ST_PASS_DENOISE_REPROJECT_DI, [&] { L.launch_denoise_reproject(a, a.di_diff_prev_colors, a.di_diff_prev_moments, a.di_diff_samples, a.di_diff_curr_colors, a.di_diff_moments, cur); });
                 if (!gi_reprojected) run(KS_DENOISE_REPROJECT, ST_PASS_DENOISE_REPROJECT_GI, [&] { L.launch_denoise_reproject(a, a.gi_diff_prev_colors, a.gi_diff_prev_moments, a.gi_diff_samples, a.gi_diff_curr_colors, a.gi_diff_moments, cur); });
-                run(KS_DENOISE_VARIANCE, ST_PASS_DENOISE_VARIANCE, [&] { L.launch_denoise_variance(a, cur); });
                 // ping-pong (passes/frame_denoising.rs:87-110): stash -> prev -> stash -> curr -> stash -> curr
                 float4* di[3] = {a.di_diff_stash, a.di_diff_prev_colors, a.di_diff_curr_colors};
                 float4* gi[3] = {a.gi_diff_stash, a.gi_diff_prev_colors, a.gi_diff_curr_colors};
                 const int in_ix[5] = {0, 1, 0, 2, 0}, out_ix[5] = {1, 0, 2, 0, 2};
-                for (uint32_t nth = 0; nth < 5; nth++) {
-                    if (nth == 4 && fuse_compose && out && c.out_format == 0u) {
-                        run(KS_DENOISE_WAVELET_COMPOSE, ((uint64_t)ST_PASS_DENOISE_WAVELET_0 << nth) | ST_PASS_COMPOSITION, [&] { L.launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nullptr, mode, static_cast<float4*>(out), cur); });
-                        composed = true;
-                    } else
-                        run(KS_DENOISE_WAVELET, (uint64_t)ST_PASS_DENOISE_WAVELET_0 << nth, [&] { L.launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], nth <= 2u ? a.sl[nth & 1u] : nullptr, nth <= 1u ? a.sl[(nth & 1u) ^ 1u] : nullptr, cur); });
-                }
+                uint32_t first = 0;
+                if (fuse && fuse_wavelet) {
+                    // variance estimation + strides 1 and 2 form one launch group of two kernels: the variance pass hands its
+                    // output over in an internal pair of planes (k_denoise.hip k_denoise_wavelet_12 says why), so the stash
+                    // planes receive the stride-2 result directly. One group = one set of pass bits (st_debug_set_pass_mask).
+                    const uint64_t group = ST_PASS_DENOISE_VARIANCE | ST_PASS_DENOISE_WAVELET_0 | ((uint64_t)ST_PASS_DENOISE_WAVELET_0 << 1);
+                    float4* tmp_di = P(ST_BUF_COUNT + 2); float4* tmp_gi = P(ST_BUF_COUNT + 3);
+                    run(KS_DENOISE_VARIANCE, group, [&] { L.launch_denoise_variance(a, tmp_di, tmp_gi, cur); });
+                    run(KS_DENOISE_WAVELET_12, group, [&] { L.launch_denoise_wavelet_12(a, 1.0f, 2.0f, tmp_di, di[1], di[0], tmp_gi, gi[1], gi[0], cur); });
+                    first = 2;
+                } else run(KS_DENOISE_VARIANCE, ST_PASS_DENOISE_VARIANCE, [&] { L.launch_denoise_variance(a, a.di_diff_stash, a.gi_diff_stash, cur); });
+                for (uint32_t nth = first; nth < 5; nth++)
+                    run(KS_DENOISE_WAVELET, (uint64_t)ST_PASS_DENOISE_WAVELET_0 << nth, [&] { L.launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], cur); });
             };
             auto do_compose = [&] {
                 if (!out || composed) return;
@@ -1119,6 +1135,7 @@ struct Engine {
             if (!l.free_ev) ST_HIP(hipEventCreateWithFlags(&l.free_ev, hipEventDisableTiming));
             ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
         }
+        profile_close();
         ST_HIP(hipGetLastError());
         if (mask_split) return fail(ST_ERR_INVALID_ARGUMENT, "the pass mask splits a fused launch (st_debug_last_launches lists the launch groups)");
         return ST_OK;

@@ -17,7 +17,7 @@ enum KernelSlot {
     KS_GI_SPATIAL_SAMPLE, KS_GI_PREVIEW, KS_GI_RESOLVING, KS_DENOISE_REPROJECT, KS_DENOISE_VARIANCE, KS_DENOISE_WAVELET,
     KS_COMPOSITION,
     // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
-    KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_COMPOSE,
+    KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_12,
     KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL, KS_DI_SPATIAL_FUSED, KS_GI_SPATIAL_FUSED,
     KS_COUNT
 };
@@ -36,7 +36,7 @@ inline const KernelInfo& kernel_info(int slot) {
         {"di_resolving+denoise_reproject", 128.f + 112.f, false},
         {"gi_preview+gi_resolving", 160.f + 256.f, false},
         {"gi_preview+gi_resolving+denoise_reproject", 160.f + 256.f + 112.f, false},
-        {"denoise_wavelet+composition", 84.f + 112.f, false},
+        {"denoise_wavelet x2 (strides 1+2)", 84.f + 84.f, false},
         {"gi_reprojection+gi_temporal", 176.f + 272.f, false},
         {"di_sampling+di_temporal", 68.f + 176.f, false},
         {"di_spatial_pick+trace+sample", 128.f + 2.f * 48.f + 192.f, true},  // per cell: the trace pass covers both of its pixels

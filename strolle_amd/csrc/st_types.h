@@ -59,10 +59,6 @@ struct KArgs {
     // (à-trous, variance, preview resampling, reprojection validity) read it instead of re-running the octahedral decode
     // (a sqrt and a division per tap); the bytes per tap are the same 16. Not part of the reference's buffer set.
     float4* sn; const float4* psn;
-    // sqrt(luma) of the (direct, indirect) colours the denoiser's current input planes hold, written by the pass that
-    // produced them (variance estimation, then each wavelet pass, ping-pong) so that the 8 taps of the next pass read 8
-    // bytes instead of redoing two luma dot products and two correctly rounded square roots. Internal only.
-    float2* sl[2];
     float4 *reprojection, *velocity;
     float4* di_res[3];
     float4 *di_diff_samples, *di_diff_prev_colors, *di_diff_curr_colors, *di_diff_moments, *di_diff_stash, *di_spec_samples;

@@ -88,13 +88,76 @@ def cornell_camera(size, mode=CameraMode.IMAGE, denoise=True, depth=0) -> Camera
     return camera_for(size, (0.0, 1.0, 3.2), (0.0, 1.0, 0.0), mode, denoise, depth)  # cornell.rs:76-78
 
 
-def build_dungeon(engine, subdivide: int = 0):
-    """demo.rs:155-218 without the three emissive tori (Bevy's shape::Torus tessellation is not available here).
-    subdivide = k splits every triangle into 4^k (SYNTHETIC: k = 2 gives the ~134 k-triangle variant that stands in for
-    BASELINE.json's "~100k tris" dungeon; level.glb itself has 8,393)."""
+def bevy_torus(radius: float = 1.0, ring_radius: float = 0.5, subdivisions_segments: int = 32, subdivisions_sides: int = 24):
+    """Bevy 0.12 `Mesh::from(shape::Torus)` (bevy_render/src/mesh/shape/torus.rs; the crate is not under /root/reference, the
+    tessellation is restated from its published source): a (segments+1) x (sides+1) vertex grid — position
+    (cos t (R + r cos p), r sin p, sin t (R + r cos p)), normal = normalize(position - ring centre), uv = (segment / segments,
+    side / sides) — and two triangles per quad: (lt, rt, lb), (rt, rb, lb). Defaults: R 1, r 0.5, 32 x 24 = 1,536 triangles.
+    Returns (positions, normals, uvs) as [n, 3, *] float32 arrays in the order bevy-strolle's mesh stage builds them
+    (prepare.rs:85-113: one MeshTriangle per index triple)."""
+    f32 = np.float32
+    seg_stride = f32(2.0) * f32(math.pi) / f32(subdivisions_segments)
+    side_stride = f32(2.0) * f32(math.pi) / f32(subdivisions_sides)
+    pos, nrm, uv = [], [], []
+    for segment in range(subdivisions_segments + 1):
+        theta = f32(seg_stride * f32(segment))
+        ct, st = f32(np.cos(theta, dtype=f32)), f32(np.sin(theta, dtype=f32))
+        for side in range(subdivisions_sides + 1):
+            phi = f32(side_stride * f32(side))
+            cp, sp = f32(np.cos(phi, dtype=f32)), f32(np.sin(phi, dtype=f32))
+            ring = f32(f32(radius) + f32(f32(ring_radius) * cp))
+            p = np.array([ct * ring, f32(ring_radius) * sp, st * ring], f32)
+            c = np.array([f32(radius) * ct, 0.0, f32(radius) * st], f32)
+            d = (p - c).astype(f32)
+            n = (d * (f32(1.0) / f32(np.sqrt(np.dot(d, d).astype(f32))))).astype(f32)   # glam Vec3::normalize = v * (1 / length)
+            pos.append(p); nrm.append(n)
+            uv.append([f32(segment) / f32(subdivisions_segments), f32(side) / f32(subdivisions_sides)])
+    pos, nrm, uv = np.array(pos, f32), np.array(nrm, f32), np.array(uv, f32)
+    per_row = subdivisions_sides + 1
+    idx = []
+    for segment in range(subdivisions_segments):
+        for side in range(subdivisions_sides):
+            lt = side + segment * per_row; rt = side + 1 + segment * per_row
+            lb = side + (segment + 1) * per_row; rb = side + 1 + (segment + 1) * per_row
+            idx += [[lt, rt, lb], [rt, rb, lb]]
+    idx = np.array(idx)
+    return pos[idx], nrm[idx], uv[idx]
+
+
+def _srgb_to_linear(c: float) -> float:
+    """Bevy Color::as_linear_rgba_f32 per channel (bevy_render color: x <= 0.04045 ? x / 12.92 : ((x + 0.055) / 1.055)^2.4)."""
+    return c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4
+
+
+DUNGEON_TORI = [(-0.5, 0.33, -5.5), (-11.0, 0.33, 28.0), (-11.5, 0.33, 13.5)]   # demo.rs:195-199
+DUNGEON_DESCRIPTION = "dungeon: level.glb (8,393 triangles, 45 textured materials) + the demo's three emissive Bevy tori (3 x 1,536 triangles) = 13,001 triangles, 7 light slots"
+
+
+def build_dungeon(engine, subdivide: int = 0, tori: bool = True):
+    """demo.rs:155-218: level.glb, six point lights, the three emissive tori (`shape::Torus::default()`, scale 0.5, rotated
+    1 rad about Z; material base colour sRGB (0.9, 0.6, 0.3), emissive 10 x that, then — like every material of the scene —
+    reflectance 0 and perceptual roughness 1, demo.rs:254-258), sun below the horizon. The spot light has intensity 0 and
+    is dropped by the extract stage (extract.rs:307-311).
+    subdivide = k splits every triangle into 4^k (SYNTHETIC: k = 2 gives the ~208 k-triangle variant that stands in for
+    BASELINE.json's "~100k tris" dungeon; the demo scene itself has 13,001)."""
     npz = np.load(os.path.join(ASSETS, "dungeon.npz"))
     engine.set_blue_noise(load_blue_noise())
-    _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0), subdivide=subdivide)
+    n = _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0), subdivide=subdivide)
+    if tori:
+        pos, nrm, uv = bevy_torus()
+        if subdivide:
+            pos, nrm, uv = _subdivide(pos, nrm, uv, subdivide)
+        mesh_handle, first = 5000, 5001
+        engine.insert_mesh(mesh_handle, Mesh(pos, nrm, uv))
+        srgb = (0.9, 0.6, 0.3)
+        base = [_srgb_to_linear(c) for c in srgb] + [1.0]
+        emissive = [_srgb_to_linear(c * 10.0) for c in srgb] + [1.0]
+        c1, s1 = math.cos(1.0), math.sin(1.0)
+        for i, t in enumerate(DUNGEON_TORI):
+            engine.insert_material(first + i, Material(base_color=base, emissive=emissive, perceptual_roughness=1.0, metallic=0.0, reflectance=0.0))
+            # Transform::from_translation(t).with_rotation(Quat::from_rotation_z(1.0)).with_scale(0.5): columns of R_z(1) * 0.5, then t
+            x = np.array([[0.5 * c1, -0.5 * s1, 0.0, t[0]], [0.5 * s1, 0.5 * c1, 0.0, t[1]], [0.0, 0.0, 0.5, t[2]]], np.float32)
+            engine.insert_instance(first + i, Instance(mesh_handle, first + i, x))
     intensity = 5000.0 / (4.0 * math.pi)
     lights = [(-3.0, 0.75, -23.0), (-23.5, 0.75, -31.0), (1.25, 0.75, -10.5), (-3.15, 0.75, 1.25), (-3.25, 0.75, 20.25), (13.25, 0.75, -28.25)]
     for i, p in enumerate(lights):

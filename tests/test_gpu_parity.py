@@ -206,7 +206,7 @@ def test_errors_are_loud():
 
 
 def test_dungeon_image_mode_bit_exact():
-    """BASELINE.json config 3's scene (level.glb: 8,393 triangles, 45 textured materials): atlas sampling,
+    """BASELINE.json config 3's scene (level.glb + three tori: 13,001 triangles, 48 materials): atlas sampling,
     multi-triangle leaves, six lights through the 16-sample RIS."""
     torch = _torch()
     size = (160, 96)

@@ -5,7 +5,7 @@ import csv, sys, re
 from collections import defaultdict
 
 def short(name):
-    m = re.search(r"st::k_([a-z_0-9]+)(<[^>]*>)?", name)
+    m = re.search(r"st::(?:fast::|exact::)?k_([a-z_0-9]+)(<[^>]*>)?", name)
     if not m: return name[:40]
     return m.group(1) + (m.group(2) or "").replace("unsigned short", "u16").replace("unsigned int", "u32").replace(" ", "")
 
