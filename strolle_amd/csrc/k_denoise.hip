@@ -316,7 +316,9 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
     const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
     const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, (y + HALO) * P + x + HALO, strength1);
     di_out[center] = o.di;
-    if (o.lit) gi_out[center] = o.gi;
+    // On a sky pixel the stride-2 pass leaves its indirect output alone, and what the reference's stash plane holds there is
+    // the variance pass's copy of the input colour — which this launch group never stored there: `o.gi` is that colour.
+    gi_out[center] = o.gi;
 }
 
 // ---- a single zero-jitter pass staged through LDS (stride 4; also strides 1 and 2 when run unfused)
