@@ -149,6 +149,11 @@ int st_render_camera(StEngine* e, StHandle camera, void* out_device, void* hip_s
 enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1 };
 int st_set_bvh_refresh(StEngine* e, int mode);
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits);
+/* Depth check of the last BVH build: the longest chain of internal nodes (= the most far-child pointers one traversal can
+ * have pending) against the per-ray stack of the kernels (24 entries, strolle-gpu/src/lib.rs:76). The reference writes past
+ * its stack array when a tree is deeper; this library drops the push and says so once on stderr — a scene for which
+ * *deepest_internal_chain > *stack_entries can miss geometry behind the dropped subtrees. */
+int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* stack_entries);
 
 /* Deterministic seeds: every pass draws seed = pass_seed(base, frame, pass_id) instead of
  * rand::thread_rng() (camera_controller.rs:189-194; passes/ref_*.rs:49-59). */

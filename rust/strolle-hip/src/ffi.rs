@@ -1,0 +1,113 @@
+//! Raw bindings of include/strolle_hip.h (the C ABI of libstrolle_hip.so) and of the four HIP runtime calls the present
+//! step needs. One `extern "C"` item per entry point; the comment names the `strolle::Engine` method it stands behind
+//! (reference: strolle/src/lib.rs:132-395).
+#![allow(non_camel_case_types, dead_code)]
+use std::ffi::c_void;
+use std::os::raw::c_char;
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct StMeshTriangle {
+    pub positions: [[f32; 3]; 3],
+    pub normals: [[f32; 3]; 3],
+    pub uvs: [[f32; 2]; 3],
+    pub tangents: [[f32; 4]; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct StMaterial {
+    pub base_color: [f32; 4],
+    pub emissive: [f32; 4],
+    pub perceptual_roughness: f32,
+    pub metallic: f32,
+    pub reflectance: f32,
+    pub ior: f32,
+    pub base_color_texture: u64, // 0 = None
+    pub emissive_texture: u64,
+    pub metallic_roughness_texture: u64,
+    pub normal_map_texture: u64,
+    pub alpha_mode: u32, // 0 Opaque, 1 Blend
+    pub _pad: u32,
+}
+
+pub const ST_LIGHT_POINT: u32 = 0;
+pub const ST_LIGHT_SPOT: u32 = 1;
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct StLight {
+    pub kind: u32,
+    pub position: [f32; 3],
+    pub radius: f32,
+    pub color: [f32; 3],
+    pub range: f32,
+    pub direction: [f32; 3],
+    pub angle: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct StCamera {
+    pub mode: u32,
+    pub denoise: u32,
+    pub depth: u32,
+    pub width: u32,
+    pub height: u32,
+    pub pos_x: u32,
+    pub pos_y: u32,
+    pub _pad: u32,
+    pub transform: [f32; 16],  // glam Mat4::to_cols_array
+    pub projection: [f32; 16],
+}
+
+pub const ST_OK: i32 = 0;
+pub const ST_FORMAT_RGBA32F: i32 = 0;
+pub const ST_FORMAT_RGBA16F: i32 = 1;
+pub const ST_FORMAT_RGBA8_UNORM_SRGB: i32 = 2;
+pub const ST_FORMAT_BGRA8_UNORM_SRGB: i32 = 3;
+
+pub enum StEngine {}
+
+extern "C" {
+    pub fn st_engine_create(device_ordinal: i32, out: *mut *mut StEngine) -> i32; // Engine::new
+    pub fn st_engine_destroy(e: *mut StEngine); // Drop
+    pub fn st_last_error() -> *const c_char;
+    pub fn st_mesh_insert(e: *mut StEngine, id: u64, triangles: *const StMeshTriangle, count: usize) -> i32; // insert_mesh
+    pub fn st_mesh_remove(e: *mut StEngine, id: u64) -> i32; // remove_mesh
+    pub fn st_material_insert(e: *mut StEngine, id: u64, material: *const StMaterial) -> i32; // insert_material
+    pub fn st_material_has(e: *mut StEngine, id: u64) -> i32; // has_material
+    pub fn st_material_remove(e: *mut StEngine, id: u64) -> i32; // remove_material
+    pub fn st_image_insert_rgba8(e: *mut StEngine, id: u64, w: u32, h: u32, rgba: *const u8, srgb: i32) -> i32; // insert_image
+    pub fn st_image_insert_device_rgba8(e: *mut StEngine, id: u64, w: u32, h: u32, device_rgba: *const c_void, row_pitch: usize, is_dynamic: i32) -> i32;
+    pub fn st_image_remove(e: *mut StEngine, id: u64) -> i32; // remove_image
+    pub fn st_instance_insert(e: *mut StEngine, id: u64, mesh: u64, material: u64, xform12: *const f32) -> i32; // insert_instance
+    pub fn st_instance_remove(e: *mut StEngine, id: u64) -> i32; // remove_instance
+    pub fn st_light_insert(e: *mut StEngine, id: u64, light: *const StLight) -> i32; // insert_light
+    pub fn st_light_remove(e: *mut StEngine, id: u64) -> i32; // remove_light
+    pub fn st_sun_update(e: *mut StEngine, azimuth: f32, altitude: f32) -> i32; // update_sun
+    pub fn st_camera_create(e: *mut StEngine, camera: *const StCamera, out: *mut u64) -> i32; // create_camera
+    pub fn st_camera_update(e: *mut StEngine, camera: u64, desc: *const StCamera) -> i32; // update_camera
+    pub fn st_camera_delete(e: *mut StEngine, camera: u64) -> i32; // delete_camera
+    pub fn st_camera_set_output_format(e: *mut StEngine, camera: u64, format: i32) -> i32; // Camera::viewport.format
+    pub fn st_tick(e: *mut StEngine, hip_stream: *mut c_void) -> i32; // tick
+    pub fn st_render_camera(e: *mut StEngine, camera: u64, out_device: *mut c_void, hip_stream: *mut c_void) -> i32; // render_camera
+    pub fn st_set_seed(e: *mut StEngine, seed: u64) -> i32;
+    pub fn st_set_blue_noise(e: *mut StEngine, rgba: *const u8, bytes: usize) -> i32; // Noise::new (noise.rs:40-50)
+    pub fn st_engine_set_arithmetic(e: *mut StEngine, arithmetic: i32) -> i32;
+    pub fn st_set_bvh_refresh(e: *mut StEngine, mode: i32) -> i32;
+}
+
+// ---- the HIP runtime, as far as the staging-copy present needs it (libamdhip64)
+pub type hipStream_t = *mut c_void;
+pub const HIP_MEMCPY_DEVICE_TO_HOST: i32 = 2;
+extern "C" {
+    pub fn hipMalloc(ptr: *mut *mut c_void, bytes: usize) -> i32;
+    pub fn hipFree(ptr: *mut c_void) -> i32;
+    pub fn hipHostMalloc(ptr: *mut *mut c_void, bytes: usize, flags: u32) -> i32;
+    pub fn hipHostFree(ptr: *mut c_void) -> i32;
+    pub fn hipMemcpyAsync(dst: *mut c_void, src: *const c_void, bytes: usize, kind: i32, stream: hipStream_t) -> i32;
+    pub fn hipStreamCreate(stream: *mut hipStream_t) -> i32;
+    pub fn hipStreamDestroy(stream: hipStream_t) -> i32;
+    pub fn hipStreamSynchronize(stream: hipStream_t) -> i32;
+}

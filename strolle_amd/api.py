@@ -279,6 +279,8 @@ class _Binding:
         self.debug_world = fn("debug_world", [vp, P(u32), P(u32)])
         self.debug_image_rect = fn("debug_image_rect", [vp, u64, P(u32)])
         self.set_bvh_refresh = fn("set_bvh_refresh", [vp, i32]); self.debug_bvh_refits = fn("debug_bvh_refits", [vp, P(u64), P(u64)])
+        if has_device:
+            self.debug_bvh_depth = fn("debug_bvh_depth", [vp, P(u32), P(u32)])
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
@@ -438,6 +440,12 @@ class EngineBase:
         """(rebuilds, refits) so far."""
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self._b.debug_bvh_refits(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def bvh_depth(self):
+        """(longest chain of internal nodes in the uploaded BVH, traversal stack entries per ray)."""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(self._b.debug_bvh_depth(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def image_rect(self, handle: int):

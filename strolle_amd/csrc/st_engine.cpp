@@ -240,6 +240,12 @@ struct CameraState {
     size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
+    // The two-stream frame pipeline (render()) belongs to the camera: its side stream and the events that order frame N+1's
+    // passes behind frame N's are per camera, so cameras rendered on different caller streams never wait on — or race
+    // with — each other's frames.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
+    bool have_prev_frame_events = false;
     bool internal_dirty = false;  // st_camera_write_buffer replaced a plane the internal planes derive from: regenerate them before the next frame
 };
 static size_t plane_texels_per_pixel(int id) {
@@ -296,6 +302,36 @@ struct Engine {
     bool have_topology = false; uint64_t topology_signature = 0;
     std::vector<uint32_t> internal_positions;  // stream offsets of the internal nodes, ascending (parents before children)
     uint64_t refits = 0, rebuilds = 0;
+    // Deepest chain of internal nodes in the uploaded stream = the most entries a traversal can have pending (every internal
+    // node on the path may push its far child). The kernels' per-lane stack holds kBvhStackSize entries (strolle-gpu/src/lib.rs:76;
+    // the reference indexes past the end there, here a push beyond the end is dropped): a deeper tree is reported, not hidden.
+    uint32_t bvh_stack_need = 0; bool bvh_depth_warned = false;
+    void measure_stack_need() {
+        std::vector<uint8_t> height(bvh_stream.size() + 1, 0);  // internal nodes only; a leaf run has height 0
+        uint32_t deepest = 0;
+        for (size_t p = bvh_stream.size(); p-- > 0;) {
+            // walk backwards; an internal node starts where d0.w == 0 and the 3 texels after it are its own
+            if (p + 3 < bvh_stream.size() && f2b(bvh_stream[p].w) == 0u && is_internal_start(p)) {
+                const size_t l = p + 4, r = f2b(bvh_stream[p + 1].w);
+                const uint32_t h = 1u + std::max<uint32_t>(l < height.size() ? height[l] : 0, r < height.size() ? height[r] : 0);
+                height[p] = (uint8_t)std::min<uint32_t>(h, 255u);
+                deepest = std::max(deepest, h);
+            }
+        }
+        bvh_stack_need = deepest;
+        if (deepest > (uint32_t)kBvhStackSize && !bvh_depth_warned) {
+            bvh_depth_warned = true;
+            fprintf(stderr, "[strolle-hip] warning: the BVH is %u internal nodes deep; traversal keeps %d pending entries per ray (as the reference does) and drops deeper ones — distant geometry may be missed. st_debug_bvh_depth reports this.\n", deepest, kBvhStackSize);
+        }
+    }
+    std::vector<uint8_t> internal_start_;  // scratch of measure_stack_need: 1 where an internal node begins
+    bool is_internal_start(size_t p) const { return p < internal_start_.size() && internal_start_[p]; }
+    void mark_internal_starts() {
+        internal_start_.assign(bvh_stream.size(), 0);
+        for (size_t p = 0; p < bvh_stream.size();) {
+            if (f2b(bvh_stream[p].w) == 0u) { internal_start_[p] = 1; p += 4; } else p += 1;
+        }
+    }
 
     // images: a single linear RGBA8 atlas of the reference's extent (images.rs:28-29); rectangles from st_atlas.h
     static constexpr uint32_t kAtlasW = 8192, kAtlasMaxH = 8192;
@@ -349,9 +385,6 @@ struct Engine {
     std::vector<uint64_t> last_launches;  // pass bits of every launch the last render considered (st_debug_last_launches)
     uint64_t pass_mask = ~0ull;  // st_debug_set_pass_mask: which reference passes a render executes (parity tests run one launch at a time)
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
-    bool have_prev_frame_events = false;
     bool fuse_wavelet = true;  // ST_NO_FUSE_WAVELET=1: strides 1 and 2 of the a-trous chain as two launches
     bool fuse_spatial = true;  // ST_NO_FUSE_SPATIAL=1: DI spatial resampling as three launches
     bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
@@ -407,11 +440,17 @@ struct Engine {
         if (ev_copy) (void)hipEventDestroy(ev_copy);
         for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
-        if (side_stream) (void)hipStreamDestroy(side_stream);
-        for (hipEvent_t e : {ev_di_head, ev_gi_done, ev_prim_ok, ev_frame_done, ev_setup, ev_tick}) if (e) (void)hipEventDestroy(e);
+        if (ev_tick) (void)hipEventDestroy(ev_tick);
         staging.release();
     }
-    static void release_camera(CameraState& c) { if (c.slab) (void)hipFree(c.slab); if (c.counters) (void)hipFree(c.counters); c.slab = nullptr; c.counters = nullptr; }
+    static void release_camera(CameraState& c) {
+        if (c.slab) (void)hipFree(c.slab);
+        if (c.counters) (void)hipFree(c.counters);
+        c.slab = nullptr; c.counters = nullptr;
+        if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
+        for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        c.side_stream = nullptr; c.have_prev_frame_events = false;
+    }
 
     // ---- materials (materials.rs:33-96, material.rs:29-50)
     float4 image_rect(uint64_t h) const {
@@ -674,6 +713,7 @@ struct Engine {
                 bvh.flatten(blend, bvh_stream);
                 const auto t4 = now();
                 rebuilds++;
+                mark_internal_starts(); measure_stack_need();
                 have_topology = false;
                 if (bvh_refresh_mode == ST_BVH_REFIT) { index_stream(); topology_signature = signature; have_topology = true; }
                 if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles, %zu reused)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size(), bvh.reused_primitives());
@@ -698,7 +738,12 @@ struct Engine {
         snapshot_lights();
         if (has_device) {
             ST_HIP(hipSetDevice(device));
-            tick_work_in_flight = false; copy_in_flight = false;
+            // Uploads of an earlier tick that no render has waited for yet stay pending until their event has completed: a
+            // tick that uploads nothing must not make a later render on another stream forget them.
+            if (tick_work_in_flight && hipEventQuery(ev_tick) == hipSuccess) tick_work_in_flight = false;
+            if (copy_in_flight && hipEventQuery(ev_copy) == hipSuccess) copy_in_flight = false;
+            (void)hipGetLastError();  // hipErrorNotReady from the queries is not an error
+            bool copied_now = false;  // this tick queued copies on copy_stream
             bool pageable = false;  // some copy of this tick reads pageable host memory (or writes it): join the stream before returning
             staging.begin_tick();
             bool pageable_copy = false;
@@ -733,7 +778,7 @@ struct Engine {
                 if ((rc = t.xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), up, staging, flag))) return rc;
                 if ((rc = t.materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), up, staging, flag))) return rc;
                 if ((rc = t.base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), up, staging, flag))) return rc;
-                if (other_copy) copy_in_flight = true;
+                if (other_copy) copied_now = true;
                 live = target;
                 scene_uploaded = true;
                 scene_changed = !other_copy;  // in-place uploads count as work on the caller's stream below
@@ -774,9 +819,10 @@ struct Engine {
                 if (rc) return rc;
                 live_lights = target; lights_uploaded = true;
                 uploaded_lights = gpu_lights;
-                if (other_copy) copy_in_flight = true; else uploaded = true;
+                if (other_copy) copied_now = true; else uploaded = true;
             }
-            if (copy_in_flight) {
+            if (copied_now) {
+                copy_in_flight = true;
                 ST_HIP(hipEventRecord(ev_copy, copy_stream));
                 ST_HIP(hipStreamWaitEvent(stream, ev_copy, 0));  // the caller's stream: the next frame's kernels (and the staging slot's event) come after the copies
             }
@@ -824,7 +870,11 @@ struct Engine {
         c.slab_bytes = total;
         size_t off = 0;
         for (int i = 0; i < ST_BUF_COUNT + kInternalPlanes; i++) { c.plane[i] = reinterpret_cast<float4*>(static_cast<char*>(c.slab) + off); off += (c.plane_bytes[i] + 255) & ~size_t(255); }
-        ST_HIP(hipMalloc(reinterpret_cast<void**>(&c.counters), kCounterBytes));
+        if (hipMalloc(reinterpret_cast<void**>(&c.counters), kCounterBytes) != hipSuccess) {
+            (void)hipGetLastError(); c.counters = nullptr;
+            release_camera(c);  // do not leak the slab
+            return fail(ST_ERR_HIP, "hipMalloc(camera counters) failed");
+        }
         ST_HIP(hipMemset(c.counters, 0, kCounterBytes));
         memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
         ST_HIP(hipDeviceSynchronize());  // the clears run on the null stream; renders may use any stream
@@ -1074,40 +1124,40 @@ struct Engine {
                 //   DI tail(N+1)   after DI head(N+1)     (and after frame N's composition by stream order: its scratch aliases
                 //                                          the denoiser's planes)
                 //   denoiser(N+1)  after GI tail(N+1)
-                if (!side_stream) {
-                    ST_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-                    for (hipEvent_t* e : {&ev_di_head, &ev_gi_done, &ev_prim_ok, &ev_frame_done, &ev_setup}) ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+                if (!c.side_stream) {
+                    ST_HIP(hipStreamCreateWithFlags(&c.side_stream, hipStreamNonBlocking));
+                    for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
                 }
                 // LUT generation issued on `stream` in this call must precede the side stream's consumers. (Do NOT do this
                 // unconditionally: an event recorded on `stream` here completes only after frame N's denoiser, which would
                 // serialise prim(N+1) behind it. Uploads in st_tick are followed by a host-side stream sync.)
-                if (luts_generated_now) { ST_HIP(hipEventRecord(ev_setup, stream)); ST_HIP(hipStreamWaitEvent(side_stream, ev_setup, 0)); }
+                if (luts_generated_now) { ST_HIP(hipEventRecord(c.ev_setup, stream)); ST_HIP(hipStreamWaitEvent(c.side_stream, c.ev_setup, 0)); }
                 // copies st_tick queued without joining the stream (staged uploads, dynamic images): they sit behind frame N on
                 // the tick's stream, so a frame that follows a scene change gives up the prim(N+1) / denoiser(N) overlap
-                if (tick_work_in_flight) ST_HIP(hipStreamWaitEvent(side_stream, ev_tick, 0));
-                if (copy_in_flight) ST_HIP(hipStreamWaitEvent(side_stream, ev_copy, 0));  // independent of frame N: the overlap stays
-                if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_prim_ok, 0));
-                cur = side_stream;
+                if (tick_work_in_flight) ST_HIP(hipStreamWaitEvent(c.side_stream, ev_tick, 0));
+                if (copy_in_flight) ST_HIP(hipStreamWaitEvent(c.side_stream, ev_copy, 0));  // independent of frame N: the overlap stays
+                if (c.have_prev_frame_events) ST_HIP(hipStreamWaitEvent(c.side_stream, c.ev_prim_ok, 0));
+                cur = c.side_stream;
                 do_prim();
                 do_di_head();
-                ST_HIP(hipEventRecord(ev_di_head, side_stream));  // primary visibility + DI head of this frame are through
+                ST_HIP(hipEventRecord(c.ev_di_head, c.side_stream));  // primary visibility + DI head of this frame are through
                 do_gi_head();
-                if (have_prev_frame_events) ST_HIP(hipStreamWaitEvent(side_stream, ev_frame_done, 0));
+                if (c.have_prev_frame_events) ST_HIP(hipStreamWaitEvent(c.side_stream, c.ev_frame_done, 0));
                 do_gi_tail();
-                ST_HIP(hipEventRecord(ev_gi_done, side_stream));
+                ST_HIP(hipEventRecord(c.ev_gi_done, c.side_stream));
                 cur = stream;
-                ST_HIP(hipStreamWaitEvent(stream, ev_di_head, 0));
+                ST_HIP(hipStreamWaitEvent(stream, c.ev_di_head, 0));
                 do_di_tail();
                 // stand-alone denoise reprojection kernels (unfused path) still read the reprojection map: prim(N+1) may
                 // only start once they are through
                 const bool reproject_later = denoise && !fuse;
-                if (!reproject_later) ST_HIP(hipEventRecord(ev_prim_ok, stream));
-                ST_HIP(hipStreamWaitEvent(stream, ev_gi_done, 0));
+                if (!reproject_later) ST_HIP(hipEventRecord(c.ev_prim_ok, stream));
+                ST_HIP(hipStreamWaitEvent(stream, c.ev_gi_done, 0));
                 do_denoise();
-                if (reproject_later) ST_HIP(hipEventRecord(ev_prim_ok, stream));
+                if (reproject_later) ST_HIP(hipEventRecord(c.ev_prim_ok, stream));
                 do_compose();
-                ST_HIP(hipEventRecord(ev_frame_done, stream));
-                have_prev_frame_events = true;
+                ST_HIP(hipEventRecord(c.ev_frame_done, stream));
+                c.have_prev_frame_events = true;
             } else {
                 do_prim();
                 if (any_objects) {
@@ -1116,7 +1166,7 @@ struct Engine {
                 }
                 do_denoise();
                 do_compose();
-                if (side_stream) { ST_HIP(hipEventRecord(ev_prim_ok, stream)); ST_HIP(hipEventRecord(ev_frame_done, stream)); }
+                if (c.side_stream) { ST_HIP(hipEventRecord(c.ev_prim_ok, stream)); ST_HIP(hipEventRecord(c.ev_frame_done, stream)); }
             }
         }
         if (out && !composed) {
@@ -1326,7 +1376,7 @@ int st_camera_update(StEngine* e, StHandle h, const StCamera* c) {
     s.desc = *c;
     s.prev = s.curr;
     s.curr = Engine::serialize_camera(*c);
-    if (invalidated) { if (en->has_device) (void)hipDeviceSynchronize(); return en->allocate_camera(s); }  // camera.rs:17-48: buffers are rebuilt
+    if (invalidated) { if (en->has_device) { ST_HIP(hipSetDevice(en->device)); ST_HIP(hipDeviceSynchronize()); } return en->allocate_camera(s); }  // camera.rs:17-48: buffers are rebuilt
     return ST_OK;
 }
 int st_camera_delete(StEngine* e, StHandle h) {
@@ -1334,7 +1384,7 @@ int st_camera_delete(StEngine* e, StHandle h) {
     Engine* en = E(e);
     auto it = en->cameras.find(h);
     if (it == en->cameras.end()) return ST_OK;
-    if (en->has_device) { (void)hipDeviceSynchronize(); Engine::release_camera(*it->second); }
+    if (en->has_device) { ST_HIP(hipSetDevice(en->device)); ST_HIP(hipDeviceSynchronize()); Engine::release_camera(*it->second); }
     en->cameras.erase(it);
     return ST_OK;
 }
@@ -1486,6 +1536,11 @@ int st_set_bvh_refresh(StEngine* e, int mode) {
     ST_REQUIRE(mode == ST_BVH_REBUILD || mode == ST_BVH_REFIT, "unknown refresh mode");
     Engine* en = E(e);
     if (en->bvh_refresh_mode != mode) { en->bvh_refresh_mode = mode; en->have_topology = false; }
+    return ST_OK;
+}
+int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* stack_entries) {
+    ST_REQUIRE(e && deepest_internal_chain && stack_entries, "null argument");
+    *deepest_internal_chain = E(e)->bvh_stack_need; *stack_entries = (uint32_t)kBvhStackSize;
     return ST_OK;
 }
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits) {

@@ -30,6 +30,30 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_rust_facade_binds_exported_symbols():
+    """rust/strolle-hip (the Rust facade a maintainer builds outside this box; no rustc here): every `st_*` function its
+    `extern "C"` block declares is exported by the library and declared in the header, its `#[repr(C)]` structs list the
+    header's fields in the header's order, and `Engine` offers every public method of the reference's engine
+    (strolle/src/lib.rs:132-395)."""
+    rust = os.path.join(ROOT, "rust", "strolle-hip", "src")
+    ffi = open(os.path.join(rust, "ffi.rs")).read()
+    bound = sorted(set(re.findall(r"pub fn (st_[a-z0-9_]+)\(", ffi)))
+    assert len(bound) >= 25
+    lib, declared = load_library(), set(declared_symbols())
+    assert not [s for s in bound if not hasattr(lib, s)] and not [s for s in bound if s not in declared]
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "strolle_hip.h")).read(), flags=re.S)
+    for name in ("StMeshTriangle", "StMaterial", "StLight", "StCamera"):
+        c_body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
+        c_fields = [f.strip().split("[")[0] for decl in c_body.split(";") if decl.strip() for f in decl.strip().split(" ", 1)[1].split(",")]
+        r_body = re.search(r"pub struct %s \{(.*?)\n\}" % name, ffi, re.S).group(1)
+        r_fields = re.findall(r"pub (\w+):", r_body)
+        assert r_fields == c_fields, (name, r_fields, c_fields)
+    engine = open(os.path.join(rust, "lib.rs")).read()
+    methods = ["new", "insert_mesh", "remove_mesh", "insert_material", "has_material", "remove_material", "insert_image", "remove_image", "insert_instance",
+               "remove_instance", "insert_light", "remove_light", "update_sun", "create_camera", "update_camera", "render_camera", "delete_camera", "tick"]
+    assert not [m for m in methods if not re.search(r"pub fn %s\b" % m, engine)]
+
+
 def test_struct_sizes_match_header():
     from strolle_amd import api
     assert (C.sizeof(api.StMeshTriangle), C.sizeof(api.StMaterial), C.sizeof(api.StLight), C.sizeof(api.StCamera)) == (144, 88, 52, 160)
