@@ -252,6 +252,20 @@ void or_probe_camera_ray(const ApiCamera* c, uint32_t x, uint32_t y, float* out6
     Ray r = s.serialize().ray(UVec2(x, y));
     out6[0] = r.origin.x; out6[1] = r.origin.y; out6[2] = r.origin.z; out6[3] = r.dir.x; out6[4] = r.dir.y; out6[5] = r.dir.z;
 }
+// glam 0.24.2 routines the path depends on (the crate is not under /root/reference), for the float32 numpy cross-check in
+// tests/test_oracle_layouts.py: op 0 Mat4::inverse (16 -> 16), 1 Vec3::any_orthonormal_pair (3 -> 6), 2 Mat4::project_point3
+// (16 + 3 -> 3), 3 Affine3A::inverse (12 -> 12), 4 Mat4 * Mat4 (16 + 16 -> 16), 5 Vec3::normalize (3 -> 3)
+void or_probe_glam(int op, const float* in, float* out) {
+    switch (op) {
+        case 0: { Mat4 r = inverse(Mat4::from_cols_array(in)); std::memcpy(out, &r, 64); break; }
+        case 1: { Vec3 t, b; any_orthonormal_pair(Vec3(in[0], in[1], in[2]), &t, &b); out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = b.x; out[4] = b.y; out[5] = b.z; break; }
+        case 2: { Vec3 r = project_point3(Mat4::from_cols_array(in), Vec3(in[16], in[17], in[18])); out[0] = r.x; out[1] = r.y; out[2] = r.z; break; }
+        case 3: { Affine3 r = inverse(Affine3::from_12(in)); const Vec3 c[4] = {r.x_axis, r.y_axis, r.z_axis, r.translation}; for (int i = 0; i < 4; i++) { out[3 * i] = c[i].x; out[3 * i + 1] = c[i].y; out[3 * i + 2] = c[i].z; } break; }
+        case 4: { Mat4 r = mul(Mat4::from_cols_array(in), Mat4::from_cols_array(in + 16)); std::memcpy(out, &r, 64); break; }
+        case 5: { Vec3 r = normalize(Vec3(in[0], in[1], in[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; break; }
+        default: break;
+    }
+}
 int or_num_threads(void) {
     int n = 1;
 #ifdef _OPENMP

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle_binding import oracle_lib
+from strolle_amd import look_at_transform, perspective_infinite_reverse_rh
 
 
 def test_camera_contain_known_answers():
@@ -109,3 +110,100 @@ def test_pow_accuracy_on_the_paths_domain():
         want = np.power(x.astype(np.float64), float(np.float32(y)))
         rel = np.abs(out - want) / np.maximum(want, 1e-30)
         assert np.all((rel < 2e-5) | (want < 1e-30)), (y, float(rel.max()))
+
+
+# ---------------------------------------------------------------------------------------------- glam 0.24.2 cross-check
+# glam is a crates.io dependency (Cargo.lock: 0.24.2) that is not under /root/reference. Its scalar-path routines are
+# restated twice, independently: in C++ (oracle/or_math.h, and again in the product's st_math.h / st_engine.cpp) and below
+# in numpy float32, both from the crate's published source order. The two must agree bit for bit; a slip in the operation
+# order of either (which term is subtracted first, where the reciprocal is taken) shows up here.
+F = np.float32
+
+
+def _glam_mat4_inverse(m):   # m[col][row]; glam-0.24.2/src/f32/scalar/mat4.rs `inverse`
+    (m00, m01, m02, m03), (m10, m11, m12, m13), (m20, m21, m22, m23), (m30, m31, m32, m33) = [[F(v) for v in col] for col in m]
+    c00 = m22 * m33 - m32 * m23; c02 = m12 * m33 - m32 * m13; c03 = m12 * m23 - m22 * m13
+    c04 = m21 * m33 - m31 * m23; c06 = m11 * m33 - m31 * m13; c07 = m11 * m23 - m21 * m13
+    c08 = m21 * m32 - m31 * m22; c10 = m11 * m32 - m31 * m12; c11 = m11 * m22 - m21 * m12
+    c12 = m20 * m33 - m30 * m23; c14 = m10 * m33 - m30 * m13; c15 = m10 * m23 - m20 * m13
+    c16 = m20 * m32 - m30 * m22; c18 = m10 * m32 - m30 * m12; c19 = m10 * m22 - m20 * m12
+    c20 = m20 * m31 - m30 * m21; c22 = m10 * m31 - m30 * m11; c23 = m10 * m21 - m20 * m11
+    v = lambda *a: np.array(a, F)
+    fac0, fac1, fac2 = v(c00, c00, c02, c03), v(c04, c04, c06, c07), v(c08, c08, c10, c11)
+    fac3, fac4, fac5 = v(c12, c12, c14, c15), v(c16, c16, c18, c19), v(c20, c20, c22, c23)
+    vec0, vec1, vec2, vec3 = v(m10, m00, m00, m00), v(m11, m01, m01, m01), v(m12, m02, m02, m02), v(m13, m03, m03, m03)
+    inv0 = (vec1 * fac0 - vec2 * fac1) + vec3 * fac2
+    inv1 = (vec0 * fac0 - vec2 * fac3) + vec3 * fac4
+    inv2 = (vec0 * fac1 - vec1 * fac3) + vec3 * fac5
+    inv3 = (vec0 * fac2 - vec1 * fac4) + vec2 * fac5
+    sign_a, sign_b = v(1, -1, 1, -1), v(-1, 1, -1, 1)
+    inv = [inv0 * sign_a, inv1 * sign_b, inv2 * sign_a, inv3 * sign_b]
+    col0 = v(inv[0][0], inv[1][0], inv[2][0], inv[3][0])
+    dot0 = v(m00, m01, m02, m03) * col0
+    dot1 = ((dot0[0] + dot0[1]) + dot0[2]) + dot0[3]
+    rcp = F(1.0) / dot1
+    return np.array([c * rcp for c in inv], F)
+
+
+def _glam_any_orthonormal_pair(n):   # glam-0.24.2/src/f32/vec3.rs `any_orthonormal_pair`
+    x, y, z = [F(c) for c in n]
+    sign = F(np.copysign(F(1.0), z))
+    a = F(-1.0) / (sign + z)
+    b = x * y * a
+    return np.array([F(1.0) + sign * x * x * a, sign * b, -sign * x, b, sign + y * y * a, -y], F)
+
+
+def _glam_project_point3(m, p):   # glam-0.24.2/src/f32/scalar/mat4.rs `project_point3`
+    cols = [np.array(c, F) for c in m]
+    res = cols[0] * F(p[0])
+    res = cols[1] * F(p[1]) + res
+    res = cols[2] * F(p[2]) + res
+    res = cols[3] + res
+    res = res * (F(1.0) / res[3])
+    return res[:3]
+
+
+def _cross(a, b):
+    return np.array([a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]], F)
+
+
+def _dot3(a, b):
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+
+
+def _glam_affine_inverse(a12):   # Mat3A::inverse + Affine3A::inverse (glam-0.24.2/src/f32/affine3a.rs, scalar Mat3A)
+    x, y, z, t = [np.array(a12[3 * i:3 * i + 3], F) for i in range(4)]
+    tmp0, tmp1, tmp2 = _cross(y, z), _cross(z, x), _cross(x, y)
+    inv_det = F(1.0) / _dot3(z, tmp2)
+    c0, c1, c2 = tmp0 * inv_det, tmp1 * inv_det, tmp2 * inv_det
+    rx, ry, rz = np.array([c0[0], c1[0], c2[0]], F), np.array([c0[1], c1[1], c2[1]], F), np.array([c0[2], c1[2], c2[2]], F)
+    m = rx * t[0]; m = m + ry * t[1]; m = m + rz * t[2]
+    return np.concatenate([rx, ry, rz, -m]).astype(F)
+
+
+def _probe_glam(op, values, n_out):
+    lib = oracle_lib()
+    lib.or_probe_glam.restype = None
+    lib.or_probe_glam.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    src = np.ascontiguousarray(values, F); out = np.zeros(n_out, F)
+    lib.or_probe_glam(op, src.ctypes.data, out.ctypes.data)
+    return out
+
+
+def test_glam_restatements_agree_bitwise_with_a_numpy_float32_restatement():
+    rng = np.random.default_rng(3)
+    with np.errstate(all="ignore"):
+        for trial in range(300):
+            m = rng.normal(size=(4, 4)).astype(F)
+            if trial % 3 == 0:   # camera-like matrices: rigid transform, and an infinite-reverse perspective
+                m = look_at_transform(rng.uniform(-3, 3, 3), rng.uniform(-1, 1, 3)).T.copy() if trial % 2 else perspective_infinite_reverse_rh(0.7 + trial * 1e-3, 16 / 9, 0.1).T.copy()
+            got = _probe_glam(0, m.reshape(-1), 16).reshape(4, 4)
+            assert np.array_equal(got.view(np.uint32), _glam_mat4_inverse(m).view(np.uint32)), ("Mat4::inverse", trial)
+            n = rng.normal(size=3); n = (n / np.linalg.norm(n)).astype(F)
+            if trial % 50 == 0:
+                n = np.array([0.0, 0.0, -1.0 if trial % 100 else 1.0], F)
+            assert np.array_equal(_probe_glam(1, n, 6).view(np.uint32), _glam_any_orthonormal_pair(n).view(np.uint32)), ("any_orthonormal_pair", trial)
+            p = rng.normal(size=3).astype(F)
+            assert np.array_equal(_probe_glam(2, np.concatenate([m.reshape(-1), p]), 3).view(np.uint32), _glam_project_point3(m, p).view(np.uint32)), ("project_point3", trial)
+            a = rng.normal(size=12).astype(F)
+            assert np.array_equal(_probe_glam(3, a, 12).view(np.uint32), _glam_affine_inverse(a).view(np.uint32)), ("Affine3A::inverse", trial)

@@ -1,0 +1,237 @@
+//! tools/reference_dump (from the strolle-hip repository): renders a scene file with the REAL Strolle — patched by
+//! strolle_deterministic_dump.patch for reproducible seeds and buffer read-back — and writes every per-camera buffer to
+//! disk, so that the CPU oracle of the HIP port can be compared with the reference itself.
+//!
+//!   STROLLE_SEED=0 cargo run --release -p strolle --example dump_cornell -- scene.bin out_dir [width height]
+//!
+//! Runs (each on a fresh engine, so frame numbers start at 1 as in the port's tests):
+//!   heatmap    CameraMode::BvhHeatmap, 1 frame                      -> REF_COLORS
+//!   reference  CameraMode::Reference { depth: 1 }, frames 1..=4    -> REF_HITS, REF_RAYS, REF_COLORS after frames 1 and 4
+//!   image      CameraMode::Image { denoise: true }, frames 1..=7   -> every buffer after every frame
+//! Output: <out_dir>/<run>_f<frame>_<BUFFER>.bin (raw little-endian bytes) and <out_dir>/manifest.txt with one line per
+//! file: `run frame buffer width height bytes`. tools/reference_dump/README.md says what to do with them.
+//!
+//! Instances are inserted one per tick: the reference bakes dirty instances in HashMap iteration order
+//! (strolle/src/instances.rs:80), which would make triangle ids — and with them the BVH — differ from run to run; one dirty
+//! instance per refresh gives insertion order, which is what the port and its oracle use.
+use std::fmt::Write as _;
+use std::future::Future;
+use std::pin::Pin;
+use std::rc::Rc;
+use std::task::{Context, Poll, RawWaker, RawWakerVTable, Waker};
+use std::{env, fs};
+
+use strolle as st;
+use strolle::glam::{uvec2, vec2, vec3, vec4, Affine3A, Mat3A, Mat4, Vec3};
+
+#[derive(Debug)]
+struct Handles;
+
+impl st::Params for Handles {
+    type ImageHandle = u32;
+    type ImageTexture = Rc<wgpu::Texture>;
+    type InstanceHandle = u32;
+    type LightHandle = u32;
+    type MaterialHandle = u32;
+    type MeshHandle = u32;
+}
+
+/// wgpu's native futures complete without being woken; this polls one to completion.
+fn block_on<F: Future>(mut fut: F) -> F::Output {
+    fn raw() -> RawWaker {
+        fn no_op(_: *const ()) {}
+        fn clone(_: *const ()) -> RawWaker {
+            raw()
+        }
+        static VTABLE: RawWakerVTable = RawWakerVTable::new(clone, no_op, no_op, no_op);
+        RawWaker::new(std::ptr::null(), &VTABLE)
+    }
+    let waker = unsafe { Waker::from_raw(raw()) };
+    let mut cx = Context::from_waker(&waker);
+    let mut fut = unsafe { Pin::new_unchecked(&mut fut) };
+    loop {
+        if let Poll::Ready(v) = fut.as_mut().poll(&mut cx) {
+            return v;
+        }
+        std::thread::yield_now();
+    }
+}
+
+/// scene.bin as written by tools/reference_dump/export_scene.py
+struct Reader<'a> {
+    bytes: &'a [u8],
+    at: usize,
+}
+
+impl Reader<'_> {
+    fn u32(&mut self) -> u32 {
+        let v = u32::from_le_bytes(self.bytes[self.at..self.at + 4].try_into().unwrap());
+        self.at += 4;
+        v
+    }
+    fn f32(&mut self) -> f32 {
+        f32::from_bits(self.u32())
+    }
+    fn vec3(&mut self) -> Vec3 {
+        vec3(self.f32(), self.f32(), self.f32())
+    }
+    fn floats<const N: usize>(&mut self) -> [f32; N] {
+        let mut out = [0.0; N];
+        for v in out.iter_mut() {
+            *v = self.f32();
+        }
+        out
+    }
+}
+
+struct Scene {
+    materials: Vec<st::Material<Handles>>,
+    instances: Vec<(u32, Affine3A, Vec<st::MeshTriangle>)>,
+    lights: Vec<st::Light>,
+    sun: st::Sun,
+    transform: Mat4,
+    projection: Mat4,
+}
+
+fn load_scene(path: &str) -> Scene {
+    let bytes = fs::read(path).expect("scene file");
+    let mut r = Reader { bytes: &bytes, at: 0 };
+    assert_eq!(r.u32(), u32::from_le_bytes(*b"STSC"), "not a scene file");
+    assert_eq!(r.u32(), 1, "scene file version");
+    let mut materials = Vec::new();
+    for _ in 0..r.u32() {
+        let f: [f32; 12] = r.floats();
+        materials.push(st::Material {
+            base_color: vec4(f[0], f[1], f[2], f[3]),
+            emissive: vec4(f[4], f[5], f[6], f[7]),
+            perceptual_roughness: f[8],
+            metallic: f[9],
+            reflectance: f[10],
+            ior: f[11],
+            ..Default::default()
+        });
+    }
+    let mut instances = Vec::new();
+    for _ in 0..r.u32() {
+        let material = r.u32();
+        let n = r.u32();
+        let x: [f32; 12] = r.floats();
+        let xform = Affine3A::from_mat3_translation(
+            Mat3A::from_cols(vec3(x[0], x[1], x[2]).into(), vec3(x[3], x[4], x[5]).into(), vec3(x[6], x[7], x[8]).into()).into(),
+            vec3(x[9], x[10], x[11]),
+        );
+        let mut triangles = Vec::with_capacity(n as usize);
+        for _ in 0..n {
+            let p = [r.vec3(), r.vec3(), r.vec3()];
+            let nrm = [r.vec3(), r.vec3(), r.vec3()];
+            let uv = [vec2(r.f32(), r.f32()), vec2(r.f32(), r.f32()), vec2(r.f32(), r.f32())];
+            triangles.push(st::MeshTriangle::default().with_positions(p).with_normals(nrm).with_uvs(uv));
+        }
+        instances.push((material, xform, triangles));
+    }
+    let mut lights = Vec::new();
+    for _ in 0..r.u32() {
+        let position = r.vec3();
+        let radius = r.f32();
+        let color = r.vec3();
+        let range = r.f32();
+        lights.push(st::Light::Point { position, radius, color, range });
+    }
+    let sun = st::Sun { azimuth: r.f32(), altitude: r.f32() };
+    let transform = Mat4::from_cols_array(&r.floats::<16>());
+    let projection = Mat4::from_cols_array(&r.floats::<16>());
+    Scene { materials, instances, lights, sun, transform, projection }
+}
+
+fn main() {
+    let args: Vec<String> = env::args().collect();
+    assert!(args.len() >= 3, "usage: dump_cornell scene.bin out_dir [width height]");
+    let scene = load_scene(&args[1]);
+    let out_dir = &args[2];
+    let width: u32 = args.get(3).map(|s| s.parse().unwrap()).unwrap_or(64);
+    let height: u32 = args.get(4).map(|s| s.parse().unwrap()).unwrap_or(48);
+    fs::create_dir_all(out_dir).unwrap();
+
+    let instance = wgpu::Instance::default();
+    let adapter = block_on(instance.request_adapter(&wgpu::RequestAdapterOptions::default())).expect("no wgpu adapter");
+    // what bevy-strolle asks Bevy's renderer for (push constants for pass parameters, Rgba32Float storage textures)
+    let (device, queue) = block_on(adapter.request_device(
+        &wgpu::DeviceDescriptor {
+            label: Some("dump_cornell"),
+            features: wgpu::Features::PUSH_CONSTANTS | wgpu::Features::TEXTURE_ADAPTER_SPECIFIC_FORMAT_FEATURES | wgpu::Features::FLOAT32_FILTERABLE,
+            limits: wgpu::Limits { max_push_constant_size: 128, max_storage_buffers_per_shader_stage: 16, max_storage_textures_per_shader_stage: 16, ..Default::default() },
+        },
+        None,
+    ))
+    .expect("no wgpu device");
+
+    let format = wgpu::TextureFormat::Rgba8UnormSrgb;
+    let target = device.create_texture(&wgpu::TextureDescriptor {
+        label: Some("dump_target"),
+        size: wgpu::Extent3d { width, height, depth_or_array_layers: 1 },
+        mip_level_count: 1,
+        sample_count: 1,
+        dimension: wgpu::TextureDimension::D2,
+        format,
+        usage: wgpu::TextureUsages::RENDER_ATTACHMENT | wgpu::TextureUsages::COPY_SRC,
+        view_formats: &[],
+    });
+    let view = target.create_view(&Default::default());
+    let mut manifest = String::new();
+
+    let runs: [(&str, st::CameraMode, u32, &[u32]); 3] = [
+        ("heatmap", st::CameraMode::BvhHeatmap, 1, &[1]),
+        ("reference", st::CameraMode::Reference { depth: 1 }, 4, &[1, 4]),
+        ("image", st::CameraMode::Image { denoise: true }, 7, &[1, 2, 3, 4, 5, 6, 7]),
+    ];
+    for (run, mode, frames, dump_at) in runs {
+        let mut engine = st::Engine::<Handles>::new(&device);
+        for (i, m) in scene.materials.iter().enumerate() {
+            engine.insert_material(1 + i as u32, m.clone());
+        }
+        for (i, l) in scene.lights.iter().enumerate() {
+            engine.insert_light(1 + i as u32, l.clone());
+        }
+        engine.update_sun(scene.sun);
+        for (i, (material, xform, triangles)) in scene.instances.iter().enumerate() {
+            let h = 1 + i as u32;
+            engine.insert_mesh(h, st::Mesh::new(triangles.clone()));
+            engine.insert_instance(h, st::Instance::new(h, 1 + *material, *xform));
+            engine.tick(&device, &queue); // one dirty instance per refresh: insertion order (see the module comment)
+        }
+        // the ticks above advanced the frame counter; a fresh camera starts from the engine's current frame, so the run's
+        // first rendered frame is `first_frame` — recorded in the manifest for the loader
+        let camera = st::Camera {
+            mode,
+            viewport: st::CameraViewport { format, size: uvec2(width, height), position: uvec2(0, 0) },
+            transform: scene.transform,
+            projection: scene.projection,
+        };
+        let handle = engine.create_camera(&device, camera.clone());
+        for frame in 1..=frames {
+            engine.update_camera(&device, handle, camera.clone());
+            engine.tick(&device, &queue);
+            let mut encoder = device.create_command_encoder(&Default::default());
+            engine.render_camera(handle, &mut encoder, &view);
+            queue.submit([encoder.finish()]);
+            device.poll(wgpu::Maintain::Wait);
+            if !dump_at.contains(&frame) {
+                continue;
+            }
+            for (name, bytes) in engine.dump_camera_buffers(&device, &queue, handle) {
+                let relevant = match run {
+                    "heatmap" => name == "REF_COLORS",
+                    "reference" => name.starts_with("REF_"),
+                    _ => true,
+                };
+                if !relevant {
+                    continue;
+                }
+                fs::write(format!("{out_dir}/{run}_f{frame}_{name}.bin"), &bytes).unwrap();
+                writeln!(manifest, "{run} {frame} {name} {width} {height} {} instances_ticked={}", bytes.len(), scene.instances.len()).unwrap();
+            }
+        }
+    }
+    fs::write(format!("{out_dir}/manifest.txt"), manifest).unwrap();
+    println!("wrote {out_dir}/manifest.txt");
+}
