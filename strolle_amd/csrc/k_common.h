@@ -51,7 +51,7 @@ constexpr uint32_t kLdsSceneNodes = 256, kLdsSceneTris = 64;  // 4 KiB + 3 KiB o
 inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len <= kLdsSceneNodes && a.tri_slots <= kLdsSceneTris; }
 // first statement of a tracing kernel whose parameter is `a_in`: defines `a`, the arguments the body uses
 #define ST_SCENE_PROLOGUE                                                                                                        \
-    __shared__ float4 s_scene_bvh_[LDS_SCENE ? kLdsSceneNodes : 1];                                                              \
+    __shared__ float4 s_scene_bvh_[LDS_SCENE ? kLdsSceneNodes + 3 : 1];  /* + 3: traverse() reads four texels at every node pointer */                                                              \
     __shared__ float4 s_scene_tri_[LDS_SCENE ? 3 * kLdsSceneTris : 1];                                                           \
     KArgs a = a_in;                                                                                                              \
     if (LDS_SCENE) {                                                                                                             \

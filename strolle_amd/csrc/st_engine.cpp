@@ -271,7 +271,7 @@ static int read_counters(const CameraState& c, unsigned long long* host /* 2*KS_
     return ST_OK;
 }
 
-struct ProfileRecord { int slot; hipEvent_t start, stop; double bytes; uint32_t launches; };
+struct ProfileRecord { int slot; hipEvent_t start, stop; double bytes; uint32_t launches; bool owns_start; };
 
 struct Light112 { GpuLight g; };
 
@@ -293,7 +293,7 @@ struct Engine {
     std::vector<float4> instance_xforms; std::vector<uint32_t> xslot_free;
     std::map<uint64_t, std::pair<size_t, size_t>> instance_triangles; SlotRanges triangle_free;
     std::vector<HostTriangle> triangles; std::vector<BuildPrim> prims; std::vector<uint8_t> prim_alive;
-    std::vector<float4> tri_geo, tri_attr, bvh_stream;
+    std::vector<float4> tri_geo, tri_attr, bvh_stream, bvh_upload_;
     BvhBuild bvh;
     bool scene_uploaded = false;
     // BVH refresh policy (st_set_bvh_refresh). Refit: while the set of (triangle slot, material) pairs and the Blend flags
@@ -438,7 +438,7 @@ struct Engine {
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (ev_copy) (void)hipEventDestroy(ev_copy);
-        for (auto& r : profile_records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+        for (auto& r : profile_records) { if (r.owns_start) (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
         if (ev_tick) (void)hipEventDestroy(ev_tick);
         staging.release();
@@ -764,7 +764,11 @@ struct Engine {
                     if (sets[target].busy) { ST_HIP(hipStreamWaitEvent(copy_stream, sets[target].free_ev, 0)); sets[target].busy = false; }
                 } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
                 SceneSet& t = sets[target];
-                if ((rc = t.bvh.upload(bvh_stream.data(), bvh_stream.size() * sizeof(float4), up, staging, flag))) return rc;
+                // the device copy carries three texels of padding: traversal fetches four texels at every node pointer
+                // (st_device.h traverse), also at the stream's last leaf entries
+                bvh_upload_.assign(bvh_stream.begin(), bvh_stream.end());
+                bvh_upload_.insert(bvh_upload_.end(), 3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                if ((rc = t.bvh.upload(bvh_upload_.data(), bvh_upload_.size() * sizeof(float4), up, staging, flag))) return rc;
                 // triangle arrays: whole the first time or after they grew, otherwise only the slots baked since this copy was written
                 const bool partial = t.valid && !t.tri_full && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4) && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
                 if (!partial) {
@@ -889,21 +893,24 @@ struct Engine {
     // One event pair per RUN of consecutive launches of the same slot on the same stream (the five a-trous launches, say):
     // an event between two kernels makes the second wait for a barrier packet, which adds microseconds to every launch
     // it brackets, so back-to-back launches of one slot are timed as one interval and divided by their count.
-    struct OpenScope { int slot = -1; hipStream_t stream = nullptr; hipEvent_t start{}; double bytes = 0; uint32_t launches = 0; } open_scope;
+    // Consecutive runs on one stream share the event between them (the stop of one is the start of the next).
+    struct OpenScope { int slot = -1; hipStream_t stream = nullptr; hipEvent_t start{}; bool owns_start = true; double bytes = 0; uint32_t launches = 0; } open_scope;
     void profile_begin(int slot, hipStream_t s, double bytes) {
         if (!profiling) return;
         if (open_scope.slot == slot && open_scope.stream == s) { open_scope.bytes += bytes; open_scope.launches += 1; return; }
-        profile_close();
+        const bool chained = open_scope.slot >= 0 && open_scope.stream == s;
+        hipEvent_t boundary = profile_close();
         open_scope.slot = slot; open_scope.stream = s; open_scope.bytes = bytes; open_scope.launches = 1;
-        open_scope.start = take_event();
-        (void)hipEventRecord(open_scope.start, s);
+        if (chained) { open_scope.start = boundary; open_scope.owns_start = false; }
+        else { open_scope.start = take_event(); open_scope.owns_start = true; (void)hipEventRecord(open_scope.start, s); }
     }
-    void profile_close() {
-        if (open_scope.slot < 0) return;
+    hipEvent_t profile_close() {
+        if (open_scope.slot < 0) return nullptr;
         hipEvent_t stop = take_event();
         (void)hipEventRecord(stop, open_scope.stream);
-        profile_records.push_back({open_scope.slot, open_scope.start, stop, open_scope.bytes, open_scope.launches});
+        profile_records.push_back({open_scope.slot, open_scope.start, stop, open_scope.bytes, open_scope.launches, open_scope.owns_start});
         open_scope.slot = -1;
+        return stop;
     }
     int drain_profile() {
         for (auto& r : profile_records) {
@@ -911,7 +918,8 @@ struct Engine {
             float ms = 0.0f;
             ST_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
             profile_totals[r.slot].launches += r.launches; profile_totals[r.slot].total_ms += ms; profile_totals[r.slot].algorithmic_bytes += r.bytes;
-            event_pool.push_back(r.start); event_pool.push_back(r.stop);
+            if (r.owns_start) event_pool.push_back(r.start);
+            event_pool.push_back(r.stop);
         }
         profile_records.clear();
         return ST_OK;
