@@ -6,8 +6,10 @@
 // swap-to-back partition, breadth-first processing) and strolle/src/bvh/serializer.rs (DFS pre-order,
 // internal = 4 float4 holding both children's bounds + right pointer, leaf entry = 1 float4).
 // Implementation notes: iterative builder over an index-free primitive array, subtrees built concurrently for large
-// scenes (the result does not depend on the schedule); subtree reuse by hash (builder.rs:205-301) is not implemented —
-// every refresh is a fresh build.
+// scenes (the result does not depend on the schedule). A refresh reuses unchanged subtrees of the previous tree the way
+// builder.rs:183-301 does — an order-sensitive hash of each child's primitives, taken while partitioning, is compared with
+// the previous tree's child and a match copies the subtree — with one guarantee added: the refreshed tree is the tree a
+// from-scratch build of the same primitives gives (BvhBuild::begin_refresh / run, below).
 #pragma once
 #include <atomic>
 #include <condition_variable>
