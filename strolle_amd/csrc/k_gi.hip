@@ -369,16 +369,24 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
     const uint32_t n = a.width * a.height;
     const uint32_t center_idx = screen_to_idx(a, center_pos);
     WhiteNoise wn = white_noise(seed, center_pos);
-    const Hit center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
+    // The pixel's Hit (camera ray + both G-buffer texels decoded) is needed by a neighbour tap and by resolving; whether the
+    // pixel has a surface at all is the first G-buffer texel's depth. Once a reservoir's m has reached 8 — which temporal
+    // resampling does within a few frames — `max_samples` is 0 and the first preview pass is a normalised copy: it then reads
+    // one G-buffer texel instead of two and skips the ray reconstruction.
+    const float4 center_g0 = tex_read(a.g0, a, center_pos);
+    const bool center_some = center_g0.x != 0.0f;  // GBufferEntry::depth (gbuffer.rs:60) == Hit::is_some
+    Hit center_hit = hit_zero();
+    if (RESOLVE) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
     GiReservoir main_ = gi_empty();
     ReprojectHistory history;  // fetched ahead of the resampling loop (st_passes.h)
     if (RESOLVE && reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
     bool keep_stored = false;  // the reference's early `return`: the output slot keeps its previous contents
-    if (hit_some(center_hit)) {
+    if (center_some) {
         float main_pdf = 0.0f;
         const GiReservoir center = gi_read(in, center_idx, n);
         if (res_merge(main_, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
         const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main_.m * 0.125f));
+        if (!RESOLVE && max_samples > 0u) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
         const float max_radius = nth == 0u ? 128.0f : 64.0f;
         uint32_t sample_nth = 0u;
         while (sample_nth < max_samples) {

@@ -266,6 +266,18 @@ def test_every_instance_moving_at_pool_size_equals_oracle(refit):
     assert prod.bvh_refits() == orac.bvh_refits() == ((1, 3) if refit else (4, 0))
 
 
+def test_bvh_depth_is_reported():
+    """st_debug_bvh_depth: the longest chain of internal nodes against the 24-entry traversal stack (strolle-gpu/src/lib.rs:76).
+    The Cornell box and the demo dungeon fit; the synthetic 208 k-triangle dungeon is deeper than the stack, which the library
+    says instead of silently dropping pushes."""
+    for build, fits in ((scenes.build_cornell, True), (scenes.build_dungeon, True), (lambda e: scenes.build_dungeon(e, subdivide=2), False)):
+        e = Engine(device=-1)
+        build(e); e.tick()
+        depth, stack = e.bvh_depth()
+        assert stack == 24 and depth >= 5
+        assert (depth <= stack) == fits, (depth, stack)
+
+
 def test_atlas_rectangles_are_released_and_reused():
     """images.rs:54-113: an image that is removed, or comes back with another size, gives its rectangle back. Rectangles of
     live images never overlap, stay inside the 8192 x 8192 atlas, and churn far beyond the atlas area never runs out of

@@ -500,6 +500,37 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
     assert_bits_equal(np.load(dump), frame.cpu().numpy(), "strong-scaling two-band frame vs single-process frame")
 
 
+def test_two_cameras_on_two_streams_bit_exact():
+    """Two cameras of one engine, rendered back to back on DIFFERENT caller streams without host synchronisation in between:
+    each camera's frame pipeline (side stream + cross-frame events) is its own, so neither waits on nor races with the other's
+    frames, and both stay bit-identical to the oracle's two cameras."""
+    torch = _torch()
+    prod, orac = Engine(device=0, exact=True), OracleEngine()
+    for e in (prod, orac):
+        scenes.build_cornell(e); e.set_seed(31)
+    sizes = [(160, 96), (136, 120)]
+    descs = [scenes.cornell_camera(sizes[0], CameraMode.IMAGE), scenes.camera_for(sizes[1], (0.4, 1.2, 3.0), (0.0, 0.9, 0.0))]
+    cps = [prod.create_camera(d) for d in descs]; cos = [orac.create_camera(d) for d in descs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.zeros((s[1], s[0], 4), dtype=torch.float32, device="cuda:0") for s in sizes]
+    refs = [None, None]
+    torch.cuda.synchronize()
+    for frame in range(9):
+        for k in range(2):
+            prod.update_camera(cps[k], descs[k]); orac.update_camera(cos[k], descs[k])
+        prod.tick(streams[0].cuda_stream); orac.tick()
+        for k in range(2):
+            prod.render_camera(cps[k], outs[k].data_ptr(), streams[k].cuda_stream)
+        for k in range(2):
+            refs[k] = orac.render_camera(cos[k])
+        if frame in (3, 8):
+            torch.cuda.synchronize()
+            for k in range(2):
+                _compare_all(prod, orac, cps[k], cos[k], frame)
+                assert_bits_equal(outs[k].cpu().numpy(), refs[k], f"camera {k} frame {frame}")
+    prod.close(); orac.close()
+
+
 def test_moving_instances_velocity_bit_exact():
     """An instance re-inserted with a new transform every frame: primary visibility derives the surface point's previous
     position from the owning instance's transforms (prev_xform * curr_xform_inv * point, prim_raster.rs:21-27), the BVH is

@@ -65,6 +65,42 @@ __global__ void calib_near64(const float4* buf, uint32_t width, uint32_t height,
     }
     sink(acc, out);
 }
+// One 64-B record per lane (a GI reservoir: buf[4 * id + k], k = 0..3), read and written the way gi_read / gi_write do it —
+// four loads / stores whose lanes are 64 B apart — against the same bytes moved as four fully coalesced 1-KB rows per wave
+// (what a 4x4 lane-quad transpose would turn the accesses into).
+__global__ void calib_aos64_strided(const float4* in, float4* out, size_t records) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= records) return;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = in[4 * i + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k].x += 1.0f; out[4 * i + k] = v[k]; }
+}
+__global__ void calib_aos64_coalesced(const float4* in, float4* out, size_t records) {
+    const size_t wave_base = ((size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) * 4;   // first texel of this wave's 64 records
+    const uint32_t lane = threadIdx.x & 63u;
+    if (wave_base / 4 + 64 > records) return;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = in[wave_base + (size_t)k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k].x += 1.0f; out[wave_base + (size_t)k * 64 + lane] = v[k]; }
+}
+// the same bytes with the accesses of each lane quad transposed (instruction k moves record k of every quad: 64 contiguous
+// bytes per quad) and of each group of 8 lanes (instruction k moves texels 8k..8k+7 of the group's 32: 128 contiguous bytes)
+template <int GROUP>
+__global__ void calib_aos64_grouped(const float4* in, float4* out, size_t records) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= records) return;
+    const size_t base = (i / GROUP) * GROUP * 4;   // first texel of the group's records
+    const uint32_t l = (uint32_t)(i % GROUP);
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = in[base + (size_t)k * GROUP + l];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k].x += 1.0f; out[base + (size_t)k * GROUP + l] = v[k]; }
+}
 __global__ void calib_write16(float4* buf, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) buf[i] = make_float4(1.0f, 2.0f, 3.0f, (float)(i & 1023u));
@@ -90,6 +126,16 @@ int main() {
         // a different 1080p-sized window of the buffer per repetition, so nothing is warm in the Infinity Cache
         hipLaunchKernelGGL(calib_near64, dim3(1920 * 1080 / 256), dim3(256), 0, 0, buf + (size_t)rep * 1920 * 1080 * 4 * 2, 1920u, 1080u, (uint32_t)rep * 7919u, out);
         hipLaunchKernelGGL(calib_write16, dim3(blocks), dim3(256), 0, 0, buf + (size_t)(rep + 8) * lanes, (size_t)lanes);
+        {   // 1080p worth of 64-B records, source and destination 1 GiB apart, a fresh window per repetition
+            const size_t records = 1920 * 1080;   // 8.3 M texels per kernel; three windows of 16.6 M texels fit in each 67 M-texel half
+            const float4* src = buf + (size_t)(rep % 3) * records * 4 * 2;
+            float4* dst = buf + (texels / 2) + (size_t)(rep % 3) * records * 4 * 2;
+            if ((size_t)(rep % 3 + 1) * records * 8 > texels / 2) { fprintf(stderr, "window out of range\n"); return 1; }
+            hipLaunchKernelGGL(calib_aos64_strided, dim3(records / 256), dim3(256), 0, 0, src, dst, records);
+            hipLaunchKernelGGL(calib_aos64_coalesced, dim3(records / 256), dim3(256), 0, 0, src + records * 4, dst + records * 4, records);
+            hipLaunchKernelGGL(calib_aos64_grouped<4>, dim3(records / 256), dim3(256), 0, 0, src, dst + records * 4, records);
+            hipLaunchKernelGGL(calib_aos64_grouped<8>, dim3(records / 256), dim3(256), 0, 0, src + records * 4, dst, records);
+        }
         CHECK(hipDeviceSynchronize());
     }
     printf("calib_stream16 %llu 0\n", (unsigned long long)lanes * 16ull);
@@ -98,5 +144,7 @@ int main() {
     printf("calib_gather<4> %llu 0\n", (unsigned long long)lanes * 64ull);
     printf("calib_near64 %llu 0\n", (unsigned long long)1920 * 1080 * 64ull);
     printf("calib_write16 0 %llu\n", (unsigned long long)lanes * 16ull);
+    printf("calib_aos64_strided %llu %llu\n", (unsigned long long)1920 * 1080 * 64ull, (unsigned long long)1920 * 1080 * 64ull);
+    printf("calib_aos64_coalesced %llu %llu\n", (unsigned long long)1920 * 1080 * 64ull, (unsigned long long)1920 * 1080 * 64ull);
     return 0;
 }
