@@ -13,12 +13,15 @@ __global__ ST_KERNEL_BOUNDS void k_gi_reprojection(const KArgs a) {
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const uint32_t n = a.width * a.height;
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
-    if (!hit_some(hit)) return;
-    const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, pos));
-    GiReservoir res = rp.confidence > 0.0f ? gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n) : gi_empty();
-    res.confidence = 1.0f;
-    res.s.v1_point = hit.point;
-    gi_write(a.gi_res[2], screen_to_idx(a, pos), res);
+    const bool some = hit_some(hit);
+    GiReservoir res = gi_empty();
+    if (some) {
+        const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, pos));
+        if (rp.confidence > 0.0f) res = gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n);
+        res.confidence = 1.0f;
+        res.s.v1_point = hit.point;
+    }
+    gi_write_own(a.gi_res[2], screen_to_idx(a, pos), res, true, some);  // a pixel without a surface leaves its slot alone
 }
 void launch_gi_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_gi_reprojection, false, s, a); }
 
@@ -164,54 +167,60 @@ __global__ ST_KERNEL_BOUNDS void k_gi_temporal(const KArgs a, uint32_t seed) {
     const float4* prev_res = a.gi_res[2];
     WhiteNoise wn = white_noise(seed, lhs_pos);
     const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
-    if (!hit_some(lhs_hit)) { gi_write(curr_res, lhs_idx, gi_empty()); return; }
+    // The pixel's own reservoirs are streamed with the quad-transposed accessors (st_device.h), which want the whole lane quad
+    // at every call: a pixel without a surface therefore runs along with `some == false` instead of leaving early.
+    const bool some = hit_some(lhs_hit);
     const bool tracing = frame_is_gi_tracing(a.frame);
     const bool got_sample = tracing ? (a.frame % 2u == 0u && got_checkerboard_at(lhs_pos, a.frame / 2u)) : got_checkerboard_at(lhs_pos, a.frame);
-    const GiReservoir lhs = got_sample ? gi_read(curr_res, lhs_idx, n) : gi_empty();
-    GiReservoir rhs = gi_empty();
-    Hit rhs_hit = hit_zero();
+    const GiReservoir lhs = gi_read_own(curr_res, lhs_idx, true, some && got_sample);
     const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, lhs_pos));
-    if (REPROJECT) {  // gi_reprojection.rs:3-51 (this pixel has a hit: the early-outs above are the same)
-        GiReservoir res = rp.confidence > 0.0f ? gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n) : gi_empty();
+    const bool reprojected = some && rp.confidence > 0.0f;
+    GiReservoir rhs = gi_empty();
+    if (REPROJECT) {  // gi_reprojection.rs:3-51 for this pixel
+        GiReservoir res = reprojected ? gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n) : gi_empty();
         res.confidence = 1.0f;
         res.s.v1_point = lhs_hit.point;
-        gi_write(a.gi_res[2], lhs_idx, res);
-        if (rp.confidence > 0.0f) rhs = gi_after_store(res);
-    }
-    if (rp.confidence > 0.0f) {
-        if (!REPROJECT) rhs = gi_read(prev_res, lhs_idx, n);
-        rhs.confidence = 1.0f;
-        rhs.m = fmin_(rhs.m, 128.0f);
-        if (!tracing && lhs.m != 0.0f && rhs.m != 0.0f && gi_exists(rhs.s)) {
-            if (distance(lhs.s.radiance, rhs.s.radiance) > 0.33f) rhs.confidence = 0.0f;
-            rhs.s.radiance = lhs.s.radiance;
-            rhs.s.v2_point = lhs.s.v2_point;
-            rhs.s.v2_normal = lhs.s.v2_normal;
-        }
-        if (rhs.m != 0.0f) rhs_hit = pixel_hit(a, a.prev_cam, a.pg0, a.pg1, reprojection_prev_round(rp));
+        gi_write_own(a.gi_res[2], lhs_idx, res, true, some);
+        if (reprojected) rhs = gi_after_store(res);
+    } else {
+        rhs = gi_read_own(prev_res, lhs_idx, true, reprojected);
     }
     GiReservoir main_ = gi_empty();
-    float main_pdf = 0.0f;
-    if (tracing) {
-        Mis mis;
-        mis.lhs_rhs_pdf = ((lhs.m > 0.0f) & hit_some(rhs_hit)) ? gi_pdf(lhs.s, rhs_hit) : 0.0f;
-        mis.rhs_lhs_pdf = (rhs.m > 0.0f) ? gi_pdf(rhs.s, lhs_hit) : 0.0f;
-        mis.lhs_m = lhs.m; mis.rhs_m = rhs.m; mis.rhs_jacobian = 1.0f; mis.lhs_lhs_pdf = lhs.s.pdf; mis.rhs_rhs_pdf = rhs.s.pdf;
-        const MisResult mr = mis_eval(mis);
-        if (res_update(main_, wn, lhs.s, mr.lhs_mis * mr.lhs_pdf * lhs.w)) main_pdf = mr.lhs_pdf;
-        if (res_update(main_, wn, rhs.s, mr.rhs_mis * mr.rhs_pdf * rhs.w)) main_pdf = mr.rhs_pdf;
-        main_.m = lhs.m + mr.m;
-        main_.confidence = 1.0f;
-        res_norm(main_, main_pdf, 1.0f, 1.0f);
-    } else {
-        if (res_merge(main_, wn, rhs, rhs.s.pdf)) main_pdf = rhs.s.pdf;
-        main_.confidence = rhs.confidence;
-        res_norm(main_, main_pdf, 1.0f, main_.m);
+    if (some) {
+        Hit rhs_hit = hit_zero();
+        if (reprojected) {
+            rhs.confidence = 1.0f;
+            rhs.m = fmin_(rhs.m, 128.0f);
+            if (!tracing && lhs.m != 0.0f && rhs.m != 0.0f && gi_exists(rhs.s)) {
+                if (distance(lhs.s.radiance, rhs.s.radiance) > 0.33f) rhs.confidence = 0.0f;
+                rhs.s.radiance = lhs.s.radiance;
+                rhs.s.v2_point = lhs.s.v2_point;
+                rhs.s.v2_normal = lhs.s.v2_normal;
+            }
+            if (rhs.m != 0.0f) rhs_hit = pixel_hit(a, a.prev_cam, a.pg0, a.pg1, reprojection_prev_round(rp));
+        } else rhs = gi_empty();
+        float main_pdf = 0.0f;
+        if (tracing) {
+            Mis mis;
+            mis.lhs_rhs_pdf = ((lhs.m > 0.0f) & hit_some(rhs_hit)) ? gi_pdf(lhs.s, rhs_hit) : 0.0f;
+            mis.rhs_lhs_pdf = (rhs.m > 0.0f) ? gi_pdf(rhs.s, lhs_hit) : 0.0f;
+            mis.lhs_m = lhs.m; mis.rhs_m = rhs.m; mis.rhs_jacobian = 1.0f; mis.lhs_lhs_pdf = lhs.s.pdf; mis.rhs_rhs_pdf = rhs.s.pdf;
+            const MisResult mr = mis_eval(mis);
+            if (res_update(main_, wn, lhs.s, mr.lhs_mis * mr.lhs_pdf * lhs.w)) main_pdf = mr.lhs_pdf;
+            if (res_update(main_, wn, rhs.s, mr.rhs_mis * mr.rhs_pdf * rhs.w)) main_pdf = mr.rhs_pdf;
+            main_.m = lhs.m + mr.m;
+            main_.confidence = 1.0f;
+            res_norm(main_, main_pdf, 1.0f, 1.0f);
+        } else {
+            if (res_merge(main_, wn, rhs, rhs.s.pdf)) main_pdf = rhs.s.pdf;
+            main_.confidence = rhs.confidence;
+            res_norm(main_, main_pdf, 1.0f, main_.m);
+        }
+        main_.s.pdf = main_pdf;
+        main_.s.v1_point = lhs_hit.point;
+        main_.w = fmin_(main_.w, 5.0f);
     }
-    main_.s.pdf = main_pdf;
-    main_.s.v1_point = lhs_hit.point;
-    main_.w = fmin_(main_.w, 5.0f);
-    gi_write(curr_res, lhs_idx, main_);
+    gi_write_own(curr_res, lhs_idx, main_, true, true);  // an empty reservoir where the pixel has no surface (gi_temporal_resampling.rs:30-33)
 }
 void launch_gi_temporal(const KArgs& a, uint32_t seed, bool fuse_reprojection, hipStream_t s) {
     if (fuse_reprojection) ST_LAUNCH(k_gi_temporal<true>, false, s, a, seed); else ST_LAUNCH(k_gi_temporal<false>, false, s, a, seed);
@@ -381,9 +390,9 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
     ReprojectHistory history;  // fetched ahead of the resampling loop (st_passes.h)
     if (RESOLVE && reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
     bool keep_stored = false;  // the reference's early `return`: the output slot keeps its previous contents
+    const GiReservoir center = gi_read_own(in, center_idx, true, center_some);  // quad-transposed (st_device.h): before the branch
     if (center_some) {
         float main_pdf = 0.0f;
-        const GiReservoir center = gi_read(in, center_idx, n);
         if (res_merge(main_, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
         const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main_.m * 0.125f));
         if (!RESOLVE && max_samples > 0u) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
@@ -415,7 +424,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
         }
     }
     if (!RESOLVE) {
-        if (!keep_stored) gi_write(out, center_idx, main_);
+        gi_write_own(out, center_idx, main_, true, !keep_stored);
         return;
     }
     if (keep_stored) main_ = gi_read(out, center_idx, n);

@@ -60,8 +60,7 @@ __global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a_in, uint32_t depth)
     count_rays(a.ray_counter, used_);
     float4 h0, h1;
     hit_pack(hit, &h0, &h1);
-    a.ref_hits[2u * idx] = h0;
-    a.ref_hits[2u * idx + 1u] = h1;
+    rec2_write_own(a.ref_hits, idx, h0, h1, true, true);  // quad-transposed 32-B records (st_device.h)
 }
 void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s) { ST_LAUNCH_TRACE(k_ref_tracing, false, s, a, depth); }
 
@@ -89,7 +88,9 @@ __global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, 
         color = xyz(d2);
         throughput = v3(d0.w, d1.w, d2.w);
     }
-    const TriangleHit t_hit = hit_unpack(a.ref_hits[2u * idx], a.ref_hits[2u * idx + 1u]);
+    float4 h0, h1;
+    rec2_read_own(a.ref_hits, idx, true, true, &h0, &h1);
+    const TriangleHit t_hit = hit_unpack(h0, h1);
     if (!hit_is_some(t_hit)) {
         color = color + throughput * atmosphere_sample(a, ray.dir);
         a.ref_rays[3u * idx] = f4z();
