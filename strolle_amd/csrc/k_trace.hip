@@ -88,9 +88,8 @@ __global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, 
         color = xyz(d2);
         throughput = v3(d0.w, d1.w, d2.w);
     }
-    float4 h0, h1;
-    rec2_read_own(a.ref_hits, idx, true, true, &h0, &h1);
-    const TriangleHit t_hit = hit_unpack(h0, h1);
+    const Rec2 packed_hit = rec2_read_own(a.ref_hits, idx, true, true);
+    const TriangleHit t_hit = hit_unpack(packed_hit.d0, packed_hit.d1);
     if (!hit_is_some(t_hit)) {
         color = color + throughput * atmosphere_sample(a, ray.dir);
         a.ref_rays[3u * idx] = f4z();

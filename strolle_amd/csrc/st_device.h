@@ -829,6 +829,8 @@ ST_D GiReservoir gi_after_store(GiReservoir r) { r.s.v2_normal = normal_decode(n
 // (image edges, divergent callers), so they are safe anywhere and fast where the quad is convergent.
 ST_D bool quad_all(bool p) { const unsigned long long b = __ballot(p); return ((b >> (threadIdx.x & 60u)) & 0xFull) == 0xFull; }
 ST_D bool quad_any(bool p) { const unsigned long long b = __ballot(p); return ((b >> (threadIdx.x & 60u)) & 0xFull) != 0ull; }
+// component-wise select (`c ? a : b` on the vector class can be lowered as a select of two stack addresses -> scratch)
+ST_D float4 sel4(bool c, float4 a, float4 b) { return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
 template <int CTRL>
 ST_D float4 quad_dpp(float4 v) {
     float4 r;
@@ -842,11 +844,11 @@ ST_D float4 quad_dpp(float4 v) {
 ST_D void quad_transpose(float4& v0, float4& v1, float4& v2, float4& v3) {
     const bool b0 = (threadIdx.x & 1u) != 0u, b1 = (threadIdx.x & 2u) != 0u;
     {   // lanes j and j ^ 1 (quad_perm [1,0,3,2] = 0xB1): 2x2 blocks of rows (0,1) and (2,3)
-        const float4 ra = quad_dpp<0xB1>(b0 ? v0 : v1), rb = quad_dpp<0xB1>(b0 ? v2 : v3);
+        const float4 ra = quad_dpp<0xB1>(sel4(b0, v0, v1)), rb = quad_dpp<0xB1>(sel4(b0, v2, v3));
         if (b0) { v0 = ra; v2 = rb; } else { v1 = ra; v3 = rb; }
     }
     {   // lanes j and j ^ 2 (quad_perm [2,3,0,1] = 0x4E): rows (0,2) and (1,3)
-        const float4 ra = quad_dpp<0x4E>(b1 ? v0 : v2), rb = quad_dpp<0x4E>(b1 ? v1 : v3);
+        const float4 ra = quad_dpp<0x4E>(sel4(b1, v0, v2)), rb = quad_dpp<0x4E>(sel4(b1, v1, v3));
         if (b1) { v0 = ra; v1 = rb; } else { v2 = ra; v3 = rb; }
     }
 }
@@ -885,24 +887,25 @@ ST_D void gi_write_own(float4* buf, uint32_t id, const GiReservoir& r, bool vali
 }
 // The same for 32-B records (two float4: a DI reservoir, a path tracer hit): the quad's four records are eight consecutive
 // texels; instruction k moves texels 4k..4k+3 (64 contiguous bytes per quad), and lane j wants texels 2j and 2j+1 = lanes
-// (2j mod 4), (2j+1 mod 4) of instruction j / 2 — two quad_perm moves per register and a select. Returns false (and zeros)
-// for a lane that does not want its record.
-ST_D bool rec2_read_own(const float4* buf, uint32_t id, bool valid, bool want, float4* d0, float4* d1) {
+// (2j mod 4), (2j+1 mod 4) of instruction j / 2 — two quad_perm moves per register and a select. `ok` is false (and the
+// texels zero) for a lane that does not want its record. (Returned by value: output pointers ended up in scratch memory.)
+struct Rec2 { float4 d0, d1; bool ok; };
+ST_D Rec2 rec2_read_own(const float4* buf, uint32_t id, bool valid, bool want) {
     want = want && valid;
-    *d0 = f4z(); *d1 = f4z();
+    Rec2 r; r.d0 = f4z(); r.d1 = f4z(); r.ok = false;
     if (quad_all(valid)) {
-        if (!quad_any(want)) return false;
+        if (!quad_any(want)) return r;
         const uint32_t j = threadIdx.x & 3u, first = id - j;
         const float4 v0 = buf[2u * first + j], v1 = buf[2u * first + 4u + j];
         const bool hi = j >= 2u;
         const float4 e0 = quad_dpp<0x88>(v0), e1 = quad_dpp<0x88>(v1);  // quad_perm [0,2,0,2]
         const float4 o0 = quad_dpp<0xDD>(v0), o1 = quad_dpp<0xDD>(v1);  // quad_perm [1,3,1,3]
-        if (want) { *d0 = hi ? e1 : e0; *d1 = hi ? o1 : o0; }
-        return want;
+        if (want) { r.d0 = sel4(hi, e1, e0); r.d1 = sel4(hi, o1, o0); r.ok = true; }
+        return r;
     }
-    if (!want) return false;
-    *d0 = buf[2u * id]; *d1 = buf[2u * id + 1u];
-    return true;
+    if (!want) return r;
+    r.d0 = buf[2u * id]; r.d1 = buf[2u * id + 1u]; r.ok = true;
+    return r;
 }
 ST_D void rec2_write_own(float4* buf, uint32_t id, float4 d0, float4 d1, bool valid, bool want) {
     want = want && valid;
@@ -913,16 +916,16 @@ ST_D void rec2_write_own(float4* buf, uint32_t id, float4 d0, float4 d1, bool va
         const bool odd = (j & 1u) != 0u;
         const float4 a0 = quad_dpp<0x50>(d0), a1 = quad_dpp<0x50>(d1);  // quad_perm [0,0,1,1]
         const float4 b0 = quad_dpp<0xFA>(d0), b1 = quad_dpp<0xFA>(d1);  // quad_perm [2,2,3,3]
-        buf[2u * first + j] = odd ? a1 : a0;
-        buf[2u * first + 4u + j] = odd ? b1 : b0;
+        buf[2u * first + j] = sel4(odd, a1, a0);
+        buf[2u * first + 4u + j] = sel4(odd, b1, b0);
         return;
     }
     if (!want) return;
     buf[2u * id] = d0; buf[2u * id + 1u] = d1;
 }
-// (Measured and not used for the DI reservoirs: with these accessors di_resolving took 126 instead of 101 us and DI sampling +
-// temporal 103 instead of 92 — their 32-B records are half-line accesses already and both kernels are bound by VALU issue,
-// which the ballots and DPP moves add to. The 64-B GI reservoirs gain 25 %.)
+// (Measured and not used for the DI reservoirs: same-box A/B of the Cornell frame 1.062 ms with these accessors in DI
+// resolving and DI sampling + temporal against 1.053 ms without — 32-B records are half-line accesses already, and both
+// kernels are bound by VALU issue, to which the ballots and DPP moves add. The 64-B GI reservoirs gain 25 %.)
 ST_D bool gi_exists(const GiSample& s) { return !is_zero(s.v2_point); }
 ST_D V3 gi_dir(const GiSample& s, V3 p) { return normalize(s.v2_point - p); }
 ST_D float gi_cosine(const GiSample& s, const Hit& hit) { return fmax_(dot(gi_dir(s, hit.point), hit.g.normal), 0.0f); }
