@@ -42,35 +42,34 @@ ST_D bool resolve_gid(const KArgs& a, bool half_x, U2* gid) {
 ST_D bool owns_pixel(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.height && p.y >= a.row0 && p.y < a.row1; }
 
 // Tracing kernels are instantiated three ways; the scene picks one at launch:
-//   <true,  uint16_t>  the whole BVH stream and the hit-test triangle records fit in LDS (Cornell: 124 + 96 float4): every
-//                      block copies them in once and traversal reads ds_read_b128 instead of going through the vector L1
-//                      (dependent node fetches are the traversal's latency chain; measured -21 % on the shadow-ray pass)
-//   <false, uint16_t>  BVH stream shorter than 65,536 float4: 16-bit stack entries
+//   <true,  uint16_t>  the whole device BVH stream fits in LDS (Cornell: 55 entries = 220 float4): every block copies it in
+//                      once and traversal reads ds_read_b128 instead of going through the vector L1 (dependent entry
+//                      fetches are the traversal's latency chain; measured -21 % on the shadow-ray pass)
+//   <false, uint16_t>  fewer than 65,536 entries (stack slots hold entry numbers = texel pointer / 4): 16-bit stack entries
 //   <false, uint32_t>  anything larger
-constexpr uint32_t kLdsSceneNodes = 256, kLdsSceneTris = 64;  // 4 KiB + 3 KiB of LDS per block
-inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len <= kLdsSceneNodes && a.tri_slots <= kLdsSceneTris; }
+constexpr uint32_t kLdsSceneTexels = 448;  // 7 KiB of LDS per block: 112 entries, e.g. 56 one-triangle leaves + 55 internal nodes
+constexpr uint32_t kStack16Texels = 4u * 65536u;
+inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len <= kLdsSceneTexels; }
 // first statement of a tracing kernel whose parameter is `a_in`: defines `a`, the arguments the body uses
 #define ST_SCENE_PROLOGUE                                                                                                        \
-    __shared__ float4 s_scene_bvh_[LDS_SCENE ? kLdsSceneNodes + 3 : 1];  /* + 3: traverse() reads four texels at every node pointer */                                                              \
-    __shared__ float4 s_scene_tri_[LDS_SCENE ? 3 * kLdsSceneTris : 1];                                                           \
+    __shared__ float4 s_scene_bvh_[LDS_SCENE ? kLdsSceneTexels : 1];                                                             \
     KArgs a = a_in;                                                                                                              \
     if (LDS_SCENE) {                                                                                                             \
         for (uint32_t i_ = threadIdx.x; i_ < a_in.bvh_len; i_ += kBlockThreads) s_scene_bvh_[i_] = a_in.bvh[i_];                 \
-        for (uint32_t i_ = threadIdx.x; i_ < 3u * a_in.tri_slots; i_ += kBlockThreads) s_scene_tri_[i_] = a_in.tri_geo[i_];      \
         __syncthreads();                                                                                                         \
-        a.bvh = s_scene_bvh_; a.tri_geo = s_scene_tri_;                                                                          \
+        a.bvh = s_scene_bvh_;                                                                                                    \
     }
 #define ST_LAUNCH_TRACE(kernel_tmpl, half, stream, ...)                                                             \
     do {                                                                                                            \
         if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL2(kernel_tmpl, true, uint16_t), half, stream, __VA_ARGS__);          \
-        else if (a.bvh_len < 65536u) ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint16_t), half, stream, __VA_ARGS__);   \
+        else if (a.bvh_len < kStack16Texels) ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint16_t), half, stream, __VA_ARGS__);   \
         else ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint32_t), half, stream, __VA_ARGS__);                           \
     } while (0)
 // the same for kernels with one more leading bool (REPROJECT)
 #define ST_LAUNCH_TRACE_B(kernel_tmpl, flag, half, stream, ...)                                                         \
     do {                                                                                                                \
         if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL3(kernel_tmpl, true, flag, uint16_t), half, stream, __VA_ARGS__);        \
-        else if (a.bvh_len < 65536u) ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint16_t), half, stream, __VA_ARGS__); \
+        else if (a.bvh_len < kStack16Texels) ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint16_t), half, stream, __VA_ARGS__); \
         else ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint32_t), half, stream, __VA_ARGS__);                         \
     } while (0)
 #define ST_TPL(k, t) k<t>

@@ -325,7 +325,7 @@ void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* bu
     const uint32_t groups_x = (d.tiles_x + 3u) / 4u, n_groups = d.blocks;
     if (!n_groups) return;
     const uint32_t blocks = (n_groups + kGroupsPerBlock - 1u) / kGroupsPerBlock;
-    if (a.bvh_len < 65536u) hipLaunchKernelGGL(k_spatial_trace_compact<uint16_t>, dim3(blocks), dim3(kBlockThreads), 0, s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
+    if (a.bvh_len < kStack16Texels) hipLaunchKernelGGL(k_spatial_trace_compact<uint16_t>, dim3(blocks), dim3(kBlockThreads), 0, s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
     else hipLaunchKernelGGL(k_spatial_trace_compact<uint32_t>, dim3(blocks), dim3(kBlockThreads), 0, s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
 }
 

@@ -324,6 +324,33 @@ struct Engine {
             fprintf(stderr, "[strolle-hip] warning: the BVH is %u internal nodes deep; traversal keeps %d pending entries per ray (as the reference does) and drops deeper ones — distant geometry may be missed. st_debug_bvh_depth reports this.\n", deepest, kBvhStackSize);
         }
     }
+    // Device form of the stream (st_types.h "device BVH stream"): every entry four texels — an internal node as the
+    // serializer wrote it (far pointer remapped), a leaf entry followed by its triangle's hit-test record — so that one
+    // four-texel fetch serves a traversal step of either kind. Entry k starts at texel 4 k.
+    std::vector<uint32_t> expand_map_;  // scratch: offset in bvh_stream -> texel pointer in bvh_upload_ (entry starts only)
+    uint32_t device_bvh_len = 0;
+    void expand_stream() {
+        const size_t n = bvh_stream.size();
+        expand_map_.resize(n);
+        size_t entries = 0;
+        for (size_t p = 0; p < n; p += f2b(bvh_stream[p].w) == 0u ? 4 : 1) expand_map_[p] = (uint32_t)(4 * entries++);
+        bvh_upload_.resize(4 * std::max<size_t>(entries, 1));
+        if (!entries) for (float4& t : bvh_upload_) t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        size_t o = 0;
+        for (size_t p = 0; p < n; o += 4) {
+            if (f2b(bvh_stream[p].w) == 0u) {
+                for (int k = 0; k < 4; k++) bvh_upload_[o + k] = bvh_stream[p + k];
+                bvh_upload_[o + 1].w = b2f(expand_map_[f2b(bvh_stream[p + 1].w)]);
+                p += 4;
+            } else {
+                const uint32_t tri = f2b(bvh_stream[p].y);
+                bvh_upload_[o] = bvh_stream[p];
+                for (int k = 0; k < 3; k++) bvh_upload_[o + 1 + k] = tri_geo[3 * (size_t)tri + k];
+                p += 1;
+            }
+        }
+        device_bvh_len = (uint32_t)(4 * entries);
+    }
     std::vector<uint8_t> internal_start_;  // scratch of measure_stack_need: 1 where an internal node begins
     bool is_internal_start(size_t p) const { return p < internal_start_.size() && internal_start_[p]; }
     void mark_internal_starts() {
@@ -364,7 +391,7 @@ struct Engine {
     // on a stream of its own, while the previous frame still renders from the other one; the next frame switches over.
     // (Updating in place would have to wait for the previous frame, and the next frame's primary rays with it.)
     struct SceneSet {
-        DeviceArray bvh, tri_geo, tri_attr, xforms, materials, base_packed;
+        DeviceArray bvh, tri_attr, xforms, materials, base_packed;
         size_t dirty_lo = SIZE_MAX, dirty_hi = 0; bool tri_full = true;  // what this copy lacks of the host's triangle arrays
         hipEvent_t free_ev = nullptr; bool busy = false;  // busy: frames reading this copy were enqueued since it was written; free_ev ends the last
         bool valid = false;
@@ -433,7 +460,7 @@ struct Engine {
         for (DeviceArray* d : {&d_byte_luts, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
         for (LightSet& l : light_sets) { l.buf.release(); if (l.free_ev) (void)hipEventDestroy(l.free_ev); }
         for (SceneSet& t : sets) {
-            for (DeviceArray* d : {&t.bvh, &t.tri_geo, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed}) d->release();
+            for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed}) d->release();
             if (t.free_ev) (void)hipEventDestroy(t.free_ev);
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -764,18 +791,13 @@ struct Engine {
                     if (sets[target].busy) { ST_HIP(hipStreamWaitEvent(copy_stream, sets[target].free_ev, 0)); sets[target].busy = false; }
                 } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
                 SceneSet& t = sets[target];
-                // the device copy carries three texels of padding: traversal fetches four texels at every node pointer
-                // (st_device.h traverse), also at the stream's last leaf entries
-                bvh_upload_.assign(bvh_stream.begin(), bvh_stream.end());
-                bvh_upload_.insert(bvh_upload_.end(), 3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                expand_stream();
                 if ((rc = t.bvh.upload(bvh_upload_.data(), bvh_upload_.size() * sizeof(float4), up, staging, flag))) return rc;
-                // triangle arrays: whole the first time or after they grew, otherwise only the slots baked since this copy was written
-                const bool partial = t.valid && !t.tri_full && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4) && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
+                // attribute records: whole the first time or after they grew, otherwise only the slots baked since this copy was written
+                const bool partial = t.valid && !t.tri_full && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
                 if (!partial) {
-                    if ((rc = t.tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), up, staging, flag))) return rc;
                     if ((rc = t.tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), up, staging, flag))) return rc;
                 } else if (t.dirty_lo < t.dirty_hi) {
-                    if ((rc = t.tri_geo.upload_range(tri_geo.data(), 3 * t.dirty_lo * sizeof(float4), 3 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
                     if ((rc = t.tri_attr.upload_range(tri_attr.data(), 4 * t.dirty_lo * sizeof(float4), 4 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
                 }
                 t.dirty_lo = SIZE_MAX; t.dirty_hi = 0; t.tri_full = false; t.valid = true;
@@ -938,12 +960,12 @@ struct Engine {
         KArgs a{};
         a.cam = c.curr; a.prev_cam = c.prev;
         const SceneSet& scene = sets[live];
-        a.bvh = static_cast<const float4*>(scene.bvh.ptr); a.tri_geo = static_cast<const float4*>(scene.tri_geo.ptr); a.tri_attr = static_cast<const float4*>(scene.tri_attr.ptr); a.instance_xforms = static_cast<const float4*>(scene.xforms.ptr);
+        a.bvh = static_cast<const float4*>(scene.bvh.ptr); a.tri_attr = static_cast<const float4*>(scene.tri_attr.ptr); a.instance_xforms = static_cast<const float4*>(scene.xforms.ptr);
         a.materials = static_cast<const GpuMaterial*>(scene.materials.ptr); a.material_base_packed = getenv("ST_NO_PACKED_BASE") ? nullptr : static_cast<const uint32_t*>(scene.base_packed.ptr); a.lights = static_cast<const GpuLight*>(light_sets[live_lights].buf.ptr);
         a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr); a.byte_luts = static_cast<const float*>(d_byte_luts.ptr);
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
         a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
-        a.bvh_len = (uint32_t)bvh_stream.size(); a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
+        a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
         a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
         a.sun_dir[0] = sun_dir_.x; a.sun_dir[1] = sun_dir_.y; a.sun_dir[2] = sun_dir_.z;
         auto P = [&](int id) { return c.plane[id]; };

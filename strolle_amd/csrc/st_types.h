@@ -26,10 +26,17 @@ struct GpuLight { float4 d0, d1, d2, d3, prev_d0, prev_d1, prev_d2; };
 static_assert(sizeof(GpuLight) == 112, "Light is 112 B");
 
 // The reference's 144-B AoS triangle (strolle-gpu/src/triangle.rs:9-21), kept on the HOST only (debug
-// read-back + BVH build). The device gets two split arrays instead:
-//   tri_geo [3 float4 / triangle]: (v0.xyz, 0) (v1-v0, 0) (v2-v0, 0)      — all a hit test reads (48 B)
-//   tri_attr[4 float4 / triangle]: (n0, uv0.x) (n1, uv0.y) (n2, uv1.x) (uv1.y, uv2.x, uv2.y, 0)
-// fetched once per ray, for the winning triangle only.
+// read-back + BVH build). The device gets:
+//   tri_attr[4 float4 / triangle]: (n0, uv0.x) (n1, uv0.y) (n2, uv1.x) (uv1.y, uv2.x, uv2.y, instance slot)
+//     fetched once per ray, for the winning triangle only;
+//   the hit-test record (v0.xyz, 0) (v1-v0, 0) (v2-v0, 0) — all a hit test reads (48 B) — inline in the BVH stream:
+// device BVH stream: the serializer's stream (bvh/serializer.rs:20-110, what st_debug_bvh_stream returns and the
+//   stream-contract test compares) re-laid so that EVERY entry is four float4 and entry k starts at texel 4 k:
+//     internal node  (min0.xyz, 0) (max0.xyz, far pointer) (min1.xyz, -) (max1.xyz, -)   the near child is the next entry
+//     leaf entry     (flags, triangle, material, marker != 0) (v0.xyz, 0) (v1-v0, 0) (v2-v0, 0)   flags & 1: another
+//                    entry of the same leaf follows
+//   One 64-B fetch per traversal step, whichever kind the entry is; pointers are texel offsets into this form (the
+//   per-lane stack keeps entry numbers). Visiting order and the `used_memory` count are those of the serializer's stream.
 struct HostTriangle { float4 d0, d1, d2, d3, d4, d5, d6, d7, d8; };
 static_assert(sizeof(HostTriangle) == 144, "Triangle is 144 B");
 
@@ -41,7 +48,7 @@ constexpr uint32_t kCounterLines = 256;  // ray/byte counters are spread over th
 struct KArgs {
     GpuCamera cam, prev_cam;
     // engine-level bindings
-    const float4* bvh; const float4* tri_geo; const float4* tri_attr;
+    const float4* bvh; const float4* tri_attr;
     const float4* instance_xforms;  // 8 float4 per instance slot: curr_xform_inv (3 axes + translation), prev_xform; slot = tri_attr[4 t + 3].w
     const GpuMaterial* materials; const GpuLight* lights;
     const uint32_t* material_base_packed;  // per material: gbuffer_pack_base_color(base_color), valid where it has no base-colour texture
@@ -49,7 +56,7 @@ struct KArgs {
     const float* byte_luts;  // 256 sRGB->linear + 256 unorm8 values (st_device.h kLut*), generated on the device at engine creation
     const float4* transmittance_lut; const float4* sky_lut;
     uint32_t bvh_len, n_lights_buf, light_count, atlas_w, atlas_h;
-    uint32_t tri_slots;  // triangle records in tri_geo / tri_attr (upper bound of every triangle id in the BVH stream)
+    uint32_t tri_slots;  // triangle records in tri_attr (upper bound of every triangle id in the BVH stream)
     float sun_altitude;
     float sun_dir[3];
     // per-camera planes (A/B resolved for this frame)

@@ -353,7 +353,7 @@ def test_back_to_back_frames_without_sync_bit_exact(scene):
 
 
 def test_large_bvh_uses_32bit_stack_entries_bit_exact():
-    """A BVH stream longer than 65,536 float4 switches the traversal kernels to 32-bit LDS stack entries (k_common.h
+    """A BVH stream of more than 65,535 entries switches the traversal kernels to 32-bit LDS stack entries (k_common.h
     ST_LAUNCH_TRACE): heatmap integers, Reference and Image planes must still equal the oracle."""
     torch = _torch()
     size = (160, 96)
@@ -361,8 +361,12 @@ def test_large_bvh_uses_32bit_stack_entries_bit_exact():
     prod, orac, desc, cp, co = _pair(build, size, CameraMode.BVH_HEATMAP)
     out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
     img, ref = _step(torch, prod, orac, desc, cp, co, out)
-    n_float4 = prod.read_scene(0).size // 4
-    assert n_float4 > 65536, f"scene too small to leave the 16-bit path: {n_float4} float4"
+    w = prod.read_scene(0).reshape(-1, 4).view(np.uint32)[:, 3]
+    entries, p = 0, 0
+    while p < len(w):  # an internal node is four float4 of the serializer's stream, a leaf entry one
+        p += 4 if w[p] == 0 else 1
+        entries += 1
+    assert entries > 65536, f"scene too small to leave the 16-bit path: {entries} stream entries"
     assert np.array_equal(prod.read_buffer(cp, Buffer.DBG_USED_MEMORY), orac.read_buffer(co, Buffer.DBG_USED_MEMORY))
     assert_bits_equal(img, ref, "heatmap colours (u32 stack)")
     for mode, frames in ((CameraMode.REFERENCE, 2), (CameraMode.IMAGE, 5)):
