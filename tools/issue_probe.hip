@@ -18,6 +18,8 @@
 #define VSS4 "v_fma_f32 %0, %0, %4, %5\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n v_fma_f32 %1, %1, %4, %5\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n v_fma_f32 %2, %2, %4, %5\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n v_fma_f32 %3, %3, %4, %5\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n"
 // the exec-mask pattern of a divergent if: compare, save exec, one VALU under the mask, restore
 #define MASK4 "v_cmp_lt_f32 vcc, %0, %4\n s_and_saveexec_b64 %8, vcc\n v_fma_f32 %1, %1, %4, %5\n s_or_b64 exec, exec, %8\n v_cmp_lt_f32 vcc, %2, %4\n s_and_saveexec_b64 %8, vcc\n v_fma_f32 %3, %3, %4, %5\n s_or_b64 exec, exec, %8\n"
+// packed f32: two lanes' worth of FMAs per instruction (what the SLP vectoriser makes of adjacent scalar f32 operations)
+#define PK4 "v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %3, %3, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %3, %3, %1, %2\n"
 // dependent chain: each VALU needs the previous one's result
 #define DEP4 "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n"
 
@@ -32,6 +34,8 @@ __global__ void k_probe(float* out, int iters, float a, float b) {
         if (MODE == 2) asm volatile(VS4 VS4 VS4 VS4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b), "s"(s0), "s"(s1), "s"(m) : "scc");
         if (MODE == 3) asm volatile(VSS4 VSS4 VSS4 VSS4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b), "s"(s0), "s"(s1), "s"(m) : "scc");
         if (MODE == 4) asm volatile(MASK4 MASK4 MASK4 MASK4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b), "s"(s0), "s"(s1), "s"(m) : "vcc", "scc");
+        if (MODE == 6) { typedef float f2 __attribute__((ext_vector_type(2))); f2 p0 = {x0, x1}, p1 = {a, a}, p2 = {b, b}, p3 = {x2, x3};
+                         asm volatile(PK4 PK4 PK4 PK4 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)); x0 = p0.x; x1 = p0.y; x2 = p3.x; x3 = p3.y; }
         if (MODE == 5) asm volatile(DEP4 DEP4 DEP4 DEP4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b), "s"(s0), "s"(s1), "s"(m));
     }
     if (x0 + x1 + x2 + x3 + (float)(s0 + s1) == 123456.789f) out[0] = x0;
@@ -61,6 +65,7 @@ int main() {
     float* out; CHECK(hipMalloc(&out, 256));
     run<0>("16 independent v_fma_f32", 16, 0, out);
     run<5>("16 dependent v_fma_f32 (4 chains)", 16, 0, out);
+    run<6>("16 v_pk_fma_f32 (2 chains)", 16, 0, out);
     run<1>("16 s_add_u32", 0, 16, out);
     run<2>("16 v_fma + 16 s_add interleaved", 16, 16, out);
     run<3>("16 v_fma + 32 s_add interleaved", 16, 32, out);
