@@ -298,6 +298,10 @@ ST_D float intersect_sphere(const Ray& r, float radius) {  // ray.rs:304-321
 }
 
 struct Candidate { float t, u, v, inv_det; uint32_t tri, material; };
+// Entry of the device BVH stream at BYTE offset `at` (traversal pointers are byte offsets: 64 per entry): base + a 32-bit
+// offset, which the global-memory form turns into `global_load v, v_offset, s[base]` with immediate offsets for the four
+// texels — no per-texel 64-bit address arithmetic (three VALU instructions per texel when indexed as bvh[ptr + k]).
+ST_D const float4* bvh_entry(const float4* bvh, uint32_t at) { return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bvh) + at); }
 
 ST_D V2 tri_uv(const KArgs& a, uint32_t tri, float u, float v) {
     const float4 q0 = a.tri_attr[4u * tri], q1 = a.tri_attr[4u * tri + 1u], q2 = a.tri_attr[4u * tri + 2u], q3 = a.tri_attr[4u * tri + 3u];
@@ -321,15 +325,16 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, C
         // (dependent fetches are the traversal's latency chain). The empty asm keeps the four loads together: the compiler
         // otherwise sinks d1..d3 behind the d0.w test, which puts a second, dependent round trip into every step (measured
         // on the dungeon: 1.99 -> 1.87 ms/frame for the internal nodes alone).
-        const float4 d0 = a.bvh[ptr], d1 = a.bvh[ptr + 1u], d2 = a.bvh[ptr + 2u], d3 = a.bvh[ptr + 3u];
+        const float4* entry = bvh_entry(a.bvh, ptr);
+        const float4 d0 = entry[0], d1 = entry[1], d2 = entry[2], d3 = entry[3];
         asm volatile("" :: "v"(d1.x), "v"(d2.x), "v"(d3.x));
         if (f2b(d0.w) == 0u) {
             used_memory += 48u;
-            uint32_t near_ptr = ptr + 4u, far_ptr = f2b(d1.w);
+            uint32_t near_ptr = ptr + 64u, far_ptr = f2b(d1.w);
             float near_d = intersect_box(ray, xyz(d0), xyz(d1));
             float far_d = intersect_box(ray, xyz(d2), xyz(d3));
             if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-            if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)(far_ptr >> 2); sp++; } }
+            if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)(far_ptr >> 6); sp++; } }
             if (near_d < best->t) { ptr = near_ptr; continue; }
         } else {
             used_memory += 144u;
@@ -357,9 +362,9 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, C
                 }
             }
             if (found && ANY_HIT) break;
-            if (flags & 1u) { ptr += 4u; continue; }
+            if (flags & 1u) { ptr += 64u; continue; }
         }
-        if (sp > 0) { sp--; ptr = (uint32_t)stack[sp * 64] << 2; } else break;
+        if (sp > 0) { sp--; ptr = (uint32_t)stack[sp * 64] << 6; } else break;
     }
     return used_memory;
 }
@@ -401,7 +406,8 @@ ST_D AnyHitState any_hit_begin() { AnyHitState s; s.ptr = 0u; s.sp = 0; s.used_m
 // dungeon. Traversal here is bound by VALU issue under lane divergence, not by its chain of dependent fetches.)
 struct NodeFetch { float4 d0, d1, d2, d3; };
 ST_D void any_hit_fetch_node(const KArgs& a, const AnyHitState& st, NodeFetch& f) {
-    f.d0 = a.bvh[st.ptr]; f.d1 = a.bvh[st.ptr + 1u]; f.d2 = a.bvh[st.ptr + 2u]; f.d3 = a.bvh[st.ptr + 3u];  // see traverse()
+    const float4* entry = bvh_entry(a.bvh, st.ptr);
+    f.d0 = entry[0]; f.d1 = entry[1]; f.d2 = entry[2]; f.d3 = entry[3];  // see traverse()
     asm volatile("" :: "v"(f.d1.x), "v"(f.d2.x), "v"(f.d3.x));
 }
 // returns true when the ray is finished (st.found tells how)
@@ -411,11 +417,11 @@ ST_D bool any_hit_process(const KArgs& a, const Ray& ray, SE* stack, AnyHitState
     const float4 d0 = f.d0;
     if (f2b(d0.w) == 0u) {
         st.used_memory += 48u;
-        uint32_t near_ptr = st.ptr + 4u, far_ptr = f2b(f.d1.w);
+        uint32_t near_ptr = st.ptr + 64u, far_ptr = f2b(f.d1.w);
         float near_d = intersect_box(ray, xyz(d0), xyz(f.d1));
         float far_d = intersect_box(ray, xyz(f.d2), xyz(f.d3));
         if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-        if (far_d < ray.len) { if (st.sp < kBvhStackSize) { stack[st.sp * 64] = (SE)(far_ptr >> 2); st.sp++; } }
+        if (far_d < ray.len) { if (st.sp < kBvhStackSize) { stack[st.sp * 64] = (SE)(far_ptr >> 6); st.sp++; } }
         if (near_d < ray.len) { st.ptr = near_ptr; return false; }
     } else {
         st.used_memory += 144u;
@@ -441,9 +447,9 @@ ST_D bool any_hit_process(const KArgs& a, const Ray& ray, SE* stack, AnyHitState
                 if (found) { st.found = true; return true; }
             }
         }
-        if (flags & 1u) { st.ptr += 4u; return false; }
+        if (flags & 1u) { st.ptr += 64u; return false; }
     }
-    if (st.sp > 0) { st.sp--; st.ptr = (uint32_t)stack[st.sp * 64] << 2; return false; }
+    if (st.sp > 0) { st.sp--; st.ptr = (uint32_t)stack[st.sp * 64] << 6; return false; }
     return true;
 }
 template <class SE>

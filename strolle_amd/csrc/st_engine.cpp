@@ -340,7 +340,7 @@ struct Engine {
         for (size_t p = 0; p < n; o += 4) {
             if (f2b(bvh_stream[p].w) == 0u) {
                 for (int k = 0; k < 4; k++) bvh_upload_[o + k] = bvh_stream[p + k];
-                bvh_upload_[o + 1].w = b2f(expand_map_[f2b(bvh_stream[p + 1].w)]);
+                bvh_upload_[o + 1].w = b2f(expand_map_[f2b(bvh_stream[p + 1].w)] * 16u);  // far pointer as a byte offset
                 p += 4;
             } else {
                 const uint32_t tri = f2b(bvh_stream[p].y);

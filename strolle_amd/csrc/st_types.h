@@ -32,11 +32,11 @@ static_assert(sizeof(GpuLight) == 112, "Light is 112 B");
 //   the hit-test record (v0.xyz, 0) (v1-v0, 0) (v2-v0, 0) — all a hit test reads (48 B) — inline in the BVH stream:
 // device BVH stream: the serializer's stream (bvh/serializer.rs:20-110, what st_debug_bvh_stream returns and the
 //   stream-contract test compares) re-laid so that EVERY entry is four float4 and entry k starts at texel 4 k:
-//     internal node  (min0.xyz, 0) (max0.xyz, far pointer) (min1.xyz, -) (max1.xyz, -)   the near child is the next entry
+//     internal node  (min0.xyz, 0) (max0.xyz, far child's byte offset) (min1.xyz, -) (max1.xyz, -)   the near child is the next entry
 //     leaf entry     (flags, triangle, material, marker != 0) (v0.xyz, 0) (v1-v0, 0) (v2-v0, 0)   flags & 1: another
 //                    entry of the same leaf follows
-//   One 64-B fetch per traversal step, whichever kind the entry is; pointers are texel offsets into this form (the
-//   per-lane stack keeps entry numbers). Visiting order and the `used_memory` count are those of the serializer's stream.
+//   One 64-B fetch per traversal step, whichever kind the entry is; traversal pointers are byte offsets into this form
+//   (the per-lane stack keeps entry numbers). Visiting order and the `used_memory` count are those of the serializer's stream.
 struct HostTriangle { float4 d0, d1, d2, d3, d4, d5, d6, d7, d8; };
 static_assert(sizeof(HostTriangle) == 144, "Triangle is 144 B");
 
