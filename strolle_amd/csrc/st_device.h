@@ -259,7 +259,11 @@ ST_D float4 atlas_sample(const KArgs& a, V2 uv) {
     const float4 bot = xe::add4(p01, xe::scale4(xe::sub4(p11, p01), tx));
     return xe::add4(top, xe::scale4(xe::sub4(bot, top), ty));
 }
-ST_D float mat_wrap(float t) { return t > 0.0f ? fmodf(t, 1.0f) : 1.0f - fmodf(-t, 1.0f); }
+// fmodf(x, 1) for x >= 0 (material.rs:86-104 `% 1.0`): x - floor(x) is exact in f32 (the fraction of x needs no more
+// significant bits than x has), NaN and +inf give NaN either way; libm's fmodf is a 40-instruction loop with two nested
+// divergent branches, six times per textured hit.
+ST_D float fmod1_nonneg(float x) { return x - floorf(x); }
+ST_D float mat_wrap(float t) { return t > 0.0f ? fmod1_nonneg(t) : 1.0f - fmod1_nonneg(-t); }
 ST_D float4 sample_atlas(const KArgs& a, V2 hit_uv, float4 multiplier, float4 texture) {
     if (is_zero(texture)) return multiplier;
     hit_uv.x = mat_wrap(hit_uv.x);
