@@ -229,12 +229,25 @@ def main():
     # graph serial) -> per-kernel average durations for the roofline object. Kept out of region 1: it costs ~10 %.
     prof, profiled_ms = [], None
     if not args.no_profile:
-        engine.profile_enable(True)
+        engine.profile_enable(1)   # ST_PROFILE_TIMING
         engine.profile_read(reset=True)
         elapsed_p, _ = timed_region()
         prof = engine.profile_read(reset=True)
-        engine.profile_enable(False)
         profiled_ms = elapsed_p / args.steps * 1e3
+        # region 3, untimed: a few more frames with the traversal-byte counters on (ST_PROFILE_TRAVERSAL_BYTES; the kernels
+        # sum the reference's `used_memory` over their rays, which costs ~10 us per tracing launch and is therefore off in
+        # regions 1 and 2) -> the LDS / L2-served A part of the algorithmic bytes, scaled to K steps
+        engine.profile_enable(2)
+        engine.profile_read(reset=True)
+        extra = max(3, min(args.steps, 6)) // 3 * 3   # whole GI schedules (three frames)
+        for _ in range(extra):
+            step()
+        torch.cuda.synchronize()
+        trav = {q["name"]: q["traversal_bytes"] * args.steps / extra for q in engine.profile_read(reset=True)}
+        engine.profile_enable(0)
+        for q in prof:
+            q["traversal_bytes"] = trav.get(q["name"], 0.0)
+            q["algorithmic_bytes"] += q["traversal_bytes"]
     on_cpu = "cpu" if debug_shared else f"cuda:{local_rank}"
     t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=on_cpu)
     per_rank_ms = None

@@ -283,11 +283,14 @@ int st_decode_png(const void* bytes, size_t size, uint8_t* out_rgba, size_t capa
  * progressive DCT; 8-bit; grey or three components). */
 int st_decode_image(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height);
 
-/* Per-kernel timing (HIP events recorded around every launch on the launch stream).
- * st_profile_read returns, per kernel slot i < *count: name, launches, total milliseconds,
- * algorithmic bytes per launch (DESIGN.md "bytes per unit" x units launched).
- * While profiling is enabled the pass graph runs serially on the caller's stream (no two-stream overlap), so that an
- * event pair times its kernel alone; the rendered bits are the same either way. */
+/* Per-kernel measurement. st_profile_enable(e, flags): bit 0 (ST_PROFILE_TIMING) = HIP events around every launch on the
+ * launch stream; while it is set the pass graph runs serially on the caller's stream (no two-stream overlap), so that an
+ * event pair times its kernel alone. Bit 1 (ST_PROFILE_TRAVERSAL_BYTES) = the tracing kernels also sum the reference's
+ * `used_memory` counter over their rays (a cross-lane reduction per ray: ~10 us per full-screen launch, which is why it
+ * is not always on; rays themselves are always counted, st_camera_ray_count). The rendered bits are the same in every
+ * mode. st_profile_read returns, per kernel slot i < *count: name, launches, total milliseconds (0 without bit 0),
+ * algorithmic bytes (DESIGN.md "bytes per unit" x units launched; the traversal part is 0 without bit 1). */
+enum { ST_PROFILE_TIMING = 1, ST_PROFILE_TRAVERSAL_BYTES = 2 };
 enum { ST_PROFILE_MAX_KERNELS = 48 };  /* >= the number of kernel slots (st_kernels.h) */
 typedef struct StKernelProfile {
     char name[48];

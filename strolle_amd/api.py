@@ -548,8 +548,9 @@ class Engine(EngineBase):
             self._check(self._b.scene_load_gltf(self._h, os.fsencode(source), C.byref(opt), C.byref(out)))
         return {name: getattr(out, name) for name, _ in StGltfSummary._fields_}
 
-    def profile_enable(self, enabled: bool):
-        self._check(self._b.profile_enable(self._h, 1 if enabled else 0))
+    def profile_enable(self, flags):
+        """st_profile_enable: bit 0 = per-kernel event timing (serial execution), bit 1 = traversal-byte counters; True = 1."""
+        self._check(self._b.profile_enable(self._h, int(flags)))
 
     def profile_read(self, reset: bool = True):
         arr = (StKernelProfile * 48)(); n = C.c_size_t()

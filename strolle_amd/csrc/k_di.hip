@@ -173,7 +173,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a_in, uint32_t s
         }
         tex_write(a.di_diff_stash, a, pos, vis[k]);
     }
-    if (rays) count_rays_n(a.ray_counter, rays, bytes);
+    if (rays) count_rays_n(a, rays, bytes);
     if (own_lhs) di_spatial_sample_cell(a, seed_sample, gid, lhs_pos, vis[0], vis[1]);
 }
 void launch_di_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_sample, hipStream_t s) {
@@ -201,7 +201,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     V3 radiance, spec_brdf;
     if (hit_some(hit)) {
         const bool occluded = trace_any(a, di_sample_ray(res.s, hit.point), lane_stack(lds), &used_);
-        count_rays(a.ray_counter, used_);
+        count_rays(a, used_);
         confidence = (res.s.is_occluded == occluded) ? res.s.confidence : 0.0f;
         res.s.confidence = 1.0f;
         res.s.is_occluded = occluded;

@@ -55,7 +55,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a_in, uint32_t seed
         gi_ray_pdf = 1.0f;
     }
     const TriangleHit gi_hit = trace_closest(a, gi_ray, lane_stack(lds), &used_);
-    count_rays(a.ray_counter, used_);
+    count_rays(a, used_);
     GBuffer gg = gbuffer_zero();
     uint32_t base_bits = 0u;  // gbuffer_pack_base_color of the zero colour
     if (hit_is_some(gi_hit)) {
@@ -132,7 +132,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed
         if (hit_some(gi_hit)) {
             const Ray ray = light_id == kLightIdSky ? make_ray(gi_hit.point, light_dir) : light_ray_wnoise(light_get(a, light_id), wn, gi_hit.point);
             const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
-            count_rays(a.ray_counter, used_);
+            count_rays(a, used_);
             light_vis = occluded ? 0.0f : 1.0f;
         } else light_vis = 1.0f;
         radiance = light_rad * light_vis / light_pdf;
@@ -358,7 +358,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_spatial_fused(const KArgs a_in, uint32_t s
         }
         tex_write(a.gi_d2, a, pos, vis[k]);
     }
-    if (rays) count_rays_n(a.ray_counter, rays, bytes);
+    if (rays) count_rays_n(a, rays, bytes);
     if (own_lhs) gi_spatial_sample_cell(a, seed_sample, gid, lhs_pos, vis[0], vis[1]);
 }
 void launch_gi_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_sample, hipStream_t s) {

@@ -34,7 +34,7 @@ __global__ ST_KERNEL_BOUNDS void k_bvh_heatmap(const KArgs a_in) {
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     Candidate c; bool any;
     const uint32_t used = traverse<false, SE>(a, camera_ray(a.cam, pos), kF32Max, lane_stack(lds), &c, &any);
-    count_rays(a.ray_counter, used);
+    count_rays(a, used);
     a.dbg_used_memory[screen_to_idx(a, pos)] = used;
     tex_write(a.ref_colors, a, pos, f4(heatmap_gradient((float)used / 8192.0f), 1.0f));
 }
@@ -57,7 +57,7 @@ __global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a_in, uint32_t depth)
         ray = make_ray(xyz(d0), xyz(d1));
     }
     const TriangleHit hit = trace_closest(a, ray, lane_stack(lds), &used_);
-    count_rays(a.ray_counter, used_);
+    count_rays(a, used_);
     float4 h0, h1;
     hit_pack(hit, &h0, &h1);
     rec2_write_own(a.ref_hits, idx, h0, h1, true, true);  // quad-transposed 32-B records (st_device.h)
@@ -116,7 +116,7 @@ __global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, 
         const float light_pdf = frcp((float)a.light_count);
         const GpuLight light = light_get(a, light_id);
         const bool occluded = trace_any(a, light_ray_wnoise(light, wn, hit.point), lane_stack(lds), &used_);
-        count_rays(a.ray_counter, used_);
+        count_rays(a, used_);
         if (!occluded) color = color + throughput * radiance_sum(light_radiance(light, hit)) / light_pdf;
     }
     const BrdfSample rs = layered_brdf_sample(hit.g, wn, -hit.dir);
@@ -164,7 +164,7 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Ray ray = camera_ray(a.cam, pos);
     const TriangleHit hit = trace_closest(a, ray, lane_stack(lds), &used_);
-    count_rays(a.ray_counter, used_);
+    count_rays(a, used_);
     if (!hit_is_some(hit)) {  // LoadOp::Clear(TRANSPARENT)
         tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z()); tex_write(a.sm, a, pos, f4z()); tex_write(a.velocity, a, pos, f4z());
         tex_write(a.sn, a, pos, f4z());
@@ -235,7 +235,7 @@ __global__ ST_KERNEL_BOUNDS void k_spatial_trace(const KArgs a_in, const float4*
     Ray ray = make_ray(xyz(ray_d0), normal_decode(v2(ray_d1.x, ray_d1.y)));
     ray.len = ray_d0.w;
     const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
-    count_rays(a.ray_counter, used_);
+    count_rays(a, used_);
     tex_write(buf_d2, a, pos, make_float4(occluded ? 0.0f : 1.0f, ray_d1.z, ray_d1.w, 0.0f));
 }
 // The same pass with ray compaction (north_star: "wavefront ballot/prefix-sum for ray compaction"). A block owns
@@ -316,7 +316,7 @@ __global__ ST_KERNEL_BOUNDS void k_spatial_trace_compact(const KArgs a, const fl
             }
         }
     }
-    if (rays_done) count_rays_n(a.ray_counter, rays_done, bytes);
+    if (rays_done) count_rays_many(a, rays_done, bytes);
 }
 void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s) {
     static const bool compact = [] { const char* e = getenv("ST_COMPACT"); return e && atoi(e) != 0; }();

@@ -57,15 +57,24 @@ ST_D SE* lane_stack(SE* lds) { return lds + (threadIdx.x >> 6) * (kBvhStackSize 
 // kCounterLines 64-byte lines picked by block id: a single hot word saturates near 88 atomics/us
 // (MI355X_MICROARCH.md, row "dequeue"), which alone cost 0.7 ms per full-screen launch at 1080p.
 
-ST_D void count_rays_n(unsigned long long* counter, uint32_t rays, unsigned long long used_memory) {
-    unsigned long long* line = counter + (blockIdx.x & (kCounterLines - 1u)) * 8u;
-    atomicAdd(line, (unsigned long long)rays);
-    atomicAdd(line + 1, used_memory);
+// The byte half is off unless st_profile_enable asked for it (KArgs::count_bytes): summing a per-lane value takes a 64-bit
+// cross-lane reduction per call (measured: 12-13 us of primary visibility's 89), counting rays takes a ballot.
+ST_D void count_rays_n(const KArgs& a, uint32_t rays /* 0..3 */, unsigned long long used_memory) {
+    unsigned long long* line = a.ray_counter + (blockIdx.x & (kCounterLines - 1u)) * 8u;
+    if (rays & 1u) atomicAdd(line, 1ull);
+    if (rays & 2u) atomicAdd(line, 2ull);
+    if (a.count_bytes) atomicAdd(line + 1, used_memory);
 }
-ST_D void count_rays(unsigned long long* counter, uint32_t used_memory) {
-    unsigned long long* line = counter + (blockIdx.x & (kCounterLines - 1u)) * 8u;
+// any number of rays per lane (the persistent-wave shadow kernel)
+ST_D void count_rays_many(const KArgs& a, uint32_t rays, unsigned long long used_memory) {
+    unsigned long long* line = a.ray_counter + (blockIdx.x & (kCounterLines - 1u)) * 8u;
+    atomicAdd(line, (unsigned long long)rays);
+    if (a.count_bytes) atomicAdd(line + 1, used_memory);
+}
+ST_D void count_rays(const KArgs& a, uint32_t used_memory) {
+    unsigned long long* line = a.ray_counter + (blockIdx.x & (kCounterLines - 1u)) * 8u;
     atomicAdd(line, 1ull);
-    atomicAdd(line + 1, (unsigned long long)used_memory);
+    if (a.count_bytes) atomicAdd(line + 1, (unsigned long long)used_memory);
 }
 
 // ------------------------------------------------------------------ small codecs

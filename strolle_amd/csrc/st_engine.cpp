@@ -421,7 +421,8 @@ struct Engine {
     // launch moves 340 instead of 205 MB through the fabric (algorithmic: 174 MB) and takes 61 instead of 56 us on its own.
     uint32_t tile_map_denoise = 2;
     uint32_t tile_map = 1;  // blockIdx -> tile mapping (st_device.h); 1 measured best on MI355X with the current kernels (2 was, before the LDS-staged denoiser); ST_TILE_MAP overrides
-    bool profiling = false;
+    bool profiling = false;       // st_profile_enable bit 0: per-kernel event timing (serial execution)
+    bool count_bytes = false;     // st_profile_enable bit 1: traversal-byte counters
     bool tick_timing = false;  // ST_TICK_TIMING=1: print the host-side cost of a scene refresh to stderr
     std::vector<ProfileRecord> profile_records; std::vector<hipEvent_t> event_pool;
     StKernelProfile profile_totals[KS_COUNT];
@@ -965,6 +966,7 @@ struct Engine {
         a.atlas = static_cast<const uchar4*>(d_atlas.ptr); a.blue_noise = static_cast<const uchar4*>(d_blue_noise.ptr); a.byte_luts = static_cast<const float*>(d_byte_luts.ptr);
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
         a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
+        a.count_bytes = count_bytes ? 1u : 0u;
         a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
         a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
         a.sun_dir[0] = sun_dir_.x; a.sun_dir[1] = sun_dir_.y; a.sun_dir[2] = sun_dir_.z;
@@ -1584,7 +1586,7 @@ int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused) {
     return ST_OK;
 }
 
-int st_profile_enable(StEngine* e, int enabled) { ST_REQUIRE(e, "null engine"); E(e)->profiling = enabled != 0; return ST_OK; }
+int st_profile_enable(StEngine* e, int enabled) { ST_REQUIRE(e, "null engine"); E(e)->profiling = (enabled & 1) != 0; E(e)->count_bytes = (enabled & 2) != 0; return ST_OK; }
 int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* count, int reset) {
     ST_REQUIRE(e && out && count, "null argument");
     Engine* en = E(e);
@@ -1609,7 +1611,7 @@ int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* 
     }
     size_t n = 0;
     for (int i = 0; i < KS_COUNT && n < capacity; i++) {
-        if (en->profile_totals[i].launches == 0) continue;
+        if (en->profile_totals[i].launches == 0 && en->profile_totals[i].traversal_bytes == 0.0) continue;  // bytes-only mode records no launches
         out[n] = en->profile_totals[i];
         n++;
     }

@@ -70,7 +70,7 @@ ST_D DiReservoir di_sampling_pixel(const KArgs& a, uint32_t seed, U2 pos, const 
         const float4 bn = blue_noise_read(a, pos);
         const Ray ray = light_ray_bnoise(light_get(a, res.light_id), v2(bn.x, bn.y), hit.point);
         const bool occluded = trace_any(a, ray, stack, &used_);
-        count_rays(a.ray_counter, used_);
+        count_rays(a, used_);
         if (occluded) res.w = 0.0f;
         out.s.light_id = res.light_id; out.s.light_point = ray.origin; out.s.is_occluded = occluded;
         out.m = 1.0f; out.w = res.w;
