@@ -49,7 +49,11 @@ ST_D bool owns_pixel(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.hei
 //   <false, uint32_t>  anything larger
 constexpr uint32_t kLdsSceneTexels = 448;  // 7 KiB of LDS per block: 112 entries, e.g. 56 one-triangle leaves + 55 internal nodes
 constexpr uint32_t kStack16Texels = 4u * 65536u;
+#ifdef ST_NO_LDS_SCENE  // experiment switch (tools/ab_bench.sh): small scenes traverse through the vector L1 like large ones
+inline bool scene_fits_lds(const KArgs&) { return false; }
+#else
 inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len <= kLdsSceneTexels; }
+#endif
 // first statement of a tracing kernel whose parameter is `a_in`: defines `a`, the arguments the body uses
 #define ST_SCENE_PROLOGUE                                                                                                        \
     __shared__ float4 s_scene_bvh_[LDS_SCENE ? kLdsSceneTexels : 1];                                                             \

@@ -246,6 +246,15 @@ struct CameraState {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
     bool have_prev_frame_events = false;
+    // GI history hand-over without the copy. gi_resolving ends every frame by copying the frame's source reservoirs into
+    // GI_RESERVOIRS_0, next frame's history (gi_resolving.rs:60-66): 128 B per pixel of pure copy. When the source is the
+    // temporal pass's output (GI_RESERVOIRS_1, four frames in six) and the whole pass graph runs, the engine swaps the two
+    // plane pointers instead: GI_RESERVOIRS_0 takes over the storage temporal resampling wrote, and GI_RESERVOIRS_1 — which
+    // the next temporal pass overwrites completely before anything reads it — gets the old history's storage. Until then
+    // reading GI_RESERVOIRS_1 back returns GI_RESERVOIRS_0's storage (`gi_aliased`; st_camera_read_buffer), and anything
+    // that could observe the difference (a pass mask, st_camera_write_buffer, a row window) first makes the copy for real
+    // (`materialize_gi_history`).
+    bool gi_aliased = false;
     bool internal_dirty = false;  // st_camera_write_buffer replaced a plane the internal planes derive from: regenerate them before the next frame
 };
 static size_t plane_texels_per_pixel(int id) {
@@ -258,6 +267,13 @@ static size_t plane_texels_per_pixel(int id) {
 
 constexpr size_t kCounterWordsPerSlot = (size_t)kCounterLines * 8;
 constexpr size_t kCounterBytes = sizeof(unsigned long long) * kCounterWordsPerSlot * KS_COUNT;
+static int materialize_gi_history(CameraState& c) {
+    if (!c.gi_aliased) return ST_OK;
+    ST_HIP(hipDeviceSynchronize());
+    ST_HIP(hipMemcpy(c.plane[ST_BUF_GI_RESERVOIRS_1], c.plane[ST_BUF_GI_RESERVOIRS_0], c.plane_bytes[ST_BUF_GI_RESERVOIRS_0], hipMemcpyDeviceToDevice));
+    c.gi_aliased = false;
+    return ST_OK;
+}
 // sums the per-line counters of every kernel slot into host[2*slot + {0: rays, 1: traversal bytes}]
 static int read_counters(const CameraState& c, unsigned long long* host /* 2*KS_COUNT */) {
     std::vector<unsigned long long> raw(kCounterWordsPerSlot * KS_COUNT);
@@ -412,6 +428,7 @@ struct Engine {
     std::vector<uint64_t> last_launches;  // pass bits of every launch the last render considered (st_debug_last_launches)
     uint64_t pass_mask = ~0ull;  // st_debug_set_pass_mask: which reference passes a render executes (parity tests run one launch at a time)
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
+    bool alias_gi_history = true;  // ST_NO_GI_ALIAS=1: gi_resolving always copies the source reservoirs into the history plane
     bool fuse_wavelet = true;  // ST_NO_FUSE_WAVELET=1: strides 1 and 2 of the a-trous chain as two launches
     bool fuse_spatial = true;  // ST_NO_FUSE_SPATIAL=1: DI spatial resampling as three launches
     bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
@@ -442,6 +459,7 @@ struct Engine {
         if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* k = getenv("ST_NO_FUSE_WAVELET")) fuse_wavelet = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_GI_ALIAS")) alias_gi_history = atoi(k) == 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
         if (const char* nd = getenv("ST_NO_DOUBLE_BUFFER")) double_buffer = atoi(nd) == 0;
         if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
@@ -897,6 +915,7 @@ struct Engine {
         c.slab_bytes = total;
         size_t off = 0;
         for (int i = 0; i < ST_BUF_COUNT + kInternalPlanes; i++) { c.plane[i] = reinterpret_cast<float4*>(static_cast<char*>(c.slab) + off); off += (c.plane_bytes[i] + 255) & ~size_t(255); }
+        c.gi_aliased = false;
         if (hipMalloc(reinterpret_cast<void**>(&c.counters), kCounterBytes) != hipSuccess) {
             (void)hipGetLastError(); c.counters = nullptr;
             release_camera(c);  // do not leak the slab
@@ -1041,6 +1060,16 @@ struct Engine {
             const bool tracing = c.frame % 6u < 4u;
             const uint32_t gi_source = (tracing && c.frame % 2u == 1u) ? 1u : 0u;
             const uint32_t pseed = seed(SEED_GI_PREVIEW);  // one seed for both preview passes (passes/gi_preview_resampling.rs:60-74)
+            // GI history hand-over by pointer swap instead of gi_resolving's copy (CameraState::gi_aliased says when)
+            const bool whole_graph = pass_mask == ~0ull && c.row0 == 0u && c.row1 == c.desc.height;
+            const bool gi_runs = needs_gi && any_objects;
+            if (c.gi_aliased && gi_runs && !whole_graph) { const int rc = materialize_gi_history(c); if (rc) return rc; }
+            // Fast build only: the reference's copy is a decode + re-encode of every reservoir, which is not the identity on all
+            // bit patterns (the octahedral normal of a few records per frame moves by an ulp), and the exact build owes the
+            // oracle those bits.
+            const bool swap_gi_history = alias_gi_history && arithmetic == ST_ARITH_FAST && gi_runs && whole_graph && gi_source == 0u;
+            if (gi_runs && whole_graph) c.gi_aliased = false;  // this frame's temporal pass rewrites GI_RESERVOIRS_1 completely
+            a.gi_skip_history_copy = swap_gi_history ? 1u : 0u;
 
             auto do_prim = [&] {
                 if (fuse && any_objects) run(KS_PRIM_VISIBILITY_REPROJECTION, ST_PASS_PRIM_VISIBILITY | ST_PASS_FRAME_REPROJECTION, [&] { L.launch_prim_visibility(a, true, cur); });
@@ -1110,6 +1139,10 @@ struct Engine {
                 } else {
                     run(KS_GI_PREVIEW, ST_PASS_GI_PREVIEW_1, [&] { L.launch_gi_preview(a, pseed, 1u, a.gi_res[3], a.gi_res[0], cur); });
                     run(KS_GI_RESOLVING, ST_PASS_GI_RESOLVING, [&] { L.launch_gi_resolving(a, gi_source, cur); });
+                }
+                if (swap_gi_history) {  // the launches above were told not to copy (KArgs::gi_skip_history_copy)
+                    std::swap(c.plane[ST_BUF_GI_RESERVOIRS_0], c.plane[ST_BUF_GI_RESERVOIRS_1]);
+                    c.gi_aliased = true;
                 }
             };
             auto do_denoise = [&] {
@@ -1427,6 +1460,7 @@ int st_camera_set_rows(StEngine* e, StHandle h, uint32_t y0, uint32_t y1) {
     CameraState& s = *it->second;
     if (y0 == 0 && y1 == 0) { y1 = s.desc.height; }
     ST_REQUIRE(y0 < y1 && y1 <= s.desc.height, "bad row window");
+    if (E(e)->has_device) { ST_HIP(hipSetDevice(E(e)->device)); const int rc = materialize_gi_history(s); if (rc) return rc; }
     s.row0 = y0; s.row1 = y1;
     return ST_OK;
 }
@@ -1481,7 +1515,8 @@ int st_camera_read_buffer(StEngine* e, StHandle h, int id, void* out, size_t cap
     ST_REQUIRE(capacity >= c.plane_bytes[id], "buffer too small");
     ST_HIP(hipSetDevice(en->device));
     ST_HIP(hipDeviceSynchronize());
-    ST_HIP(hipMemcpy(out, c.plane[id], c.plane_bytes[id], hipMemcpyDeviceToHost));
+    const float4* src = (id == ST_BUF_GI_RESERVOIRS_1 && c.gi_aliased) ? c.plane[ST_BUF_GI_RESERVOIRS_0] : c.plane[id];
+    ST_HIP(hipMemcpy(out, src, c.plane_bytes[id], hipMemcpyDeviceToHost));
     return ST_OK;
 }
 int st_camera_write_buffer(StEngine* e, StHandle h, int id, const void* data, size_t bytes) {
@@ -1494,11 +1529,18 @@ int st_camera_write_buffer(StEngine* e, StHandle h, int id, const void* data, si
     ST_REQUIRE(bytes == c.plane_bytes[id], "size does not match the buffer");
     ST_HIP(hipSetDevice(en->device));
     ST_HIP(hipDeviceSynchronize());
+    { const int rc = materialize_gi_history(c); if (rc) return rc; }
     ST_HIP(hipMemcpy(c.plane[id], data, bytes, hipMemcpyHostToDevice));
     c.internal_dirty = true;
     return ST_OK;
 }
-int st_debug_set_pass_mask(StEngine* e, uint64_t mask) { ST_REQUIRE(e, "null engine"); E(e)->pass_mask = mask; return ST_OK; }
+int st_debug_set_pass_mask(StEngine* e, uint64_t mask) {
+    ST_REQUIRE(e, "null engine");
+    Engine* en = E(e);
+    if (en->has_device) { ST_HIP(hipSetDevice(en->device)); for (auto& kv : en->cameras) { const int rc = materialize_gi_history(*kv.second); if (rc) return rc; } }
+    en->pass_mask = mask;
+    return ST_OK;
+}
 int st_debug_last_launches(StEngine* e, uint64_t* out_bits, size_t capacity, size_t* count) {
     ST_REQUIRE(e && count, "null argument");
     const std::vector<uint64_t>& v = E(e)->last_launches;

@@ -53,7 +53,7 @@ ST_D float4 gi_resolve_pixel(const KArgs& a, U2 pos, uint32_t idx, const Hit& hi
     tex_write(a.gi_diff_samples, a, pos, diff);
     tex_write(a.gi_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
     const float4* in = source == 0u ? a.gi_res[1] : a.gi_res[2];
-    gi_write_own(a.gi_res[0], idx, gi_read_own(in, idx, true, true), true, true);  // the frame's source reservoir becomes next frame's history
+    if (!a.gi_skip_history_copy) gi_write_own(a.gi_res[0], idx, gi_read_own(in, idx, true, true), true, true);  // the frame's source reservoir becomes next frame's history
     return diff;
 }
 

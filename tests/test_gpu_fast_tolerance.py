@@ -203,3 +203,42 @@ def test_image_mode_statistics_match_the_exact_build():
     p = psnr(np.clip(fast_img, 0, peak), np.clip(exact_img, 0, peak), peak)
     assert p >= 40.0, f"PSNR {p:.1f} dB"
     assert abs(fast_img.mean() / exact_img.mean() - 1.0) <= 0.01, (fast_img.mean(), exact_img.mean())
+
+
+def test_gi_history_pointer_swap_is_unobservable_through_the_buffers():
+    """Fast build: on frames whose GI source is the temporal pass's output, gi_resolving's copy into GI_RESERVOIRS_0 is a
+    plane-pointer swap (st_engine.cpp `gi_aliased`). Two engines in lockstep, one with ST_NO_GI_ALIAS=1 (the copy as the
+    reference does it): after every frame both reservoir planes read back the same within the fast build's tolerance (the
+    reference's copy re-encodes each record, which moves a few normals by an ulp — tolerance, not bits), also across a
+    pass-mask / write_buffer seam in the middle, which must find real copies."""
+    torch = _torch()
+    size = (160, 96)
+    engines = []
+    for alias in (True, False):
+        if not alias:
+            os.environ["ST_NO_GI_ALIAS"] = "1"
+        try:
+            e = Engine(device=0, exact=False)
+        finally:
+            os.environ.pop("ST_NO_GI_ALIAS", None)
+        scenes.build_cornell(e); e.set_seed(21)
+        desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+        engines.append((e, e.create_camera(desc), torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")))
+    for frame in range(13):
+        for e, cam, out in engines:
+            e.update_camera(cam, desc); e.tick(); e.render_camera(cam, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for b in (Buffer.GI_RESERVOIRS_0, Buffer.GI_RESERVOIRS_1, Buffer.GI_DIFF_SAMPLES):
+            x, y = (e.read_buffer(cam, b) for e, cam, _ in engines)
+            close = np.isclose(x, y, rtol=RTOL, atol=ATOL) | (np.isnan(x) & np.isnan(y))
+            assert close.mean() >= 0.99, f"frame {frame} {b.name}: {1 - close.mean():.5f} of the floats differ between swap and copy"
+        if frame == 6:   # a debug seam in the middle: must not disturb the sequence
+            for e, cam, _ in engines:
+                e.set_pass_mask(0xFFFFFFFFFFFFFFFF); e.write_buffer(cam, Buffer.GI_RESERVOIRS_1, e.read_buffer(cam, Buffer.GI_RESERVOIRS_1))
+    imgs = [out.cpu().numpy()[..., :3] for _, _, out in engines]
+    assert np.isfinite(imgs[0]).all()
+    peak = float(np.percentile(imgs[1], 99.9))
+    p = psnr(np.clip(imgs[0], 0, peak), np.clip(imgs[1], 0, peak), peak)
+    assert p >= 40.0, f"frame 12 with and without the pointer swap: PSNR {p:.1f} dB"
+    for e, _, _ in engines:
+        e.close()
