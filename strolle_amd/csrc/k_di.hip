@@ -80,7 +80,8 @@ ST_D SpatialRecords di_spatial_pick_cell(const KArgs& a, uint32_t seed, U2 gid, 
         if (rhs.m != 0.0f) break;
     }
     out.wrote_d1 = true;
-    if (rhs.m == 0.0f) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return out; }
+    const bool store = !a.skip_dead_scratch;  // fused launch inside a whole denoised frame: the records travel in registers and the planes are rewritten before anything can read them
+    if (rhs.m == 0.0f) { if (store) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); } return out; }
     const float lhs_rhs_pdf = di_pdf_ex(lhs.s, light_get(a, lhs.s.light_id), rhs_hit);
     const float rhs_lhs_pdf = di_pdf_ex(rhs.s, light_get(a, rhs.s.light_id), lhs_hit);
     const Ray ray_a = lhs_rhs_pdf > 0.0f ? di_sample_ray(lhs.s, rhs_hit.point) : zero_ray();
@@ -89,8 +90,10 @@ ST_D SpatialRecords di_spatial_pick_cell(const KArgs& a, uint32_t seed, U2 gid, 
     out.wrote_d0 = true;
     out.a0 = f4(ray_a.origin, ray_a.len); out.a1 = make_float4(ea.x, ea.y, b2f(rhs_idx + 1u), 0.0f);
     out.b0 = f4(ray_b.origin, ray_b.len); out.b1 = make_float4(eb.x, eb.y, lhs_rhs_pdf, rhs_lhs_pdf);
-    tex_write(buf_d0, a, buf_pos_a, out.a0); tex_write(buf_d1, a, buf_pos_a, out.a1);
-    tex_write(buf_d0, a, buf_pos_b, out.b0); tex_write(buf_d1, a, buf_pos_b, out.b1);
+    if (store) {
+        tex_write(buf_d0, a, buf_pos_a, out.a0); tex_write(buf_d1, a, buf_pos_a, out.a1);
+        tex_write(buf_d0, a, buf_pos_b, out.b0); tex_write(buf_d1, a, buf_pos_b, out.b1);
+    }
     return out;
 }
 __global__ ST_KERNEL_BOUNDS void k_di_spatial_pick(const KArgs a, uint32_t seed) {
@@ -143,7 +146,8 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_sample(const KArgs a, uint32_t see
 // di_spatial_resampling.rs pick + trace + sample for one 2x1 checkerboard cell in one launch. The three passes of a cell talk
 // to each other only through that cell's two texels of the scratch planes, so the records and visibilities travel in
 // registers; they are still stored (later passes, or the next frame's stale reads, must find what the reference leaves
-// there), and a texel the pick stage did not write is read back from the plane, stale contents included.
+// there) unless the engine knows the rest of the frame rewrites all three planes (KArgs::skip_dead_scratch), and a texel the
+// pick stage did not write is read back from the plane, stale contents included.
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a_in, uint32_t seed_pick, uint32_t seed_sample) {
     ST_SCENE_PROLOGUE
@@ -171,7 +175,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a_in, uint32_t s
             rays += 1u; bytes += used_;
             vis[k] = make_float4(occluded ? 0.0f : 1.0f, r1.z, r1.w, 0.0f);
         }
-        tex_write(a.di_diff_stash, a, pos, vis[k]);
+        if (!a.skip_dead_scratch) tex_write(a.di_diff_stash, a, pos, vis[k]);
     }
     if (rays) count_rays_n(a, rays, bytes);
     if (own_lhs) di_spatial_sample_cell(a, seed_sample, gid, lhs_pos, vis[0], vis[1]);

@@ -428,6 +428,7 @@ struct Engine {
     std::vector<uint64_t> last_launches;  // pass bits of every launch the last render considered (st_debug_last_launches)
     uint64_t pass_mask = ~0ull;  // st_debug_set_pass_mask: which reference passes a render executes (parity tests run one launch at a time)
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
+    bool skip_scratch_stores = true;  // ST_KEEP_SCRATCH=1: the fused DI spatial launch stores its intermediate records as the three separate passes would
     bool alias_gi_history = true;  // ST_NO_GI_ALIAS=1: gi_resolving always copies the source reservoirs into the history plane
     bool fuse_wavelet = true;  // ST_NO_FUSE_WAVELET=1: strides 1 and 2 of the a-trous chain as two launches
     bool fuse_spatial = true;  // ST_NO_FUSE_SPATIAL=1: DI spatial resampling as three launches
@@ -460,6 +461,7 @@ struct Engine {
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* k = getenv("ST_NO_FUSE_WAVELET")) fuse_wavelet = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_GI_ALIAS")) alias_gi_history = atoi(k) == 0;
+        if (const char* k = getenv("ST_KEEP_SCRATCH")) skip_scratch_stores = atoi(k) == 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
         if (const char* nd = getenv("ST_NO_DOUBLE_BUFFER")) double_buffer = atoi(nd) == 0;
         if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
@@ -1070,6 +1072,9 @@ struct Engine {
             const bool swap_gi_history = alias_gi_history && arithmetic == ST_ARITH_FAST && gi_runs && whole_graph && gi_source == 0u;
             if (gi_runs && whole_graph) c.gi_aliased = false;  // this frame's temporal pass rewrites GI_RESERVOIRS_1 completely
             a.gi_skip_history_copy = swap_gi_history ? 1u : 0u;
+            // di_spatial's scratch records (di_diff_samples / curr_colors / stash as the reference binds them) are dead stores
+            // when the fused launch is followed by resolving, denoise-reproject and the a-trous chain of the same frame
+            a.skip_dead_scratch = (skip_scratch_stores && whole_graph && fuse && fuse_spatial && ((((a.width + 7u) / 8u) & 1u) == 0u) && needs_di && denoise && any_objects) ? 1u : 0u;
 
             auto do_prim = [&] {
                 if (fuse && any_objects) run(KS_PRIM_VISIBILITY_REPROJECTION, ST_PASS_PRIM_VISIBILITY | ST_PASS_FRAME_REPROJECTION, [&] { L.launch_prim_visibility(a, true, cur); });
