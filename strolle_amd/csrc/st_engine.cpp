@@ -252,7 +252,7 @@ struct CameraState {
     // plane pointers instead: GI_RESERVOIRS_0 takes over the storage temporal resampling wrote, and GI_RESERVOIRS_1 — which
     // the next temporal pass overwrites completely before anything reads it — gets the old history's storage. Until then
     // reading GI_RESERVOIRS_1 back returns GI_RESERVOIRS_0's storage (`gi_aliased`; st_camera_read_buffer), and anything
-    // that could observe the difference (a pass mask, st_camera_write_buffer, a row window) first makes the copy for real
+    // that could observe the difference (a pass mask, st_camera_write_buffer) first makes the copy for real
     // (`materialize_gi_history`).
     bool gi_aliased = false;
     bool internal_dirty = false;  // st_camera_write_buffer replaced a plane the internal planes derive from: regenerate them before the next frame
@@ -1063,7 +1063,7 @@ struct Engine {
             const uint32_t gi_source = (tracing && c.frame % 2u == 1u) ? 1u : 0u;
             const uint32_t pseed = seed(SEED_GI_PREVIEW);  // one seed for both preview passes (passes/gi_preview_resampling.rs:60-74)
             // GI history hand-over by pointer swap instead of gi_resolving's copy (CameraState::gi_aliased says when)
-            const bool whole_graph = pass_mask == ~0ull && c.row0 == 0u && c.row1 == c.desc.height;
+            const bool whole_graph = pass_mask == ~0ull;  // a row window (multi-GPU band) changes which pixels a pass owns, not which passes follow it
             const bool gi_runs = needs_gi && any_objects;
             if (c.gi_aliased && gi_runs && !whole_graph) { const int rc = materialize_gi_history(c); if (rc) return rc; }
             // Fast build only: the reference's copy is a decode + re-encode of every reservoir, which is not the identity on all
@@ -1465,7 +1465,6 @@ int st_camera_set_rows(StEngine* e, StHandle h, uint32_t y0, uint32_t y1) {
     CameraState& s = *it->second;
     if (y0 == 0 && y1 == 0) { y1 = s.desc.height; }
     ST_REQUIRE(y0 < y1 && y1 <= s.desc.height, "bad row window");
-    if (E(e)->has_device) { ST_HIP(hipSetDevice(E(e)->device)); const int rc = materialize_gi_history(s); if (rc) return rc; }
     s.row0 = y0; s.row1 = y1;
     return ST_OK;
 }

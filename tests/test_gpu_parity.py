@@ -846,3 +846,36 @@ def test_c_example_renders_the_cornell_box(tmp_path):
     # left wall red, right wall green (the Cornell box): the walls' colour channels dominate on their side
     left, right = img[100:140, 10:40].mean((0, 1)), img[100:140, 280:310].mean((0, 1))
     assert left[0] > left[1] and right[1] > right[0], (left, right)
+
+
+def test_profile_flags_timing_and_traversal_bytes():
+    """st_profile_enable bit 0 = per-kernel event timing, bit 1 = the tracing kernels also sum the reference's `used_memory`
+    over their rays (off by default: it costs a cross-lane reduction per ray). Rays are counted either way, identically."""
+    torch = _torch()
+    size = (160, 96)
+    e = Engine(device=0)
+    scenes.build_cornell(e); e.set_seed(5)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    cam = e.create_camera(desc)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+
+    def frames(n):
+        for _ in range(n):
+            e.update_camera(cam, desc); e.tick(); e.render_camera(cam, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    frames(6)
+    rays = {}
+    for flags in (0, 1, 2, 3):
+        e.profile_enable(flags); e.profile_read(reset=True); e.ray_count(cam, reset=True)
+        frames(6)
+        prof = e.profile_read(reset=True)
+        rays[flags] = e.ray_count(cam)
+        timed = sum(p["total_ms"] for p in prof) > 0.0
+        traversal = sum(p["traversal_bytes"] for p in prof)
+        assert timed == bool(flags & 1), (flags, prof)
+        assert (traversal > 0) == bool(flags & 2), (flags, traversal)
+        if flags & 2:   # every traced ray reads at least the root: 16 B + one internal node's 48 B
+            assert traversal >= 64 * rays[flags]
+    e.profile_enable(0)
+    assert rays[0] > 0 and rays[0] >= size[0] * size[1] * 6
+    e.close()
