@@ -48,7 +48,8 @@ ST_D U2 pixel_in_tile(TileCoord t) {
     return u2(t.x * 8u + (lane & 7u), t.y * 8u + (lane >> 3));
 }
 // Traversal stack in LDS, [wave][entry][lane] (consecutive lanes -> consecutive banks). Entries are BVH stream indices:
-// streams shorter than 65536 float4 (Cornell: 124, dungeon: ~35 k) use 16-bit entries, which halves the LDS footprint
+// entry numbers (byte offset / 64): device streams of fewer than 65536 entries (Cornell: 55, dungeon: ~26 k) use 16-bit
+// stack slots, which halves the LDS footprint
 // (12 KiB per 4-wave block) and lifts the LDS cap on occupancy from 6 to 8 waves per SIMD.
 template <class SE>
 ST_D SE* lane_stack(SE* lds) { return lds + (threadIdx.x >> 6) * (kBvhStackSize * 64) + (threadIdx.x & 63u); }
@@ -416,7 +417,8 @@ ST_D AnyHitState any_hit_begin() { AnyHitState s; s.ptr = 0u; s.sp = 0; s.used_m
 // One iteration of the loop in two parts: the entry fetch and the arithmetic.
 // (Measured and dropped, round 2: running the two shadow rays of a spatial-resampling cell interleaved in one loop, with
 // both fetch chains overlapped — 144 VGPRs, 3 waves per SIMD, di_spatial 127 -> 175 us on Cornell, 154 -> 188 us on the
-// dungeon. Traversal here is bound by VALU issue under lane divergence, not by its chain of dependent fetches.)
+// dungeon. The loop is bound by instruction issue — about 45 VALU and 25 SALU instructions per step, DESIGN.md section 4
+// "What a SIMD can issue" — and by lane divergence, not by the latency of its fetches once those are one round trip.)
 struct NodeFetch { float4 d0, d1, d2, d3; };
 ST_D void any_hit_fetch_node(const KArgs& a, const AnyHitState& st, NodeFetch& f) {
     const float4* entry = bvh_entry(a.bvh, st.ptr);
