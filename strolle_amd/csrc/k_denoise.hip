@@ -84,9 +84,19 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
     const bool mine = tc.valid && owns_pixel(a, pos);
     const uint32_t center = pos.y * a.width + pos.x;
     float4 csn = f4z(), cdi = f4z(), cdi_m = f4z(), cgi = f4z(), cgi_m = f4z();
-    if (mine) { csn = a.sn[center]; cdi = a.di_diff_curr_colors[center]; cdi_m = a.di_diff_moments[center]; cgi = a.gi_diff_curr_colors[center]; cgi_m = a.gi_diff_moments[center]; }
-    const bool slow = mine && csn.w != 0.0f && !(cdi_m.x >= 4.0f);
-    if (__syncthreads_or(slow ? 1 : 0)) {
+    bool slow;
+    if (a.variance_in_reproject) {
+        // The reproject stages have already stored the long-history variance in the colour texels' w (st_passes.h
+        // denoise_reproject_finish) and flagged the short-history pixels: this launch only serves those, in place. A block
+        // without any leaves after one 8-byte load per wave.
+        slow = mine && ((a.tile_mask[tile_mask_index(a, pos)] >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+        if (!__syncthreads_or(slow ? 1 : 0)) return;
+        if (slow) { csn = a.sn[center]; cdi = a.di_diff_curr_colors[center]; cgi = a.gi_diff_curr_colors[center]; }
+    } else {
+        if (mine) { csn = a.sn[center]; cdi = a.di_diff_curr_colors[center]; cdi_m = a.di_diff_moments[center]; cgi = a.gi_diff_curr_colors[center]; cgi_m = a.gi_diff_moments[center]; }
+        slow = mine && csn.w != 0.0f && !(cdi_m.x >= 4.0f);
+    }
+    if (a.variance_in_reproject || __syncthreads_or(slow ? 1 : 0)) {
         const int32_t bx0 = (int32_t)((tc.x - wave) * 8u) - 3, by0 = (int32_t)(tc.y * 8u) - 2;
         for (int i = (int)threadIdx.x; i < RW * RH; i += kBlockThreads) {
             const int ry = i / RW, rx = i - ry * RW;
@@ -101,6 +111,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
         }
         __syncthreads();
     }
+    if (a.variance_in_reproject && !slow) return;
     if (!mine) return;
     if (csn.w == 0.0f) { di_out[center] = cdi; gi_out[center] = cgi; return; }  // sky
     const float cdi_luma = luma(xyz(cdi)), cgi_luma = luma(xyz(cgi));
@@ -139,6 +150,11 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
     }
     di_var = fmax_(di_var, 0.0f);
     gi_var = fmax_(gi_var, 0.0f);
+    if (a.variance_in_reproject) {  // in place, the w component only: other blocks are staging these texels' colours right now
+        reinterpret_cast<float*>(&di_out[center])[3] = di_var;
+        reinterpret_cast<float*>(&gi_out[center])[3] = gi_var;
+        return;
+    }
     di_out[center] = f4(xyz(cdi), di_var);
     gi_out[center] = f4(xyz(cgi), gi_var);
 }

@@ -221,7 +221,13 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     tex_write(a.di_diff_samples, a, pos, diff);
     tex_write(a.di_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
     di_write(a.di_res[0], idx, res);
-    if (REPROJECT) denoise_reproject_finish(a, pos, diff, history, a.di_diff_curr_colors, a.di_diff_moments);
+    if (REPROJECT) {
+        const bool short_history = denoise_reproject_finish(a, pos, diff, history, a.di_diff_curr_colors, a.di_diff_moments);
+        if (a.variance_in_reproject) {  // tell the variance kernel which pixels of this tile still need it
+            const unsigned long long flagged = __ballot(short_history), active = __ballot(true);
+            if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) a.tile_mask[tile_mask_index(a, pos)] = flagged;
+        }
+    }
 }
 void launch_di_resolving(const KArgs& a, bool reproject, hipStream_t s) {
     if (reproject) ST_LAUNCH_TRACE_B(k_di_resolving, true, false, s, a); else ST_LAUNCH_TRACE_B(k_di_resolving, false, false, s, a);

@@ -238,6 +238,7 @@ struct CameraState {
     void* slab = nullptr; size_t slab_bytes = 0;
     float4* plane[ST_BUF_COUNT + kInternalPlanes] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
     size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
+    unsigned long long* tile_mask = nullptr;  // one u64 per 8x8 tile (KArgs::tile_mask)
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
     // The two-stream frame pipeline (render()) belongs to the camera: its side stream and the events that order frame N+1's
@@ -428,6 +429,7 @@ struct Engine {
     std::vector<uint64_t> last_launches;  // pass bits of every launch the last render considered (st_debug_last_launches)
     uint64_t pass_mask = ~0ull;  // st_debug_set_pass_mask: which reference passes a render executes (parity tests run one launch at a time)
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
+    bool variance_in_reproject = true;  // ST_NO_VARIANCE_IN_REPROJECT=1: estimate_variance as its own full-screen pass
     bool skip_scratch_stores = true;  // ST_KEEP_SCRATCH=1: the fused DI spatial launch stores its intermediate records as the three separate passes would
     bool alias_gi_history = true;  // ST_NO_GI_ALIAS=1: gi_resolving always copies the source reservoirs into the history plane
     bool fuse_wavelet = true;  // ST_NO_FUSE_WAVELET=1: strides 1 and 2 of the a-trous chain as two launches
@@ -462,6 +464,7 @@ struct Engine {
         if (const char* k = getenv("ST_NO_FUSE_WAVELET")) fuse_wavelet = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_GI_ALIAS")) alias_gi_history = atoi(k) == 0;
         if (const char* k = getenv("ST_KEEP_SCRATCH")) skip_scratch_stores = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_VARIANCE_IN_REPROJECT")) variance_in_reproject = atoi(k) == 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
         if (const char* nd = getenv("ST_NO_DOUBLE_BUFFER")) double_buffer = atoi(nd) == 0;
         if (const char* tt = getenv("ST_TICK_TIMING")) tick_timing = atoi(tt) != 0;
@@ -494,6 +497,8 @@ struct Engine {
     static void release_camera(CameraState& c) {
         if (c.slab) (void)hipFree(c.slab);
         if (c.counters) (void)hipFree(c.counters);
+        if (c.tile_mask) (void)hipFree(c.tile_mask);
+        c.tile_mask = nullptr;
         c.slab = nullptr; c.counters = nullptr;
         if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
         for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
@@ -924,6 +929,11 @@ struct Engine {
             return fail(ST_ERR_HIP, "hipMalloc(camera counters) failed");
         }
         ST_HIP(hipMemset(c.counters, 0, kCounterBytes));
+        {
+            const size_t tiles = (size_t)((c.desc.width + 7u) / 8u) * ((c.desc.height + 7u) / 8u);
+            if (hipMalloc(reinterpret_cast<void**>(&c.tile_mask), tiles * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); c.tile_mask = nullptr; release_camera(c); return fail(ST_ERR_HIP, "hipMalloc(camera tile mask) failed"); }
+            ST_HIP(hipMemset(c.tile_mask, 0, tiles * sizeof(unsigned long long)));
+        }
         memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
         ST_HIP(hipDeviceSynchronize());  // the clears run on the null stream; renders may use any stream
         return ST_OK;
@@ -1072,6 +1082,10 @@ struct Engine {
             const bool swap_gi_history = alias_gi_history && arithmetic == ST_ARITH_FAST && gi_runs && whole_graph && gi_source == 0u;
             if (gi_runs && whole_graph) c.gi_aliased = false;  // this frame's temporal pass rewrites GI_RESERVOIRS_1 completely
             a.gi_skip_history_copy = swap_gi_history ? 1u : 0u;
+            // estimate_variance's long-history branch rides in the fused reproject stages (st_passes.h denoise_reproject_finish);
+            // the variance launch then serves the short-history pixels only, in place, and the strides-1+2 launch reads curr_colors
+            a.tile_mask = c.tile_mask;
+            a.variance_in_reproject = (variance_in_reproject && whole_graph && fuse && fuse_wavelet && denoise && needs_di && needs_gi && any_objects && c.tile_mask) ? 1u : 0u;
             // di_spatial's scratch records (di_diff_samples / curr_colors / stash as the reference binds them) are dead stores
             // when the fused launch is followed by resolving, denoise-reproject and the a-trous chain of the same frame
             a.skip_dead_scratch = (skip_scratch_stores && whole_graph && fuse && fuse_spatial && ((((a.width + 7u) / 8u) & 1u) == 0u) && needs_di && denoise && any_objects) ? 1u : 0u;
@@ -1166,7 +1180,9 @@ struct Engine {
                     // output over in an internal pair of planes (k_denoise.hip k_denoise_wavelet_12 says why), so the stash
                     // planes receive the stride-2 result directly. One group = one set of pass bits (st_debug_set_pass_mask).
                     const uint64_t group = ST_PASS_DENOISE_VARIANCE | ST_PASS_DENOISE_WAVELET_0 | ((uint64_t)ST_PASS_DENOISE_WAVELET_0 << 1);
-                    float4* tmp_di = P(ST_BUF_COUNT + 2); float4* tmp_gi = P(ST_BUF_COUNT + 3);
+                    // (with KArgs::variance_in_reproject the hand-over planes are the reproject stages' own outputs)
+                    float4* tmp_di = a.variance_in_reproject ? a.di_diff_curr_colors : P(ST_BUF_COUNT + 2);
+                    float4* tmp_gi = a.variance_in_reproject ? a.gi_diff_curr_colors : P(ST_BUF_COUNT + 3);
                     run(KS_DENOISE_VARIANCE, group, [&] { L.launch_denoise_variance(a, tmp_di, tmp_gi, cur); });
                     run(KS_DENOISE_WAVELET_12, group, [&] { L.launch_denoise_wavelet_12(a, 1.0f, 2.0f, tmp_di, di[1], di[0], tmp_gi, gi[1], gi[0], cur); });
                     first = 2;

@@ -19,8 +19,12 @@ ST_D ReprojectHistory denoise_reproject_prefetch(const KArgs& a, U2 pos, const f
     if (rp.confidence > 0.0f) { h.have = true; h.pc = bilinear_reproject(a, rp, prev_colors); h.pm = bilinear_reproject(a, rp, prev_moments); }
     return h;
 }
-ST_D void denoise_reproject_finish(const KArgs& a, U2 pos, float4 sample, const ReprojectHistory& h, float4* colors, float4* moments) {
-    if (h.sky) { tex_write(colors, a, pos, sample); return; }
+// Returns true where estimate_variance will take its short-history path for this pixel (frame_denoising.rs:118-121; decided
+// by the DIRECT signal's history length, so only the DI caller's answer means anything). With KArgs::variance_in_reproject
+// the long-history variance (frame_denoising.rs:122-126: second moment - first moment squared, clamped at 0) rides in the
+// colour texel's w, where estimate_variance would put it: the plane is rewritten by the a-trous chain before the frame ends.
+ST_D bool denoise_reproject_finish(const KArgs& a, U2 pos, float4 sample, const ReprojectHistory& h, float4* colors, float4* moments) {
+    if (h.sky) { tex_write(colors, a, pos, sample); return false; }
     const float sample_luma = luma(xyz(sample));
     V3 color, moment;
     if (h.have && sample.w > 0.0f) {
@@ -33,9 +37,13 @@ ST_D void denoise_reproject_finish(const KArgs& a, U2 pos, float4 sample, const 
         color = xyz(sample);
         moment = v3(1.0f, sample_luma, sample_luma * sample_luma);
     }
-    tex_write(colors, a, pos, f4(color, 0.0f));
+    const float variance = a.variance_in_reproject ? fmax_(moment.z - sqr(moment.y), 0.0f) : 0.0f;
+    tex_write(colors, a, pos, f4(color, variance));
     tex_write(moments, a, pos, f4(moment, 0.0f));
+    return !(moment.x >= 4.0f);
 }
+// one bit per pixel of an 8x8 tile (bit = lane = pixel_in_tile's numbering), one word per tile
+ST_D uint32_t tile_mask_index(const KArgs& a, U2 pos) { return (pos.y >> 3) * ((a.width + 7u) >> 3) + (pos.x >> 3); }
 ST_D void denoise_reproject_pixel(const KArgs& a, U2 pos, float4 sample, const float4* prev_colors, const float4* prev_moments, float4* colors, float4* moments) {
     denoise_reproject_finish(a, pos, sample, denoise_reproject_prefetch(a, pos, prev_colors, prev_moments), colors, moments);
 }
