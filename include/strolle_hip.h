@@ -228,8 +228,10 @@ int st_debug_set_pass_mask(StEngine* e, uint64_t mask);
 int st_debug_last_launches(StEngine* e, uint64_t* out_bits, size_t capacity, size_t* count);
 /* Rays traced for this camera since the last reset (device counters, closest-hit + any-hit). */
 int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
-/* Host-side copies of what st_tick uploads: what = 0 BVH stream (float4), 1 triangles in the reference's
- * 144-B layout, 2 lights (112 B), 3 materials (112 B). Works on host-only engines. */
+/* Host-side copies of what st_tick uploads: what = 0 BVH stream as the reference's serializer writes it (float4), 1
+ * triangles in the reference's 144-B layout, 2 lights (112 B), 3 materials (112 B), 4 the BVH stream in its device form
+ * (every entry four float4: internal nodes with the far child's byte offset, leaf entries followed by the triangle's
+ * hit-test record; st_types.h). Works on host-only engines. */
 int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written);
 int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame);
 /* Where an image sits in the 8192-wide atlas: x, y, width, height in texels (images.rs:115-124 `lookup`). */

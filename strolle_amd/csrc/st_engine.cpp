@@ -1611,6 +1611,7 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
         case 1: p = en->triangles.data(); bytes = en->triangles.size() * sizeof(HostTriangle); break;
         case 2: p = en->gpu_lights.data(); bytes = en->gpu_lights.size() * sizeof(GpuLight); break;
         case 3: p = en->gpu_materials.data(); bytes = en->gpu_materials.size() * sizeof(GpuMaterial); break;
+        case 4: en->expand_stream(); p = en->bvh_upload_.data(); bytes = (size_t)en->device_bvh_len * sizeof(float4); break;  // as st_tick would upload it now
         default: return fail(ST_ERR_INVALID_ARGUMENT, "unknown scene buffer");
     }
     if (written) *written = bytes;

@@ -100,6 +100,40 @@ def test_bvh_stream_contract():
     assert seen_tris == set(range(32)), "every Cornell triangle is referenced exactly by the leaves"
 
 
+@pytest.mark.parametrize("scene", ["cornell", "soup", "dungeon"])
+def test_device_bvh_stream_is_the_serializers_stream_relaid(scene):
+    """The device form of the BVH stream (st_types.h "device BVH stream", read_scene(4)): every entry 64 B, an internal node
+    as the serializer wrote it with the far pointer turned into a byte offset, a leaf entry followed by its triangle's
+    hit-test record (v0, v1 - v0, v2 - v0 of the reference's 144-B triangle). Walking both forms in lockstep must visit the
+    same nodes, boxes, flags, triangles and materials."""
+    prod = Engine(device=-1)
+    {"cornell": scenes.build_cornell, "soup": lambda e: scenes.build_random_soup(e, 700, seed=3), "dungeon": scenes.build_dungeon}[scene](prod)
+    prod.tick()
+    ref = prod.read_scene(0).reshape(-1, 4); rb = ref.view(np.uint32)
+    dev = prod.read_scene(4).reshape(-1, 4); db = dev.view(np.uint32)
+    tris = prod.read_scene(1).reshape(-1, 36)   # 144-B triangles: d0..d8
+    assert len(dev) % 4 == 0
+    # entry k of the device stream <-> k-th entry (internal node or leaf entry) of the serializer's stream, in stream order
+    starts, p = [], 0
+    while p < len(ref):
+        starts.append(p)
+        p += 4 if rb[p, 3] == 0 else 1
+    assert len(dev) == 4 * len(starts)
+    where = {p: k for k, p in enumerate(starts)}
+    for k, p in enumerate(starts):
+        d = dev[4 * k:4 * k + 4]; u = db[4 * k:4 * k + 4]
+        if rb[p, 3] == 0:
+            assert u[0, 3] == 0
+            assert np.array_equal(d[:, :3].view(np.uint32), ref[p:p + 4, :3].view(np.uint32)), "child boxes"
+            assert u[1, 3] == 64 * where[int(rb[p + 1, 3])], "far pointer = byte offset of the far child's entry"
+            assert where[p + 4] == k + 1, "the near child is the next entry"
+        else:
+            assert np.array_equal(u[0], rb[p]), "leaf entry texel"
+            t = tris[int(rb[p, 1])]
+            v0, v1, v2 = t[0:3], t[12:15], t[24:27]   # triangle.rs:9-21: (position, uv.x) (normal, uv.y) (tangent) per vertex
+            assert np.array_equal(d[1, :3], v0) and np.array_equal(d[2, :3], v1 - v0) and np.array_equal(d[3, :3], v2 - v0)
+
+
 def test_light_table_remap_and_kill_equal_oracle():
     """lights.rs:97-154: removing a light shifts later slots, marks the killed slot 0xcafebabe and the remapped ones."""
     prod, orac = Engine(device=-1), OracleEngine()
