@@ -1078,7 +1078,7 @@ struct Engine {
             if (c.gi_aliased && gi_runs && !whole_graph) { const int rc = materialize_gi_history(c); if (rc) return rc; }
             // Fast build only: the reference's copy is a decode + re-encode of every reservoir, which is not the identity on all
             // bit patterns (the octahedral normal of a few records per frame moves by an ulp), and the exact build owes the
-            // oracle those bits.
+            // parity suite those bits.
             const bool swap_gi_history = alias_gi_history && arithmetic == ST_ARITH_FAST && gi_runs && whole_graph && gi_source == 0u;
             if (gi_runs && whole_graph) c.gi_aliased = false;  // this frame's temporal pass rewrites GI_RESERVOIRS_1 completely
             a.gi_skip_history_copy = swap_gi_history ? 1u : 0u;
