@@ -201,7 +201,11 @@ enum StBufferId {
     ST_BUF_COUNT = 36
 };
 /* Synchronises the device, then copies a per-camera buffer (camera_controller/buffers.rs:7-51) to host
- * memory. out == NULL: only report the size in *written. */
+ * memory. out == NULL: only report the size in *written.
+ * After a frame every buffer holds what the reference's pass graph leaves in it — bit for bit in the exact build, within
+ * the documented tolerance in the fast build, with one stated difference there: on frames whose GI source is the temporal
+ * pass's output the history plane GI_RESERVOIRS_0 is that output itself (a pointer swap) instead of the reference's
+ * decoded-and-re-encoded copy of it, so a few normals per frame differ by an ulp between the two planes' read-backs. */
 int st_camera_read_buffer(StEngine* e, StHandle camera, int buffer_id, void* out, size_t capacity, size_t* written);
 /* The inverse of st_camera_read_buffer: overwrite a per-camera buffer with host data (`bytes` must be the buffer's size).
  * With st_debug_set_pass_mask this lets a test hand one launch exactly the inputs the oracle's pass saw, so the fast
