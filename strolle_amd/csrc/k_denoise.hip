@@ -161,8 +161,9 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
 void launch_denoise_variance(const KArgs& a, float4* di_out, float4* gi_out, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a, di_out, gi_out); }
 
 // ---------------------------------------------------------------- frame_denoising.rs:219-361 (five à-trous passes)
-// Measured (rocprofv3, MI355X): these passes are bound by the bytes they move, not by arithmetic — in the fast build a wave
-// spends under 10 % of its life issuing VALU work. So the layout below is about traffic:
+// Measured (rocprofv3, MI355X): the LDS-staged passes run at 70-75 % of their VALU issue time and within 10-30 % of the
+// device-copy rate at once, the gather passes are bound by address processing. The layout below
+// keeps the traffic at the compulsory bytes:
 //   * strides 1 and 2 run as ONE launch (k_denoise_wavelet_12): a block stages the (32+6) x (16+6) window of its 32x16
 //     pixels once, runs the stride-1 pass for the (32+4) x (16+4) pixels the stride-2 taps will touch, keeps those results
 //     in LDS, and runs the stride-2 pass from there. Both outputs are stored (the first pass's output is next frame's colour
