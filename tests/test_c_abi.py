@@ -134,6 +134,46 @@ def test_device_bvh_stream_is_the_serializers_stream_relaid(scene):
             assert np.array_equal(d[1, :3], v0) and np.array_equal(d[2, :3], v1 - v0) and np.array_equal(d[3, :3], v2 - v0)
 
 
+def test_device_bvh_stream_edge_cases():
+    """Empty scene, a scene whose tree is a single leaf, and a scene that changes between ticks (refit and rebuild): the
+    device form always has four float4 per entry of the serializer's stream and follows it."""
+    from strolle_amd import Instance, Material, Mesh
+
+    def entries(e):
+        ref = e.read_scene(0).reshape(-1, 4).view(np.uint32)
+        n, p = 0, 0
+        while p < len(ref):
+            p += 4 if ref[p, 3] == 0 else 1
+            n += 1
+        return n
+
+    e = Engine(device=-1)
+    e.tick()
+    assert e.read_scene(0).size == 0 and e.read_scene(4).size == 0
+    e.insert_material(1, Material(base_color=(0.5, 0.5, 0.5, 1.0)))
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+    nrm = np.tile(np.array([[[0, 0, 1]]], np.float32), (1, 3, 1))
+    e.insert_mesh(1, Mesh(tri, nrm))
+    eye = np.concatenate([np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32)], axis=1)
+    e.insert_instance(1, Instance(1, 1, eye))
+    e.tick()
+    dev = e.read_scene(4).reshape(-1, 4)
+    assert entries(e) == 1 and dev.shape == (4, 4), "one triangle: one leaf entry, no internal node"
+    assert dev.view(np.uint32)[0, 3] != 0 and np.array_equal(dev[1:, :3], np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32))
+    for refit in (False, True):
+        e.set_bvh_refresh(refit)
+        for k in range(3):
+            more = tri + np.float32(2 + k)
+            e.insert_mesh(10 + k, Mesh(more, nrm)); e.insert_instance(10 + k, Instance(10 + k, 1, eye))
+            e.tick()
+            assert e.read_scene(4).size == 16 * entries(e)
+        for k in range(3):
+            e.remove_instance(10 + k); e.remove_mesh(10 + k)
+        e.tick()
+        assert e.read_scene(4).size == 16 * entries(e) == 16
+    e.close()
+
+
 def test_light_table_remap_and_kill_equal_oracle():
     """lights.rs:97-154: removing a light shifts later slots, marks the killed slot 0xcafebabe and the remapped ones."""
     prod, orac = Engine(device=-1), OracleEngine()
