@@ -431,6 +431,7 @@ struct Engine {
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
     bool variance_in_reproject = true;  // ST_NO_VARIANCE_IN_REPROJECT=1: estimate_variance as its own full-screen pass
     bool skip_scratch_stores = true;  // ST_KEEP_SCRATCH=1: the fused DI spatial launch stores its intermediate records as the three separate passes would
+    bool di_head_on_main = true;  // ST_DI_HEAD_ON_MAIN=0: DI sampling + temporal on the side stream (behind primary visibility) instead of the caller's
     bool alias_gi_history = true;  // ST_NO_GI_ALIAS=1: gi_resolving always copies the source reservoirs into the history plane
     bool fuse_wavelet = true;  // ST_NO_FUSE_WAVELET=1: strides 1 and 2 of the a-trous chain as two launches
     bool fuse_spatial = true;  // ST_NO_FUSE_SPATIAL=1: DI spatial resampling as three launches
@@ -463,6 +464,7 @@ struct Engine {
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* k = getenv("ST_NO_FUSE_WAVELET")) fuse_wavelet = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_GI_ALIAS")) alias_gi_history = atoi(k) == 0;
+        if (const char* k = getenv("ST_DI_HEAD_ON_MAIN")) di_head_on_main = atoi(k) != 0;
         if (const char* k = getenv("ST_KEEP_SCRATCH")) skip_scratch_stores = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_VARIANCE_IN_REPROJECT")) variance_in_reproject = atoi(k) == 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
@@ -1201,12 +1203,13 @@ struct Engine {
             // per-kernel profiling runs the graph serially on `stream`: a launch's event pair then times that kernel alone,
             // not the kernels of the other stream it would share the chip with
             if (overlap && !profiling && needs_di && needs_gi && any_objects) {
-                // Two streams, software-pipelined across frames and balanced (≈ 0.7 ms of kernels each at 1080p): `side`
-                // carries primary visibility, DI sampling + temporal resampling and the GI chain; `stream` carries the DI
-                // spatial passes + resolving, the denoiser and composition. Events express the true data dependencies only,
-                // so the reservoir passes of frame N+1 overlap the denoiser of frame N:
+                // Two streams, software-pipelined across frames: `side` carries primary visibility and the GI chain; `stream`
+                // carries the DI passes (sampling + temporal resampling too, by default: measured 1.2 % on the dungeon, nothing
+                // on Cornell, against running them behind primary visibility on `side`), the denoiser and composition. Events
+                // express the true data dependencies only, so the reservoir passes of frame N+1 overlap the denoiser of frame N:
                 //   prim(N+1)      after DI tail(N)       — it overwrites frame N's "previous" G-buffer + the reprojection map
                 //   GI tail(N+1)   after frame N is done  — it writes gi sample/colour/moment planes the denoiser + composition read
+                //   DI head(N+1)   after prim(N+1)        (ev_di_head)
                 //   DI tail(N+1)   after DI head(N+1)     (and after frame N's composition by stream order: its scratch aliases
                 //                                          the denoiser's planes)
                 //   denoiser(N+1)  after GI tail(N+1)
@@ -1225,14 +1228,15 @@ struct Engine {
                 if (c.have_prev_frame_events) ST_HIP(hipStreamWaitEvent(c.side_stream, c.ev_prim_ok, 0));
                 cur = c.side_stream;
                 do_prim();
-                do_di_head();
-                ST_HIP(hipEventRecord(c.ev_di_head, c.side_stream));  // primary visibility + DI head of this frame are through
+                if (!di_head_on_main) do_di_head();
+                ST_HIP(hipEventRecord(c.ev_di_head, c.side_stream));  // primary visibility (+ DI head) of this frame are through
                 do_gi_head();
                 if (c.have_prev_frame_events) ST_HIP(hipStreamWaitEvent(c.side_stream, c.ev_frame_done, 0));
                 do_gi_tail();
                 ST_HIP(hipEventRecord(c.ev_gi_done, c.side_stream));
                 cur = stream;
                 ST_HIP(hipStreamWaitEvent(stream, c.ev_di_head, 0));
+                if (di_head_on_main) do_di_head();
                 do_di_tail();
                 // stand-alone denoise reprojection kernels (unfused path) still read the reprojection map: prim(N+1) may
                 // only start once they are through
