@@ -370,14 +370,80 @@ void launch_gi_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_s
 // for the same pixel right here. Resolving consumes exactly what this pass would have stored at gi_res[0][pixel] — the merged
 // reservoir, an empty one on sky, or (the reference's early `return`, :84-86) whatever gi_res[0] already held — and then
 // overwrites that slot with the frame's source reservoir, so the intermediate store is dropped.
+// One preview pass for one pixel (gi_preview_resampling.rs:60-128). `center`: the pixel's reservoir as the pass loads it;
+// `center_hit`: the pixel's Hit if `hit_ready`, otherwise it is rebuilt here, and only when a neighbour is actually drawn.
+// keep_stored: the reference's early `return` (:84-86) — the output slot keeps its previous contents.
+struct PreviewPass { GiReservoir r; bool keep_stored; uint32_t max_samples; };
+ST_D PreviewPass gi_preview_pass(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, U2 center_pos, bool center_some, const GiReservoir& center,
+                                 Hit center_hit, bool hit_ready) {
+    PreviewPass o; o.r = gi_empty(); o.keep_stored = false; o.max_samples = 0u;
+    if (!center_some) return o;
+    const uint32_t n = a.width * a.height;
+    WhiteNoise wn = white_noise(seed, center_pos);
+    float main_pdf = 0.0f;
+    if (res_merge(o.r, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
+    const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, o.r.m * 0.125f));
+    o.max_samples = max_samples;
+    if (!hit_ready && max_samples > 0u) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
+    const float max_radius = nth == 0u ? 128.0f : 64.0f;
+    uint32_t sample_nth = 0u;
+    while (sample_nth < max_samples) {
+        sample_nth += 1u;
+        const V2 disk = wn.sample_disk();
+        const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
+        if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) { o.keep_stored = true; break; }  // sic: `return`, not `continue`
+        const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
+        if (ss.depth == 0.0f) continue;
+        if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
+        if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
+        const GiReservoir s = gi_read(in, screen_to_idx(a, sample_pos), n);
+        if (s.m == 0.0f) continue;
+        const float sample_pdf = gi_pdf(s.s, center_hit);
+        float sample_jacobian = gi_jacobian(s.s, center_hit.point);
+        if (sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f) continue;
+        sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
+        if (res_merge(o.r, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
+    }
+    if (!o.keep_stored) {
+        o.r.confidence = center.confidence;
+        o.r.s.pdf = main_pdf;
+        o.r.s.v1_point = center.s.v1_point;
+        res_norm(o.r, main_pdf, 1.0f, o.r.m);
+        o.r.w = fmin_(o.r.w, 5.0f);
+    }
+    return o;
+}
+// the same for a pixel that turns out to draw no neighbour (max_samples == 0); otherwise only max_samples is meaningful
+ST_D PreviewPass gi_preview_pass_if_alone(uint32_t seed, U2 center_pos, const GiReservoir& center) {
+    PreviewPass o; o.r = gi_empty(); o.keep_stored = false;
+    WhiteNoise wn = white_noise(seed, center_pos);
+    float main_pdf = 0.0f;
+    if (res_merge(o.r, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
+    o.max_samples = f2u_sat(lerpf(8.0f, 0.0f, o.r.m * 0.125f));
+    if (o.max_samples > 0u) return o;
+    o.r.confidence = center.confidence;
+    o.r.s.pdf = main_pdf;
+    o.r.s.v1_point = center.s.v1_point;
+    res_norm(o.r, main_pdf, 1.0f, o.r.m);
+    o.r.w = fmin_(o.r.w, 5.0f);
+    return o;
+}
+// one bit per pixel of an 8x8 tile (bit = lane = pixel_in_tile's numbering), one word per tile (KArgs::gi_late_mask)
+ST_D uint32_t gi_late_index(const KArgs& a, U2 pos) { return (pos.y >> 3) * ((a.width + 7u) >> 3) + (pos.x >> 3); }
+
+// RESOLVE (second preview pass only): gi_resolving.rs and, if `reproject`, the GI half of frame_denoising.rs::reproject run
+// for the same pixel right here. Resolving consumes exactly what this pass would have stored at gi_res[0][pixel] — the merged
+// reservoir, an empty one on sky, or (the reference's early `return`, :84-86) whatever gi_res[0] already held — and then
+// overwrites that slot with the frame's source reservoir, so the intermediate store is dropped.
+// With KArgs::gi_preview_late the launch follows k_gi_preview_both and serves only the pixels that one flagged.
 template <bool RESOLVE>
 __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint32_t nth, const float4* in, float4* out, uint32_t source,
                                                               uint32_t reproject) {
     U2 center_pos;
     if (!resolve_gid(a, false, &center_pos) || !owns_pixel(a, center_pos)) return;
+    if (RESOLVE && a.gi_preview_late && ((a.gi_late_mask[gi_late_index(a, center_pos)] >> (threadIdx.x & 63u)) & 1ull) == 0ull) return;
     const uint32_t n = a.width * a.height;
     const uint32_t center_idx = screen_to_idx(a, center_pos);
-    WhiteNoise wn = white_noise(seed, center_pos);
     // The pixel's Hit (camera ray + both G-buffer texels decoded) is needed by a neighbour tap and by resolving; whether the
     // pixel has a surface at all is the first G-buffer texel's depth. Once a reservoir's m has reached 8 — which temporal
     // resampling does within a few frames — `max_samples` is 0 and the first preview pass is a normalised copy: it then reads
@@ -386,49 +452,48 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
     const bool center_some = center_g0.x != 0.0f;  // GBufferEntry::depth (gbuffer.rs:60) == Hit::is_some
     Hit center_hit = hit_zero();
     if (RESOLVE) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
-    GiReservoir main_ = gi_empty();
     ReprojectHistory history;  // fetched ahead of the resampling loop (st_passes.h)
     if (RESOLVE && reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
-    bool keep_stored = false;  // the reference's early `return`: the output slot keeps its previous contents
     const GiReservoir center = gi_read_own(in, center_idx, true, center_some);  // quad-transposed (st_device.h): before the branch
-    if (center_some) {
-        float main_pdf = 0.0f;
-        if (res_merge(main_, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
-        const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, main_.m * 0.125f));
-        if (!RESOLVE && max_samples > 0u) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
-        const float max_radius = nth == 0u ? 128.0f : 64.0f;
-        uint32_t sample_nth = 0u;
-        while (sample_nth < max_samples) {
-            sample_nth += 1u;
-            const V2 disk = wn.sample_disk();
-            const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
-            if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) { keep_stored = true; break; }  // sic: `return`, not `continue`
-            const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
-            if (ss.depth == 0.0f) continue;
-            if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
-            if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
-            const GiReservoir s = gi_read(in, screen_to_idx(a, sample_pos), n);
-            if (s.m == 0.0f) continue;
-            const float sample_pdf = gi_pdf(s.s, center_hit);
-            float sample_jacobian = gi_jacobian(s.s, center_hit.point);
-            if (sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f) continue;
-            sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
-            if (res_merge(main_, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
-        }
-        if (!keep_stored) {
-            main_.confidence = center.confidence;
-            main_.s.pdf = main_pdf;
-            main_.s.v1_point = center.s.v1_point;
-            res_norm(main_, main_pdf, 1.0f, main_.m);
-            main_.w = fmin_(main_.w, 5.0f);
-        }
-    }
+    const PreviewPass pass = gi_preview_pass(a, seed, nth, in, center_pos, center_some, center, center_hit, RESOLVE);
+    GiReservoir main_ = pass.r;
     if (!RESOLVE) {
-        gi_write_own(out, center_idx, main_, true, !keep_stored);
+        gi_write_own(out, center_idx, main_, true, !pass.keep_stored);
         return;
     }
-    if (keep_stored) main_ = gi_read(out, center_idx, n);
+    if (pass.keep_stored) main_ = gi_read(out, center_idx, n);
     const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, main_, source);
+    if (reproject) denoise_reproject_finish(a, center_pos, diff, history, a.gi_diff_curr_colors, a.gi_diff_moments);
+}
+// Both preview passes, resolving and (if `reproject`) the GI half of denoise-reproject in one launch, for the pixels whose
+// SECOND pass draws no neighbour — nearly all of them once the reservoirs have history: such a pixel's second pass reads
+// nothing but what its first pass has just produced (through the store / load codec), so the 64-B round trip through
+// gi_res[3] and a second decode of the G-buffer go away. The first pass's result is stored for every pixel as always (a
+// neighbour's second pass may draw it); pixels whose second pass does resample — or whose first pass hit the early `return`
+// — are flagged per tile and served by k_gi_preview<true> afterwards, when every first-pass result is in memory.
+__global__ ST_KERNEL_BOUNDS void k_gi_preview_both(const KArgs a, uint32_t seed, const float4* in, float4* mid, uint32_t source, uint32_t reproject) {
+    U2 center_pos;
+    if (!resolve_gid(a, false, &center_pos) || !owns_pixel(a, center_pos)) return;
+    const uint32_t center_idx = screen_to_idx(a, center_pos);
+    const float4 center_g0 = tex_read(a.g0, a, center_pos);
+    const bool center_some = center_g0.x != 0.0f;
+    const Hit center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
+    ReprojectHistory history;
+    if (reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
+    const GiReservoir center0 = gi_read_own(in, center_idx, true, center_some);
+    const PreviewPass first = gi_preview_pass(a, seed, 0u, in, center_pos, center_some, center0, center_hit, true);
+    gi_write_own(mid, center_idx, first.r, true, !first.keep_stored);
+    // second pass, if it is the neighbour-free kind: its `center` is what gi_read would return for the record just stored
+    bool late = first.keep_stored;
+    PreviewPass second; second.r = gi_empty(); second.keep_stored = false; second.max_samples = 0u;
+    if (!late && center_some) {
+        second = gi_preview_pass_if_alone(seed, center_pos, gi_after_store(first.r));
+        late = second.max_samples > 0u;
+    }
+    const unsigned long long flagged = __ballot(late), active = __ballot(true);
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) a.gi_late_mask[gi_late_index(a, center_pos)] = flagged;
+    if (late) return;
+    const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, second.r, source);
     if (reproject) denoise_reproject_finish(a, center_pos, diff, history, a.gi_diff_curr_colors, a.gi_diff_moments);
 }
 void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s) {
@@ -436,6 +501,9 @@ void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4
 }
 void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, uint32_t source, bool reproject, hipStream_t s) {
     ST_LAUNCH(k_gi_preview<true>, false, s, a, seed, nth, in, a.gi_res[0], source, reproject ? 1u : 0u);
+}
+void launch_gi_preview_both(const KArgs& a, uint32_t seed, const float4* in, float4* mid, uint32_t source, bool reproject, hipStream_t s) {
+    ST_LAUNCH(k_gi_preview_both, false, s, a, seed, in, mid, source, reproject ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------- gi_resolving.rs:3-67

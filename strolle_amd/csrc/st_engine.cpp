@@ -238,7 +238,7 @@ struct CameraState {
     void* slab = nullptr; size_t slab_bytes = 0;
     float4* plane[ST_BUF_COUNT + kInternalPlanes] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
     size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
-    unsigned long long* tile_mask = nullptr;  // one u64 per 8x8 tile (KArgs::tile_mask)
+    unsigned long long* tile_mask = nullptr; size_t tile_mask_tiles = 0;  // two arrays of one u64 per 8x8 tile (KArgs::tile_mask, KArgs::gi_late_mask)
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
     // The two-stream frame pipeline (render()) belongs to the camera: its side stream and the events that order frame N+1's
@@ -430,6 +430,7 @@ struct Engine {
     uint64_t pass_mask = ~0ull;  // st_debug_set_pass_mask: which reference passes a render executes (parity tests run one launch at a time)
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
     bool variance_in_reproject = true;  // ST_NO_VARIANCE_IN_REPROJECT=1: estimate_variance as its own full-screen pass
+    bool preview_both = true;  // ST_NO_PREVIEW_BOTH=1: the two GI preview passes as two full-screen launches
     bool skip_scratch_stores = true;  // ST_KEEP_SCRATCH=1: the fused DI spatial launch stores its intermediate records as the three separate passes would
     bool di_head_on_main = true;  // ST_DI_HEAD_ON_MAIN=0: DI sampling + temporal on the side stream (behind primary visibility) instead of the caller's
     bool alias_gi_history = true;  // ST_NO_GI_ALIAS=1: gi_resolving always copies the source reservoirs into the history plane
@@ -466,6 +467,7 @@ struct Engine {
         if (const char* k = getenv("ST_NO_GI_ALIAS")) alias_gi_history = atoi(k) == 0;
         if (const char* k = getenv("ST_DI_HEAD_ON_MAIN")) di_head_on_main = atoi(k) != 0;
         if (const char* k = getenv("ST_KEEP_SCRATCH")) skip_scratch_stores = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_PREVIEW_BOTH")) preview_both = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_VARIANCE_IN_REPROJECT")) variance_in_reproject = atoi(k) == 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
         if (const char* nd = getenv("ST_NO_DOUBLE_BUFFER")) double_buffer = atoi(nd) == 0;
@@ -933,8 +935,9 @@ struct Engine {
         ST_HIP(hipMemset(c.counters, 0, kCounterBytes));
         {
             const size_t tiles = (size_t)((c.desc.width + 7u) / 8u) * ((c.desc.height + 7u) / 8u);
-            if (hipMalloc(reinterpret_cast<void**>(&c.tile_mask), tiles * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); c.tile_mask = nullptr; release_camera(c); return fail(ST_ERR_HIP, "hipMalloc(camera tile mask) failed"); }
-            ST_HIP(hipMemset(c.tile_mask, 0, tiles * sizeof(unsigned long long)));
+            if (hipMalloc(reinterpret_cast<void**>(&c.tile_mask), 2 * tiles * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); c.tile_mask = nullptr; release_camera(c); return fail(ST_ERR_HIP, "hipMalloc(camera tile mask) failed"); }
+            ST_HIP(hipMemset(c.tile_mask, 0, 2 * tiles * sizeof(unsigned long long)));  // [0, tiles): variance's, [tiles, 2 tiles): the GI preview's
+            c.tile_mask_tiles = tiles;
         }
         memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
         ST_HIP(hipDeviceSynchronize());  // the clears run on the null stream; renders may use any stream
@@ -1087,6 +1090,10 @@ struct Engine {
             // estimate_variance's long-history branch rides in the fused reproject stages (st_passes.h denoise_reproject_finish);
             // the variance launch then serves the short-history pixels only, in place, and the strides-1+2 launch reads curr_colors
             a.tile_mask = c.tile_mask;
+            // both GI preview passes + resolving in one launch for the pixels whose second pass draws no neighbour (k_gi.hip
+            // k_gi_preview_both); the second-pass launch then serves the flagged rest
+            a.gi_late_mask = c.tile_mask ? c.tile_mask + c.tile_mask_tiles : nullptr; a.gi_preview_late = 0u;
+            const bool gi_preview_both = preview_both && whole_graph && fuse && gi_runs && a.gi_late_mask;
             a.variance_in_reproject = (variance_in_reproject && whole_graph && fuse && fuse_wavelet && denoise && needs_di && needs_gi && any_objects && c.tile_mask) ? 1u : 0u;
             // di_spatial's scratch records (di_diff_samples / curr_colors / stash as the reference binds them) are dead stores
             // when the fused launch is followed by resolving, denoise-reproject and the a-trous chain of the same frame
@@ -1150,11 +1157,18 @@ struct Engine {
                     sampling();
                     temporal();
                 }
-                run(KS_GI_PREVIEW, ST_PASS_GI_PREVIEW_0, [&] { L.launch_gi_preview(a, pseed, 0u, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], cur); });
+                if (!gi_preview_both) run(KS_GI_PREVIEW, ST_PASS_GI_PREVIEW_0, [&] { L.launch_gi_preview(a, pseed, 0u, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], cur); });
             };
             // second preview pass + resolving (+ reproject): the first GI stage that writes planes the denoiser/composition read
             auto do_gi_tail = [&] {
-                if (fuse) {
+                if (gi_preview_both) {
+                    run(KS_GI_PREVIEW, ST_PASS_GI_PREVIEW_0, [&] { L.launch_gi_preview_both(a, pseed, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], gi_source, denoise, cur); });
+                    a.gi_preview_late = 1u;
+                    run(denoise ? KS_GI_PREVIEW_RESOLVE_REPROJECT : KS_GI_PREVIEW_RESOLVE, ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING | (denoise ? (uint64_t)ST_PASS_DENOISE_REPROJECT_GI : 0ull),
+                        [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, denoise, cur); });
+                    a.gi_preview_late = 0u;
+                    if (denoise) gi_reprojected = true;
+                } else if (fuse) {
                     if (denoise) { run(KS_GI_PREVIEW_RESOLVE_REPROJECT, ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING | ST_PASS_DENOISE_REPROJECT_GI, [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, true, cur); }); gi_reprojected = true; }
                     else run(KS_GI_PREVIEW_RESOLVE, ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING, [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, false, cur); });
                 } else {

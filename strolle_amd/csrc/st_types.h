@@ -59,6 +59,9 @@ struct KArgs {
     // k_denoise.hip "variance in the reproject stage": the fused reproject stages store each pixel's long-history variance in
     // curr_colors.w and the DI one flags short-history pixels per 8x8 tile (bit = lane) for the variance kernel
     unsigned long long* tile_mask; uint32_t variance_in_reproject;
+    // k_gi.hip k_gi_preview_both: pixels whose second preview pass resamples, per 8x8 tile (bit = lane); gi_preview_late: the
+    // second-pass launch serves flagged pixels only
+    unsigned long long* gi_late_mask; uint32_t gi_preview_late;
     uint32_t skip_dead_scratch;  // the fused DI spatial launch keeps its pick / trace records in registers only: resolving, denoise-reproject and the a-trous chain rewrite the three scratch planes later in this frame
     uint32_t gi_skip_history_copy;  // gi_resolving leaves GI_RESERVOIRS_0 alone: the engine swaps plane pointers instead (st_engine.cpp gi_aliased)
     uint32_t count_bytes;  // st_profile_enable bit 1: kernels also sum the reference's used_memory over their rays
