@@ -316,11 +316,19 @@ def main():
                                   "traversal_bytes_per_launch_not_hbm": round(trav / launches),
                                   "note": "HIP events on the launch stream around each run of back-to-back launches of the slot, over a second region of the same K steps; algorithmic bytes = compulsory screen-space plane bytes of the reference passes the launches execute (SURVEY.md 8d / DESIGN.md section 4)"}
             tot = sum(p["total_ms"] for p in prof)
+            def counter_rate(p):  # the slot's HBM bytes per launch by the committed counter passes over this run's launch time
+                per_launch, _ = static_traffic([p["name"]])
+                return round(per_launch / (p["total_ms"] / p["launches"] * 1e-3) / 1e9, 1) if per_launch and p["total_ms"] > 0 else None
             result["kernels"] = {p["name"]: {"ms_per_frame": round(p["total_ms"] / args.steps, 5), "launches_per_frame": round(p["launches"] / args.steps, 2),
                                             "us_per_launch": round(p["total_ms"] / p["launches"] * 1e3, 2),
                                             "B_only_GBps": round((p["algorithmic_bytes"] - p["traversal_bytes"]) / (p["total_ms"] * 1e-3) / 1e9, 1) if p["total_ms"] > 0 else None,
+                                            "counter_GBps": counter_rate(p),
                                             "traversal_GBps_cache_served": round(p["traversal_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1) if p["total_ms"] > 0 and p["traversal_bytes"] else 0.0}
                                  for p in sorted(prof, key=lambda p: -p["total_ms"])}
+            result["kernels_note"] = ("B_only_GBps: compulsory screen-space bytes of the REFERENCE passes a launch executes (unfused accounting, SURVEY.md 8d) "
+                                      "over its duration - an equivalent rate: a fused launch never moves part of those bytes, so it can exceed the HBM peak; "
+                                      "counter_GBps: the same launch's FETCH_SIZE / WRITE_SIZE bytes from profiles/pmc_latest.json (static, an upper bound for gather kernels) "
+                                      "over this run's duration - the figure to hold against the 8 TB/s peak")
             result["gpu_kernel_ms_per_frame"] = round(tot / args.steps, 4)
             # both components of the algorithmic bytes for the whole frame, against the unprofiled frame time
             a_bytes = sum(p["traversal_bytes"] for p in prof) / args.steps

@@ -19,6 +19,7 @@ enum KernelSlot {
     // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
     KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_12,
     KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL, KS_DI_SPATIAL_FUSED, KS_GI_SPATIAL_FUSED,
+    KS_GI_PREVIEW_BOTH, KS_GI_PREVIEW_BOTH_NO_REPROJECT, KS_GI_PREVIEW_LATE,
     KS_COUNT
 };
 struct KernelInfo { const char* name; float bytes_per_unit; bool half; };
@@ -41,6 +42,9 @@ inline const KernelInfo& kernel_info(int slot) {
         {"di_sampling+di_temporal", 68.f + 176.f, false},
         {"di_spatial_pick+trace+sample", 128.f + 2.f * 48.f + 192.f, true},  // per cell: the trace pass covers both of its pixels
         {"gi_spatial_pick+trace+sample", 160.f + 2.f * 48.f + 352.f, true},
+        {"gi_preview x2+gi_resolving+denoise_reproject", 160.f + 160.f + 256.f + 112.f, false},
+        {"gi_preview x2+gi_resolving", 160.f + 160.f + 256.f, false},
+        {"gi_preview 2nd pass (pixels that resample)", 0.f, false},  // its bytes are credited to the launch above
     };
     return k[slot];
 }
