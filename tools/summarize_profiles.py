@@ -47,6 +47,7 @@ SLOT_SYMBOLS = {
     "gi_sampling_b": ["gi_sampling_b<true,u16>", "gi_sampling_b<false,u16>", "gi_sampling_b<false,u32>"],
     "gi_reprojection+gi_temporal": ["gi_temporal<true>"], "gi_temporal": ["gi_temporal<false>"],
     "gi_preview": ["gi_preview<false>"], "gi_preview+gi_resolving+denoise_reproject": ["gi_preview<true>"],
+    "denoise_wavelet x2 (strides 1+2)": ["denoise_wavelet_12"],
     "gi_preview x2+gi_resolving+denoise_reproject": ["gi_preview_both"], "gi_preview 2nd pass (pixels that resample)": ["gi_preview<true>"],
 }
 
