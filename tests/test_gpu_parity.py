@@ -879,3 +879,39 @@ def test_profile_flags_timing_and_traversal_bytes():
     e.profile_enable(0)
     assert rays[0] > 0 and rays[0] >= size[0] * size[1] * 6
     e.close()
+
+
+@pytest.mark.parametrize("switches", [
+    {"ST_NO_FUSE": "1"},
+    {"ST_NO_OVERLAP": "1", "ST_NO_FUSE_WAVELET": "1"},
+    {"ST_TILE_MAP": "0"},
+    {"ST_NO_PREVIEW_BOTH": "1", "ST_NO_VARIANCE_IN_REPROJECT": "1", "ST_KEEP_SCRATCH": "1", "ST_DI_HEAD_ON_MAIN": "0"},
+    {"ST_NO_FUSE_SPATIAL": "1", "ST_NO_FUSE_DI_HEAD": "1", "ST_NO_FUSE_GI_REPROJECTION": "1"},
+], ids=lambda s: "+".join(sorted(s)))
+def test_every_scheduling_variant_produces_the_same_bits(switches):
+    """The engine's fusion / overlap / mapping switches (read from the environment when an engine is created) select other
+    launch structures for the same pass graph: each must leave every plane bit-identical to the oracle's, frame after frame
+    (exact build; Cornell 160x96 Image{denoise}, 8 frames = every GI schedule)."""
+    torch = _torch()
+    size = (160, 96)
+    saved = {k: os.environ.get(k) for k in switches}
+    os.environ.update(switches)
+    try:
+        prod = Engine(device=0, exact=True)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    orac = OracleEngine()
+    for e in (prod, orac):
+        scenes.build_cornell(e); e.set_seed(17)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    cp, co = prod.create_camera(desc), orac.create_camera(desc)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    for frame in range(8):
+        img, ref = _step(torch, prod, orac, desc, cp, co, out)
+        _compare_all(prod, orac, cp, co, frame)
+        assert_bits_equal(img, ref, f"composed frame {frame}")
+    prod.close(); orac.close()
