@@ -323,6 +323,17 @@ def main():
                                   "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": round(b_bytes),
                                   "traversal_bytes_per_launch_not_hbm": round(trav / launches),
                                   "note": "HIP events on the launch stream around each run of back-to-back launches of the slot, over a second region of the same K steps; algorithmic bytes = compulsory screen-space plane bytes of the reference passes the launches execute (SURVEY.md 8d / DESIGN.md section 4)"}
+            # the whole of frame_denoising.rs after reprojection: estimate_variance + the five a-trous passes (five launches). With
+            # the variance pass's long-history branch riding in the reproject stages its share of the work moved into the
+            # strides-1+2 launch's inputs, so the wavelet-only figure above and this one are both given.
+            den = [by[n] for n in list(WAVELET_SLOTS) + ["denoise_variance"] if n in by]
+            if den and sum(p["total_ms"] for p in den) > 0:
+                den_alg = sum(p["algorithmic_bytes"] - p["traversal_bytes"] for p in den)
+                den_ms = sum(p["total_ms"] for p in den)
+                den_rate = den_alg / (den_ms * 1e-3) / 1e9
+                result["roofline_denoiser"] = {"kernel": "estimate_variance + 5 a-trous passes (frame_denoising.rs:80-361)", "bound": "hbm",
+                                               "achieved": round(den_rate, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(den_rate / HBM_PEAK_GBS, 5),
+                                               "ms_per_frame": round(den_ms / args.steps, 5), "algorithmic_bytes_per_frame": round(den_alg / args.steps)}
             tot = sum(p["total_ms"] for p in prof)
             def counter_rate(p):  # the slot's HBM bytes per launch by the committed counter passes over this run's launch time
                 per_launch, _ = static_traffic([p["name"]])
