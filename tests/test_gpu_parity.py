@@ -455,7 +455,7 @@ def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
     env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", ST_EXACT="1")  # exact build: the bit-compare below needs it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--width", "128", "--height", "64", "--mode", "reference",
-           "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
+           "--preroll", "0", "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
@@ -486,7 +486,7 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--width", "160", "--height", "96", "--mode", "reference", "--scaling", "strong",
-           "--exact", "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
+           "--exact", "--preroll", "0", "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
