@@ -88,15 +88,37 @@ int main(int argc, char** argv) {
     CHECK(st_camera_create(engine, &camera, &cam));
     CHECK(st_camera_set_output_format(engine, cam, ST_FORMAT_RGBA8_UNORM_SRGB));        /* what a swap chain would hold */
 
-    void* frame = NULL;
-    if (hipMalloc(&frame, (size_t)width * height * 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
+    /* The present path of the Rust facade (rust/strolle-hip/src/present.rs), in C: two device frames and two page-locked
+     * host frames alternate; frame N's copy to the host is enqueued behind its composition and runs while frame N+1
+     * renders, and what gets presented at tick N+1 is frame N (one frame of latency, no stream synchronisation). */
+    const size_t frame_bytes = (size_t)width * height * 4;
+    void* frame[2] = {NULL, NULL};
+    void* host_frame[2] = {NULL, NULL};
+    for (int k = 0; k < 2; k++)
+        if (hipMalloc(&frame[k], frame_bytes) != hipSuccess || hipHostMalloc(&host_frame[k], frame_bytes, 0) != hipSuccess) { fprintf(stderr, "allocation failed\n"); return 1; }
+    unsigned char* host = (unsigned char*)malloc(frame_bytes);   /* stands in for queue.write_texture's destination */
+    if (!host) return 1;
+    int presented = 0, waited = 0;
     for (int i = 0; i < frames; i++) {        /* the loop of bevy-strolle's render node: update_camera, tick, render_camera */
+        const int k = i & 1;
         CHECK(st_camera_update(engine, cam, &camera));
         CHECK(st_tick(engine, NULL));
-        CHECK(st_render_camera(engine, cam, frame, NULL));
+        CHECK(st_render_camera(engine, cam, frame[k], NULL));
+        CHECK(st_camera_present_copy(engine, cam, frame[k], host_frame[k], frame_bytes, NULL));
+        if (i > 0) {                          /* present frame i-1: its copy was enqueued a whole frame ago */
+            int ready = 0;
+            CHECK(st_camera_present_ready(engine, cam, host_frame[k ^ 1], 0, &ready));
+            if (!ready) { waited++; CHECK(st_camera_present_ready(engine, cam, host_frame[k ^ 1], 1, &ready)); }
+            memcpy(host, host_frame[k ^ 1], frame_bytes);
+            presented++;
+        }
     }
-    unsigned char* host = (unsigned char*)malloc((size_t)width * height * 4);
-    if (!host || hipMemcpy(host, frame, (size_t)width * height * 4, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "read-back failed\n"); return 1; }
+    {                                         /* the last frame */
+        int ready = 0;
+        CHECK(st_camera_present_ready(engine, cam, host_frame[(frames - 1) & 1], 1, &ready));
+        memcpy(host, host_frame[(frames - 1) & 1], frame_bytes);
+        presented++;
+    }
     uint64_t rays = 0;
     CHECK(st_camera_ray_count(engine, cam, &rays, 0));
 
@@ -105,10 +127,10 @@ int main(int argc, char** argv) {
     fprintf(f, "P6\n%u %u\n255\n", width, height);
     for (size_t i = 0; i < (size_t)width * height; i++) fwrite(host + 4 * i, 1, 3, f);
     fclose(f);
-    fprintf(stderr, "%d frames, %llu rays, wrote %s\n", frames, (unsigned long long)rays, argv[2]);
+    fprintf(stderr, "%d frames (%d presented, %d waited for their copy), %llu rays, wrote %s\n", frames, presented, waited, (unsigned long long)rays, argv[2]);
 
     free(host);
-    (void)hipFree(frame);
+    for (int k = 0; k < 2; k++) { (void)hipFree(frame[k]); (void)hipHostFree(host_frame[k]); }
     CHECK(st_camera_delete(engine, cam));
     st_engine_destroy(engine);
     return 0;

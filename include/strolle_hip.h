@@ -139,6 +139,19 @@ int st_tick(StEngine* e, void* hip_stream);                                     
  * st_camera_set_output_format said otherwise; may be NULL to skip composition). Asynchronous. */
 int st_render_camera(StEngine* e, StHandle camera, void* out_device, void* hip_stream); /* lib.rs:279 */
 
+/* ---- present hand-over. Engine::render_camera (lib.rs:279-286) records the frame into the caller's wgpu encoder and
+ * texture view; a facade over this library (rust/strolle-hip) owns no resource the other API can sample, so the composed
+ * frame has to reach it through host memory. These two calls do that WITHOUT stalling the pipeline:
+ *   st_camera_present_copy  enqueues `bytes` of `src_device` (the buffer st_render_camera just composed into on
+ *                           `hip_stream`) -> `dst_host` on a copy stream the camera owns, ordered behind that frame only;
+ *                           returns at once. The next frames' kernels overlap the copy (8 MB per 1080p RGBA8 frame).
+ *   st_camera_present_ready *ready = 1 once the copy into `dst_host` has landed (wait != 0: block until then).
+ * Use page-locked host memory (hipHostMalloc) — a pageable destination makes the copy synchronous — and alternate two
+ * (src_device, dst_host) pairs: frame N-1 is presented while frame N renders (one frame of latency). Rendering into a
+ * `src_device` whose copy is still in flight is safe: the engine orders that frame's composition behind the copy. */
+int st_camera_present_copy(StEngine* e, StHandle camera, const void* src_device, void* dst_host, size_t bytes, void* hip_stream);
+int st_camera_present_ready(StEngine* e, StHandle camera, const void* dst_host, int wait, int* ready);
+
 /* ---- NEW seams (no counterpart in the reference) */
 /* BVH refresh policy for scenes that change every frame (examples/stress-bvh.rs).
  * ST_BVH_REBUILD (default) is the reference's behaviour: every change rebuilds the tree — with unchanged subtrees

@@ -1,5 +1,5 @@
-//! Raw bindings of include/strolle_hip.h (the C ABI of libstrolle_hip.so) and of the four HIP runtime calls the present
-//! step needs. One `extern "C"` item per entry point; the comment names the `strolle::Engine` method it stands behind
+//! Raw bindings of include/strolle_hip.h (the C ABI of libstrolle_hip.so) and of the HIP runtime calls the present
+//! step needs (allocation only: the copy itself is the library's, `st_camera_present_copy`). One `extern "C"` item per entry point; the comment names the `strolle::Engine` method it stands behind
 //! (reference: strolle/src/lib.rs:132-395).
 #![allow(non_camel_case_types, dead_code)]
 use std::ffi::c_void;
@@ -92,6 +92,9 @@ extern "C" {
     pub fn st_camera_set_output_format(e: *mut StEngine, camera: u64, format: i32) -> i32; // Camera::viewport.format
     pub fn st_tick(e: *mut StEngine, hip_stream: *mut c_void) -> i32; // tick
     pub fn st_render_camera(e: *mut StEngine, camera: u64, out_device: *mut c_void, hip_stream: *mut c_void) -> i32; // render_camera
+    // the present hand-over (present.rs): frame N leaves for host memory behind its composition while frame N+1 renders
+    pub fn st_camera_present_copy(e: *mut StEngine, camera: u64, src_device: *const c_void, dst_host: *mut c_void, bytes: usize, hip_stream: *mut c_void) -> i32;
+    pub fn st_camera_present_ready(e: *mut StEngine, camera: u64, dst_host: *const c_void, wait: i32, ready: *mut i32) -> i32;
     pub fn st_set_seed(e: *mut StEngine, seed: u64) -> i32;
     pub fn st_set_blue_noise(e: *mut StEngine, rgba: *const u8, bytes: usize) -> i32; // Noise::new (noise.rs:40-50)
     pub fn st_engine_set_arithmetic(e: *mut StEngine, arithmetic: i32) -> i32;
@@ -100,14 +103,11 @@ extern "C" {
 
 // ---- the HIP runtime, as far as the staging-copy present needs it (libamdhip64)
 pub type hipStream_t = *mut c_void;
-pub const HIP_MEMCPY_DEVICE_TO_HOST: i32 = 2;
 extern "C" {
     pub fn hipMalloc(ptr: *mut *mut c_void, bytes: usize) -> i32;
     pub fn hipFree(ptr: *mut c_void) -> i32;
     pub fn hipHostMalloc(ptr: *mut *mut c_void, bytes: usize, flags: u32) -> i32;
     pub fn hipHostFree(ptr: *mut c_void) -> i32;
-    pub fn hipMemcpyAsync(dst: *mut c_void, src: *const c_void, bytes: usize, kind: i32, stream: hipStream_t) -> i32;
     pub fn hipStreamCreate(stream: *mut hipStream_t) -> i32;
     pub fn hipStreamDestroy(stream: hipStream_t) -> i32;
-    pub fn hipStreamSynchronize(stream: hipStream_t) -> i32;
 }

@@ -100,8 +100,11 @@ where
         check(unsafe { ffi::st_engine_create(ordinal, &mut raw) });
         let mut stream = std::ptr::null_mut();
         assert_eq!(unsafe { ffi::hipStreamCreate(&mut stream) }, 0, "hipStreamCreate");
-        // Noise::new (noise.rs:40-50): the blue-noise texture ships with the crate as a PNG; the library takes texels
-        let noise = image::load_from_memory(include_bytes!("../assets/blue-noise.png")).expect("blue-noise.png").to_rgba8();
+        // Noise::new (noise.rs:40-50) embeds strolle/assets/blue-noise.png; the library takes texels, and the repository
+        // carries that texture decoded (assets/blue_noise.npy: a 128-byte NumPy header, then 256 x 256 RGBA8 — written by
+        // tools/convert_assets.py, sha256 of the texels in SURVEY.md section 8c)
+        let noise: &[u8] = &include_bytes!("../../../assets/blue_noise.npy")[128..];
+        assert_eq!(noise.len(), 256 * 256 * 4, "assets/blue_noise.npy");
         check(unsafe { ffi::st_set_blue_noise(raw, noise.as_ptr(), noise.len()) });
         // rand::thread_rng() seeds in the reference (camera_controller.rs:189-194); the library derives per-pass seeds
         // from one base seed
@@ -253,6 +256,7 @@ where
         if resized {
             let (format, _) = camera.output_format().expect("viewport.format");
             check(unsafe { ffi::st_camera_set_output_format(self.raw, slot.raw, format) });
+            slot.presenter.finish(self.raw, slot.raw); // its buffers are about to be freed
             slot.presenter = Presenter::new(device, &camera);
         } else {
             slot.presenter.set_position(&camera);
@@ -279,7 +283,7 @@ where
         check(unsafe { ffi::st_tick(self.raw, self.stream) });
         for slot in self.cameras.values() {
             check(unsafe { ffi::st_render_camera(self.raw, slot.raw, slot.presenter.device_frame(), self.stream) });
-            slot.presenter.upload(queue, self.stream);
+            slot.presenter.upload(self.raw, slot.raw, queue, self.stream);
         }
     }
 
@@ -338,6 +342,9 @@ where
     P: Params,
 {
     fn drop(&mut self) {
+        for slot in self.cameras.values() {
+            slot.presenter.finish(self.raw, slot.raw);
+        }
         self.cameras.clear(); // presenters free their HIP buffers before the engine goes
         unsafe {
             ffi::st_engine_destroy(self.raw);

@@ -2,17 +2,29 @@
 //! (reference: strolle/src/camera_controller/passes/frame_composition.rs draws a full-screen triangle into the view).
 //!
 //! The composition KERNEL already produced the pixels — in the viewport's own format (`st_camera_set_output_format`) — in
-//! device memory owned by HIP. This module moves them across the API boundary with a staging copy:
+//! device memory owned by HIP. This module moves them across the API boundary with a staging copy that never joins a
+//! stream, so the engine's cross-frame pipelining (st_engine.cpp `render`: frame N+1's primary rays and reservoir passes
+//! overlap frame N's denoiser) survives the facade:
 //!
-//!   tick():           HIP frame -> hipMemcpyAsync -> page-locked host buffer -> queue.write_texture -> `frame` texture
-//!   render_camera():  one render pass that copies `frame` into the target view (full-screen triangle, textureLoad)
+//!   tick() of frame N:  st_render_camera -> device frame [N % 2]
+//!                       st_camera_present_copy -> page-locked host frame [N % 2]   (asynchronous, on the camera's copy
+//!                                                                                    stream, behind frame N only)
+//!                       host frame [(N - 1) % 2] — enqueued a whole frame ago — -> queue.write_texture -> `frame` texture
+//!   render_camera():    one render pass that copies `frame` into the target view (full-screen triangle, textureLoad)
+//!
+//! What the view shows at frame N is therefore frame N - 1: ONE FRAME OF LATENCY, the price of not waiting for the GPU
+//! inside `tick` (the first tick presents a cleared texture). `st_camera_present_ready` is polled; if frame N - 1's copy has
+//! not landed yet (the application ticks faster than the MI355X renders) the call blocks on that copy alone.
 //!
 //! Rendering moves into `tick` because that is the only call that has the `wgpu::Queue`; bevy-strolle calls
-//! `update_camera`, then `tick`, then `render_camera` every frame (stages/prepare.rs:300-340, rendering_node.rs:14-36), so
-//! the view receives the same frame it would have. The copy costs 8 MB per 1080p frame in an 8-bit swap-chain format (33 MB
-//! in Rgba32Float): fine for the examples. The zero-copy alternative — allocate `frame` as Vulkan external memory, import
-//! it with hipImportExternalMemory and let the kernel write into it — needs wgpu-hal escape hatches and is left out.
+//! `update_camera`, then `tick`, then `render_camera` every frame (stages/prepare.rs:300-340, rendering_node.rs:14-36).
+//! The copy costs 8 MB per 1080p frame in an 8-bit swap-chain format (33 MB in Rgba32Float); measured from C with the same
+//! call order (`bench.py --present rgba8`). The zero-copy alternative — allocate `frame` as Vulkan
+//! external memory, import it with hipImportExternalMemory and let the kernel write into it — needs wgpu-hal escape hatches
+//! and is left out.
 use std::ffi::c_void;
+
+use std::cell::Cell;
 
 use crate::{ffi, Camera};
 
@@ -40,8 +52,9 @@ pub(crate) struct Presenter {
     bytes_per_pixel: u32,
     size: (u32, u32),
     position: (u32, u32),
-    device_frame: *mut c_void, // HIP allocation the composition kernel writes
-    host_frame: *mut c_void,   // page-locked staging copy
+    device_frame: [*mut c_void; 2], // HIP allocations the composition kernel writes, alternating by frame
+    host_frame: [*mut c_void; 2],   // page-locked staging copies, alternating with them
+    ticks: Cell<u64>,               // frames handed to `upload` so far
     frame: wgpu::Texture,
     bind_group: wgpu::BindGroup,
     pipeline: wgpu::RenderPipeline,
@@ -58,10 +71,12 @@ impl Presenter {
         });
         let (w, h) = (camera.viewport.size.x.max(1), camera.viewport.size.y.max(1));
         let bytes = (w * h * bytes_per_pixel) as usize;
-        let (mut device_frame, mut host_frame) = (std::ptr::null_mut(), std::ptr::null_mut());
-        unsafe {
-            assert_eq!(ffi::hipMalloc(&mut device_frame, bytes), 0, "hipMalloc");
-            assert_eq!(ffi::hipHostMalloc(&mut host_frame, bytes, 0), 0, "hipHostMalloc");
+        let (mut device_frame, mut host_frame) = ([std::ptr::null_mut(); 2], [std::ptr::null_mut(); 2]);
+        for k in 0..2 {
+            unsafe {
+                assert_eq!(ffi::hipMalloc(&mut device_frame[k], bytes), 0, "hipMalloc");
+                assert_eq!(ffi::hipHostMalloc(&mut host_frame[k], bytes, 0), 0, "hipHostMalloc");
+            }
         }
         let frame = device.create_texture(&wgpu::TextureDescriptor {
             label: Some("strolle_hip_frame"),
@@ -113,36 +128,61 @@ impl Presenter {
             position: (camera.viewport.position.x, camera.viewport.position.y),
             device_frame,
             host_frame,
+            ticks: Cell::new(0),
             frame,
             bind_group,
             pipeline,
         }
     }
 
-    /// Where `st_render_camera` writes the composed frame.
+    /// Where `st_render_camera` writes this tick's composed frame.
     pub fn device_frame(&self) -> *mut c_void {
-        self.device_frame
+        self.device_frame[(self.ticks.get() & 1) as usize]
     }
 
     pub fn set_position(&mut self, camera: &Camera) {
         self.position = (camera.viewport.position.x, camera.viewport.position.y);
     }
 
-    /// HIP -> host -> wgpu texture; call after `st_render_camera` was enqueued on `stream`.
-    pub fn upload(&self, queue: &wgpu::Queue, stream: ffi::hipStream_t) {
+    /// Call after this tick's `st_render_camera` was enqueued on `stream`: sends the new frame on its way to the host and
+    /// hands the PREVIOUS frame — whose copy has had a whole frame to land — to wgpu. No stream is joined.
+    pub fn upload(&self, engine: *mut ffi::StEngine, camera: u64, queue: &wgpu::Queue, stream: ffi::hipStream_t) {
         let (w, h) = self.size;
         let bytes = (w * h * self.bytes_per_pixel) as usize;
+        let n = self.ticks.get();
+        let (cur, prev) = ((n & 1) as usize, ((n + 1) & 1) as usize);
         unsafe {
-            assert_eq!(ffi::hipMemcpyAsync(self.host_frame, self.device_frame, bytes, ffi::HIP_MEMCPY_DEVICE_TO_HOST, stream), 0, "hipMemcpyAsync");
-            assert_eq!(ffi::hipStreamSynchronize(stream), 0, "hipStreamSynchronize");
+            assert_eq!(ffi::st_camera_present_copy(engine, camera, self.device_frame[cur], self.host_frame[cur], bytes, stream), ffi::ST_OK, "st_camera_present_copy");
         }
-        let pixels = unsafe { std::slice::from_raw_parts(self.host_frame as *const u8, bytes) };
+        self.ticks.set(n + 1);
+        if n == 0 {
+            return; // nothing rendered before this tick: the view shows the cleared texture once
+        }
+        let mut ready = 0;
+        unsafe {
+            assert_eq!(ffi::st_camera_present_ready(engine, camera, self.host_frame[prev], 0, &mut ready), ffi::ST_OK, "st_camera_present_ready");
+            if ready == 0 {
+                // the application is ahead of the GPU: wait for that one copy (not for the stream)
+                assert_eq!(ffi::st_camera_present_ready(engine, camera, self.host_frame[prev], 1, &mut ready), ffi::ST_OK, "st_camera_present_ready");
+            }
+        }
+        let pixels = unsafe { std::slice::from_raw_parts(self.host_frame[prev] as *const u8, bytes) };
         queue.write_texture(
             wgpu::ImageCopyTexture { texture: &self.frame, mip_level: 0, origin: wgpu::Origin3d::ZERO, aspect: wgpu::TextureAspect::All },
             pixels,
             wgpu::ImageDataLayout { offset: 0, bytes_per_row: Some(w * self.bytes_per_pixel), rows_per_image: Some(h) },
             wgpu::Extent3d { width: w, height: h, depth_or_array_layers: 1 },
         );
+    }
+
+    /// Blocks until no copy into this presenter's host frames is in flight (before its buffers are freed).
+    pub fn finish(&self, engine: *mut ffi::StEngine, camera: u64) {
+        for k in 0..2 {
+            let mut ready = 0;
+            unsafe {
+                assert_eq!(ffi::st_camera_present_ready(engine, camera, self.host_frame[k], 1, &mut ready), ffi::ST_OK, "st_camera_present_ready");
+            }
+        }
     }
 
     /// The stand-in for the reference's frame-composition render pass: same target, same viewport rectangle.
@@ -164,9 +204,12 @@ impl Presenter {
 
 impl Drop for Presenter {
     fn drop(&mut self) {
-        unsafe {
-            ffi::hipFree(self.device_frame);
-            ffi::hipHostFree(self.host_frame);
+        // callers run `finish` (or delete the camera, which joins its copy stream) first: no copy is in flight here
+        for k in 0..2 {
+            unsafe {
+                ffi::hipFree(self.device_frame[k]);
+                ffi::hipHostFree(self.host_frame[k]);
+            }
         }
     }
 }

@@ -293,6 +293,8 @@ class _Binding:
             self.engine_set_arithmetic = fn("engine_set_arithmetic", [vp, i32]); self.engine_get_arithmetic = fn("engine_get_arithmetic", [vp, P(i32)])
             self.camera_write_buffer = fn("camera_write_buffer", [vp, u64, i32, vp, sz])
             self.debug_set_pass_mask = fn("debug_set_pass_mask", [vp, u64]); self.debug_last_launches = fn("debug_last_launches", [vp, P(u64), sz, P(sz)])
+            self.camera_present_copy = fn("camera_present_copy", [vp, u64, vp, vp, sz, vp])
+            self.camera_present_ready = fn("camera_present_ready", [vp, u64, vp, i32, P(i32)])
             self.profile_enable = fn("profile_enable", [vp, i32])
             self.profile_read = fn("profile_read", [vp, P(StKernelProfile), sz, P(sz), i32])
             self.last_error = getattr(lib, prefix + "last_error"); self.last_error.restype = C.c_char_p; self.last_error.argtypes = []
@@ -523,6 +525,17 @@ class Engine(EngineBase):
     def set_output_format(self, handle: int, fmt: "OutputFormat"):
         """viewport.format (camera.rs:170-175): what st_render_camera writes into its output buffer."""
         self._check(self._b.camera_set_output_format(self._h, handle, int(fmt)))
+
+    def present_copy(self, handle: int, src_device_ptr: int, dst_host_ptr: int, nbytes: int, stream: int = 0):
+        """st_camera_present_copy: the frame just composed into `src_device_ptr` on `stream` -> page-locked host memory,
+        asynchronously on the camera's copy stream (the facade's present path; the next frame overlaps the copy)."""
+        self._check(self._b.camera_present_copy(self._h, handle, src_device_ptr, dst_host_ptr, nbytes, stream))
+
+    def present_ready(self, handle: int, dst_host_ptr: int, wait: bool = False) -> bool:
+        """st_camera_present_ready: has the copy into `dst_host_ptr` landed? wait=True blocks until it has."""
+        out = C.c_int()
+        self._check(self._b.camera_present_ready(self._h, handle, dst_host_ptr, 1 if wait else 0, C.byref(out)))
+        return out.value == 1
 
     def set_camera_rows(self, handle: int, y0: int, y1: int):
         self._check(self._b.camera_set_rows(self._h, handle, y0, y1))

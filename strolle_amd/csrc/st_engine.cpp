@@ -257,6 +257,13 @@ struct CameraState {
     // (`materialize_gi_history`).
     bool gi_aliased = false;
     bool internal_dirty = false;  // st_camera_write_buffer replaced a plane the internal planes derive from: regenerate them before the next frame
+    // Present hand-over (st_camera_present_copy): composed frames leave for host memory on a stream of their own, behind the
+    // frame that produced them, while the next frame's kernels run. Two copies may be in flight (the caller alternates two
+    // output buffers); a render into a buffer whose copy is still pending is ordered behind that copy.
+    struct PresentSlot { const void* src = nullptr; void* dst = nullptr; hipEvent_t ev_src = nullptr, ev_done = nullptr; bool pending = false; };
+    hipStream_t present_stream = nullptr;
+    PresentSlot present[2];
+    uint32_t present_next = 0;
 };
 static size_t plane_texels_per_pixel(int id) {
     if (id >= ST_BUF_DI_RESERVOIRS_0 && id <= ST_BUF_DI_RESERVOIRS_2) return 2;
@@ -507,6 +514,42 @@ struct Engine {
         if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
         for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
         c.side_stream = nullptr; c.have_prev_frame_events = false;
+        if (c.present_stream) { (void)hipStreamSynchronize(c.present_stream); (void)hipStreamDestroy(c.present_stream); c.present_stream = nullptr; }
+        for (auto& p : c.present) { for (hipEvent_t* e : {&p.ev_src, &p.ev_done}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; } p = CameraState::PresentSlot(); }
+    }
+    // st_camera_present_copy: `src_device` (what st_render_camera composed into on `stream`) -> `dst_host`, asynchronously
+    int present_copy(CameraState& c, const void* src, void* dst, size_t bytes, hipStream_t stream) {
+        if (!has_device) return fail(ST_ERR_NO_DEVICE, "present copy on a host-only engine");
+        ST_HIP(hipSetDevice(device));
+        if (!c.present_stream) ST_HIP(hipStreamCreateWithFlags(&c.present_stream, hipStreamNonBlocking));
+        // the slot that already serves this destination, else the older one
+        CameraState::PresentSlot* slot = nullptr;
+        for (auto& p : c.present) if (p.dst == dst) slot = &p;
+        if (!slot) { slot = &c.present[c.present_next & 1u]; c.present_next++; }
+        if (slot->pending) ST_HIP(hipEventSynchronize(slot->ev_done));  // only when the caller runs more than two frames ahead
+        if (!slot->ev_src) { ST_HIP(hipEventCreateWithFlags(&slot->ev_src, hipEventDisableTiming)); ST_HIP(hipEventCreateWithFlags(&slot->ev_done, hipEventDisableTiming)); }
+        slot->src = src; slot->dst = dst;
+        ST_HIP(hipEventRecord(slot->ev_src, stream));                    // the frame is composed
+        ST_HIP(hipStreamWaitEvent(c.present_stream, slot->ev_src, 0));
+        ST_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.present_stream));
+        ST_HIP(hipEventRecord(slot->ev_done, c.present_stream));
+        slot->pending = true;
+        return ST_OK;
+    }
+    // 1 = the copy into `dst` has landed (or none was asked for), 0 = still in flight; wait != 0 blocks until it has
+    int present_ready(CameraState& c, const void* dst, int wait, int* ready) {
+        *ready = 1;
+        for (auto& p : c.present) {
+            if (p.dst != dst || !p.pending) continue;
+            if (wait) { ST_HIP(hipEventSynchronize(p.ev_done)); p.pending = false; }
+            else {
+                const hipError_t q = hipEventQuery(p.ev_done);
+                if (q == hipSuccess) p.pending = false;
+                else if (q == hipErrorNotReady) { (void)hipGetLastError(); *ready = 0; }
+                else return fail(ST_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+            }
+        }
+        return ST_OK;
     }
 
     // ---- materials (materials.rs:33-96, material.rs:29-50)
@@ -984,6 +1027,12 @@ struct Engine {
         return ST_OK;
     }
 
+    // a composition into a buffer whose present copy has not finished waits for that copy (callers that alternate two
+    // buffers never meet this)
+    static void present_guard(CameraState& c, const void* out, hipStream_t s) {
+        for (auto& p : c.present) if (p.pending && p.src == out) (void)hipStreamWaitEvent(s, p.ev_done, 0);
+    }
+
     // ---- render (camera_controller.rs:87-174)
     int render(CameraState& c, void* out, hipStream_t stream) {
         if (!has_device) return fail(ST_ERR_NO_DEVICE, "render_camera on a host-only engine");
@@ -1209,6 +1258,7 @@ struct Engine {
             };
             auto do_compose = [&] {
                 if (!out || composed) return;
+                present_guard(c, out, cur);
                 const float4* di_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
                 const float4* gi_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
                 run(KS_COMPOSITION, ST_PASS_COMPOSITION, [&] { L.launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
@@ -1275,6 +1325,7 @@ struct Engine {
             }
         }
         if (out && !composed) {
+            present_guard(c, out, cur);
             const bool dn = c.desc.denoise != 0u;
             const float4* di_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
             const float4* gi_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
@@ -1519,6 +1570,19 @@ int st_render_camera(StEngine* e, StHandle h, void* out, void* stream) {
     auto it = E(e)->cameras.find(h);
     if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
     return E(e)->render(*it->second, out, static_cast<hipStream_t>(stream));
+}
+
+int st_camera_present_copy(StEngine* e, StHandle h, const void* src_device, void* dst_host, size_t bytes, void* stream) {
+    ST_REQUIRE(e && src_device && dst_host && bytes, "null argument");
+    auto it = E(e)->cameras.find(h);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    return E(e)->present_copy(*it->second, src_device, dst_host, bytes, static_cast<hipStream_t>(stream));
+}
+int st_camera_present_ready(StEngine* e, StHandle h, const void* dst_host, int wait, int* ready) {
+    ST_REQUIRE(e && ready, "null argument");
+    auto it = E(e)->cameras.find(h);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    return E(e)->present_ready(*it->second, dst_host, wait, ready);
 }
 
 int st_set_seed(StEngine* e, uint64_t seed) { ST_REQUIRE(e, "null engine"); E(e)->base_seed = seed; return ST_OK; }

@@ -7,7 +7,7 @@ import pytest
 
 from oracle_binding import OracleEngine
 from parity import assert_bits_equal, bits_equal_mask
-from strolle_amd import Buffer, CameraMode, Engine, scenes
+from strolle_amd import Buffer, CameraMode, Engine, OutputFormat, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -603,7 +603,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 from oracle_binding import OracleEngine
 from parity import assert_bits_equal
-from strolle_amd import Buffer, CameraMode, Engine, scenes
+from strolle_amd import Buffer, CameraMode, Engine, OutputFormat, scenes
 for build, cam_fn in ((scenes.build_cornell, scenes.cornell_camera), (scenes.build_dungeon, scenes.dungeon_camera)):
     prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
@@ -838,6 +838,7 @@ def test_c_example_renders_the_cornell_box(tmp_path):
     run = subprocess.run([exe, str(glb), str(out), "320", "240", "24"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stderr
     assert "32 triangles" in run.stderr and " rays" in run.stderr
+    assert "24 frames (24 presented" in run.stderr, run.stderr   # every frame left through st_camera_present_copy
     data = out.read_bytes()
     assert data.startswith(b"P6\n320 240\n255\n")
     img = np.frombuffer(data[len(b"P6\n320 240\n255\n"):], np.uint8).reshape(240, 320, 3).astype(np.float32)
@@ -915,3 +916,49 @@ def test_every_scheduling_variant_produces_the_same_bits(switches):
         _compare_all(prod, orac, cp, co, frame)
         assert_bits_equal(img, ref, f"composed frame {frame}")
     prod.close(); orac.close()
+
+
+@pytest.mark.gpu
+def test_present_copy_hands_over_every_frame_without_a_stream_sync():
+    """st_camera_present_copy / st_camera_present_ready (the facade's half of Engine::render_camera, lib.rs:279-286): frame N
+    is copied to page-locked host memory behind its composition while frame N+1 renders; what arrives is what a
+    synchronous read-back of the same device buffer gives, for every frame, with two buffers alternating — and a render
+    into a buffer whose copy is still pending is ordered behind that copy."""
+    torch = _torch()
+    size = (320, 200)
+    e = Engine(device=0, exact=True)
+    scenes.build_cornell(e); e.set_seed(3)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    cam = e.create_camera(desc)
+    e.set_output_format(cam, OutputFormat.RGBA8_UNORM_SRGB)
+    stream = torch.cuda.current_stream().cuda_stream
+    dev = [torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    host = [torch.zeros((size[1], size[0], 4), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    twin = Engine(device=0, exact=True)   # the same frames, read back synchronously
+    scenes.build_cornell(twin); twin.set_seed(3)
+    tcam = twin.create_camera(desc); twin.set_output_format(tcam, OutputFormat.RGBA8_UNORM_SRGB)
+    tout = torch.zeros_like(dev[0])
+    want = []
+    for i in range(7):
+        twin.update_camera(tcam, desc); twin.tick(stream); twin.render_camera(tcam, tout.data_ptr(), stream)
+        torch.cuda.synchronize(); want.append(tout.cpu().numpy().copy())
+    for i in range(7):
+        k = i & 1
+        e.update_camera(cam, desc); e.tick(stream); e.render_camera(cam, dev[k].data_ptr(), stream)
+        e.present_copy(cam, dev[k].data_ptr(), host[k].data_ptr(), dev[k].numel(), stream)
+        if i > 0:
+            e.present_ready(cam, host[k ^ 1].data_ptr(), wait=True)
+            assert np.array_equal(host[k ^ 1].numpy(), want[i - 1]), f"frame {i - 1} through the present path differs from its read-back"
+    assert e.present_ready(cam, host[0].data_ptr(), wait=True)
+    assert np.array_equal(host[0].numpy(), want[6])
+    # one buffer only: the next composition must wait for the pending copy (no tearing)
+    for i in range(7, 10):
+        twin.update_camera(tcam, desc); twin.tick(stream); twin.render_camera(tcam, tout.data_ptr(), stream)
+        torch.cuda.synchronize(); want.append(tout.cpu().numpy().copy())
+    for i in range(7, 10):
+        e.update_camera(cam, desc); e.tick(stream); e.render_camera(cam, dev[0].data_ptr(), stream)
+        e.present_copy(cam, dev[0].data_ptr(), host[i & 1].data_ptr(), dev[0].numel(), stream)
+    for i in (8, 9):
+        e.present_ready(cam, host[i & 1].data_ptr(), wait=True)
+        assert np.array_equal(host[i & 1].numpy(), want[i]), f"frame {i}: a later frame's composition overtook the copy"
+    e.close(); twin.close()
