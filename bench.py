@@ -14,6 +14,15 @@ config), each rank renders one row band (+ apron) and the bands are gathered to 
 --scaling strong: the frame stays width x height and is split into N row bands — BASELINE.json configs 4 and 5 as written:
   ... bench.py --gpus 4 --scaling strong --width 3840 --height 2160 --scene cornell --mode reference     (config 4)
   ... bench.py --gpus 8 --scaling strong --width 3840 --height 2160 --scene dungeon --mode image         (config 5; N = 1, 2, 4, 8)
+Extra regions, all in the same ONE JSON line (none of them changes `value` / `ms_per_step`, which stay the static headline):
+  N = 1, headline workload:  `moving`  — the same K steps with the light orbiting as bevy-strolle/examples/cornell.rs:82-93 animates
+                             it and the camera on a slow orbit (`ms_per_step_moving`);
+                             `present` — the same K steps through the facade's present path (RGBA8 target, two buffers,
+                             st_camera_present_copy to page-locked host memory, previous frame polled: `ms_per_step_with_present`).
+  N > 1:                     `multi_gpu.strong_config5` — BASELINE.json config 5 as written (dungeon 3840x2160 Image, ONE frame split
+                             into N row bands + apron, gathered to rank 0), whatever --scaling the main region used; N = 4 also runs
+                             config 4 (Cornell 3840x2160 Reference, 4 bands) as `multi_gpu.strong_config4`.
+  --no-extras skips them.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -98,6 +107,173 @@ def static_traffic(symbols):
     return (round(total / n) if n else None), "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; (2 x FETCH_SIZE + WRITE_SIZE) x 1024, calibration in profiles/README.md)"
 
 
+def n1_reference(key):
+    """Single-GPU frame time of a BASELINE.json config measured by the builder on one MI355X (profiles/n1_reference.json) —
+    the N = 1 point a strong-scaling figure of this run can be held against. Static, labelled as such."""
+    path = os.path.join(ROOT, "profiles", "n1_reference.json")
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
+
+
+class Job:
+    """One camera of one scene on this rank: engine, row band (+ apron), double-buffered render targets and the per-frame
+    gather of the bands to rank 0 on a communication stream."""
+
+    def __init__(self, torch, dist, args, scene, mode_name, size, world, rank, local_rank, debug_shared):
+        from strolle_amd import CameraMode, Engine, scenes
+        from strolle_amd.distributed import band_for_rank, render_window
+        self.torch, self.dist, self.world, self.rank, self.debug_shared = torch, dist, world, rank, debug_shared
+        self.scenes = scenes
+        self.scene, self.mode_name = scene, mode_name
+        self.width, self.height = size
+        self.engine = Engine(device=local_rank, exact=True if args.exact else None)
+        mode = {"image": CameraMode.IMAGE, "gi_diffuse": CameraMode.GI_DIFFUSE, "reference": CameraMode.REFERENCE, "heatmap": CameraMode.BVH_HEATMAP}[mode_name]
+        if scene == "cornell":
+            scenes.build_cornell(self.engine)
+            self.desc = scenes.cornell_camera(size, mode, depth=1)
+        else:
+            scenes.build_dungeon(self.engine, subdivide=2 if scene == "dungeon134k" else 0)
+            self.desc = scenes.dungeon_camera(size, mode, depth=1)
+        self.mode = mode
+        self.engine.set_seed(args.seed)
+        self.cam = self.engine.create_camera(self.desc)
+        self.band = band_for_rank(self.height, world, rank)
+        self.window = (0, self.height)
+        self.needs_apron = mode_name in ("image", "gi_diffuse")   # Reference / heatmap pixels read nothing but their own
+        self.apron = (args.apron if self.needs_apron else 0) if world > 1 else 0
+        if world > 1:
+            self.window = render_window(self.height, self.band, self.apron)
+            self.engine.set_camera_rows(self.cam, *self.window)
+        self.dev = f"cuda:{local_rank}"
+        # double-buffered render targets: frame i is gathered on `comm` while frame i+1 renders on `main`
+        self.outs = [torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=self.dev) for _ in range(2 if world > 1 else 1)]
+        self.full = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=self.dev) if (world > 1 and rank == 0) else None
+        self.main = torch.cuda.current_stream()
+        self.comm = torch.cuda.Stream(device=self.dev) if world > 1 else None
+        self.gathered = [None, None]  # events: gather that read outs[k] has finished
+        self.gather_events = []       # (start, stop) of every gather on the comm stream
+        self.stream = self.main.cuda_stream
+        self.frame_no = 0
+        self.moving = False
+        self.moving_t0 = None
+
+    def animate(self):
+        """bevy-strolle/examples/cornell.rs:82-93: the point light at (sin t / 2, 1.5, cos t / 2), t = elapsed seconds (one frame =
+        1/60 s here); the camera — an orbit controller in the example — circles the box's centre at 0.1 rad/s."""
+        import math
+        from strolle_amd import Light
+        if self.moving_t0 is None:
+            self.moving_t0 = self.frame_no
+        t = (self.frame_no - self.moving_t0) / 60.0
+        self.engine.insert_light(1, Light.point((math.sin(t) / 2.0, 1.5, math.cos(t) / 2.0), 0.15, (50.0 / (4.0 * math.pi),) * 3, 20.0))
+        a = 0.1 * t
+        self.desc = self.scenes.camera_for((self.width, self.height), (3.2 * math.sin(a), 1.0, 3.2 * math.cos(a)), (0.0, 1.0, 0.0), self.mode, True, 1)
+
+    def step(self):
+        torch, world, rank = self.torch, self.world, self.rank
+        k = self.frame_no % len(self.outs)
+        if self.moving:
+            self.animate()
+        self.frame_no += 1
+        out = self.outs[k]
+        if world > 1 and self.gathered[k] is not None:
+            self.main.wait_event(self.gathered[k])   # outs[k] may be overwritten only after its previous gather has read it
+        self.engine.update_camera(self.cam, self.desc)   # Bevy calls update_camera every frame (bevy-strolle/src/stages/prepare.rs:300-340)
+        self.engine.tick(self.stream)
+        self.engine.render_camera(self.cam, out.data_ptr(), self.stream)
+        if world == 1:
+            return out
+        from strolle_amd.distributed import gather_bands_to_root
+        rendered = torch.cuda.Event(); rendered.record(self.main)
+        self.comm.wait_event(rendered)
+        with torch.cuda.stream(self.comm):
+            g0 = torch.cuda.Event(enable_timing=True); g0.record(self.comm)
+            if self.debug_shared:
+                self.comm.synchronize()
+                host_full = torch.zeros((self.height, self.width, 4)) if rank == 0 else None
+                gather_bands_to_root(out.cpu(), host_full, self.height, world, rank)
+                if rank == 0:
+                    self.full.copy_(host_full)
+            else:
+                gather_bands_to_root(out, self.full, self.height, world, rank)   # the only collective: bands -> rank 0 over RCCL
+            done = torch.cuda.Event(enable_timing=True); done.record(self.comm)
+        self.gather_events.append((g0, done))
+        self.gathered[k] = done
+        return self.full if rank == 0 else out
+
+    def run(self, n):
+        f = None
+        for _ in range(n):
+            f = self.step()
+        return f
+
+    def timed_region(self, steps):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides."""
+        torch = self.torch
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f = self.run(steps)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, f
+
+    def counted_rays(self):
+        """rays of this rank's OWN band: apron rows are redundant work and not counted"""
+        return self.engine.ray_count(self.cam) * (self.band[1] - self.band[0]) / (self.window[1] - self.window[0])
+
+    def reduce(self, elapsed, rays):
+        """max over ranks of the time, sum of the rays, every rank's ms per step"""
+        torch, dist, world = self.torch, self.dist, self.world
+        if world == 1:
+            return elapsed, float(rays), None
+        on = "cpu" if self.debug_shared else self.dev
+        t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=on)
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        each = [torch.zeros(1, dtype=torch.float64, device=on) for _ in range(world)]
+        dist.all_gather(each, torch.tensor([elapsed], dtype=torch.float64, device=on))
+        return float(tmax[0]), float(tsum[1]), [float(x[0]) for x in each]
+
+    def gather_ms(self):
+        ev = self.gather_events
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
+
+    def close(self):
+        self.torch.cuda.synchronize()
+        self.engine.close()
+        self.outs = []; self.full = None
+
+
+def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scene, mode_name, size, key):
+    """A BASELINE.json multi-GPU config as written — ONE frame of `size` split into `world` row bands (+ apron in Image mode),
+    bands gathered to rank 0 every frame — timed like the main region (barrier + synchronize on both sides, max over ranks)."""
+    job = Job(torch, dist, args, scene, mode_name, size, world, rank, local_rank, debug_shared)
+    steps = max(2, min(args.steps, 30))
+    job.run(min(args.preroll, 48)); job.run(args.warmup)
+    torch.cuda.synchronize()
+    job.engine.ray_count(job.cam, reset=True); job.gather_events.clear()
+    elapsed, frame = job.timed_region(steps)
+    elapsed, rays_total, per_rank = job.reduce(elapsed, job.counted_rays())
+    finite = bool(torch.isfinite(frame).all())
+    out = {"workload": f"{scene} {size[0]}x{size[1]} mode {mode_name}, strong: one frame in {world} row bands, gathered to rank 0",
+           "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4), "Mray_per_s": round(rays_total / elapsed / 1e6, 2),
+           "per_rank_ms": None if per_rank is None else [round(x / steps * 1e3, 4) for x in per_rank],
+           "gather_ms": None if job.gather_ms() is None else round(job.gather_ms(), 4),
+           "gathered_bytes_per_frame": (job.height - (job.band[1] - job.band[0])) * job.width * 16,
+           "band_rows": job.band[1] - job.band[0], "apron_rows": job.apron,
+           "apron_overhead_frac": round((job.window[1] - job.window[0]) / (job.band[1] - job.band[0]) - 1.0, 4),
+           "n1_ms_reference": n1_reference(key), "n1_ms_reference_source": "profiles/n1_reference.json (builder-run single-GPU figure, not measured by this process)",
+           "frame_finite": finite}
+    job.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +297,8 @@ def main():
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last (gathered) frame as .npy — tests compare it with a single-GPU render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra regions (moving scene, present path; N > 1: BASELINE configs 5 / 4 as written)")
+    ap.add_argument("--extras-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"), help="frame of the N > 1 strong-scaling extras (tests shrink it)")
     args = ap.parse_args()
 
     import torch
@@ -153,86 +331,28 @@ def main():
 
     base = (args.width, args.height)
     width, height = weak_scaling_frame(base, world) if args.scaling == "weak" else base
-    engine = Engine(device=local_rank, exact=True if args.exact else None)
-    mode = {"image": CameraMode.IMAGE, "gi_diffuse": CameraMode.GI_DIFFUSE, "reference": CameraMode.REFERENCE, "heatmap": CameraMode.BVH_HEATMAP}[args.mode]
-    if args.scene == "cornell":
-        scenes.build_cornell(engine)
-        desc = scenes.cornell_camera((width, height), mode, depth=1)
-    else:
-        scenes.build_dungeon(engine, subdivide=2 if args.scene == "dungeon134k" else 0)
-        desc = scenes.dungeon_camera((width, height), mode, depth=1)
-    engine.set_seed(args.seed)
-    cam = engine.create_camera(desc)
-    band = band_for_rank(height, world, rank)
-    window = (0, height)
-    needs_apron = args.mode in ("image", "gi_diffuse")   # Reference / heatmap pixels read nothing but their own
-    if world > 1:
-        window = render_window(height, band, args.apron if needs_apron else 0)
-        engine.set_camera_rows(cam, *window)
-    dev = f"cuda:{local_rank}"
-    # double-buffered render targets: frame i is gathered on `comm` while frame i+1 renders on `main`
-    outs = [torch.zeros((height, width, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
-    full = torch.zeros((height, width, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
-    main = torch.cuda.current_stream()
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
-    gathered = [None, None]  # events: gather that read outs[k] has finished
-    gather_events = []       # (start, stop) of every gather on the comm stream
-    stream = main.cuda_stream
-    frame_no = [0]
+    rccl_ranks, backend = None, None
+    if world > 1:   # an actual collective on the backend the gather will use: every rank must have joined it
+        backend = dist.get_backend()
+        one = torch.ones(1, dtype=torch.float32, device="cpu" if debug_shared else f"cuda:{local_rank}")
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        assert rccl_ranks == dist.get_world_size() == world
+    job = Job(torch, dist, args, args.scene, args.mode, (width, height), world, rank, local_rank, debug_shared)
+    engine, cam, band, window, dev = job.engine, job.cam, job.band, job.window, job.dev
+    needs_apron = job.needs_apron
+    step, timed_region = job.step, lambda: job.timed_region(args.steps)
 
-    def step():
-        k = frame_no[0] % len(outs)
-        frame_no[0] += 1
-        out = outs[k]
-        if world > 1 and gathered[k] is not None:
-            main.wait_event(gathered[k])   # outs[k] may be overwritten only after its previous gather has read it
-        engine.update_camera(cam, desc)   # Bevy calls update_camera every frame (bevy-strolle/src/stages/prepare.rs:300-340)
-        engine.tick(stream)
-        engine.render_camera(cam, out.data_ptr(), stream)
-        if world == 1:
-            return out
-        rendered = torch.cuda.Event(); rendered.record(main)
-        comm.wait_event(rendered)
-        with torch.cuda.stream(comm):
-            g0 = torch.cuda.Event(enable_timing=True); g0.record(comm)
-            if debug_shared:
-                comm.synchronize()
-                host_full = torch.zeros((height, width, 4)) if rank == 0 else None
-                gather_bands_to_root(out.cpu(), host_full, height, world, rank)
-                if rank == 0:
-                    full.copy_(host_full)
-            else:
-                gather_bands_to_root(out, full, height, world, rank)   # the only collective: bands -> rank 0 over RCCL
-            done = torch.cuda.Event(enable_timing=True); done.record(comm)
-        gather_events.append((g0, done))
-        gathered[k] = done
-        return full if rank == 0 else out
-
-    for _ in range(args.preroll):   # setup: bring the camera's temporal accumulators to their steady state (see --preroll)
-        step()
-    for _ in range(args.warmup):
-        step()
+    job.run(args.preroll)   # setup: bring the camera's temporal accumulators to their steady state (see --preroll)
+    job.run(args.warmup)
     torch.cuda.synchronize()
     engine.ray_count(cam, reset=True)
-    gather_events.clear()
-
-    def timed_region():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            f = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, f
+    job.gather_events.clear()
 
     # region 1: EXACTLY K steps, no instrumentation -> value / ms_per_step
     elapsed, frame = timed_region()
-    rays = engine.ray_count(cam) * (band[1] - band[0]) / (window[1] - window[0])   # apron rows are redundant work: not counted
-    gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events)) if gather_events else None
+    rays = job.counted_rays()
+    gather_ms = job.gather_ms()
     # region 2: the same K steps again with HIP events around every run of same-slot launches (on the launch stream, pass
     # graph serial) -> per-kernel average durations for the roofline object. Kept out of region 1: it costs ~10 %.
     prof, profiled_ms = [], None
@@ -256,27 +376,73 @@ def main():
         for q in prof:
             q["traversal_bytes"] = trav.get(q["name"], 0.0)
             q["algorithmic_bytes"] += q["traversal_bytes"]
-    on_cpu = "cpu" if debug_shared else f"cuda:{local_rank}"
-    t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=on_cpu)
-    per_rank_ms = None
-    if world > 1:
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        each = [torch.zeros(1, dtype=torch.float64, device=on_cpu) for _ in range(world)]
-        dist.all_gather(each, torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=on_cpu))
-        per_rank_ms = [round(float(x[0]), 4) for x in each]
-        elapsed, rays_total = float(tmax[0]), float(tsum[1])
-    else:
-        rays_total = float(rays)
+    elapsed, rays_total, per_rank = job.reduce(elapsed, rays)
+    per_rank_ms = None if per_rank is None else [round(x / args.steps * 1e3, 4) for x in per_rank]
     finite = bool(torch.isfinite(frame).all())
     if rank == 0 and args.dump_frame:
         import numpy as np
         np.save(args.dump_frame, frame.cpu().numpy())
+    headline = (args.scene, args.mode) == ("cornell", "image")
+    engine_exact = engine.exact
+    extras = {}
+    if not args.no_extras and world == 1 and headline:
+        # -- the headline under motion (bevy-strolle/examples/cornell.rs animates its light every frame; the static figure
+        #    above is the renderer's cheapest state: no reservoir is invalidated, preview resampling draws no neighbour)
+        job.moving = True
+        job.run(args.warmup)
+        torch.cuda.synchronize(); engine.ray_count(cam, reset=True)
+        el_m, frame_m = job.timed_region(args.steps)
+        rays_m = engine.ray_count(cam)
+        job.moving = False
+        extras["ms_per_step_moving"] = round(el_m / args.steps * 1e3, 4)
+        extras["moving"] = {"what": "same K steps; point light at (sin t / 2, 1.5, cos t / 2), t advancing 1/60 s per frame (cornell.rs:82-93), camera orbiting the box at 0.1 rad/s; light + camera updated through insert_light / update_camera before every tick",
+                            "Mray_per_s": round(rays_m / el_m / 1e6, 2), "rays_per_frame": round(rays_m / args.steps), "frame_finite": bool(torch.isfinite(frame_m).all())}
+        # -- the facade's present path (rust/strolle-hip/src/present.rs, examples/render_gltf.c): RGBA8 target, two device
+        #    frames + two page-locked host frames alternate, frame N-1 is polled (never a stream join) while frame N renders
+        from strolle_amd import OutputFormat
+        job.desc = job.scenes.cornell_camera((width, height), job.mode, depth=1)
+        import math
+        from strolle_amd import Light
+        engine.insert_light(1, Light.point((0.0, 1.5, 0.5), 0.15, (50.0 / (4.0 * math.pi),) * 3, 20.0))   # light back at t = 0
+        engine.set_output_format(cam, OutputFormat.RGBA8_UNORM_SRGB)
+        dev8 = [torch.zeros((height, width, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+        host8 = [torch.zeros((height, width, 4), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        waited = [0]
+
+        def present_step(i):
+            k = i & 1
+            engine.update_camera(cam, job.desc); engine.tick(job.stream)
+            engine.render_camera(cam, dev8[k].data_ptr(), job.stream)
+            engine.present_copy(cam, dev8[k].data_ptr(), host8[k].data_ptr(), dev8[k].numel(), job.stream)
+            if i > 0 and not engine.present_ready(cam, host8[k ^ 1].data_ptr()):
+                waited[0] += 1
+                engine.present_ready(cam, host8[k ^ 1].data_ptr(), wait=True)
+        for i in range(args.warmup + 12):
+            present_step(i)
+        torch.cuda.synchronize(); waited[0] = 0
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            present_step(i)
+        engine.present_ready(cam, host8[(args.steps - 1) & 1].data_ptr(), wait=True)   # the last frame has to arrive too
+        torch.cuda.synchronize()
+        el_p = time.perf_counter() - t0
+        engine.set_output_format(cam, OutputFormat.RGBA32F)
+        extras["ms_per_step_with_present"] = round(el_p / args.steps * 1e3, 4)
+        extras["present"] = {"what": "same K steps composed as RGBA8 sRGB into two alternating device frames, st_camera_present_copy to two page-locked host frames, the previous frame's copy polled before the next tick (one frame of latency, no stream join)",
+                             "bytes_per_frame": width * height * 4, "frames_that_had_to_wait_for_their_copy": waited[0],
+                             "host_frame_nonzero": bool(host8[(args.steps - 1) & 1].any())}
+        del dev8, host8
+    strong = {}
+    if not args.no_extras and world > 1:
+        job.close()
+        ex = tuple(args.extras_size)
+        strong["strong_config5"] = strong_config(torch, dist, args, world, rank, local_rank, debug_shared, "dungeon", "image", ex, "config5_dungeon_3840x2160_image_ms")
+        if world == 4:
+            strong["strong_config4"] = strong_config(torch, dist, args, world, rank, local_rank, debug_shared, "cornell", "reference", ex, "config4_cornell_3840x2160_reference_ms")
     copy_ceiling = measure_copy_ceiling(torch, dev) if (rank == 0 and not debug_shared) else None
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        headline = (args.scene, args.mode) == ("cornell", "image")
         result = {
             "metric": "Mray/s (primary + shadow + GI rays traced per second, whole job)",
             "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mray/s",
@@ -286,7 +452,7 @@ def main():
                                     if headline else f"{args.scene} {width}x{height}, mode {args.mode} (NOT the headline workload)"),
                        "scene": {"cornell": "cornell (32 triangles, 2 light slots)", "dungeon": scenes.DUNGEON_DESCRIPTION,
                                  "dungeon134k": "SYNTHETIC: the dungeon with every triangle split into 16, same materials and lights"}[args.scene],
-                       "arithmetic": "exact (bit-identical to the CPU oracle)" if engine.exact else "fast (hardware rcp/sqrt/exp/log, FMA contraction; traversal exact; tolerances in tests/test_gpu_fast_tolerance.py)",
+                       "arithmetic": "exact (bit-identical to the CPU oracle)" if engine_exact else "fast (hardware rcp/sqrt/exp/log, FMA contraction; traversal exact; tolerances in tests/test_gpu_fast_tolerance.py)",
                        "width": width, "height": height,
                        "per_gpu_rows": band[1] - band[0], "apron_rows": (args.apron if needs_apron else 0) if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
@@ -294,8 +460,14 @@ def main():
                        "partition": "single GPU" if world == 1 else f"{world} row bands, per-frame RCCL gather of the RGBA32F bands to rank 0 overlapped with the next frame"},
         }
         if world > 1:
-            result["multi_gpu"] = {"rccl_ranks": world, "per_rank_ms_per_step": per_rank_ms, "gather_ms_on_comm_stream_rank0": None if gather_ms is None else round(gather_ms, 4),
-                                   "gathered_bytes_per_frame": (height - (band[1] - band[0])) * width * 16}
+            result["multi_gpu"] = {"rccl_ranks": rccl_ranks, "backend": backend, "rccl_ranks_note": "sum of ones over an all-reduce on that backend before the first frame (nccl = RCCL on ROCm)",
+                                   "per_rank_ms_per_step": per_rank_ms, "gather_ms_on_comm_stream_rank0": None if gather_ms is None else round(gather_ms, 4),
+                                   "gathered_bytes_per_frame": (height - (band[1] - band[0])) * width * 16,
+                                   "apron_overhead_frac": round((window[1] - window[0]) / (band[1] - band[0]) - 1.0, 4),
+                                   "main_region": "weak scaling: NOT a BASELINE config for N > 1 (the frame grows with N); the BASELINE configs as written are strong_config5 / strong_config4 below" if args.scaling == "weak" else "strong scaling of --width x --height",
+                                   "hardware_scaling_curve": "none measured by the builder (gpurun boxes have one GPU); whatever the driver's N = 1, 2, 4, 8 runs print is the first",
+                                   **strong}
+        result.update(extras)
         if copy_ceiling is not None:
             result["hbm_copy_ceiling_GBps_measured"] = round(copy_ceiling, 1)
         if prof:
@@ -357,6 +529,20 @@ def main():
                                      "B_frac_of_peak": round(b_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "B_frac_of_measured_copy_ceiling": None if not copy_ceiling else round(b_bytes / (ms * 1e-3) / 1e9 / copy_ceiling, 4),
                                      "note": "B = compulsory screen-space plane bytes of the reference's passes (unfused accounting; HBM), A = the reference's used_memory traversal bytes (cache- or LDS-served on these scenes: not HBM traffic, not added to B)"}
+            # the frame's REAL traffic: the committed counter passes' bytes per launch x this run's launches per frame. This — not
+            # B_frac_of_peak, an unfused-accounting equivalent rate that fusion inflates — is the achieved HBM bandwidth.
+            counted, missing = 0.0, []
+            for q in prof:
+                per_launch, _ = static_traffic([q["name"]])
+                if per_launch is None:
+                    missing.append(q["name"])
+                else:
+                    counted += per_launch * q["launches"] / args.steps
+            result["frame_bytes"].update({"counter_GB_per_frame": round(counted / 1e9, 4), "counter_GBps": round(counted / (ms * 1e-3) / 1e9, 1),
+                                          "counter_frac_of_peak": round(counted / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "counter_frac_of_measured_copy_ceiling": None if not copy_ceiling else round(counted / (ms * 1e-3) / 1e9 / copy_ceiling, 4),
+                                          "counter_slots_without_data": missing,
+                                          "counter_note": "sum over slots of (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/pmc_latest.json (static: an earlier rocprofv3 --pmc run of this command; an upper bound for the gather kernels) x launches per frame of THIS run, over THIS run's ms_per_step"})
             result["ms_per_step_with_event_timing"] = round(profiled_ms, 4)
         if world == 1 and not args.no_cpu_baseline and headline:
             try:

@@ -341,7 +341,14 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
 // ---- a single zero-jitter pass staged through LDS (stride 4; also strides 1 and 2 when run unfused)
 template <int S>
 __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_lds(const KArgs a, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out) {
-    constexpr int WH = kWvH + 2 * S, P = (kWvW + 2 * S + 15) / 16 * 16 + 8;  // pitch = 8 mod 16 texels
+#ifdef ST_WAVELET_PITCH_LOOSE   // round 2's pitch (A/B, tools/ab_bench.sh): 56 texels for every stride
+    constexpr int WH = kWvH + 2 * S, P = (kWvW + 2 * S + 15) / 16 * 16 + 8;
+#else
+    // row pitch: the smallest P >= window width with P = 8 mod 16 texels (conflict-free ds_read_b128 of two row segments per
+    // wave). Stride 4: 40 texels -> 46 KB of LDS per block, three blocks per CU (56 gave 64.5 KB and two)
+    constexpr int WH = kWvH + 2 * S, P = (kWvW + 2 * S + 7) / 16 * 16 + 8;
+    static_assert(P >= kWvW + 2 * S && P % 16 == 8, "pitch");
+#endif
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
     __shared__ float4 s_gi[P * WH];

@@ -455,13 +455,22 @@ def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
     env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", ST_EXACT="1")  # exact build: the bit-compare below needs it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--width", "128", "--height", "64", "--mode", "reference",
-           "--preroll", "0", "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
+           "--preroll", "0", "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump), "--extras-size", "160", "96"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["width"] == 128 and out["config"]["height"] == 128 and out["config"]["frame_finite"]
     assert out["config"]["rays_per_frame"] > 0 and out["value"] > 0
+    # the line the driver's N > 1 runs will produce also carries BASELINE.json's config 5 as written (here shrunk to 160x96):
+    # one dungeon Image frame split into the ranks' row bands + apron, gathered to rank 0
+    mg = out["multi_gpu"]
+    assert mg["rccl_ranks"] == 2 and mg["backend"] == "gloo"   # shared-GPU debug mode gathers through gloo
+    c5 = mg["strong_config5"]
+    assert c5["band_rows"] == 48 and c5["apron_rows"] == 16 and c5["frame_finite"] and c5["ms_per_step"] > 0 and c5["Mray_per_s"] > 0
+    assert len(c5["per_rank_ms"]) == 2 and c5["gather_ms"] is not None and c5["gathered_bytes_per_frame"] == 48 * 160 * 16
+    assert abs(c5["apron_overhead_frac"] - (64 / 48 - 1)) < 1e-3 and "n1_ms_reference" in c5
+    assert "strong_config4" not in mg   # N = 4 only
     got = np.load(dump)
     # the same 5 frames in one process
     prod = Engine(device=0, exact=True)
@@ -486,7 +495,7 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--width", "160", "--height", "96", "--mode", "reference", "--scaling", "strong",
-           "--exact", "--preroll", "0", "--no-cpu-baseline", "--no-profile", "--dump-frame", str(dump)]
+           "--exact", "--preroll", "0", "--no-cpu-baseline", "--no-profile", "--no-extras", "--dump-frame", str(dump)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- 'bash tools/gpu_batch.sh <steps...>'): a batch of independent measurement steps, each
+# logging to gpurun_out/<tag>_<step>.log. Steps: probe steady tests bench dungeon config5 ab:<flags> profile
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+TAG=${TAG:-r03}
+mkdir -p gpurun_out
+python -c 'import __graft_entry__ as g; g.build()' > gpurun_out/${TAG}_build.log 2>&1 || { tail -20 gpurun_out/${TAG}_build.log; exit 1; }
+for step in "$@"; do
+  echo "=== $step"; t0=$(date +%s)
+  case "$step" in
+    probe)
+      hipcc --offload-arch=gfx950 -O3 tools/tap_probe.hip -o /tmp/tap_probe && timeout 120 /tmp/tap_probe > gpurun_out/${TAG}_tap_probe.txt 2>&1; cat gpurun_out/${TAG}_tap_probe.txt ;;
+    steady)
+      ST_TOL_REPORT_ONLY=${REPORT_ONLY:-1} timeout 1500 python -m pytest tests/test_gpu_fast_steady_state.py -x -q --durations=8 > gpurun_out/${TAG}_steady.log 2>&1; tail -15 gpurun_out/${TAG}_steady.log ;;
+    newtests)
+      timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "present_copy or bench_two_rank or bench_strong or c_example" --durations=8 > gpurun_out/${TAG}_newtests.log 2>&1; tail -8 gpurun_out/${TAG}_newtests.log ;;
+    tests)
+      timeout 2400 python -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -25 gpurun_out/${TAG}_pytest_gpu.log ;;
+    bench)
+      timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; head -c 1500 gpurun_out/${TAG}_bench.json; echo; tail -3 gpurun_out/${TAG}_bench.err ;;
+    dungeon)
+      timeout 600 python bench.py --scene dungeon --no-cpu-baseline > gpurun_out/${TAG}_bench_dungeon.json 2> gpurun_out/${TAG}_bench_dungeon.err; head -c 600 gpurun_out/${TAG}_bench_dungeon.json; echo ;;
+    config5)
+      timeout 600 python bench.py --scene dungeon --width 3840 --height 2160 --no-cpu-baseline --no-profile > gpurun_out/${TAG}_bench_config5_n1.json 2> gpurun_out/${TAG}_bench_config5_n1.err; head -c 400 gpurun_out/${TAG}_bench_config5_n1.json; echo
+      timeout 600 python bench.py --mode reference --width 3840 --height 2160 --no-cpu-baseline --no-profile > gpurun_out/${TAG}_bench_config4_n1.json 2> gpurun_out/${TAG}_bench_config4_n1.err; head -c 400 gpurun_out/${TAG}_bench_config4_n1.json; echo ;;
+    ab:*)
+      bash tools/ab_bench.sh "${step#ab:}" --no-extras > gpurun_out/${TAG}_ab.log 2>&1; cat gpurun_out/${TAG}_ab.log ;;
+    profile)
+      bash tools/gpu_profile_quick.sh > gpurun_out/${TAG}_profile.log 2>&1; tail -5 gpurun_out/${TAG}_profile.log ;;
+    *) echo "unknown step $step" ;;
+  esac
+  echo "--- $step took $(( $(date +%s) - t0 )) s"
+done
