@@ -429,7 +429,7 @@ def main():
         engine.set_output_format(cam, OutputFormat.RGBA32F)
         extras["ms_per_step_with_present"] = round(el_p / args.steps * 1e3, 4)
         extras["present"] = {"what": "same K steps composed as RGBA8 sRGB into two alternating device frames, st_camera_present_copy to two page-locked host frames, the previous frame's copy polled before the next tick (one frame of latency, no stream join)",
-                             "bytes_per_frame": width * height * 4, "frames_that_had_to_wait_for_their_copy": waited[0],
+                             "bytes_per_frame": width * height * 4, "polls_that_found_the_copy_pending": waited[0], "polls_note": "the host enqueues frames faster than the GPU renders them; a pending poll blocks on that ONE copy (never on the render stream), which paces the host one frame ahead",
                              "host_frame_nonzero": bool(host8[(args.steps - 1) & 1].any())}
         del dev8, host8
     strong = {}

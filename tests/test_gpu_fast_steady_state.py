@@ -21,7 +21,7 @@ Both draw on one oracle run per (scene, size): frames alternate between the two 
 
 Tolerance per 32-bit lane as in test_gpu_fast_tolerance.py (bit-equal, or floats within ATOL + RTOL * max(|a|, |b|));
 per plane a stated fraction of the lanes may miss it:
-  launch by launch ......... BAD_FRACTION_LAUNCH (same figure as the small-size test)
+  launch by launch ......... BAD_FRACTION_LAUNCH
   whole frame, reservoirs .. BAD_FRACTION_FRAME_DISCRETE: a flipped discrete choice early in the frame (a shadow ray at a
                              silhouette, `rand * w_sum < w`) hands every later pass of that pixel another sample
   whole frame, colours ..... the a-trous chain spreads one flipped sample over a 63-pixel footprint with a small weight:
@@ -38,19 +38,24 @@ import pytest
 from oracle_binding import OracleEngine
 from parity import psnr
 from strolle_amd import Buffer, CameraMode, Engine, PassBit, scenes
-from test_gpu_fast_tolerance import ATOL, BAD_FRACTION, RTOL, lanes_outside_tolerance
+from test_gpu_fast_tolerance import ATOL, RTOL, lanes_outside_tolerance
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT_ONLY = os.environ.get("ST_TOL_REPORT_ONLY") == "1"
 FLOAT_BUFFERS = [b for b in Buffer if b != Buffer.DBG_USED_MEMORY]
-BAD_FRACTION_LAUNCH = BAD_FRACTION
+# Measured on MI355X (round 3, gpurun_out/fast_steady_*.json): launch by launch at 1080p the worst plane of any launch has
+# 3.4e-5 of its lanes outside the per-lane tolerance (an a-trous plane; the worst resampling launch 1.7e-5). After one WHOLE
+# unmasked frame: Cornell 1080p <= 3.6e-4 on every plane, dungeon 1080p <= 1.7e-3 on reservoir / sample planes and
+# <= 6.9e-3 on the filtered GI planes (PSNR >= 73 dB, means within 3.2e-5), dungeon 4K <= 8.9e-4 (PSNR >= 79 dB).
+BAD_FRACTION_LAUNCH = 5e-4
 # Whole frame: planes whose content is a discrete choice carried through the frame (reservoirs, samples before filtering)
-BAD_FRACTION_FRAME_DISCRETE = 2e-2
+BAD_FRACTION_FRAME_DISCRETE = 5e-3
 # Whole frame: filtered colour planes and the composed frame (PSNR against the oracle's plane, peak = its 99.9th percentile)
-FRAME_PSNR_DB = 50.0
-FRAME_MEAN_RTOL = 2e-3
+BAD_FRACTION_FRAME_FILTERED = 2e-2
+FRAME_PSNR_DB = 65.0
+FRAME_MEAN_RTOL = 5e-4
 
 # planes a frame leaves behind for the next one or for the caller (everything else is scratch that later launches of
 # the same frame overwrite; the fused launches of the whole-frame graph never store some of it — DESIGN.md section 4)
@@ -215,6 +220,7 @@ def _check_whole_rows(rows, what):
             assert REPORT_ONLY or r["nonfinite_px"] == 0, f"{what} frame {r['frame']} {r['plane']}: non-finite pixels"
             assert REPORT_ONLY or r["psnr"] >= FRAME_PSNR_DB, f"{what} frame {r['frame']} {r['plane']}: PSNR {r['psnr']:.1f} dB against the oracle"
             assert REPORT_ONLY or abs(r["mean_ratio"] - 1.0) <= FRAME_MEAN_RTOL, f"{what} frame {r['frame']} {r['plane']}: mean ratio {r['mean_ratio']:.5f}"
+            assert REPORT_ONLY or r["bad_fraction"] <= BAD_FRACTION_FRAME_FILTERED, f"{what} frame {r['frame']} {r['plane']}: {r['bad_fraction']:.2e} of the lanes outside tolerance after one whole frame"
         else:
             assert REPORT_ONLY or r["bad_fraction"] <= BAD_FRACTION_FRAME_DISCRETE, f"{what} frame {r['frame']} {r['plane']}: {r['bad_fraction']:.2e} of the lanes outside tolerance after one whole frame"
 

@@ -32,7 +32,7 @@ from strolle_amd import Buffer, CameraMode, Engine, PassBit, scenes
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 2e-3, 1e-5          # per lane (floats)
-BAD_FRACTION = 5e-3              # per plane and launch: lanes allowed outside RTOL/ATOL (discrete decisions that flipped)
+BAD_FRACTION = 2e-3              # per plane and launch: lanes allowed outside RTOL/ATOL (discrete decisions that flipped); measured worst 1.55e-3 (soup, an a-trous plane)
 FLOAT_BUFFERS = [b for b in Buffer if b != Buffer.DBG_USED_MEMORY]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT_ONLY = os.environ.get("ST_TOL_REPORT_ONLY") == "1"   # calibration runs: write the report, do not fail on the thresholds
