@@ -37,8 +37,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
 # profiler slots (st_kernels.h kernel_info names) that implement the reference's five `frame_denoising::wavelet` passes:
 # name -> reference passes executed per launch
-WAVELET_SLOTS = {"denoise_wavelet": 1, "denoise_wavelet x2 (strides 1+2)": 2}
-WAVELET_SYMBOLS = ["denoise_wavelet_12", "denoise_wavelet_lds<1>", "denoise_wavelet_lds<2>", "denoise_wavelet_lds<4>", "denoise_wavelet_far"]
+WAVELET_SLOTS = {"denoise_wavelet": 1, "denoise_wavelet x2 (strides 1+2)": 2, "denoise_wavelet+composition": 1}
+WAVELET_SYMBOLS = ["denoise_wavelet_12", "denoise_wavelet_lds<1>", "denoise_wavelet_lds<2>", "denoise_wavelet_lds<4>", "denoise_wavelet_far<false>", "denoise_wavelet_far<true>"]
+# the last a-trous pass also runs frame composition (st_kernels.h: 84 + 112 B per pixel credited to that launch); for the
+# a-trous family's roofline only the pass's own 84 B count — its launch time still includes the composition work
+COMPOSE_SHARE = {"denoise_wavelet+composition": 112.0 / (84.0 + 112.0)}
 
 
 def measure_copy_ceiling(torch, dev):
@@ -479,7 +482,7 @@ def main():
             if fam and fam_ms >= max(p["total_ms"] for p in prof if p["name"] not in WAVELET_SLOTS):
                 launches = sum(p["launches"] for p in fam)
                 passes = sum(p["launches"] * WAVELET_SLOTS[p["name"]] for p in fam)
-                alg = sum(p["algorithmic_bytes"] for p in fam)
+                alg = sum(p["algorithmic_bytes"] * (1.0 - COMPOSE_SHARE.get(p["name"], 0.0)) for p in fam)
                 trav = sum(p["traversal_bytes"] for p in fam)
                 name = f"denoise_wavelet ({passes // args.steps} a-trous passes per frame in {launches // args.steps} launches)"
                 tot_ms, symbols = fam_ms, WAVELET_SYMBOLS
@@ -500,7 +503,7 @@ def main():
             # strides-1+2 launch's inputs, so the wavelet-only figure above and this one are both given.
             den = [by[n] for n in list(WAVELET_SLOTS) + ["denoise_variance"] if n in by]
             if den and sum(p["total_ms"] for p in den) > 0:
-                den_alg = sum(p["algorithmic_bytes"] - p["traversal_bytes"] for p in den)
+                den_alg = sum((p["algorithmic_bytes"] - p["traversal_bytes"]) * (1.0 - COMPOSE_SHARE.get(p["name"], 0.0)) for p in den)
                 den_ms = sum(p["total_ms"] for p in den)
                 den_rate = den_alg / (den_ms * 1e-3) / 1e9
                 result["roofline_denoiser"] = {"kernel": "estimate_variance + 5 a-trous passes (frame_denoising.rs:80-361)", "bound": "hbm",

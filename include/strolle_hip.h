@@ -225,6 +225,15 @@ int st_camera_read_buffer(StEngine* e, StHandle camera, int buffer_id, void* out
  * build is compared pass by pass instead of through ReSTIR's chaotic temporal feedback. Planes this library derives from
  * the reference's (decoded surface twins, sqrt-luma planes) are regenerated before the next render. Synchronises. */
 int st_camera_write_buffer(StEngine* e, StHandle camera, int buffer_id, const void* data, size_t bytes);
+/* The lean frame. In the fast build, when the whole pass graph of an Image{denoise} frame runs, planes that nothing reads
+ * again — not a later pass of the frame, not the next frame — are not stored: the velocity map and the encoded surface map
+ * (every kernel reads the decoded twin this library keeps), both diffuse-sample planes (the fused denoise-reproject stages
+ * consume them in registers), the reprojected GI reservoirs of tracing frames, and the last a-trous pass's colour planes
+ * (frame composition runs inside that launch). st_camera_read_buffer of ST_BUF_VELOCITY_MAP, PRIM_SURFACE_MAP_*,
+ * DI/GI_DIFF_SAMPLES, GI_RESERVOIRS_2 and DI/GI_DIFF_CURR_COLORS then returns what an earlier launch left there.
+ * keep != 0 (or ST_KEEP_ALL_PLANES=1 in the environment) makes every frame store all planes as the reference does; the exact
+ * build, a pass mask and the partial camera modes always do. */
+int st_debug_keep_all_planes(StEngine* e, int keep);
 /* One bit per reference pass (strolle/src/camera_controller.rs:87-174 order). st_render_camera executes a launch only when
  * ALL the passes it covers are in the mask (a fused launch covers several); a mask that splits a fused launch is an
  * ST_ERR_INVALID_ARGUMENT. Default: all ones. Frame counters, seeds and plane ping-pong are unaffected. */

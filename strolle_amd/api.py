@@ -293,6 +293,7 @@ class _Binding:
             self.engine_set_arithmetic = fn("engine_set_arithmetic", [vp, i32]); self.engine_get_arithmetic = fn("engine_get_arithmetic", [vp, P(i32)])
             self.camera_write_buffer = fn("camera_write_buffer", [vp, u64, i32, vp, sz])
             self.debug_set_pass_mask = fn("debug_set_pass_mask", [vp, u64]); self.debug_last_launches = fn("debug_last_launches", [vp, P(u64), sz, P(sz)])
+            self.debug_keep_all_planes = fn("debug_keep_all_planes", [vp, i32])
             self.camera_present_copy = fn("camera_present_copy", [vp, u64, vp, vp, sz, vp])
             self.camera_present_ready = fn("camera_present_ready", [vp, u64, vp, i32, P(i32)])
             self.profile_enable = fn("profile_enable", [vp, i32])
@@ -504,6 +505,11 @@ class Engine(EngineBase):
         """st_camera_write_buffer: the inverse of read_buffer (parity tests hand a launch its reference input planes)."""
         data = np.ascontiguousarray(data)
         self._check(self._b.camera_write_buffer(self._h, camera, int(buffer), data.ctypes.data, data.nbytes))
+
+    def keep_all_planes(self, keep: bool):
+        """st_debug_keep_all_planes: True = every frame stores every plane the reference does; False (default in the fast build) =
+        the lean frame, which leaves planes nothing reads again unwritten (include/strolle_hip.h lists them)."""
+        self._check(self._b.debug_keep_all_planes(self._h, 1 if keep else 0))
 
     def set_pass_mask(self, mask: int):
         """st_debug_set_pass_mask: bit set = that reference pass runs (PassBit)."""

@@ -182,10 +182,10 @@ struct WaveletCenter {
     f2 sum_w, sum_r, sum_g, sum_b, sum_v;
 };
 ST_D f2 sqrt_luma2(float4 di, float4 gi) { return sqrt2((mk2(di.x, gi.x) * 0.2126f + mk2(di.y, gi.y) * 0.7152f) + mk2(di.z, gi.z) * 0.0722f); }
-ST_D WaveletCenter wavelet_begin(float4 csn, float4 cdi, float4 cgi, float strength) {
+ST_D WaveletCenter wavelet_begin(float4 csn, float4 cdi, float4 cgi, float strength, f2 c_sqrt_luma) {
     WaveletCenter c;
     c.sn = csn; c.n = v3(csn.x, csn.y, csn.z);
-    c.sqrt_luma = sqrt_luma2(cdi, cgi);
+    c.sqrt_luma = c_sqrt_luma;
     c.luma_sigma = mk2(lerpf(2.5f, 0.5f, fsqrt(cdi.w)), lerpf(1.0f, 0.0f, fsqrt(cgi.w)));
     c.leeway = csn.w * (0.33f / strength); c.inv_leeway = frcp(c.leeway);  // depth sigma is the same for both signals
     c.sum_w = splat2(1.0f); c.sum_r = mk2(cdi.x, cgi.x); c.sum_g = mk2(cdi.y, cgi.y); c.sum_b = mk2(cdi.z, cgi.z); c.sum_v = mk2(cdi.w, cgi.w);
@@ -199,9 +199,10 @@ ST_D bool wavelet_shared(const WaveletCenter& c, float4 ssn, float* depth_weight
     *normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), c.n), 0.0f));
     return !(*depth_weight == 0.0f || *normal_weight == 0.0f);
 }
-ST_D void wavelet_tap(WaveletCenter& c, float4 sdi, float4 sgi, float depth_weight, float normal_weight) {
+// `t_sqrt_luma`: sqrt_luma2() of the tap's two colours (the LDS passes evaluate it once per staged texel, not once per tap)
+ST_D void wavelet_tap(WaveletCenter& c, float4 sdi, float4 sgi, f2 t_sqrt_luma, float depth_weight, float normal_weight) {
     const f2 r = mk2(sdi.x, sgi.x), g = mk2(sdi.y, sgi.y), b = mk2(sdi.z, sgi.z), v = mk2(sdi.w, sgi.w);
-    const f2 d = c.sqrt_luma - sqrt2((r * 0.2126f + g * 0.7152f) + b * 0.0722f);
+    const f2 d = c.sqrt_luma - t_sqrt_luma;
     const f2 luma_weight = mk2(fabsf(d.x), fabsf(d.y)) * c.luma_sigma;
     const f2 w = exp_pair(-luma_weight) * depth_weight * normal_weight;
     if (w.x > 0.0f && w.y > 0.0f) {
@@ -223,18 +224,28 @@ ST_D WaveletOut wavelet_end(const WaveletCenter& c) {
 // one pixel of a zero-jitter pass whose window is in LDS: `lc` = the pixel's texel, taps at +-S texels / rows (pitch P).
 // Texels outside the viewport were staged with depth 0, which is skipped like an out-of-bounds or sky tap. Returns false
 // for a sky pixel (the reference copies the direct colour and leaves the indirect output alone).
+// `s_sl`: sqrt_luma2() of every staged texel with a surface (-DST_WAVELET_NO_SL: recomputed per tap as round 2 did, for A/B)
 template <int S, int P>
-ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const float4* s_gi, int lc, float strength) {
+ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const float4* s_gi, const f2* s_sl, int lc, float strength) {
     const float4 csn = s_sn[lc], cdi = s_di[lc], cgi = s_gi[lc];
     if (csn.w == 0.0f) { WaveletOut o; o.di = cdi; o.gi = cgi; o.lit = false; return o; }
-    WaveletCenter c = wavelet_begin(csn, cdi, cgi, strength);
+#ifdef ST_WAVELET_NO_SL
+    WaveletCenter c = wavelet_begin(csn, cdi, cgi, strength, sqrt_luma2(cdi, cgi));
+#else
+    WaveletCenter c = wavelet_begin(csn, cdi, cgi, strength, s_sl[lc]);
+#endif
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
         const int lt = lc + oy * S * P + ox * S;
         float dw, nw;
         if (!wavelet_shared(c, s_sn[lt], &dw, &nw)) continue;
-        wavelet_tap(c, s_di[lt], s_gi[lt], dw, nw);
+        const float4 tdi = s_di[lt], tgi = s_gi[lt];
+#ifdef ST_WAVELET_NO_SL
+        wavelet_tap(c, tdi, tgi, sqrt_luma2(tdi, tgi), dw, nw);
+#else
+        wavelet_tap(c, tdi, tgi, s_sl[lt], dw, nw);
+#endif
     }
     return wavelet_end(c);
 }
@@ -270,7 +281,7 @@ inline uint32_t wavelet_blocks(const KArgs& a) {
 }
 // stages the (kWvW + 2 HALO) x (kWvH + 2 HALO) window around the block into LDS (row pitch P texels)
 template <int HALO, int P>
-ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* di_in, const float4* gi_in, float4* s_sn, float4* s_di, float4* s_gi) {
+ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* di_in, const float4* gi_in, float4* s_sn, float4* s_di, float4* s_gi, f2* s_sl) {
     constexpr int WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO;
     for (int i = (int)threadIdx.x; i < WW * WH; i += kWvThreads) {
         const int ry = i / WW, rx = i - ry * WW;
@@ -278,7 +289,11 @@ ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* d
         const int li = ry * P + rx;
         if (gx >= 0 && gy >= 0 && gx < (int32_t)a.width && gy < (int32_t)a.height) {
             const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
-            s_sn[li] = a.sn[at]; s_di[li] = di_in[at]; s_gi[li] = gi_in[at];
+            const float4 tsn = a.sn[at], tdi = di_in[at], tgi = gi_in[at];
+            s_sn[li] = tsn; s_di[li] = tdi; s_gi[li] = tgi;
+#ifndef ST_WAVELET_NO_SL
+            if (tsn.w != 0.0f) s_sl[li] = sqrt_luma2(tdi, tgi);  // sky texels are never tapped and never a centre that filters
+#endif
         } else {
             s_sn[li] = f4z();
         }
@@ -297,9 +312,10 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
     __shared__ float4 s_gi[P * WH];
+    __shared__ f2 s_sl[P * WH];
     const WaveletBlock blk = wavelet_block(a);
     if (!blk.valid) return;
-    wavelet_stage<HALO, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi);
+    wavelet_stage<HALO, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi, s_sl);
     __syncthreads();
     // stride-1 pass over the 36 x 20 region (row-major over the threads: 1.4 pixels each)
     float4 r_di[2], r_gi[2]; int r_at[2];
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
         const int ry = idx / RW, rx = idx - ry * RW;
         const int lc = (ry + 1) * P + rx + 1;
         r_at[it] = lc;
-        const WaveletOut o = wavelet_pixel_lds<1, P>(s_sn, s_di, s_gi, lc, strength0);
+        const WaveletOut o = wavelet_pixel_lds<1, P>(s_sn, s_di, s_gi, s_sl, lc, strength0);
         r_di[it] = o.di; r_gi[it] = o.gi;  // sky (or outside the viewport): the indirect colour is never read, as a tap or as a centre
         const bool lit = o.lit;
         // the block's own pixels: this is what the stand-alone stride-1 pass stores
@@ -324,14 +340,19 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
     }
     __syncthreads();  // every stride-1 read of the staged colours is done: replace them by the stride-1 results
 #pragma unroll
-    for (int it = 0; it < 2; it++) if (r_at[it] >= 0) { s_di[r_at[it]] = r_di[it]; s_gi[r_at[it]] = r_gi[it]; }
+    for (int it = 0; it < 2; it++) if (r_at[it] >= 0) {
+        s_di[r_at[it]] = r_di[it]; s_gi[r_at[it]] = r_gi[it];
+#ifndef ST_WAVELET_NO_SL
+        s_sl[r_at[it]] = sqrt_luma2(r_di[it], r_gi[it]);  // (a sky texel's entry is never read)
+#endif
+    }
     __syncthreads();
     // stride-2 pass for the block's own pixels
     const int x = (int)(threadIdx.x & 31u), y = (int)(threadIdx.x >> 5);
     const int32_t px = blk.x0 + x, py = blk.y0 + y;
     if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) return;
     const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
-    const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, (y + HALO) * P + x + HALO, strength1);
+    const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, s_sl, (y + HALO) * P + x + HALO, strength1);
     di_out[center] = o.di;
     // On a sky pixel the stride-2 pass leaves its indirect output alone, and what the reference's stash plane holds there is
     // the variance pass's copy of the input colour — which this launch group never stored there: `o.gi` is that colour.
@@ -352,15 +373,16 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_lds(const KArgs 
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
     __shared__ float4 s_gi[P * WH];
+    __shared__ f2 s_sl[P * WH];
     const WaveletBlock blk = wavelet_block(a);
     if (!blk.valid) return;
-    wavelet_stage<S, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi);
+    wavelet_stage<S, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi, s_sl);
     __syncthreads();
     const int x = (int)(threadIdx.x & 31u), y = (int)(threadIdx.x >> 5);
     const int32_t px = blk.x0 + x, py = blk.y0 + y;
     if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) return;
     const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
-    const WaveletOut o = wavelet_pixel_lds<S, P>(s_sn, s_di, s_gi, (y + S) * P + x + S, strength);
+    const WaveletOut o = wavelet_pixel_lds<S, P>(s_sn, s_di, s_gi, s_sl, (y + S) * P + x + S, strength);
     di_out[center] = o.di;
     if (o.lit) gi_out[center] = o.gi;
 }
@@ -383,13 +405,23 @@ ST_D void signal_tap(WaveletSignal& s, float4 t, float depth_weight, float norma
     if (w > 0.0f) { s.sw += w; s.sr += w * t.x; s.sg += w * t.y; s.sb += w * t.z; s.sv += (w * w) * t.w; }
 }
 ST_D float4 signal_end(const WaveletSignal& s) { return wavelet_resolve(s.sr, s.sg, s.sb, s.sv, s.sw, s.sw * s.sw); }
-__global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out) {
+// COMPOSE: frame_composition.rs runs for the same pixel at the end of the LAST pass (it reads this pixel's two denoised
+// colours — in registers here — plus planes no a-trous pass writes); `keep_colours` == 0 (the lean frame) leaves the pass's
+// own output planes unwritten: nothing but composition reads the last pass's result.
+struct ComposeArgs { void* out; uint32_t format, camera_mode, keep_colours; };
+template <bool COMPOSE>
+__global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out, const ComposeArgs co) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const uint32_t center = pos.y * a.width + pos.x;
     const float4 csn = a.sn[center];
     const float4 cdi = di_in[center];
-    if (csn.w == 0.0f) { di_out[center] = cdi; return; }  // sky
+    const bool store = !COMPOSE || co.keep_colours != 0u;
+    if (csn.w == 0.0f) {  // sky
+        if (store) di_out[center] = cdi;
+        if (COMPOSE) store_output(co.out, center, compose_pixel(a, pos, co.camera_mode, cdi, f4z()), co.format);  // the indirect colour is not read where depth == 0
+        return;
+    }
     const float4 bn = blue_noise_read(a, pos);
     const I2 jitter = as_i2((v2(bn.z, bn.w) - 0.5f) * ((float)stride - 1.0f) * 0.5f);
     uint32_t at[8];
@@ -411,6 +443,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const 
         for (int t = 0; t < 8; t++) if (!wavelet_shared(c, ssn[t], &dw[t], &nw[t])) { dw[t] = 0.0f; nw[t] = 0.0f; at[t] = center; }  // a dead tap re-reads the centre's line
     }
     __builtin_amdgcn_sched_barrier(0);
+    float4 res_di;
     {
         WaveletSignal sg = signal_begin(cdi, 2.5f, 0.5f);
         float4 tap[8];
@@ -418,7 +451,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const 
         for (int t = 0; t < 8; t++) tap[t] = di_in[at[t]];
 #pragma unroll
         for (int t = 0; t < 8; t++) if (dw[t] != 0.0f) signal_tap(sg, tap[t], dw[t], nw[t]);
-        di_out[center] = signal_end(sg);
+        res_di = signal_end(sg);
+        if (store) di_out[center] = res_di;
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -428,7 +462,12 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const 
         for (int t = 0; t < 8; t++) tap[t] = gi_in[at[t]];
 #pragma unroll
         for (int t = 0; t < 8; t++) if (dw[t] != 0.0f) signal_tap(sg, tap[t], dw[t], nw[t]);
-        gi_out[center] = signal_end(sg);
+        const float4 res_gi = signal_end(sg);
+        if (store) gi_out[center] = res_gi;
+        if (COMPOSE) {
+            __builtin_amdgcn_sched_barrier(0);
+            store_output(co.out, center, compose_pixel(a, pos, co.camera_mode, res_di, res_gi), co.format);
+        }
     }
 }
 
@@ -439,7 +478,12 @@ void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, con
     if (stride == 1u) hipLaunchKernelGGL(k_denoise_wavelet_lds<1>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
     else if (stride == 2u) hipLaunchKernelGGL(k_denoise_wavelet_lds<2>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
     else if (stride == 4u) hipLaunchKernelGGL(k_denoise_wavelet_lds<4>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
-    else ST_LAUNCH(k_denoise_wavelet_far, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out);
+    else ST_LAUNCH(k_denoise_wavelet_far<false>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, ComposeArgs{nullptr, 0u, 0u, 1u});
+}
+// a gather pass (stride 8 or 16) with frame_composition.rs appended (the last pass of the chain)
+void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out,
+                                    uint32_t camera_mode, void* out, uint32_t format, bool keep_colours, hipStream_t s) {
+    ST_LAUNCH(k_denoise_wavelet_far<true>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, ComposeArgs{out, format, camera_mode, keep_colours ? 1u : 0u});
 }
 void launch_denoise_wavelet_12(const KArgs& a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out, const float4* gi_in,
                                float4* gi_mid, float4* gi_out, hipStream_t s) {
@@ -448,17 +492,18 @@ void launch_denoise_wavelet_12(const KArgs& a, float strength0, float strength1,
 }
 
 // ---------------------------------------------------------------- st_camera_write_buffer support
-__global__ ST_KERNEL_BOUNDS void k_refresh_internal_planes(const KArgs a, float4* psn_out) {
+// `which`: bit 0 = the current frame's twin (KArgs::sn from KArgs::sm), bit 1 = the previous frame's (psn from psm) — only the
+// twin of a surface map that was actually replaced: in the lean frame the encoded maps are not kept up to date
+__global__ ST_KERNEL_BOUNDS void k_refresh_internal_planes(const KArgs a, float4* psn_out, uint32_t which) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !contains_u(a, pos)) return;
     const uint32_t i = pos.y * a.width + pos.x;
-    const float4 sm = a.sm[i], psm = a.psm[i];
-    a.sn[i] = sm.z == 0.0f ? f4z() : f4(normal_decode(v2(sm.x, sm.y)), sm.z);   // what primary visibility writes beside the surface map
-    psn_out[i] = psm.z == 0.0f ? f4z() : f4(normal_decode(v2(psm.x, psm.y)), psm.z);
+    if (which & 1u) { const float4 sm = a.sm[i]; a.sn[i] = sm.z == 0.0f ? f4z() : f4(normal_decode(v2(sm.x, sm.y)), sm.z); }   // what primary visibility writes beside the surface map
+    if (which & 2u) { const float4 psm = a.psm[i]; psn_out[i] = psm.z == 0.0f ? f4z() : f4(normal_decode(v2(psm.x, psm.y)), psm.z); }
 }
-void launch_refresh_internal_planes(const KArgs& a_in, hipStream_t s) {
+void launch_refresh_internal_planes(const KArgs& a_in, uint32_t which, hipStream_t s) {
     KArgs a = a_in; a.row0 = 0; a.row1 = a.height;
-    ST_LAUNCH(k_refresh_internal_planes, false, s, a, const_cast<float4*>(a.psn));
+    ST_LAUNCH(k_refresh_internal_planes, false, s, a, const_cast<float4*>(a.psn), which);
 }
 
 }  // namespace ST_KNS

@@ -218,7 +218,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     }
     const float diff_brdf = fdivc(1.0f - hit.g.metallic, kPi);
     const float4 diff = f4(radiance * diff_brdf, confidence);
-    tex_write(a.di_diff_samples, a, pos, diff);
+    if (!(REPROJECT && (a.lean & kLeanSamples))) tex_write(a.di_diff_samples, a, pos, diff);
     tex_write(a.di_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
     di_write(a.di_res[0], idx, res);
     if (REPROJECT) {

@@ -180,7 +180,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_temporal(const KArgs a, uint32_t seed) {
         GiReservoir res = reprojected ? gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n) : gi_empty();
         res.confidence = 1.0f;
         res.s.v1_point = lhs_hit.point;
-        gi_write_own(a.gi_res[2], lhs_idx, res, true, some);
+        if (!(a.lean & kLeanGiRes2)) gi_write_own(a.gi_res[2], lhs_idx, res, true, some);
         if (reprojected) rhs = gi_after_store(res);
     } else {
         rhs = gi_read_own(prev_res, lhs_idx, true, reprojected);
@@ -462,7 +462,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
         return;
     }
     if (pass.keep_stored) main_ = gi_read(out, center_idx, n);
-    const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, main_, source);
+    const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, main_, source, reproject != 0u);
     if (reproject) denoise_reproject_finish(a, center_pos, diff, history, a.gi_diff_curr_colors, a.gi_diff_moments);
 }
 // Both preview passes, resolving and (if `reproject`) the GI half of denoise-reproject in one launch, for the pixels whose
@@ -493,7 +493,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview_both(const KArgs a, uint32_t seed,
     const unsigned long long flagged = __ballot(late), active = __ballot(true);
     if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) a.gi_late_mask[gi_late_index(a, center_pos)] = flagged;
     if (late) return;
-    const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, second.r, source);
+    const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, second.r, source, reproject != 0u);
     if (reproject) denoise_reproject_finish(a, center_pos, diff, history, a.gi_diff_curr_colors, a.gi_diff_moments);
 }
 void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, hipStream_t s) {

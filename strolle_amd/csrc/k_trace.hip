@@ -166,7 +166,8 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
     const TriangleHit hit = trace_closest(a, ray, lane_stack(lds), &used_);
     count_rays(a, used_);
     if (!hit_is_some(hit)) {  // LoadOp::Clear(TRANSPARENT)
-        tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z()); tex_write(a.sm, a, pos, f4z()); tex_write(a.velocity, a, pos, f4z());
+        tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z());
+        if (!(REPROJECT && (a.lean & kLeanPrim))) { tex_write(a.sm, a, pos, f4z()); tex_write(a.velocity, a, pos, f4z()); }
         tex_write(a.sn, a, pos, f4z());
         if (REPROJECT) tex_write(a.reprojection, a, pos, f4z());
         return;
@@ -186,14 +187,15 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
     tex_write(a.g0, a, pos, d0);
     tex_write(a.g1, a, pos, d1);
     const V2 en = normal_encode(hit.normal);
-    tex_write(a.sm, a, pos, make_float4(en.x, en.y, g.depth, material.roughness));
+    const bool lean = REPROJECT && (a.lean & kLeanPrim) != 0u;
+    if (!lean) tex_write(a.sm, a, pos, make_float4(en.x, en.y, g.depth, material.roughness));
     tex_write(a.sn, a, pos, f4(normal_decode(en), g.depth));
     // prim_raster.rs:21-27: where this surface point was under its instance's previous transform
     const float4* xf = a.instance_xforms + 8u * hit.xform_slot;
     const V3 prev_point = affine_point(xf + 4, affine_point(xf, hit.point));
     const V2 velocity = clip_to_screen(a.cam, world_to_clip(a.cam, hit.point)) - clip_to_screen(a.prev_cam, world_to_clip(a.prev_cam, prev_point));
     const bool moving = dot(velocity, velocity) >= 0.001f;
-    tex_write(a.velocity, a, pos, moving ? make_float4(velocity.x, velocity.y, 0.0f, 0.0f) : f4z());
+    if (!lean) tex_write(a.velocity, a, pos, moving ? make_float4(velocity.x, velocity.y, 0.0f, 0.0f) : f4z());
     if (REPROJECT) {
         Surface surface; surface.normal = normal_decode(en); surface.depth = g.depth; surface.roughness = 0.0f;
         frame_reprojection_pixel(a, pos, surface, moving ? velocity : v2(0.0f, 0.0f));
@@ -335,13 +337,7 @@ __global__ ST_KERNEL_BOUNDS void k_composition(const KArgs a, uint32_t camera_mo
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const float4 c = compose_pixel(a, pos, camera_mode, tex_read(di_diff, a, pos), tex_read(gi_diff, a, pos));
-    const uint32_t at = pos.y * a.width + pos.x;
-    if (format == 0u) static_cast<float4*>(out)[at] = c;
-    else if (format == 1u) static_cast<uint2*>(out)[at] = make_uint2(f16_bits(c.x) | (f16_bits(c.y) << 16), f16_bits(c.z) | (f16_bits(c.w) << 16));
-    else {
-        const uint32_t r = srgb8_encode(c.x), g = srgb8_encode(c.y), b = srgb8_encode(c.z);
-        static_cast<uint32_t*>(out)[at] = format == 2u ? (r | (g << 8) | (b << 16) | 0xff000000u) : (b | (g << 8) | (r << 16) | 0xff000000u);
-    }
+    store_output(out, pos.y * a.width + pos.x, c, format);
 }
 void launch_composition(const KArgs& a, uint32_t camera_mode, const float4* di_diff, const float4* gi_diff, void* out, uint32_t format, hipStream_t s) {
     ST_LAUNCH(k_composition, false, s, a, camera_mode, di_diff, gi_diff, out, format);

@@ -256,7 +256,7 @@ struct CameraState {
     // that could observe the difference (a pass mask, st_camera_write_buffer) first makes the copy for real
     // (`materialize_gi_history`).
     bool gi_aliased = false;
-    bool internal_dirty = false;  // st_camera_write_buffer replaced a plane the internal planes derive from: regenerate them before the next frame
+    bool surface_map_replaced[2] = {false, false};  // st_camera_write_buffer replaced PRIM_SURFACE_MAP_A / _B: regenerate its decoded twin before the next frame
     // Present hand-over (st_camera_present_copy): composed frames leave for host memory on a stream of their own, behind the
     // frame that produced them, while the next frame's kernels run. Two copies may be in flight (the caller alternates two
     // output buffers); a render into a buffer whose copy is still pending is ordered behind that copy.
@@ -438,6 +438,13 @@ struct Engine {
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
     bool variance_in_reproject = true;  // ST_NO_VARIANCE_IN_REPROJECT=1: estimate_variance as its own full-screen pass
     bool preview_both = true;  // ST_NO_PREVIEW_BOTH=1: the two GI preview passes as two full-screen launches
+    // The lean frame (KArgs::lean, st_types.h kLean*; fast build + whole pass graph + Image-family mode with the denoiser):
+    // planes nothing reads again are not stored — velocity and the encoded surface map (primary visibility), both diffuse
+    // sample planes (resolving + reproject stages), the reprojected GI reservoirs of tracing frames, and the last a-trous
+    // pass's colours when composition rides in that launch. st_camera_read_buffer of those planes returns what an earlier
+    // frame or launch left there; ST_KEEP_ALL_PLANES=1 / st_debug_keep_all_planes(e, 1) stores everything the reference does.
+    bool lean_frame = true;
+    bool fuse_compose = true;  // ST_NO_FUSE_COMPOSE=1: frame composition as its own launch (both builds fuse it into the last a-trous pass by default)
     bool skip_scratch_stores = true;  // ST_KEEP_SCRATCH=1: the fused DI spatial launch stores its intermediate records as the three separate passes would
     bool di_head_on_main = true;  // ST_DI_HEAD_ON_MAIN=0: DI sampling + temporal on the side stream (behind primary visibility) instead of the caller's
     bool alias_gi_history = true;  // ST_NO_GI_ALIAS=1: gi_resolving always copies the source reservoirs into the history plane
@@ -474,6 +481,8 @@ struct Engine {
         if (const char* k = getenv("ST_NO_GI_ALIAS")) alias_gi_history = atoi(k) == 0;
         if (const char* k = getenv("ST_DI_HEAD_ON_MAIN")) di_head_on_main = atoi(k) != 0;
         if (const char* k = getenv("ST_KEEP_SCRATCH")) skip_scratch_stores = atoi(k) == 0;
+        if (const char* k = getenv("ST_KEEP_ALL_PLANES")) lean_frame = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_FUSE_COMPOSE")) fuse_compose = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_PREVIEW_BOTH")) preview_both = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_VARIANCE_IN_REPROJECT")) variance_in_reproject = atoi(k) == 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
@@ -1098,7 +1107,11 @@ struct Engine {
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
         const uint32_t mode = c.desc.mode;
         bool di_reprojected = false, gi_reprojected = false, composed = false, luts_generated_now = false;
-        if (c.internal_dirty) { L.launch_refresh_internal_planes(a, stream); c.internal_dirty = false; luts_generated_now = true; }  // ordered before the side stream like the LUTs
+        if (c.surface_map_replaced[0] || c.surface_map_replaced[1]) {  // ordered before the side stream like the LUTs
+            const uint32_t cur = alt ? 1u : 0u;
+            L.launch_refresh_internal_planes(a, (c.surface_map_replaced[cur] ? 1u : 0u) | (c.surface_map_replaced[cur ^ 1u] ? 2u : 0u), stream);
+            c.surface_map_replaced[0] = c.surface_map_replaced[1] = false; luts_generated_now = true;
+        }
         if (mode != ST_MODE_BVH_HEATMAP) {  // AtmospherePass::run (passes/atmosphere.rs:78-110)
             if (!atmosphere_initialized) {
                 L.launch_atmosphere_static(static_cast<float4*>(d_transmittance.ptr), static_cast<float4*>(d_scattering.ptr), stream);
@@ -1146,6 +1159,14 @@ struct Engine {
             a.variance_in_reproject = (variance_in_reproject && whole_graph && fuse && fuse_wavelet && denoise && needs_di && needs_gi && any_objects && c.tile_mask) ? 1u : 0u;
             // di_spatial's scratch records (di_diff_samples / curr_colors / stash as the reference binds them) are dead stores
             // when the fused launch is followed by resolving, denoise-reproject and the a-trous chain of the same frame
+            const bool even_tiles_x = (((a.width + 7u) / 8u) & 1u) == 0u;
+            a.lean = 0u;
+            if (lean_frame && arithmetic == ST_ARITH_FAST && whole_graph && fuse && denoise && any_objects && mode == ST_MODE_IMAGE) {
+                a.lean = kLeanPrim | kLeanSamples;
+                if (fuse_gi_reproj && tracing && even_tiles_x) a.lean |= kLeanGiRes2;
+            }
+            // frame composition rides in the last a-trous pass (k_denoise.hip k_denoise_wavelet_far<true>)
+            const bool compose_in_wavelet = fuse_compose && whole_graph && fuse && denoise && out != nullptr && mode <= ST_MODE_GI_SPECULAR;
             a.skip_dead_scratch = (skip_scratch_stores && whole_graph && fuse && fuse_spatial && ((((a.width + 7u) / 8u) & 1u) == 0u) && needs_di && denoise && any_objects) ? 1u : 0u;
 
             auto do_prim = [&] {
@@ -1253,8 +1274,16 @@ struct Engine {
                     run(KS_DENOISE_WAVELET_12, group, [&] { L.launch_denoise_wavelet_12(a, 1.0f, 2.0f, tmp_di, di[1], di[0], tmp_gi, gi[1], gi[0], cur); });
                     first = 2;
                 } else run(KS_DENOISE_VARIANCE, ST_PASS_DENOISE_VARIANCE, [&] { L.launch_denoise_variance(a, a.di_diff_stash, a.gi_diff_stash, cur); });
-                for (uint32_t nth = first; nth < 5; nth++)
+                for (uint32_t nth = first; nth < 5; nth++) {
+                    if (nth == 4u && compose_in_wavelet) {
+                        present_guard(c, out, cur);
+                        run(KS_DENOISE_WAVELET_COMPOSE, ((uint64_t)ST_PASS_DENOISE_WAVELET_0 << nth) | ST_PASS_COMPOSITION, [&] {
+                            L.launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], mode, out, c.out_format, a.lean == 0u, cur); });
+                        composed = true;
+                        continue;
+                    }
                     run(KS_DENOISE_WAVELET, (uint64_t)ST_PASS_DENOISE_WAVELET_0 << nth, [&] { L.launch_denoise_wavelet(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], cur); });
+                }
             };
             auto do_compose = [&] {
                 if (!out || composed) return;
@@ -1572,6 +1601,7 @@ int st_render_camera(StEngine* e, StHandle h, void* out, void* stream) {
     return E(e)->render(*it->second, out, static_cast<hipStream_t>(stream));
 }
 
+int st_debug_keep_all_planes(StEngine* e, int keep) { ST_REQUIRE(e, "null engine"); E(e)->lean_frame = keep == 0; return ST_OK; }
 int st_camera_present_copy(StEngine* e, StHandle h, const void* src_device, void* dst_host, size_t bytes, void* stream) {
     ST_REQUIRE(e && src_device && dst_host && bytes, "null argument");
     auto it = E(e)->cameras.find(h);
@@ -1634,7 +1664,8 @@ int st_camera_write_buffer(StEngine* e, StHandle h, int id, const void* data, si
     ST_HIP(hipDeviceSynchronize());
     { const int rc = materialize_gi_history(c); if (rc) return rc; }
     ST_HIP(hipMemcpy(c.plane[id], data, bytes, hipMemcpyHostToDevice));
-    c.internal_dirty = true;
+    if (id == ST_BUF_PRIM_SURFACE_MAP_A) c.surface_map_replaced[0] = true;
+    if (id == ST_BUF_PRIM_SURFACE_MAP_B) c.surface_map_replaced[1] = true;
     return ST_OK;
 }
 int st_debug_set_pass_mask(StEngine* e, uint64_t mask) {

@@ -19,7 +19,7 @@ enum KernelSlot {
     // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
     KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_12,
     KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL, KS_DI_SPATIAL_FUSED, KS_GI_SPATIAL_FUSED,
-    KS_GI_PREVIEW_BOTH, KS_GI_PREVIEW_BOTH_NO_REPROJECT, KS_GI_PREVIEW_LATE,
+    KS_GI_PREVIEW_BOTH, KS_GI_PREVIEW_BOTH_NO_REPROJECT, KS_GI_PREVIEW_LATE, KS_DENOISE_WAVELET_COMPOSE,
     KS_COUNT
 };
 struct KernelInfo { const char* name; float bytes_per_unit; bool half; };
@@ -45,6 +45,7 @@ inline const KernelInfo& kernel_info(int slot) {
         {"gi_preview x2+gi_resolving+denoise_reproject", 160.f + 160.f + 256.f + 112.f, false},
         {"gi_preview x2+gi_resolving", 160.f + 160.f + 256.f, false},
         {"gi_preview 2nd pass (pixels that resample)", 0.f, false},  // its bytes are credited to the launch above
+        {"denoise_wavelet+composition", 84.f + 112.f, false},
     };
     return k[slot];
 }

@@ -50,7 +50,8 @@ ST_D void denoise_reproject_pixel(const KArgs& a, U2 pos, float4 sample, const f
 
 // gi_resolving.rs:3-67 for one pixel. `res` is what out_reservoirs (gi_res[0]) holds for this pixel when the pass starts.
 // Returns the diffuse sample texel (for a fused reprojection stage).
-ST_D float4 gi_resolve_pixel(const KArgs& a, U2 pos, uint32_t idx, const Hit& hit, const GiReservoir& res, uint32_t source) {
+// `reprojects`: the caller runs the GI half of denoise-reproject on the returned texel (the lean frame then skips its store)
+ST_D float4 gi_resolve_pixel(const KArgs& a, U2 pos, uint32_t idx, const Hit& hit, const GiReservoir& res, uint32_t source, bool reprojects = false) {
     const uint32_t n = a.width * a.height;
     float confidence; V3 radiance;
     if (hit_some(hit)) { confidence = res.confidence; radiance = res.w * gi_cosine(res.s, hit) * res.s.radiance; }
@@ -58,7 +59,7 @@ ST_D float4 gi_resolve_pixel(const KArgs& a, U2 pos, uint32_t idx, const Hit& hi
     const float diff_brdf = fdivc(1.0f - hit.g.metallic, kPi);
     const V3 spec_brdf = gi_spec_brdf(res.s, hit);
     const float4 diff = f4(radiance * diff_brdf, confidence);
-    tex_write(a.gi_diff_samples, a, pos, diff);
+    if (!(reprojects && (a.lean & kLeanSamples))) tex_write(a.gi_diff_samples, a, pos, diff);
     tex_write(a.gi_spec_samples, a, pos, f4(radiance * spec_brdf, confidence));
     const float4* in = source == 0u ? a.gi_res[1] : a.gi_res[2];
     if (!a.gi_skip_history_copy) gi_write_own(a.gi_res[0], idx, gi_read_own(in, idx, true, true), true, true);  // the frame's source reservoir becomes next frame's history
@@ -144,6 +145,16 @@ ST_D float4 compose_pixel(const KArgs& a, U2 pos, uint32_t camera_mode, float4 d
         default: color = v3s(0.0f);
     }
     return f4(color, 1.0f);
+}
+
+// what the render target's format does to the composed colour (camera.rs:170-175 viewport.format; StOutputFormat)
+ST_D void store_output(void* out, uint32_t at, float4 c, uint32_t format) {
+    if (format == 0u) static_cast<float4*>(out)[at] = c;
+    else if (format == 1u) static_cast<uint2*>(out)[at] = make_uint2(f16_bits(c.x) | (f16_bits(c.y) << 16), f16_bits(c.z) | (f16_bits(c.w) << 16));
+    else {
+        const uint32_t r = srgb8_encode(c.x), g = srgb8_encode(c.y), b = srgb8_encode(c.z);
+        static_cast<uint32_t*>(out)[at] = format == 2u ? (r | (g << 8) | (b << 16) | 0xff000000u) : (b | (g << 8) | (r << 16) | 0xff000000u);
+    }
 }
 
 }  // namespace st

@@ -40,6 +40,12 @@ static_assert(sizeof(GpuLight) == 112, "Light is 112 B");
 struct HostTriangle { float4 d0, d1, d2, d3, d4, d5, d6, d7, d8; };
 static_assert(sizeof(HostTriangle) == 144, "Triangle is 144 B");
 
+// KArgs::lean bits
+constexpr uint32_t kLeanPrim = 1u;     // primary visibility + frame reprojection in one launch: the velocity map (consumed in registers) and the
+                                       // encoded surface map (every kernel reads its decoded twin, KArgs::sn) stay unwritten
+constexpr uint32_t kLeanSamples = 2u;  // di / gi diffuse sample planes: the fused denoise-reproject stages consume them in registers
+constexpr uint32_t kLeanGiRes2 = 4u;   // tracing frames: the reprojected GI reservoirs the fused temporal pass consumes in registers (on odd
+                                       // tracing frames the spatial pass rewrites the whole plane anyway)
 constexpr int kBvhStackSize = 24;  // strolle-gpu/src/lib.rs:76
 constexpr uint32_t kLightIdSky = 0xffffffffu;
 constexpr uint32_t kCounterLines = 256;  // ray/byte counters are spread over this many 64-B lines per kernel slot
@@ -64,6 +70,10 @@ struct KArgs {
     unsigned long long* gi_late_mask; uint32_t gi_preview_late;
     uint32_t skip_dead_scratch;  // the fused DI spatial launch keeps its pick / trace records in registers only: resolving, denoise-reproject and the a-trous chain rewrite the three scratch planes later in this frame
     uint32_t gi_skip_history_copy;  // gi_resolving leaves GI_RESERVOIRS_0 alone: the engine swaps plane pointers instead (st_engine.cpp gi_aliased)
+    // The lean frame (fast build, whole pass graph, Image{denoise}; st_engine.cpp `lean_frame`): stores that nothing reads —
+    // not a later pass of this frame, not the next frame — are not made. Bits: kLean*. st_debug_keep_all_planes(1) /
+    // ST_KEEP_ALL_PLANES=1 keeps every plane as the reference leaves it.
+    uint32_t lean;
     uint32_t count_bytes;  // st_profile_enable bit 1: kernels also sum the reference's used_memory over their rays
     uint32_t tri_slots;  // triangle records in tri_attr (upper bound of every triangle id in the BVH stream)
     float sun_altitude;

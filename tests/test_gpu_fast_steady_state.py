@@ -12,10 +12,14 @@ st_engine.cpp `whole_graph`). This module closes both holes at the benchmark's o
   tracing frame, validation frame) at 1920x1080: every launch of the fast build reads the oracle's state and is compared
   with the oracle's result, every plane, same per-lane tolerance.
 * test_fast_whole_frame_single_step — the oracle's complete state after frame F-1 is uploaded, the product renders frame
-  F UNMASKED (all whole-frame switches ON: exactly the launch structure bench.py times), and every plane that persists
-  beyond the frame plus the composed frame are compared with the oracle's state after frame F. One frame each of the three
-  schedules; Cornell 1080p (the headline), dungeon 1080p (config 3's scene in Image mode), dungeon 3840x2160 (config 5).
-  Errors accumulate over the ~15 launches of one frame but never from frame to frame (see the numbers below).
+  F UNMASKED (all whole-frame switches ON, the LEAN frame included: exactly the launch structure bench.py times), and every
+  plane the frame leaves behind plus the composed frame are compared with the oracle's state after frame F. One frame each
+  of the three schedules; Cornell 1080p (the headline), dungeon 1080p (config 3's scene in Image mode), dungeon 3840x2160
+  (config 5). Errors accumulate over the ~15 launches of one frame but never from frame to frame (see the numbers below).
+  The lean frame does not store the planes nothing reads again (include/strolle_hip.h st_debug_keep_all_planes: velocity,
+  the encoded surface map, both diffuse-sample planes, the reprojected GI reservoirs of tracing frames, the last a-trous
+  pass's colours — whose content reaches the composed frame, which IS compared); one more frame per run is rendered with
+  st_debug_keep_all_planes(1) and compared on every plane ("whole_keep").
 
 Both draw on one oracle run per (scene, size): frames alternate between the two kinds of check.
 
@@ -60,6 +64,15 @@ FRAME_MEAN_RTOL = 5e-4
 # planes a frame leaves behind for the next one or for the caller (everything else is scratch that later launches of
 # the same frame overwrite; the fused launches of the whole-frame graph never store some of it — DESIGN.md section 4)
 REF_PLANES = {Buffer.REF_HITS, Buffer.REF_RAYS, Buffer.REF_COLORS}
+def lean_planes(frame):
+    """planes the lean frame leaves unwritten on `frame` (st_types.h kLean*, st_engine.cpp `lean_frame`)"""
+    sm = Buffer.PRIM_SURFACE_MAP_B if frame % 2 else Buffer.PRIM_SURFACE_MAP_A
+    skip = {Buffer.VELOCITY_MAP, sm, Buffer.DI_DIFF_SAMPLES, Buffer.GI_DIFF_SAMPLES, Buffer.DI_DIFF_CURR_COLORS, Buffer.GI_DIFF_CURR_COLORS}
+    if frame % 6 < 4:
+        skip.add(Buffer.GI_RESERVOIRS_2)
+    return skip
+
+
 FILTERED = {Buffer.DI_DIFF_PREV_COLORS, Buffer.DI_DIFF_CURR_COLORS, Buffer.DI_DIFF_STASH,
             Buffer.GI_DIFF_PREV_COLORS, Buffer.GI_DIFF_CURR_COLORS, Buffer.GI_DIFF_STASH}
 
@@ -175,15 +188,18 @@ def _run(scene, size, plan):
             want = read_orac()
             upload(before)
             prod.set_pass_mask(full_mask)
+            prod.keep_all_planes(kind == "whole_keep")
             prod.render_camera(cp, out.data_ptr(), stream); torch.cuda.synchronize()
+            prod.keep_all_planes(False)
             assert prod.last_launches(), "no launches"
             got = read_prod()
-            for b, frac in _bad_fractions(got, want, [b for b in FLOAT_BUFFERS if b not in REF_PLANES]).items():
-                row = {"frame": frame, "plane": b.name, "bad_fraction": frac}
+            skip = REF_PLANES | (set() if kind == "whole_keep" else lean_planes(frame))
+            for b, frac in _bad_fractions(got, want, [b for b in FLOAT_BUFFERS if b not in skip]).items():
+                row = {"frame": frame, "kind": kind, "plane": b.name, "bad_fraction": frac}
                 if b in FILTERED:
                     row.update(_plane_stats(got[b], want[b]))
                 report["whole"].append(row)
-            row = {"frame": frame, "plane": "composed frame", "bad_fraction": _bad_fraction(out.cpu().numpy().reshape(-1), np.ascontiguousarray(ref_frame).reshape(-1))}
+            row = {"frame": frame, "kind": kind, "plane": "composed frame", "bad_fraction": _bad_fraction(out.cpu().numpy().reshape(-1), np.ascontiguousarray(ref_frame).reshape(-1))}
             row.update(_plane_stats(out.cpu().numpy(), ref_frame))
             report["whole"].append(row)
             # reservoir sample counts: the state must be the steady one the benchmark times
@@ -203,8 +219,8 @@ def _run(scene, size, plan):
 
 # frames 18 / 19 / 22: even tracing, odd tracing (spatial resampling), validation — launch by launch;
 # frames 20 / 21 / 23: the same three schedules as whole frames
-PLAN_1080P = {18: "launches", 19: "launches", 20: "whole", 21: "whole", 22: "launches", 23: "whole"}
-PLAN_DUNGEON_1080P = {12: "whole", 13: "whole", 16: "whole"}
+PLAN_1080P = {18: "launches", 19: "launches", 20: "whole", 21: "whole", 22: "launches", 23: "whole", 24: "whole_keep"}
+PLAN_DUNGEON_1080P = {12: "whole", 13: "whole", 14: "whole_keep", 16: "whole"}
 PLAN_DUNGEON_4K = {8: "whole", 9: "whole", 10: "whole"}   # frame 10 % 6 == 4: validation
 
 
@@ -235,7 +251,10 @@ def test_fast_launches_1080p_steady_state():
 
 def test_fast_whole_frame_single_step():
     rep = _run("cornell", (1920, 1080), PLAN_1080P)
-    assert {r["frame"] for r in rep["whole"]} == {20, 21, 23}
+    assert {(r["frame"], r["kind"]) for r in rep["whole"]} == {(20, "whole"), (21, "whole"), (23, "whole"), (24, "whole_keep")}
+    lean_frames = [r for r in rep["whole"] if r["kind"] == "whole"]
+    assert not [r for r in lean_frames if r["plane"] in ("VELOCITY_MAP", "DI_DIFF_SAMPLES", "GI_DIFF_CURR_COLORS")]   # not compared: not stored
+    assert [r for r in rep["whole"] if r["kind"] == "whole_keep" and r["plane"] == "GI_DIFF_CURR_COLORS"]               # the keep frame compares them
     _check_whole_rows(rep["whole"], "cornell 1080p")
 
 

@@ -222,6 +222,7 @@ def test_gi_history_pointer_swap_is_unobservable_through_the_buffers():
         finally:
             os.environ.pop("ST_NO_GI_ALIAS", None)
         scenes.build_cornell(e); e.set_seed(21)
+        e.keep_all_planes(True)   # GI_DIFF_SAMPLES is read back below: the lean frame would leave it unwritten
         desc = scenes.cornell_camera(size, CameraMode.IMAGE)
         engines.append((e, e.create_camera(desc), torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")))
     for frame in range(13):

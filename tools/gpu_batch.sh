@@ -23,6 +23,16 @@ for step in "$@"; do
     config5)
       timeout 600 python bench.py --scene dungeon --width 3840 --height 2160 --no-cpu-baseline --no-profile > gpurun_out/${TAG}_bench_config5_n1.json 2> gpurun_out/${TAG}_bench_config5_n1.err; head -c 400 gpurun_out/${TAG}_bench_config5_n1.json; echo
       timeout 600 python bench.py --mode reference --width 3840 --height 2160 --no-cpu-baseline --no-profile > gpurun_out/${TAG}_bench_config4_n1.json 2> gpurun_out/${TAG}_bench_config4_n1.err; head -c 400 gpurun_out/${TAG}_bench_config4_n1.json; echo ;;
+    env:*)   # env:<name>:<VAR=1,VAR2=1>[:bench args]  — the default bench command under environment switches
+      spec="${step#env:}"; name="${spec%%:*}"; rest="${spec#*:}"; vars="${rest%%:*}"; extra=""; [ "$rest" != "$vars" ] && extra="${rest#*:}"
+      env $(echo "$vars" | tr ',' ' ') timeout 600 python bench.py --no-cpu-baseline --no-extras $extra > gpurun_out/${TAG}_bench_${name}.json 2> gpurun_out/${TAG}_bench_${name}.err
+      python - <<PY
+import json
+d = json.loads(open("gpurun_out/${TAG}_bench_${name}.json").read().strip().splitlines()[-1])
+print("${name}: %.4f ms/frame, %.1f Mray/s, roofline frac %s" % (d["ms_per_step"], d["value"], d.get("roofline", {}).get("frac")))
+for k, v in d.get("kernels", {}).items(): print("   %-48s %7.1f us x%.2f" % (k, v["us_per_launch"], v["launches_per_frame"]))
+PY
+      ;;
     ab:*)
       bash tools/ab_bench.sh "${step#ab:}" --no-extras > gpurun_out/${TAG}_ab.log 2>&1; cat gpurun_out/${TAG}_ab.log ;;
     profile)

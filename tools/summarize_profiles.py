@@ -35,8 +35,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # bench.py profiler slot (st_kernels.h kernel_info) -> the kernel symbols it launches
 SLOT_SYMBOLS = {
-    "denoise_wavelet": ["denoise_wavelet_lds<1>", "denoise_wavelet_lds<2>", "denoise_wavelet_lds<4>", "denoise_wavelet<false>"],
-    "denoise_wavelet+composition": ["denoise_wavelet<true>"],
+    "denoise_wavelet": ["denoise_wavelet_lds<1>", "denoise_wavelet_lds<2>", "denoise_wavelet_lds<4>", "denoise_wavelet_far<false>"],
+    "denoise_wavelet+composition": ["denoise_wavelet_far<true>"],
     # tracing kernels: <LDS scene, [REPROJECT,] stack entry>; whichever instance the scene selected
     "prim_visibility+frame_reprojection": ["prim_visibility<true,true,u16>", "prim_visibility<false,true,u16>", "prim_visibility<false,true,u32>"],
     "di_sampling+di_temporal": ["di_sampling_temporal<true,u16>", "di_sampling_temporal<false,u16>", "di_sampling_temporal<false,u32>"],
