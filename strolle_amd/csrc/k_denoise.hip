@@ -405,12 +405,19 @@ ST_D void signal_tap(WaveletSignal& s, float4 t, float depth_weight, float norma
     if (w > 0.0f) { s.sw += w; s.sr += w * t.x; s.sg += w * t.y; s.sb += w * t.z; s.sv += (w * w) * t.w; }
 }
 ST_D float4 signal_end(const WaveletSignal& s) { return wavelet_resolve(s.sr, s.sg, s.sb, s.sv, s.sw, s.sw * s.sw); }
-// COMPOSE: frame_composition.rs runs for the same pixel at the end of the LAST pass (it reads this pixel's two denoised
-// colours — in registers here — plus planes no a-trous pass writes); `keep_colours` == 0 (the lean frame) leaves the pass's
-// own output planes unwritten: nothing but composition reads the last pass's result.
+// COMPOSE (fast build, CameraMode::Image): frame_composition.rs:18-82 runs for the same pixel at the end of the LAST pass — it
+// reads this pixel's two denoised colours, in registers here, plus planes no a-trous pass writes. What composition needs
+// from those planes is fetched with the centre texels, ahead of the three gather rounds, and reduced to six floats (the
+// G-buffer's base colour; emissive + both specular samples): fetched at the end instead, the dependent chain G-buffer ->
+// byte table -> store sat behind the last round with nothing left to overlap it (measured: 119 us against 48 + 51 us for
+// the two separate launches). The sum's association differs from compose_pixel's, hence fast build only.
+// `keep_colours` == 0 (the lean frame) leaves the pass's own output planes unwritten: nothing but composition reads them.
 struct ComposeArgs { void* out; uint32_t format, camera_mode, keep_colours; };
+#ifndef ST_FAR_COMPOSE_WAVES
+#define ST_FAR_COMPOSE_WAVES 5  // the six floats composition carries through the gather rounds do not fit the 80 registers of 6 waves per SIMD without spilling
+#endif
 template <bool COMPOSE>
-__global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out, const ComposeArgs co) {
+__global__ __launch_bounds__(kBlockThreads, COMPOSE ? ST_FAR_COMPOSE_WAVES : 6) void k_denoise_wavelet_far(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out, const ComposeArgs co) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const uint32_t center = pos.y * a.width + pos.x;
@@ -419,8 +426,16 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const 
     const bool store = !COMPOSE || co.keep_colours != 0u;
     if (csn.w == 0.0f) {  // sky
         if (store) di_out[center] = cdi;
-        if (COMPOSE) store_output(co.out, center, compose_pixel(a, pos, co.camera_mode, cdi, f4z()), co.format);  // the indirect colour is not read where depth == 0
+        if (COMPOSE) store_output(co.out, center, f4(xyz(cdi), 1.0f), co.format);  // frame_composition.rs: depth == 0 shows the direct colour
         return;
+    }
+    V3 c_base = v3s(0.0f), c_add = v3s(0.0f);
+    if (COMPOSE) {
+        const float4 g1 = a.g1[center], ds = a.di_spec_samples[center], gs = a.gi_spec_samples[center];
+        const uint32_t w1 = f2b(g1.w);
+        const float* lut = a.byte_luts;
+        c_base = v3(lut[kLutGamma8 + (w1 & 0xffu)], lut[kLutGamma8 + ((w1 >> 8) & 0xffu)], lut[kLutGamma8 + ((w1 >> 16) & 0xffu)]);  // gbuffer_unpack's base colour
+        c_add = xyz(g1) + xyz(ds) + xyz(gs);                                                                                      // emissive + specular samples
     }
     const float4 bn = blue_noise_read(a, pos);
     const I2 jitter = as_i2((v2(bn.z, bn.w) - 0.5f) * ((float)stride - 1.0f) * 0.5f);
@@ -464,10 +479,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_denoise_wavelet_far(const 
         for (int t = 0; t < 8; t++) if (dw[t] != 0.0f) signal_tap(sg, tap[t], dw[t], nw[t]);
         const float4 res_gi = signal_end(sg);
         if (store) gi_out[center] = res_gi;
-        if (COMPOSE) {
-            __builtin_amdgcn_sched_barrier(0);
-            store_output(co.out, center, compose_pixel(a, pos, co.camera_mode, res_di, res_gi), co.format);
-        }
+        if (COMPOSE) store_output(co.out, center, f4(c_add + (xyz(res_di) + xyz(res_gi)) * c_base, 1.0f), co.format);
     }
 }
 

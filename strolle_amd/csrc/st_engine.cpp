@@ -444,7 +444,7 @@ struct Engine {
     // pass's colours when composition rides in that launch. st_camera_read_buffer of those planes returns what an earlier
     // frame or launch left there; ST_KEEP_ALL_PLANES=1 / st_debug_keep_all_planes(e, 1) stores everything the reference does.
     bool lean_frame = true;
-    bool fuse_compose = true;  // ST_NO_FUSE_COMPOSE=1: frame composition as its own launch (both builds fuse it into the last a-trous pass by default)
+    bool fuse_compose = true;  // ST_NO_FUSE_COMPOSE=1: frame composition as its own launch (the fast build's Image frames run it inside the last a-trous pass)
     bool skip_scratch_stores = true;  // ST_KEEP_SCRATCH=1: the fused DI spatial launch stores its intermediate records as the three separate passes would
     bool di_head_on_main = true;  // ST_DI_HEAD_ON_MAIN=0: DI sampling + temporal on the side stream (behind primary visibility) instead of the caller's
     bool alias_gi_history = true;  // ST_NO_GI_ALIAS=1: gi_resolving always copies the source reservoirs into the history plane
@@ -1166,7 +1166,7 @@ struct Engine {
                 if (fuse_gi_reproj && tracing && even_tiles_x) a.lean |= kLeanGiRes2;
             }
             // frame composition rides in the last a-trous pass (k_denoise.hip k_denoise_wavelet_far<true>)
-            const bool compose_in_wavelet = fuse_compose && whole_graph && fuse && denoise && out != nullptr && mode <= ST_MODE_GI_SPECULAR;
+            const bool compose_in_wavelet = fuse_compose && arithmetic == ST_ARITH_FAST && whole_graph && fuse && denoise && out != nullptr && mode == ST_MODE_IMAGE && any_objects;
             a.skip_dead_scratch = (skip_scratch_stores && whole_graph && fuse && fuse_spatial && ((((a.width + 7u) / 8u) & 1u) == 0u) && needs_di && denoise && any_objects) ? 1u : 0u;
 
             auto do_prim = [&] {

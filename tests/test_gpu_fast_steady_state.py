@@ -99,6 +99,15 @@ def _bad_fraction(got, want, chunk=1 << 23):
     return bad / got.size
 
 
+def _diagnose(got, want, lanes_per_px, width):
+    """Where a plane's outliers sit: count per lane of the pixel's record, and a few examples (pixel, lane, got, want)."""
+    bad = lanes_outside_tolerance(got, want)
+    idx = np.flatnonzero(bad)
+    per_lane = np.bincount(idx % lanes_per_px, minlength=lanes_per_px).tolist()
+    ex = [{"px": [int((i // lanes_per_px) % width), int((i // lanes_per_px) // width)], "lane": int(i % lanes_per_px), "got": float(got[i]), "want": float(want[i])} for i in idx[:: max(1, len(idx) // 6)][:6]]
+    return {"outliers_per_record_lane": per_lane, "examples": ex}
+
+
 def _bad_fractions(got, want, planes):
     """{plane: bad fraction} with the planes compared on a thread pool (numpy releases the GIL in these loops)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -196,6 +205,8 @@ def _run(scene, size, plan):
             skip = REF_PLANES | (set() if kind == "whole_keep" else lean_planes(frame))
             for b, frac in _bad_fractions(got, want, [b for b in FLOAT_BUFFERS if b not in skip]).items():
                 row = {"frame": frame, "kind": kind, "plane": b.name, "bad_fraction": frac}
+                if frac > 1e-3 and b not in FILTERED:
+                    row.update(_diagnose(got[b], want[b], got[b].size // (size[0] * size[1]), size[0]))
                 if b in FILTERED:
                     row.update(_plane_stats(got[b], want[b]))
                 report["whole"].append(row)

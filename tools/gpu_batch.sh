@@ -12,6 +12,9 @@ for step in "$@"; do
       hipcc --offload-arch=gfx950 -O3 tools/tap_probe.hip -o /tmp/tap_probe && timeout 120 /tmp/tap_probe > gpurun_out/${TAG}_tap_probe.txt 2>&1; cat gpurun_out/${TAG}_tap_probe.txt ;;
     steady)
       ST_TOL_REPORT_ONLY=${REPORT_ONLY:-1} timeout 1500 python -m pytest tests/test_gpu_fast_steady_state.py -x -q --durations=8 > gpurun_out/${TAG}_steady.log 2>&1; tail -15 gpurun_out/${TAG}_steady.log ;;
+    pytest:*)   # pytest:<name>:<file or dir>:<-k expression>
+      spec="${step#pytest:}"; name="${spec%%:*}"; rest="${spec#*:}"; what="${rest%%:*}"; expr="${rest#*:}"
+      ST_TOL_REPORT_ONLY=${REPORT_ONLY:-0} timeout 1800 python -m pytest "$what" -m gpu -x -q -k "$expr" --durations=6 > gpurun_out/${TAG}_pytest_${name}.log 2>&1; tail -12 gpurun_out/${TAG}_pytest_${name}.log ;;
     newtests)
       timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "present_copy or bench_two_rank or bench_strong or c_example" --durations=8 > gpurun_out/${TAG}_newtests.log 2>&1; tail -8 gpurun_out/${TAG}_newtests.log ;;
     tests)
