@@ -224,12 +224,14 @@ ST_D WaveletOut wavelet_end(const WaveletCenter& c) {
 // one pixel of a zero-jitter pass whose window is in LDS: `lc` = the pixel's texel, taps at +-S texels / rows (pitch P).
 // Texels outside the viewport were staged with depth 0, which is skipped like an out-of-bounds or sky tap. Returns false
 // for a sky pixel (the reference copies the direct colour and leaves the indirect output alone).
-// `s_sl`: sqrt_luma2() of every staged texel with a surface (-DST_WAVELET_NO_SL: recomputed per tap as round 2 did, for A/B)
+// `s_sl`: sqrt_luma2() of every staged texel with a surface — only with -DST_WAVELET_SL. Measured (round 3, same-box A/B): evaluating
+// sqrt(luma) once per staged texel instead of once per tap (2 square roots + 6 FMAs fewer per tap, one 8-B LDS read more)
+// changes nothing: strides 1+2 69.6 vs 68.5 us, stride 4 39.7 vs 39.2 us. The default recomputes per tap (8 B of LDS per texel less).
 template <int S, int P>
 ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const float4* s_gi, const f2* s_sl, int lc, float strength) {
     const float4 csn = s_sn[lc], cdi = s_di[lc], cgi = s_gi[lc];
     if (csn.w == 0.0f) { WaveletOut o; o.di = cdi; o.gi = cgi; o.lit = false; return o; }
-#ifdef ST_WAVELET_NO_SL
+#ifndef ST_WAVELET_SL
     WaveletCenter c = wavelet_begin(csn, cdi, cgi, strength, sqrt_luma2(cdi, cgi));
 #else
     WaveletCenter c = wavelet_begin(csn, cdi, cgi, strength, s_sl[lc]);
@@ -241,7 +243,7 @@ ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const 
         float dw, nw;
         if (!wavelet_shared(c, s_sn[lt], &dw, &nw)) continue;
         const float4 tdi = s_di[lt], tgi = s_gi[lt];
-#ifdef ST_WAVELET_NO_SL
+#ifndef ST_WAVELET_SL
         wavelet_tap(c, tdi, tgi, sqrt_luma2(tdi, tgi), dw, nw);
 #else
         wavelet_tap(c, tdi, tgi, s_sl[lt], dw, nw);
@@ -291,7 +293,7 @@ ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* d
             const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
             const float4 tsn = a.sn[at], tdi = di_in[at], tgi = gi_in[at];
             s_sn[li] = tsn; s_di[li] = tdi; s_gi[li] = tgi;
-#ifndef ST_WAVELET_NO_SL
+#ifdef ST_WAVELET_SL
             if (tsn.w != 0.0f) s_sl[li] = sqrt_luma2(tdi, tgi);  // sky texels are never tapped and never a centre that filters
 #endif
         } else {
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
 #pragma unroll
     for (int it = 0; it < 2; it++) if (r_at[it] >= 0) {
         s_di[r_at[it]] = r_di[it]; s_gi[r_at[it]] = r_gi[it];
-#ifndef ST_WAVELET_NO_SL
+#ifdef ST_WAVELET_SL
         s_sl[r_at[it]] = sqrt_luma2(r_di[it], r_gi[it]);  // (a sky texel's entry is never read)
 #endif
     }

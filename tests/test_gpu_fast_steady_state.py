@@ -7,7 +7,7 @@ eight neighbours, the short-history variance path serves every pixel) and — be
 whole-frame switches off (gi_skip_history_copy, variance_in_reproject, skip_dead_scratch, gi_preview_both;
 st_engine.cpp `whole_graph`). This module closes both holes at the benchmark's own size:
 
-* test_fast_launches_1080p_steady_state — the oracle carries the history to frame >= 18, then the launch-by-launch loop of
+* test_fast_launches_1080p_steady_state — the oracle carries the history to frame >= 19, then the launch-by-launch loop of
   test_gpu_fast_tolerance.py runs on one frame of each of the three GI schedules (frame.rs:19-21: even tracing frame, odd
   tracing frame, validation frame) at 1920x1080: every launch of the fast build reads the oracle's state and is compared
   with the oracle's result, every plane, same per-lane tolerance.
@@ -129,8 +129,9 @@ _runs = {}
 
 
 def _run(scene, size, plan):
-    """One oracle run of max(plan)+1 frames; frame f is checked as plan[f] says ("launches" / "whole"); other frames only
-    advance the oracle. Returns {"launches": [...], "whole": [...]} of report rows; cached per (scene, size)."""
+    """One oracle run of max(plan) frames; frame f (the ENGINE's frame number, which starts at 1 and decides the GI schedule:
+    f % 6 < 4 tracing — even f samples, odd f resamples spatially —, else validation) is checked as plan[f] says ("launches" /
+    "whole" / "whole_keep"); other frames only advance the oracle. Returns {"launches": [...], "whole": [...]} of report rows; cached per (scene, size)."""
     key = (scene, size)
     if key in _runs:
         return _runs[key]
@@ -162,10 +163,11 @@ def _run(scene, size, plan):
     def read_orac():
         return {b: orac.read_buffer(co, b) for b in FLOAT_BUFFERS}
 
-    for frame in range(max(plan) + 1):
+    for frame in range(1, max(plan) + 1):   # the engine numbers frames from 1 (strolle/src/lib.rs:152)
         for e, c in ((prod, cp), (orac, co)):
             e.update_camera(c, desc)
         prod.tick(); orac.tick()
+        assert prod.world()[1] == frame + 1 and orac.world()[1] == frame + 1, "frame numbering"
         kind = plan.get(frame)
         if kind is None:
             orac.render_camera(co, compose=False)
@@ -228,11 +230,11 @@ def _run(scene, size, plan):
     return report
 
 
-# frames 18 / 19 / 22: even tracing, odd tracing (spatial resampling), validation — launch by launch;
-# frames 20 / 21 / 23: the same three schedules as whole frames
-PLAN_1080P = {18: "launches", 19: "launches", 20: "whole", 21: "whole", 22: "launches", 23: "whole", 24: "whole_keep"}
-PLAN_DUNGEON_1080P = {12: "whole", 13: "whole", 14: "whole_keep", 16: "whole"}
-PLAN_DUNGEON_4K = {8: "whole", 9: "whole", 10: "whole"}   # frame 10 % 6 == 4: validation
+# frames 19 / 20 / 23: odd tracing (spatial resampling), even tracing, validation — launch by launch;
+# frames 21 / 22 / 24: odd tracing, validation, even tracing as whole lean frames; 25 (odd tracing) with every plane kept
+PLAN_1080P = {19: "launches", 20: "launches", 21: "whole", 22: "whole", 23: "launches", 24: "whole", 25: "whole_keep"}
+PLAN_DUNGEON_1080P = {13: "whole", 14: "whole", 15: "whole_keep", 17: "whole"}   # odd tracing, even tracing, odd tracing, validation
+PLAN_DUNGEON_4K = {8: "whole", 9: "whole", 10: "whole"}                           # even tracing, odd tracing, validation
 
 
 def _check_launch_rows(rows, what):
@@ -254,7 +256,7 @@ def _check_whole_rows(rows, what):
 
 def test_fast_launches_1080p_steady_state():
     rep = _run("cornell", (1920, 1080), PLAN_1080P)
-    assert {r["frame"] for r in rep["launches"]} <= {18, 19, 22}
+    assert {r["frame"] for r in rep["launches"]} <= {19, 20, 23}
     _check_launch_rows(rep["launches"], "cornell 1080p")
     for s in rep["state"]:   # the state the benchmark times: sample counts at their cap, long denoiser history
         assert REPORT_ONLY or (s["gi_m_median"] is not None and s["gi_m_median"] >= 8.0 and s["history_median"] >= 4.0), s
@@ -262,7 +264,7 @@ def test_fast_launches_1080p_steady_state():
 
 def test_fast_whole_frame_single_step():
     rep = _run("cornell", (1920, 1080), PLAN_1080P)
-    assert {(r["frame"], r["kind"]) for r in rep["whole"]} == {(20, "whole"), (21, "whole"), (23, "whole"), (24, "whole_keep")}
+    assert {(r["frame"], r["kind"]) for r in rep["whole"]} == {(21, "whole"), (22, "whole"), (24, "whole"), (25, "whole_keep")}
     lean_frames = [r for r in rep["whole"] if r["kind"] == "whole"]
     assert not [r for r in lean_frames if r["plane"] in ("VELOCITY_MAP", "DI_DIFF_SAMPLES", "GI_DIFF_CURR_COLORS")]   # not compared: not stored
     assert [r for r in rep["whole"] if r["kind"] == "whole_keep" and r["plane"] == "GI_DIFF_CURR_COLORS"]               # the keep frame compares them
