@@ -3,6 +3,7 @@
 //! disk, so that the CPU oracle of the HIP port can be compared with the reference itself.
 //!
 //!   STROLLE_SEED=0 cargo run --release -p strolle --example dump_cornell -- scene.bin out_dir [width height]
+//! (the scene file is whatever export_scene.py wrote: the Cornell box or the dungeon of demo.rs, textures included)
 //!
 //! Runs (each on a fresh engine, so frame numbers start at 1 as in the port's tests):
 //!   heatmap    CameraMode::BvhHeatmap, 1 frame                      -> REF_COLORS
@@ -84,7 +85,14 @@ impl Reader<'_> {
     }
 }
 
+struct SceneImage {
+    width: u32,
+    height: u32,
+    rgba: Vec<u8>,
+}
+
 struct Scene {
+    images: Vec<SceneImage>,
     materials: Vec<st::Material<Handles>>,
     instances: Vec<(u32, Affine3A, Vec<st::MeshTriangle>)>,
     lights: Vec<st::Light>,
@@ -97,17 +105,28 @@ fn load_scene(path: &str) -> Scene {
     let bytes = fs::read(path).expect("scene file");
     let mut r = Reader { bytes: &bytes, at: 0 };
     assert_eq!(r.u32(), u32::from_le_bytes(*b"STSC"), "not a scene file");
-    assert_eq!(r.u32(), 1, "scene file version");
+    assert_eq!(r.u32(), 2, "scene file version");
+    let mut images = Vec::new();
+    for _ in 0..r.u32() {
+        let (width, height) = (r.u32(), r.u32());
+        let n = (width * height * 4) as usize;
+        images.push(SceneImage { width, height, rgba: r.bytes[r.at..r.at + n].to_vec() });
+        r.at += n;
+    }
     let mut materials = Vec::new();
     for _ in 0..r.u32() {
         let f: [f32; 12] = r.floats();
+        let texture = r.u32(); // 0 = none, else 1 + image index; image handles are 1000 + index as in strolle_amd/scenes.py
+        let alpha_mode = r.u32();
         materials.push(st::Material {
             base_color: vec4(f[0], f[1], f[2], f[3]),
+            base_color_texture: if texture == 0 { None } else { Some(1000 + texture - 1) },
             emissive: vec4(f[4], f[5], f[6], f[7]),
             perceptual_roughness: f[8],
             metallic: f[9],
             reflectance: f[10],
             ior: f[11],
+            alpha_mode: if alpha_mode == 1 { st::AlphaMode::Blend } else { st::AlphaMode::Opaque },
             ..Default::default()
         });
     }
@@ -140,7 +159,7 @@ fn load_scene(path: &str) -> Scene {
     let sun = st::Sun { azimuth: r.f32(), altitude: r.f32() };
     let transform = Mat4::from_cols_array(&r.floats::<16>());
     let projection = Mat4::from_cols_array(&r.floats::<16>());
-    Scene { materials, instances, lights, sun, transform, projection }
+    Scene { images, materials, instances, lights, sun, transform, projection }
 }
 
 fn main() {
@@ -186,6 +205,20 @@ fn main() {
     ];
     for (run, mode, frames, dump_at) in runs {
         let mut engine = st::Engine::<Handles>::new(&device);
+        for (i, img) in scene.images.iter().enumerate() {
+            // what bevy-strolle hands over for a glTF base-colour texture (bevy-strolle/src/stages/prepare.rs): raw RGBA8 sRGB texels
+            let descriptor = wgpu::TextureDescriptor {
+                label: None,
+                size: wgpu::Extent3d { width: img.width, height: img.height, depth_or_array_layers: 1 },
+                mip_level_count: 1,
+                sample_count: 1,
+                dimension: wgpu::TextureDimension::D2,
+                format: wgpu::TextureFormat::Rgba8UnormSrgb,
+                usage: wgpu::TextureUsages::TEXTURE_BINDING | wgpu::TextureUsages::COPY_DST,
+                view_formats: &[],
+            };
+            engine.insert_image(1000 + i as u32, st::Image::new(st::ImageData::Raw { data: img.rgba.clone() }, descriptor, wgpu::SamplerDescriptor::default()));
+        }
         for (i, m) in scene.materials.iter().enumerate() {
             engine.insert_material(1 + i as u32, m.clone());
         }
