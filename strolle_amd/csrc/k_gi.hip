@@ -239,31 +239,51 @@ ST_D GiSpatialRecords gi_spatial_pick_cell(const KArgs& a, uint32_t seed, U2 gid
     const float4* reservoirs = a.gi_res[1];
     const U2 buf_pos_a = u2(gid.x * 2u, gid.y), buf_pos_b = u2(gid.x * 2u + 1u, gid.y);
     const Hit lhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, lhs_pos);
-    const GiReservoir lhs = gi_read(reservoirs, lhs_idx, n);
-    if (!hit_some(lhs_hit) || lhs.m == 0.0f) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return out; }
+    // Reservoirs are fetched with the quad-cooperative gather (st_device.h gi_read_coop): a whole 64-B record per quad and
+    // instruction instead of four loads per lane that each touch 64 different segments. That wants the quad's four lanes at
+    // the fetch together, so the reference's `while rhs_nth < 8 { ... continue ... break }` (gi_spatial_resampling.rs:56-113)
+    // runs in lockstep: every lane goes round until no lane of the wave is searching any more; a lane outside the loop — done,
+    // or never in it because its pixel has no surface / no sample — idles along. Per lane the sequence of random numbers,
+    // tests and fetches is the reference's.
+    const GiReservoir lhs = gi_read_coop(reservoirs, lhs_idx, n, true);
+    const bool valid = hit_some(lhs_hit) && lhs.m != 0.0f;
     GiReservoir rhs = gi_empty();
     uint32_t rhs_nth = 0u, rhs_idx = 0u;
     Hit rhs_hit = hit_zero();
     float rhs_jacobian = 0.0f;
     float max_radius = 128.0f;
-    while (rhs_nth < 8u) {
-        rhs_nth += 1u;
-        const V2 disk = wn.sample_disk();
-        const U2 rhs_pos = camera_contain(a, as_i2(as_v2(lhs_pos) + disk * max_radius));
-        if (rhs_pos.x == lhs_pos.x && rhs_pos.y == lhs_pos.y) continue;
-        rhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, rhs_pos);
-        if (!hit_some(rhs_hit)) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
-        if (fabsf(rhs_hit.g.depth - lhs_hit.g.depth) > 0.33f * lhs_hit.g.depth) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
-        if (dot(rhs_hit.g.normal, lhs_hit.g.normal) < 0.33f) { max_radius = fmax_(max_radius * 0.5f, 5.0f); continue; }
-        rhs_idx = screen_to_idx(a, rhs_pos);
-        rhs = gi_read(reservoirs, rhs_idx, n);
-        if (rhs.m == 0.0f) continue;
-        rhs_jacobian = gi_jacobian(rhs.s, lhs_hit.point);
-        if (rhs_jacobian < 1.0f / 10.0f || rhs_jacobian > 10.0f) { rhs.m = 0.0f; continue; }
-        rhs_jacobian = clampf(rhs_jacobian, 1.0f / 3.0f, 3.0f);
-        break;
+    bool searching = valid;
+    for (;;) {
+        bool fetch = false;
+        uint32_t cand_idx = 0u;
+        if (searching) {
+            if (rhs_nth >= 8u) searching = false;
+            else {
+                rhs_nth += 1u;
+                const V2 disk = wn.sample_disk();
+                const U2 rhs_pos = camera_contain(a, as_i2(as_v2(lhs_pos) + disk * max_radius));
+                if (!(rhs_pos.x == lhs_pos.x && rhs_pos.y == lhs_pos.y)) {
+                    rhs_hit = pixel_hit(a, a.cam, a.g0, a.g1, rhs_pos);
+                    if (!hit_some(rhs_hit)) max_radius = fmax_(max_radius * 0.5f, 5.0f);
+                    else if (fabsf(rhs_hit.g.depth - lhs_hit.g.depth) > 0.33f * lhs_hit.g.depth) max_radius = fmax_(max_radius * 0.5f, 5.0f);
+                    else if (dot(rhs_hit.g.normal, lhs_hit.g.normal) < 0.33f) max_radius = fmax_(max_radius * 0.5f, 5.0f);
+                    else { cand_idx = screen_to_idx(a, rhs_pos); fetch = true; }
+                }
+            }
+        }
+        if (!__ballot(searching)) break;
+        const GiReservoir cand = gi_read_coop(reservoirs, cand_idx, n, fetch);
+        if (fetch) {
+            rhs_idx = cand_idx;
+            rhs = cand;
+            if (rhs.m != 0.0f) {
+                rhs_jacobian = gi_jacobian(rhs.s, lhs_hit.point);
+                if (rhs_jacobian < 1.0f / 10.0f || rhs_jacobian > 10.0f) rhs.m = 0.0f;
+                else { rhs_jacobian = clampf(rhs_jacobian, 1.0f / 3.0f, 3.0f); searching = false; }  // `break`
+            }
+        }
     }
-    if (rhs.m == 0.0f || !hit_some(rhs_hit)) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return out; }
+    if (!valid || rhs.m == 0.0f || !hit_some(rhs_hit)) { tex_write(buf_d1, a, buf_pos_a, f4z()); tex_write(buf_d1, a, buf_pos_b, f4z()); return out; }
     const float lhs_rhs_pdf = gi_pdf(lhs.s, rhs_hit);
     const float rhs_lhs_pdf = gi_pdf(rhs.s, lhs_hit);
     const Ray ray_a = lhs_rhs_pdf > 0.0f ? gi_sample_ray(lhs.s, rhs_hit.point) : zero_ray();
@@ -297,9 +317,12 @@ ST_D void gi_spatial_sample_cell(const KArgs& a, uint32_t seed, U2 gid, U2 pos, 
     const uint32_t rhs_idx = f2b(d0.y);
     const float rhs_jacobian = d0.z;
     const float rhs_lhs_vis = d1.x, lhs_rhs_pdf = d1.y, rhs_lhs_pdf = d1.z;
-    const GiReservoir lhs = gi_read(in_res, idx, n);
-    if (rhs_idx > 0u) {
-        const GiReservoir rhs = gi_read(in_res, rhs_idx - 1u, n);
+    // quad-cooperative record I/O (st_device.h): the cell's pixel, the picked neighbour, the other checkerboard pixel
+    const GiReservoir lhs = gi_read_coop(in_res, idx, n, true);
+    const bool merge = rhs_idx > 0u;
+    const GiReservoir rhs = gi_read_coop(in_res, rhs_idx - 1u, n, merge);
+    GiReservoir result = lhs;
+    if (merge) {
         Mis mis;
         mis.lhs_m = lhs.m; mis.rhs_m = rhs.m; mis.rhs_jacobian = rhs_jacobian; mis.lhs_lhs_pdf = lhs.s.pdf;
         mis.lhs_rhs_pdf = lhs_rhs_pdf * lhs_rhs_vis; mis.rhs_lhs_pdf = rhs_lhs_pdf * rhs_lhs_vis; mis.rhs_rhs_pdf = rhs.s.pdf;
@@ -314,10 +337,13 @@ ST_D void gi_spatial_sample_cell(const KArgs& a, uint32_t seed, U2 gid, U2 pos, 
         main_.s.v1_point = lhs.s.v1_point;
         res_norm(main_, main_pdf, 1.0f, 1.0f);
         main_.w = fmin_(main_.w, 5.0f);
-        gi_write(out_res, idx, main_);
-    } else gi_write(out_res, idx, lhs);
+        result = main_;
+    }
+    gi_write_coop(out_res, idx, result, true);
     const U2 other = resolve_checkerboard(gid, a.frame / 2u);
-    if (contains_u(a, other)) { const uint32_t oi = screen_to_idx(a, other); gi_write(out_res, oi, gi_read(in_res, oi, n)); }
+    const bool has_other = contains_u(a, other);
+    const uint32_t oi = has_other ? screen_to_idx(a, other) : 0u;
+    gi_write_coop(out_res, oi, gi_read_coop(in_res, oi, n, has_other), has_other);
 }
 __global__ ST_KERNEL_BOUNDS void k_gi_spatial_sample(const KArgs a, uint32_t seed) {
     U2 gid;
@@ -377,33 +403,53 @@ struct PreviewPass { GiReservoir r; bool keep_stored; uint32_t max_samples; };
 ST_D PreviewPass gi_preview_pass(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, U2 center_pos, bool center_some, const GiReservoir& center,
                                  Hit center_hit, bool hit_ready) {
     PreviewPass o; o.r = gi_empty(); o.keep_stored = false; o.max_samples = 0u;
-    if (!center_some) return o;
     const uint32_t n = a.width * a.height;
     WhiteNoise wn = white_noise(seed, center_pos);
     float main_pdf = 0.0f;
-    if (res_merge(o.r, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
-    const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, o.r.m * 0.125f));
-    o.max_samples = max_samples;
-    if (!hit_ready && max_samples > 0u) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
+    uint32_t max_samples = 0u;
+    if (center_some) {
+        if (res_merge(o.r, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
+        max_samples = f2u_sat(lerpf(8.0f, 0.0f, o.r.m * 0.125f));
+        o.max_samples = max_samples;
+        if (!hit_ready && max_samples > 0u) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
+    }
     const float max_radius = nth == 0u ? 128.0f : 64.0f;
     uint32_t sample_nth = 0u;
-    while (sample_nth < max_samples) {
-        sample_nth += 1u;
-        const V2 disk = wn.sample_disk();
-        const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
-        if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) { o.keep_stored = true; break; }  // sic: `return`, not `continue`
-        const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
-        if (ss.depth == 0.0f) continue;
-        if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
-        if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
-        const GiReservoir s = gi_read(in, screen_to_idx(a, sample_pos), n);
-        if (s.m == 0.0f) continue;
-        const float sample_pdf = gi_pdf(s.s, center_hit);
-        float sample_jacobian = gi_jacobian(s.s, center_hit.point);
-        if (sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f) continue;
-        sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
-        if (res_merge(o.r, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
+    // The reference's `while sample_nth < max_samples { ... continue ... }` (gi_preview_resampling.rs:76-128) in lockstep, so that
+    // neighbour reservoirs can be fetched with the quad-cooperative gather (st_device.h gi_read_coop; k_gi_spatial's pick loop
+    // says why): a lane outside the loop — done, a sky pixel, max_samples == 0 — idles along until no lane of the wave loops.
+    // In the steady state (every reservoir's m at its cap) no lane ever enters and the ballot ends it at once.
+    bool looping = center_some && max_samples > 0u;
+    for (;;) {
+        bool fetch = false;
+        uint32_t sample_idx = 0u;
+        if (looping) {
+            if (sample_nth >= max_samples) looping = false;
+            else {
+                sample_nth += 1u;
+                const V2 disk = wn.sample_disk();
+                const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
+                if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) { o.keep_stored = true; looping = false; }  // sic: `return`, not `continue`
+                else {
+                    const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
+                    if (ss.depth != 0.0f && !(fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) && !(dot(ss.normal, center_hit.g.normal) < 0.5f)) {
+                        sample_idx = screen_to_idx(a, sample_pos); fetch = true;
+                    }
+                }
+            }
+        }
+        if (!__ballot(looping)) break;
+        const GiReservoir s = gi_read_coop(in, sample_idx, n, fetch);
+        if (fetch && s.m != 0.0f) {
+            const float sample_pdf = gi_pdf(s.s, center_hit);
+            float sample_jacobian = gi_jacobian(s.s, center_hit.point);
+            if (!(sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f)) {
+                sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
+                if (res_merge(o.r, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
+            }
+        }
     }
+    if (!center_some) return o;
     if (!o.keep_stored) {
         o.r.confidence = center.confidence;
         o.r.s.pdf = main_pdf;

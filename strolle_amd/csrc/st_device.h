@@ -905,6 +905,49 @@ ST_D void gi_write_own(float4* buf, uint32_t id, const GiReservoir& r, bool vali
     if (!want) return;
     buf[4u * id] = v0; buf[4u * id + 1u] = v1; buf[4u * id + 2u] = v2; buf[4u * id + 3u] = v3;
 }
+// ---- quad-cooperative gathers: ANY record per lane (spatial-neighbour reservoirs)
+// A lane that fetches a neighbour's 64-B reservoir with gi_read issues four 16-B loads, and across the wave every one of them
+// lands on 64 different 64-B segments: the texture-address unit serialises them (tools/tap_probe.hip: 64-B records read per
+// lane 127-158 us, a whole record per quad and instruction 99 us; k_gi_spatial_fused shows the far a-trous kernel's
+// signature in the SQ counters — 42 % of its waves' life stalled at issue). Here the four lanes of a quad fetch ONE lane's
+// record per instruction — 64 contiguous bytes, one segment — for each lane of the quad that wants one (the record index is
+// broadcast with a DPP move; quads in which no lane wants that round skip it), and the 4x4 transpose of quad_transpose
+// hands every lane its own record. Pure data movement: same bytes, same values. The call must be made by all four lanes
+// of a quad together (`want` says who needs a record); where the quad is not whole — divergent callers, image edges —
+// the helper falls back to gi_read, so it is safe anywhere.
+template <int CTRL>
+ST_D uint32_t quad_dpp_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+#ifdef ST_NO_COOP_GATHER  // A/B (tools/ab_bench.sh): every gather takes the per-lane fallback
+ST_D bool quad_whole() { return false; }
+#else
+ST_D bool quad_whole() { const unsigned long long b = __ballot(true); return ((b >> (threadIdx.x & 60u)) & 0xFull) == 0xFull; }
+#endif
+ST_D GiReservoir gi_read_coop(const float4* buf, uint32_t id, uint32_t count, bool want) {
+    want = want && id < count;
+    if (!quad_whole()) return want ? gi_read(buf, id, count) : gi_empty();
+    const uint32_t j = threadIdx.x & 3u;
+    const uint32_t w = want ? 1u : 0u;
+    float4 v0 = f4z(), v1 = f4z(), v2 = f4z(), v3 = f4z();
+    if (quad_dpp_u<0x00>(w)) v0 = buf[4u * quad_dpp_u<0x00>(id) + j];   // lane 0's record: the quad's lanes take its four texels
+    if (quad_dpp_u<0x55>(w)) v1 = buf[4u * quad_dpp_u<0x55>(id) + j];
+    if (quad_dpp_u<0xAA>(w)) v2 = buf[4u * quad_dpp_u<0xAA>(id) + j];
+    if (quad_dpp_u<0xFF>(w)) v3 = buf[4u * quad_dpp_u<0xFF>(id) + j];
+    quad_transpose(v0, v1, v2, v3);
+    return want ? gi_from_texels(v0, v1, v2, v3) : gi_empty();
+}
+// the inverse: every lane with `want` stores its record at its own index, one whole record per quad and instruction
+ST_D void gi_write_coop(float4* buf, uint32_t id, const GiReservoir& r, bool want) {
+    if (!quad_whole()) { if (want) gi_write(buf, id, r); return; }
+    const V2 n = normal_encode(r.s.v2_normal);
+    float4 v0 = f4(r.s.radiance, r.m), v1 = f4(r.s.v1_point, r.w), v2 = f4(r.s.v2_point, r.s.pdf), v3 = make_float4(n.x, n.y, r.confidence, b2f(r.s.rng));
+    quad_transpose(v0, v1, v2, v3);   // lane j now holds texel j of lane k's record in v<k>
+    const uint32_t j = threadIdx.x & 3u;
+    const uint32_t w = want ? 1u : 0u;
+    if (quad_dpp_u<0x00>(w)) buf[4u * quad_dpp_u<0x00>(id) + j] = v0;
+    if (quad_dpp_u<0x55>(w)) buf[4u * quad_dpp_u<0x55>(id) + j] = v1;
+    if (quad_dpp_u<0xAA>(w)) buf[4u * quad_dpp_u<0xAA>(id) + j] = v2;
+    if (quad_dpp_u<0xFF>(w)) buf[4u * quad_dpp_u<0xFF>(id) + j] = v3;
+}
 // The same for 32-B records (two float4: a DI reservoir, a path tracer hit): the quad's four records are eight consecutive
 // texels; instruction k moves texels 4k..4k+3 (64 contiguous bytes per quad), and lane j wants texels 2j and 2j+1 = lanes
 // (2j mod 4), (2j+1 mod 4) of instruction j / 2 — two quad_perm moves per register and a select. `ok` is false (and the

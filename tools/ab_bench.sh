@@ -18,7 +18,7 @@ for round in 1 2; do for v in A B; do for scene in cornell dungeon; do
   python - <<PY
 import json
 d = json.loads(open("gpurun_out/ab_${v}_${scene}.json").read().strip().splitlines()[-1])
-print("$v $scene round $round: %.4f ms" % d["ms_per_step"])
+print("$v $scene round $round: %.4f ms" % d["ms_per_step"] + (" (moving %.4f)" % d["ms_per_step_moving"] if "ms_per_step_moving" in d else ""))
 PY
 done; done; done
 python - <<PY

@@ -37,7 +37,7 @@ for k, v in d.get("kernels", {}).items(): print("   %-48s %7.1f us x%.2f" % (k, 
 PY
       ;;
     ab:*)
-      bash tools/ab_bench.sh "${step#ab:}" --no-extras > gpurun_out/${TAG}_ab.log 2>&1; cat gpurun_out/${TAG}_ab.log ;;
+      bash tools/ab_bench.sh "${step#ab:}" ${AB_ARGS---no-extras} > gpurun_out/${TAG}_ab.log 2>&1; cat gpurun_out/${TAG}_ab.log ;;
     profile)
       bash tools/gpu_profile_quick.sh > gpurun_out/${TAG}_profile.log 2>&1; tail -5 gpurun_out/${TAG}_profile.log ;;
     *) echo "unknown step $step" ;;
