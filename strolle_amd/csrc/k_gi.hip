@@ -403,53 +403,36 @@ struct PreviewPass { GiReservoir r; bool keep_stored; uint32_t max_samples; };
 ST_D PreviewPass gi_preview_pass(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, U2 center_pos, bool center_some, const GiReservoir& center,
                                  Hit center_hit, bool hit_ready) {
     PreviewPass o; o.r = gi_empty(); o.keep_stored = false; o.max_samples = 0u;
+    if (!center_some) return o;
     const uint32_t n = a.width * a.height;
     WhiteNoise wn = white_noise(seed, center_pos);
     float main_pdf = 0.0f;
-    uint32_t max_samples = 0u;
-    if (center_some) {
-        if (res_merge(o.r, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
-        max_samples = f2u_sat(lerpf(8.0f, 0.0f, o.r.m * 0.125f));
-        o.max_samples = max_samples;
-        if (!hit_ready && max_samples > 0u) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
-    }
+    if (res_merge(o.r, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
+    const uint32_t max_samples = f2u_sat(lerpf(8.0f, 0.0f, o.r.m * 0.125f));
+    o.max_samples = max_samples;
+    if (!hit_ready && max_samples > 0u) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
     const float max_radius = nth == 0u ? 128.0f : 64.0f;
+    // (Measured and not kept, round 3: this loop in lockstep with quad-cooperative neighbour fetches, as k_gi_spatial's pick loop
+    // runs — bit-identical, static frame unchanged, but the moving-scene frame, where these loops actually run, 0.889 against
+    // 0.878 ms: the late launch's lanes are sparse, so most quads fall back to per-lane loads and still pay for the lockstep.)
     uint32_t sample_nth = 0u;
-    // The reference's `while sample_nth < max_samples { ... continue ... }` (gi_preview_resampling.rs:76-128) in lockstep, so that
-    // neighbour reservoirs can be fetched with the quad-cooperative gather (st_device.h gi_read_coop; k_gi_spatial's pick loop
-    // says why): a lane outside the loop — done, a sky pixel, max_samples == 0 — idles along until no lane of the wave loops.
-    // In the steady state (every reservoir's m at its cap) no lane ever enters and the ballot ends it at once.
-    bool looping = center_some && max_samples > 0u;
-    for (;;) {
-        bool fetch = false;
-        uint32_t sample_idx = 0u;
-        if (looping) {
-            if (sample_nth >= max_samples) looping = false;
-            else {
-                sample_nth += 1u;
-                const V2 disk = wn.sample_disk();
-                const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
-                if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) { o.keep_stored = true; looping = false; }  // sic: `return`, not `continue`
-                else {
-                    const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
-                    if (ss.depth != 0.0f && !(fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) && !(dot(ss.normal, center_hit.g.normal) < 0.5f)) {
-                        sample_idx = screen_to_idx(a, sample_pos); fetch = true;
-                    }
-                }
-            }
-        }
-        if (!__ballot(looping)) break;
-        const GiReservoir s = gi_read_coop(in, sample_idx, n, fetch);
-        if (fetch && s.m != 0.0f) {
-            const float sample_pdf = gi_pdf(s.s, center_hit);
-            float sample_jacobian = gi_jacobian(s.s, center_hit.point);
-            if (!(sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f)) {
-                sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
-                if (res_merge(o.r, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
-            }
-        }
+    while (sample_nth < max_samples) {
+        sample_nth += 1u;
+        const V2 disk = wn.sample_disk();
+        const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
+        if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) { o.keep_stored = true; break; }  // sic: `return`, not `continue`
+        const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
+        if (ss.depth == 0.0f) continue;
+        if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
+        if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
+        const GiReservoir s = gi_read(in, screen_to_idx(a, sample_pos), n);
+        if (s.m == 0.0f) continue;
+        const float sample_pdf = gi_pdf(s.s, center_hit);
+        float sample_jacobian = gi_jacobian(s.s, center_hit.point);
+        if (sample_jacobian < 1.0f / 10.0f || sample_jacobian > 10.0f) continue;
+        sample_jacobian = clampf(sample_jacobian, 1.0f / 3.0f, 3.0f);
+        if (res_merge(o.r, wn, s, sample_pdf * sample_jacobian)) main_pdf = sample_pdf;
     }
-    if (!center_some) return o;
     if (!o.keep_stored) {
         o.r.confidence = center.confidence;
         o.r.s.pdf = main_pdf;
