@@ -400,6 +400,29 @@ void launch_gi_spatial_fused(const KArgs& a, uint32_t seed_pick, uint32_t seed_s
 // `center_hit`: the pixel's Hit if `hit_ready`, otherwise it is rebuilt here, and only when a neighbour is actually drawn.
 // keep_stored: the reference's early `return` (:84-86) — the output slot keeps its previous contents.
 struct PreviewPass { GiReservoir r; bool keep_stored; uint32_t max_samples; };
+// the same for a pixel that turns out to draw no neighbour (max_samples == 0); otherwise only max_samples is meaningful
+ST_D PreviewPass gi_preview_pass_if_alone(uint32_t seed, U2 center_pos, const GiReservoir& center) {
+    PreviewPass o; o.r = gi_empty(); o.keep_stored = false;
+    WhiteNoise wn = white_noise(seed, center_pos);
+    float main_pdf = 0.0f;
+    if (res_merge(o.r, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
+    o.max_samples = f2u_sat(lerpf(8.0f, 0.0f, o.r.m * 0.125f));
+    if (o.max_samples > 0u) return o;
+    o.r.confidence = center.confidence;
+    o.r.s.pdf = main_pdf;
+    o.r.s.v1_point = center.s.v1_point;
+    res_norm(o.r, main_pdf, 1.0f, o.r.m);
+    o.r.w = fmin_(o.r.w, 5.0f);
+    return o;
+}
+// What GI_RESERVOIRS_3 holds for pixel `pos` (index `idx`) after the first preview pass, in the lean frame (kLeanGiMid): a pixel
+// whose first pass drew no neighbour was not stored — its record is that pass's normalisation of the input plane's record,
+// rebuilt here (through the store / load codec, as a reader of the plane would see it); a pixel that did resample (or hit the
+// reference's early `return`) has its slot as always.
+ST_D GiReservoir gi_mid_value(const KArgs& a, uint32_t seed, const float4* mid, U2 pos, uint32_t idx, uint32_t n) {
+    const PreviewPass p = gi_preview_pass_if_alone(seed, pos, gi_read(a.gi_mid_src, idx, n));
+    return p.max_samples == 0u ? gi_after_store(p.r) : gi_read(mid, idx, n);
+}
 ST_D PreviewPass gi_preview_pass(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, U2 center_pos, bool center_some, const GiReservoir& center,
                                  Hit center_hit, bool hit_ready) {
     PreviewPass o; o.r = gi_empty(); o.keep_stored = false; o.max_samples = 0u;
@@ -425,7 +448,8 @@ ST_D PreviewPass gi_preview_pass(const KArgs& a, uint32_t seed, uint32_t nth, co
         if (ss.depth == 0.0f) continue;
         if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
         if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
-        const GiReservoir s = gi_read(in, screen_to_idx(a, sample_pos), n);
+        const uint32_t sample_idx = screen_to_idx(a, sample_pos);
+        const GiReservoir s = (nth != 0u && a.gi_mid_src) ? gi_mid_value(a, seed, in, sample_pos, sample_idx, n) : gi_read(in, sample_idx, n);
         if (s.m == 0.0f) continue;
         const float sample_pdf = gi_pdf(s.s, center_hit);
         float sample_jacobian = gi_jacobian(s.s, center_hit.point);
@@ -440,21 +464,6 @@ ST_D PreviewPass gi_preview_pass(const KArgs& a, uint32_t seed, uint32_t nth, co
         res_norm(o.r, main_pdf, 1.0f, o.r.m);
         o.r.w = fmin_(o.r.w, 5.0f);
     }
-    return o;
-}
-// the same for a pixel that turns out to draw no neighbour (max_samples == 0); otherwise only max_samples is meaningful
-ST_D PreviewPass gi_preview_pass_if_alone(uint32_t seed, U2 center_pos, const GiReservoir& center) {
-    PreviewPass o; o.r = gi_empty(); o.keep_stored = false;
-    WhiteNoise wn = white_noise(seed, center_pos);
-    float main_pdf = 0.0f;
-    if (res_merge(o.r, wn, center, center.s.pdf)) main_pdf = center.s.pdf;
-    o.max_samples = f2u_sat(lerpf(8.0f, 0.0f, o.r.m * 0.125f));
-    if (o.max_samples > 0u) return o;
-    o.r.confidence = center.confidence;
-    o.r.s.pdf = main_pdf;
-    o.r.s.v1_point = center.s.v1_point;
-    res_norm(o.r, main_pdf, 1.0f, o.r.m);
-    o.r.w = fmin_(o.r.w, 5.0f);
     return o;
 }
 // one bit per pixel of an 8x8 tile (bit = lane = pixel_in_tile's numbering), one word per tile (KArgs::gi_late_mask)
@@ -483,7 +492,9 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
     if (RESOLVE) center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
     ReprojectHistory history;  // fetched ahead of the resampling loop (st_passes.h)
     if (RESOLVE && reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
-    const GiReservoir center = gi_read_own(in, center_idx, true, center_some);  // quad-transposed (st_device.h): before the branch
+    GiReservoir center;
+    if (RESOLVE && a.gi_mid_src) center = center_some ? gi_mid_value(a, seed, in, center_pos, center_idx, n) : gi_empty();  // lean frame: see gi_mid_value
+    else center = gi_read_own(in, center_idx, true, center_some);  // quad-transposed (st_device.h): before the branch
     const PreviewPass pass = gi_preview_pass(a, seed, nth, in, center_pos, center_some, center, center_hit, RESOLVE);
     GiReservoir main_ = pass.r;
     if (!RESOLVE) {
@@ -511,7 +522,8 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview_both(const KArgs a, uint32_t seed,
     if (reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
     const GiReservoir center0 = gi_read_own(in, center_idx, true, center_some);
     const PreviewPass first = gi_preview_pass(a, seed, 0u, in, center_pos, center_some, center0, center_hit, true);
-    gi_write_own(mid, center_idx, first.r, true, !first.keep_stored);
+    // lean frame: a result that is the plain normalisation of the input needs no slot (gi_mid_value rebuilds it where it is read)
+    gi_write_own(mid, center_idx, first.r, true, !first.keep_stored && !((a.lean & kLeanGiMid) && (!center_some || first.max_samples == 0u)));
     // second pass, if it is the neighbour-free kind: its `center` is what gi_read would return for the record just stored
     bool late = first.keep_stored;
     PreviewPass second; second.r = gi_empty(); second.keep_stored = false; second.max_samples = 0u;

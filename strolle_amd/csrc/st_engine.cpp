@@ -440,7 +440,8 @@ struct Engine {
     bool preview_both = true;  // ST_NO_PREVIEW_BOTH=1: the two GI preview passes as two full-screen launches
     // The lean frame (KArgs::lean, st_types.h kLean*; fast build + whole pass graph + Image-family mode with the denoiser):
     // planes nothing reads again are not stored — velocity and the encoded surface map (primary visibility), both diffuse
-    // sample planes (resolving + reproject stages), the reprojected GI reservoirs of tracing frames, and the last a-trous
+    // sample planes (resolving + reproject stages), the reprojected GI reservoirs of tracing frames, first-preview-pass results
+    // that merely normalise their input, and the last a-trous
     // pass's colours when composition rides in that launch. st_camera_read_buffer of those planes returns what an earlier
     // frame or launch left there; ST_KEEP_ALL_PLANES=1 / st_debug_keep_all_planes(e, 1) stores everything the reference does.
     bool lean_frame = true;
@@ -1164,6 +1165,7 @@ struct Engine {
             if (lean_frame && arithmetic == ST_ARITH_FAST && whole_graph && fuse && denoise && any_objects && mode == ST_MODE_IMAGE) {
                 a.lean = kLeanPrim | kLeanSamples;
                 if (fuse_gi_reproj && tracing && even_tiles_x) a.lean |= kLeanGiRes2;
+                if (gi_preview_both) a.lean |= kLeanGiMid;
             }
             // frame composition rides in the last a-trous pass (k_denoise.hip k_denoise_wavelet_far<true>)
             const bool compose_in_wavelet = fuse_compose && arithmetic == ST_ARITH_FAST && whole_graph && fuse && denoise && out != nullptr && mode == ST_MODE_IMAGE && any_objects;
@@ -1236,8 +1238,9 @@ struct Engine {
                     const uint64_t group = ST_PASS_GI_PREVIEW_0 | ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING | (denoise ? (uint64_t)ST_PASS_DENOISE_REPROJECT_GI : 0ull);
                     run(denoise ? KS_GI_PREVIEW_BOTH : KS_GI_PREVIEW_BOTH_NO_REPROJECT, group, [&] { L.launch_gi_preview_both(a, pseed, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], gi_source, denoise, cur); });
                     a.gi_preview_late = 1u;
+                    a.gi_mid_src = (a.lean & kLeanGiMid) ? (gi_source == 0 ? a.gi_res[1] : a.gi_res[2]) : nullptr;
                     run(KS_GI_PREVIEW_LATE, group, [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, denoise, cur); });
-                    a.gi_preview_late = 0u;
+                    a.gi_preview_late = 0u; a.gi_mid_src = nullptr;
                     if (denoise) gi_reprojected = true;
                 } else if (fuse) {
                     if (denoise) { run(KS_GI_PREVIEW_RESOLVE_REPROJECT, ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING | ST_PASS_DENOISE_REPROJECT_GI, [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, true, cur); }); gi_reprojected = true; }

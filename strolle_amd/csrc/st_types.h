@@ -46,6 +46,9 @@ constexpr uint32_t kLeanPrim = 1u;     // primary visibility + frame reprojectio
 constexpr uint32_t kLeanSamples = 2u;  // di / gi diffuse sample planes: the fused denoise-reproject stages consume them in registers
 constexpr uint32_t kLeanGiRes2 = 4u;   // tracing frames: the reprojected GI reservoirs the fused temporal pass consumes in registers (on odd
                                        // tracing frames the spatial pass rewrites the whole plane anyway)
+constexpr uint32_t kLeanGiMid = 8u;    // both GI preview passes in one launch: a first-pass result that is a plain normalisation of its input (the pixel drew
+                                       // no neighbour: every pixel once the reservoirs have history) is not stored to GI_RESERVOIRS_3; the few pixels
+                                       // whose second pass does resample rebuild such a neighbour's record from the pass's input (KArgs::gi_mid_src)
 constexpr int kBvhStackSize = 24;  // strolle-gpu/src/lib.rs:76
 constexpr uint32_t kLightIdSky = 0xffffffffu;
 constexpr uint32_t kCounterLines = 256;  // ray/byte counters are spread over this many 64-B lines per kernel slot
@@ -74,6 +77,7 @@ struct KArgs {
     // not a later pass of this frame, not the next frame — are not made. Bits: kLean*. st_debug_keep_all_planes(1) /
     // ST_KEEP_ALL_PLANES=1 keeps every plane as the reference leaves it.
     uint32_t lean;
+    const float4* gi_mid_src;  // kLeanGiMid, second-pass launch only: the first preview pass's input plane (nullptr: GI_RESERVOIRS_3 holds every first-pass result)
     uint32_t count_bytes;  // st_profile_enable bit 1: kernels also sum the reference's used_memory over their rays
     uint32_t tri_slots;  // triangle records in tri_attr (upper bound of every triangle id in the BVH stream)
     float sun_altitude;

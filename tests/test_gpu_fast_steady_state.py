@@ -17,8 +17,9 @@ st_engine.cpp `whole_graph`). This module closes both holes at the benchmark's o
   of the three schedules; Cornell 1080p (the headline), dungeon 1080p (config 3's scene in Image mode), dungeon 3840x2160
   (config 5). Errors accumulate over the ~15 launches of one frame but never from frame to frame (see the numbers below).
   The lean frame does not store the planes nothing reads again (include/strolle_hip.h st_debug_keep_all_planes: velocity,
-  the encoded surface map, both diffuse-sample planes, the reprojected GI reservoirs of tracing frames, the last a-trous
-  pass's colours — whose content reaches the composed frame, which IS compared); one more frame per run is rendered with
+  the encoded surface map, both diffuse-sample planes, the reprojected GI reservoirs of tracing frames, first-preview-pass
+  results that are a plain normalisation of their input, the last a-trous pass's colours — whose content reaches the
+  composed frame, which IS compared); one more frame per run is rendered with
   st_debug_keep_all_planes(1) and compared on every plane ("whole_keep").
 
 Both draw on one oracle run per (scene, size): frames alternate between the two kinds of check.
@@ -67,7 +68,8 @@ REF_PLANES = {Buffer.REF_HITS, Buffer.REF_RAYS, Buffer.REF_COLORS}
 def lean_planes(frame):
     """planes the lean frame leaves unwritten on `frame` (st_types.h kLean*, st_engine.cpp `lean_frame`)"""
     sm = Buffer.PRIM_SURFACE_MAP_B if frame % 2 else Buffer.PRIM_SURFACE_MAP_A
-    skip = {Buffer.VELOCITY_MAP, sm, Buffer.DI_DIFF_SAMPLES, Buffer.GI_DIFF_SAMPLES, Buffer.DI_DIFF_CURR_COLORS, Buffer.GI_DIFF_CURR_COLORS}
+    skip = {Buffer.VELOCITY_MAP, sm, Buffer.DI_DIFF_SAMPLES, Buffer.GI_DIFF_SAMPLES, Buffer.DI_DIFF_CURR_COLORS, Buffer.GI_DIFF_CURR_COLORS,
+            Buffer.GI_RESERVOIRS_3}   # the first preview pass's results: stored only where that pass resampled
     if frame % 6 < 4:
         skip.add(Buffer.GI_RESERVOIRS_2)
     return skip
