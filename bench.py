@@ -358,13 +358,19 @@ def main():
     gather_ms = job.gather_ms()
     # region 2: the same K steps again with HIP events around every run of same-slot launches (on the launch stream, pass
     # graph serial) -> per-kernel average durations for the roofline object. Kept out of region 1: it costs ~10 %.
-    prof, profiled_ms = [], None
+    prof, profiled_ms, grouped = [], None, []
     if not args.no_profile:
         engine.profile_enable(1)   # ST_PROFILE_TIMING
         engine.profile_read(reset=True)
         elapsed_p, _ = timed_region()
         prof = engine.profile_read(reset=True)
         profiled_ms = elapsed_p / args.steps * 1e3
+        # region 2b: the same once more with the a-trous chain's four back-to-back launches under ONE event pair
+        # (ST_PROFILE_GROUP_ATROUS): an event between two kernels makes the second wait for a barrier packet, 3-15 us each
+        engine.profile_enable(1 | 4)
+        engine.profile_read(reset=True)
+        timed_region()
+        grouped = [q for q in engine.profile_read(reset=True) if q["name"].startswith("a-trous chain")]
         # region 3, untimed: a few more frames with the traversal-byte counters on (ST_PROFILE_TRAVERSAL_BYTES; the kernels
         # sum the reference's `used_memory` over their rays, which costs ~10 us per tracing launch and is therefore off in
         # regions 1 and 2) -> the LDS / L2-served A part of the algorithmic bytes, scaled to K steps
@@ -489,6 +495,11 @@ def main():
                 tot_ms, symbols = fam_ms, WAVELET_SYMBOLS
             else:
                 launches, alg, trav, tot_ms, name, symbols = top["launches"], top["algorithmic_bytes"], top["traversal_bytes"], top["total_ms"], top["name"], [top["name"]]
+            per_slot = {"avg_launch_ms": round(tot_ms / launches, 5), "achieved": round((alg - trav) / (tot_ms * 1e-3) / 1e9, 2), "frac": round((alg - trav) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            timing = "one HIP-event pair per profiler slot (three pairs over the chain's four launches)"
+            if grouped and grouped[0]["launches"] == launches and fam and fam_ms >= max(p["total_ms"] for p in prof if p["name"] not in WAVELET_SLOTS):
+                tot_ms = grouped[0]["total_ms"]   # same launches, same bytes; one interval around the four launches of a frame
+                timing = "ONE HIP-event pair around the chain's four back-to-back launches of a frame (ST_PROFILE_GROUP_ATROUS)"
             avg_ms = tot_ms / launches
             b_bytes = (alg - trav) / launches
             achieved = b_bytes / (avg_ms * 1e-3) / 1e9   # screen-space (HBM) bytes only: traversal bytes are cache- / LDS-served
@@ -500,7 +511,7 @@ def main():
                 if r_ms > 0:
                     wavelet_only = {"passes_per_frame": sum(p["launches"] * WAVELET_SLOTS[p["name"]] for p in rest) // args.steps, "launches_per_frame": sum(p["launches"] for p in rest) // args.steps,
                                     "achieved": round(r_alg / (r_ms * 1e-3) / 1e9, 2), "frac": round(r_alg / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "ms_per_frame": round(r_ms / args.steps, 5)}
-            result["roofline"] = {"bound": "hbm", "kernel": name, "wavelet_only": wavelet_only, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            result["roofline"] = {"bound": "hbm", "kernel": name, "timing": timing, "with_one_event_pair_per_slot": per_slot, "wavelet_only": wavelet_only, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
                                   "frac_of_measured_copy_ceiling": None if not copy_ceiling else round(achieved / copy_ceiling, 5),
                                   "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": round(b_bytes),

@@ -319,7 +319,9 @@ int st_decode_image(const void* bytes, size_t size, uint8_t* out_rgba, size_t ca
  * is not always on; rays themselves are always counted, st_camera_ray_count). The rendered bits are the same in every
  * mode. st_profile_read returns, per kernel slot i < *count: name, launches, total milliseconds (0 without bit 0),
  * algorithmic bytes (DESIGN.md "bytes per unit" x units launched; the traversal part is 0 without bit 1). */
-enum { ST_PROFILE_TIMING = 1, ST_PROFILE_TRAVERSAL_BYTES = 2 };
+enum { ST_PROFILE_TIMING = 1, ST_PROFILE_TRAVERSAL_BYTES = 2,
+       ST_PROFILE_GROUP_ATROUS = 4 /* with TIMING: the a-trous chain's launches (4 per frame, back to back on one stream) are timed as ONE
+                                      interval under the slot "a-trous chain (one timed interval)" instead of one event pair per slot */ };
 enum { ST_PROFILE_MAX_KERNELS = 48 };  /* >= the number of kernel slots (st_kernels.h) */
 typedef struct StKernelProfile {
     char name[48];

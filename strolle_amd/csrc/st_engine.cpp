@@ -460,6 +460,7 @@ struct Engine {
     uint32_t tile_map = 1;  // blockIdx -> tile mapping (st_device.h); 1 measured best on MI355X with the current kernels (2 was, before the LDS-staged denoiser); ST_TILE_MAP overrides
     bool profiling = false;       // st_profile_enable bit 0: per-kernel event timing (serial execution)
     bool count_bytes = false;     // st_profile_enable bit 1: traversal-byte counters
+    bool profile_group_atrous = false;  // st_profile_enable bit 2: the a-trous chain's back-to-back launches share ONE event pair (an event between two kernels costs the second one 3-15 us)
     bool tick_timing = false;  // ST_TICK_TIMING=1: print the host-side cost of a scene refresh to stderr
     std::vector<ProfileRecord> profile_records; std::vector<hipEvent_t> event_pool;
     StKernelProfile profile_totals[KS_COUNT];
@@ -1102,7 +1103,8 @@ struct Engine {
             if ((bits & pass_mask) != bits) { mask_split |= (bits & pass_mask) != 0; return; }
             const double bytes = slot_bytes(slot);
             a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
-            profile_begin(slot, cur, bytes);
+            const bool atrous = slot == KS_DENOISE_WAVELET || slot == KS_DENOISE_WAVELET_12 || slot == KS_DENOISE_WAVELET_COMPOSE;
+            profile_begin(profile_group_atrous && atrous ? (int)KS_DENOISE_WAVELET_FAMILY : slot, cur, bytes);
             launch();
         };
         auto seed = [&](uint32_t pass) { return pass_seed(base_seed, c.frame, pass); };
@@ -1766,7 +1768,7 @@ int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused) {
     return ST_OK;
 }
 
-int st_profile_enable(StEngine* e, int enabled) { ST_REQUIRE(e, "null engine"); E(e)->profiling = (enabled & 1) != 0; E(e)->count_bytes = (enabled & 2) != 0; return ST_OK; }
+int st_profile_enable(StEngine* e, int enabled) { ST_REQUIRE(e, "null engine"); E(e)->profiling = (enabled & 1) != 0; E(e)->count_bytes = (enabled & 2) != 0; E(e)->profile_group_atrous = (enabled & 4) != 0; return ST_OK; }
 int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* count, int reset) {
     ST_REQUIRE(e && out && count, "null argument");
     Engine* en = E(e);
