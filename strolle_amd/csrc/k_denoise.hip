@@ -258,8 +258,9 @@ ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const 
 // two block rows (32 pixel rows) per XCD chunk so the halo rows a block shares with its vertical neighbour stay in one L2.
 constexpr int kWvW = 32, kWvH = 16, kWvThreads = kWvW * kWvH;
 struct WaveletBlock { int32_t x0, y0; bool valid; };
+template <int BW = kWvW>
 ST_D WaveletBlock wavelet_block(const KArgs& a) {
-    const uint32_t groups_x = (a.width + kWvW - 1u) / kWvW;
+    const uint32_t groups_x = (a.width + BW - 1u) / BW;
     const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
     const uint32_t rows = ((ty1 - ty0) * 8u + kWvH - 1u) / kWvH;
     const uint32_t n_blocks = groups_x * rows, b = blockIdx.x;
@@ -273,18 +274,18 @@ ST_D WaveletBlock wavelet_block(const KArgs& a) {
     }
     WaveletBlock w;
     const uint32_t gy = lin / groups_x, gx = lin - gy * groups_x;
-    w.x0 = (int32_t)(gx * kWvW); w.y0 = (int32_t)(ty0 * 8u + gy * kWvH);
+    w.x0 = (int32_t)(gx * BW); w.y0 = (int32_t)(ty0 * 8u + gy * kWvH);
     w.valid = gy < rows;
     return w;
 }
-inline uint32_t wavelet_blocks(const KArgs& a) {
-    const uint32_t groups_x = (a.width + kWvW - 1u) / kWvW, ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
+inline uint32_t wavelet_blocks(const KArgs& a, uint32_t block_w = kWvW) {
+    const uint32_t groups_x = (a.width + block_w - 1u) / block_w, ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
     return groups_x * (((ty1 - ty0) * 8u + kWvH - 1u) / kWvH);
 }
 // stages the (kWvW + 2 HALO) x (kWvH + 2 HALO) window around the block into LDS (row pitch P texels)
-template <int HALO, int P>
+template <int HALO, int P, int BW = kWvW>
 ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* di_in, const float4* gi_in, float4* s_sn, float4* s_di, float4* s_gi, f2* s_sl) {
-    constexpr int WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO;
+    constexpr int WW = BW + 2 * HALO, WH = kWvH + 2 * HALO;
     for (int i = (int)threadIdx.x; i < WW * WH; i += kWvThreads) {
         const int ry = i / WW, rx = i - ry * WW;
         const int32_t gx = blk.x0 - HALO + rx, gy = blk.y0 - HALO + ry;
@@ -314,7 +315,11 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
     __shared__ float4 s_gi[P * WH];
+#ifdef ST_WAVELET_SL
     __shared__ f2 s_sl[P * WH];
+#else
+    f2* s_sl = nullptr;
+#endif
     const WaveletBlock blk = wavelet_block(a);
     if (!blk.valid) return;
     wavelet_stage<HALO, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi, s_sl);
@@ -361,6 +366,68 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
     gi_out[center] = o.gi;
 }
 
+// ---- the same launch with 64 x 16-pixel blocks (512 threads, 76 KB of LDS, two blocks per CU). The 32 x 16 form runs the
+// stride-1 pass for 36 x 20 = 720 pixels on 512 threads — two rounds, the second 41 % full — and stages 1.63 texels per
+// pixel; here 68 x 20 = 1360 pixels take three rounds (88 % full), the stride-2 pass two full ones, and the window is 1.50
+// texels per pixel: 2.5 thread-rounds of tap arithmetic per pixel instead of 3.0. (-DST_W12_NARROW selects the 32 x 16 form.)
+constexpr int kW12W = 64;
+__global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12_wide(const KArgs a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out,
+                                                                        const float4* gi_in, float4* gi_mid, float4* gi_out) {
+    constexpr int HALO = 3, WW = kW12W + 2 * HALO, WH = kWvH + 2 * HALO, P = 72;  // 70 x 22 texels, pitch 72 = 8 mod 16
+    constexpr int RW = kW12W + 4, RH = kWvH + 4;                                  // 68 x 20: where the stride-1 pass must run
+    constexpr int ROUNDS = (RW * RH + kWvThreads - 1) / kWvThreads;               // 3
+    static_assert(P >= WW && P % 16 == 8, "pitch");
+    __shared__ float4 s_sn[P * WH];
+    __shared__ float4 s_di[P * WH];
+    __shared__ float4 s_gi[P * WH];
+#ifdef ST_WAVELET_SL
+    __shared__ f2 s_sl[P * WH];
+#else
+    f2* s_sl = nullptr;
+#endif
+    const WaveletBlock blk = wavelet_block<kW12W>(a);
+    if (!blk.valid) return;
+    wavelet_stage<HALO, P, kW12W>(a, blk, di_in, gi_in, s_sn, s_di, s_gi, s_sl);
+    __syncthreads();
+    float4 r_di[ROUNDS], r_gi[ROUNDS]; int r_at[ROUNDS];
+#pragma unroll
+    for (int it = 0; it < ROUNDS; it++) {
+        const int idx = (int)threadIdx.x + it * kWvThreads;
+        r_at[it] = -1;
+        if (idx >= RW * RH) continue;
+        const int ry = idx / RW, rx = idx - ry * RW;
+        const int lc = (ry + 1) * P + rx + 1;
+        r_at[it] = lc;
+        const WaveletOut o = wavelet_pixel_lds<1, P>(s_sn, s_di, s_gi, s_sl, lc, strength0);
+        r_di[it] = o.di; r_gi[it] = o.gi;
+        const int32_t px = blk.x0 - 2 + rx, py = blk.y0 - 2 + ry;
+        if (rx >= 2 && rx < 2 + kW12W && ry >= 2 && ry < 2 + kWvH && px < (int32_t)a.width && py < (int32_t)a.height && (uint32_t)py >= a.row0 && (uint32_t)py < a.row1) {
+            const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
+            di_mid[center] = r_di[it];
+            if (o.lit) gi_mid[center] = r_gi[it];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ROUNDS; it++) if (r_at[it] >= 0) {
+        s_di[r_at[it]] = r_di[it]; s_gi[r_at[it]] = r_gi[it];
+#ifdef ST_WAVELET_SL
+        s_sl[r_at[it]] = sqrt_luma2(r_di[it], r_gi[it]);
+#endif
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; it++) {   // stride-2 pass: thread t -> pixels (t % 64, t / 64) and (t % 64, t / 64 + 8)
+        const int x = (int)(threadIdx.x & 63u), y = (int)(threadIdx.x >> 6) + it * 8;
+        const int32_t px = blk.x0 + x, py = blk.y0 + y;
+        if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) continue;
+        const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
+        const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, s_sl, (y + HALO) * P + x + HALO, strength1);
+        di_out[center] = o.di;
+        gi_out[center] = o.gi;   // (see k_denoise_wavelet_12 for the sky case)
+    }
+}
+
 // ---- a single zero-jitter pass staged through LDS (stride 4; also strides 1 and 2 when run unfused)
 template <int S>
 __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_lds(const KArgs a, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out) {
@@ -375,7 +442,11 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_lds(const KArgs 
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
     __shared__ float4 s_gi[P * WH];
+#ifdef ST_WAVELET_SL
     __shared__ f2 s_sl[P * WH];
+#else
+    f2* s_sl = nullptr;
+#endif
     const WaveletBlock blk = wavelet_block(a);
     if (!blk.valid) return;
     wavelet_stage<S, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi, s_sl);
@@ -501,8 +572,13 @@ void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float stren
 }
 void launch_denoise_wavelet_12(const KArgs& a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out, const float4* gi_in,
                                float4* gi_mid, float4* gi_out, hipStream_t s) {
+#ifdef ST_W12_NARROW
     const uint32_t blocks = wavelet_blocks(a);
     if (blocks) hipLaunchKernelGGL(k_denoise_wavelet_12, dim3(blocks), dim3(kWvThreads), 0, s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
+#else
+    const uint32_t blocks = wavelet_blocks(a, kW12W);
+    if (blocks) hipLaunchKernelGGL(k_denoise_wavelet_12_wide, dim3(blocks), dim3(kWvThreads), 0, s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
+#endif
 }
 
 // ---------------------------------------------------------------- st_camera_write_buffer support
