@@ -310,7 +310,10 @@ ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* d
 // an internal pair of planes instead (st_engine.cpp) and the stash planes first receive the stride-2 output.
 __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out,
                                                                    const float4* gi_in, float4* gi_mid, float4* gi_out) {
-    constexpr int HALO = 3, WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO, P = 40;  // 38 x 22 texels, pitch 40 = 8 mod 16
+#ifndef ST_W12_PITCH
+#define ST_W12_PITCH 40
+#endif
+    constexpr int HALO = 3, WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO, P = ST_W12_PITCH;  // 38 x 22 texels, pitch 40 = 8 mod 16
     constexpr int RW = kWvW + 4, RH = kWvH + 4;                                   // 36 x 20: where the stride-1 pass must run
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
@@ -369,7 +372,9 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
 // ---- the same launch with 64 x 16-pixel blocks (512 threads, 76 KB of LDS, two blocks per CU). The 32 x 16 form runs the
 // stride-1 pass for 36 x 20 = 720 pixels on 512 threads — two rounds, the second 41 % full — and stages 1.63 texels per
 // pixel; here 68 x 20 = 1360 pixels take three rounds (88 % full), the stride-2 pass two full ones, and the window is 1.50
-// texels per pixel: 2.5 thread-rounds of tap arithmetic per pixel instead of 3.0. (-DST_W12_NARROW selects the 32 x 16 form.)
+// texels per pixel: 2.5 thread-rounds of tap arithmetic per pixel instead of 3.0. MEASURED SLOWER (round 3, same-box A/B: 78.1 against
+// 69.1 us on Cornell, 85.2 against 74.6 on the dungeon): two blocks per CU leave 4 waves per SIMD where the 32 x 16 form has 6, and
+// these passes live on occupancy, not on arithmetic slots. Kept behind -DST_W12_WIDE.
 constexpr int kW12W = 64;
 __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12_wide(const KArgs a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out,
                                                                         const float4* gi_in, float4* gi_mid, float4* gi_out) {
@@ -572,7 +577,7 @@ void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float stren
 }
 void launch_denoise_wavelet_12(const KArgs& a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out, const float4* gi_in,
                                float4* gi_mid, float4* gi_out, hipStream_t s) {
-#ifdef ST_W12_NARROW
+#ifndef ST_W12_WIDE
     const uint32_t blocks = wavelet_blocks(a);
     if (blocks) hipLaunchKernelGGL(k_denoise_wavelet_12, dim3(blocks), dim3(kWvThreads), 0, s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
 #else
