@@ -311,9 +311,9 @@ ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* d
 __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out,
                                                                    const float4* gi_in, float4* gi_mid, float4* gi_out) {
 #ifndef ST_W12_PITCH
-#define ST_W12_PITCH 40
+#define ST_W12_PITCH 38  // 40,128 B of LDS: four blocks per CU (pitch 40: three); measured 68.9 -> 63.3 us. A wave's ds_read_b128 covers whole 16-texel row runs either way
 #endif
-    constexpr int HALO = 3, WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO, P = ST_W12_PITCH;  // 38 x 22 texels, pitch 40 = 8 mod 16
+    constexpr int HALO = 3, WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO, P = ST_W12_PITCH;  // 38 x 22 texels
     constexpr int RW = kWvW + 4, RH = kWvH + 4;                                   // 36 x 20: where the stride-1 pass must run
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
