@@ -120,6 +120,17 @@ def n1_reference(key):
         return None
 
 
+def apron_overhead(height, world, apron):
+    """Redundant rows a rank renders around its band (windows are kept on 8-row tile boundaries), as a fraction of the band:
+    the largest over the ranks (an interior band) and the mean."""
+    from strolle_amd.distributed import band_for_rank, render_window
+    fr = []
+    for r in range(world):
+        b = band_for_rank(height, world, r); w = render_window(height, b, apron)
+        fr.append((w[1] - w[0]) / (b[1] - b[0]) - 1.0)
+    return {"max": round(max(fr), 4), "mean": round(sum(fr) / len(fr), 4)}
+
+
 class Job:
     """One camera of one scene on this rank: engine, row band (+ apron), double-buffered render targets and the per-frame
     gather of the bands to rank 0 on a communication stream."""
@@ -270,7 +281,7 @@ def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scen
            "gather_ms": None if job.gather_ms() is None else round(job.gather_ms(), 4),
            "gathered_bytes_per_frame": (job.height - (job.band[1] - job.band[0])) * job.width * 16,
            "band_rows": job.band[1] - job.band[0], "apron_rows": job.apron,
-           "apron_overhead_frac": round((job.window[1] - job.window[0]) / (job.band[1] - job.band[0]) - 1.0, 4),
+           "apron_overhead_frac": apron_overhead(job.height, world, job.apron),
            "n1_ms_reference": n1_reference(key), "n1_ms_reference_source": "profiles/n1_reference.json (builder-run single-GPU figure, not measured by this process)",
            "frame_finite": finite}
     job.close()
@@ -472,7 +483,7 @@ def main():
             result["multi_gpu"] = {"rccl_ranks": rccl_ranks, "backend": backend, "rccl_ranks_note": "sum of ones over an all-reduce on that backend before the first frame (nccl = RCCL on ROCm)",
                                    "per_rank_ms_per_step": per_rank_ms, "gather_ms_on_comm_stream_rank0": None if gather_ms is None else round(gather_ms, 4),
                                    "gathered_bytes_per_frame": (height - (band[1] - band[0])) * width * 16,
-                                   "apron_overhead_frac": round((window[1] - window[0]) / (band[1] - band[0]) - 1.0, 4),
+                                   "apron_overhead_frac": apron_overhead(height, world, job.apron),
                                    "main_region": "weak scaling: NOT a BASELINE config for N > 1 (the frame grows with N); the BASELINE configs as written are strong_config5 / strong_config4 below" if args.scaling == "weak" else "strong scaling of --width x --height",
                                    "hardware_scaling_curve": "none measured by the builder (gpurun boxes have one GPU); whatever the driver's N = 1, 2, 4, 8 runs print is the first",
                                    **strong}
