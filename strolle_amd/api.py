@@ -14,6 +14,7 @@ import dataclasses
 import enum
 import math
 import os
+import sys
 from typing import Optional, Sequence
 
 import numpy as np
@@ -447,6 +448,8 @@ class EngineBase:
 
     def bvh_depth(self):
         """(longest chain of internal nodes in the uploaded BVH, traversal stack entries per ray)."""
+        if not hasattr(self._b, "debug_bvh_depth"):
+            raise StrolleError("bvh_depth() is a seam of libstrolle_hip.so (st_debug_bvh_depth); this engine's library does not export it")
         a, b = C.c_uint32(), C.c_uint32()
         self._check(self._b.debug_bvh_depth(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
@@ -472,12 +475,12 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         if not os.path.exists(path):
             raise StrolleError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
         # One HIP runtime per process: PyTorch ships its own libamdhip64. If this library were loaded first it would bring
-        # in /opt/rocm's copy, torch would then load its bundled one beside it, and device enumeration fails in whichever
-        # comes second. Loading torch first makes both share torch's runtime (this library only needs the HIP API).
-        try:
+        # in /opt/rocm's copy, a later `import torch` would load its bundled one beside it, and device enumeration fails in
+        # whichever comes second. So: a process that uses torch together with this package imports torch FIRST (tests and
+        # bench.py do; then both share torch's runtime — this library only needs the HIP API). Nothing is imported behind
+        # the caller's back unless STROLLE_HIP_PRELOAD_TORCH=1 asks for it.
+        if os.environ.get("STROLLE_HIP_PRELOAD_TORCH") == "1" and "torch" not in sys.modules:
             import torch  # noqa: F401
-        except ImportError:
-            pass
         _lib_cache[path] = C.CDLL(path)
     return _lib_cache[path]
 

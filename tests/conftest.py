@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:   # one HIP runtime per process: torch's bundled one must be the first (strolle_amd/api.py load_library)
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -243,3 +243,42 @@ def test_gi_history_pointer_swap_is_unobservable_through_the_buffers():
     assert p >= 40.0, f"frame 12 with and without the pointer swap: PSNR {p:.1f} dB"
     for e, _, _ in engines:
         e.close()
+
+
+@pytest.mark.parametrize("switch", ["ST_NO_PREVIEW_BOTH", "ST_NO_VARIANCE_IN_REPROJECT", "ST_KEEP_SCRATCH", "ST_KEEP_ALL_PLANES", "ST_NO_FUSE_COMPOSE", "ST_NO_GI_ALIAS", "ST_NO_OVERLAP"])
+def test_fast_build_whole_graph_switches_agree_with_the_default(switch):
+    """The fast build's whole-frame launch structures against each other: the default (both GI preview passes in one launch,
+    variance in the reproject stages, dead scratch stores skipped, the lean frame, composition inside the last a-trous pass,
+    GI history by pointer swap, two streams) and the same build with ONE of those switched off render the same four frames from
+    the same seeds. Fused and unfused kernels contract their multiply-adds differently, so the comparison is the per-lane
+    tolerance of this module on the planes both variants store, with a per-plane allowance for discrete choices that flip
+    and grow over the four frames (measured: <= 4e-3), and the composed frame by PSNR."""
+    torch = _torch()
+    size = (192, 112)
+    runs = []
+    for env in ({}, {switch: "1"}):
+        os.environ.update(env)
+        try:
+            e = Engine(device=0, exact=False)
+        finally:
+            for k in env:
+                os.environ.pop(k)
+        scenes.build_cornell(e); e.set_seed(17)
+        desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+        cam = e.create_camera(desc)
+        out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+        for frame in range(4):
+            e.update_camera(cam, desc); e.tick(); e.render_camera(cam, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        planes = {b: e.read_buffer(cam, b) for b in (Buffer.DI_RESERVOIRS_0, Buffer.GI_RESERVOIRS_0, Buffer.DI_DIFF_PREV_COLORS, Buffer.GI_DIFF_PREV_COLORS,
+                                                     Buffer.DI_DIFF_MOMENTS_A, Buffer.GI_DIFF_MOMENTS_A, Buffer.PRIM_GBUFFER_D0_A, Buffer.REPROJECTION_MAP)}
+        runs.append((out.cpu().numpy()[..., :3], planes))
+        e.close()
+    (img_a, planes_a), (img_b, planes_b) = runs
+    assert np.isfinite(img_b).all()
+    peak = float(np.percentile(img_a, 99.9))
+    p = psnr(np.clip(img_b, 0, peak), np.clip(img_a, 0, peak), peak)
+    assert p >= 45.0, f"{switch}: composed frame 4 PSNR {p:.1f} dB against the default structure"
+    for b in planes_a:
+        frac = float(lanes_outside_tolerance(planes_b[b], planes_a[b]).mean())
+        assert frac <= 2e-2, f"{switch}: plane {b.name}: {frac:.2e} of the lanes outside tolerance after four frames"
