@@ -252,7 +252,7 @@ def test_fast_build_whole_graph_switches_agree_with_the_default(switch):
     GI history by pointer swap, two streams) and the same build with ONE of those switched off render the same four frames from
     the same seeds. Fused and unfused kernels contract their multiply-adds differently, so the comparison is the per-lane
     tolerance of this module on the planes both variants store, with a per-plane allowance for discrete choices that flip
-    and grow over the four frames (measured: <= 4e-3), and the composed frame by PSNR."""
+    and grow over the four frames, and the composed frame by PSNR."""
     torch = _torch()
     size = (192, 112)
     runs = []
