@@ -229,11 +229,9 @@ int st_camera_write_buffer(StEngine* e, StHandle camera, int buffer_id, const vo
  * again — not a later pass of the frame, not the next frame — are not stored: the velocity map and the encoded surface map
  * (every kernel reads the decoded twin this library keeps), both diffuse-sample planes (the fused denoise-reproject stages
  * consume them in registers), the reprojected GI reservoirs of tracing frames, the first GI preview pass's result where it
- * is a plain normalisation of its input (the second pass rebuilds it where it reads one), the DI spatial pass's copy of the
- * other checkerboard pixels (resolving reads them from the pass's input plane), and the last a-trous pass's colour
+ * is a plain normalisation of its input (the second pass rebuilds it where it reads one), and the last a-trous pass's colour
  * planes (frame composition runs inside that launch). st_camera_read_buffer of ST_BUF_VELOCITY_MAP, PRIM_SURFACE_MAP_*,
- * DI/GI_DIFF_SAMPLES, DI_RESERVOIRS_2, GI_RESERVOIRS_2, GI_RESERVOIRS_3 and DI/GI_DIFF_CURR_COLORS then returns what an earlier launch
- * left (DI_RESERVOIRS_2: for every other pixel).
+ * DI/GI_DIFF_SAMPLES, GI_RESERVOIRS_2, GI_RESERVOIRS_3 and DI/GI_DIFF_CURR_COLORS then returns what an earlier launch left.
  * keep != 0 (or ST_KEEP_ALL_PLANES=1 in the environment) makes every frame store all planes as the reference does; the exact
  * build, a pass mask and the partial camera modes always do. */
 int st_debug_keep_all_planes(StEngine* e, int keep);

@@ -132,7 +132,6 @@ ST_D void di_spatial_sample_cell(const KArgs& a, uint32_t seed, U2 gid, U2 lhs_p
         res_norm(main_, main_pdf, 1.0f, 1.0f);
         di_write(out_res, lhs_idx, main_);
     } else di_write(out_res, lhs_idx, lhs);
-    if (a.lean & kLeanDiCopy) return;  // lean frame: k_di_resolving reads the other pixel's reservoir where it is
     const U2 other = resolve_checkerboard(gid, a.frame / 2u);
     if (contains_u(a, other)) { const uint32_t oi = screen_to_idx(a, other); di_write(out_res, oi, di_read(in_res, oi, n)); }
 }
@@ -199,9 +198,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     const uint32_t n = a.width * a.height;
     const uint32_t idx = screen_to_idx(a, pos);
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
-    // lean frame (kLeanDiCopy): the spatial pass resampled this frame's checkerboard pixels into di_res[2] and left the others in di_res[1]
-    const float4* resampled = ((a.lean & kLeanDiCopy) && !got_checkerboard_at(pos, a.frame / 2u + 1u)) ? a.di_res[1] : a.di_res[2];
-    DiReservoir res = di_read(resampled, idx, n);
+    DiReservoir res = di_read(a.di_res[2], idx, n);
     ReprojectHistory history;  // fetched ahead of the shadow ray (st_passes.h)
     if (REPROJECT) history = denoise_reproject_prefetch(a, pos, a.di_diff_prev_colors, a.di_diff_prev_moments);
     float confidence;

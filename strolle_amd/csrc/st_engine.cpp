@@ -1170,10 +1170,6 @@ struct Engine {
                 a.lean = kLeanPrim | kLeanSamples;
                 if (fuse_gi_reproj && tracing && even_tiles_x) a.lean |= kLeanGiRes2;
                 if (gi_preview_both) a.lean |= kLeanGiMid;
-#ifndef ST_NO_LEAN_DI_COPY  // A/B (tools/ab_bench.sh)
-                if (fuse_spatial && even_tiles_x) a.lean |= kLeanDiCopy;
-#endif
-                 // (an odd tile count leaves the last column to the unfused passes: no split then)
             }
             // frame composition rides in the last a-trous pass (k_denoise.hip k_denoise_wavelet_far<true>)
             const bool compose_in_wavelet = fuse_compose && arithmetic == ST_ARITH_FAST && whole_graph && fuse && denoise && out != nullptr && mode == ST_MODE_IMAGE && any_objects;

@@ -49,8 +49,6 @@ constexpr uint32_t kLeanGiRes2 = 4u;   // tracing frames: the reprojected GI res
 constexpr uint32_t kLeanGiMid = 8u;    // both GI preview passes in one launch: a first-pass result that is a plain normalisation of its input (the pixel drew
                                        // no neighbour: every pixel once the reservoirs have history) is not stored to GI_RESERVOIRS_3; the few pixels
                                        // whose second pass does resample rebuild such a neighbour's record from the pass's input (KArgs::gi_mid_src)
-constexpr uint32_t kLeanDiCopy = 16u;  // DI spatial resampling does not copy the OTHER checkerboard pixel's reservoir from its input plane to its output plane
-                                       // (di_spatial_resampling.rs:289-296): resolving, the only reader, takes those pixels from the input plane
 constexpr int kBvhStackSize = 24;  // strolle-gpu/src/lib.rs:76
 constexpr uint32_t kLightIdSky = 0xffffffffu;
 constexpr uint32_t kCounterLines = 256;  // ray/byte counters are spread over this many 64-B lines per kernel slot

@@ -69,8 +69,7 @@ def lean_planes(frame):
     """planes the lean frame leaves unwritten on `frame` (st_types.h kLean*, st_engine.cpp `lean_frame`)"""
     sm = Buffer.PRIM_SURFACE_MAP_B if frame % 2 else Buffer.PRIM_SURFACE_MAP_A
     skip = {Buffer.VELOCITY_MAP, sm, Buffer.DI_DIFF_SAMPLES, Buffer.GI_DIFF_SAMPLES, Buffer.DI_DIFF_CURR_COLORS, Buffer.GI_DIFF_CURR_COLORS,
-            Buffer.GI_RESERVOIRS_3,   # the first preview pass's results: stored only where that pass resampled
-            Buffer.DI_RESERVOIRS_2}   # the spatial pass's output: the other checkerboard pixels are not copied into it
+            Buffer.GI_RESERVOIRS_3}   # the first preview pass's results: stored only where that pass resampled
     if frame % 6 < 4:
         skip.add(Buffer.GI_RESERVOIRS_2)
     return skip
