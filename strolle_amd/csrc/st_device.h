@@ -402,9 +402,66 @@ ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32
 }
 // glam Affine3A::transform_point3 with the transform stored as 4 float4 (x, y, z axes, translation)
 ST_D V3 affine_point(const float4* m, V3 p) { return ((xyz(m[0]) * p.x) + (xyz(m[1]) * p.y) + (xyz(m[2]) * p.z)) + xyz(m[3]); }
+// Any-hit traversal over the 4-wide nodes the engine appends behind the binary stream (st_engine.cpp append_wide_nodes; fast
+// build only: KArgs::bvh_wide_len). A wide node's four child boxes are tested with intersect_box's own arithmetic; every
+// child the ray reaches is pushed (the order is irrelevant to "is anything in the way") and the next entry popped, so the
+// node step has no data-dependent branch at all — the binary loop's four divergent `if`s per internal step are what its
+// scalar-issue time goes to. Leaf runs are the binary stream's own entries: same triangles, same hit test, same answer.
+// A child offset at or beyond the end of the binary stream is a wide node, below it a leaf run.
+template <class SE>
+ST_D bool trace_any_wide(const KArgs& a, const Ray& ray, SE* stack) {
+    const uint32_t wide_base = a.bvh_len * 16u;
+    const float limit = ray.len;
+    uint32_t cur = wide_base;
+    int sp = 0;
+    for (;;) {
+        const float4* entry = bvh_entry(a.bvh, cur);
+        if (cur >= wide_base) {
+            const float4 mnx = entry[0], mny = entry[1], mnz = entry[2], mxx = entry[3], mxy = entry[4], mxz = entry[5], rf = entry[6];
+            asm volatile("" :: "v"(mny.x), "v"(mnz.x), "v"(mxx.x), "v"(mxy.x), "v"(mxz.x), "v"(rf.x));
+            const float t0 = intersect_box(ray, v3(mnx.x, mny.x, mnz.x), v3(mxx.x, mxy.x, mxz.x));
+            const float t1 = intersect_box(ray, v3(mnx.y, mny.y, mnz.y), v3(mxx.y, mxy.y, mxz.y));
+            const float t2 = intersect_box(ray, v3(mnx.z, mny.z, mnz.z), v3(mxx.z, mxy.z, mxz.z));
+            const float t3 = intersect_box(ray, v3(mnx.w, mny.w, mnz.w), v3(mxx.w, mxy.w, mxz.w));
+            // unconditional stores, conditional advance: a child the ray misses is overwritten by the next push or never popped
+            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.x) >> 6); sp += t0 < limit ? 1 : 0;
+            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.y) >> 6); sp += t1 < limit ? 1 : 0;
+            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.z) >> 6); sp += t2 < limit ? 1 : 0;
+            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.w) >> 6); sp += t3 < limit ? 1 : 0;
+            sp = sp < kBvhStackSize ? sp : kBvhStackSize;  // a chain deeper than the stack loses its oldest pending children, as the binary loop drops pushes
+        } else {
+            const float4 d0 = entry[0], d1 = entry[1], d2 = entry[2], d3 = entry[3];
+            asm volatile("" :: "v"(d1.x), "v"(d2.x), "v"(d3.x));
+            const uint32_t flags = f2b(d0.x), tri = f2b(d0.y), material = f2b(d0.z);
+            const V3 p0 = xyz(d1), e1 = xyz(d2), e2 = xyz(d3);
+            const V3 pvec = xe::cross(ray.dir, e2);
+            const float det = xe::dot(e1, pvec);
+            if (!(fabsf(det) < kF32Eps)) {
+                const float inv_det = 1.0f / det;
+                const V3 tvec = xe::sub(ray.origin, p0);
+                const float u = xe::dot(tvec, pvec) * inv_det;
+                const V3 qvec = xe::cross(tvec, e1);
+                const float v = xe::dot(ray.dir, qvec) * inv_det;
+                const float t = xe::dot(e2, qvec) * inv_det;
+                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= limit))) {
+                    bool found = true;
+                    if (flags & 2u) {
+                        const GpuMaterial m = a.materials[material];
+                        const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
+                        if (bc.w < 1.0f) found = false;
+                    }
+                    if (found) return true;
+                }
+            }
+            if (flags & 1u) { cur += 64u; continue; }
+        }
+        if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64] << 6; } else return false;
+    }
+}
 // Ray::intersect (shadow ray)
 template <class SE>
 ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
+    if (a.bvh_wide_len != 0u) { *used_memory = 0u; return trace_any_wide(a, ray, stack); }
     Candidate c; bool any;
     *used_memory = traverse<true>(a, ray, ray.len, stack, &c, &any);
     return c.t < ray.len;

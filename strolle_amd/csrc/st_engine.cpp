@@ -375,6 +375,62 @@ struct Engine {
         }
         device_bvh_len = (uint32_t)(4 * entries);
     }
+    // 4-wide nodes for the ANY-HIT rays of the fast build (st_device.h trace_any_wide): the binary tree's internal nodes collapsed
+    // four children at a time (the child with the largest box is opened first), appended behind the device stream; a child is
+    // another wide node or a leaf run of the binary stream itself — same leaves, same triangles, so the same occlusion answer.
+    // The heatmap, closest-hit rays and the reference's `used_memory` counter keep the binary stream (the stream contract).
+    // A wide node is eight texels: min.x[4] min.y[4] min.z[4] max.x[4] max.y[4] max.z[4] child byte offsets[4] (spare);
+    // an unused slot holds a box no finite ray reaches.
+    bool wide_nodes = true;   // ST_NO_WIDE_NODES=1: any-hit rays walk the binary stream too
+    uint32_t device_wide_len = 0;
+    void append_wide_nodes() {
+        device_wide_len = 0;
+        bvh_upload_.resize(device_bvh_len ? device_bvh_len : bvh_upload_.size());
+        if (!wide_nodes || device_bvh_len == 0 || f2b(bvh_upload_[0].w) != 0u) return;  // empty scene, or the root is a leaf run
+        struct Child { float mn[3], mx[3]; uint32_t off; };
+        const uint32_t wide_base = device_bvh_len * 16u;
+        auto internal = [&](uint32_t off) { return f2b(bvh_upload_[off / 16u].w) == 0u; };
+        auto children_of = [&](uint32_t off, Child* out) {
+            const float4* e = &bvh_upload_[off / 16u];
+            out[0] = Child{{e[0].x, e[0].y, e[0].z}, {e[1].x, e[1].y, e[1].z}, off + 64u};
+            out[1] = Child{{e[2].x, e[2].y, e[2].z}, {e[3].x, e[3].y, e[3].z}, f2b(e[1].w)};
+        };
+        auto half_area = [](const Child& c) { const float x = c.mx[0] - c.mn[0], y = c.mx[1] - c.mn[1], z = c.mx[2] - c.mn[2]; return x * y + y * z + z * x; };
+        std::vector<float4> wide(8);
+        std::vector<std::pair<uint32_t, uint32_t>> work{{0u, 0u}};  // (binary internal entry, wide node number)
+        while (!work.empty()) {
+            const auto [off, node] = work.back(); work.pop_back();
+            Child c[4]; int n = 2;
+            children_of(off, c);
+            while (n < 4) {
+                int pick = -1; float best = -1.0f;
+                for (int i = 0; i < n; i++) if (internal(c[i].off) && half_area(c[i]) > best) { best = half_area(c[i]); pick = i; }
+                if (pick < 0) break;
+                Child two[2]; children_of(c[pick].off, two);
+                c[pick] = two[0]; c[n++] = two[1];
+            }
+            uint32_t ref[4];
+            for (int i = 0; i < 4; i++) {
+                if (i >= n) { c[i] = Child{{kF32Max, kF32Max, kF32Max}, {kF32Max, kF32Max, kF32Max}, 0u}; ref[i] = 0u; continue; }
+                if (internal(c[i].off)) {
+                    const uint32_t next = (uint32_t)(wide.size() / 8u);
+                    wide.resize(wide.size() + 8u);
+                    work.push_back({c[i].off, next});
+                    ref[i] = wide_base + next * 128u;
+                } else ref[i] = c[i].off;
+            }
+            float4* w = &wide[(size_t)node * 8u];
+            for (int k = 0; k < 3; k++) {
+                w[k] = make_float4(c[0].mn[k], c[1].mn[k], c[2].mn[k], c[3].mn[k]);
+                w[3 + k] = make_float4(c[0].mx[k], c[1].mx[k], c[2].mx[k], c[3].mx[k]);
+            }
+            w[6] = make_float4(b2f(ref[0]), b2f(ref[1]), b2f(ref[2]), b2f(ref[3]));
+            w[7] = make_float4(b2f((uint32_t)n), 0.0f, 0.0f, 0.0f);
+        }
+        if ((size_t)device_bvh_len * 16u + wide.size() * 16u > 0xffffffffull) return;  // offsets would not fit: binary stream only
+        bvh_upload_.insert(bvh_upload_.end(), wide.begin(), wide.end());
+        device_wide_len = (uint32_t)wide.size();
+    }
     std::vector<uint8_t> internal_start_;  // scratch of measure_stack_need: 1 where an internal node begins
     bool is_internal_start(size_t p) const { return p < internal_start_.size() && internal_start_[p]; }
     void mark_internal_starts() {
@@ -484,6 +540,7 @@ struct Engine {
         if (const char* k = getenv("ST_DI_HEAD_ON_MAIN")) di_head_on_main = atoi(k) != 0;
         if (const char* k = getenv("ST_KEEP_SCRATCH")) skip_scratch_stores = atoi(k) == 0;
         if (const char* k = getenv("ST_KEEP_ALL_PLANES")) lean_frame = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_WIDE_NODES")) wide_nodes = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_COMPOSE")) fuse_compose = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_PREVIEW_BOTH")) preview_both = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_VARIANCE_IN_REPROJECT")) variance_in_reproject = atoi(k) == 0;
@@ -876,6 +933,7 @@ struct Engine {
                 } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
                 SceneSet& t = sets[target];
                 expand_stream();
+                append_wide_nodes();
                 // traversal pointers are 32-bit BYTE offsets into the device stream (64 B per entry) and stack slots hold entry numbers
                 if ((size_t)device_bvh_len * sizeof(float4) > 0xffffffffull) return fail(ST_ERR_INVALID_ARGUMENT, "the BVH stream exceeds 4 GiB (2^26 entries): traversal pointers are 32-bit byte offsets");
                 if ((rc = t.bvh.upload(bvh_upload_.data(), bvh_upload_.size() * sizeof(float4), up, staging, flag))) return rc;
@@ -1065,6 +1123,7 @@ struct Engine {
         a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
         a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
         a.count_bytes = count_bytes ? 1u : 0u;
+        a.bvh_wide_len = (arithmetic == ST_ARITH_FAST && !count_bytes) ? device_wide_len : 0u;  // any-hit rays of the fast build; the byte counters are the binary stream's
         a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
         a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
         a.sun_dir[0] = sun_dir_.x; a.sun_dir[1] = sun_dir_.y; a.sun_dir[2] = sun_dir_.z;
@@ -1733,6 +1792,7 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
         case 2: p = en->gpu_lights.data(); bytes = en->gpu_lights.size() * sizeof(GpuLight); break;
         case 3: p = en->gpu_materials.data(); bytes = en->gpu_materials.size() * sizeof(GpuMaterial); break;
         case 4: en->expand_stream(); p = en->bvh_upload_.data(); bytes = (size_t)en->device_bvh_len * sizeof(float4); break;  // as st_tick would upload it now
+        case 5: en->expand_stream(); en->append_wide_nodes(); p = en->bvh_upload_.data() + en->device_bvh_len; bytes = (size_t)en->device_wide_len * sizeof(float4); break;  // the 4-wide nodes behind it
         default: return fail(ST_ERR_INVALID_ARGUMENT, "unknown scene buffer");
     }
     if (written) *written = bytes;

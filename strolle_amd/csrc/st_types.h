@@ -65,6 +65,7 @@ struct KArgs {
     const float* byte_luts;  // 256 sRGB->linear + 256 unorm8 values (st_device.h kLut*), generated on the device at engine creation
     const float4* transmittance_lut; const float4* sky_lut;
     uint32_t bvh_len, n_lights_buf, light_count, atlas_w, atlas_h;
+    uint32_t bvh_wide_len;  // texels of 4-wide nodes appended behind the bvh_len texels of `bvh` (0: none; st_device.h trace_any_wide)
     // k_denoise.hip "variance in the reproject stage": the fused reproject stages store each pixel's long-history variance in
     // curr_colors.w and the DI one flags short-history pixels per 8x8 tile (bit = lane) for the variance kernel
     unsigned long long* tile_mask; uint32_t variance_in_reproject;
