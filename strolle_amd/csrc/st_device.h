@@ -402,12 +402,19 @@ ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32
 }
 // glam Affine3A::transform_point3 with the transform stored as 4 float4 (x, y, z axes, translation)
 ST_D V3 affine_point(const float4* m, V3 p) { return ((xyz(m[0]) * p.x) + (xyz(m[1]) * p.y) + (xyz(m[2]) * p.z)) + xyz(m[3]); }
-// Any-hit traversal over the 4-wide nodes the engine appends behind the binary stream (st_engine.cpp append_wide_nodes; fast
-// build only: KArgs::bvh_wide_len). A wide node's four child boxes are tested with intersect_box's own arithmetic; every
-// child the ray reaches is pushed (the order is irrelevant to "is anything in the way") and the next entry popped, so the
-// node step has no data-dependent branch at all — the binary loop's four divergent `if`s per internal step are what its
-// scalar-issue time goes to. Leaf runs are the binary stream's own entries: same triangles, same hit test, same answer.
+// Any-hit traversal over 4-wide nodes the engine can append behind the binary stream (st_engine.cpp append_wide_nodes).
+// MEASURED SLOWER, hence compiled only with -DST_WIDE_NODES=1 and switched on by ST_WIDE_NODES=1 (round 3, same box, 1080p
+// Image, wide vs binary): Cornell 0.822 vs 0.810 ms, dungeon 1.509 vs 1.478 ms; per kernel on the dungeon DI resolving 139 vs
+// 149 us, DI spatial 120 vs 120, DI sampling + temporal 213 vs 200, GI sampling b 215 vs 184, GI spatial 426 vs 382. A wide
+// step runs the same four box tests as two binary steps (92 VALU instructions), picks the nearest child (≈ 25 more) and makes
+// four LDS stack stores where the binary pair makes at most two: it saves scalar issue, which overlaps vector issue anyway,
+// and pays for it in the vector and LDS pipes — worst on incoherent rays (GI sampling b's shadow rays start at secondary hits).
+// Results agree with the binary traversal within the fast build's tolerances (tests/test_gpu_fast_tolerance.py ran with it).
+// Fast build only: KArgs::bvh_wide_len. A wide node's four child boxes are tested with intersect_box's own arithmetic; every
+// child the ray reaches other than the nearest is pushed without a branch and the nearest is walked next — the binary
+// loop's four divergent `if`s per internal step are what its scalar-issue time goes to. Leaf runs are the binary stream's own entries: same triangles, same hit test, same answer.
 // A child offset at or beyond the end of the binary stream is a wide node, below it a leaf run.
+#ifdef ST_WIDE_NODES
 template <class SE>
 ST_D bool trace_any_wide(const KArgs& a, const Ray& ray, SE* stack) {
     const uint32_t wide_base = a.bvh_len * 16u;
@@ -423,12 +430,18 @@ ST_D bool trace_any_wide(const KArgs& a, const Ray& ray, SE* stack) {
             const float t1 = intersect_box(ray, v3(mnx.y, mny.y, mnz.y), v3(mxx.y, mxy.y, mxz.y));
             const float t2 = intersect_box(ray, v3(mnx.z, mny.z, mnz.z), v3(mxx.z, mxy.z, mxz.z));
             const float t3 = intersect_box(ray, v3(mnx.w, mny.w, mnz.w), v3(mxx.w, mxy.w, mxz.w));
-            // unconditional stores, conditional advance: a child the ray misses is overwritten by the next push or never popped
-            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.x) >> 6); sp += t0 < limit ? 1 : 0;
-            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.y) >> 6); sp += t1 < limit ? 1 : 0;
-            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.z) >> 6); sp += t2 < limit ? 1 : 0;
-            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.w) >> 6); sp += t3 < limit ? 1 : 0;
+            // The nearest child the ray reaches is walked next (an occluder is most likely found there first); the others are
+            // pushed with unconditional stores and a conditional advance — a child the ray misses is overwritten by the next
+            // push or never popped — so the node step has one data-dependent branch instead of the binary step's four.
+            const float tn = fmin_(fmin_(t0, t1), fmin_(t2, t3));
+            const bool c0 = t0 == tn, c1 = !c0 && t1 == tn, c2 = !c0 && !c1 && t2 == tn, c3 = !c0 && !c1 && !c2;
+            const uint32_t nearest = c0 ? f2b(rf.x) : (c1 ? f2b(rf.y) : (c2 ? f2b(rf.z) : f2b(rf.w)));
+            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.x) >> 6); sp += (t0 < limit && !c0) ? 1 : 0;
+            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.y) >> 6); sp += (t1 < limit && !c1) ? 1 : 0;
+            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.z) >> 6); sp += (t2 < limit && !c2) ? 1 : 0;
+            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.w) >> 6); sp += (t3 < limit && !c3) ? 1 : 0;
             sp = sp < kBvhStackSize ? sp : kBvhStackSize;  // a chain deeper than the stack loses its oldest pending children, as the binary loop drops pushes
+            if (tn < limit) { cur = nearest; continue; }
         } else {
             const float4 d0 = entry[0], d1 = entry[1], d2 = entry[2], d3 = entry[3];
             asm volatile("" :: "v"(d1.x), "v"(d2.x), "v"(d3.x));
@@ -458,10 +471,13 @@ ST_D bool trace_any_wide(const KArgs& a, const Ray& ray, SE* stack) {
         if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64] << 6; } else return false;
     }
 }
+#endif
 // Ray::intersect (shadow ray)
 template <class SE>
 ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
+#ifdef ST_WIDE_NODES
     if (a.bvh_wide_len != 0u) { *used_memory = 0u; return trace_any_wide(a, ray, stack); }
+#endif
     Candidate c; bool any;
     *used_memory = traverse<true>(a, ray, ray.len, stack, &c, &any);
     return c.t < ray.len;

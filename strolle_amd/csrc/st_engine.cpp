@@ -375,13 +375,14 @@ struct Engine {
         }
         device_bvh_len = (uint32_t)(4 * entries);
     }
-    // 4-wide nodes for the ANY-HIT rays of the fast build (st_device.h trace_any_wide): the binary tree's internal nodes collapsed
+    // OPT-IN (a build with -DST_WIDE_NODES=1 run with ST_WIDE_NODES=1; measured slower, st_device.h trace_any_wide says by how much):
+    // 4-wide nodes for the ANY-HIT rays of the fast build: the binary tree's internal nodes collapsed
     // four children at a time (the child with the largest box is opened first), appended behind the device stream; a child is
     // another wide node or a leaf run of the binary stream itself — same leaves, same triangles, so the same occlusion answer.
     // The heatmap, closest-hit rays and the reference's `used_memory` counter keep the binary stream (the stream contract).
     // A wide node is eight texels: min.x[4] min.y[4] min.z[4] max.x[4] max.y[4] max.z[4] child byte offsets[4] (spare);
     // an unused slot holds a box no finite ray reaches.
-    bool wide_nodes = true;   // ST_NO_WIDE_NODES=1: any-hit rays walk the binary stream too
+    bool wide_nodes = false;
     uint32_t device_wide_len = 0;
     void append_wide_nodes() {
         device_wide_len = 0;
@@ -540,7 +541,9 @@ struct Engine {
         if (const char* k = getenv("ST_DI_HEAD_ON_MAIN")) di_head_on_main = atoi(k) != 0;
         if (const char* k = getenv("ST_KEEP_SCRATCH")) skip_scratch_stores = atoi(k) == 0;
         if (const char* k = getenv("ST_KEEP_ALL_PLANES")) lean_frame = atoi(k) == 0;
-        if (const char* k = getenv("ST_NO_WIDE_NODES")) wide_nodes = atoi(k) == 0;
+#ifdef ST_WIDE_NODES
+        if (const char* k = getenv("ST_WIDE_NODES")) wide_nodes = atoi(k) != 0;
+#endif
         if (const char* k = getenv("ST_NO_FUSE_COMPOSE")) fuse_compose = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_PREVIEW_BOTH")) preview_both = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_VARIANCE_IN_REPROJECT")) variance_in_reproject = atoi(k) == 0;
@@ -1792,7 +1795,12 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
         case 2: p = en->gpu_lights.data(); bytes = en->gpu_lights.size() * sizeof(GpuLight); break;
         case 3: p = en->gpu_materials.data(); bytes = en->gpu_materials.size() * sizeof(GpuMaterial); break;
         case 4: en->expand_stream(); p = en->bvh_upload_.data(); bytes = (size_t)en->device_bvh_len * sizeof(float4); break;  // as st_tick would upload it now
-        case 5: en->expand_stream(); en->append_wide_nodes(); p = en->bvh_upload_.data() + en->device_bvh_len; bytes = (size_t)en->device_wide_len * sizeof(float4); break;  // the 4-wide nodes behind it
+        case 5: {  // the 4-wide nodes st_tick would append behind it when they are switched on (built here either way: a host-side test walks them)
+            const bool was = en->wide_nodes; en->wide_nodes = true;
+            en->expand_stream(); en->append_wide_nodes();
+            en->wide_nodes = was;
+            p = en->bvh_upload_.data() + en->device_bvh_len; bytes = (size_t)en->device_wide_len * sizeof(float4); break;
+        }
         default: return fail(ST_ERR_INVALID_ARGUMENT, "unknown scene buffer");
     }
     if (written) *written = bytes;

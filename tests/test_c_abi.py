@@ -539,8 +539,8 @@ def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):
 
 @pytest.mark.parametrize("scene", ["cornell", "soup", "dungeon"])
 def test_wide_nodes_cover_the_binary_tree(scene):
-    """The 4-wide nodes the engine appends behind the device stream for the fast build's any-hit rays (read_scene(5);
-    st_engine.cpp append_wide_nodes): walked from its root, the wide tree reaches every leaf run of the binary stream exactly
+    """The 4-wide nodes the engine can append behind the device stream for the fast build's any-hit rays (read_scene(5);
+    st_engine.cpp append_wide_nodes; opt-in, measured slower than the binary traversal — st_device.h trace_any_wide): walked from its root, the wide tree reaches every leaf run of the binary stream exactly
     once, every child box is a box of the binary tree (the child's box in its binary parent), a node has 2..4 children, and an
     unused slot holds a box no finite ray reaches."""
     prod = Engine(device=-1)
