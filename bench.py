@@ -369,7 +369,7 @@ def main():
     gather_ms = job.gather_ms()
     # region 2: the same K steps again with HIP events around every run of same-slot launches (on the launch stream, pass
     # graph serial) -> per-kernel average durations for the roofline object. Kept out of region 1: it costs ~10 %.
-    prof, profiled_ms, grouped = [], None, []
+    prof, profiled_ms, grouped, kernel_events = [], None, [], {}
     if not args.no_profile:
         engine.profile_enable(1)   # ST_PROFILE_TIMING
         engine.profile_read(reset=True)
@@ -382,6 +382,12 @@ def main():
         engine.profile_read(reset=True)
         timed_region()
         grouped = [q for q in engine.profile_read(reset=True) if q["name"].startswith("a-trous chain")]
+        # region 2c: once more with every launch carrying its own start / stop events (ST_PROFILE_KERNEL_EVENTS: the dispatch's
+        # timestamps through hipExtLaunchKernelGGL, no event packet between kernels) -> per-kernel durations as rocprofv3 sees them
+        engine.profile_enable(1 | 8)
+        engine.profile_read(reset=True)
+        timed_region()
+        kernel_events = {q["name"]: q for q in engine.profile_read(reset=True)}
         # region 3, untimed: a few more frames with the traversal-byte counters on (ST_PROFILE_TRAVERSAL_BYTES; the kernels
         # sum the reference's `used_memory` over their rays, which costs ~10 us per tracing launch and is therefore off in
         # regions 1 and 2) -> the LDS / L2-served A part of the algorithmic bytes, scaled to K steps
@@ -511,6 +517,11 @@ def main():
             if grouped and grouped[0]["launches"] == launches and fam and fam_ms >= max(p["total_ms"] for p in prof if p["name"] not in WAVELET_SLOTS):
                 tot_ms = grouped[0]["total_ms"]   # same launches, same bytes; one interval around the four launches of a frame
                 timing = "ONE HIP-event pair around the chain's four back-to-back launches of a frame (ST_PROFILE_GROUP_ATROUS)"
+            one_pair = {"avg_launch_ms": round(tot_ms / launches, 5), "achieved": round((alg - trav) / (tot_ms * 1e-3) / 1e9, 2), "frac": round((alg - trav) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            ke = [kernel_events[p["name"]] for p in (fam if fam and name.startswith("denoise_wavelet (") else [top]) if p["name"] in kernel_events]
+            if ke and sum(q["launches"] for q in ke) == launches and sum(q["total_ms"] for q in ke) > 0:
+                tot_ms = sum(q["total_ms"] for q in ke)   # same launches, same bytes; each kernel's own dispatch timestamps
+                timing = "per-launch start / stop events attached to the dispatch (hipExtLaunchKernelGGL, ST_PROFILE_KERNEL_EVENTS): the kernels' own durations, as rocprofv3's kernel trace reports them"
             avg_ms = tot_ms / launches
             b_bytes = (alg - trav) / launches
             achieved = b_bytes / (avg_ms * 1e-3) / 1e9   # screen-space (HBM) bytes only: traversal bytes are cache- / LDS-served
@@ -522,7 +533,7 @@ def main():
                 if r_ms > 0:
                     wavelet_only = {"passes_per_frame": sum(p["launches"] * WAVELET_SLOTS[p["name"]] for p in rest) // args.steps, "launches_per_frame": sum(p["launches"] for p in rest) // args.steps,
                                     "achieved": round(r_alg / (r_ms * 1e-3) / 1e9, 2), "frac": round(r_alg / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "ms_per_frame": round(r_ms / args.steps, 5)}
-            result["roofline"] = {"bound": "hbm", "kernel": name, "timing": timing, "with_one_event_pair_per_slot": per_slot, "wavelet_only": wavelet_only, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            result["roofline"] = {"bound": "hbm", "kernel": name, "timing": timing, "with_one_event_pair_around_the_chain": one_pair, "with_one_event_pair_per_slot": per_slot, "wavelet_only": wavelet_only, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
                                   "frac_of_measured_copy_ceiling": None if not copy_ceiling else round(achieved / copy_ceiling, 5),
                                   "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": round(b_bytes),
@@ -553,6 +564,10 @@ def main():
                                       "over its duration - an equivalent rate: a fused launch never moves part of those bytes, so it can exceed the HBM peak; "
                                       "counter_GBps: the same launch's FETCH_SIZE / WRITE_SIZE bytes from profiles/pmc_latest.json (static, an upper bound for gather kernels) "
                                       "over this run's duration - the figure to hold against the 8 TB/s peak")
+            if kernel_events:
+                for name_, q in kernel_events.items():
+                    if name_ in result["kernels"] and q["launches"]:
+                        result["kernels"][name_]["us_per_launch_kernel_events"] = round(q["total_ms"] / q["launches"] * 1e3, 2)
             result["gpu_kernel_ms_per_frame"] = round(tot / args.steps, 4)
             # both components of the algorithmic bytes for the whole frame, against the unprofiled frame time
             a_bytes = sum(p["traversal_bytes"] for p in prof) / args.steps

@@ -321,7 +321,9 @@ int st_decode_image(const void* bytes, size_t size, uint8_t* out_rgba, size_t ca
  * algorithmic bytes (DESIGN.md "bytes per unit" x units launched; the traversal part is 0 without bit 1). */
 enum { ST_PROFILE_TIMING = 1, ST_PROFILE_TRAVERSAL_BYTES = 2,
        ST_PROFILE_GROUP_ATROUS = 4 /* with TIMING: the a-trous chain's launches (4 per frame, back to back on one stream) are timed as ONE
-                                      interval under the slot "a-trous chain (one timed interval)" instead of one event pair per slot */ };
+                                      interval under the slot "a-trous chain (one timed interval)" instead of one event pair per slot */,
+       ST_PROFILE_KERNEL_EVENTS = 8 /* with TIMING: every launch carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's
+                                       timestamps, what rocprofv3's kernel trace reports) instead of events recorded between kernels */ };
 enum { ST_PROFILE_MAX_KERNELS = 48 };  /* >= the number of kernel slots (st_kernels.h) */
 typedef struct StKernelProfile {
     char name[48];

@@ -188,11 +188,11 @@ __global__ void k_atmosphere_sky(const float4* transmittance_lut, const float4* 
 }
 
 void launch_atmosphere_static(float4* transmittance_lut, float4* scattering_lut, hipStream_t s) {
-    hipLaunchKernelGGL(k_atmosphere_transmittance, dim3(32, 8), dim3(64), 0, s, transmittance_lut);
-    hipLaunchKernelGGL(k_atmosphere_scattering, dim3(4, 4), dim3(64), 0, s, transmittance_lut, scattering_lut);
+    ST_KLAUNCH(k_atmosphere_transmittance, dim3(32, 8), dim3(64), s, transmittance_lut);
+    ST_KLAUNCH(k_atmosphere_scattering, dim3(4, 4), dim3(64), s, transmittance_lut, scattering_lut);
 }
 void launch_atmosphere_sky(const float4* transmittance_lut, const float4* scattering_lut, float sun_altitude, float4* sky_lut, hipStream_t s) {
-    hipLaunchKernelGGL(k_atmosphere_sky, dim3(32, 32), dim3(64), 0, s, transmittance_lut, scattering_lut, sun_altitude, sky_lut);
+    ST_KLAUNCH(k_atmosphere_sky, dim3(32, 32), dim3(64), s, transmittance_lut, scattering_lut, sun_altitude, sky_lut);
 }
 
 }  // namespace ST_KNS

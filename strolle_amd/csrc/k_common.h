@@ -83,7 +83,7 @@ inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len 
 #define ST_LAUNCH(kernel, half, stream, ...)                                                          \
     do {                                                                                              \
         const LaunchDims d_ = launch_dims(a, half);                                                   \
-        if (d_.blocks) hipLaunchKernelGGL(kernel, dim3(d_.blocks), dim3(kBlockThreads), 0, stream, __VA_ARGS__); \
+        if (d_.blocks) ST_KLAUNCH(kernel, dim3(d_.blocks), dim3(kBlockThreads), stream, __VA_ARGS__); \
     } while (0)
 
 }  // namespace st

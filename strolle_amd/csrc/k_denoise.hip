@@ -565,9 +565,9 @@ void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, con
                             float4* gi_out, hipStream_t s) {
     const uint32_t blocks = wavelet_blocks(a);
     if (!blocks) return;
-    if (stride == 1u) hipLaunchKernelGGL(k_denoise_wavelet_lds<1>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
-    else if (stride == 2u) hipLaunchKernelGGL(k_denoise_wavelet_lds<2>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
-    else if (stride == 4u) hipLaunchKernelGGL(k_denoise_wavelet_lds<4>, dim3(blocks), dim3(kWvThreads), 0, s, a, strength, di_in, di_out, gi_in, gi_out);
+    if (stride == 1u) ST_KLAUNCH((k_denoise_wavelet_lds<1>), dim3(blocks), dim3(kWvThreads), s, a, strength, di_in, di_out, gi_in, gi_out);
+    else if (stride == 2u) ST_KLAUNCH((k_denoise_wavelet_lds<2>), dim3(blocks), dim3(kWvThreads), s, a, strength, di_in, di_out, gi_in, gi_out);
+    else if (stride == 4u) ST_KLAUNCH((k_denoise_wavelet_lds<4>), dim3(blocks), dim3(kWvThreads), s, a, strength, di_in, di_out, gi_in, gi_out);
     else ST_LAUNCH(k_denoise_wavelet_far<false>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, ComposeArgs{nullptr, 0u, 0u, 1u});
 }
 // a gather pass (stride 8 or 16) with frame_composition.rs appended (the last pass of the chain)
@@ -579,10 +579,10 @@ void launch_denoise_wavelet_12(const KArgs& a, float strength0, float strength1,
                                float4* gi_mid, float4* gi_out, hipStream_t s) {
 #ifndef ST_W12_WIDE
     const uint32_t blocks = wavelet_blocks(a);
-    if (blocks) hipLaunchKernelGGL(k_denoise_wavelet_12, dim3(blocks), dim3(kWvThreads), 0, s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
+    if (blocks) ST_KLAUNCH(k_denoise_wavelet_12, dim3(blocks), dim3(kWvThreads), s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
 #else
     const uint32_t blocks = wavelet_blocks(a, kW12W);
-    if (blocks) hipLaunchKernelGGL(k_denoise_wavelet_12_wide, dim3(blocks), dim3(kWvThreads), 0, s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
+    if (blocks) ST_KLAUNCH(k_denoise_wavelet_12_wide, dim3(blocks), dim3(kWvThreads), s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
 #endif
 }
 

@@ -213,7 +213,7 @@ __global__ void k_build_byte_luts(float* out) {
     out[kLutGamma8 + v] = gamma8_eval(v);
     out[kLutGamma6 + v] = gamma6_eval(v);
 }
-void launch_build_byte_luts(float* out, hipStream_t s) { hipLaunchKernelGGL(k_build_byte_luts, dim3(1), dim3(256), 0, s, out); }
+void launch_build_byte_luts(float* out, hipStream_t s) { ST_KLAUNCH(k_build_byte_luts, dim3(1), dim3(256), s, out); }
 
 // ---------------------------------------------------------------- frame_reprojection.rs:6-95
 __global__ ST_KERNEL_BOUNDS void k_frame_reprojection(const KArgs a) {
@@ -327,8 +327,8 @@ void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* bu
     const uint32_t groups_x = (d.tiles_x + 3u) / 4u, n_groups = d.blocks;
     if (!n_groups) return;
     const uint32_t blocks = (n_groups + kGroupsPerBlock - 1u) / kGroupsPerBlock;
-    if (a.bvh_len < kStack16Texels) hipLaunchKernelGGL(k_spatial_trace_compact<uint16_t>, dim3(blocks), dim3(kBlockThreads), 0, s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
-    else hipLaunchKernelGGL(k_spatial_trace_compact<uint32_t>, dim3(blocks), dim3(kBlockThreads), 0, s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
+    if (a.bvh_len < kStack16Texels) ST_KLAUNCH((k_spatial_trace_compact<uint16_t>), dim3(blocks), dim3(kBlockThreads), s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
+    else ST_KLAUNCH((k_spatial_trace_compact<uint32_t>), dim3(blocks), dim3(kBlockThreads), s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
 }
 
 // ---------------------------------------------------------------- frame_composition.rs:18-82 as a compute pass into an RGBA32F buffer

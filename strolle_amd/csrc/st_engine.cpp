@@ -295,6 +295,8 @@ static int read_counters(const CameraState& c, unsigned long long* host /* 2*KS_
     return ST_OK;
 }
 
+thread_local LaunchEvents g_launch_events;  // st_kernels.h: set around one launch while ST_PROFILE_KERNEL_EVENTS is on
+
 struct ProfileRecord { int slot; hipEvent_t start, stop; double bytes; uint32_t launches; bool owns_start; };
 
 struct Light112 { GpuLight g; };
@@ -517,6 +519,7 @@ struct Engine {
     uint32_t tile_map = 1;  // blockIdx -> tile mapping (st_device.h); 1 measured best on MI355X with the current kernels (2 was, before the LDS-staged denoiser); ST_TILE_MAP overrides
     bool profiling = false;       // st_profile_enable bit 0: per-kernel event timing (serial execution)
     bool count_bytes = false;     // st_profile_enable bit 1: traversal-byte counters
+    bool profile_kernel_events = false;  // st_profile_enable bit 3: every launch carries its own start / stop events (hipExtLaunchKernelGGL): no event packets between kernels
     bool profile_group_atrous = false;  // st_profile_enable bit 2: the a-trous chain's back-to-back launches share ONE event pair (an event between two kernels costs the second one 3-15 us)
     bool tick_timing = false;  // ST_TICK_TIMING=1: print the host-side cost of a scene refresh to stderr
     std::vector<ProfileRecord> profile_records; std::vector<hipEvent_t> event_pool;
@@ -1167,6 +1170,13 @@ struct Engine {
             if ((bits & pass_mask) != bits) { mask_split |= (bits & pass_mask) != 0; return; }
             const double bytes = slot_bytes(slot);
             a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
+            if (profiling && profile_kernel_events) {  // the dispatch's own timestamps (what rocprofv3's kernel trace reads)
+                g_launch_events.start = take_event(); g_launch_events.stop = take_event();
+                launch();
+                profile_records.push_back({slot, g_launch_events.start, g_launch_events.stop, bytes, 1u, true});
+                g_launch_events = LaunchEvents();
+                return;
+            }
             const bool atrous = slot == KS_DENOISE_WAVELET || slot == KS_DENOISE_WAVELET_12 || slot == KS_DENOISE_WAVELET_COMPOSE;
             profile_begin(profile_group_atrous && atrous ? (int)KS_DENOISE_WAVELET_FAMILY : slot, cur, bytes);
             launch();
@@ -1838,7 +1848,7 @@ int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused) {
     return ST_OK;
 }
 
-int st_profile_enable(StEngine* e, int enabled) { ST_REQUIRE(e, "null engine"); E(e)->profiling = (enabled & 1) != 0; E(e)->count_bytes = (enabled & 2) != 0; E(e)->profile_group_atrous = (enabled & 4) != 0; return ST_OK; }
+int st_profile_enable(StEngine* e, int enabled) { ST_REQUIRE(e, "null engine"); E(e)->profiling = (enabled & 1) != 0; E(e)->count_bytes = (enabled & 2) != 0; E(e)->profile_group_atrous = (enabled & 4) != 0; E(e)->profile_kernel_events = (enabled & 8) != 0; return ST_OK; }
 int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* count, int reset) {
     ST_REQUIRE(e && out && count, "null argument");
     Engine* en = E(e);

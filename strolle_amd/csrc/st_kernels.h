@@ -2,10 +2,23 @@
 // Each launcher enqueues exactly one kernel on `stream`; `KArgs` travels by value in the kernarg segment.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "st_types.h"
 
 namespace st {
+
+// Per-kernel timing without event packets between kernels (ST_PROFILE_KERNEL_EVENTS): when the engine sets this pair, the next
+// launch goes through hipExtLaunchKernelGGL, which writes the dispatch's own start / stop timestamps into the two events — what
+// rocprofv3's kernel trace reads too. An event RECORDED between two kernels instead makes the second wait for a barrier packet
+// (3-15 us each, measured), which is how the default profiling mode times runs of launches.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local LaunchEvents g_launch_events;  // st_engine.cpp
+#define ST_KLAUNCH(kernel, grid, block, stream, ...)                                                                                             \
+    do {                                                                                                                                         \
+        if (::st::g_launch_events.start) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ::st::g_launch_events.start, ::st::g_launch_events.stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                                                    \
+    } while (0)
 
 // Kernel slots: index into the per-camera counter array (2 x u64 per slot: rays, traversal bytes) and into the
 // profiler's table. `bytes_per_unit` = compulsory screen-space bytes one launch unit (pixel or 2x1 cell) reads +
