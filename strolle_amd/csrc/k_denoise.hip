@@ -65,7 +65,6 @@ void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const f
 }
 
 // ---------------------------------------------------------------- frame_denoising.rs:80-217
-constexpr int kVarianceDirectMax = 32;  // flagged pixels per 32 x 8 block up to which they are served without the staged window
 __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_out, float4* gi_out) {
     // Window of the short-history estimate, staged per block when any of its pixels needs it: ox in [-3, 2], oy in
     // [-2, 2] around 32x8 pixels = 38 x 12 texels of (surface, direct colour, indirect colour). Only ~15 % of the waves
@@ -91,48 +90,8 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
         // denoise_reproject_finish) and flagged the short-history pixels: this launch only serves those, in place. A block
         // without any leaves after one 8-byte load per wave.
         slow = mine && ((a.tile_mask[tile_mask_index(a, pos)] >> (threadIdx.x & 63u)) & 1ull) != 0ull;
-        const int n_slow = __syncthreads_count(slow ? 1 : 0);
-        if (n_slow == 0) return;
+        if (!__syncthreads_or(slow ? 1 : 0)) return;
         if (slow) { csn = a.sn[center]; cdi = a.di_diff_curr_colors[center]; cgi = a.gi_diff_curr_colors[center]; }
-#ifndef ST_VARIANCE_NO_DIRECT
-        // A block with only a few flagged pixels (the steady state: shadow edges) serves them straight from L2 — 29 x 3 gathers
-        // per flagged lane — instead of staging the whole 38 x 12 window for all of its 256 threads and meeting at a barrier:
-        // the same taps in the same order with the same arithmetic, so the same bits. Dense blocks (a new camera, a moving
-        // scene, the dungeon's unlit walls) keep the staged window below.
-        if (n_slow <= kVarianceDirectMax) {
-            if (!slow) return;
-            if (csn.w == 0.0f) return;  // sky: the reproject stage's colour stays as it is
-            const float cdi_luma_ = luma(xyz(cdi)), cgi_luma_ = luma(xyz(cgi));
-            const V3 cn = v3(csn.x, csn.y, csn.z);
-            const f2 c_sqrt_luma = mk2(fsqrt(cdi_luma_), fsqrt(cgi_luma_));
-            const float leeway = csn.w * 0.2f, inv_leeway = frcp(leeway);
-            f2 sum_l = splat2(0.0f), sum_ll = splat2(0.0f), sum_1 = splat2(0.0f);
-            for (int oy = -2; oy <= 2; oy++) {
-                for (int ox = -3; ox <= 2; ox++) {
-                    if (ox == -3 && oy == -2) continue;
-                    const int32_t gx = (int32_t)pos.x + ox, gy = (int32_t)pos.y + oy;
-                    if (gx < 0 || gy < 0 || gx >= (int32_t)a.width || gy >= (int32_t)a.height) continue;
-                    const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
-                    const float4 ssn = a.sn[at];
-                    if (ssn.w == 0.0f) continue;
-                    const float4 sdi = a.di_diff_curr_colors[at], sgi = a.gi_diff_curr_colors[at];
-                    const f2 l = (mk2(sdi.x, sgi.x) * 0.2126f + mk2(sdi.y, sgi.y) * 0.7152f) + mk2(sdi.z, sgi.z) * 0.0722f;
-                    const f2 d = c_sqrt_luma - sqrt2(l);
-                    const float diff = fabsf(ssn.w - csn.w);
-                    const float depth_weight = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
-                    const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
-                    const f2 w = exp_pair(-mk2(fabsf(d.x), fabsf(d.y))) * depth_weight * normal_weight;
-                    sum_l = sum_l + l * w; sum_ll = sum_ll + (l * l) * w; sum_1 = sum_1 + w;
-                }
-            }
-            float dv, gv;
-            { const float m1 = fdiv(sum_l.x, sum_1.x), m2 = fdiv(sum_ll.x, sum_1.x); dv = fabsf(m2 - m1 * m1) * 4.0f; }
-            { const float m1 = fdiv(sum_l.y, sum_1.y), m2 = fdiv(sum_ll.y, sum_1.y); gv = fabsf(m2 - m1 * m1) * 4.0f; }
-            reinterpret_cast<float*>(&di_out[center])[3] = fmax_(dv, 0.0f);
-            reinterpret_cast<float*>(&gi_out[center])[3] = fmax_(gv, 0.0f);
-            return;
-        }
-#endif
     } else {
         if (mine) { csn = a.sn[center]; cdi = a.di_diff_curr_colors[center]; cdi_m = a.di_diff_moments[center]; cgi = a.gi_diff_curr_colors[center]; cgi_m = a.gi_diff_moments[center]; }
         slow = mine && csn.w != 0.0f && !(cdi_m.x >= 4.0f);
