@@ -475,7 +475,11 @@ ST_D uint32_t gi_late_index(const KArgs& a, U2 pos) { return (pos.y >> 3) * ((a.
 // overwrites that slot with the frame's source reservoir, so the intermediate store is dropped.
 // With KArgs::gi_preview_late the launch follows k_gi_preview_both and serves only the pixels that one flagged.
 template <bool RESOLVE>
-ST_D void gi_preview_pixel(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, float4* out, uint32_t source, uint32_t reproject, U2 center_pos) {
+__global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint32_t nth, const float4* in, float4* out, uint32_t source,
+                                                              uint32_t reproject) {
+    U2 center_pos;
+    if (!resolve_gid(a, false, &center_pos) || !owns_pixel(a, center_pos)) return;
+    if (RESOLVE && a.gi_preview_late && ((a.gi_late_mask[gi_late_index(a, center_pos)] >> (threadIdx.x & 63u)) & 1ull) == 0ull) return;
     const uint32_t n = a.width * a.height;
     const uint32_t center_idx = screen_to_idx(a, center_pos);
     // The pixel's Hit (camera ray + both G-buffer texels decoded) is needed by a neighbour tap and by resolving; whether the
@@ -500,31 +504,6 @@ ST_D void gi_preview_pixel(const KArgs& a, uint32_t seed, uint32_t nth, const fl
     if (pass.keep_stored) main_ = gi_read(out, center_idx, n);
     const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, main_, source, reproject != 0u);
     if (reproject) denoise_reproject_finish(a, center_pos, diff, history, a.gi_diff_curr_colors, a.gi_diff_moments);
-}
-template <bool RESOLVE>
-__global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint32_t nth, const float4* in, float4* out, uint32_t source,
-                                                              uint32_t reproject) {
-    U2 center_pos;
-    if (!resolve_gid(a, false, &center_pos) || !owns_pixel(a, center_pos)) return;
-    if (RESOLVE && a.gi_preview_late && ((a.gi_late_mask[gi_late_index(a, center_pos)] >> (threadIdx.x & 63u)) & 1ull) == 0ull) return;
-    gi_preview_pixel<RESOLVE>(a, seed, nth, in, out, source, reproject, center_pos);
-}
-// The second-pass launch after k_gi_preview_both, COMPACTED: that kernel appended every tile with a flagged pixel to
-// KArgs::gi_late_list (one ballot + one atomic per flagged tile); a small persistent grid walks the list, one wave per listed
-// tile at a time, instead of 32,400 waves each loading a mask word to find — in the steady state, for 99 % of them — nothing to
-// do (measured: 17-20 us per frame for ~1 % of the tiles). Which wave serves a pixel changes, its arithmetic does not.
-constexpr uint32_t kLateListBlocks = 512u;
-__global__ ST_KERNEL_BOUNDS void k_gi_preview_late_list(const KArgs a, uint32_t seed, const float4* in, float4* out, uint32_t source, uint32_t reproject) {
-    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
-    const uint32_t count = a.gi_late_list[0], tiles_x = (a.width + 7u) >> 3;
-    for (uint32_t i = wave; i < count; i += n_waves) {
-        const uint32_t tile = a.gi_late_list[1u + i];
-        if (((a.gi_late_mask[tile] >> lane) & 1ull) == 0ull) continue;
-        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        const U2 center_pos = u2(tx * 8u + (lane & 7u), ty * 8u + (lane >> 3));
-        if (!owns_pixel(a, center_pos)) continue;
-        gi_preview_pixel<true>(a, seed, 1u, in, out, source, reproject, center_pos);
-    }
 }
 // Both preview passes, resolving and (if `reproject`) the GI half of denoise-reproject in one launch, for the pixels whose
 // SECOND pass draws no neighbour — nearly all of them once the reservoirs have history: such a pixel's second pass reads
@@ -553,11 +532,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview_both(const KArgs a, uint32_t seed,
         late = second.max_samples > 0u;
     }
     const unsigned long long flagged = __ballot(late), active = __ballot(true);
-    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) {
-        const uint32_t tile = gi_late_index(a, center_pos);
-        a.gi_late_mask[tile] = flagged;
-        if (flagged != 0ull && a.gi_late_list) a.gi_late_list[1u + atomicAdd(a.gi_late_list, 1u)] = tile;  // compaction: k_gi_preview_late_list walks these
-    }
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) a.gi_late_mask[gi_late_index(a, center_pos)] = flagged;
     if (late) return;
     const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, second.r, source, reproject != 0u);
     if (reproject) denoise_reproject_finish(a, center_pos, diff, history, a.gi_diff_curr_colors, a.gi_diff_moments);
@@ -567,11 +542,6 @@ void launch_gi_preview(const KArgs& a, uint32_t seed, uint32_t nth, const float4
 }
 void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, uint32_t source, bool reproject, hipStream_t s) {
     ST_LAUNCH(k_gi_preview<true>, false, s, a, seed, nth, in, a.gi_res[0], source, reproject ? 1u : 0u);
-}
-void launch_gi_preview_late_list(const KArgs& a, uint32_t seed, const float4* in, uint32_t source, bool reproject, hipStream_t s) {
-    const LaunchDims d = launch_dims(a, false);
-    const uint32_t blocks = d.blocks < kLateListBlocks ? d.blocks : kLateListBlocks;
-    if (blocks) ST_KLAUNCH(k_gi_preview_late_list, dim3(blocks), dim3(kBlockThreads), s, a, seed, in, a.gi_res[0], source, reproject ? 1u : 0u);
 }
 void launch_gi_preview_both(const KArgs& a, uint32_t seed, const float4* in, float4* mid, uint32_t source, bool reproject, hipStream_t s) {
     ST_LAUNCH(k_gi_preview_both, false, s, a, seed, in, mid, source, reproject ? 1u : 0u);

@@ -238,7 +238,6 @@ struct CameraState {
     void* slab = nullptr; size_t slab_bytes = 0;
     float4* plane[ST_BUF_COUNT + kInternalPlanes] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
     size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
-    uint32_t* late_list = nullptr;  // KArgs::gi_late_list: count + one slot per tile
     unsigned long long* tile_mask = nullptr; size_t tile_mask_tiles = 0;  // two arrays of one u64 per 8x8 tile (KArgs::tile_mask, KArgs::gi_late_mask)
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
@@ -497,7 +496,6 @@ struct Engine {
     uint64_t pass_mask = ~0ull;  // st_debug_set_pass_mask: which reference passes a render executes (parity tests run one launch at a time)
     bool overlap = true;    // two-stream, cross-frame software pipelining of the Image-mode pass graph (ST_NO_OVERLAP=1 disables)
     bool variance_in_reproject = true;  // ST_NO_VARIANCE_IN_REPROJECT=1: estimate_variance as its own full-screen pass
-    bool late_list = true;  // ST_NO_LATE_LIST=1: no compaction of the tiles the second preview pass still has to serve
     bool preview_both = true;  // ST_NO_PREVIEW_BOTH=1: the two GI preview passes as two full-screen launches
     // The lean frame (KArgs::lean, st_types.h kLean*; fast build + whole pass graph + Image-family mode with the denoiser):
     // planes nothing reads again are not stored — velocity and the encoded surface map (primary visibility), both diffuse
@@ -551,7 +549,6 @@ struct Engine {
 #endif
         if (const char* k = getenv("ST_NO_FUSE_COMPOSE")) fuse_compose = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_PREVIEW_BOTH")) preview_both = atoi(k) == 0;
-        if (const char* k = getenv("ST_NO_LATE_LIST")) late_list = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_VARIANCE_IN_REPROJECT")) variance_in_reproject = atoi(k) == 0;
         if (const char* ns = getenv("ST_NO_STAGING")) staging.enabled = atoi(ns) == 0;
         if (const char* nd = getenv("ST_NO_DOUBLE_BUFFER")) double_buffer = atoi(nd) == 0;
@@ -587,8 +584,6 @@ struct Engine {
         if (c.counters) (void)hipFree(c.counters);
         if (c.tile_mask) (void)hipFree(c.tile_mask);
         c.tile_mask = nullptr;
-        if (c.late_list) (void)hipFree(c.late_list);
-        c.late_list = nullptr;
         c.slab = nullptr; c.counters = nullptr;
         if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
         for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
@@ -1063,8 +1058,6 @@ struct Engine {
             if (hipMalloc(reinterpret_cast<void**>(&c.tile_mask), 2 * tiles * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); c.tile_mask = nullptr; release_camera(c); return fail(ST_ERR_HIP, "hipMalloc(camera tile mask) failed"); }
             ST_HIP(hipMemset(c.tile_mask, 0, 2 * tiles * sizeof(unsigned long long)));  // [0, tiles): variance's, [tiles, 2 tiles): the GI preview's
             c.tile_mask_tiles = tiles;
-            if (hipMalloc(reinterpret_cast<void**>(&c.late_list), (tiles + 1) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c.late_list = nullptr; release_camera(c); return fail(ST_ERR_HIP, "hipMalloc(camera late list) failed"); }
-            ST_HIP(hipMemset(c.late_list, 0, (tiles + 1) * sizeof(uint32_t)));
         }
         memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
         ST_HIP(hipDeviceSynchronize());  // the clears run on the null stream; renders may use any stream
@@ -1319,16 +1312,11 @@ struct Engine {
                 if (gi_preview_both) {
                     // one launch group of two kernels = one set of pass bits
                     const uint64_t group = ST_PASS_GI_PREVIEW_0 | ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING | (denoise ? (uint64_t)ST_PASS_DENOISE_REPROJECT_GI : 0ull);
-                    const bool listed = late_list && c.late_list != nullptr;  // ST_NO_LATE_LIST=1: the second-pass launch visits every tile again
-                    a.gi_late_list = listed ? c.late_list : nullptr;
-                    if (listed && (group & pass_mask) == group) (void)hipMemsetAsync(c.late_list, 0, sizeof(uint32_t), cur);  // the list's counter (an error surfaces at the hipGetLastError below)
                     run(denoise ? KS_GI_PREVIEW_BOTH : KS_GI_PREVIEW_BOTH_NO_REPROJECT, group, [&] { L.launch_gi_preview_both(a, pseed, gi_source == 0 ? a.gi_res[1] : a.gi_res[2], a.gi_res[3], gi_source, denoise, cur); });
                     a.gi_preview_late = 1u;
                     a.gi_mid_src = (a.lean & kLeanGiMid) ? (gi_source == 0 ? a.gi_res[1] : a.gi_res[2]) : nullptr;
-                    run(KS_GI_PREVIEW_LATE, group, [&] {
-                        if (listed) L.launch_gi_preview_late_list(a, pseed, a.gi_res[3], gi_source, denoise, cur);
-                        else L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, denoise, cur); });
-                    a.gi_preview_late = 0u; a.gi_mid_src = nullptr; a.gi_late_list = nullptr;
+                    run(KS_GI_PREVIEW_LATE, group, [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, denoise, cur); });
+                    a.gi_preview_late = 0u; a.gi_mid_src = nullptr;
                     if (denoise) gi_reprojected = true;
                 } else if (fuse) {
                     if (denoise) { run(KS_GI_PREVIEW_RESOLVE_REPROJECT, ST_PASS_GI_PREVIEW_1 | ST_PASS_GI_RESOLVING | ST_PASS_DENOISE_REPROJECT_GI, [&] { L.launch_gi_preview_resolve(a, pseed, 1u, a.gi_res[3], gi_source, true, cur); }); gi_reprojected = true; }

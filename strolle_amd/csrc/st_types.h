@@ -72,9 +72,6 @@ struct KArgs {
     // k_gi.hip k_gi_preview_both: pixels whose second preview pass resamples, per 8x8 tile (bit = lane); gi_preview_late: the
     // second-pass launch serves flagged pixels only
     unsigned long long* gi_late_mask; uint32_t gi_preview_late;
-    // compaction of the flagged tiles: [0] = how many, [1 ..] = their tile indices, appended by k_gi_preview_both (one ballot + one atomic per
-    // flagged tile); the second-pass launch then walks the list with a small persistent grid instead of visiting every tile of the frame
-    uint32_t* gi_late_list;
     uint32_t skip_dead_scratch;  // the fused DI spatial launch keeps its pick / trace records in registers only: resolving, denoise-reproject and the a-trous chain rewrite the three scratch planes later in this frame
     uint32_t gi_skip_history_copy;  // gi_resolving leaves GI_RESERVOIRS_0 alone: the engine swaps plane pointers instead (st_engine.cpp gi_aliased)
     // The lean frame (fast build, whole pass graph, Image{denoise}; st_engine.cpp `lean_frame`): stores that nothing reads —
