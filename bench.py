@@ -452,11 +452,12 @@ def main():
         engine.present_ready(cam, host8[(args.steps - 1) & 1].data_ptr(), wait=True)   # the last frame has to arrive too
         torch.cuda.synchronize()
         el_p = time.perf_counter() - t0
+        arrived = bool((host8[(args.steps - 1) & 1] == dev8[(args.steps - 1) & 1].cpu()).all())   # what landed on the host is the frame that was composed
         engine.set_output_format(cam, OutputFormat.RGBA32F)
         extras["ms_per_step_with_present"] = round(el_p / args.steps * 1e3, 4)
         extras["present"] = {"what": "same K steps composed as RGBA8 sRGB into two alternating device frames, st_camera_present_copy to two page-locked host frames, the previous frame's copy polled before the next tick (one frame of latency, no stream join)",
                              "bytes_per_frame": width * height * 4, "polls_that_found_the_copy_pending": waited[0], "polls_note": "the host enqueues frames faster than the GPU renders them; a pending poll blocks on that ONE copy (never on the render stream), which paces the host one frame ahead",
-                             "host_frame_nonzero": bool(host8[(args.steps - 1) & 1].any())}
+                             "host_frame_nonzero": bool(host8[(args.steps - 1) & 1].any()), "host_frame_equals_device_frame": arrived}
         del dev8, host8
     strong = {}
     if not args.no_extras and world > 1:

@@ -130,11 +130,11 @@ _SCENES = {"cornell": (scenes.build_cornell, scenes.cornell_camera), "dungeon": 
 _runs = {}
 
 
-def _run(scene, size, plan):
+def _run(scene, size, plan, moving=False):
     """One oracle run of max(plan) frames; frame f (the ENGINE's frame number, which starts at 1 and decides the GI schedule:
     f % 6 < 4 tracing — even f samples, odd f resamples spatially —, else validation) is checked as plan[f] says ("launches" /
     "whole" / "whole_keep"); other frames only advance the oracle. Returns {"launches": [...], "whole": [...]} of report rows; cached per (scene, size)."""
-    key = (scene, size)
+    key = (scene, size, moving)
     if key in _runs:
         return _runs[key]
     torch = _torch()
@@ -166,6 +166,13 @@ def _run(scene, size, plan):
         return {b: orac.read_buffer(co, b) for b in FLOAT_BUFFERS}
 
     for frame in range(1, max(plan) + 1):   # the engine numbers frames from 1 (strolle/src/lib.rs:152)
+        if moving:   # what bench.py's `moving` region does: the light of cornell.rs:82-93 (1/60 s per frame), the camera on an orbit
+            import math
+            from strolle_amd import Light
+            t = frame / 60.0
+            desc = scenes.camera_for(size, (3.2 * math.sin(0.1 * t), 1.0, 3.2 * math.cos(0.1 * t)), (0.0, 1.0, 0.0), CameraMode.IMAGE)
+            for e in (prod, orac):
+                e.insert_light(1, Light.point((math.sin(t) / 2.0, 1.5, math.cos(t) / 2.0), 0.15, (50.0 / (4.0 * math.pi),) * 3, 20.0))
         for e, c in ((prod, cp), (orac, co)):
             e.update_camera(c, desc)
         prod.tick(); orac.tick()
@@ -223,7 +230,7 @@ def _run(scene, size, plan):
             report.setdefault("state", []).append({"frame": frame, "gi_m_median": float(np.median(m[lit])) if lit.any() else None,
                                                   "history_median": float(np.median(want[Buffer.DI_DIFF_MOMENTS_A if frame % 2 == 0 else Buffer.DI_DIFF_MOMENTS_B].reshape(-1, 4)[:, 0][lit])) if lit.any() else None})
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"fast_steady_{scene}_{size[0]}x{size[1]}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"fast_steady_{scene}{'_moving' if moving else ''}_{size[0]}x{size[1]}.json"), "w") as f:
         json.dump({"scene": scene, "size": size, "plan": {str(k): v for k, v in plan.items()}, "rtol": RTOL, "atol": ATOL,
                    "launch_rows_with_outliers": sorted(report["launches"], key=lambda r: -r["bad_fraction"])[:60],
                    "whole_frame_rows": report["whole"], "state": report.get("state", [])}, f, indent=1)
@@ -237,6 +244,7 @@ def _run(scene, size, plan):
 PLAN_1080P = {19: "launches", 20: "launches", 21: "whole", 22: "whole", 23: "launches", 24: "whole", 25: "whole_keep"}
 PLAN_DUNGEON_1080P = {13: "whole", 14: "whole", 15: "whole_keep", 17: "whole"}   # odd tracing, even tracing, odd tracing, validation
 PLAN_DUNGEON_4K = {8: "whole", 9: "whole", 10: "whole"}                           # even tracing, odd tracing, validation
+PLAN_MOVING = {13: "whole", 14: "whole", 15: "launches", 16: "whole", 17: "whole_keep"}   # odd tracing, even tracing, odd tracing, validation, validation
 
 
 def _check_launch_rows(rows, what):
@@ -281,3 +289,14 @@ def test_fast_whole_frame_single_step_dungeon_1080p():
 def test_fast_whole_frame_single_step_dungeon_4k():
     rep = _run("dungeon", (3840, 2160), PLAN_DUNGEON_4K)
     _check_whole_rows(rep["whole"], "dungeon 4K")
+
+
+def test_fast_whole_frames_with_light_and_camera_moving():
+    """The state bench.py's `moving` region times (`ms_per_step_moving`): the point light on cornell.rs's orbit and the camera
+    circling the box, both updated before every tick. Reprojection follows real motion, shadow edges reset the DI history, the
+    preview passes draw neighbours again and the lean frame's rebuilt first-pass records are read; whole unmasked frames of
+    every GI schedule (and one launch-by-launch frame) against the oracle, Cornell 1280x720."""
+    rep = _run("cornell", (1280, 720), PLAN_MOVING, moving=True)
+    assert {(r["frame"], r["kind"]) for r in rep["whole"]} == {(13, "whole"), (14, "whole"), (16, "whole"), (17, "whole_keep")}
+    _check_whole_rows(rep["whole"], "cornell 720p moving")
+    _check_launch_rows(rep["launches"], "cornell 720p moving")
