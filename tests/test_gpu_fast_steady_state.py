@@ -89,7 +89,13 @@ def _bits(x):
     return x.view(np.uint32)
 
 
-def _bad_fraction(got, want, chunk=1 << 23):
+# The velocity map is a DIFFERENCE of two screen positions (prim_raster.rs:114-127: current minus previous, each ~ 10^3 pixels): under
+# motion it is a sub-pixel number whose absolute error is that of its operands, so it gets an absolute tolerance in pixels (what
+# consumes it, the reprojection map, holds positions and is compared with the ordinary relative tolerance).
+VELOCITY_ATOL_PX = 1e-3
+
+
+def _bad_fraction(got, want, chunk=1 << 23, atol=ATOL):
     """Fraction of 32-bit lanes outside the per-lane tolerance. Bit-equal stretches cost one compare; the float test runs on
     the lanes that differ, a chunk at a time (a 4K reservoir plane is 133 M lanes)."""
     gb, wb = _bits(got), _bits(want)
@@ -97,7 +103,7 @@ def _bad_fraction(got, want, chunk=1 << 23):
     for i in range(0, got.size, chunk):
         ne = gb[i:i + chunk] != wb[i:i + chunk]
         if ne.any():
-            bad += int(lanes_outside_tolerance(got[i:i + chunk][ne], want[i:i + chunk][ne]).sum())
+            bad += int(lanes_outside_tolerance(got[i:i + chunk][ne], want[i:i + chunk][ne], atol=atol).sum())
     return bad / got.size
 
 
@@ -114,7 +120,7 @@ def _bad_fractions(got, want, planes):
     """{plane: bad fraction} with the planes compared on a thread pool (numpy releases the GIL in these loops)."""
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
-        futures = {b: pool.submit(_bad_fraction, got[b], want[b]) for b in planes}
+        futures = {b: pool.submit(_bad_fraction, got[b], want[b], 1 << 23, VELOCITY_ATOL_PX if b == Buffer.VELOCITY_MAP else ATOL) for b in planes}
         return {b: f.result() for b, f in futures.items()}
 
 
