@@ -159,9 +159,14 @@ int st_camera_present_ready(StEngine* e, StHandle camera, const void* dst_host, 
  * while instances only move (same triangles, same materials, same Blend flags) and recomputes its boxes bottom-up,
  * which costs a fraction of a rebuild; traversal stays correct, `used_memory` and the tree's quality follow the old
  * topology until something other than a transform changes (or the mode is set again), which rebuilds. */
-enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1 };
+enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
+                    ST_BVH_REFIT_DEVICE = 2 /* as ST_BVH_REFIT, but the boxes are recomputed ON THE DEVICE: st_tick sends the moved triangles'
+                                               hit-test records and bounds (80 B each) instead of refitting the stream on the host and
+                                               re-sending all of it; two small kernels patch the leaf entries and refit the boxes bottom-up.
+                                               Same bits as ST_BVH_REFIT. */ };
 int st_set_bvh_refresh(StEngine* e, int mode);
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits);
+int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits);   /* ticks whose boxes were recomputed by k_bvh.hip (ST_BVH_REFIT_DEVICE) */
 /* Depth check of the last BVH build: the longest chain of internal nodes (= the most far-child pointers one traversal can
  * have pending) against the per-ray stack of the kernels (24 entries, strolle-gpu/src/lib.rs:76). The reference writes past
  * its stack array when a tree is deeper; this library drops the push and says so once on stderr — a scene for which

@@ -282,6 +282,7 @@ class _Binding:
         self.set_bvh_refresh = fn("set_bvh_refresh", [vp, i32]); self.debug_bvh_refits = fn("debug_bvh_refits", [vp, P(u64), P(u64)])
         if has_device:
             self.debug_bvh_depth = fn("debug_bvh_depth", [vp, P(u32), P(u32)])
+            self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
@@ -436,9 +437,15 @@ class EngineBase:
         self._check(self._b.debug_world(self._h, C.byref(lc), C.byref(fr)))
         return lc.value, fr.value
 
-    def set_bvh_refresh(self, refit: bool):
-        """st_set_bvh_refresh: False = rebuild on every change (the reference's behaviour), True = refit while instances only move."""
-        self._check(self._b.set_bvh_refresh(self._h, 1 if refit else 0))
+    def set_bvh_refresh(self, refit):
+        """st_set_bvh_refresh: False / 0 = rebuild on every change (the reference's behaviour), True / 1 = refit while instances only
+        move, 2 = the same with the boxes recomputed on the device (ST_BVH_REFIT_DEVICE; libstrolle_hip.so only)."""
+        self._check(self._b.set_bvh_refresh(self._h, int(refit)))
+
+    def bvh_device_refits(self) -> int:
+        out = C.c_uint64()
+        self._check(self._b.debug_bvh_device_refits(self._h, C.byref(out)))
+        return out.value
 
     def bvh_refits(self):
         """(rebuilds, refits) so far."""

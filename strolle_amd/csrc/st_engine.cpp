@@ -319,7 +319,7 @@ struct Engine {
     std::vector<float4> instance_xforms; std::vector<uint32_t> xslot_free;
     std::map<uint64_t, std::pair<size_t, size_t>> instance_triangles; SlotRanges triangle_free;
     std::vector<HostTriangle> triangles; std::vector<BuildPrim> prims; std::vector<uint8_t> prim_alive;
-    std::vector<float4> tri_geo, tri_attr, bvh_stream, bvh_upload_;
+    std::vector<float4> tri_geo, tri_attr, tri_bounds, bvh_stream, bvh_upload_;  // tri_bounds: (lo, hi) per triangle slot (device refit)
     BvhBuild bvh;
     bool scene_uploaded = false;
     // BVH refresh policy (st_set_bvh_refresh). Refit: while the set of (triangle slot, material) pairs and the Blend flags
@@ -328,6 +328,11 @@ struct Engine {
     bool have_topology = false; uint64_t topology_signature = 0;
     std::vector<uint32_t> internal_positions;  // stream offsets of the internal nodes, ascending (parents before children)
     uint64_t refits = 0, rebuilds = 0;
+    uint64_t device_refits = 0;    // ticks whose boxes were recomputed on the device
+    uint64_t tree_version = 0;     // bumped by every rebuild (ST_BVH_REFIT_DEVICE: a scene copy whose arrays are of this version can be refitted in place)
+    bool host_stream_stale = false;  // device refits happened since bvh_stream's boxes were last recomputed (debug reads and full uploads refit it first)
+    std::vector<float4> readback_; uint32_t live_bvh_texels = 0;  // st_debug_read_scene(6)
+    std::vector<uint32_t> entry_of_tri_, parent_, runs_;  // host images of the device refit's index arrays (index_device_tree)
     // Deepest chain of internal nodes in the uploaded stream = the most entries a traversal can have pending (every internal
     // node on the path may push its far child). The kernels' per-lane stack holds kBvhStackSize entries (strolle-gpu/src/lib.rs:76;
     // the reference indexes past the end there, here a push beyond the end is dropped): a deeper tree is reported, not hidden.
@@ -376,6 +381,26 @@ struct Engine {
             }
         }
         device_bvh_len = (uint32_t)(4 * entries);
+    }
+    // index arrays of the device refit, from the device form of the stream (bvh_upload_, entries of four texels)
+    void index_device_tree() {
+        const uint32_t n_entries = device_bvh_len / 4u;
+        entry_of_tri_.assign(tri_geo.size() / 3u, 0xffffffffu);
+        parent_.assign(std::max<uint32_t>(n_entries, 1u), 0xffffffffu);
+        runs_.clear();
+        bool in_run = false;
+        for (uint32_t k = 0; k < n_entries; k++) {
+            const float4* e = &bvh_upload_[4u * (size_t)k];
+            if (f2b(e[0].w) == 0u) {
+                parent_[k + 1u] = (k << 1) | 0u;
+                parent_[f2b(e[1].w) / 64u] = (k << 1) | 1u;
+                in_run = false;
+            } else {
+                if (!in_run) runs_.push_back(k);
+                entry_of_tri_[f2b(e[0].y)] = k;
+                in_run = (f2b(e[0].x) & 1u) != 0u;
+            }
+        }
     }
     // OPT-IN (a build with -DST_WIDE_NODES=1 run with ST_WIDE_NODES=1; measured slower, st_device.h trace_any_wide says by how much):
     // 4-wide nodes for the ANY-HIT rays of the fast build: the binary tree's internal nodes collapsed
@@ -475,6 +500,11 @@ struct Engine {
     // (Updating in place would have to wait for the previous frame, and the next frame's primary rays with it.)
     struct SceneSet {
         DeviceArray bvh, tri_attr, xforms, materials, base_packed;
+        // ST_BVH_REFIT_DEVICE: what k_bvh.hip needs beside the stream — per triangle slot the hit-test record, the bounds and the
+        // device entry that holds it; per entry its parent (entry << 1 | child slot); the leaf runs; an arrival counter per entry.
+        // tree_version says which build of the tree these (and the stream's topology) belong to.
+        DeviceArray tri_geo, tri_bounds, entry_of_tri, parent, runs, arrived;
+        uint64_t tree_version = 0; uint32_t n_runs = 0, n_entries = 0;
         size_t dirty_lo = SIZE_MAX, dirty_hi = 0; bool tri_full = true;  // what this copy lacks of the host's triangle arrays
         hipEvent_t free_ev = nullptr; bool busy = false;  // busy: frames reading this copy were enqueued since it was written; free_ev ends the last
         bool valid = false;
@@ -569,7 +599,7 @@ struct Engine {
         for (DeviceArray* d : {&d_byte_luts, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
         for (LightSet& l : light_sets) { l.buf.release(); if (l.free_ev) (void)hipEventDestroy(l.free_ev); }
         for (SceneSet& t : sets) {
-            for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed}) d->release();
+            for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed, &t.tri_geo, &t.tri_bounds, &t.entry_of_tri, &t.parent, &t.runs, &t.arrived}) d->release();
             if (t.free_ev) (void)hipEventDestroy(t.free_ev);
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -742,6 +772,7 @@ struct Engine {
         bp.bounds = Aabb(); bp.bounds.grow(p[0]); bp.bounds.grow(p[1]); bp.bounds.grow(p[2]);
         prims[slot] = bp; prim_alive[slot] = 1;
         tri_geo[3 * slot] = f4(p[0], 0.0f); tri_geo[3 * slot + 1] = f4(p[1] - p[0], 0.0f); tri_geo[3 * slot + 2] = f4(p[2] - p[0], 0.0f);
+        tri_bounds[2 * slot] = f4(bp.bounds.lo, 0.0f); tri_bounds[2 * slot + 1] = f4(bp.bounds.hi, 0.0f);
         tri_attr[4 * slot] = f4(n[0], t.uvs[0][0]); tri_attr[4 * slot + 1] = f4(n[1], t.uvs[0][1]); tri_attr[4 * slot + 2] = f4(n[2], t.uvs[1][0]);
         tri_attr[4 * slot + 3] = make_float4(t.uvs[1][1], t.uvs[2][0], t.uvs[2][1], b2f(inst.xslot));
     }
@@ -775,7 +806,7 @@ struct Engine {
             if (have != instance_triangles.end()) { b = have->second.first; e = have->second.second; }
             else if (!triangle_free.take(count, &b, &e)) {
                 b = triangles.size(); e = b + count;
-                triangles.resize(e); prims.resize(e); prim_alive.resize(e, 0); tri_geo.resize(3 * e); tri_attr.resize(4 * e);
+                triangles.resize(e); prims.resize(e); prim_alive.resize(e, 0); tri_geo.resize(3 * e); tri_attr.resize(4 * e); tri_bounds.resize(2 * e);
                 for (SceneSet& t : sets) t.tri_full = true;
             }
             jobs.push_back({&mesh->second, &inst, mat->second, b, count});
@@ -855,6 +886,7 @@ struct Engine {
     }
     // One thread: at 134 k triangles the sweep is about a millisecond, less than starting a worker pool for it would buy back.
     void refit_stream() { refit_span(0, bvh_stream.size()); }
+    bool device_refit_possible() const { return bvh_refresh_mode == ST_BVH_REFIT_DEVICE && has_device && !wide_nodes; }
 
     // ---- tick (lib.rs:301-395)
     int tick(hipStream_t stream) {
@@ -873,9 +905,12 @@ struct Engine {
             const auto t1 = now();
             std::vector<uint8_t> blend(materials.size());
             for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
-            const uint64_t signature = bvh_refresh_mode == ST_BVH_REFIT ? topology_of(blend) : 0;
-            if (bvh_refresh_mode == ST_BVH_REFIT && have_topology && signature == topology_signature) {
-                refit_stream();
+            const bool refitting = bvh_refresh_mode != ST_BVH_REBUILD;
+            const uint64_t signature = refitting ? topology_of(blend) : 0;
+            if (refitting && have_topology && signature == topology_signature) {
+                // ST_BVH_REFIT_DEVICE: the boxes are recomputed on the device from the moved triangles' bounds (k_bvh.hip); the host's
+                // copy of the stream is brought up to date only when something reads it
+                if (device_refit_possible()) host_stream_stale = true; else refit_stream();
                 refits++;
                 if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, refit %.2f ms (%zu internal nodes)\n", ms(t0, t1), ms(t1, now()), internal_positions.size());
             } else {
@@ -886,10 +921,10 @@ struct Engine {
                 const auto t3 = now();
                 bvh.flatten(blend, bvh_stream);
                 const auto t4 = now();
-                rebuilds++;
+                rebuilds++; tree_version++; host_stream_stale = false;
                 mark_internal_starts(); measure_stack_need();
                 have_topology = false;
-                if (bvh_refresh_mode == ST_BVH_REFIT) { index_stream(); topology_signature = signature; have_topology = true; }
+                if (refitting) { index_stream(); topology_signature = signature; have_topology = true; }
                 if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles, %zu reused)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size(), bvh.reused_primitives());
             }
             scene_changed = true;
@@ -938,11 +973,36 @@ struct Engine {
                     if (sets[target].busy) { ST_HIP(hipStreamWaitEvent(copy_stream, sets[target].free_ev, 0)); sets[target].busy = false; }
                 } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
                 SceneSet& t = sets[target];
-                expand_stream();
-                append_wide_nodes();
-                // traversal pointers are 32-bit BYTE offsets into the device stream (64 B per entry) and stack slots hold entry numbers
-                if ((size_t)device_bvh_len * sizeof(float4) > 0xffffffffull) return fail(ST_ERR_INVALID_ARGUMENT, "the BVH stream exceeds 4 GiB (2^26 entries): traversal pointers are 32-bit byte offsets");
-                if ((rc = t.bvh.upload(bvh_upload_.data(), bvh_upload_.size() * sizeof(float4), up, staging, flag))) return rc;
+                if (device_refit_possible() && t.valid && !t.tri_full && t.tree_version == tree_version && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4)) {
+                    // This copy holds the current tree; only boxes and moved triangles are behind. Send the records and bounds of the
+                    // triangle slots baked since it was written and let the device patch its leaf entries and refit its boxes.
+                    if (t.dirty_lo < t.dirty_hi) {
+                        if ((rc = t.tri_geo.upload_range(tri_geo.data(), 3 * t.dirty_lo * sizeof(float4), 3 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
+                        if ((rc = t.tri_bounds.upload_range(tri_bounds.data(), 2 * t.dirty_lo * sizeof(float4), 2 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
+                        L.launch_bvh_patch_leaves(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_geo.ptr), static_cast<const uint32_t*>(t.entry_of_tri.ptr), (uint32_t)t.dirty_lo, (uint32_t)t.dirty_hi, up);
+                    }
+                    ST_HIP(hipMemsetAsync(t.arrived.ptr, 0, (size_t)t.n_entries * sizeof(uint32_t), up));
+                    L.launch_bvh_refit(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_bounds.ptr), static_cast<const uint32_t*>(t.parent.ptr), static_cast<const uint32_t*>(t.runs.ptr), t.n_runs,
+                                       static_cast<uint32_t*>(t.arrived.ptr), up);
+                    device_refits++;
+                } else {
+                    if (host_stream_stale) { refit_stream(); host_stream_stale = false; }
+                    expand_stream();
+                    append_wide_nodes();
+                    // traversal pointers are 32-bit BYTE offsets into the device stream (64 B per entry) and stack slots hold entry numbers
+                    if ((size_t)device_bvh_len * sizeof(float4) > 0xffffffffull) return fail(ST_ERR_INVALID_ARGUMENT, "the BVH stream exceeds 4 GiB (2^26 entries): traversal pointers are 32-bit byte offsets");
+                    if ((rc = t.bvh.upload(bvh_upload_.data(), bvh_upload_.size() * sizeof(float4), up, staging, flag))) return rc;
+                    if (device_refit_possible()) {  // what the device refit of later ticks needs beside the stream
+                        index_device_tree();
+                        if ((rc = t.tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), up, staging, flag))) return rc;
+                        if ((rc = t.tri_bounds.upload(tri_bounds.data(), tri_bounds.size() * sizeof(float4), up, staging, flag))) return rc;
+                        if ((rc = t.entry_of_tri.upload(entry_of_tri_.data(), entry_of_tri_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                        if ((rc = t.parent.upload(parent_.data(), parent_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                        if (!runs_.empty() && (rc = t.runs.upload(runs_.data(), runs_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                        if ((rc = t.arrived.upload(parent_.data(), parent_.size() * sizeof(uint32_t), up, staging, flag))) return rc;  // sized like `parent`; zeroed before every refit
+                        t.tree_version = tree_version; t.n_runs = (uint32_t)runs_.size(); t.n_entries = (uint32_t)parent_.size();
+                    }
+                }
                 // attribute records: whole the first time or after they grew, otherwise only the slots baked since this copy was written
                 const bool partial = t.valid && !t.tri_full && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
                 if (!partial) {
@@ -955,7 +1015,7 @@ struct Engine {
                 if ((rc = t.materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), up, staging, flag))) return rc;
                 if ((rc = t.base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), up, staging, flag))) return rc;
                 if (other_copy) copied_now = true;
-                live = target;
+                live = target; live_bvh_texels = device_bvh_len;
                 scene_uploaded = true;
                 scene_changed = !other_copy;  // in-place uploads count as work on the caller's stream below
             }
@@ -1799,6 +1859,7 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
     ST_REQUIRE(e, "null engine");
     Engine* en = E(e);
     const void* p; size_t bytes;
+    if ((what == 0 || what == 4 || what == 5) && en->host_stream_stale) { en->refit_stream(); en->host_stream_stale = false; }  // device refits since the host copy was current
     switch (what) {
         case 0: p = en->bvh_stream.data(); bytes = en->bvh_stream.size() * sizeof(float4); break;
         case 1: p = en->triangles.data(); bytes = en->triangles.size() * sizeof(HostTriangle); break;
@@ -1810,6 +1871,14 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
             en->expand_stream(); en->append_wide_nodes();
             en->wide_nodes = was;
             p = en->bvh_upload_.data() + en->device_bvh_len; bytes = (size_t)en->device_wide_len * sizeof(float4); break;
+        }
+        case 6: {  // the device stream as it is on the device right now (the live copy): what a device refit left there
+            if (!en->has_device || !en->scene_uploaded) return fail(ST_ERR_NO_DEVICE, "no device copy of the scene");
+            const size_t n = en->sets[en->live].bvh.capacity ? (size_t)en->live_bvh_texels : 0;
+            en->readback_.resize(n);
+            ST_HIP(hipSetDevice(en->device)); ST_HIP(hipDeviceSynchronize());
+            if (n) ST_HIP(hipMemcpy(en->readback_.data(), en->sets[en->live].bvh.ptr, n * sizeof(float4), hipMemcpyDeviceToHost));
+            p = en->readback_.data(); bytes = n * sizeof(float4); break;
         }
         default: return fail(ST_ERR_INVALID_ARGUMENT, "unknown scene buffer");
     }
@@ -1827,7 +1896,7 @@ int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame) {
 
 int st_set_bvh_refresh(StEngine* e, int mode) {
     ST_REQUIRE(e, "null engine");
-    ST_REQUIRE(mode == ST_BVH_REBUILD || mode == ST_BVH_REFIT, "unknown refresh mode");
+    ST_REQUIRE(mode == ST_BVH_REBUILD || mode == ST_BVH_REFIT || mode == ST_BVH_REFIT_DEVICE, "unknown refresh mode");
     Engine* en = E(e);
     if (en->bvh_refresh_mode != mode) { en->bvh_refresh_mode = mode; en->have_topology = false; }
     return ST_OK;
@@ -1840,6 +1909,11 @@ int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* 
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits) {
     ST_REQUIRE(e && rebuilds && refits, "null argument");
     *rebuilds = E(e)->rebuilds; *refits = E(e)->refits;
+    return ST_OK;
+}
+int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits) {
+    ST_REQUIRE(e && device_refits, "null argument");
+    *device_refits = E(e)->device_refits;
     return ST_OK;
 }
 int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused) {

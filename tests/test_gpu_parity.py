@@ -765,17 +765,22 @@ def test_output_formats_bit_exact(fmt):
 
 
 @pytest.mark.gpu
-def test_bvh_refit_mode_renders_bit_exact():
+@pytest.mark.parametrize("mode", [1, 2], ids=["host", "device"])
+def test_bvh_refit_mode_renders_bit_exact(mode):
     """ST_BVH_REFIT with instances moving every frame: the tree of frame 0 is refitted, never rebuilt, and only the moved
     triangles travel to the device — heatmap integers, every Image-mode plane and the frame must still equal the oracle's,
-    which refits its own tree. A removal then forces a rebuild, after which refitting resumes."""
+    which refits its own tree. A removal then forces a rebuild, after which refitting resumes.
+    mode 2 = ST_BVH_REFIT_DEVICE: the boxes are recomputed by k_bvh.hip from the moved triangles' bounds (the host sends 80 B per
+    moved triangle instead of the whole stream); after every frame the stream read back FROM THE DEVICE must equal, bit for bit,
+    the device form of the host's own refit — which equals the oracle's."""
     torch = _torch()
     import math
     from strolle_amd import Instance
     size = (144, 96)
     prod, orac = Engine(device=0, exact=True), OracleEngine()
     for e in (prod, orac):
-        scenes.build_random_soup(e, 2400, seed=23, n_lights=3); e.set_seed(4); e.set_bvh_refresh(True)
+        scenes.build_random_soup(e, 2400, seed=23, n_lights=3); e.set_seed(4)
+    prod.set_bvh_refresh(mode); orac.set_bvh_refresh(True)
     desc = scenes.cornell_camera(size, CameraMode.IMAGE)
     heat = scenes.cornell_camera(size, CameraMode.BVH_HEATMAP)
     cp, co = prod.create_camera(desc), orac.create_camera(desc)
@@ -800,7 +805,11 @@ def test_bvh_refit_mode_renders_bit_exact():
         assert np.array_equal(prod.read_buffer(hp, Buffer.DBG_USED_MEMORY), orac.read_buffer(ho, Buffer.DBG_USED_MEMORY)), f"refit frame {frame}: used_memory"
         _compare_all(prod, orac, cp, co, frame)
         assert_bits_equal(out.cpu().numpy(), ref, f"refit frame {frame}")
+        if mode == 2:
+            assert_bits_equal(prod.read_scene(6), prod.read_scene(4), f"refit frame {frame}: the stream on the device vs the host's refit")
+            assert_bits_equal(prod.read_scene(0), orac.read_scene(0), f"refit frame {frame}: the host's (lazily refitted) stream vs the oracle's")
     assert prod.bvh_refits() == orac.bvh_refits() == (2, 6)
+    assert prod.bvh_device_refits() == (4 if mode == 2 else 0)   # refit ticks whose target copy already held the tree (the first refit after a build goes to the other copy in full)
 
 
 def _cornell_glb() -> bytes:
