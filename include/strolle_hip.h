@@ -162,8 +162,8 @@ int st_camera_present_ready(StEngine* e, StHandle camera, const void* dst_host, 
 enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                     ST_BVH_REFIT_DEVICE = 2 /* as ST_BVH_REFIT, but the boxes are recomputed ON THE DEVICE: st_tick sends the moved triangles'
                                                hit-test records and bounds (80 B each) instead of refitting the stream on the host and
-                                               re-sending all of it; two small kernels patch the leaf entries and refit the boxes bottom-up.
-                                               Same bits as ST_BVH_REFIT. */ };
+                                               re-sending all of it; k_bvh.hip patches the leaf entries and refits the boxes bottom-up (one launch per
+                                               level of 512-leaf subtrees: two at 208 k triangles). Same bits as ST_BVH_REFIT. */ };
 int st_set_bvh_refresh(StEngine* e, int mode);
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits);
 int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits);   /* ticks whose boxes were recomputed by k_bvh.hip (ST_BVH_REFIT_DEVICE) */

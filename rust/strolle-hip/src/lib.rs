@@ -331,9 +331,10 @@ where
         check(unsafe { ffi::st_engine_set_arithmetic(self.raw, exact as i32) });
     }
 
-    /// Not part of the reference's API: refit the BVH instead of rebuilding it while instances only move.
+    /// Not part of the reference's API: refit the BVH instead of rebuilding it while instances only move — on the device
+    /// (ST_BVH_REFIT_DEVICE = 2: st_tick sends the moved triangles only; same bits as the host refit).
     pub fn set_bvh_refit(&mut self, refit: bool) {
-        check(unsafe { ffi::st_set_bvh_refresh(self.raw, refit as i32) });
+        check(unsafe { ffi::st_set_bvh_refresh(self.raw, if refit { 2 } else { 0 }) });
     }
 }
 

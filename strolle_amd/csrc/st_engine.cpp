@@ -332,7 +332,8 @@ struct Engine {
     uint64_t tree_version = 0;     // bumped by every rebuild (ST_BVH_REFIT_DEVICE: a scene copy whose arrays are of this version can be refitted in place)
     bool host_stream_stale = false;  // device refits happened since bvh_stream's boxes were last recomputed (debug reads and full uploads refit it first)
     std::vector<float4> readback_; uint32_t live_bvh_texels = 0;  // st_debug_read_scene(6)
-    std::vector<uint32_t> entry_of_tri_, parent_, runs_;  // host images of the device refit's index arrays (index_device_tree)
+    std::vector<uint32_t> entry_of_tri_, parent_, refit_local_, refit_items_, refit_batch_off_;  // host images of the device refit's index arrays (index_device_tree)
+    std::vector<std::pair<uint32_t, uint32_t>> refit_levels_;  // (first batch, batches) of each launch, leaves first
     // Deepest chain of internal nodes in the uploaded stream = the most entries a traversal can have pending (every internal
     // node on the path may push its far child). The kernels' per-lane stack holds kBvhStackSize entries (strolle-gpu/src/lib.rs:76;
     // the reference indexes past the end there, here a push beyond the end is dropped): a deeper tree is reported, not hidden.
@@ -382,24 +383,64 @@ struct Engine {
         }
         device_bvh_len = (uint32_t)(4 * entries);
     }
-    // index arrays of the device refit, from the device form of the stream (bvh_upload_, entries of four texels)
+    // Index arrays of the device refit, from the device form of the stream (bvh_upload_, entries of four texels): per triangle
+    // slot its leaf entry, per entry its parent (entry << 1 | child slot), and the work list of k_bvh_refit.
+    // The refit must not pass data between workgroups inside a launch (XCD L2s are not coherent; an agent-scope fence per node
+    // measured 2.1 ms for 208 k triangles), so the tree is cut into TASKS — maximal subtrees with at most kRefitBatch leaves —,
+    // each refitted bottom-up by one workgroup that keeps the child boxes in LDS. Finished task roots are the leaves of the next
+    // LEVEL (their boxes already sit in the stream, in their parent's entry), one launch per level: two for 208 k triangles.
+    // Small tasks share a workgroup (a batch: <= kRefitBatch items, LDS slots numbered within the batch).
+    // items: leaf entry of a run's first triangle, or (1 << 31 | entry) for a finished task root; refit_local_[entry]: the LDS slot
+    // of an internal node, bit 31 set on a task's root.
     void index_device_tree() {
         const uint32_t n_entries = device_bvh_len / 4u;
         entry_of_tri_.assign(tri_geo.size() / 3u, 0xffffffffu);
         parent_.assign(std::max<uint32_t>(n_entries, 1u), 0xffffffffu);
-        runs_.clear();
-        bool in_run = false;
+        refit_local_.assign(std::max<uint32_t>(n_entries, 1u), 0u);
+        refit_items_.clear(); refit_batch_off_.assign(1, 0u); refit_levels_.clear();
+        std::vector<uint32_t> internals;
+        auto internal = [&](uint32_t k) { return f2b(bvh_upload_[4u * (size_t)k].w) == 0u; };
+        auto child = [&](uint32_t k, int which) { return which ? f2b(bvh_upload_[4u * (size_t)k + 1u].w) / 64u : k + 1u; };
         for (uint32_t k = 0; k < n_entries; k++) {
-            const float4* e = &bvh_upload_[4u * (size_t)k];
-            if (f2b(e[0].w) == 0u) {
-                parent_[k + 1u] = (k << 1) | 0u;
-                parent_[f2b(e[1].w) / 64u] = (k << 1) | 1u;
-                in_run = false;
-            } else {
-                if (!in_run) runs_.push_back(k);
-                entry_of_tri_[f2b(e[0].y)] = k;
-                in_run = (f2b(e[0].x) & 1u) != 0u;
+            if (internal(k)) {
+                parent_[child(k, 0)] = (k << 1) | 0u;
+                parent_[child(k, 1)] = (k << 1) | 1u;
+                internals.push_back(k);
+            } else entry_of_tri_[f2b(bvh_upload_[4u * (size_t)k].y)] = k;
+        }
+        std::vector<uint32_t> leaves(n_entries, 0u);  // of an unfinished internal node: runs + finished task roots beneath it
+        std::vector<uint8_t> finished(n_entries, 0);
+        std::vector<uint32_t> stack;
+        for (size_t left = internals.size(); left;) {
+            for (size_t i = internals.size(); i-- > 0;) {   // children sit behind their parent
+                const uint32_t k = internals[i];
+                if (finished[k]) continue;
+                uint32_t n = 0;
+                for (int c = 0; c < 2; c++) { const uint32_t ck = child(k, c); n += internal(ck) && !finished[ck] ? leaves[ck] : 1u; }
+                leaves[k] = n;
             }
+            const uint32_t first_batch = (uint32_t)refit_batch_off_.size() - 1u;
+            uint32_t in_batch = 0, slots = 0;
+            for (const uint32_t k : internals) {
+                if (finished[k] || leaves[k] > kRefitBatch) continue;
+                // finished[] of a task's nodes is set when its root is met, so an unfinished node here has no parent in a task
+                if (in_batch + leaves[k] > kRefitBatch) { refit_batch_off_.push_back((uint32_t)refit_items_.size()); in_batch = 0; slots = 0; }
+                in_batch += leaves[k];
+                stack.assign(1, k);
+                while (!stack.empty()) {
+                    const uint32_t n = stack.back(); stack.pop_back();
+                    refit_local_[n] = slots++ | (n == k ? 0x80000000u : 0u);
+                    finished[n] = 1; left--;
+                    for (int c = 1; c >= 0; c--) {
+                        const uint32_t ck = child(n, c);
+                        if (!internal(ck)) refit_items_.push_back(ck);
+                        else if (finished[ck]) refit_items_.push_back(ck | 0x80000000u);
+                        else stack.push_back(ck);
+                    }
+                }
+            }
+            if (in_batch) refit_batch_off_.push_back((uint32_t)refit_items_.size());
+            refit_levels_.push_back({first_batch, (uint32_t)refit_batch_off_.size() - 1u - first_batch});
         }
     }
     // OPT-IN (a build with -DST_WIDE_NODES=1 run with ST_WIDE_NODES=1; measured slower, st_device.h trace_any_wide says by how much):
@@ -503,8 +544,8 @@ struct Engine {
         // ST_BVH_REFIT_DEVICE: what k_bvh.hip needs beside the stream — per triangle slot the hit-test record, the bounds and the
         // device entry that holds it; per entry its parent (entry << 1 | child slot); the leaf runs; an arrival counter per entry.
         // tree_version says which build of the tree these (and the stream's topology) belong to.
-        DeviceArray tri_geo, tri_bounds, entry_of_tri, parent, runs, arrived;
-        uint64_t tree_version = 0; uint32_t n_runs = 0, n_entries = 0;
+        DeviceArray tri_geo, tri_bounds, entry_of_tri, parent, refit_local, refit_items, refit_batch_off;
+        uint64_t tree_version = 0;
         size_t dirty_lo = SIZE_MAX, dirty_hi = 0; bool tri_full = true;  // what this copy lacks of the host's triangle arrays
         hipEvent_t free_ev = nullptr; bool busy = false;  // busy: frames reading this copy were enqueued since it was written; free_ev ends the last
         bool valid = false;
@@ -599,7 +640,7 @@ struct Engine {
         for (DeviceArray* d : {&d_byte_luts, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
         for (LightSet& l : light_sets) { l.buf.release(); if (l.free_ev) (void)hipEventDestroy(l.free_ev); }
         for (SceneSet& t : sets) {
-            for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed, &t.tri_geo, &t.tri_bounds, &t.entry_of_tri, &t.parent, &t.runs, &t.arrived}) d->release();
+            for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed, &t.tri_geo, &t.tri_bounds, &t.entry_of_tri, &t.parent, &t.refit_local, &t.refit_items, &t.refit_batch_off}) d->release();
             if (t.free_ev) (void)hipEventDestroy(t.free_ev);
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -981,9 +1022,9 @@ struct Engine {
                         if ((rc = t.tri_bounds.upload_range(tri_bounds.data(), 2 * t.dirty_lo * sizeof(float4), 2 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
                         L.launch_bvh_patch_leaves(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_geo.ptr), static_cast<const uint32_t*>(t.entry_of_tri.ptr), (uint32_t)t.dirty_lo, (uint32_t)t.dirty_hi, up);
                     }
-                    ST_HIP(hipMemsetAsync(t.arrived.ptr, 0, (size_t)t.n_entries * sizeof(uint32_t), up));
-                    L.launch_bvh_refit(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_bounds.ptr), static_cast<const uint32_t*>(t.parent.ptr), static_cast<const uint32_t*>(t.runs.ptr), t.n_runs,
-                                       static_cast<uint32_t*>(t.arrived.ptr), up);
+                    for (const auto& level : refit_levels_)   // this copy holds the current tree, so the engine's work list is its own
+                        L.launch_bvh_refit(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_bounds.ptr), static_cast<const uint32_t*>(t.parent.ptr), static_cast<const uint32_t*>(t.refit_local.ptr),
+                                           static_cast<const uint32_t*>(t.refit_items.ptr), static_cast<const uint32_t*>(t.refit_batch_off.ptr), level.first, level.second, up);
                     device_refits++;
                 } else {
                     if (host_stream_stale) { refit_stream(); host_stream_stale = false; }
@@ -998,9 +1039,10 @@ struct Engine {
                         if ((rc = t.tri_bounds.upload(tri_bounds.data(), tri_bounds.size() * sizeof(float4), up, staging, flag))) return rc;
                         if ((rc = t.entry_of_tri.upload(entry_of_tri_.data(), entry_of_tri_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
                         if ((rc = t.parent.upload(parent_.data(), parent_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
-                        if (!runs_.empty() && (rc = t.runs.upload(runs_.data(), runs_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
-                        if ((rc = t.arrived.upload(parent_.data(), parent_.size() * sizeof(uint32_t), up, staging, flag))) return rc;  // sized like `parent`; zeroed before every refit
-                        t.tree_version = tree_version; t.n_runs = (uint32_t)runs_.size(); t.n_entries = (uint32_t)parent_.size();
+                        if ((rc = t.refit_local.upload(refit_local_.data(), refit_local_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                        if (!refit_items_.empty() && (rc = t.refit_items.upload(refit_items_.data(), refit_items_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                        if ((rc = t.refit_batch_off.upload(refit_batch_off_.data(), refit_batch_off_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                        t.tree_version = tree_version;
                     }
                 }
                 // attribute records: whole the first time or after they grew, otherwise only the slots baked since this copy was written

@@ -41,6 +41,7 @@ struct HostTriangle { float4 d0, d1, d2, d3, d4, d5, d6, d7, d8; };
 static_assert(sizeof(HostTriangle) == 144, "Triangle is 144 B");
 
 // KArgs::lean bits
+constexpr uint32_t kRefitBatch = 512;  // leaves one workgroup of k_bvh_refit takes (st_engine.cpp index_device_tree): 26 KB of LDS
 constexpr uint32_t kLeanPrim = 1u;     // primary visibility + frame reprojection in one launch: the velocity map (consumed in registers) and the
                                        // encoded surface map (every kernel reads its decoded twin, KArgs::sn) stay unwritten
 constexpr uint32_t kLeanSamples = 2u;  // di / gi diffuse sample planes: the fused denoise-reproject stages consume them in registers

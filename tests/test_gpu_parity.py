@@ -812,6 +812,29 @@ def test_bvh_refit_mode_renders_bit_exact(mode):
     assert prod.bvh_device_refits() == (4 if mode == 2 else 0)   # refit ticks whose target copy already held the tree (the first refit after a build goes to the other copy in full)
 
 
+@pytest.mark.gpu
+def test_device_refit_of_the_dungeon_equals_the_host_refit():
+    """ST_BVH_REFIT_DEVICE on a tree deep and large enough for several launches of k_bvh_refit (52 k triangles, 26 levels; the
+    work list is cut into 512-leaf tasks): with every instance of the dungeon moving each tick, the stream on the device must stay,
+    bit for bit, the device form of the host's own backward sweep over the same tree."""
+    from strolle_amd import Instance
+    e = Engine(device=0)
+    scenes.build_dungeon(e, subdivide=1)
+    e.set_bvh_refresh(2)
+    npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
+    e.tick()
+    for tick in range(5):
+        for k in range(int(npz["n_meshes"])):
+            if tick == 3 and k % 3: continue          # one tick moves only a third of the instances
+            x = npz[f"xform_{k}"].reshape(4, 3).T.copy(); x[:3, 3] += 0.01 * (tick + 1) * np.array([1.0, -0.5, 0.25]) * (1 + k % 5)
+            e.insert_instance(1 + k, Instance(1 + k, 1 + int(npz[f"material_{k}"]), x))
+        e.tick()
+        on_device, on_host = e.read_scene(6), e.read_scene(4)
+        assert on_device.size > 4 * 60_000
+        assert_bits_equal(on_device, on_host, f"tick {tick}: the stream on the device vs the host's refit")
+    assert e.bvh_refits() == (1, 5) and e.bvh_device_refits() == 4
+
+
 def _cornell_glb() -> bytes:
     """assets/cornell.npz written back out as a GLB (the original file does not travel to the GPU box)."""
     import json, struct

@@ -13,7 +13,7 @@ ap.add_argument("--subdivide", type=int, default=0)
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--light", action="store_true", help="move a light every frame instead of an instance (cornell.rs animates its light)")
 ap.add_argument("--cornell", action="store_true")
-ap.add_argument("--refit", action="store_true", help="ST_BVH_REFIT: refit the tree instead of rebuilding it")
+ap.add_argument("--refit", nargs="?", const=1, default=0, type=int, help="1 = ST_BVH_REFIT (boxes refitted on the host instead of a rebuild), 2 = ST_BVH_REFIT_DEVICE (refitted by k_bvh.hip)")
 args = ap.parse_args()
 e = Engine(device=0)
 scenes.build_cornell(e) if args.cornell else scenes.build_dungeon(e, subdivide=args.subdivide)

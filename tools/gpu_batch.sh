@@ -38,6 +38,11 @@ PY
       ;;
     ab:*)
       bash tools/ab_bench.sh "${step#ab:}" ${AB_ARGS---no-extras} > gpurun_out/${TAG}_ab.log 2>&1; cat gpurun_out/${TAG}_ab.log ;;
+    refitcost)   # host tick + frame time with moving instances: rebuild / host refit / device refit, 134 k-triangle dungeon
+      { for m in 0 1 2; do timeout 300 python tools/tick_cost.py --device 0 --subdivide 2 --refit $m; done
+        for m in 1 2; do timeout 300 python tools/tick_cost.py --device 0 --subdivide 2 --refit $m --all; done
+        for m in 1 2; do timeout 300 python tools/animated_cost.py --subdivide 2 --refit $m; done
+        for m in 1 2; do timeout 300 python tools/animated_cost.py --refit $m; done; } > gpurun_out/${TAG}_refit_cost.txt 2>&1; cat gpurun_out/${TAG}_refit_cost.txt ;;
     profile)
       bash tools/gpu_profile_quick.sh > gpurun_out/${TAG}_profile.log 2>&1; tail -5 gpurun_out/${TAG}_profile.log ;;
     *) echo "unknown step $step" ;;

@@ -11,7 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--device", type=int, default=-1)
 ap.add_argument("--subdivide", type=int, default=0)
 ap.add_argument("--ticks", type=int, default=20)
-ap.add_argument("--refit", action="store_true")
+ap.add_argument("--refit", nargs="?", const=1, default=0, type=int, help="1 = ST_BVH_REFIT (boxes refitted on the host instead of a rebuild), 2 = ST_BVH_REFIT_DEVICE (refitted by k_bvh.hip)")
 ap.add_argument("--all", action="store_true", help="move every instance per tick, not just one (stress-bvh.rs: many bodies under physics)")
 args = ap.parse_args()
 e = Engine(device=args.device)
