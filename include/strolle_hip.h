@@ -263,7 +263,11 @@ int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
 /* Host-side copies of what st_tick uploads: what = 0 BVH stream as the reference's serializer writes it (float4), 1
  * triangles in the reference's 144-B layout, 2 lights (112 B), 3 materials (112 B), 4 the BVH stream in its device form
  * (every entry four float4: internal nodes with the far child's byte offset, leaf entries followed by the triangle's
- * hit-test record; st_types.h). Works on host-only engines. */
+ * hit-test record; st_types.h), 5 the optional 4-wide nodes, 6 the device form read back FROM the device (live copy),
+ * 7-13 the inputs of the device refit (k_bvh.hip; uint32 unless noted): 7 parent of every entry (entry << 1 | child slot),
+ * 8 LDS slot of every internal entry (bit 31: a task's root), 9 work items (bit 31: root of a finished task), 10 batch offsets
+ * into 9, 11 (first batch, batches) per launch, 12 leaf entry of every triangle slot, 13 triangle bounds (two float4 per slot).
+ * All but 6 work on host-only engines. */
 int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written);
 int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame);
 /* Where an image sits in the 8192-wide atlas: x, y, width, height in texels (images.rs:115-124 `lookup`). */

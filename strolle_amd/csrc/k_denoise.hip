@@ -104,7 +104,12 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
             const int li = ry * PITCH + rx;
             if (gx >= 0 && gy >= 0 && gx < (int32_t)a.width && gy < (int32_t)a.height) {
                 const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
-                s_sn[li] = a.sn[at]; s_di[li] = a.di_diff_curr_colors[at]; s_gi[li] = a.gi_diff_curr_colors[at];
+                // sqrt(luma) of a staged texel rides in its w (the taps read x, y, z only): evaluated once per texel, not once per tap
+                float4 tdi = a.di_diff_curr_colors[at], tgi = a.gi_diff_curr_colors[at];
+                const f2 tl = (mk2(tdi.x, tgi.x) * 0.2126f + mk2(tdi.y, tgi.y) * 0.7152f) + mk2(tdi.z, tgi.z) * 0.0722f;
+                const f2 ts = sqrt2(tl);
+                tdi.w = ts.x; tgi.w = ts.y;
+                s_sn[li] = a.sn[at]; s_di[li] = tdi; s_gi[li] = tgi;
             } else {
                 s_sn[li] = f4z();
             }
@@ -137,7 +142,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
                 if (ssn.w == 0.0f) continue;
                 const float4 sdi = s_di[lt], sgi = s_gi[lt];
                 const f2 l = (mk2(sdi.x, sgi.x) * 0.2126f + mk2(sdi.y, sgi.y) * 0.7152f) + mk2(sdi.z, sgi.z) * 0.0722f;
-                const f2 d = c_sqrt_luma - sqrt2(l);
+                const f2 d = c_sqrt_luma - mk2(sdi.w, sgi.w);  // = sqrt2(l), staged
                 const float diff = fabsf(ssn.w - csn.w);
                 const float depth_weight = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
                 const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));

@@ -333,6 +333,7 @@ struct Engine {
     bool host_stream_stale = false;  // device refits happened since bvh_stream's boxes were last recomputed (debug reads and full uploads refit it first)
     std::vector<float4> readback_; uint32_t live_bvh_texels = 0;  // st_debug_read_scene(6)
     std::vector<uint32_t> entry_of_tri_, parent_, refit_local_, refit_items_, refit_batch_off_;  // host images of the device refit's index arrays (index_device_tree)
+    std::vector<uint32_t> readback_levels_;
     std::vector<std::pair<uint32_t, uint32_t>> refit_levels_;  // (first batch, batches) of each launch, leaves first
     // Deepest chain of internal nodes in the uploaded stream = the most entries a traversal can have pending (every internal
     // node on the path may push its far child). The kernels' per-lane stack holds kBvhStackSize entries (strolle-gpu/src/lib.rs:76;
@@ -1921,6 +1922,17 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
             ST_HIP(hipSetDevice(en->device)); ST_HIP(hipDeviceSynchronize());
             if (n) ST_HIP(hipMemcpy(en->readback_.data(), en->sets[en->live].bvh.ptr, n * sizeof(float4), hipMemcpyDeviceToHost));
             p = en->readback_.data(); bytes = n * sizeof(float4); break;
+        }
+        case 7: case 8: case 9: case 10: case 11: case 12: case 13: {  // the device refit's inputs (k_bvh.hip), built here for a host-side emulation
+            if (en->host_stream_stale) { en->refit_stream(); en->host_stream_stale = false; }
+            en->expand_stream(); en->index_device_tree();
+            en->readback_levels_.clear();
+            for (const auto& l : en->refit_levels_) { en->readback_levels_.push_back(l.first); en->readback_levels_.push_back(l.second); }
+            const std::vector<uint32_t>* v = what == 7 ? &en->parent_ : what == 8 ? &en->refit_local_ : what == 9 ? &en->refit_items_ : what == 10 ? &en->refit_batch_off_
+                                           : what == 11 ? &en->readback_levels_ : &en->entry_of_tri_;
+            if (what == 13) { p = en->tri_bounds.data(); bytes = en->tri_bounds.size() * sizeof(float4); }
+            else { p = v->data(); bytes = v->size() * sizeof(uint32_t); }
+            break;
         }
         default: return fail(ST_ERR_INVALID_ARGUMENT, "unknown scene buffer");
     }

@@ -340,6 +340,98 @@ def test_every_instance_moving_at_pool_size_equals_oracle(refit):
     assert prod.bvh_refits() == orac.bvh_refits() == ((1, 3) if refit else (4, 0))
 
 
+def _emulate_device_refit(stream, target, parent, local, items, batch_off, levels, entry_of_tri, tri_bounds, batch_limit=512):
+    """k_bvh.hip on the host, in numpy: patch the leaf entries, then run the work list launch by launch, batch by batch. Inside a
+    batch the items are taken in REVERSE order (the kernel's lanes arrive in no particular order; the result must not depend on
+    it), child boxes live in a per-batch dictionary (the LDS slots) and only boxes stored by EARLIER launches are read from the
+    stream — exactly what the kernel may rely on."""
+    s = stream.reshape(-1, 4, 4).copy(); t = target.reshape(-1, 4, 4)
+    su = s.view(np.uint32)
+    leaf = su[:, 0, 3] != 0
+    s[leaf, 1:] = t[leaf, 1:]                                            # k_bvh_patch_leaves (the moved records are in the target)
+    assert np.array_equal(np.flatnonzero(leaf), np.sort(entry_of_tri[entry_of_tri != 0xffffffff])), "entry_of_tri names every leaf entry once"
+    def grow(lo, hi, p): return np.minimum(lo, p), np.maximum(hi, p)
+    stored = np.zeros((len(s), 2), bool)                                 # child slots written so far (by whom does not matter)
+    for first, count in levels.reshape(-1, 2):
+        written_now = []
+        for b in range(first, first + count):
+            work = items[batch_off[b]:batch_off[b + 1]]
+            assert 0 < len(work) <= batch_limit
+            slots, arrived = {}, {}
+            for item in work[::-1]:
+                e = int(item & 0x7fffffff); p = int(parent[e])
+                lo, hi = np.full(3, np.float32(3.4028235e38)), np.full(3, np.float32(-3.4028235e38))
+                if item >> 31:
+                    assert stored[p >> 1, p & 1], "a finished task's box must have been stored by an earlier launch"
+                    assert (p >> 1, p & 1) not in written_now, "... not by this one (no hand-off between workgroups inside a launch)"
+                    lo, hi = s[p >> 1, 2 * (p & 1), :3].copy(), s[p >> 1, 2 * (p & 1) + 1, :3].copy(); have = True
+                else:
+                    k = e
+                    while True:
+                        tri = int(su[k, 0, 1])
+                        for pt in (tri_bounds[2 * tri, :3], tri_bounds[2 * tri + 1, :3]): lo, hi = grow(lo, hi, pt)
+                        if not su[k, 0, 0] & 1: break
+                        k += 1
+                    have = False
+                while True:
+                    pe, slot = p >> 1, p & 1
+                    if not have:
+                        s[pe, 2 * slot, :3] = lo; s[pe, 2 * slot + 1, :3] = hi; stored[pe, slot] = True; written_now.append((pe, slot))
+                    l = int(local[pe] & 0x7fffffff)
+                    assert l < batch_limit
+                    slots[(l, slot)] = (lo, hi)
+                    arrived[l] = arrived.get(l, 0) + 1
+                    if arrived[l] == 1: break
+                    assert arrived[l] == 2
+                    lo, hi = np.full(3, np.float32(3.4028235e38)), np.full(3, np.float32(-3.4028235e38))
+                    for c in (0, 1):
+                        for pt in slots[(l, c)]: lo, hi = grow(lo, hi, pt)
+                    p = int(parent[pe]); have = False
+                    if p == 0xffffffff: break
+                    if local[pe] >> 31:
+                        s[p >> 1, 2 * (p & 1), :3] = lo; s[p >> 1, 2 * (p & 1) + 1, :3] = hi; stored[p >> 1, p & 1] = True; written_now.append((p >> 1, p & 1))
+                        break
+            assert all(v == 2 for v in arrived.values()), "every node of a batch must see both children arrive"
+    internal = ~leaf
+    assert stored[internal].all(), "every child box must have been rewritten"
+    return s.reshape(-1)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "dungeon", "dungeon x4"])
+def test_device_refit_work_list_reproduces_the_host_refit(scene):
+    """ST_BVH_REFIT_DEVICE's host half (st_engine.cpp index_device_tree): the tree cut into 512-leaf tasks, batches and launches.
+    A numpy emulation of k_bvh.hip run over that work list, starting from the stream of BEFORE the move, must arrive bit for bit at
+    the device form of the host's own refit — with no box read inside a launch that the same launch wrote from another batch."""
+    from strolle_amd import Instance
+    e = Engine(device=-1)
+    if scene == "cornell":
+        scenes.build_cornell(e)
+    else:
+        scenes.build_dungeon(e, subdivide=1 if scene.endswith("x4") else 0)
+    e.set_bvh_refresh(1)
+    e.tick()
+    before = e.read_scene(4).copy()
+    u32 = lambda what: e.read_scene(what).view(np.uint32).copy()
+    parent, local, items, batch_off, levels, entry_of_tri = (u32(w) for w in (7, 8, 9, 10, 11, 12))
+    n_levels = len(levels) // 2
+    assert n_levels == {"cornell": 1, "dungeon": 2, "dungeon x4": 2}[scene]
+    assert batch_off[0] == 0 and batch_off[-1] == len(items) and np.all(np.diff(batch_off.astype(np.int64)) > 0)
+    npz = np.load(os.path.join(scenes.ASSETS, "cornell.npz" if scene == "cornell" else "dungeon.npz"))
+    for i in range(int(npz["n_meshes"])):
+        if scene != "cornell" and i % 2: continue
+        x = np.ascontiguousarray(npz[f"xform_{i}"].reshape(4, 3).T, np.float32)
+        x[:, 3] += np.float32(0.02 * (1 + i % 4)) * np.array([1.0, -0.5, 0.25], np.float32)
+        e.insert_instance(1 + i, Instance(1 + i, 1 + int(npz[f"material_{i}"]), x))
+    e.tick()
+    assert e.bvh_refits() == (1, 1)
+    after = e.read_scene(4)
+    assert not np.array_equal(before, after)
+    for w, old in ((7, parent), (8, local), (9, items), (10, batch_off), (12, entry_of_tri)):
+        assert np.array_equal(u32(w), old), "a refit keeps the tree, so its work list too"
+    got = _emulate_device_refit(before, after, parent, local, items, batch_off, levels, entry_of_tri, e.read_scene(13).reshape(-1, 4))
+    assert_bits_equal(got, after, "emulated device refit vs the host's refit")
+
+
 def test_bvh_depth_is_reported():
     """st_debug_bvh_depth: the longest chain of internal nodes against the 24-entry traversal stack (strolle-gpu/src/lib.rs:76).
     The Cornell box and the demo dungeon fit; the synthetic 208 k-triangle dungeon is deeper than the stack, which the library
