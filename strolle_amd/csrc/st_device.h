@@ -328,55 +328,6 @@ ST_D V2 tri_uv(const KArgs& a, uint32_t tri, float u, float v) {
 // and wait, so that each body runs with more of its lanes: majority vote, triangles-only-when-no-node-is-pending ("while-while")
 // and a 16-lane threshold all lost, dungeon 1080p 1.46 -> 1.57 / 1.60 / 1.58 ms per frame, GI sampling a 203 -> 235 / 303 / 268 us.
 // The loop below already skips a body no lane wants (s_cbranch_execz); making lanes wait costs more steps than the fuller bodies save.)
-        const bool run_leaves = nodes == 0ull || __popcll(leaves) >= ST_TRAVERSE_VOTE;
-#endif
-        bool pop = false;
-        if (!run_leaves) {
-            if (at_node) {
-                used_memory += 16u + 48u;
-                uint32_t near_ptr = ptr + 64u, far_ptr = f2b(d1.w);
-                float near_d = intersect_box(ray, xyz(d0), xyz(d1));
-                float far_d = intersect_box(ray, xyz(d2), xyz(d3));
-                if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-                if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)(far_ptr >> 6); sp++; } }
-                if (near_d < best->t) ptr = near_ptr; else pop = true;
-                need = true;
-            }
-        } else if (at_leaf) {
-            used_memory += 16u + 144u;
-            const uint32_t flags = f2b(d0.x), tri = f2b(d0.y), material = f2b(d0.z);
-            const V3 p0 = xyz(d1), e1 = xyz(d2), e2 = xyz(d3);
-            const V3 pvec = xe::cross(ray.dir, e2);
-            const float det = xe::dot(e1, pvec);
-            bool found = false;
-            if (!(fabsf(det) < kF32Eps)) {
-                const float inv_det = 1.0f / det;
-                const V3 tvec = xe::sub(ray.origin, p0);
-                const float u = xe::dot(tvec, pvec) * inv_det;
-                const V3 qvec = xe::cross(tvec, e1);
-                const float v = xe::dot(ray.dir, qvec) * inv_det;
-                const float t = xe::dot(e2, qvec) * inv_det;
-                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t))) {
-                    found = true;
-                    if (flags & 2u) {  // AlphaMode::Blend: the hit only counts where the base colour is opaque
-                        used_memory += 112u + 16u;
-                        const GpuMaterial m = a.materials[material];
-                        const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
-                        if (bc.w < 1.0f) found = false;
-                    }
-                    if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = tri; best->material = material; *found_any = true; }
-                }
-            }
-            need = true;
-            if (found && ANY_HIT) { alive = false; need = false; }
-            else if (flags & 1u) ptr += 64u;
-            else pop = true;
-        }
-        if (pop) { if (sp > 0) { sp--; ptr = (uint32_t)stack[sp * 64] << 6; } else { alive = false; need = false; } }
-    }
-    return used_memory;
-}
-#else
 template <bool ANY_HIT, class SE>
 ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, Candidate* best, bool* found_any) {
     best->t = max_t; best->tri = 0xffffffffu; best->material = 0u; best->u = 0.0f; best->v = 0.0f; best->inv_det = 1.0f;
