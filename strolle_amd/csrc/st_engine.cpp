@@ -593,6 +593,7 @@ struct Engine {
     bool count_bytes = false;     // st_profile_enable bit 1: traversal-byte counters
     bool profile_kernel_events = false;  // st_profile_enable bit 3: every launch carries its own start / stop events (hipExtLaunchKernelGGL): no event packets between kernels
     bool profile_group_atrous = false;  // st_profile_enable bit 2: the a-trous chain's back-to-back launches share ONE event pair (an event between two kernels costs the second one 3-15 us)
+    int side_priority = 0;     // ST_SIDE_PRIORITY: > 0 the side stream (primary visibility + GI chain) gets the device's highest stream priority, < 0 the lowest
     bool tick_timing = false;  // ST_TICK_TIMING=1: print the host-side cost of a scene refresh to stderr
     std::vector<ProfileRecord> profile_records; std::vector<hipEvent_t> event_pool;
     StKernelProfile profile_totals[KS_COUNT];
@@ -611,6 +612,7 @@ struct Engine {
         if (const char* k = getenv("ST_NO_FUSE_SPATIAL")) fuse_spatial = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
+        if (const char* k = getenv("ST_SIDE_PRIORITY")) side_priority = atoi(k);
         if (const char* k = getenv("ST_NO_FUSE_WAVELET")) fuse_wavelet = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_GI_ALIAS")) alias_gi_history = atoi(k) == 0;
         if (const char* k = getenv("ST_DI_HEAD_ON_MAIN")) di_head_on_main = atoi(k) != 0;
@@ -1490,7 +1492,10 @@ struct Engine {
                 //                                          the denoiser's planes)
                 //   denoiser(N+1)  after GI tail(N+1)
                 if (!c.side_stream) {
-                    ST_HIP(hipStreamCreateWithFlags(&c.side_stream, hipStreamNonBlocking));
+                    int least = 0, greatest = 0;
+                    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                    const int priority = side_priority > 0 ? greatest : (side_priority < 0 ? least : 0);
+                    ST_HIP(hipStreamCreateWithPriority(&c.side_stream, hipStreamNonBlocking, priority));
                     for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
                 }
                 // LUT generation issued on `stream` in this call must precede the side stream's consumers. (Do NOT do this
