@@ -16,7 +16,8 @@ config), each rank renders one row band (+ apron) and the bands are gathered to 
   ... bench.py --gpus 8 --scaling strong --width 3840 --height 2160 --scene dungeon --mode image         (config 5; N = 1, 2, 4, 8)
 Extra regions, all in the same ONE JSON line (none of them changes `value` / `ms_per_step`, which stay the static headline):
   N = 1, headline workload:  `moving`  — the same K steps with the light orbiting as bevy-strolle/examples/cornell.rs:82-93 animates
-                             it and the camera on a slow orbit (`ms_per_step_moving`);
+                             it and the camera on a slow orbit (`ms_per_step_moving`); with one object moving every frame and the BVH refitted
+                             on the device (`ms_per_step_geometry_moving`);
                              `present` — the same K steps through the facade's present path (RGBA8 target, two buffers,
                              st_camera_present_copy to page-locked host memory, previous frame polled: `ms_per_step_with_present`).
   N > 1:                     `multi_gpu.strong_config5` — BASELINE.json config 5 as written (dungeon 3840x2160 Image, ONE frame split
@@ -172,6 +173,7 @@ class Job:
         self.frame_no = 0
         self.moving = False
         self.moving_t0 = None
+        self.geometry = None          # (handle, Instance factory): re-inserted with a new transform before every tick
 
     def animate(self):
         """bevy-strolle/examples/cornell.rs:82-93: the point light at (sin t / 2, 1.5, cos t / 2), t = elapsed seconds (one frame =
@@ -190,6 +192,8 @@ class Job:
         k = self.frame_no % len(self.outs)
         if self.moving:
             self.animate()
+        if self.geometry is not None:
+            self.engine.insert_instance(self.geometry[0], self.geometry[1](self.frame_no))
         self.frame_no += 1
         out = self.outs[k]
         if world > 1 and self.gathered[k] is not None:
@@ -311,7 +315,7 @@ def main():
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last (gathered) frame as .npy — tests compare it with a single-GPU render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra regions (moving scene, present path; N > 1: BASELINE configs 5 / 4 as written)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra regions (moving light + camera, moving geometry, present path; N > 1: BASELINE configs 5 / 4 as written)")
     ap.add_argument("--extras-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"), help="frame of the N > 1 strong-scaling extras (tests shrink it)")
     args = ap.parse_args()
 
@@ -423,6 +427,33 @@ def main():
         extras["ms_per_step_moving"] = round(el_m / args.steps * 1e3, 4)
         extras["moving"] = {"what": "same K steps; point light at (sin t / 2, 1.5, cos t / 2), t advancing 1/60 s per frame (cornell.rs:82-93), camera orbiting the box at 0.1 rad/s; light + camera updated through insert_light / update_camera before every tick",
                             "Mray_per_s": round(rays_m / el_m / 1e6, 2), "rays_per_frame": round(rays_m / args.steps), "frame_finite": bool(torch.isfinite(frame_m).all())}
+        # -- geometry moving (examples/stress-bvh.rs in miniature): one object of the scene is re-inserted with a new transform before
+        #    every tick; the tree is refitted on the device (ST_BVH_REFIT_DEVICE), st_tick sends the moved triangles only
+        import math
+        import numpy as np
+        from strolle_amd import Instance, Light
+        job.desc = job.scenes.cornell_camera((width, height), job.mode, depth=1)                          # camera and light back at t = 0
+        engine.insert_light(1, Light.point((0.0, 1.5, 0.5), 0.15, (50.0 / (4.0 * math.pi),) * 3, 20.0))
+        npz = np.load(os.path.join(job.scenes.ASSETS, "cornell.npz"))
+        mesh = int(npz["n_meshes"]) - 1
+        rest = np.ascontiguousarray(npz[f"xform_{mesh}"].reshape(4, 3).T, np.float32)
+        def placed(i):
+            x = rest.copy(); x[0, 3] += np.float32(0.15 * math.sin(i / 20.0))
+            return Instance(1 + mesh, 1 + int(npz[f"material_{mesh}"]), x)
+        engine.set_bvh_refresh(2)
+        job.geometry = (1 + mesh, placed)
+        job.run(args.warmup)
+        torch.cuda.synchronize(); engine.ray_count(cam, reset=True)
+        el_g, frame_g = job.timed_region(args.steps)
+        rays_g = engine.ray_count(cam)
+        job.geometry = None
+        rebuilds, refits = engine.bvh_refits()
+        engine.insert_instance(1 + mesh, Instance(1 + mesh, 1 + int(npz[f"material_{mesh}"]), rest))
+        engine.set_bvh_refresh(0)
+        extras["ms_per_step_geometry_moving"] = round(el_g / args.steps * 1e3, 4)
+        extras["geometry_moving"] = {"what": f"same K steps; instance {1 + mesh} of the scene re-inserted with a new transform before every tick, BVH refitted on the device (k_bvh.hip; ST_BVH_REFIT_DEVICE)",
+                                     "Mray_per_s": round(rays_g / el_g / 1e6, 2), "bvh_rebuilds": rebuilds, "bvh_refits": refits, "bvh_device_refits": engine.bvh_device_refits(),
+                                     "frame_finite": bool(torch.isfinite(frame_g).all())}
         # -- the facade's present path (rust/strolle-hip/src/present.rs, examples/render_gltf.c): RGBA8 target, two device
         #    frames + two page-locked host frames alternate, frame N-1 is polled (never a stream join) while frame N renders
         from strolle_amd import OutputFormat
