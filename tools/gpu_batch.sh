@@ -38,7 +38,7 @@ PY
       ;;
     ab:*)
       bash tools/ab_bench.sh "${step#ab:}" ${AB_ARGS---no-extras} > gpurun_out/${TAG}_ab.log 2>&1; cat gpurun_out/${TAG}_ab.log ;;
-    refitcost)   # host tick + frame time with moving instances: rebuild / host refit / device refit, 134 k-triangle dungeon
+    refitcost)   # host tick + frame time with moving instances: rebuild / host refit / device refit, 208 k-triangle dungeon
       { for m in 0 1 2; do timeout 300 python tools/tick_cost.py --device 0 --subdivide 2 --refit $m; done
         for m in 1 2; do timeout 300 python tools/tick_cost.py --device 0 --subdivide 2 --refit $m --all; done
         for m in 1 2; do timeout 300 python tools/animated_cost.py --subdivide 2 --refit $m; done
