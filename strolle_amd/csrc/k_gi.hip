@@ -28,34 +28,26 @@ void launch_gi_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_gi_repr
 ST_D bool frame_is_gi_tracing(uint32_t frame) { return frame % 6u < 4u; }  // frame.rs:19-21
 
 // ---------------------------------------------------------------- gi_sampling_a.rs:3-122
-template <bool LDS_SCENE, class SE>
-__global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a_in, uint32_t seed) {
-    ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
-    uint32_t used_ = 0u;
-    U2 gid;
-    if (!resolve_gid(a, true, &gid)) return;
-    const bool tracing = frame_is_gi_tracing(a.frame);
-    const U2 pos = tracing ? resolve_checkerboard(gid, a.frame / 2u) : resolve_checkerboard(gid, a.frame);
-    if (!owns_pixel(a, pos)) return;
-    const uint32_t n = a.width * a.height;
-    const uint32_t idx = screen_to_idx(a, pos);
+// The two sampling passes as per-cell bodies, so that they can run as the reference's two launches or as one (k_gi_sampling_ab).
+// `prim_hit`: pixel_hit() of the cell's pixel (tracing frames: pass a samples its BRDF; pass b needs it on every frame);
+// `vres`: the reprojected reservoir of validation frames (both passes re-trace / re-shade its sample).
+// Pass a: what it stores in gi_d0..2 — false when the pass leaves early (nothing stored, stale texels stay, as in the reference).
+template <class SE>
+ST_D bool gi_sampling_a_cell(const KArgs& a, uint32_t seed, bool tracing, U2 pos, const Hit& prim_hit, const GiReservoir& vres, SE* stack, uint32_t* used_,
+                             float4* d0, float4* d1, float4* d2) {
     Ray gi_ray; float gi_ray_pdf;
     if (tracing) {
         WhiteNoise wn = white_noise(seed, pos);
-        const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
-        if (!hit_some(hit)) return;
-        const BrdfSample s = layered_brdf_sample(hit.g, wn, -hit.dir);
-        gi_ray = make_ray(hit.point, s.dir);
+        if (!hit_some(prim_hit)) return false;
+        const BrdfSample s = layered_brdf_sample(prim_hit.g, wn, -prim_hit.dir);
+        gi_ray = make_ray(prim_hit.point, s.dir);
         gi_ray_pdf = s.pdf;
     } else {
-        const GiReservoir res = gi_read(a.gi_res[2], idx, n);
-        if (res.m == 0.0f) return;
-        gi_ray = make_ray(res.s.v1_point, gi_dir(res.s, res.s.v1_point));
+        if (vres.m == 0.0f) return false;
+        gi_ray = make_ray(vres.s.v1_point, gi_dir(vres.s, vres.s.v1_point));
         gi_ray_pdf = 1.0f;
     }
-    const TriangleHit gi_hit = trace_closest(a, gi_ray, lane_stack(lds), &used_);
-    count_rays(a, used_);
+    const TriangleHit gi_hit = trace_closest(a, gi_ray, stack, used_);
     GBuffer gg = gbuffer_zero();
     uint32_t base_bits = 0u;  // gbuffer_pack_base_color of the zero colour
     if (hit_is_some(gi_hit)) {
@@ -68,17 +60,12 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a_in, uint32_t seed
         gg.roughness = m.roughness; gg.reflectance = m.reflectance;
         gg.depth = distance(gi_ray.origin, gi_hit.point);
     }
-    float4 p0, p1;
-    gbuffer_pack_bits(gg, base_bits, &p0, &p1);
-    tex_write(a.gi_d0, a, gid, f4(gi_ray.dir, gi_ray_pdf));  // indexed by the half-resolution gid (gi_sampling_a.rs:117-121)
-    tex_write(a.gi_d1, a, gid, p0);
-    tex_write(a.gi_d2, a, gid, p1);
+    *d0 = f4(gi_ray.dir, gi_ray_pdf);
+    gbuffer_pack_bits(gg, base_bits, d1, d2);
+    return true;
 }
-void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_a, true, s, a, seed); }
-
-// ---------------------------------------------------------------- gi_sampling_b.rs:3-235
 template <bool LDS_SCENE, class SE>
-__global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed) {
+__global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a_in, uint32_t seed) {
     ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
@@ -87,21 +74,31 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed
     const bool tracing = frame_is_gi_tracing(a.frame);
     const U2 pos = tracing ? resolve_checkerboard(gid, a.frame / 2u) : resolve_checkerboard(gid, a.frame);
     if (!owns_pixel(a, pos)) return;
-    const uint32_t n = a.width * a.height;
+    const Hit prim_hit = tracing ? pixel_hit(a, a.cam, a.g0, a.g1, pos) : hit_zero();
+    const GiReservoir vres = tracing ? gi_empty() : gi_read(a.gi_res[2], screen_to_idx(a, pos), a.width * a.height);
+    float4 d0, d1, d2;
+    if (!gi_sampling_a_cell(a, seed, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, &d0, &d1, &d2)) return;
+    count_rays(a, used_);
+    tex_write(a.gi_d0, a, gid, d0);  // indexed by the half-resolution gid (gi_sampling_a.rs:117-121)
+    tex_write(a.gi_d1, a, gid, d1);
+    tex_write(a.gi_d2, a, gid, d2);
+}
+void launch_gi_sampling_a(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_a, true, s, a, seed); }
+
+// ---------------------------------------------------------------- gi_sampling_b.rs:3-235
+// d0..2: pass a's texels for this cell. The caller has checked hit_some(prim_hit) and, on validation frames, vres.m != 0.
+template <class SE>
+ST_D void gi_sampling_b_cell(const KArgs& a, uint32_t seed, bool tracing, U2 pos, const Hit& prim_hit, const GiReservoir& vres, SE* stack, uint32_t* used_,
+                             float4 d0, float4 d1, float4 d2) {
     const uint32_t idx = screen_to_idx(a, pos);
-    const Hit prim_hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
-    if (!hit_some(prim_hit)) return;
-    const float4 d0 = tex_read(a.gi_d0, a, gid), d1 = tex_read(a.gi_d1, a, gid), d2 = tex_read(a.gi_d2, a, gid);
     WhiteNoise wn; Hit gi_hit; float gi_ray_pdf;
     if (tracing) {
         wn = white_noise(seed, pos);
         gi_hit = hit_make(make_ray(prim_hit.point, xyz(d0)), gbuffer_unpack(a, d1, d2));
         gi_ray_pdf = d0.w;
     } else {
-        const GiReservoir res = gi_read(a.gi_res[2], idx, n);
-        if (res.m == 0.0f) return;
-        wn.state = res.s.rng;
-        gi_hit = hit_make(make_ray(res.s.v1_point, xyz(d0)), gbuffer_unpack(a, d1, d2));
+        wn.state = vres.s.rng;
+        gi_hit = hit_make(make_ray(vres.s.v1_point, xyz(d0)), gbuffer_unpack(a, d1, d2));
         gi_ray_pdf = 1.0f;
     }
     const uint32_t rng = wn.state;
@@ -131,8 +128,10 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed
         float light_vis;
         if (hit_some(gi_hit)) {
             const Ray ray = light_id == kLightIdSky ? make_ray(gi_hit.point, light_dir) : light_ray_wnoise(light_get(a, light_id), wn, gi_hit.point);
-            const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
-            count_rays(a, used_);
+            uint32_t used_now = 0u;
+            const bool occluded = trace_any(a, ray, stack, &used_now);
+            *used_ += used_now;
+            count_rays(a, used_now);
             light_vis = occluded ? 0.0f : 1.0f;
         } else light_vis = 1.0f;
         radiance = light_rad * light_vis / light_pdf;
@@ -150,7 +149,50 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed
     }
     gi_write(a.gi_res[1], idx, res);
 }
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed) {
+    ST_SCENE_PROLOGUE
+    __shared__ SE lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const bool tracing = frame_is_gi_tracing(a.frame);
+    const U2 pos = tracing ? resolve_checkerboard(gid, a.frame / 2u) : resolve_checkerboard(gid, a.frame);
+    if (!owns_pixel(a, pos)) return;
+    const Hit prim_hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    if (!hit_some(prim_hit)) return;
+    const float4 d0 = tex_read(a.gi_d0, a, gid), d1 = tex_read(a.gi_d1, a, gid), d2 = tex_read(a.gi_d2, a, gid);
+    GiReservoir vres = gi_empty();
+    if (!tracing) { vres = gi_read(a.gi_res[2], screen_to_idx(a, pos), a.width * a.height); if (vres.m == 0.0f) return; }
+    gi_sampling_b_cell(a, seed, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, d0, d1, d2);
+}
 void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_b, true, s, a, seed); }
+
+// Both sampling passes of a cell in one launch: pass b takes pass a's three texels from registers (they are still stored:
+// gi_d0..2 are planes of the reference), the pixel's G-buffer and, on validation frames, the reprojected reservoir are read once.
+// Wherever pass b runs pass a has run (tracing: both need the pixel's surface; validation: both need a non-empty reservoir).
+template <bool LDS_SCENE, class SE>
+__global__ ST_KERNEL_BOUNDS void k_gi_sampling_ab(const KArgs a_in, uint32_t seed_a, uint32_t seed_b) {
+    ST_SCENE_PROLOGUE
+    __shared__ SE lds[kStackWords];
+    uint32_t used_ = 0u;
+    U2 gid;
+    if (!resolve_gid(a, true, &gid)) return;
+    const bool tracing = frame_is_gi_tracing(a.frame);
+    const U2 pos = tracing ? resolve_checkerboard(gid, a.frame / 2u) : resolve_checkerboard(gid, a.frame);
+    if (!owns_pixel(a, pos)) return;
+    const Hit prim_hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
+    const GiReservoir vres = tracing ? gi_empty() : gi_read(a.gi_res[2], screen_to_idx(a, pos), a.width * a.height);
+    float4 d0, d1, d2;
+    if (!gi_sampling_a_cell(a, seed_a, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, &d0, &d1, &d2)) return;
+    count_rays(a, used_);
+    tex_write(a.gi_d0, a, gid, d0);
+    tex_write(a.gi_d1, a, gid, d1);
+    tex_write(a.gi_d2, a, gid, d2);
+    if (!hit_some(prim_hit)) return;  // validation frames: pass a re-traces a reservoir wherever one is, pass b wants a surface too
+    gi_sampling_b_cell(a, seed_b, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, d0, d1, d2);
+}
+void launch_gi_sampling_ab(const KArgs& a, uint32_t seed_a, uint32_t seed_b, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_ab, true, s, a, seed_a, seed_b); }
 
 // ---------------------------------------------------------------- gi_temporal_resampling.rs:3-156
 // REPROJECT: gi_reprojection.rs for the same pixel runs right here (tracing frames only, where this pass is the only reader

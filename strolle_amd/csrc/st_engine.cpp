@@ -582,6 +582,7 @@ struct Engine {
     bool alias_gi_history = true;  // ST_NO_GI_ALIAS=1: gi_resolving always copies the source reservoirs into the history plane
     bool fuse_wavelet = true;  // ST_NO_FUSE_WAVELET=1: strides 1 and 2 of the a-trous chain as two launches
     bool fuse_spatial = true;  // ST_NO_FUSE_SPATIAL=1: DI spatial resampling as three launches
+    bool fuse_gi_sampling = true;  // ST_NO_FUSE_GI_SAMPLING=1: GI sampling passes a and b as two launches
     bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
     // ... and for the SVGF passes (ST_TILE_MAP_DENOISE): mode 2 keeps the halo rows of the LDS windows and the a-trous taps
@@ -610,6 +611,7 @@ struct Engine {
         if (const char* nf = getenv("ST_NO_FUSE")) fuse = atoi(nf) == 0;
         if (const char* k = getenv("ST_NO_FUSE_DI_HEAD")) fuse_di_head = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_SPATIAL")) fuse_spatial = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_FUSE_GI_SAMPLING")) fuse_gi_sampling = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* k = getenv("ST_SIDE_PRIORITY")) side_priority = atoi(k);
@@ -1391,6 +1393,7 @@ struct Engine {
                 };
                 if (!fuse_gi_reprojection) run(KS_GI_REPROJECTION, ST_PASS_GI_REPROJECTION, [&] { L.launch_gi_reprojection(a, cur); });
                 auto sampling = [&] {
+                    if (fuse && fuse_gi_sampling) { run(KS_GI_SAMPLING_AB, ST_PASS_GI_SAMPLING_A | ST_PASS_GI_SAMPLING_B, [&] { L.launch_gi_sampling_ab(a, seed(SEED_GI_SAMPLING_A), seed(SEED_GI_SAMPLING_B), cur); }); return; }
                     run(KS_GI_SAMPLING_A, ST_PASS_GI_SAMPLING_A, [&] { L.launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), cur); });
                     run(KS_GI_SAMPLING_B, ST_PASS_GI_SAMPLING_B, [&] { L.launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), cur); });
                 };

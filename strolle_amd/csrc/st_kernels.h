@@ -32,7 +32,7 @@ enum KernelSlot {
     // fused launches (own-pixel consumer passes appended to their producer); bytes = sum of the reference passes they execute
     KS_PRIM_VISIBILITY_REPROJECTION, KS_DI_RESOLVING_REPROJECT, KS_GI_PREVIEW_RESOLVE, KS_GI_PREVIEW_RESOLVE_REPROJECT, KS_DENOISE_WAVELET_12,
     KS_GI_REPROJECTION_TEMPORAL, KS_DI_SAMPLING_TEMPORAL, KS_DI_SPATIAL_FUSED, KS_GI_SPATIAL_FUSED,
-    KS_GI_PREVIEW_BOTH, KS_GI_PREVIEW_BOTH_NO_REPROJECT, KS_GI_PREVIEW_LATE, KS_DENOISE_WAVELET_COMPOSE,
+    KS_GI_PREVIEW_BOTH, KS_GI_PREVIEW_BOTH_NO_REPROJECT, KS_GI_PREVIEW_LATE, KS_DENOISE_WAVELET_COMPOSE, KS_GI_SAMPLING_AB,
     KS_DENOISE_WAVELET_FAMILY,  // profiling only (ST_PROFILE_GROUP_ATROUS): the a-trous chain's launches timed as ONE interval
     KS_COUNT
 };
@@ -60,6 +60,7 @@ inline const KernelInfo& kernel_info(int slot) {
         {"gi_preview x2+gi_resolving", 160.f + 160.f + 256.f, false},
         {"gi_preview 2nd pass (pixels that resample)", 0.f, false},  // its bytes are credited to the launch above
         {"denoise_wavelet+composition", 84.f + 112.f, false},
+        {"gi_sampling_a+b", 80.f + 144.f, true},
         {"a-trous chain (one timed interval)", 0.f, false},  // bytes: the sum its member launches are credited
     };
     return k[slot];

@@ -39,6 +39,7 @@ SLOT_SYMBOLS = {
     "denoise_wavelet+composition": ["denoise_wavelet_far<true>"],
     # tracing kernels: <LDS scene, [REPROJECT,] stack entry>; whichever instance the scene selected
     "prim_visibility+frame_reprojection": ["prim_visibility<true,true,u16>", "prim_visibility<false,true,u16>", "prim_visibility<false,true,u32>"],
+    "gi_sampling_a+b": ["gi_sampling_ab<true,u16>", "gi_sampling_ab<false,u16>", "gi_sampling_ab<false,u32>"],
     "di_sampling+di_temporal": ["di_sampling_temporal<true,u16>", "di_sampling_temporal<false,u16>", "di_sampling_temporal<false,u32>"],
     "di_spatial_pick+trace+sample": ["di_spatial_fused<true,u16>", "di_spatial_fused<false,u16>", "di_spatial_fused<false,u32>"],
     "di_resolving+denoise_reproject": ["di_resolving<true,true,u16>", "di_resolving<false,true,u16>", "di_resolving<false,true,u32>"],
