@@ -190,6 +190,7 @@ void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST
 // ---------------------------------------------------------------- di_resolving.rs:3-119
 // REPROJECT: the DI half of frame_denoising.rs::reproject is appended (it reads only this pixel's fresh diffuse sample
 // plus previous-frame planes).
+// (76 VGPRs with REPROJECT = 6 waves per SIMD; asking for 7 spills 4 registers and measures 78.2 -> 79.9 us.)
 template <bool LDS_SCENE, bool REPROJECT, class SE>
 __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     ST_SCENE_PROLOGUE
