@@ -173,7 +173,7 @@ void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAU
 // Wherever pass b runs pass a has run (tracing: both need the pixel's surface; validation: both need a non-empty reservoir).
 // 6 waves per SIMD: the allocator fits 80 VGPRs without a spill where it would take 83 (5 waves): 96.5 -> 93.2 us, dungeon 356 -> 345.
 template <bool LDS_SCENE, class SE>
-__global__ __launch_bounds__(kBlockThreads, 6) void k_gi_sampling_ab(const KArgs a_in, uint32_t seed_a, uint32_t seed_b) {
+__global__ __launch_bounds__(kBlockThreads, 6) void k_gi_sampling_ab(const KArgs a_in, uint32_t seed_a, uint32_t seed_b, uint32_t reproject) {
     ST_SCENE_PROLOGUE
     __shared__ SE lds[kStackWords];
     uint32_t used_ = 0u;
@@ -183,7 +183,20 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_gi_sampling_ab(const KArgs
     const U2 pos = tracing ? resolve_checkerboard(gid, a.frame / 2u) : resolve_checkerboard(gid, a.frame);
     if (!owns_pixel(a, pos)) return;
     const Hit prim_hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
-    const GiReservoir vres = tracing ? gi_empty() : gi_read(a.gi_res[2], screen_to_idx(a, pos), a.width * a.height);
+    GiReservoir vres = gi_empty();
+    if (!tracing) {
+        const uint32_t n = a.width * a.height;
+        if (reproject && hit_some(prim_hit)) {
+            // validation frames of a whole frame: gi_reprojection.rs for this pixel runs here (and again in k_gi_temporal<true>, which
+            // stores it) instead of as a launch of its own — what that pass would have stored, through the store / load codec
+            GiReservoir r = gi_empty();
+            const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, pos));
+            if (rp.confidence > 0.0f) r = gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n);
+            r.confidence = 1.0f;
+            r.s.v1_point = prim_hit.point;
+            vres = gi_after_store(r);
+        } else vres = gi_read(a.gi_res[2], screen_to_idx(a, pos), n);  // a pixel without a surface: the slot gi_reprojection leaves alone
+    }
     float4 d0, d1, d2;
     if (!gi_sampling_a_cell(a, seed_a, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, &d0, &d1, &d2)) return;
     count_rays(a, used_);
@@ -193,7 +206,9 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_gi_sampling_ab(const KArgs
     if (!hit_some(prim_hit)) return;  // validation frames: pass a re-traces a reservoir wherever one is, pass b wants a surface too
     gi_sampling_b_cell(a, seed_b, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, d0, d1, d2);
 }
-void launch_gi_sampling_ab(const KArgs& a, uint32_t seed_a, uint32_t seed_b, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_ab, true, s, a, seed_a, seed_b); }
+void launch_gi_sampling_ab(const KArgs& a, uint32_t seed_a, uint32_t seed_b, bool reproject, hipStream_t s) {
+    ST_LAUNCH_TRACE(k_gi_sampling_ab, true, s, a, seed_a, seed_b, reproject ? 1u : 0u);
+}
 
 // ---------------------------------------------------------------- gi_temporal_resampling.rs:3-156
 // REPROJECT: gi_reprojection.rs for the same pixel runs right here (tracing frames only, where this pass is the only reader

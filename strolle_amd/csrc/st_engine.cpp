@@ -583,6 +583,7 @@ struct Engine {
     bool fuse_wavelet = true;  // ST_NO_FUSE_WAVELET=1: strides 1 and 2 of the a-trous chain as two launches
     bool fuse_spatial = true;  // ST_NO_FUSE_SPATIAL=1: DI spatial resampling as three launches
     bool fuse_gi_sampling = true;  // ST_NO_FUSE_GI_SAMPLING=1: GI sampling passes a and b as two launches
+    bool fuse_gi_valid = true;     // ST_NO_FUSE_GI_VALIDATION=1: gi_reprojection is a launch of its own on validation frames too
     bool fuse_di_head = true, fuse_gi_reproj = true;  // A/B switches for the two newest fusions (ST_NO_FUSE_DI_HEAD / ST_NO_FUSE_GI_REPROJECTION)
     bool fuse = true;       // run own-pixel consumer passes inside their producer's launch (ST_NO_FUSE=1: one launch per reference pass)
     // ... and for the SVGF passes (ST_TILE_MAP_DENOISE): mode 2 keeps the halo rows of the LDS windows and the a-trous taps
@@ -612,6 +613,7 @@ struct Engine {
         if (const char* k = getenv("ST_NO_FUSE_DI_HEAD")) fuse_di_head = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_SPATIAL")) fuse_spatial = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_GI_SAMPLING")) fuse_gi_sampling = atoi(k) == 0;
+        if (const char* k = getenv("ST_NO_FUSE_GI_VALIDATION")) fuse_gi_valid = atoi(k) == 0;
         if (const char* k = getenv("ST_NO_FUSE_GI_REPROJECTION")) fuse_gi_reproj = atoi(k) == 0;
         if (const char* no = getenv("ST_NO_OVERLAP")) overlap = atoi(no) == 0;
         if (const char* k = getenv("ST_SIDE_PRIORITY")) side_priority = atoi(k);
@@ -1386,14 +1388,17 @@ struct Engine {
             // GI up to the first preview pass: touches only reservoirs, gi_d0..2 and read-only frame inputs
             auto do_gi_head = [&] {
                 // on tracing frames gi_temporal is the only reader of the reprojected reservoirs and does the reprojection itself
-                const bool fuse_gi_reprojection = fuse && fuse_gi_reproj && tracing;
+                // ... and on validation frames of a whole frame both of its readers — the sampling launch for the half of the pixels it
+                // re-traces, then gi_temporal, which stores it — do it for themselves (ST_NO_FUSE_GI_VALIDATION=1: a launch of its own)
+                const bool fuse_gi_validation = fuse && fuse_gi_reproj && fuse_gi_sampling && fuse_gi_valid && !tracing && whole_graph;
+                const bool fuse_gi_reprojection = (fuse && fuse_gi_reproj && tracing) || fuse_gi_validation;
                 auto temporal = [&] {
                     if (fuse_gi_reprojection) run(KS_GI_REPROJECTION_TEMPORAL, ST_PASS_GI_REPROJECTION | ST_PASS_GI_TEMPORAL, [&] { L.launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), true, cur); });
                     else run(KS_GI_TEMPORAL, ST_PASS_GI_TEMPORAL, [&] { L.launch_gi_temporal(a, seed(SEED_GI_TEMPORAL), false, cur); });
                 };
                 if (!fuse_gi_reprojection) run(KS_GI_REPROJECTION, ST_PASS_GI_REPROJECTION, [&] { L.launch_gi_reprojection(a, cur); });
                 auto sampling = [&] {
-                    if (fuse && fuse_gi_sampling) { run(KS_GI_SAMPLING_AB, ST_PASS_GI_SAMPLING_A | ST_PASS_GI_SAMPLING_B, [&] { L.launch_gi_sampling_ab(a, seed(SEED_GI_SAMPLING_A), seed(SEED_GI_SAMPLING_B), cur); }); return; }
+                    if (fuse && fuse_gi_sampling) { run(KS_GI_SAMPLING_AB, ST_PASS_GI_SAMPLING_A | ST_PASS_GI_SAMPLING_B, [&] { L.launch_gi_sampling_ab(a, seed(SEED_GI_SAMPLING_A), seed(SEED_GI_SAMPLING_B), fuse_gi_validation, cur); }); return; }
                     run(KS_GI_SAMPLING_A, ST_PASS_GI_SAMPLING_A, [&] { L.launch_gi_sampling_a(a, seed(SEED_GI_SAMPLING_A), cur); });
                     run(KS_GI_SAMPLING_B, ST_PASS_GI_SAMPLING_B, [&] { L.launch_gi_sampling_b(a, seed(SEED_GI_SAMPLING_B), cur); });
                 };

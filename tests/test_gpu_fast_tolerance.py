@@ -245,7 +245,7 @@ def test_gi_history_pointer_swap_is_unobservable_through_the_buffers():
         e.close()
 
 
-@pytest.mark.parametrize("switch", ["ST_NO_PREVIEW_BOTH", "ST_NO_VARIANCE_IN_REPROJECT", "ST_KEEP_SCRATCH", "ST_KEEP_ALL_PLANES", "ST_NO_FUSE_COMPOSE", "ST_NO_GI_ALIAS", "ST_NO_OVERLAP"])
+@pytest.mark.parametrize("switch", ["ST_NO_PREVIEW_BOTH", "ST_NO_VARIANCE_IN_REPROJECT", "ST_KEEP_SCRATCH", "ST_KEEP_ALL_PLANES", "ST_NO_FUSE_COMPOSE", "ST_NO_GI_ALIAS", "ST_NO_OVERLAP", "ST_NO_FUSE_GI_VALIDATION"])
 def test_fast_build_whole_graph_switches_agree_with_the_default(switch):
     """The fast build's whole-frame launch structures against each other: the default (both GI preview passes in one launch,
     variance in the reproject stages, dead scratch stores skipped, the lean frame, composition inside the last a-trous pass,

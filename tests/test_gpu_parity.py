@@ -927,7 +927,7 @@ def test_profile_flags_timing_and_traversal_bytes():
     {"ST_NO_FUSE": "1"},
     {"ST_NO_OVERLAP": "1", "ST_NO_FUSE_WAVELET": "1"},
     {"ST_TILE_MAP": "0"},
-    {"ST_NO_PREVIEW_BOTH": "1", "ST_NO_VARIANCE_IN_REPROJECT": "1", "ST_KEEP_SCRATCH": "1", "ST_DI_HEAD_ON_MAIN": "0"},
+    {"ST_NO_PREVIEW_BOTH": "1", "ST_NO_VARIANCE_IN_REPROJECT": "1", "ST_KEEP_SCRATCH": "1", "ST_DI_HEAD_ON_MAIN": "0", "ST_NO_FUSE_GI_VALIDATION": "1"},
     {"ST_NO_FUSE_SPATIAL": "1", "ST_NO_FUSE_DI_HEAD": "1", "ST_NO_FUSE_GI_REPROJECTION": "1", "ST_NO_FUSE_GI_SAMPLING": "1"},
 ], ids=lambda s: "+".join(sorted(s)))
 def test_every_scheduling_variant_produces_the_same_bits(switches):
