@@ -414,6 +414,7 @@ def main():
         np.save(args.dump_frame, frame.cpu().numpy())
     headline = (args.scene, args.mode) == ("cornell", "image")
     engine_exact = engine.exact
+    bvh_depth = engine.bvh_depth()   # read here: the N > 1 extras close this job's engine
     extras = {}
     if not args.no_extras and world == 1 and headline:
         # -- the headline under motion (bevy-strolle/examples/cornell.rs animates its light every frame; the static figure
@@ -512,7 +513,7 @@ def main():
                                  "dungeon134k": "SYNTHETIC: the dungeon with every triangle split into 16, same materials and lights"}[args.scene],
                        "arithmetic": "exact (bit-identical to the CPU oracle)" if engine_exact else "fast (hardware rcp/sqrt/exp/log, FMA contraction; traversal exact; tolerances in tests/test_gpu_fast_tolerance.py)",
                        "width": width, "height": height,
-                       "bvh_deepest_internal_chain": engine.bvh_depth()[0], "bvh_stack_entries": engine.bvh_depth()[1],   # deeper than the stack = dropped pushes (st_debug_bvh_depth)
+                       "bvh_deepest_internal_chain": bvh_depth[0], "bvh_stack_entries": bvh_depth[1],   # deeper than the stack = dropped pushes (st_debug_bvh_depth)
                        "per_gpu_rows": band[1] - band[0], "apron_rows": (args.apron if needs_apron else 0) if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
                        **({"DEBUG_NOT_A_RESULT": "ranks share cuda:0, gather through gloo + host copies"} if debug_shared else {}),
