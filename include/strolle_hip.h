@@ -14,11 +14,8 @@
  * joins it into the caller's stream before the frame's last kernel. Frames may be enqueued
  * back to back without host synchronisation. st_tick queues its uploads on the stream it was given (from
  * page-locked copies, so the scene may be edited again as soon as it returns); st_render_camera orders itself behind them.
- * Environment switches (read once per engine; every combination renders the same bits): ST_NO_OVERLAP=1
- * single stream; ST_NO_FUSE=1 one launch per reference pass (ST_NO_FUSE_SPATIAL / _DI_HEAD /
- * _GI_REPROJECTION=1 undo one fusion); ST_TILE_MAP=0|1|2 and ST_TILE_MAP_DENOISE block->tile mapping;
- * ST_NO_FUSE_WAVELET=1 strides 1 and 2 of the a-trous chain as two launches; ST_COMPACT=1 compacted shadow-ray kernel; ST_NO_PACKED_BASE=1; ST_NO_STAGING=1 st_tick uploads from
- * pageable memory and joins its stream; ST_NO_DOUBLE_BUFFER=1 scene changes update the device arrays in place; ST_TICK_TIMING=1 host refresh timing on stderr.
+ * Scheduling and tuning switches: StTuning below (st_engine_get_tuning / st_engine_set_tuning; environment variables of the
+ * same meaning override the defaults when an engine is created).
  */
 #ifndef STROLLE_HIP_H
 #define STROLLE_HIP_H
@@ -43,7 +40,12 @@ enum StStatus {
     ST_ERR_ATLAS_FULL = 6,       /* reference: warn + drop (images.rs:71-79) */
     ST_ERR_IO = 7,               /* scene ingest: a file could not be read */
     ST_ERR_PARSE = 8,            /* scene ingest: malformed glTF / GLB / PNG; st_last_error() says where */
-    ST_ERR_UNSUPPORTED = 9       /* scene ingest: valid file using something this loader does not read (JPEG, Draco, ...) */
+    ST_ERR_UNSUPPORTED = 9,      /* scene ingest: valid file using something this loader does not read (JPEG, Draco, ...) */
+    ST_ERR_BVH_TOO_DEEP = 10,    /* st_tick: the tree's deepest chain of internal nodes exceeds the kernels' 24-entry traversal stack
+                                  * (strolle-gpu/src/lib.rs:76; the reference indexes past its stack array there). The scene IS uploaded and
+                                  * renders — pushes beyond the stack are dropped, so geometry behind them can be missed — but the tick
+                                  * says so instead of returning ST_OK; StTuning::allow_deep_bvh = 1 turns the status back into a warning */
+    ST_ERR_DIST = 11             /* st_dist_*: the collective transport failed (RCCL status in st_last_error()) */
 };
 
 /* strolle/src/mesh_triangle.rs:6-33 — object-space triangle */
@@ -189,6 +191,53 @@ int st_camera_set_rows(StEngine* e, StHandle camera, uint32_t y0, uint32_t y1);
 enum StOutputFormat { ST_FORMAT_RGBA32F = 0, ST_FORMAT_RGBA16F = 1, ST_FORMAT_RGBA8_UNORM_SRGB = 2, ST_FORMAT_BGRA8_UNORM_SRGB = 3 };
 int st_camera_set_output_format(StEngine* e, StHandle camera, int format);
 
+/* ---- scheduling / tuning switches of one engine (NEW seam). Every field selects another launch structure or host policy for
+ * the SAME pass graph: in the exact build every combination renders the same bits (tests/test_gpu_parity.py runs several
+ * against the oracle). Defaults are what bench.py times. Get, change, set — between frames; `struct_size` must be
+ * sizeof(StTuning). Environment variables (read once, when the engine is created) override the defaults:
+ *   ST_NO_OVERLAP ST_NO_FUSE ST_NO_FUSE_DI_HEAD ST_NO_FUSE_SPATIAL ST_NO_FUSE_GI_SAMPLING ST_NO_FUSE_GI_VALIDATION
+ *   ST_NO_FUSE_GI_REPROJECTION ST_NO_FUSE_WAVELET ST_NO_FUSE_COMPOSE ST_NO_PREVIEW_BOTH ST_NO_VARIANCE_IN_REPROJECT
+ *   ST_NO_VARIANCE_COMPACTION ST_KEEP_ALL_PLANES ST_KEEP_SCRATCH ST_NO_GI_ALIAS ST_NO_STAGING ST_NO_DOUBLE_BUFFER ST_NO_PACKED_BASE
+ *   ST_NO_ANYHIT_FAST ST_NO_OCCLUDER_TABLE ST_ALLOW_DEEP_BVH (=1 clears / sets the field), ST_DI_HEAD_ON_MAIN ST_TILE_MAP
+ *   ST_TILE_MAP_DENOISE ST_SIDE_PRIORITY ST_TICK_TIMING ST_OCCLUDER_TABLE_LOG2 ST_DEVICE_BAKE (= value). */
+typedef struct StTuning {
+    uint32_t struct_size;
+    uint32_t overlap;               /* 1: two HIP streams per camera, software-pipelined across frames */
+    uint32_t fuse;                  /* 1: own-pixel consumer passes ride in their producer's launch (0: one launch per reference pass) */
+    uint32_t fuse_di_head;          /* DI sampling + temporal resampling in one launch */
+    uint32_t fuse_spatial;          /* DI / GI spatial resampling: pick + trace + sample per 2x1 cell in one launch */
+    uint32_t fuse_gi_sampling;      /* GI sampling passes a + b in one launch */
+    uint32_t fuse_gi_validation;    /* validation frames: gi_reprojection done by its two readers */
+    uint32_t fuse_gi_reprojection;  /* tracing frames: gi_reprojection inside gi_temporal */
+    uint32_t fuse_wavelet;          /* a-trous strides 1 and 2 as one launch */
+    uint32_t fuse_compose;          /* fast build: frame composition inside the last a-trous pass */
+    uint32_t preview_both;          /* both GI preview passes + resolving in one launch, flagged pixels served afterwards */
+    uint32_t variance_in_reproject; /* estimate_variance's long-history branch inside the reproject stages */
+    uint32_t variance_compaction;   /* ... and its short-history pixels through a compacted list of flagged tile groups (ballot + one
+                                     * atomic append per flagged group) walked by a small persistent grid, instead of a full-screen launch */
+    uint32_t lean_frame;            /* fast build: planes nothing reads again are not stored (st_debug_keep_all_planes) */
+    uint32_t skip_scratch_stores;   /* fused DI spatial launch keeps its scratch records in registers */
+    uint32_t di_head_on_main;       /* DI sampling + temporal on the caller's stream (0: on the side stream) */
+    uint32_t alias_gi_history;      /* fast build: GI history hand-over by pointer swap instead of gi_resolving's copy */
+    uint32_t tile_map;              /* blockIdx -> 8x8 tile mapping of the ReSTIR passes: 0 XCD bands, 1 hardware order, 2 chunks of 4 tile rows */
+    uint32_t tile_map_denoise;      /* the same for the SVGF passes */
+    int32_t side_priority;          /* > 0: the side stream gets the device's highest stream priority, < 0 the lowest */
+    uint32_t staging;               /* st_tick uploads through page-locked staging slots (0: from pageable memory, joining the stream) */
+    uint32_t double_buffer;         /* scene / light arrays exist twice on the device; a change fills the copy no frame in flight reads */
+    uint32_t packed_base;           /* per-material packed base colour (0: primary visibility packs it per pixel) */
+    uint32_t tick_timing;           /* 1: host-side cost of a scene refresh on stderr */
+    uint32_t anyhit_fast;           /* fast build: shadow rays (boolean result only, ray.rs:84-112) walk with fast arithmetic
+                                     * (st_device.h any_hit_fast); 0: the contract loop. Always 0 while traversal bytes are counted */
+    uint32_t occluder_table_log2;   /* fast build: world-space last-occluder table for rays towards lights, 2^n slots of 4 B (0: off) */
+    uint32_t occluder_min_texels;   /* ... used only for device streams of at least this many float4 (tiny scenes live in LDS) */
+    uint32_t allow_deep_bvh;        /* 1: a tree deeper than the traversal stack is a warning on stderr, not ST_ERR_BVH_TOO_DEEP */
+    uint32_t device_bake;           /* 1: instances are baked into world space ON THE DEVICE from object-space meshes uploaded once
+                                     * (k_bvh.hip k_bvh_bake) when only transforms changed under ST_BVH_REFIT_DEVICE; 0: on the host */
+    uint32_t _reserved[4];
+} StTuning;
+int st_engine_get_tuning(StEngine* e, StTuning* out);
+int st_engine_set_tuning(StEngine* e, const StTuning* tuning);
+
 /* Arithmetic of the per-pixel kernels. Both builds of every kernel live in the library (csrc/Makefile):
  * ST_ARITH_FAST (default) uses the hardware's reciprocal / square root / exp2 / log2 / sin / cos (1 ulp each) and lets the
  * compiler contract a*b+c into FMAs, everywhere except the ray-generation + BVH-traversal compare chain (Camera::ray,
@@ -263,7 +312,7 @@ int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
 /* Host-side copies of what st_tick uploads: what = 0 BVH stream as the reference's serializer writes it (float4), 1
  * triangles in the reference's 144-B layout, 2 lights (112 B), 3 materials (112 B), 4 the BVH stream in its device form
  * (every entry four float4: internal nodes with the far child's byte offset, leaf entries followed by the triangle's
- * hit-test record; st_types.h), 5 the optional 4-wide nodes, 6 the device form read back FROM the device (live copy),
+ * hit-test record; st_types.h), 6 the device form read back FROM the device (live copy),
  * 7-13 the inputs of the device refit (k_bvh.hip; uint32 unless noted): 7 parent of every entry (entry << 1 | child slot),
  * 8 LDS slot of every internal entry (bit 31: a task's root), 9 work items (bit 31: root of a finished task), 10 batch offsets
  * into 9, 11 (first batch, batches) per launch, 12 leaf entry of every triangle slot, 13 triangle bounds (two float4 per slot).

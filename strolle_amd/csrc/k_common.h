@@ -52,28 +52,28 @@ constexpr uint32_t kStack16Texels = 4u * 65536u;
 #ifdef ST_NO_LDS_SCENE  // experiment switch (tools/ab_bench.sh): small scenes traverse through the vector L1 like large ones
 inline bool scene_fits_lds(const KArgs&) { return false; }
 #else
-inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len + a.bvh_wide_len <= kLdsSceneTexels; }
+inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len <= kLdsSceneTexels; }
 #endif
 // first statement of a tracing kernel whose parameter is `a_in`: defines `a`, the arguments the body uses
 #define ST_SCENE_PROLOGUE                                                                                                        \
     __shared__ float4 s_scene_bvh_[LDS_SCENE ? kLdsSceneTexels : 1];                                                             \
     KArgs a = a_in;                                                                                                              \
     if (LDS_SCENE) {                                                                                                             \
-        for (uint32_t i_ = threadIdx.x; i_ < a_in.bvh_len + a_in.bvh_wide_len; i_ += kBlockThreads) s_scene_bvh_[i_] = a_in.bvh[i_];                 \
+        for (uint32_t i_ = threadIdx.x; i_ < a_in.bvh_len; i_ += kBlockThreads) s_scene_bvh_[i_] = a_in.bvh[i_];                 \
         __syncthreads();                                                                                                         \
         a.bvh = s_scene_bvh_;                                                                                                    \
     }
 #define ST_LAUNCH_TRACE(kernel_tmpl, half, stream, ...)                                                             \
     do {                                                                                                            \
         if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL2(kernel_tmpl, true, uint16_t), half, stream, __VA_ARGS__);          \
-        else if (a.bvh_len + a.bvh_wide_len < kStack16Texels) ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint16_t), half, stream, __VA_ARGS__);   \
+        else if (a.bvh_len < kStack16Texels) ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint16_t), half, stream, __VA_ARGS__);   \
         else ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint32_t), half, stream, __VA_ARGS__);                           \
     } while (0)
 // the same for kernels with one more leading bool (REPROJECT)
 #define ST_LAUNCH_TRACE_B(kernel_tmpl, flag, half, stream, ...)                                                         \
     do {                                                                                                                \
         if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL3(kernel_tmpl, true, flag, uint16_t), half, stream, __VA_ARGS__);        \
-        else if (a.bvh_len + a.bvh_wide_len < kStack16Texels) ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint16_t), half, stream, __VA_ARGS__); \
+        else if (a.bvh_len < kStack16Texels) ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint16_t), half, stream, __VA_ARGS__); \
         else ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint32_t), half, stream, __VA_ARGS__);                         \
     } while (0)
 #define ST_TPL(k, t) k<t>

@@ -229,18 +229,12 @@ ST_D WaveletOut wavelet_end(const WaveletCenter& c) {
 // one pixel of a zero-jitter pass whose window is in LDS: `lc` = the pixel's texel, taps at +-S texels / rows (pitch P).
 // Texels outside the viewport were staged with depth 0, which is skipped like an out-of-bounds or sky tap. Returns false
 // for a sky pixel (the reference copies the direct colour and leaves the indirect output alone).
-// `s_sl`: sqrt_luma2() of every staged texel with a surface — only with -DST_WAVELET_SL. Measured (round 3, same-box A/B): evaluating
-// sqrt(luma) once per staged texel instead of once per tap (2 square roots + 6 FMAs fewer per tap, one 8-B LDS read more)
-// changes nothing: strides 1+2 69.6 vs 68.5 us, stride 4 39.7 vs 39.2 us. The default recomputes per tap (8 B of LDS per texel less).
+// (Evaluating sqrt(luma) once per staged texel instead of once per tap measured neutral in round 3 — tools/experiments/README.md.)
 template <int S, int P>
-ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const float4* s_gi, const f2* s_sl, int lc, float strength) {
+ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const float4* s_gi, int lc, float strength) {
     const float4 csn = s_sn[lc], cdi = s_di[lc], cgi = s_gi[lc];
     if (csn.w == 0.0f) { WaveletOut o; o.di = cdi; o.gi = cgi; o.lit = false; return o; }
-#ifndef ST_WAVELET_SL
     WaveletCenter c = wavelet_begin(csn, cdi, cgi, strength, sqrt_luma2(cdi, cgi));
-#else
-    WaveletCenter c = wavelet_begin(csn, cdi, cgi, strength, s_sl[lc]);
-#endif
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
@@ -248,11 +242,7 @@ ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const 
         float dw, nw;
         if (!wavelet_shared(c, s_sn[lt], &dw, &nw)) continue;
         const float4 tdi = s_di[lt], tgi = s_gi[lt];
-#ifndef ST_WAVELET_SL
         wavelet_tap(c, tdi, tgi, sqrt_luma2(tdi, tgi), dw, nw);
-#else
-        wavelet_tap(c, tdi, tgi, s_sl[lt], dw, nw);
-#endif
     }
     return wavelet_end(c);
 }
@@ -289,7 +279,7 @@ inline uint32_t wavelet_blocks(const KArgs& a, uint32_t block_w = kWvW) {
 }
 // stages the (kWvW + 2 HALO) x (kWvH + 2 HALO) window around the block into LDS (row pitch P texels)
 template <int HALO, int P, int BW = kWvW>
-ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* di_in, const float4* gi_in, float4* s_sn, float4* s_di, float4* s_gi, f2* s_sl) {
+ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* di_in, const float4* gi_in, float4* s_sn, float4* s_di, float4* s_gi) {
     constexpr int WW = BW + 2 * HALO, WH = kWvH + 2 * HALO;
     for (int i = (int)threadIdx.x; i < WW * WH; i += kWvThreads) {
         const int ry = i / WW, rx = i - ry * WW;
@@ -299,9 +289,6 @@ ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* d
             const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
             const float4 tsn = a.sn[at], tdi = di_in[at], tgi = gi_in[at];
             s_sn[li] = tsn; s_di[li] = tdi; s_gi[li] = tgi;
-#ifdef ST_WAVELET_SL
-            if (tsn.w != 0.0f) s_sl[li] = sqrt_luma2(tdi, tgi);  // sky texels are never tapped and never a centre that filters
-#endif
         } else {
             s_sn[li] = f4z();
         }
@@ -315,22 +302,15 @@ ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* d
 // an internal pair of planes instead (st_engine.cpp) and the stash planes first receive the stride-2 output.
 __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out,
                                                                    const float4* gi_in, float4* gi_mid, float4* gi_out) {
-#ifndef ST_W12_PITCH
-#define ST_W12_PITCH 38  // 40,128 B of LDS: four blocks per CU (pitch 40: three); measured 68.9 -> 63.3 us. A wave's ds_read_b128 covers whole 16-texel row runs either way
-#endif
-    constexpr int HALO = 3, WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO, P = ST_W12_PITCH;  // 38 x 22 texels
+    // pitch 38: 40,128 B of LDS, four blocks per CU (pitch 40: three; measured 68.9 -> 63.3 us). A wave's ds_read_b128 covers whole 16-texel row runs either way
+    constexpr int HALO = 3, WW = kWvW + 2 * HALO, WH = kWvH + 2 * HALO, P = 38;  // 38 x 22 texels
     constexpr int RW = kWvW + 4, RH = kWvH + 4;                                   // 36 x 20: where the stride-1 pass must run
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
     __shared__ float4 s_gi[P * WH];
-#ifdef ST_WAVELET_SL
-    __shared__ f2 s_sl[P * WH];
-#else
-    f2* s_sl = nullptr;
-#endif
     const WaveletBlock blk = wavelet_block(a);
     if (!blk.valid) return;
-    wavelet_stage<HALO, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi, s_sl);
+    wavelet_stage<HALO, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi);
     __syncthreads();
     // stride-1 pass over the 36 x 20 region (row-major over the threads: 1.4 pixels each)
     float4 r_di[2], r_gi[2]; int r_at[2];
@@ -342,7 +322,7 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
         const int ry = idx / RW, rx = idx - ry * RW;
         const int lc = (ry + 1) * P + rx + 1;
         r_at[it] = lc;
-        const WaveletOut o = wavelet_pixel_lds<1, P>(s_sn, s_di, s_gi, s_sl, lc, strength0);
+        const WaveletOut o = wavelet_pixel_lds<1, P>(s_sn, s_di, s_gi, lc, strength0);
         r_di[it] = o.di; r_gi[it] = o.gi;  // sky (or outside the viewport): the indirect colour is never read, as a tap or as a centre
         const bool lit = o.lit;
         // the block's own pixels: this is what the stand-alone stride-1 pass stores
@@ -357,9 +337,6 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
 #pragma unroll
     for (int it = 0; it < 2; it++) if (r_at[it] >= 0) {
         s_di[r_at[it]] = r_di[it]; s_gi[r_at[it]] = r_gi[it];
-#ifdef ST_WAVELET_SL
-        s_sl[r_at[it]] = sqrt_luma2(r_di[it], r_gi[it]);  // (a sky texel's entry is never read)
-#endif
     }
     __syncthreads();
     // stride-2 pass for the block's own pixels
@@ -367,105 +344,32 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
     const int32_t px = blk.x0 + x, py = blk.y0 + y;
     if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) return;
     const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
-    const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, s_sl, (y + HALO) * P + x + HALO, strength1);
+    const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, (y + HALO) * P + x + HALO, strength1);
     di_out[center] = o.di;
     // On a sky pixel the stride-2 pass leaves its indirect output alone, and what the reference's stash plane holds there is
     // the variance pass's copy of the input colour — which this launch group never stored there: `o.gi` is that colour.
     gi_out[center] = o.gi;
 }
 
-// ---- the same launch with 64 x 16-pixel blocks (512 threads, 76 KB of LDS, two blocks per CU). The 32 x 16 form runs the
-// stride-1 pass for 36 x 20 = 720 pixels on 512 threads — two rounds, the second 41 % full — and stages 1.63 texels per
-// pixel; here 68 x 20 = 1360 pixels take three rounds (88 % full), the stride-2 pass two full ones, and the window is 1.50
-// texels per pixel: 2.5 thread-rounds of tap arithmetic per pixel instead of 3.0. MEASURED SLOWER (round 3, same-box A/B: 78.1 against
-// 69.1 us on Cornell, 85.2 against 74.6 on the dungeon): two blocks per CU leave 4 waves per SIMD where the 32 x 16 form has 6, and
-// these passes live on occupancy, not on arithmetic slots. Kept behind -DST_W12_WIDE.
-constexpr int kW12W = 64;
-__global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12_wide(const KArgs a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out,
-                                                                        const float4* gi_in, float4* gi_mid, float4* gi_out) {
-    constexpr int HALO = 3, WW = kW12W + 2 * HALO, WH = kWvH + 2 * HALO, P = 72;  // 70 x 22 texels, pitch 72 = 8 mod 16
-    constexpr int RW = kW12W + 4, RH = kWvH + 4;                                  // 68 x 20: where the stride-1 pass must run
-    constexpr int ROUNDS = (RW * RH + kWvThreads - 1) / kWvThreads;               // 3
-    static_assert(P >= WW && P % 16 == 8, "pitch");
-    __shared__ float4 s_sn[P * WH];
-    __shared__ float4 s_di[P * WH];
-    __shared__ float4 s_gi[P * WH];
-#ifdef ST_WAVELET_SL
-    __shared__ f2 s_sl[P * WH];
-#else
-    f2* s_sl = nullptr;
-#endif
-    const WaveletBlock blk = wavelet_block<kW12W>(a);
-    if (!blk.valid) return;
-    wavelet_stage<HALO, P, kW12W>(a, blk, di_in, gi_in, s_sn, s_di, s_gi, s_sl);
-    __syncthreads();
-    float4 r_di[ROUNDS], r_gi[ROUNDS]; int r_at[ROUNDS];
-#pragma unroll
-    for (int it = 0; it < ROUNDS; it++) {
-        const int idx = (int)threadIdx.x + it * kWvThreads;
-        r_at[it] = -1;
-        if (idx >= RW * RH) continue;
-        const int ry = idx / RW, rx = idx - ry * RW;
-        const int lc = (ry + 1) * P + rx + 1;
-        r_at[it] = lc;
-        const WaveletOut o = wavelet_pixel_lds<1, P>(s_sn, s_di, s_gi, s_sl, lc, strength0);
-        r_di[it] = o.di; r_gi[it] = o.gi;
-        const int32_t px = blk.x0 - 2 + rx, py = blk.y0 - 2 + ry;
-        if (rx >= 2 && rx < 2 + kW12W && ry >= 2 && ry < 2 + kWvH && px < (int32_t)a.width && py < (int32_t)a.height && (uint32_t)py >= a.row0 && (uint32_t)py < a.row1) {
-            const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
-            di_mid[center] = r_di[it];
-            if (o.lit) gi_mid[center] = r_gi[it];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ROUNDS; it++) if (r_at[it] >= 0) {
-        s_di[r_at[it]] = r_di[it]; s_gi[r_at[it]] = r_gi[it];
-#ifdef ST_WAVELET_SL
-        s_sl[r_at[it]] = sqrt_luma2(r_di[it], r_gi[it]);
-#endif
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; it++) {   // stride-2 pass: thread t -> pixels (t % 64, t / 64) and (t % 64, t / 64 + 8)
-        const int x = (int)(threadIdx.x & 63u), y = (int)(threadIdx.x >> 6) + it * 8;
-        const int32_t px = blk.x0 + x, py = blk.y0 + y;
-        if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) continue;
-        const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
-        const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, s_sl, (y + HALO) * P + x + HALO, strength1);
-        di_out[center] = o.di;
-        gi_out[center] = o.gi;   // (see k_denoise_wavelet_12 for the sky case)
-    }
-}
-
 // ---- a single zero-jitter pass staged through LDS (stride 4; also strides 1 and 2 when run unfused)
 template <int S>
 __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_lds(const KArgs a, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out) {
-#ifdef ST_WAVELET_PITCH_LOOSE   // round 2's pitch (A/B, tools/ab_bench.sh): 56 texels for every stride
-    constexpr int WH = kWvH + 2 * S, P = (kWvW + 2 * S + 15) / 16 * 16 + 8;
-#else
     // row pitch: the smallest P >= window width with P = 8 mod 16 texels (conflict-free ds_read_b128 of two row segments per
     // wave). Stride 4: 40 texels -> 46 KB of LDS per block, three blocks per CU (56 gave 64.5 KB and two)
     constexpr int WH = kWvH + 2 * S, P = (kWvW + 2 * S + 7) / 16 * 16 + 8;
     static_assert(P >= kWvW + 2 * S && P % 16 == 8, "pitch");
-#endif
     __shared__ float4 s_sn[P * WH];
     __shared__ float4 s_di[P * WH];
     __shared__ float4 s_gi[P * WH];
-#ifdef ST_WAVELET_SL
-    __shared__ f2 s_sl[P * WH];
-#else
-    f2* s_sl = nullptr;
-#endif
     const WaveletBlock blk = wavelet_block(a);
     if (!blk.valid) return;
-    wavelet_stage<S, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi, s_sl);
+    wavelet_stage<S, P>(a, blk, di_in, gi_in, s_sn, s_di, s_gi);
     __syncthreads();
     const int x = (int)(threadIdx.x & 31u), y = (int)(threadIdx.x >> 5);
     const int32_t px = blk.x0 + x, py = blk.y0 + y;
     if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) return;
     const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
-    const WaveletOut o = wavelet_pixel_lds<S, P>(s_sn, s_di, s_gi, s_sl, (y + S) * P + x + S, strength);
+    const WaveletOut o = wavelet_pixel_lds<S, P>(s_sn, s_di, s_gi, (y + S) * P + x + S, strength);
     di_out[center] = o.di;
     if (o.lit) gi_out[center] = o.gi;
 }
@@ -582,13 +486,8 @@ void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float stren
 }
 void launch_denoise_wavelet_12(const KArgs& a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out, const float4* gi_in,
                                float4* gi_mid, float4* gi_out, hipStream_t s) {
-#ifndef ST_W12_WIDE
     const uint32_t blocks = wavelet_blocks(a);
     if (blocks) ST_KLAUNCH(k_denoise_wavelet_12, dim3(blocks), dim3(kWvThreads), s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
-#else
-    const uint32_t blocks = wavelet_blocks(a, kW12W);
-    if (blocks) ST_KLAUNCH(k_denoise_wavelet_12_wide, dim3(blocks), dim3(kWvThreads), s, a, strength0, strength1, di_in, di_mid, di_out, gi_in, gi_mid, gi_out);
-#endif
 }
 
 // ---------------------------------------------------------------- st_camera_write_buffer support

@@ -115,7 +115,7 @@ __global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, 
         const uint32_t light_id = wn.sample_int() % a.light_count;
         const float light_pdf = frcp((float)a.light_count);
         const GpuLight light = light_get(a, light_id);
-        const bool occluded = trace_any(a, light_ray_wnoise(light, wn, hit.point), lane_stack(lds), &used_);
+        const bool occluded = trace_any<1>(a, light_ray_wnoise(light, wn, hit.point), lane_stack(lds), &used_);
         count_rays(a, used_);
         if (!occluded) color = color + throughput * radiance_sum(light_radiance(light, hit)) / light_pdf;
     }
@@ -240,95 +240,8 @@ __global__ ST_KERNEL_BOUNDS void k_spatial_trace(const KArgs a_in, const float4*
     count_rays(a, used_);
     tex_write(buf_d2, a, pos, make_float4(occluded ? 0.0f : 1.0f, ray_d1.z, ray_d1.w, 0.0f));
 }
-// The same pass with ray compaction (north_star: "wavefront ballot/prefix-sum for ray compaction"). A block owns
-// kGroupsPerBlock groups of 4 tiles; its pixels' ray records are gathered with a wave ballot + prefix sum into a dense
-// pool in LDS (pixels without a ray write their zero and leave), and the block's four waves then run as persistent
-// workers: a lane whose shadow ray ends fetches the next pool entry instead of idling until its wave's longest traversal
-// is over. Which lane traces a ray changes, the ray's arithmetic does not; any-hit results do not depend on the order.
-// MEASURED SLOWER, hence opt-in (ST_COMPACT=1): 137 vs 92 us on Cornell, 152 vs 83 us on the dungeon at 1080p, although
-// lane utilisation of the plain kernel is only 0.56 / 0.32 — the resumable-step loop, the scattered result writes and the
-// LDS pool (5 instead of 8 waves per SIMD) cost more than the idle lanes did. Kept as the starting point for round 2.
-constexpr uint32_t kGroupsPerBlock = 2u, kPoolRays = kGroupsPerBlock * 256u;
-template <class SE>
-__global__ ST_KERNEL_BOUNDS void k_spatial_trace_compact(const KArgs a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2,
-                                                                          uint32_t groups_x, uint32_t tile_y0, uint32_t n_groups) {
-    __shared__ SE lds[kStackWords];
-    __shared__ float4 pool_d0[kPoolRays];
-    __shared__ float4 pool_d1[kPoolRays];
-    __shared__ uint32_t pool_px[kPoolRays];
-    __shared__ uint32_t pool_n, pool_next;
-    if (threadIdx.x == 0u) { pool_n = 0u; pool_next = 0u; }
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    // contiguous ranges of blocks per XCD (hardware sends block b to XCD b % 8); shadow rays have no neighbour taps
-    const uint32_t n_blocks = gridDim.x, q = n_blocks >> 3, r = n_blocks & 7u, xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
-    const uint32_t sb = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
-    for (uint32_t g = 0; g < kGroupsPerBlock; g++) {
-        const uint32_t lin = sb * kGroupsPerBlock + g;
-        bool has = false; float4 d0 = f4z(), d1 = f4z(); uint32_t px = 0u;
-        if (lin < n_groups) {
-            const uint32_t ty = lin / groups_x, tx = (lin - ty * groups_x) * 4u + wave;
-            const U2 pos = u2(tx * 8u + (lane & 7u), (ty + tile_y0) * 8u + (lane >> 3));
-            if (owns_pixel(a, pos)) {
-                px = pos.y * a.width + pos.x;
-                d0 = buf_d0[px]; d1 = buf_d1[px];
-                has = !is_zero(d1);
-                if (!has) buf_d2[px] = f4z();
-            }
-        }
-        const unsigned long long mask = __ballot(has);
-        uint32_t base = 0u;
-        if (lane == 0u && mask) base = atomicAdd(&pool_n, (uint32_t)__popcll(mask));
-        base = __shfl(base, 0);
-        if (has) { const uint32_t slot = base + (uint32_t)__popcll(mask & lt_mask); pool_d0[slot] = d0; pool_d1[slot] = d1; pool_px[slot] = px; }
-    }
-    __syncthreads();
-    const uint32_t total = pool_n;
-    SE* stack = lane_stack(lds);
-    bool active = false, exhausted = false;
-    Ray ray = zero_ray(); AnyHitState st = any_hit_begin(); float4 rec1 = f4z(); uint32_t px = 0u;
-    uint32_t rays_done = 0u; unsigned long long bytes = 0ull;
-    for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        // refill when a quarter of the wave idles (each refill issues the ray set-up code for the whole wave)
-        if (!exhausted && (__popcll(idle) >= 16 || idle == ~0ull)) {
-            uint32_t base = 0u;
-            if (lane == (uint32_t)__ffsll((long long)idle) - 1u) base = atomicAdd(&pool_next, (uint32_t)__popcll(idle));
-            base = __shfl(base, __ffsll((long long)idle) - 1);
-            if (!active) {
-                const uint32_t slot = base + (uint32_t)__popcll(idle & lt_mask);
-                if (slot < total) {
-                    const float4 r0 = pool_d0[slot]; rec1 = pool_d1[slot]; px = pool_px[slot];
-                    ray = make_ray(xyz(r0), normal_decode(v2(rec1.x, rec1.y)));
-                    ray.len = r0.w;
-                    st = any_hit_begin();
-                    active = true;
-                }
-            }
-            if (base + (uint32_t)__popcll(idle) >= total) exhausted = true;
-        }
-        if (!__ballot(active)) break;
-#pragma unroll 1
-        for (int burst = 0; burst < 4; burst++) {
-            if (active && any_hit_step(a, ray, stack, st)) {
-                buf_d2[px] = make_float4(st.found ? 0.0f : 1.0f, rec1.z, rec1.w, 0.0f);
-                rays_done += 1u; bytes += st.used_memory;
-                active = false;
-            }
-        }
-    }
-    if (rays_done) count_rays_many(a, rays_done, bytes);
-}
 void launch_spatial_trace(const KArgs& a, const float4* buf_d0, const float4* buf_d1, float4* buf_d2, hipStream_t s) {
-    static const bool compact = [] { const char* e = getenv("ST_COMPACT"); return e && atoi(e) != 0; }();
-    if (!compact) { ST_LAUNCH_TRACE(k_spatial_trace, false, s, a, buf_d0, buf_d1, buf_d2); return; }
-    const LaunchDims d = launch_dims(a, false);
-    const uint32_t groups_x = (d.tiles_x + 3u) / 4u, n_groups = d.blocks;
-    if (!n_groups) return;
-    const uint32_t blocks = (n_groups + kGroupsPerBlock - 1u) / kGroupsPerBlock;
-    if (a.bvh_len < kStack16Texels) ST_KLAUNCH((k_spatial_trace_compact<uint16_t>), dim3(blocks), dim3(kBlockThreads), s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
-    else ST_KLAUNCH((k_spatial_trace_compact<uint32_t>), dim3(blocks), dim3(kBlockThreads), s, a, buf_d0, buf_d1, buf_d2, groups_x, d.tile_y0, n_groups);
+    ST_LAUNCH_TRACE(k_spatial_trace, false, s, a, buf_d0, buf_d1, buf_d2);
 }
 
 // ---------------------------------------------------------------- frame_composition.rs:18-82 as a compute pass into an RGBA32F buffer

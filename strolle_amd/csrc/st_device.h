@@ -406,155 +406,130 @@ ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32
 }
 // glam Affine3A::transform_point3 with the transform stored as 4 float4 (x, y, z axes, translation)
 ST_D V3 affine_point(const float4* m, V3 p) { return ((xyz(m[0]) * p.x) + (xyz(m[1]) * p.y) + (xyz(m[2]) * p.z)) + xyz(m[3]); }
-// Any-hit traversal over 4-wide nodes the engine can append behind the binary stream (st_engine.cpp append_wide_nodes).
-// MEASURED SLOWER, hence compiled only with -DST_WIDE_NODES=1 and switched on by ST_WIDE_NODES=1 (round 3, same box, 1080p
-// Image, wide vs binary): Cornell 0.822 vs 0.810 ms, dungeon 1.509 vs 1.478 ms; per kernel on the dungeon DI resolving 139 vs
-// 149 us, DI spatial 120 vs 120, DI sampling + temporal 213 vs 200, GI sampling b 215 vs 184, GI spatial 426 vs 382. A wide
-// step runs the same four box tests as two binary steps (92 VALU instructions), picks the nearest child (≈ 25 more) and makes
-// four LDS stack stores where the binary pair makes at most two: it saves scalar issue, which overlaps vector issue anyway,
-// and pays for it in the vector and LDS pipes — worst on incoherent rays (GI sampling b's shadow rays start at secondary hits).
-// Results agree with the binary traversal within the fast build's tolerances (tests/test_gpu_fast_tolerance.py ran with it).
-// Fast build only: KArgs::bvh_wide_len. A wide node's four child boxes are tested with intersect_box's own arithmetic; every
-// child the ray reaches other than the nearest is pushed without a branch and the nearest is walked next — the binary
-// loop's four divergent `if`s per internal step are what its scalar-issue time goes to. Leaf runs are the binary stream's own entries: same triangles, same hit test, same answer.
-// A child offset at or beyond the end of the binary stream is a wide node, below it a leaf run.
-#ifdef ST_WIDE_NODES
+// Ray::intersect (shadow ray) as the contract states it: the reference's visiting order, arithmetic and `used_memory` count
 template <class SE>
-ST_D bool trace_any_wide(const KArgs& a, const Ray& ray, SE* stack) {
-    const uint32_t wide_base = a.bvh_len * 16u;
-    const float limit = ray.len;
-    uint32_t cur = wide_base;
-    int sp = 0;
-    for (;;) {
-        const float4* entry = bvh_entry(a.bvh, cur);
-        if (cur >= wide_base) {
-            const float4 mnx = entry[0], mny = entry[1], mnz = entry[2], mxx = entry[3], mxy = entry[4], mxz = entry[5], rf = entry[6];
-            asm volatile("" :: "v"(mny.x), "v"(mnz.x), "v"(mxx.x), "v"(mxy.x), "v"(mxz.x), "v"(rf.x));
-            const float t0 = intersect_box(ray, v3(mnx.x, mny.x, mnz.x), v3(mxx.x, mxy.x, mxz.x));
-            const float t1 = intersect_box(ray, v3(mnx.y, mny.y, mnz.y), v3(mxx.y, mxy.y, mxz.y));
-            const float t2 = intersect_box(ray, v3(mnx.z, mny.z, mnz.z), v3(mxx.z, mxy.z, mxz.z));
-            const float t3 = intersect_box(ray, v3(mnx.w, mny.w, mnz.w), v3(mxx.w, mxy.w, mxz.w));
-            // The nearest child the ray reaches is walked next (an occluder is most likely found there first); the others are
-            // pushed with unconditional stores and a conditional advance — a child the ray misses is overwritten by the next
-            // push or never popped — so the node step has one data-dependent branch instead of the binary step's four.
-            const float tn = fmin_(fmin_(t0, t1), fmin_(t2, t3));
-            const bool c0 = t0 == tn, c1 = !c0 && t1 == tn, c2 = !c0 && !c1 && t2 == tn, c3 = !c0 && !c1 && !c2;
-            const uint32_t nearest = c0 ? f2b(rf.x) : (c1 ? f2b(rf.y) : (c2 ? f2b(rf.z) : f2b(rf.w)));
-            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.x) >> 6); sp += (t0 < limit && !c0) ? 1 : 0;
-            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.y) >> 6); sp += (t1 < limit && !c1) ? 1 : 0;
-            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.z) >> 6); sp += (t2 < limit && !c2) ? 1 : 0;
-            stack[(sp < kBvhStackSize - 1 ? sp : kBvhStackSize - 1) * 64] = (SE)(f2b(rf.w) >> 6); sp += (t3 < limit && !c3) ? 1 : 0;
-            sp = sp < kBvhStackSize ? sp : kBvhStackSize;  // a chain deeper than the stack loses its oldest pending children, as the binary loop drops pushes
-            if (tn < limit) { cur = nearest; continue; }
-        } else {
-            const float4 d0 = entry[0], d1 = entry[1], d2 = entry[2], d3 = entry[3];
-            asm volatile("" :: "v"(d1.x), "v"(d2.x), "v"(d3.x));
-            const uint32_t flags = f2b(d0.x), tri = f2b(d0.y), material = f2b(d0.z);
-            const V3 p0 = xyz(d1), e1 = xyz(d2), e2 = xyz(d3);
-            const V3 pvec = xe::cross(ray.dir, e2);
-            const float det = xe::dot(e1, pvec);
-            if (!(fabsf(det) < kF32Eps)) {
-                const float inv_det = 1.0f / det;
-                const V3 tvec = xe::sub(ray.origin, p0);
-                const float u = xe::dot(tvec, pvec) * inv_det;
-                const V3 qvec = xe::cross(tvec, e1);
-                const float v = xe::dot(ray.dir, qvec) * inv_det;
-                const float t = xe::dot(e2, qvec) * inv_det;
-                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= limit))) {
-                    bool found = true;
-                    if (flags & 2u) {
-                        const GpuMaterial m = a.materials[material];
-                        const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
-                        if (bc.w < 1.0f) found = false;
-                    }
-                    if (found) return true;
-                }
-            }
-            if (flags & 1u) { cur += 64u; continue; }
-        }
-        if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64] << 6; } else return false;
-    }
-}
-#endif
-// Ray::intersect (shadow ray)
-template <class SE>
-ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
-#ifdef ST_WIDE_NODES
-    if (a.bvh_wide_len != 0u) { *used_memory = 0u; return trace_any_wide(a, ray, stack); }
-#endif
+ST_D bool trace_any_contract(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
     Candidate c; bool any;
     *used_memory = traverse<true>(a, ray, ray.len, stack, &c, &any);
     return c.t < ray.len;
-}
-// The any-hit traversal as a resumable state machine: any_hit_step() is one iteration of traverse<true>()'s loop for a
-// ray whose cut-off distance stays at ray.len until a hit ends it. Used by the compacted shadow-ray kernel, where a lane
-// that finishes its ray picks up another one instead of idling until the slowest lane of the wave is done.
-struct AnyHitState { uint32_t ptr; int32_t sp; uint32_t used_memory; bool found; };
-ST_D AnyHitState any_hit_begin() { AnyHitState s; s.ptr = 0u; s.sp = 0; s.used_memory = 0u; s.found = false; return s; }
-// One iteration of the loop in two parts: the entry fetch and the arithmetic.
-// (Measured and dropped, round 2: running the two shadow rays of a spatial-resampling cell interleaved in one loop, with
-// both fetch chains overlapped — 144 VGPRs, 3 waves per SIMD, di_spatial 127 -> 175 us on Cornell, 154 -> 188 us on the
-// dungeon. The loop is bound by instruction issue — about 45 VALU and 25 SALU instructions per step, DESIGN.md section 4
-// "What a SIMD can issue" — and by lane divergence, not by the latency of its fetches once those are one round trip.)
-struct NodeFetch { float4 d0, d1, d2, d3; };
-ST_D void any_hit_fetch_node(const KArgs& a, const AnyHitState& st, NodeFetch& f) {
-    const float4* entry = bvh_entry(a.bvh, st.ptr);
-    f.d0 = entry[0]; f.d1 = entry[1]; f.d2 = entry[2]; f.d3 = entry[3];  // see traverse()
-    asm volatile("" :: "v"(f.d1.x), "v"(f.d2.x), "v"(f.d3.x));
-}
-// returns true when the ray is finished (st.found tells how)
-template <class SE>
-ST_D bool any_hit_process(const KArgs& a, const Ray& ray, SE* stack, AnyHitState& st, const NodeFetch& f) {
-    st.used_memory += 16u;
-    const float4 d0 = f.d0;
-    if (f2b(d0.w) == 0u) {
-        st.used_memory += 48u;
-        uint32_t near_ptr = st.ptr + 64u, far_ptr = f2b(f.d1.w);
-        float near_d = intersect_box(ray, xyz(d0), xyz(f.d1));
-        float far_d = intersect_box(ray, xyz(f.d2), xyz(f.d3));
-        if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-        if (far_d < ray.len) { if (st.sp < kBvhStackSize) { stack[st.sp * 64] = (SE)(far_ptr >> 6); st.sp++; } }
-        if (near_d < ray.len) { st.ptr = near_ptr; return false; }
-    } else {
-        st.used_memory += 144u;
-        const uint32_t flags = f2b(d0.x), tri = f2b(d0.y), material = f2b(d0.z);
-        const V3 p0 = xyz(f.d1), e1 = xyz(f.d2), e2 = xyz(f.d3);
-        const V3 pvec = xe::cross(ray.dir, e2);
-        const float det = xe::dot(e1, pvec);
-        if (!(fabsf(det) < kF32Eps)) {
-            const float inv_det = 1.0f / det;
-            const V3 tvec = xe::sub(ray.origin, p0);
-            const float u = xe::dot(tvec, pvec) * inv_det;
-            const V3 qvec = xe::cross(tvec, e1);
-            const float v = xe::dot(ray.dir, qvec) * inv_det;
-            const float t = xe::dot(e2, qvec) * inv_det;
-            if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= ray.len))) {
-                bool found = true;
-                if (flags & 2u) {
-                    st.used_memory += 112u + 16u;
-                    const GpuMaterial m = a.materials[material];
-                    const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
-                    if (bc.w < 1.0f) found = false;
-                }
-                if (found) { st.found = true; return true; }
-            }
-        }
-        if (flags & 1u) { st.ptr += 64u; return false; }
-    }
-    if (st.sp > 0) { st.sp--; st.ptr = (uint32_t)stack[st.sp * 64] << 6; return false; }
-    return true;
-}
-template <class SE>
-ST_D bool any_hit_step(const KArgs& a, const Ray& ray, SE* stack, AnyHitState& st) {
-    if (a.bvh_len == 0u) return true;
-    NodeFetch f;
-    any_hit_fetch_node(a, st, f);
-    return any_hit_process(a, ray, stack, st, f);
 }
 #if defined(ST_FAST_MATH)
 #pragma clang fp contract(fast)
 #endif
 // ================================================================== end of exact island (3/3)
+
+// ------------------------------------------------------------------ any-hit rays of the fast build
+// `Ray::intersect` (strolle-gpu/src/ray.rs:84-112) hands back ONE boolean — "some triangle is hit closer than ray.len" — and
+// nothing else of the traversal (its `used_memory` is observable only through st_profile_enable(ST_PROFILE_TRAVERSAL_BYTES),
+// which switches back to the contract loop above). The fast build therefore walks shadow rays with ordinary fast arithmetic:
+//   * the slab test is two FMAs per plane pair against a precomputed -origin * inv_dir (the exact island's (b - o) * inv is a
+//     subtraction and a multiplication: 12 VALU instructions fewer per internal node). In position space the difference is
+//     one ulp of the coordinate's magnitude; a direction component of exactly 0 turns that axis' test into "no constraint"
+//     (inf - inf = NaN, which v_min / v_max drop), i.e. conservative;
+//   * Möller–Trumbore is contracted into FMAs and divides by v_rcp_f32 (the island's IEEE division alone is 13 instructions);
+//   * near-child-first order is KEPT: tools/packet_sim.py prices "left child first, no near/far sort" at +27 % loop bodies on
+//     the dungeon's DI shadow rays (occluded rays find their occluder later) against the ~15 % of an internal step the sort costs;
+//     a wave-wide packet walk of the same rays (one node per step for all lanes, scalar fetch) visits 1.8x (DI) to 3x (GI) MORE
+//     entries than the per-lane loop executes bodies — rays of one 8x8 tile go to 4-5 different lights — and is not built.
+//   * SITE 1 (rays towards a light: DI sampling / resolving / spatial, GI sampling b): a WORLD-SPACE LAST-OCCLUDER TABLE
+//     (KArgs::occluder_table; key = hash of the ray's origin cell (1 unit) and end-point cell (1/4 unit)). The leaf entry
+//     that ended an earlier ray between the same two cells is tested first; a hit ends the ray after one entry, and whole
+//     tiles in shadow end after one step (packet_sim.py, dungeon: 0.74 of the DI shadow rays end there, loop bodies per wave
+//     / 1.6). Any leaf entry of the current stream is a legitimate occluder to test, so a stale or colliding slot costs one
+//     test and nothing else; slots are validated against the stream (inside it, a leaf entry, not AlphaMode::Blend).
+// The boolean can differ from the contract loop's only where a ray grazes a box or a triangle edge within an ulp; the fast
+// build's launch-by-launch tolerance tests (tests/test_gpu_fast_*.py) bound how often. The exact build never comes here.
+#if ST_FAST_DEVICE
+ST_D float any_slab(V3 lo, V3 hi, V3 inv, V3 oi) {
+    const float ax = fmaf(lo.x, inv.x, oi.x), bx = fmaf(hi.x, inv.x, oi.x);
+    const float ay = fmaf(lo.y, inv.y, oi.y), by = fmaf(hi.y, inv.y, oi.y);
+    const float az = fmaf(lo.z, inv.z, oi.z), bz = fmaf(hi.z, inv.z, oi.z);
+    const float tmin = fmax_(fmax_(fmax_(0.0f, fmin_(ax, bx)), fmin_(ay, by)), fmin_(az, bz));
+    const float tmax = fmin_(fmin_(fmin_(kF32Max, fmax_(ax, bx)), fmax_(ay, by)), fmax_(az, bz));
+    return tmin <= tmax ? tmin : kF32Max;
+}
+// Triangle::hit's accept / reject for a ray that only asks "closer than limit?" (alpha test excluded)
+ST_D bool any_triangle(const Ray& ray, V3 p0, V3 e1, V3 e2, float limit, float* u_out, float* v_out) {
+    const V3 pvec = cross(ray.dir, e2);
+    const float det = dot(e1, pvec);
+    if (fabsf(det) < kF32Eps) return false;
+    const float inv_det = __builtin_amdgcn_rcpf(det);
+    const V3 tvec = ray.origin - p0;
+    const float u = dot(tvec, pvec) * inv_det;
+    const V3 qvec = cross(tvec, e1);
+    const float v = dot(ray.dir, qvec) * inv_det;
+    const float t = dot(e2, qvec) * inv_det;
+    *u_out = u; *v_out = v;
+    return !((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= limit));
+}
+// cells are hashed through the bits of floorf(): no float -> int conversion whose range the compiler could reason about
+ST_D uint32_t occluder_slot(const KArgs& a, const Ray& ray) {
+    const V3 end = ray_at(ray, ray.len);
+    const uint32_t ox = f2b(floorf(ray.origin.x)), oy = f2b(floorf(ray.origin.y)), oz = f2b(floorf(ray.origin.z));
+    const uint32_t ex = f2b(floorf(end.x * 4.0f)), ey = f2b(floorf(end.y * 4.0f)), ez = f2b(floorf(end.z * 4.0f));
+    uint32_t h = (ox >> 7) * 73856093u ^ (oy >> 7) * 19349663u ^ (oz >> 7) * 83492791u;
+    h = h * 0x9e3779b1u ^ ((ex >> 7) * 2654435761u ^ (ey >> 7) * 2654404609u ^ (ez >> 7) * 2246822519u);
+    h ^= h >> 15;
+    return h & a.occluder_mask;
+}
+template <int SITE, class SE>
+ST_D bool any_hit_fast(const KArgs& a, const Ray& ray, SE* stack) {
+    if (a.bvh_len == 0u) return false;
+    const float limit = ray.len;
+    uint32_t slot = 0u;
+    const bool cached = SITE != 0 && a.occluder_table != nullptr && limit < 1.0e30f;   // (a sky ray has no end point)
+    if (cached) {
+        slot = occluder_slot(a, ray);
+        const uint32_t entry = a.occluder_table[slot];
+        if (entry < (a.bvh_len >> 2)) {
+            const float4* e = bvh_entry(a.bvh, entry << 6);
+            const float4 d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3];
+            float u, v;
+            if (f2b(d0.w) != 0u && (f2b(d0.x) & 2u) == 0u && any_triangle(ray, xyz(d1), xyz(d2), xyz(d3), limit, &u, &v)) return true;
+        }
+    }
+    const V3 inv = v3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
+    const V3 oi = v3(-ray.origin.x * inv.x, -ray.origin.y * inv.y, -ray.origin.z * inv.z);
+    uint32_t ptr = 0u;
+    int sp = 0;
+    for (;;) {
+        const float4* entry = bvh_entry(a.bvh, ptr);
+        const float4 d0 = entry[0], d1 = entry[1], d2 = entry[2], d3 = entry[3];
+        asm volatile("" :: "v"(d1.x), "v"(d2.x), "v"(d3.x));   // one round trip for the four texels (see traverse())
+        if (f2b(d0.w) == 0u) {
+            uint32_t near_ptr = ptr + 64u, far_ptr = f2b(d1.w);
+            float near_d = any_slab(xyz(d0), xyz(d1), inv, oi);
+            float far_d = any_slab(xyz(d2), xyz(d3), inv, oi);
+            if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
+            if (far_d < limit) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)(far_ptr >> 6); sp++; } }
+            if (near_d < limit) { ptr = near_ptr; continue; }
+        } else {
+            const uint32_t flags = f2b(d0.x);
+            float u, v;
+            if (any_triangle(ray, xyz(d1), xyz(d2), xyz(d3), limit, &u, &v)) {
+                bool found = true;
+                if (flags & 2u) {  // AlphaMode::Blend: the texel decides (exact-island fetch, as in traverse())
+                    const uint32_t tri = f2b(d0.y), material = f2b(d0.z);
+                    const GpuMaterial m = a.materials[material];
+                    const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
+                    if (bc.w < 1.0f) found = false;
+                } else if (cached) a.occluder_table[slot] = ptr >> 6;   // benign race: every value ever stored is a leaf entry of some stream
+                if (found) return true;
+            }
+            if (flags & 1u) { ptr += 64u; continue; }
+        }
+        if (sp > 0) { sp--; ptr = (uint32_t)stack[sp * 64] << 6; } else return false;
+    }
+}
+#endif
+// Ray::intersect (shadow ray). SITE 1: a ray towards a light (see above); SITE 0: everything else.
+template <int SITE = 0, class SE>
+ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
+#if ST_FAST_DEVICE && !defined(ST_NO_ANYHIT_FAST)
+    if (!a.anyhit_contract) { *used_memory = 0u; return any_hit_fast<SITE>(a, ray, stack); }
+#endif
+    return trace_any_contract(a, ray, stack, used_memory);
+}
 ST_D void hit_pack(const TriangleHit& h, float4* d0, float4* d1) {  // hit.rs:112-120
     *d0 = f4(h.point, b2f(h.material_id));
     const V2 n = normal_encode(h.normal);

@@ -1,0 +1,198 @@
+// st_tick.cpp — host engine of libstrolle_hip.so: Engine::tick (lib.rs:301-395): refresh of the stores + uploads. See st_engine.h.
+#include "st_engine.h"
+
+namespace st {
+
+// ---- tick (lib.rs:301-395)
+int Engine::tick(hipStream_t stream) {
+    bool scene_changed = false;
+    if (materials_dirty || atlas_dirty) { materials_dirty = false; rebuild_gpu_materials(); scene_changed = true; }
+    const bool timing = tuning.tick_timing;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    if (refresh_instances()) {
+        for (const auto& inst : instances) {
+            float4* x = instance_xforms.data() + 8u * inst.xslot;
+            const Affine* src[2] = {&inst.xform_inv, &inst.prev_xform};
+            for (int k = 0; k < 2; k++) { x[4 * k] = f4(src[k]->x, 0.0f); x[4 * k + 1] = f4(src[k]->y, 0.0f); x[4 * k + 2] = f4(src[k]->z, 0.0f); x[4 * k + 3] = f4(src[k]->t, 0.0f); }
+        }
+        const auto t1 = now();
+        std::vector<uint8_t> blend(materials.size());
+        for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
+        const bool refitting = bvh_refresh_mode != ST_BVH_REBUILD;
+        const uint64_t signature = refitting ? topology_of(blend) : 0;
+        if (refitting && have_topology && signature == topology_signature) {
+            // ST_BVH_REFIT_DEVICE: the boxes are recomputed on the device from the moved triangles' bounds (k_bvh.hip); the host's
+            // copy of the stream is brought up to date only when something reads it
+            if (device_refit_possible()) host_stream_stale = true; else refit_stream();
+            refits++;
+            if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, refit %.2f ms (%zu internal nodes)\n", ms(t0, t1), ms(t1, now()), internal_positions.size());
+        } else {
+            bvh.begin_refresh();  // keeps the previous tree: unchanged subtrees are copied, not rebuilt (same result as a fresh build)
+            for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
+            const auto t2 = now();
+            bvh.run();
+            const auto t3 = now();
+            bvh.flatten(blend, bvh_stream);
+            const auto t4 = now();
+            rebuilds++; tree_version++; host_stream_stale = false;
+            mark_internal_starts(); measure_stack_need();
+            have_topology = false;
+            if (refitting) { index_stream(); topology_signature = signature; have_topology = true; }
+            if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles, %zu reused)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size(), bvh.reused_primitives());
+        }
+        scene_changed = true;
+    }
+    light_count = next_light_id;
+    {   // World::sun_dir (world.rs:18-24)
+        float sa, ca, sz, cz;
+        sincos_(sun_altitude, &sa, &ca); sincos_(sun_azimuth, &sz, &cz);
+        sun_dir_ = v3(ca * sz, sa, -ca * cz);
+    }
+    if (sun_dirty) {
+        sun_dirty = false;
+        V3 color = sun_transmittance(v3(0.0f, 6.360f + 0.0002f, 0.0f), sun_dir_);
+        color = color * 20.0f * 5.0f;
+        GpuLight sun{};
+        const V3 pos = sun_dir_ * 1000.0f;
+        sun.d0 = f4(pos, 25.0f); sun.d1 = f4(color, INFINITY); sun.d2 = make_float4(b2f(1u), 0, 0, 0);
+        overwrite_light(0, -1, sun);
+    }
+    snapshot_lights();
+    if (has_device) {
+        ST_HIP(hipSetDevice(device));
+        // Uploads of an earlier tick that no render has waited for yet stay pending until their event has completed: a
+        // tick that uploads nothing must not make a later render on another stream forget them.
+        if (tick_work_in_flight && hipEventQuery(ev_tick) == hipSuccess) tick_work_in_flight = false;
+        if (copy_in_flight && hipEventQuery(ev_copy) == hipSuccess) copy_in_flight = false;
+        (void)hipGetLastError();  // hipErrorNotReady from the queries is not an error
+        bool copied_now = false;  // this tick queued copies on copy_stream
+        bool pageable = false;  // some copy of this tick reads pageable host memory (or writes it): join the stream before returning
+        staging.begin_tick();
+        bool pageable_copy = false;
+        if (scene_changed || !scene_uploaded) {
+            int rc;
+            // which copy, on which stream: the first upload and ST_NO_DOUBLE_BUFFER=1 write the live copy in place on the
+            // caller's stream (behind the frames queued there); every later change goes to the other copy on copy_stream
+            int target = live; hipStream_t up = stream; bool* flag = &pageable; bool other_copy = false;
+            if (tuning.double_buffer && scene_uploaded && !mixed_render_streams) {
+                if (!copy_stream) { ST_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); ST_HIP(hipEventCreateWithFlags(&ev_copy, hipEventDisableTiming)); }
+                if (!alternating) {  // frames enqueued so far read the live copy without marking their end: mark it now, behind them
+                    alternating = true;
+                    SceneSet& l = sets[live];
+                    if (!l.free_ev) ST_HIP(hipEventCreateWithFlags(&l.free_ev, hipEventDisableTiming));
+                    ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
+                }
+                target = live ^ 1; up = copy_stream; flag = &pageable_copy; other_copy = true;
+                if (sets[target].busy) { ST_HIP(hipStreamWaitEvent(copy_stream, sets[target].free_ev, 0)); sets[target].busy = false; }
+            } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
+            SceneSet& t = sets[target];
+            if (device_refit_possible() && t.valid && !t.tri_full && t.tree_version == tree_version && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4)) {
+                // This copy holds the current tree; only boxes and moved triangles are behind. Send the records and bounds of the
+                // triangle slots baked since it was written and let the device patch its leaf entries and refit its boxes.
+                if (t.dirty_lo < t.dirty_hi) {
+                    if ((rc = t.tri_geo.upload_range(tri_geo.data(), 3 * t.dirty_lo * sizeof(float4), 3 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
+                    if ((rc = t.tri_bounds.upload_range(tri_bounds.data(), 2 * t.dirty_lo * sizeof(float4), 2 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
+                    L.launch_bvh_patch_leaves(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_geo.ptr), static_cast<const uint32_t*>(t.entry_of_tri.ptr), (uint32_t)t.dirty_lo, (uint32_t)t.dirty_hi, up);
+                }
+                for (const auto& level : refit_levels_)   // this copy holds the current tree, so the engine's work list is its own
+                    L.launch_bvh_refit(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_bounds.ptr), static_cast<const uint32_t*>(t.parent.ptr), static_cast<const uint32_t*>(t.refit_local.ptr),
+                                       static_cast<const uint32_t*>(t.refit_items.ptr), static_cast<const uint32_t*>(t.refit_batch_off.ptr), level.first, level.second, up);
+                device_refits++;
+            } else {
+                if (host_stream_stale) { refit_stream(); host_stream_stale = false; }
+                expand_stream();
+                // traversal pointers are 32-bit BYTE offsets into the device stream (64 B per entry) and stack slots hold entry numbers
+                if ((size_t)device_bvh_len * sizeof(float4) > 0xffffffffull) return fail(ST_ERR_INVALID_ARGUMENT, "the BVH stream exceeds 4 GiB (2^26 entries): traversal pointers are 32-bit byte offsets");
+                if ((rc = t.bvh.upload(bvh_upload_.data(), bvh_upload_.size() * sizeof(float4), up, staging, flag))) return rc;
+                if (device_refit_possible()) {  // what the device refit of later ticks needs beside the stream
+                    index_device_tree();
+                    if ((rc = t.tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), up, staging, flag))) return rc;
+                    if ((rc = t.tri_bounds.upload(tri_bounds.data(), tri_bounds.size() * sizeof(float4), up, staging, flag))) return rc;
+                    if ((rc = t.entry_of_tri.upload(entry_of_tri_.data(), entry_of_tri_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                    if ((rc = t.parent.upload(parent_.data(), parent_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                    if ((rc = t.refit_local.upload(refit_local_.data(), refit_local_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                    if (!refit_items_.empty() && (rc = t.refit_items.upload(refit_items_.data(), refit_items_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                    if ((rc = t.refit_batch_off.upload(refit_batch_off_.data(), refit_batch_off_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+                    t.tree_version = tree_version;
+                }
+            }
+            // attribute records: whole the first time or after they grew, otherwise only the slots baked since this copy was written
+            const bool partial = t.valid && !t.tri_full && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
+            if (!partial) {
+                if ((rc = t.tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), up, staging, flag))) return rc;
+            } else if (t.dirty_lo < t.dirty_hi) {
+                if ((rc = t.tri_attr.upload_range(tri_attr.data(), 4 * t.dirty_lo * sizeof(float4), 4 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
+            }
+            t.dirty_lo = SIZE_MAX; t.dirty_hi = 0; t.tri_full = false; t.valid = true;
+            if ((rc = t.xforms.upload(instance_xforms.data(), instance_xforms.size() * sizeof(float4), up, staging, flag))) return rc;
+            if ((rc = t.materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), up, staging, flag))) return rc;
+            if ((rc = t.base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), up, staging, flag))) return rc;
+            if (other_copy) copied_now = true;
+            live = target; live_bvh_texels = device_bvh_len;
+            scene_uploaded = true;
+            scene_changed = !other_copy;  // in-place uploads count as work on the caller's stream below
+        }
+        bool misc_uploaded = atlas_dirty || blue_noise_dirty, uploaded_device_images = false;
+        if (atlas_dirty) { int rc = d_atlas.upload(atlas.data(), atlas.size(), stream, staging, &pageable); if (rc) return rc; }
+        for (auto& kv : device_images) {
+            DeviceImage& di = kv.second;
+            if (!di.pending && !di.dynamic) continue;
+            const ImageRec& r = images.at(kv.first);
+            uint8_t* dst = static_cast<uint8_t*>(d_atlas.ptr) + ((size_t)r.y * atlas_w + r.x) * 4;
+            ST_HIP(hipMemcpy2DAsync(dst, (size_t)atlas_w * 4, di.pixels, di.pitch, (size_t)r.w * 4, r.h, hipMemcpyDeviceToDevice, stream));
+            if (!di.dynamic) {  // keep the host copy complete: it is what a later full upload sends
+                ST_HIP(hipMemcpy2DAsync(&atlas[((size_t)r.y * atlas_w + r.x) * 4], (size_t)atlas_w * 4, di.pixels, di.pitch, (size_t)r.w * 4, r.h, hipMemcpyDeviceToHost, stream));
+                misc_uploaded = true; pageable = true;  // joins the stream below before the host copy is read again
+            }
+            di.pending = false;
+            uploaded_device_images = true;
+        }
+        if (blue_noise_dirty) { int rc = d_blue_noise.upload(blue_noise.data(), blue_noise.size(), stream, staging, &pageable); if (rc) return rc; blue_noise_dirty = false; }
+        bool uploaded = scene_changed || misc_uploaded || uploaded_device_images;
+        // lights change rarely; skipping the identical re-upload also skips the stream sync below, so the host can
+        // run a frame ahead of the GPU (the reference re-uploads only dirty buffers too: mapped_storage_buffer.rs:103-121)
+        if (gpu_lights.size() != uploaded_lights.size() || memcmp(gpu_lights.data(), uploaded_lights.data(), gpu_lights.size() * sizeof(GpuLight)) != 0) {
+            int target = live_lights; hipStream_t up = stream; bool* flag = &pageable; bool other_copy = false;
+            if (tuning.double_buffer && lights_uploaded && !mixed_render_streams) {
+                if (!copy_stream) { ST_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); ST_HIP(hipEventCreateWithFlags(&ev_copy, hipEventDisableTiming)); }
+                if (!lights_alternating) {  // as for the scene: the frames queued so far end here
+                    lights_alternating = true;
+                    LightSet& l = light_sets[live_lights];
+                    if (!l.free_ev) ST_HIP(hipEventCreateWithFlags(&l.free_ev, hipEventDisableTiming));
+                    ST_HIP(hipEventRecord(l.free_ev, stream)); l.busy = true;
+                }
+                target = live_lights ^ 1; up = copy_stream; flag = &pageable_copy; other_copy = true;
+                if (light_sets[target].busy) { ST_HIP(hipStreamWaitEvent(copy_stream, light_sets[target].free_ev, 0)); light_sets[target].busy = false; }
+            } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());
+            int rc = light_sets[target].buf.upload(gpu_lights.data(), gpu_lights.size() * sizeof(GpuLight), up, staging, flag);
+            if (rc) return rc;
+            live_lights = target; lights_uploaded = true;
+            uploaded_lights = gpu_lights;
+            if (other_copy) copied_now = true; else uploaded = true;
+        }
+        if (copied_now) {
+            copy_in_flight = true;
+            ST_HIP(hipEventRecord(ev_copy, copy_stream));
+            ST_HIP(hipStreamWaitEvent(stream, ev_copy, 0));  // the caller's stream: the next frame's kernels (and the staging slot's event) come after the copies
+        }
+        if (int rc = staging.end_tick(stream)) return rc;
+        // What was uploaded went through page-locked staging, so the caller may change the scene again at once; the next
+        // frame's side stream is ordered behind these copies by an event (render). Only copies that touch pageable
+        // host memory directly (staging full or disabled) make the tick wait for the stream.
+        if (uploaded) {
+            if (!ev_tick) ST_HIP(hipEventCreateWithFlags(&ev_tick, hipEventDisableTiming));
+            ST_HIP(hipEventRecord(ev_tick, stream));
+            tick_work_in_flight = true;
+        }
+        if (pageable_copy) ST_HIP(hipStreamSynchronize(copy_stream));
+        if ((uploaded && pageable) || sync_every_tick) ST_HIP(hipStreamSynchronize(stream));
+    }
+    atlas_dirty = false;
+    for (auto& kv : cameras) kv.second->frame = frame;  // CameraController::flush
+    frame += 1;
+    return ST_OK;
+}
+
+}  // namespace st

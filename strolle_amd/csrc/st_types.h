@@ -66,7 +66,6 @@ struct KArgs {
     const float* byte_luts;  // 256 sRGB->linear + 256 unorm8 values (st_device.h kLut*), generated on the device at engine creation
     const float4* transmittance_lut; const float4* sky_lut;
     uint32_t bvh_len, n_lights_buf, light_count, atlas_w, atlas_h;
-    uint32_t bvh_wide_len;  // texels of 4-wide nodes appended behind the bvh_len texels of `bvh` (0: none; st_device.h trace_any_wide)
     // k_denoise.hip "variance in the reproject stage": the fused reproject stages store each pixel's long-history variance in
     // curr_colors.w and the DI one flags short-history pixels per 8x8 tile (bit = lane) for the variance kernel
     unsigned long long* tile_mask; uint32_t variance_in_reproject;
@@ -80,6 +79,9 @@ struct KArgs {
     // ST_KEEP_ALL_PLANES=1 keeps every plane as the reference leaves it.
     uint32_t lean;
     const float4* gi_mid_src;  // kLeanGiMid, second-pass launch only: the first preview pass's input plane (nullptr: GI_RESERVOIRS_3 holds every first-pass result)
+    // any-hit rays of the fast build (st_device.h any_hit_fast): world-space last-occluder table (nullptr: off), its index mask,
+    // and the switch back to the contract loop (set while the reference's used_memory bytes are being counted, or by StTuning)
+    uint32_t* occluder_table; uint32_t occluder_mask, anyhit_contract;
     uint32_t count_bytes;  // st_profile_enable bit 1: kernels also sum the reference's used_memory over their rays
     uint32_t tri_slots;  // triangle records in tri_attr (upper bound of every triangle id in the BVH stream)
     float sun_altitude;

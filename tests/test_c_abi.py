@@ -629,51 +629,3 @@ def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):
     assert got == want, (got, want)
 
 
-@pytest.mark.parametrize("scene", ["cornell", "soup", "dungeon"])
-def test_wide_nodes_cover_the_binary_tree(scene):
-    """The 4-wide nodes the engine can append behind the device stream for the fast build's any-hit rays (read_scene(5);
-    st_engine.cpp append_wide_nodes; opt-in, measured slower than the binary traversal — st_device.h trace_any_wide): walked from its root, the wide tree reaches every leaf run of the binary stream exactly
-    once, every child box is a box of the binary tree (the child's box in its binary parent), a node has 2..4 children, and an
-    unused slot holds a box no finite ray reaches."""
-    prod = Engine(device=-1)
-    {"cornell": scenes.build_cornell, "soup": lambda e: scenes.build_random_soup(e, 700, seed=3), "dungeon": scenes.build_dungeon}[scene](prod)
-    prod.tick()
-    dev = prod.read_scene(4).reshape(-1, 4); db = dev.view(np.uint32)
-    wide = prod.read_scene(5).reshape(-1, 4); wb = wide.view(np.uint32)
-    assert len(wide) % 8 == 0 and len(wide) > 0
-    wide_base = len(dev) * 16
-    # the binary tree: box of every entry as its parent states it, and the leaf runs
-    box_of, leaf_runs, stack = {}, set(), [0]
-    while stack:
-        off = stack.pop(); k = off // 16
-        if db[k, 3] == 0:
-            left, right = off + 64, int(db[k + 1, 3])
-            box_of[left] = (dev[k, :3].copy(), dev[k + 1, :3].copy()); box_of[right] = (dev[k + 2, :3].copy(), dev[k + 3, :3].copy())
-            stack += [left, right]
-        else:
-            leaf_runs.add(off)
-    seen_leaves, n_nodes, stack = [], 0, [wide_base]
-    fmax = np.float32(np.finfo(np.float32).max)
-    while stack:
-        off = stack.pop(); n_nodes += 1
-        node = wide[(off - wide_base) // 16:(off - wide_base) // 16 + 8]; refs = wb[(off - wide_base) // 16 + 6]
-        n = int(wb[(off - wide_base) // 16 + 7, 0])
-        assert 2 <= n <= 4
-        for c in range(4):
-            mn, mx = node[0:3, c], node[3:6, c]
-            if c >= n:
-                assert (mn == fmax).all() and (mx == fmax).all() and refs[c] == 0
-                continue
-            child = int(refs[c])
-            if child >= wide_base:
-                stack.append(child)
-            else:
-                assert child in leaf_runs
-                seen_leaves.append(child)
-                want_mn, want_mx = box_of[child]
-                assert np.array_equal(mn, want_mn) and np.array_equal(mx, want_mx), "a leaf child's box is its box in the binary tree"
-    assert sorted(seen_leaves) == sorted(leaf_runs), "every leaf run exactly once"
-    assert n_nodes == len(wide) // 8
-    internal = sum(1 for k in range(0, len(dev), 4) if db[k, 3] == 0)
-    assert n_nodes <= internal and n_nodes >= (internal + 2) // 3, (n_nodes, internal)   # a wide node absorbs 1..3 binary nodes
-    prod.close()

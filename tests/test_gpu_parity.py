@@ -601,40 +601,6 @@ def test_spot_lights_metallic_surfaces_bit_exact():
     assert float(np.nanmean(ref[..., :3])) > 0.0
 
 
-def test_compacted_shadow_ray_kernel_opt_in_bit_exact():
-    """ST_COMPACT=1 switches the spatial-resampling shadow-ray pass to the ballot/prefix-sum compacted, persistent-wave
-    kernel (k_trace.hip k_spatial_trace_compact). It is off by default (measured slower) but must stay correct."""
-    import os, subprocess, sys
-    _torch()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = """
-import sys, numpy as np, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from oracle_binding import OracleEngine
-from parity import assert_bits_equal
-from strolle_amd import Buffer, CameraMode, Engine, OutputFormat, scenes
-for build, cam_fn in ((scenes.build_cornell, scenes.cornell_camera), (scenes.build_dungeon, scenes.dungeon_camera)):
-    prod, orac = Engine(device=0, exact=True), OracleEngine()
-    for e in (prod, orac):
-        build(e); e.set_seed(4)
-    size = (136, 88)
-    desc = cam_fn(size, CameraMode.IMAGE)
-    cp, co = prod.create_camera(desc), orac.create_camera(desc)
-    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
-    for frame in range(6):
-        prod.update_camera(cp, desc); orac.update_camera(co, desc); prod.tick(); orac.tick()
-        prod.render_camera(cp, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        ref = orac.render_camera(co); torch.cuda.synchronize()
-        for b in Buffer:
-            assert_bits_equal(prod.read_buffer(cp, b), orac.read_buffer(co, b), f"frame {frame} {b.name}")
-        assert_bits_equal(out.cpu().numpy(), ref, f"frame {frame}")
-    assert prod.ray_count(cp) == orac.ray_count(co)
-print("compact ok")
-""" % (root, os.path.join(root, "tests"))
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, ST_COMPACT="1"))
-    assert res.returncode == 0 and "compact ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
-
-
 @pytest.mark.parametrize("seed", [101, 202])
 def test_random_edit_history_renders_bit_exact(seed):
     """Random scene edits between frames (instances moved / removed / re-added, lights added / removed, materials
