@@ -370,6 +370,10 @@ int st_decode_png(const void* bytes, size_t size, uint8_t* out_rgba, size_t capa
  * progressive DCT; 8-bit; grey or three components). */
 int st_decode_image(const void* bytes, size_t size, uint8_t* out_rgba, size_t capacity, uint32_t* width, uint32_t* height);
 
+/* This device's streaming ceiling measured with the library's own grid-stride float4 copy kernel (k_util.hip): best of `iters`
+ * copies of `bytes`, (bytes read + bytes written) / time in GB/s. bench.py reports it beside the 8 TB/s spec peak. */
+int st_debug_copy_bandwidth(StEngine* e, size_t bytes, int iters, double* out_gbps);
+
 /* Per-kernel measurement. st_profile_enable(e, flags): bit 0 (ST_PROFILE_TIMING) = HIP events around every launch on the
  * launch stream; while it is set the pass graph runs serially on the caller's stream (no two-stream overlap), so that an
  * event pair times its kernel alone. Bit 1 (ST_PROFILE_TRAVERSAL_BYTES) = the tracing kernels also sum the reference's

@@ -50,6 +50,16 @@ class StCamera(C.Structure):
                 ("pos_x", C.c_uint32), ("pos_y", C.c_uint32), ("_pad", C.c_uint32), ("transform", C.c_float * 16), ("projection", C.c_float * 16)]
 
 
+class StTuning(C.Structure):
+    """include/strolle_hip.h StTuning: scheduling / tuning switches of one engine."""
+    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "overlap", "fuse", "fuse_di_head", "fuse_spatial", "fuse_gi_sampling", "fuse_gi_validation",
+                                          "fuse_gi_reprojection", "fuse_wavelet", "fuse_compose", "preview_both", "variance_in_reproject", "variance_compaction",
+                                          "lean_frame", "skip_scratch_stores", "di_head_on_main", "alias_gi_history", "tile_map", "tile_map_denoise")] + \
+               [("side_priority", C.c_int32)] + \
+               [(n, C.c_uint32) for n in ("staging", "double_buffer", "packed_base", "tick_timing", "anyhit_fast", "occluder_table_log2", "occluder_min_texels",
+                                          "allow_deep_bvh", "device_bake")] + [("_reserved", C.c_uint32 * 4)]
+
+
 class StKernelProfile(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_float), ("algorithmic_bytes", C.c_double), ("traversal_bytes", C.c_double)]
 
@@ -283,6 +293,8 @@ class _Binding:
         if has_device:
             self.debug_bvh_depth = fn("debug_bvh_depth", [vp, P(u32), P(u32)])
             self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
+            self.engine_get_tuning = fn("engine_get_tuning", [vp, P(StTuning)]); self.engine_set_tuning = fn("engine_set_tuning", [vp, P(StTuning)])
+            self.debug_copy_bandwidth = fn("debug_copy_bandwidth", [vp, sz, i32, P(C.c_double)])
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
@@ -305,7 +317,10 @@ class _Binding:
 
 _STATUS = {1: "invalid argument", 2: "no HIP device (host-only engine or HIP unavailable)", 3: "camera does not exist",
            4: "mesh contains no triangles", 5: "HIP runtime error", 6: "no more space in the atlas", 7: "file could not be read",
-           8: "malformed scene file", 9: "unsupported scene file feature"}
+           8: "malformed scene file", 9: "unsupported scene file feature",
+           10: "the BVH is deeper than the kernels' traversal stack (the scene was uploaded; pushes beyond 24 pending entries are dropped)",
+           11: "collective transport error"}
+ST_ERR_BVH_TOO_DEEP = 10
 
 
 class EngineBase:
@@ -440,9 +455,16 @@ class EngineBase:
     def set_bvh_refresh(self, refit):
         """st_set_bvh_refresh: False / 0 = rebuild on every change (the reference's behaviour), True / 1 = refit while instances only
         move, 2 = the same with the boxes recomputed on the device (ST_BVH_REFIT_DEVICE; libstrolle_hip.so only)."""
-        self._check(self._b.set_bvh_refresh(self._h, int(refit)))
+        refit = int(refit)
+        if refit not in (0, 1, 2):
+            raise StrolleError(f"unknown BVH refresh mode {refit}")
+        if refit == 2 and not hasattr(self._b, "debug_bvh_device_refits"):
+            raise StrolleError("ST_BVH_REFIT_DEVICE is a mode of libstrolle_hip.so; this engine's library does not have it")
+        self._check(self._b.set_bvh_refresh(self._h, refit))
 
     def bvh_device_refits(self) -> int:
+        if not hasattr(self._b, "debug_bvh_device_refits"):
+            raise StrolleError("bvh_device_refits() is a seam of libstrolle_hip.so (st_debug_bvh_device_refits); this engine's library does not export it")
         out = C.c_uint64()
         self._check(self._b.debug_bvh_device_refits(self._h, C.byref(out)))
         return out.value
@@ -576,6 +598,27 @@ class Engine(EngineBase):
         else:
             self._check(self._b.scene_load_gltf(self._h, os.fsencode(source), C.byref(opt), C.byref(out)))
         return {name: getattr(out, name) for name, _ in StGltfSummary._fields_}
+
+    def tuning(self) -> "StTuning":
+        """st_engine_get_tuning: the engine's scheduling / tuning switches (a copy; change fields and hand it to set_tuning)."""
+        t = StTuning()
+        self._check(self._b.engine_get_tuning(self._h, C.byref(t)))
+        return t
+
+    def set_tuning(self, tuning=None, **fields):
+        """st_engine_set_tuning. Either a whole StTuning, or keyword fields applied on top of the current one: set_tuning(fuse=0)."""
+        t = tuning if tuning is not None else self.tuning()
+        for k, v in fields.items():
+            if not hasattr(t, k):
+                raise StrolleError(f"StTuning has no field {k!r}")
+            setattr(t, k, int(v))
+        self._check(self._b.engine_set_tuning(self._h, C.byref(t)))
+
+    def copy_bandwidth(self, nbytes: int = 1 << 30, iters: int = 6) -> float:
+        """st_debug_copy_bandwidth: GB/s (read + write) of the library's own grid-stride float4 copy on this device."""
+        out = C.c_double()
+        self._check(self._b.debug_copy_bandwidth(self._h, nbytes, iters, C.byref(out)))
+        return out.value
 
     def profile_enable(self, flags):
         """st_profile_enable: bit 0 = per-kernel event timing (serial execution), bit 1 = traversal-byte counters; True = 1."""

@@ -64,6 +64,35 @@ void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const f
     ST_LAUNCH(k_denoise_reproject, false, s, a, prev_colors, prev_moments, samples, colors, moments);
 }
 
+// Short history (frame_denoising.rs:128,180-189): spatial estimate over the reference's 29-tap window — the walk starts at
+// (-2,-2) and every later row starts at -3 —, kept as is, from a window staged in LDS (`lc` = the pixel's texel, row pitch
+// `pitch`; sqrt(luma) of a staged colour rides in its w). The two signals share the arithmetic as in the wavelet pass.
+ST_D void variance_short_history(float4 csn, float4 cdi, float4 cgi, const float4* s_sn, const float4* s_di, const float4* s_gi, int lc, int pitch, float* di_var, float* gi_var) {
+    const V3 cn = v3(csn.x, csn.y, csn.z);
+    const f2 c_sqrt_luma = mk2(fsqrt(luma(xyz(cdi))), fsqrt(luma(xyz(cgi))));
+    const float leeway = csn.w * 0.2f, inv_leeway = frcp(leeway);
+    f2 sum_l = splat2(0.0f), sum_ll = splat2(0.0f), sum_1 = splat2(0.0f);
+    for (int oy = -2; oy <= 2; oy++) {
+#pragma unroll
+        for (int ox = -3; ox <= 2; ox++) {
+            if (ox == -3 && oy == -2) continue;
+            const int lt = lc + oy * pitch + ox;
+            const float4 ssn = s_sn[lt];
+            if (ssn.w == 0.0f) continue;
+            const float4 sdi = s_di[lt], sgi = s_gi[lt];
+            const f2 l = (mk2(sdi.x, sgi.x) * 0.2126f + mk2(sdi.y, sgi.y) * 0.7152f) + mk2(sdi.z, sgi.z) * 0.0722f;
+            const f2 d = c_sqrt_luma - mk2(sdi.w, sgi.w);  // = sqrt2(l), staged
+            const float diff = fabsf(ssn.w - csn.w);
+            const float depth_weight = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
+            const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
+            const f2 w = exp_pair(-mk2(fabsf(d.x), fabsf(d.y))) * depth_weight * normal_weight;  // luma sigma 1: |d| * 1 == |d|
+            sum_l = sum_l + l * w; sum_ll = sum_ll + (l * l) * w; sum_1 = sum_1 + w;
+        }
+    }
+    { const float m1 = fdiv(sum_l.x, sum_1.x), m2 = fdiv(sum_ll.x, sum_1.x); *di_var = fabsf(m2 - m1 * m1) * 4.0f; }
+    { const float m1 = fdiv(sum_l.y, sum_1.y), m2 = fdiv(sum_ll.y, sum_1.y); *gi_var = fabsf(m2 - m1 * m1) * 4.0f; }
+}
+
 // ---------------------------------------------------------------- frame_denoising.rs:80-217
 __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_out, float4* gi_out) {
     // Window of the short-history estimate, staged per block when any of its pixels needs it: ox in [-3, 2], oy in
@@ -119,39 +148,12 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
     if (a.variance_in_reproject && !slow) return;
     if (!mine) return;
     if (csn.w == 0.0f) { di_out[center] = cdi; gi_out[center] = cgi; return; }  // sky
-    const float cdi_luma = luma(xyz(cdi)), cgi_luma = luma(xyz(cgi));
     float di_var, gi_var;
     if (!slow) {
         di_var = cdi_m.z - sqr(cdi_m.y);
         gi_var = cgi_m.z - sqr(cgi_m.y);
     } else {
-        // Short history: spatial estimate over the reference's 29-tap window (frame_denoising.rs:128,180-189: the walk
-        // starts at (-2,-2) and every later row starts at -3), kept as is; the two signals share packed-f32 arithmetic
-        // as in the wavelet pass.
-        const V3 cn = v3(csn.x, csn.y, csn.z);
-        const f2 c_sqrt_luma = mk2(fsqrt(cdi_luma), fsqrt(cgi_luma));
-        const float leeway = csn.w * 0.2f, inv_leeway = frcp(leeway);
-        const int lc = ((int)(pos.y & 7u) + 2) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + 3;
-        f2 sum_l = splat2(0.0f), sum_ll = splat2(0.0f), sum_1 = splat2(0.0f);
-        for (int oy = -2; oy <= 2; oy++) {
-#pragma unroll
-            for (int ox = -3; ox <= 2; ox++) {
-                if (ox == -3 && oy == -2) continue;
-                const int lt = lc + oy * PITCH + ox;
-                const float4 ssn = s_sn[lt];
-                if (ssn.w == 0.0f) continue;
-                const float4 sdi = s_di[lt], sgi = s_gi[lt];
-                const f2 l = (mk2(sdi.x, sgi.x) * 0.2126f + mk2(sdi.y, sgi.y) * 0.7152f) + mk2(sdi.z, sgi.z) * 0.0722f;
-                const f2 d = c_sqrt_luma - mk2(sdi.w, sgi.w);  // = sqrt2(l), staged
-                const float diff = fabsf(ssn.w - csn.w);
-                const float depth_weight = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
-                const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
-                const f2 w = exp_pair(-mk2(fabsf(d.x), fabsf(d.y))) * depth_weight * normal_weight;  // luma sigma 1: |d| * 1 == |d|
-                sum_l = sum_l + l * w; sum_ll = sum_ll + (l * l) * w; sum_1 = sum_1 + w;
-            }
-        }
-        { const float m1 = fdiv(sum_l.x, sum_1.x), m2 = fdiv(sum_ll.x, sum_1.x); di_var = fabsf(m2 - m1 * m1) * 4.0f; }
-        { const float m1 = fdiv(sum_l.y, sum_1.y), m2 = fdiv(sum_ll.y, sum_1.y); gi_var = fabsf(m2 - m1 * m1) * 4.0f; }
+        variance_short_history(csn, cdi, cgi, s_sn, s_di, s_gi, ((int)(pos.y & 7u) + 2) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + 3, PITCH, &di_var, &gi_var);
     }
     di_var = fmax_(di_var, 0.0f);
     gi_var = fmax_(gi_var, 0.0f);
@@ -163,7 +165,70 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
     di_out[center] = f4(xyz(cdi), di_var);
     gi_out[center] = f4(xyz(cgi), gi_var);
 }
-void launch_denoise_variance(const KArgs& a, float4* di_out, float4* gi_out, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a, di_out, gi_out); }
+// ---- the short-history pixels through a COMPACTED list of tile groups (KArgs::var_compact; StTuning::variance_compaction).
+// With KArgs::variance_in_reproject the full-screen launch above has nothing to do for almost every block once histories are
+// four frames long — on a static Cornell frame all 32,400 waves load one mask word and leave, 27 us for 33 MB — so the DI
+// resolving launch, which decides the flags, also APPENDS each 32x8-pixel group that has a flagged pixel to a list (one ballot
+// per wave, one atomic exchange on the group's epoch word per flagged wave, one atomic append per flagged group: k_di.hip), and
+// a small persistent grid walks the list. Layout of var_compact: [0] count, [1] blocks finished, [2, 2 + G) the render epoch
+// that last flagged each group, [2 + G, 2 + 2 G) the list (G = KArgs::var_groups). The last block to finish clears the count
+// for the next frame (every block has read it by then). Per group the work is the kernel's above, windows and arithmetic alike.
+constexpr uint32_t kVarianceGridMax = 2048;
+__global__ ST_KERNEL_BOUNDS void k_denoise_variance_compact(const KArgs a, float4* di_out, float4* gi_out) {
+    constexpr int RW = 38, RH = 12, PITCH = 40;
+    __shared__ float4 s_sn[PITCH * RH];
+    __shared__ float4 s_di[PITCH * RH];
+    __shared__ float4 s_gi[PITCH * RH];
+    const uint32_t tiles_x = (a.width + 7u) >> 3, groups_x = (tiles_x + 3u) >> 2;
+    const uint32_t count = min(a.var_compact[0], a.var_groups);
+    const uint32_t* list = a.var_compact + 2u + a.var_groups;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t g = list[i];
+        const uint32_t gy = g / groups_x, gx = g - gy * groups_x;
+        const uint32_t tx = gx * 4u + wave;
+        const U2 pos = u2(tx * 8u + (lane & 7u), gy * 8u + (lane >> 3));
+        const bool mine = tx < tiles_x && owns_pixel(a, pos);
+        const uint32_t center = pos.y * a.width + pos.x;
+        const bool slow = mine && ((a.tile_mask[tile_mask_index(a, pos)] >> lane) & 1ull) != 0ull;
+        float4 csn = f4z(), cdi = f4z(), cgi = f4z();
+        if (slow) { csn = a.sn[center]; cdi = a.di_diff_curr_colors[center]; cgi = a.gi_diff_curr_colors[center]; }
+        const int32_t bx0 = (int32_t)(gx * 32u) - 3, by0 = (int32_t)(gy * 8u) - 2;
+        for (int k = (int)threadIdx.x; k < RW * RH; k += kBlockThreads) {
+            const int ry = k / RW, rx = k - ry * RW;
+            const int32_t px = bx0 + rx, py = by0 + ry;
+            const int li = ry * PITCH + rx;
+            if (px >= 0 && py >= 0 && px < (int32_t)a.width && py < (int32_t)a.height) {
+                const uint32_t at = (uint32_t)py * a.width + (uint32_t)px;
+                float4 tdi = a.di_diff_curr_colors[at], tgi = a.gi_diff_curr_colors[at];
+                const f2 tl = (mk2(tdi.x, tgi.x) * 0.2126f + mk2(tdi.y, tgi.y) * 0.7152f) + mk2(tdi.z, tgi.z) * 0.0722f;
+                const f2 ts = sqrt2(tl);
+                tdi.w = ts.x; tgi.w = ts.y;
+                s_sn[li] = a.sn[at]; s_di[li] = tdi; s_gi[li] = tgi;
+            } else s_sn[li] = f4z();
+        }
+        __syncthreads();
+        if (slow && csn.w != 0.0f) {
+            float di_var, gi_var;
+            variance_short_history(csn, cdi, cgi, s_sn, s_di, s_gi, ((int)(pos.y & 7u) + 2) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + 3, PITCH, &di_var, &gi_var);
+            reinterpret_cast<float*>(&di_out[center])[3] = fmax_(di_var, 0.0f);
+            reinterpret_cast<float*>(&gi_out[center])[3] = fmax_(gi_var, 0.0f);
+        }
+        __syncthreads();   // the window is restaged by the next group
+    }
+    if (threadIdx.x == 0u) {
+        __threadfence();
+        if (atomicAdd(&a.var_compact[1], 1u) == gridDim.x - 1u) { a.var_compact[0] = 0u; a.var_compact[1] = 0u; }
+    }
+}
+void launch_denoise_variance(const KArgs& a, float4* di_out, float4* gi_out, hipStream_t s) {
+    if (a.var_compact && a.variance_in_reproject) {
+        const uint32_t blocks = a.var_groups < kVarianceGridMax ? a.var_groups : kVarianceGridMax;
+        if (blocks) ST_KLAUNCH(k_denoise_variance_compact, dim3(blocks), dim3(kBlockThreads), s, a, di_out, gi_out);
+        return;
+    }
+    ST_LAUNCH(k_denoise_variance, false, s, a, di_out, gi_out);
+}
 
 // ---------------------------------------------------------------- frame_denoising.rs:219-361 (five à-trous passes)
 // Measured (rocprofv3, MI355X): the LDS-staged passes run at 70-75 % of their VALU issue time and within 10-30 % of the

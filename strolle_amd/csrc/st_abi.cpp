@@ -414,6 +414,35 @@ int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused) {
     return ST_OK;
 }
 
+// Streaming ceiling of this device by this library's own kernel: `iters` grid-stride float4 copies of `bytes` (src -> dst, both
+// allocated here), best of them, as (bytes read + bytes written) / time in GB/s.
+int st_debug_copy_bandwidth(StEngine* e, size_t bytes, int iters, double* out_gbps) {
+    ST_REQUIRE(e && out_gbps && bytes >= 16 && iters > 0, "bad argument");
+    Engine* en = E(e);
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "host-only engine");
+    ST_HIP(hipSetDevice(en->device));
+    const size_t n = bytes / 16;
+    void *src = nullptr, *dst = nullptr;
+    ST_HIP(hipMalloc(&src, n * 16));
+    if (hipMalloc(&dst, n * 16) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(src); return fail(ST_ERR_HIP, "hipMalloc(copy destination) failed"); }
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int rc = ST_OK; double best = 0.0;
+    if (hipMemset(src, 0x3c, n * 16) != hipSuccess || hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) rc = fail(ST_ERR_HIP, "copy bandwidth set-up failed");
+    for (int i = 0; rc == ST_OK && i < iters + 1; i++) {   // the first pass is a warm-up
+        (void)hipEventRecord(t0, nullptr);
+        en->L.launch_copy_float4(static_cast<float4*>(dst), static_cast<const float4*>(src), n, 256u * 16u, nullptr);
+        (void)hipEventRecord(t1, nullptr);
+        if (hipEventSynchronize(t1) != hipSuccess) { rc = fail(ST_ERR_HIP, "copy kernel failed"); break; }
+        float ms = 0.0f; (void)hipEventElapsedTime(&ms, t0, t1);
+        if (i > 0 && ms > 0.0f) best = std::max(best, 2.0 * (double)(n * 16) / (ms * 1e-3) / 1e9);
+    }
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    (void)hipFree(src); (void)hipFree(dst);
+    *out_gbps = best;
+    return rc;
+}
+
 int st_profile_enable(StEngine* e, int enabled) { ST_REQUIRE(e, "null engine"); E(e)->profiling = (enabled & 1) != 0; E(e)->count_bytes = (enabled & 2) != 0; E(e)->profile_group_atrous = (enabled & 4) != 0; E(e)->profile_kernel_events = (enabled & 8) != 0; return ST_OK; }
 int st_profile_read(StEngine* e, StKernelProfile* out, size_t capacity, size_t* count, int reset) {
     ST_REQUIRE(e && out && count, "null argument");

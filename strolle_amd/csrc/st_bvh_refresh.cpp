@@ -16,7 +16,10 @@ void Engine::measure_stack_need() {
         }
     }
     bvh_stack_need = deepest;
-    if (deepest > (uint32_t)kBvhStackSize && !bvh_depth_warned) {
+    // A deeper tree is reported through st_tick's status (ST_ERR_BVH_TOO_DEEP, once per build) — or, with StTuning::allow_deep_bvh,
+    // once on stderr
+    bvh_too_deep_unreported = deepest > (uint32_t)kBvhStackSize;
+    if (bvh_too_deep_unreported && tuning.allow_deep_bvh && !bvh_depth_warned) {
         bvh_depth_warned = true;
         fprintf(stderr, "[strolle-hip] warning: the BVH is %u internal nodes deep; traversal keeps %d pending entries per ray (as the reference does) and drops deeper ones — distant geometry may be missed. st_debug_bvh_depth reports this.\n", deepest, kBvhStackSize);
     }

@@ -246,6 +246,7 @@ struct CameraState {
     void* slab = nullptr; size_t slab_bytes = 0;
     float4* plane[ST_BUF_COUNT + kInternalPlanes] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
     size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
+    uint32_t* var_compact = nullptr; uint32_t var_groups = 0, var_epoch = 0;  // KArgs::var_compact: {count, finished, epoch[G], list[G]}
     unsigned long long* tile_mask = nullptr; size_t tile_mask_tiles = 0;  // two arrays of one u64 per 8x8 tile (KArgs::tile_mask, KArgs::gi_late_mask)
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
@@ -347,7 +348,7 @@ struct Engine {
     // Deepest chain of internal nodes in the uploaded stream = the most entries a traversal can have pending (every internal
     // node on the path may push its far child). The kernels' per-lane stack holds kBvhStackSize entries (strolle-gpu/src/lib.rs:76;
     // the reference indexes past the end there, here a push beyond the end is dropped): a deeper tree is reported, not hidden.
-    uint32_t bvh_stack_need = 0; bool bvh_depth_warned = false;
+    uint32_t bvh_stack_need = 0; bool bvh_depth_warned = false, bvh_too_deep_unreported = false;
     void measure_stack_need();
     // Device form of the stream (st_types.h "device BVH stream"): every entry four texels — an internal node as the
     // serializer wrote it (far pointer remapped), a leaf entry followed by its triangle's hit-test record — so that one

@@ -444,6 +444,43 @@ def test_bvh_depth_is_reported():
         assert (depth <= stack) == fits, (depth, stack)
 
 
+def test_a_tree_deeper_than_the_stack_fails_the_tick_loudly():
+    """a tree deeper than the 24-entry traversal stack drops pushes — st_tick says ST_ERR_BVH_TOO_DEEP (once per
+    build; the scene is uploaded all the same) unless StTuning::allow_deep_bvh accepts it."""
+    from strolle_amd.api import ST_ERR_BVH_TOO_DEEP, StrolleError
+    e = Engine(device=-1)
+    scenes.build_dungeon(e, subdivide=1)        # the builder sets allow_deep_bvh for its synthetic variants ...
+    assert e.tuning().allow_deep_bvh == 1
+    e.set_tuning(allow_deep_bvh=0)              # ... undo that: the status must come
+    with pytest.raises(StrolleError) as err:
+        e.tick()
+    assert f"status {ST_ERR_BVH_TOO_DEEP}" in str(err.value) and "25 internal nodes deep" in str(err.value)
+    depth, stack = e.bvh_depth()
+    assert depth == 25 and len(e.read_scene(0)) > 0, "the tick did its work before reporting"
+    e.tick()                                     # reported once per build: a tick that rebuilds nothing is clean
+    e.set_tuning(allow_deep_bvh=1)
+    e.insert_light(99, Light.point((0.0, 1.0, 0.0), 0.1, (1.0, 1.0, 1.0), 5.0)); e.tick()
+    e.close()
+
+
+def test_tuning_round_trips_and_rejects_a_foreign_struct():
+    """StTuning (include/strolle_hip.h): get / set round trip, defaults as documented, a wrong struct_size is refused."""
+    from strolle_amd.api import StrolleError
+    e = Engine(device=-1)
+    t = e.tuning()
+    assert t.struct_size == C.sizeof(type(t)) and t.overlap == 1 and t.fuse == 1 and t.tile_map == 1 and t.tile_map_denoise == 2
+    assert t.anyhit_fast == 1 and t.occluder_table_log2 == 19 and t.allow_deep_bvh == 0 and t.variance_compaction == 1
+    e.set_tuning(fuse=0, tile_map=2, side_priority=-1)
+    t2 = e.tuning()
+    assert (t2.fuse, t2.tile_map, t2.side_priority, t2.overlap) == (0, 2, -1, 1)
+    t2.struct_size = 12
+    with pytest.raises(StrolleError):
+        e.set_tuning(t2)
+    with pytest.raises(StrolleError):
+        e.set_tuning(tile_map=7)
+    e.close()
+
+
 def test_atlas_rectangles_are_released_and_reused():
     """images.rs:54-113: an image that is removed, or comes back with another size, gives its rectangle back. Rectangles of
     live images never overlap, stay inside the 8192 x 8192 atlas, and churn far beyond the atlas area never runs out of
