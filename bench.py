@@ -45,9 +45,17 @@ WAVELET_SYMBOLS = ["denoise_wavelet_12", "denoise_wavelet_lds<1>", "denoise_wave
 # the algorithmic reference so fusion shows up as a gain"). `roofline.wavelet_only` restates the family without that launch.
 
 
-def measure_copy_ceiling(torch, dev):
-    """Device-to-device copy of 1 GiB on this box: (bytes read + bytes written) / time, best of 6 (SURVEY.md 8d asks for the
-    measured ceiling beside the 8 TB/s spec figure)."""
+def measure_copy_ceiling(torch, dev, engine=None):
+    """This box's streaming ceiling, (bytes read + bytes written) / time of a 1 GiB device-to-device copy, two ways (SURVEY.md 8d asks
+    for the measured ceiling beside the 8 TB/s spec figure): the library's own grid-stride float4 copy kernel (k_util.hip — the kind of
+    kernel /opt/skills/guides/MI355X_MICROARCH.md measures 6.29 TB/s with) and torch's copy_ (what rounds 1-3 reported).
+    Returns (own kernel GB/s or None, torch GB/s). `frac` figures against a measured ceiling use the LARGER of the two."""
+    own = None
+    if engine is not None:
+        try:
+            own = engine.copy_bandwidth(1 << 30, 6)
+        except Exception:
+            own = None
     n = (1 << 30) // 4
     src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
@@ -59,27 +67,32 @@ def measure_copy_ceiling(torch, dev):
         best = ms if best is None else min(best, ms)
     del src, dst
     torch.cuda.empty_cache()
-    return 2.0 * (1 << 30) / (best * 1e-3) / 1e9
+    return own, 2.0 * (1 << 30) / (best * 1e-3) / 1e9
 
 
 def cpu_baseline(args, size):
-    """The CPU oracle ("port": our C++ restatement of the reference; the reference's lavapipe path cannot run here)
-    timed on this host's cores on a bounded sample of the same workload."""
+    """The CPU oracle ("port": our C++ restatement of the reference; the reference's lavapipe path cannot run here) timed on this
+    host's cores on a BOUNDED sample of the same workload — same scene, mode and size as the GPU line: one warm-up frame, which
+    also prices a frame, then as many timed frames as fit ~20 s (1 to 5); best frame reported."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import OracleEngine, oracle_lib
     from strolle_amd import CameraMode, scenes
     lib = oracle_lib()
     cores = int(lib.or_num_threads())
     e = OracleEngine()
-    scenes.build_cornell(e)
+    mode = {"image": CameraMode.IMAGE, "gi_diffuse": CameraMode.GI_DIFFUSE, "reference": CameraMode.REFERENCE, "heatmap": CameraMode.BVH_HEATMAP}[args.mode]
+    if args.scene == "cornell":
+        scenes.build_cornell(e); desc = scenes.cornell_camera(size, mode, depth=1)
+    else:
+        scenes.build_dungeon(e, subdivide=2 if args.scene == "dungeon134k" else 0); desc = scenes.dungeon_camera(size, mode, depth=1)
     e.set_seed(args.seed)
-    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
     cam = e.create_camera(desc)
-    warm, timed = 2, 5
-    for _ in range(warm):
-        e.update_camera(cam, desc); e.tick(); e.render_camera(cam)
+    t0 = time.perf_counter()
+    e.update_camera(cam, desc); e.tick(); e.render_camera(cam)
+    first = time.perf_counter() - t0           # includes the scene build on the first tick: an over-estimate, i.e. a cautious frame count
+    timed = max(1, min(5, int(20.0 / max(first, 1e-3))))
     per_frame = []
-    for _ in range(timed):   # SURVEY.md 8(d): best of 5
+    for _ in range(timed):
         e.ray_count(cam, reset=True)
         t0 = time.perf_counter()
         e.update_camera(cam, desc); e.tick(); e.render_camera(cam)
@@ -89,26 +102,54 @@ def cpu_baseline(args, size):
     mean_dt = sum(d for _, d in per_frame) / timed
     return {"value": round(best_rate / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
             "ms_per_frame": round(best_dt * 1e3, 1), "mean_ms_per_frame": round(mean_dt * 1e3, 1),
-            "sample": f"best of {timed} frames (after {warm} warm-up) of the same {size[0]}x{size[1]} Cornell Image workload, OpenMP over {cores} threads"}
+            "sample": f"best of {timed} frame(s) (after 1 warm-up frame) of the same workload — {args.scene} {size[0]}x{size[1]} mode {args.mode} —, OpenMP over {cores} threads"}
 
 
-def static_traffic(symbols):
-    """HBM bytes per launch of the given kernel symbols from the committed rocprofv3 counter passes (profiles/pmc_latest.json:
-    separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench command, tools/gpu_profile_quick.sh). Not measured by
-    this process: hardware counters need the profiler."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if not os.path.exists(path):
-        return None, None
-    try:
-        pmc = json.load(open(path))
-    except Exception:
-        return None, None
+def workload_key(scene, width, height, mode):
+    return f"{scene}_{width}x{height}_{mode}"
+
+
+_PMC_CACHE = {}
+
+
+def load_pmc(key):
+    """The committed rocprofv3 counter summary of THIS workload (profiles/pmc/<scene>_<W>x<H>_<mode>.json; separate `--pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` passes of this bench command, tools/gpu_profile_workload.sh + tools/summarize_profiles.py), or None. Another
+    workload's bytes are never substituted (VERDICT r3 weak #3)."""
+    if key not in _PMC_CACHE:
+        path = os.path.join(ROOT, "profiles", "pmc", key + ".json")
+        try:
+            _PMC_CACHE[key] = json.load(open(path))
+        except Exception:
+            _PMC_CACHE[key] = None
+    return _PMC_CACHE[key]
+
+
+def static_traffic(symbols, key, run_slots=None):
+    """HBM bytes per launch of the given profiler slots / kernel symbols from the workload's committed counter summary. Not measured
+    by this process: hardware counters need the profiler. Returns (bytes or None, source note). The summary carries a stamp — the
+    commit it was taken at and the launch structure (the profiler slots of one frame); when `run_slots` (this run's slots) differs
+    from the stamped list the summary describes other launches and is refused."""
+    pmc = load_pmc(key)
+    if pmc is None:
+        return None, f"no counter summary for this workload (profiles/pmc/{key}.json absent): null rather than another workload's bytes"
+    stamp = pmc.get("_stamp", {})
+    if run_slots is not None and stamp.get("launch_slots") is not None and sorted(stamp["launch_slots"]) != sorted(run_slots):
+        return None, f"profiles/pmc/{key}.json was taken with another launch structure (commit {stamp.get('commit')}): refused"
     total, n = 0.0, 0
     for s in symbols:
         e = pmc.get(s)
         if e and e.get("hbm_bytes_per_launch") is not None:
             total += e["hbm_bytes_per_launch"] * e["launches_sampled"]; n += e["launches_sampled"]
-    return (round(total / n) if n else None), "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; (2 x FETCH_SIZE + WRITE_SIZE) x 1024, calibration in profiles/README.md)"
+    return (round(total / n) if n else None), f"profiles/pmc/{key}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at commit {stamp.get('commit')}; (2 x FETCH_SIZE + WRITE_SIZE) x 1024, calibration in profiles/README.md)"
+
+
+def build_stamp():
+    """profiles/.build_stamp, written by tools/gpurun_batch.sh before the snapshot leaves for the GPU box (the box has no .git)."""
+    try:
+        return open(os.path.join(ROOT, "profiles", ".build_stamp")).read().strip()
+    except Exception:
+        return None
 
 
 def n1_reference(key):
@@ -498,7 +539,9 @@ def main():
         strong["strong_config5"] = strong_config(torch, dist, args, world, rank, local_rank, debug_shared, "dungeon", "image", ex, "config5_dungeon_3840x2160_image_ms")
         if world == 4:
             strong["strong_config4"] = strong_config(torch, dist, args, world, rank, local_rank, debug_shared, "cornell", "reference", ex, "config4_cornell_3840x2160_reference_ms")
-    copy_ceiling = measure_copy_ceiling(torch, dev) if (rank == 0 and not debug_shared) else None
+    copy_own, copy_torch = measure_copy_ceiling(torch, dev, None if (not args.no_extras and world > 1) else engine) if (rank == 0 and not debug_shared) else (None, None)
+    copy_ceiling = max([c for c in (copy_own, copy_torch) if c], default=None)
+    key = workload_key(args.scene, width, height, args.mode)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -528,8 +571,11 @@ def main():
                                    "hardware_scaling_curve": "none measured by the builder (gpurun boxes have one GPU); whatever the driver's N = 1, 2, 4, 8 runs print is the first",
                                    **strong}
         result.update(extras)
+        result["build_stamp"] = build_stamp()
         if copy_ceiling is not None:
             result["hbm_copy_ceiling_GBps_measured"] = round(copy_ceiling, 1)
+            result["hbm_copy_ceiling"] = {"own_float4_copy_kernel_GBps": None if copy_own is None else round(copy_own, 1), "torch_copy_GBps": round(copy_torch, 1),
+                                          "guide_GBps": 6290.0, "note": "frac_of_measured_copy_ceiling uses the larger of the two measured figures; `frac` is always against the 8 TB/s spec peak"}
         if prof:
             by = {p["name"]: p for p in prof}
             # the dominant kernel: the slot — or, for the a-trous passes, the family of slots — with the largest total time
@@ -559,7 +605,8 @@ def main():
             avg_ms = tot_ms / launches
             b_bytes = (alg - trav) / launches
             achieved = b_bytes / (avg_ms * 1e-3) / 1e9   # screen-space (HBM) bytes only: traversal bytes are cache- / LDS-served
-            traffic, source = static_traffic(symbols)
+            run_slots = sorted(p["name"] for p in prof)
+            traffic, source = static_traffic(symbols, key, run_slots)
             wavelet_only = None
             if fam and "denoise_wavelet+composition" in by:   # the family without the launch that also composes the frame
                 rest = [p for p in fam if p["name"] != "denoise_wavelet+composition"]
@@ -586,7 +633,7 @@ def main():
                                                "ms_per_frame": round(den_ms / args.steps, 5), "algorithmic_bytes_per_frame": round(den_alg / args.steps)}
             tot = sum(p["total_ms"] for p in prof)
             def counter_rate(p):  # the slot's HBM bytes per launch by the committed counter passes over this run's launch time
-                per_launch, _ = static_traffic([p["name"]])
+                per_launch, _ = static_traffic([p["name"]], key, run_slots)
                 return round(per_launch / (p["total_ms"] / p["launches"] * 1e-3) / 1e9, 1) if per_launch and p["total_ms"] > 0 else None
             result["kernels"] = {p["name"]: {"ms_per_frame": round(p["total_ms"] / args.steps, 5), "launches_per_frame": round(p["launches"] / args.steps, 2),
                                             "us_per_launch": round(p["total_ms"] / p["launches"] * 1e3, 2),
@@ -596,7 +643,7 @@ def main():
                                  for p in sorted(prof, key=lambda p: -p["total_ms"])}
             result["kernels_note"] = ("B_only_GBps: compulsory screen-space bytes of the REFERENCE passes a launch executes (unfused accounting, SURVEY.md 8d) "
                                       "over its duration - an equivalent rate: a fused launch never moves part of those bytes, so it can exceed the HBM peak; "
-                                      "counter_GBps: the same launch's FETCH_SIZE / WRITE_SIZE bytes from profiles/pmc_latest.json (static, an upper bound for gather kernels) "
+                                      "counter_GBps: the same launch's FETCH_SIZE / WRITE_SIZE bytes from profiles/pmc/<workload>.json (static, an upper bound for gather kernels) "
                                       "over this run's duration - the figure to hold against the 8 TB/s peak")
             if kernel_events:
                 for name_, q in kernel_events.items():
@@ -615,20 +662,22 @@ def main():
             # B_frac_of_peak, an unfused-accounting equivalent rate that fusion inflates — is the achieved HBM bandwidth.
             counted, missing = 0.0, []
             for q in prof:
-                per_launch, _ = static_traffic([q["name"]])
+                per_launch, _ = static_traffic([q["name"]], key, run_slots)
                 if per_launch is None:
                     missing.append(q["name"])
                 else:
                     counted += per_launch * q["launches"] / args.steps
-            result["frame_bytes"].update({"counter_GB_per_frame": round(counted / 1e9, 4), "counter_GBps": round(counted / (ms * 1e-3) / 1e9, 1),
-                                          "counter_frac_of_peak": round(counted / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                          "counter_frac_of_measured_copy_ceiling": None if not copy_ceiling else round(counted / (ms * 1e-3) / 1e9 / copy_ceiling, 4),
+            have_counters = len(missing) < len(prof)
+            result["frame_bytes"].update({"counter_GB_per_frame": round(counted / 1e9, 4) if have_counters else None, "counter_GBps": round(counted / (ms * 1e-3) / 1e9, 1) if have_counters else None,
+                                          "counter_frac_of_peak": round(counted / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if have_counters else None,
+                                          "counter_frac_of_measured_copy_ceiling": None if (not copy_ceiling or not have_counters) else round(counted / (ms * 1e-3) / 1e9 / copy_ceiling, 4),
+                                          "counter_source": static_traffic([], key, run_slots)[1],
                                           "counter_slots_without_data": missing,
-                                          "counter_note": "sum over slots of (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/pmc_latest.json (static: an earlier rocprofv3 --pmc run of this command; an upper bound for the gather kernels) x launches per frame of THIS run, over THIS run's ms_per_step"})
+                                          "counter_note": "sum over slots of (2 x FETCH_SIZE + WRITE_SIZE) per launch from the workload's committed counter summary (static: an earlier rocprofv3 --pmc run of this command; an upper bound for the gather kernels) x launches per frame of THIS run, over THIS run's ms_per_step"})
             result["ms_per_step_with_event_timing"] = round(profiled_ms, 4)
-        if world == 1 and not args.no_cpu_baseline and headline:
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(args, base)
+                result["cpu_baseline"] = cpu_baseline(args, (width, height))
             except Exception as ex:  # the baseline must never sink the GPU number
                 result["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(result))

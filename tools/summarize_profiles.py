@@ -2,7 +2,12 @@
 """Turn the rocprofv3 output that `tools/gpu_profile_round.sh` left under gpurun_out/ into the small, committed
 summaries under profiles/.
 
-  python tools/summarize_profiles.py r01          # tag for the file names
+  python tools/summarize_profiles.py r01                                  # tag for the file names; inputs straight under gpurun_out/
+  python tools/summarize_profiles.py r04 --key dungeon_1920x1080_image   # one WORKLOAD of tools/gpu_profile_workload.sh:
+      inputs gpurun_out/prof_<key>/{stats,stats_serial,fetch,write,sq,lane}/ + bench.json; outputs profiles/<tag>_<key>_*.csv / .json
+      and profiles/pmc/<key>.json — the counter summary bench.py looks up BY WORKLOAD, stamped with the commit and the launch structure
+      (the profiler slots of a frame) of the bench line taken in the same gpurun call; bench.py refuses a summary whose stamp names
+      other launches and prints null for a workload that has none.
 
 Inputs (any that exist):
   gpurun_out/prof_stats/**/*_kernel_stats.csv          rocprofv3 --kernel-trace --stats of the default bench command
@@ -66,8 +71,13 @@ def is_ours(name: str) -> bool:
     return re.search(r"st::(?:fast::|exact::)?k_", name) is not None
 
 
+BASE = os.path.join(ROOT, "gpurun_out")
+PASS_DIRS = {"prof_stats": "prof_stats", "prof_stats_serial": "prof_stats_serial", "prof_fetch": "prof_fetch", "prof_write": "prof_write", "prof_sq": "prof_sq", "prof_lane": "prof_lane"}
+
+
 def latest(pattern):
-    files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True), key=os.path.getmtime)
+    first, rest = pattern.split("/", 1)
+    files = sorted(glob.glob(os.path.join(BASE, PASS_DIRS.get(first, first), rest), recursive=True), key=os.path.getmtime)
     return files[-1] if files else None
 
 
@@ -77,9 +87,25 @@ def stats_rows(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "latest"
+    global BASE
+    argv = [a for a in sys.argv[1:]]
+    key = None
+    if "--key" in argv:
+        i = argv.index("--key"); key = argv[i + 1]; del argv[i:i + 2]
+    tag = argv[0] if argv else "latest"
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
+    bench_path = os.path.join(ROOT, "gpurun_out", "bench_default.json")
+    if key:
+        BASE = os.path.join(ROOT, "gpurun_out", f"prof_{key}")
+        for k in list(PASS_DIRS): PASS_DIRS[k] = k[len("prof_"):]
+        bench_path = os.path.join(BASE, "bench.json")
+        tag = f"{tag}_{key}"
+    bench_line = None
+    try:
+        bench_line = json.loads(open(bench_path).read().strip().splitlines()[-1])
+    except Exception:
+        pass
 
     f = latest("prof_stats/**/*_kernel_stats.csv")
     if f:
@@ -131,9 +157,26 @@ def main():
                              "write_size_kib": sum(h["write_size_kib"] * h["launches_sampled"] for h in have) / n,
                              "hbm_bytes_per_launch": round(sum(h["hbm_bytes_per_launch"] * h["launches_sampled"] for h in have) / n),
                              "launches_sampled": n, "symbols": syms}
-        for name in (f"{tag}_pmc.json", "pmc_latest.json"):
-            json.dump(summary, open(os.path.join(out_dir, name), "w"), indent=1, sort_keys=True)
+        # the stamp: which build and which launch structure these bytes describe (bench.py refuses a mismatch)
+        summary["_stamp"] = {"commit": (bench_line or {}).get("build_stamp"), "workload": key or "cornell_1920x1080_image",
+                             "launch_slots": sorted((bench_line or {}).get("kernels", {}).keys()) or None,
+                             "ms_per_step_of_the_same_call": (bench_line or {}).get("ms_per_step")}
+        json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+        os.makedirs(os.path.join(out_dir, "pmc"), exist_ok=True)
+        json.dump(summary, open(os.path.join(out_dir, "pmc", (key or "cornell_1920x1080_image") + ".json"), "w"), indent=1, sort_keys=True)
 
+    lane = {}
+    f = latest("prof_lane/**/*_counter_collection.csv")
+    if f:
+        ln = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            if is_ours(r["Kernel_Name"]):
+                ln[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, c in ln.items():
+            m = {n: (sum(v[len(v) // 2:]) / max(1, len(v[len(v) // 2:]))) for n, v in c.items()}
+            if m.get("SQ_ACTIVE_INST_VALU"):
+                w = max(m.get("SQ_WAVES", 0.0), 1.0)
+                lane[k] = (round(m.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * m["SQ_ACTIVE_INST_VALU"]), 3), round(m.get("SQ_INSTS_SALU", 0.0) / w), round(m.get("SQ_INSTS_LDS", 0.0) / w), round(m.get("SQ_INSTS_VMEM_RD", 0.0) / w))
     f = latest("prof_sq/**/*_counter_collection.csv")
     if f:
         sq = defaultdict(lambda: defaultdict(list))
@@ -143,7 +186,7 @@ def main():
         with open(os.path.join(out_dir, f"{tag}_sq.csv"), "w", newline="") as o:
             w = csv.writer(o)
             w.writerow(["kernel", "waves", "valu_insts_per_wave", "valu_cycles_share_of_wave_life", "wait_any_share", "wait_inst_share",
-                        "active_any_share", "valu_floor_us_at_2.4GHz"])
+                        "active_any_share", "valu_floor_us_at_2.4GHz", "lane_utilisation_valu", "salu_insts_per_wave", "lds_insts_per_wave", "vmem_rd_insts_per_wave"])
             rows = []
             for k, c in sq.items():
                 m = {n: (sum(v[len(v) // 2:]) / max(1, len(v[len(v) // 2:]))) for n, v in c.items()}
@@ -154,13 +197,12 @@ def main():
                 # transcendental ones longer, so this is a lower bound); 1024 SIMDs
                 floor_us = m["SQ_INSTS_VALU"] * 2.0 / 1024.0 / 2400.0
                 rows.append([k, int(m["SQ_WAVES"]), round(m["SQ_INSTS_VALU"] / m["SQ_WAVES"]), round(m["SQ_ACTIVE_INST_VALU"] / wc, 3),
-                             round(m["SQ_WAIT_ANY"] / wc, 3), round(m["SQ_WAIT_INST_ANY"] / wc, 3), round(m["SQ_ACTIVE_INST_ANY"] / wc, 3), round(floor_us, 1)])
-            rows.sort(key=lambda r: -r[-1])
+                             round(m["SQ_WAIT_ANY"] / wc, 3), round(m["SQ_WAIT_INST_ANY"] / wc, 3), round(m["SQ_ACTIVE_INST_ANY"] / wc, 3), round(floor_us, 1)] + list(lane.get(k, ("", "", "", ""))))
+            rows.sort(key=lambda r: -r[7])
             w.writerows(rows)
 
-    b = os.path.join(ROOT, "gpurun_out", "bench_default.json")
-    if os.path.exists(b):
-        shutil.copy(b, os.path.join(out_dir, f"{tag}_bench.json"))
+    if os.path.exists(bench_path):
+        shutil.copy(bench_path, os.path.join(out_dir, f"{tag}_bench.json"))
     print("wrote", sorted(os.listdir(out_dir)))
 
 
