@@ -181,9 +181,46 @@ int st_set_seed(StEngine* e, uint64_t base_seed);
 /* Blue-noise texture (256x256 RGBA8), decoded by the caller from strolle/assets/blue-noise.png
  * (strolle/src/noise.rs:40-50 embeds the PNG; this library carries no image decoder). */
 int st_set_blue_noise(StEngine* e, const uint8_t* rgba_256x256x4, size_t bytes);
-/* Multi-GPU tiling: restrict every per-pixel launch of this camera to the pixel rows [y0, y1)
- * of the full viewport (0,0 = whole frame). Pixels keep their absolute coordinates. */
+/* Multi-GPU tiling: restrict every per-pixel launch of this camera to the window [x0, x1) x [y0, y1) of the full viewport
+ * (x0 = x1 = 0: all columns; y0 = y1 = 0: all rows). Pixels keep their absolute coordinates — RNG, reprojection and every
+ * neighbour tap are those of the full frame, so Reference / heatmap tiles reproduce the single-GPU image bit for bit; Image
+ * mode reads neighbours, which is what the apron of st_dist_set_partition is for. x0 and x1 must be multiples of 16 (the
+ * half-resolution passes work on 2x1 cells in tiles of 8) or the frame's right edge. st_camera_set_rows = all columns. */
+int st_camera_set_window(StEngine* e, StHandle camera, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 int st_camera_set_rows(StEngine* e, StHandle camera, uint32_t y0, uint32_t y1);
+/* ---- multi-GPU behind the boundary (NEW seam; SURVEY.md section 8e, BASELINE.json configs 4 and 5). One process per GPU, one
+ * engine per process, the scene replicated; the frame is cut into tiles, every rank renders its tile (+ an apron of redundant
+ * pixels in Image mode, whose passes read neighbours) with absolute pixel coordinates, and the ONE collective of the path
+ * gathers the composed tiles to rank 0: grouped ncclSend / ncclRecv over RCCL — one point-to-point message per xGMI link into
+ * the root, not a ring — on a communication stream the engine owns, ordered behind the frame by an event and overlapped with
+ * the next frame. librccl is opened at run time (a process that already loaded it, e.g. through torch, shares that copy). */
+typedef struct StDistRect { uint32_t x0, y0, x1, y1; } StDistRect;          /* [x0, x1) x [y0, y1) in pixels */
+typedef struct StDistUniqueId { char internal[128]; } StDistUniqueId;      /* ncclUniqueId */
+/* The partition rule (a pure function; `e` is not needed): `world` tiles in a grid of `cols` columns (0: the default grid — 1x1,
+ * two row bands, 2x2, 3x2, 4x2, ... columns >= rows; a prime world gives row bands) whose edges sit on multiples of 16 pixels in
+ * x and 8 in y; rank r owns tile (r % cols, r / cols). */
+int st_dist_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, uint32_t rank, StDistRect* owned);
+/* `owned` widened by `apron` pixels on every side that has a neighbour, outward to the same 16 / 8 grid: what a rank renders. */
+int st_dist_window(uint32_t width, uint32_t height, const StDistRect* owned, uint32_t apron, StDistRect* window);
+/* RCCL transport: rank 0 makes an id (ncclGetUniqueId) and hands it to the other processes by its own means (the Rust host: a
+ * pipe or MPI; bench.py: torch.distributed's store); every rank then joins with st_dist_init on its engine's device. */
+int st_dist_unique_id(StDistUniqueId* out);
+int st_dist_init(StEngine* e, int rank, int world, const StDistUniqueId* id);
+/* In-process transport (tests; a single-GPU box): the engines of one process that share `group` exchange tiles through a
+ * mailbox — same partition, pack / unpack and stream ordering, no RCCL. Works on host-only engines too (host frames). Within a
+ * frame the non-root ranks call st_dist_gather before rank 0 does. */
+int st_dist_init_local(StEngine* e, int rank, int world, uint64_t group);
+int st_dist_shutdown(StEngine* e);
+int st_dist_rank(StEngine* e, int* rank, int* world);
+/* Sets the camera's window (st_camera_set_window) to this rank's tile + apron; reports both rectangles (either may be NULL). */
+int st_dist_set_partition(StEngine* e, StHandle camera, uint32_t cols, uint32_t apron, StDistRect* owned, StDistRect* window);
+/* `frame`: the buffer st_render_camera just composed into on `hip_stream` (full-frame sized, the camera's output format; this
+ * rank's tile of it is what travels). `full_on_root`: where rank 0 assembles the frame (may be `frame` itself: its own tile is
+ * then already in place); ignored on other ranks. Returns at once; the caller alternates two frame buffers so that frame N is
+ * gathered while frame N+1 renders. st_dist_wait orders `hip_stream` behind the camera's last gather (host_wait != 0: blocks). */
+int st_dist_gather(StEngine* e, StHandle camera, const void* frame, void* full_on_root, void* hip_stream);
+int st_dist_wait(StEngine* e, StHandle camera, void* hip_stream, int host_wait);
+
 /* camera.rs:170-175 `viewport.format`: the reference renders into a texture view of that format and the hardware converts
  * on store; here the composition kernel does. RGBA32F (default, 16 B/pixel), RGBA16F (8 B, round to nearest even),
  * RGBA8 / BGRA8 sRGB (4 B: clamp, IEC 61966-2-1 encode, round to nearest; alpha 255). The buffer handed to
@@ -197,7 +234,7 @@ int st_camera_set_output_format(StEngine* e, StHandle camera, int format);
  * sizeof(StTuning). Environment variables (read once, when the engine is created) override the defaults:
  *   ST_NO_OVERLAP ST_NO_FUSE ST_NO_FUSE_DI_HEAD ST_NO_FUSE_SPATIAL ST_NO_FUSE_GI_SAMPLING ST_NO_FUSE_GI_VALIDATION
  *   ST_NO_FUSE_GI_REPROJECTION ST_NO_FUSE_WAVELET ST_NO_FUSE_COMPOSE ST_NO_PREVIEW_BOTH ST_NO_VARIANCE_IN_REPROJECT
- *   ST_NO_VARIANCE_COMPACTION ST_KEEP_ALL_PLANES ST_KEEP_SCRATCH ST_NO_GI_ALIAS ST_NO_STAGING ST_NO_DOUBLE_BUFFER ST_NO_PACKED_BASE
+ *   ST_KEEP_ALL_PLANES ST_KEEP_SCRATCH ST_NO_GI_ALIAS ST_NO_STAGING ST_NO_DOUBLE_BUFFER ST_NO_PACKED_BASE
  *   ST_NO_ANYHIT_FAST ST_NO_OCCLUDER_TABLE ST_ALLOW_DEEP_BVH (=1 clears / sets the field), ST_DI_HEAD_ON_MAIN ST_TILE_MAP
  *   ST_TILE_MAP_DENOISE ST_SIDE_PRIORITY ST_TICK_TIMING ST_OCCLUDER_TABLE_LOG2 ST_DEVICE_BAKE (= value). */
 typedef struct StTuning {
@@ -213,8 +250,6 @@ typedef struct StTuning {
     uint32_t fuse_compose;          /* fast build: frame composition inside the last a-trous pass */
     uint32_t preview_both;          /* both GI preview passes + resolving in one launch, flagged pixels served afterwards */
     uint32_t variance_in_reproject; /* estimate_variance's long-history branch inside the reproject stages */
-    uint32_t variance_compaction;   /* ... and its short-history pixels through a compacted list of flagged tile groups (ballot + one
-                                     * atomic append per flagged group) walked by a small persistent grid, instead of a full-screen launch */
     uint32_t lean_frame;            /* fast build: planes nothing reads again are not stored (st_debug_keep_all_planes) */
     uint32_t skip_scratch_stores;   /* fused DI spatial launch keeps its scratch records in registers */
     uint32_t di_head_on_main;       /* DI sampling + temporal on the caller's stream (0: on the side stream) */
@@ -304,6 +339,11 @@ enum StPassBit {
     ST_PASS_COMPOSITION = 1u << 26, ST_PASS_BVH_HEATMAP = 1u << 27, ST_PASS_REF_TRACING = 1u << 28, ST_PASS_REF_SHADING = 1u << 29
 };
 int st_debug_set_pass_mask(StEngine* e, uint64_t mask);
+/* The variance pass's short-history flags after the last frame (StTuning::variance_in_reproject): one 64-bit word per 8x8 tile, bit =
+ * pixel of the tile — the pixels whose estimate_variance takes the 29-tap spatial branch (frame_denoising.rs:128-189). out == NULL: only
+ * the tile count. (Steady state, 1080p: 8 % of the pixels on the Cornell box, 84 % in the dungeon — DI samples without confidence reset
+ * their history every frame.) */
+int st_debug_variance_flags(StEngine* e, StHandle camera, uint64_t* tile_mask_out, size_t capacity_tiles, size_t* tiles);
 /* The pass bits of every launch the last st_render_camera considered, in launch order (executed or not): lets a test walk
  * the shipped launch structure without knowing it. Returns the count; writes at most `capacity` entries. */
 int st_debug_last_launches(StEngine* e, uint64_t* out_bits, size_t capacity, size_t* count);

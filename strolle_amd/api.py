@@ -50,10 +50,21 @@ class StCamera(C.Structure):
                 ("pos_x", C.c_uint32), ("pos_y", C.c_uint32), ("_pad", C.c_uint32), ("transform", C.c_float * 16), ("projection", C.c_float * 16)]
 
 
+class StDistRect(C.Structure):
+    _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32)]
+
+    def as_tuple(self):
+        return (self.x0, self.y0, self.x1, self.y1)
+
+
+class StDistUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
 class StTuning(C.Structure):
     """include/strolle_hip.h StTuning: scheduling / tuning switches of one engine."""
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "overlap", "fuse", "fuse_di_head", "fuse_spatial", "fuse_gi_sampling", "fuse_gi_validation",
-                                          "fuse_gi_reprojection", "fuse_wavelet", "fuse_compose", "preview_both", "variance_in_reproject", "variance_compaction",
+                                          "fuse_gi_reprojection", "fuse_wavelet", "fuse_compose", "preview_both", "variance_in_reproject",
                                           "lean_frame", "skip_scratch_stores", "di_head_on_main", "alias_gi_history", "tile_map", "tile_map_denoise")] + \
                [("side_priority", C.c_int32)] + \
                [(n, C.c_uint32) for n in ("staging", "double_buffer", "packed_base", "tick_timing", "anyhit_fast", "occluder_table_log2", "occluder_min_texels",
@@ -295,6 +306,12 @@ class _Binding:
             self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
             self.engine_get_tuning = fn("engine_get_tuning", [vp, P(StTuning)]); self.engine_set_tuning = fn("engine_set_tuning", [vp, P(StTuning)])
             self.debug_copy_bandwidth = fn("debug_copy_bandwidth", [vp, sz, i32, P(C.c_double)])
+            self.debug_variance_flags = fn("debug_variance_flags", [vp, u64, vp, sz, P(sz)])
+            self.camera_set_window = fn("camera_set_window", [vp, u64, u32, u32, u32, u32])
+            self.dist_init = fn("dist_init", [vp, i32, i32, P(StDistUniqueId)]); self.dist_init_local = fn("dist_init_local", [vp, i32, i32, u64])
+            self.dist_shutdown = fn("dist_shutdown", [vp]); self.dist_rank = fn("dist_rank", [vp, P(i32), P(i32)])
+            self.dist_set_partition = fn("dist_set_partition", [vp, u64, u32, u32, P(StDistRect), P(StDistRect)])
+            self.dist_gather = fn("dist_gather", [vp, u64, vp, vp, vp]); self.dist_wait = fn("dist_wait", [vp, u64, vp, i32])
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
@@ -578,6 +595,44 @@ class Engine(EngineBase):
     def set_camera_rows(self, handle: int, y0: int, y1: int):
         self._check(self._b.camera_set_rows(self._h, handle, y0, y1))
 
+    def variance_flags(self, cam: int) -> np.ndarray:
+        """st_debug_variance_flags: one uint64 per 8x8 tile, bit = pixel whose variance estimate takes the short-history branch."""
+        n = C.c_size_t()
+        self._check(self._b.debug_variance_flags(self._h, cam, None, 0, C.byref(n)))
+        mask = np.zeros(n.value, np.uint64)
+        self._check(self._b.debug_variance_flags(self._h, cam, mask.ctypes.data, mask.size, C.byref(n)))
+        return mask
+
+    def set_camera_window(self, handle: int, x0: int, y0: int, x1: int, y1: int):
+        """st_camera_set_window: restrict the camera's launches to [x0, x1) x [y0, y1) of the viewport (0, 0 = everything on that axis)."""
+        self._check(self._b.camera_set_window(self._h, handle, x0, y0, x1, y1))
+
+    # ---- multi-GPU behind the boundary (include/strolle_hip.h st_dist_*)
+    def dist_init(self, rank: int, world: int, unique_id: bytes):
+        """RCCL transport: `unique_id` = dist_unique_id() of rank 0, handed to every rank by the caller's own means."""
+        uid = StDistUniqueId(); C.memmove(C.byref(uid), unique_id, 128)
+        self._check(self._b.dist_init(self._h, rank, world, C.byref(uid)))
+
+    def dist_init_local(self, rank: int, world: int, group: int = 1):
+        """In-process transport: the engines of this process that share `group` (tests, single-GPU boxes)."""
+        self._check(self._b.dist_init_local(self._h, rank, world, group))
+
+    def dist_shutdown(self):
+        self._check(self._b.dist_shutdown(self._h))
+
+    def dist_set_partition(self, cam: int, cols: int = 0, apron: int = 0):
+        """This rank's tile of the camera's frame (+ apron) becomes the camera's window. Returns (owned, window) as (x0, y0, x1, y1)."""
+        o, w = StDistRect(), StDistRect()
+        self._check(self._b.dist_set_partition(self._h, cam, cols, apron, C.byref(o), C.byref(w)))
+        return o.as_tuple(), w.as_tuple()
+
+    def dist_gather(self, cam: int, frame_ptr: int, full_ptr: int = 0, stream: int = 0):
+        """st_dist_gather: this rank's tile of `frame_ptr` travels to rank 0, which assembles the frame at `full_ptr`."""
+        self._check(self._b.dist_gather(self._h, cam, frame_ptr, full_ptr or None, stream))
+
+    def dist_wait(self, cam: int, stream: int = 0, host: bool = True):
+        self._check(self._b.dist_wait(self._h, cam, stream, 1 if host else 0))
+
     def insert_device_image(self, handle: int, device_ptr: int, width: int, height: int, row_pitch_bytes: int = 0, dynamic: bool = False):
         """ImageData::Texture: RGBA8 pixels in device memory (e.g. `tensor.data_ptr()` of a [h, w, 4] uint8 CUDA tensor)."""
         self._check(self._b.image_insert_device_rgba8(self._h, handle, width, height, device_ptr, row_pitch_bytes or width * 4, 1 if dynamic else 0))
@@ -629,6 +684,42 @@ class Engine(EngineBase):
         self._check(self._b.profile_read(self._h, arr, 48, C.byref(n), 1 if reset else 0))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, algorithmic_bytes=arr[i].algorithmic_bytes, traversal_bytes=arr[i].traversal_bytes)
                 for i in range(n.value)]
+
+
+def dist_partition(width: int, height: int, world: int, rank: int, cols: int = 0):
+    """st_dist_partition: the tile (x0, y0, x1, y1) rank `rank` of `world` owns (cols = 0: the default grid)."""
+    lib = load_library()
+    r = StDistRect()
+    lib.st_dist_partition.restype = C.c_int
+    lib.st_dist_partition.argtypes = [C.c_uint32] * 5 + [C.POINTER(StDistRect)]
+    if lib.st_dist_partition(width, height, world, cols, rank, C.byref(r)) != 0:
+        lib.st_last_error.restype = C.c_char_p
+        raise StrolleError(lib.st_last_error().decode(errors="replace"))
+    return r.as_tuple()
+
+
+def dist_window(width: int, height: int, owned, apron: int):
+    """st_dist_window: `owned` widened by `apron` pixels towards its neighbours, on the 16 x 8 pixel grid."""
+    lib = load_library()
+    o, w = StDistRect(*owned), StDistRect()
+    lib.st_dist_window.restype = C.c_int
+    lib.st_dist_window.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(StDistRect), C.c_uint32, C.POINTER(StDistRect)]
+    if lib.st_dist_window(width, height, C.byref(o), apron, C.byref(w)) != 0:
+        lib.st_last_error.restype = C.c_char_p
+        raise StrolleError(lib.st_last_error().decode(errors="replace"))
+    return w.as_tuple()
+
+
+def dist_unique_id() -> bytes:
+    """st_dist_unique_id (ncclGetUniqueId): rank 0 makes it, every rank passes it to Engine.dist_init."""
+    lib = load_library()
+    uid = StDistUniqueId()
+    lib.st_dist_unique_id.restype = C.c_int
+    lib.st_dist_unique_id.argtypes = [C.POINTER(StDistUniqueId)]
+    if lib.st_dist_unique_id(C.byref(uid)) != 0:
+        lib.st_last_error.restype = C.c_char_p
+        raise StrolleError(lib.st_last_error().decode(errors="replace"))
+    return bytes(C.string_at(C.byref(uid), 128))
 
 
 def decode_png(data: bytes) -> np.ndarray:

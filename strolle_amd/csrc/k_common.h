@@ -15,31 +15,49 @@ constexpr int kBlockThreads = 256;               // 4 wavefronts, one 8x8 tile e
 #endif
 constexpr int kStackWords = 4 * kBvhStackSize * 64;  // 24 KiB of LDS per block for the traversal stacks
 
-struct LaunchDims { uint32_t tiles_x, tile_y0, tile_y1, blocks; };
+// The window of 8x8 tiles a launch covers: all of the viewport, or the rows / columns of st_camera_set_rows / st_camera_set_window
+// widened to tile boundaries (owns_pixel masks the rest). Half-resolution passes (2x1 checkerboard cells, `(size + 7) / 8 / (2, 1)`
+// workgroups: passes/*_resampling.rs, gi_sampling.rs) count tiles of 8 CELLS = 16 pixels in x.
+struct TileWindow { uint32_t tx0, tx1, ty0, ty1; };
+__host__ __device__ inline TileWindow tile_window(const KArgs& a, bool half_x) {
+    uint32_t tiles_x = (a.width + 7u) >> 3;
+    if (half_x) tiles_x >>= 1;
+    const uint32_t shift = half_x ? 4u : 3u, round = half_x ? 15u : 7u;
+    TileWindow w;
+    w.tx0 = a.col0 >> shift;
+    w.tx1 = (a.col1 + round) >> shift; if (w.tx1 > tiles_x) w.tx1 = tiles_x;
+    if (w.tx0 > w.tx1) w.tx0 = w.tx1;
+    w.ty0 = a.row0 >> 3;
+    w.ty1 = (a.row1 + 7u) >> 3;
+    return w;
+}
+struct LaunchDims { uint32_t tiles_x, tile_x0, tile_y0, tile_y1, blocks; };
 inline LaunchDims launch_dims(const KArgs& a, bool half_x) {
+    const TileWindow w = tile_window(a, half_x);
     LaunchDims d;
-    d.tiles_x = (a.width + 7u) / 8u;
-    if (half_x) d.tiles_x /= 2u;  // `(size + 7) / 8 / uvec2(2, 1)` workgroups (passes/*_resampling.rs, gi_sampling.rs)
-    d.tile_y0 = a.row0 / 8u;
-    d.tile_y1 = (a.row1 + 7u) / 8u;
+    d.tiles_x = w.tx1 - w.tx0; d.tile_x0 = w.tx0;
+    d.tile_y0 = w.ty0; d.tile_y1 = w.ty1;
     const uint32_t groups_x = (d.tiles_x + 3u) / 4u;
     d.blocks = groups_x * (d.tile_y1 - d.tile_y0);
     return d;
 }
 
+// This wave's tile (absolute tile coordinates). valid == false: outside the dispatch.
+ST_D TileCoord resolve_tile(const KArgs& a, bool half_x) {
+    const TileWindow w = tile_window(a, half_x);
+    TileCoord tc = tile_for_thread(w.tx1 - w.tx0, w.ty1 - w.ty0, a.tile_map);
+    tc.x += w.tx0; tc.y += w.ty0;
+    return tc;
+}
 // Resolves this thread's `global_invocation_id` (gid). Returns false for lanes outside the dispatch.
 ST_D bool resolve_gid(const KArgs& a, bool half_x, U2* gid) {
-    uint32_t tiles_x = (a.width + 7u) >> 3;
-    if (half_x) tiles_x >>= 1;
-    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
-    TileCoord tc = tile_for_thread(tiles_x, ty1 - ty0, a.tile_map);
+    const TileCoord tc = resolve_tile(a, half_x);
     if (!tc.valid) return false;
-    tc.y += ty0;
     *gid = pixel_in_tile(tc);
     return true;
 }
-// pixel belongs to this launch: inside the viewport (Camera::contains) and inside the row window
-ST_D bool owns_pixel(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.height && p.y >= a.row0 && p.y < a.row1; }
+// pixel belongs to this launch: inside the viewport (Camera::contains) and inside the window
+ST_D bool owns_pixel(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.height && p.y >= a.row0 && p.y < a.row1 && p.x >= a.col0 && p.x < a.col1; }
 
 // Tracing kernels are instantiated three ways; the scene picks one at launch:
 //   <true,  uint16_t>  the whole device BVH stream fits in LDS (Cornell: 55 entries = 220 float4): every block copies it in

@@ -104,11 +104,8 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
     __shared__ float4 s_sn[PITCH * RH];
     __shared__ float4 s_di[PITCH * RH];
     __shared__ float4 s_gi[PITCH * RH];
-    const uint32_t tiles_x = (a.width + 7u) >> 3;
-    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
-    TileCoord tc = tile_for_thread(tiles_x, ty1 - ty0, a.tile_map);
+    const TileCoord tc = resolve_tile(a, false);
     const uint32_t wave = threadIdx.x >> 6;
-    tc.y += ty0;
     const U2 pos = pixel_in_tile(tc);
     const bool mine = tc.valid && owns_pixel(a, pos);
     const uint32_t center = pos.y * a.width + pos.x;
@@ -165,70 +162,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
     di_out[center] = f4(xyz(cdi), di_var);
     gi_out[center] = f4(xyz(cgi), gi_var);
 }
-// ---- the short-history pixels through a COMPACTED list of tile groups (KArgs::var_compact; StTuning::variance_compaction).
-// With KArgs::variance_in_reproject the full-screen launch above has nothing to do for almost every block once histories are
-// four frames long — on a static Cornell frame all 32,400 waves load one mask word and leave, 27 us for 33 MB — so the DI
-// resolving launch, which decides the flags, also APPENDS each 32x8-pixel group that has a flagged pixel to a list (one ballot
-// per wave, one atomic exchange on the group's epoch word per flagged wave, one atomic append per flagged group: k_di.hip), and
-// a small persistent grid walks the list. Layout of var_compact: [0] count, [1] blocks finished, [2, 2 + G) the render epoch
-// that last flagged each group, [2 + G, 2 + 2 G) the list (G = KArgs::var_groups). The last block to finish clears the count
-// for the next frame (every block has read it by then). Per group the work is the kernel's above, windows and arithmetic alike.
-constexpr uint32_t kVarianceGridMax = 2048;
-__global__ ST_KERNEL_BOUNDS void k_denoise_variance_compact(const KArgs a, float4* di_out, float4* gi_out) {
-    constexpr int RW = 38, RH = 12, PITCH = 40;
-    __shared__ float4 s_sn[PITCH * RH];
-    __shared__ float4 s_di[PITCH * RH];
-    __shared__ float4 s_gi[PITCH * RH];
-    const uint32_t tiles_x = (a.width + 7u) >> 3, groups_x = (tiles_x + 3u) >> 2;
-    const uint32_t count = min(a.var_compact[0], a.var_groups);
-    const uint32_t* list = a.var_compact + 2u + a.var_groups;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const uint32_t g = list[i];
-        const uint32_t gy = g / groups_x, gx = g - gy * groups_x;
-        const uint32_t tx = gx * 4u + wave;
-        const U2 pos = u2(tx * 8u + (lane & 7u), gy * 8u + (lane >> 3));
-        const bool mine = tx < tiles_x && owns_pixel(a, pos);
-        const uint32_t center = pos.y * a.width + pos.x;
-        const bool slow = mine && ((a.tile_mask[tile_mask_index(a, pos)] >> lane) & 1ull) != 0ull;
-        float4 csn = f4z(), cdi = f4z(), cgi = f4z();
-        if (slow) { csn = a.sn[center]; cdi = a.di_diff_curr_colors[center]; cgi = a.gi_diff_curr_colors[center]; }
-        const int32_t bx0 = (int32_t)(gx * 32u) - 3, by0 = (int32_t)(gy * 8u) - 2;
-        for (int k = (int)threadIdx.x; k < RW * RH; k += kBlockThreads) {
-            const int ry = k / RW, rx = k - ry * RW;
-            const int32_t px = bx0 + rx, py = by0 + ry;
-            const int li = ry * PITCH + rx;
-            if (px >= 0 && py >= 0 && px < (int32_t)a.width && py < (int32_t)a.height) {
-                const uint32_t at = (uint32_t)py * a.width + (uint32_t)px;
-                float4 tdi = a.di_diff_curr_colors[at], tgi = a.gi_diff_curr_colors[at];
-                const f2 tl = (mk2(tdi.x, tgi.x) * 0.2126f + mk2(tdi.y, tgi.y) * 0.7152f) + mk2(tdi.z, tgi.z) * 0.0722f;
-                const f2 ts = sqrt2(tl);
-                tdi.w = ts.x; tgi.w = ts.y;
-                s_sn[li] = a.sn[at]; s_di[li] = tdi; s_gi[li] = tgi;
-            } else s_sn[li] = f4z();
-        }
-        __syncthreads();
-        if (slow && csn.w != 0.0f) {
-            float di_var, gi_var;
-            variance_short_history(csn, cdi, cgi, s_sn, s_di, s_gi, ((int)(pos.y & 7u) + 2) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + 3, PITCH, &di_var, &gi_var);
-            reinterpret_cast<float*>(&di_out[center])[3] = fmax_(di_var, 0.0f);
-            reinterpret_cast<float*>(&gi_out[center])[3] = fmax_(gi_var, 0.0f);
-        }
-        __syncthreads();   // the window is restaged by the next group
-    }
-    if (threadIdx.x == 0u) {
-        __threadfence();
-        if (atomicAdd(&a.var_compact[1], 1u) == gridDim.x - 1u) { a.var_compact[0] = 0u; a.var_compact[1] = 0u; }
-    }
-}
-void launch_denoise_variance(const KArgs& a, float4* di_out, float4* gi_out, hipStream_t s) {
-    if (a.var_compact && a.variance_in_reproject) {
-        const uint32_t blocks = a.var_groups < kVarianceGridMax ? a.var_groups : kVarianceGridMax;
-        if (blocks) ST_KLAUNCH(k_denoise_variance_compact, dim3(blocks), dim3(kBlockThreads), s, a, di_out, gi_out);
-        return;
-    }
-    ST_LAUNCH(k_denoise_variance, false, s, a, di_out, gi_out);
-}
+void launch_denoise_variance(const KArgs& a, float4* di_out, float4* gi_out, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a, di_out, gi_out); }
 
 // ---------------------------------------------------------------- frame_denoising.rs:219-361 (five à-trous passes)
 // Measured (rocprofv3, MI355X): the LDS-staged passes run at 70-75 % of their VALU issue time and within 10-30 % of the
@@ -318,11 +252,20 @@ ST_D WaveletOut wavelet_pixel_lds(const float4* s_sn, const float4* s_di, const 
 // two block rows (32 pixel rows) per XCD chunk so the halo rows a block shares with its vertical neighbour stay in one L2.
 constexpr int kWvW = 32, kWvH = 16, kWvThreads = kWvW * kWvH;
 struct WaveletBlock { int32_t x0, y0; bool valid; };
+// blocks of the window: columns [col0 / BW, ceil(col1 / BW)) x block rows from the window's first tile row
+__host__ __device__ inline void wavelet_grid(const KArgs& a, uint32_t bw, uint32_t* bx0, uint32_t* groups_x, uint32_t* rows) {
+    const uint32_t c1 = a.col1 < a.width ? a.col1 : a.width;
+    *bx0 = a.col0 / bw;
+    const uint32_t bx1 = (c1 + bw - 1u) / bw;
+    *groups_x = bx1 > *bx0 ? bx1 - *bx0 : 0u;
+    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
+    *rows = ((ty1 - ty0) * 8u + kWvH - 1u) / kWvH;
+}
 template <int BW = kWvW>
 ST_D WaveletBlock wavelet_block(const KArgs& a) {
-    const uint32_t groups_x = (a.width + BW - 1u) / BW;
-    const uint32_t ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
-    const uint32_t rows = ((ty1 - ty0) * 8u + kWvH - 1u) / kWvH;
+    uint32_t bx0, groups_x, rows;
+    wavelet_grid(a, BW, &bx0, &groups_x, &rows);
+    const uint32_t ty0 = a.row0 >> 3;
     const uint32_t n_blocks = groups_x * rows, b = blockIdx.x;
     uint32_t lin = b;
     if (a.tile_map == 0u) {
@@ -334,14 +277,17 @@ ST_D WaveletBlock wavelet_block(const KArgs& a) {
     }
     WaveletBlock w;
     const uint32_t gy = lin / groups_x, gx = lin - gy * groups_x;
-    w.x0 = (int32_t)(gx * BW); w.y0 = (int32_t)(ty0 * 8u + gy * kWvH);
+    w.x0 = (int32_t)((bx0 + gx) * BW); w.y0 = (int32_t)(ty0 * 8u + gy * kWvH);
     w.valid = gy < rows;
     return w;
 }
 inline uint32_t wavelet_blocks(const KArgs& a, uint32_t block_w = kWvW) {
-    const uint32_t groups_x = (a.width + block_w - 1u) / block_w, ty0 = a.row0 >> 3, ty1 = (a.row1 + 7u) >> 3;
-    return groups_x * (((ty1 - ty0) * 8u + kWvH - 1u) / kWvH);
+    uint32_t bx0, groups_x, rows;
+    wavelet_grid(a, block_w, &bx0, &groups_x, &rows);
+    return groups_x * rows;
 }
+// the pixel belongs to this launch's window (the LDS passes address pixels as signed block offsets)
+ST_D bool wavelet_owns(const KArgs& a, int32_t px, int32_t py) { return px >= 0 && py >= 0 && owns_pixel(a, u2((uint32_t)px, (uint32_t)py)); }
 // stages the (kWvW + 2 HALO) x (kWvH + 2 HALO) window around the block into LDS (row pitch P texels)
 template <int HALO, int P, int BW = kWvW>
 ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* di_in, const float4* gi_in, float4* s_sn, float4* s_di, float4* s_gi) {
@@ -392,7 +338,7 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
         const bool lit = o.lit;
         // the block's own pixels: this is what the stand-alone stride-1 pass stores
         const int32_t px = blk.x0 - 2 + rx, py = blk.y0 - 2 + ry;
-        if (rx >= 2 && rx < 2 + kWvW && ry >= 2 && ry < 2 + kWvH && px < (int32_t)a.width && py < (int32_t)a.height && (uint32_t)py >= a.row0 && (uint32_t)py < a.row1) {
+        if (rx >= 2 && rx < 2 + kWvW && ry >= 2 && ry < 2 + kWvH && wavelet_owns(a, px, py)) {
             const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
             di_mid[center] = r_di[it];
             if (lit) gi_mid[center] = r_gi[it];
@@ -407,7 +353,7 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_12(const KArgs a
     // stride-2 pass for the block's own pixels
     const int x = (int)(threadIdx.x & 31u), y = (int)(threadIdx.x >> 5);
     const int32_t px = blk.x0 + x, py = blk.y0 + y;
-    if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) return;
+    if (!wavelet_owns(a, px, py)) return;
     const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
     const WaveletOut o = wavelet_pixel_lds<2, P>(s_sn, s_di, s_gi, (y + HALO) * P + x + HALO, strength1);
     di_out[center] = o.di;
@@ -432,7 +378,7 @@ __global__ __launch_bounds__(kWvThreads) void k_denoise_wavelet_lds(const KArgs 
     __syncthreads();
     const int x = (int)(threadIdx.x & 31u), y = (int)(threadIdx.x >> 5);
     const int32_t px = blk.x0 + x, py = blk.y0 + y;
-    if (px >= (int32_t)a.width || py >= (int32_t)a.height || (uint32_t)py < a.row0 || (uint32_t)py >= a.row1) return;
+    if (!wavelet_owns(a, px, py)) return;
     const uint32_t center = (uint32_t)py * a.width + (uint32_t)px;
     const WaveletOut o = wavelet_pixel_lds<S, P>(s_sn, s_di, s_gi, (y + S) * P + x + S, strength);
     di_out[center] = o.di;
@@ -566,7 +512,7 @@ __global__ ST_KERNEL_BOUNDS void k_refresh_internal_planes(const KArgs a, float4
     if (which & 2u) { const float4 psm = a.psm[i]; psn_out[i] = psm.z == 0.0f ? f4z() : f4(normal_decode(v2(psm.x, psm.y)), psm.z); }
 }
 void launch_refresh_internal_planes(const KArgs& a_in, uint32_t which, hipStream_t s) {
-    KArgs a = a_in; a.row0 = 0; a.row1 = a.height;
+    KArgs a = a_in; a.row0 = 0; a.row1 = a.height; a.col0 = 0; a.col1 = a.width;
     ST_LAUNCH(k_refresh_internal_planes, false, s, a, const_cast<float4*>(a.psn), which);
 }
 

@@ -228,18 +228,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
         const bool short_history = denoise_reproject_finish(a, pos, diff, history, a.di_diff_curr_colors, a.di_diff_moments);
         if (a.variance_in_reproject) {  // tell the variance kernel which pixels of this tile still need it
             const unsigned long long flagged = __ballot(short_history), active = __ballot(true);
-            if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) {
-                a.tile_mask[tile_mask_index(a, pos)] = flagged;
-                // ... and, for the compacted variance launch (k_denoise.hip k_denoise_variance_compact), which 32x8 groups have any:
-                // the first flagged wave of a group this frame (epoch word) appends it
-                if (flagged != 0ull && a.var_compact) {
-                    const uint32_t g = (pos.y >> 3) * ((((a.width + 7u) >> 3) + 3u) >> 2) + (pos.x >> 5);
-                    if (g < a.var_groups && atomicExch(&a.var_compact[2u + g], a.var_epoch) != a.var_epoch) {
-                        const uint32_t at = atomicAdd(&a.var_compact[0], 1u);
-                        if (at < a.var_groups) a.var_compact[2u + a.var_groups + at] = g;
-                    }
-                }
-            }
+            if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) a.tile_mask[tile_mask_index(a, pos)] = flagged;
         }
     }
 }

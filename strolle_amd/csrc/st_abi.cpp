@@ -197,16 +197,21 @@ int st_camera_delete(StEngine* e, StHandle h) {
     en->cameras.erase(it);
     return ST_OK;
 }
-int st_camera_set_rows(StEngine* e, StHandle h, uint32_t y0, uint32_t y1) {
+int st_camera_set_window(StEngine* e, StHandle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
     ST_REQUIRE(e, "null engine");
     auto it = E(e)->cameras.find(h);
     if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
     CameraState& s = *it->second;
-    if (y0 == 0 && y1 == 0) { y1 = s.desc.height; }
+    if (x0 == 0 && x1 == 0) x1 = s.desc.width;
+    if (y0 == 0 && y1 == 0) y1 = s.desc.height;
     ST_REQUIRE(y0 < y1 && y1 <= s.desc.height, "bad row window");
-    s.row0 = y0; s.row1 = y1;
+    ST_REQUIRE(x0 < x1 && x1 <= s.desc.width, "bad column window");
+    // half-resolution passes work on 2x1 cells in tiles of 8 cells: a window starts and ends on a multiple of 16 pixels (or at the frame's edge)
+    ST_REQUIRE(x0 % 16u == 0u && (x1 % 16u == 0u || x1 == s.desc.width), "window columns must be multiples of 16 (or the frame's right edge)");
+    s.row0 = y0; s.row1 = y1; s.col0 = x0; s.col1 = x1;
     return ST_OK;
 }
+int st_camera_set_rows(StEngine* e, StHandle h, uint32_t y0, uint32_t y1) { return st_camera_set_window(e, h, 0u, y0, 0u, y1); }
 
 int st_camera_set_output_format(StEngine* e, StHandle h, int format) {
     ST_REQUIRE(e, "null engine");
@@ -290,6 +295,20 @@ int st_camera_write_buffer(StEngine* e, StHandle h, int id, const void* data, si
     ST_HIP(hipMemcpy(c.plane[id], data, bytes, hipMemcpyHostToDevice));
     if (id == ST_BUF_PRIM_SURFACE_MAP_A) c.surface_map_replaced[0] = true;
     if (id == ST_BUF_PRIM_SURFACE_MAP_B) c.surface_map_replaced[1] = true;
+    return ST_OK;
+}
+int st_debug_variance_flags(StEngine* e, StHandle h, uint64_t* tile_mask_out, size_t capacity_tiles, size_t* tiles) {
+    ST_REQUIRE(e && tiles, "null argument");
+    Engine* en = E(e);
+    auto it = en->cameras.find(h);
+    if (it == en->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "host-only engine");
+    CameraState& c = *it->second;
+    *tiles = c.tile_mask_tiles;
+    if (!tile_mask_out) return ST_OK;
+    ST_REQUIRE(capacity_tiles >= c.tile_mask_tiles, "buffer too small");
+    ST_HIP(hipSetDevice(en->device)); ST_HIP(hipDeviceSynchronize());
+    ST_HIP(hipMemcpy(tile_mask_out, c.tile_mask, c.tile_mask_tiles * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return ST_OK;
 }
 int st_debug_set_pass_mask(StEngine* e, uint64_t mask) {

@@ -1,0 +1,350 @@
+// st_dist.cpp — multi-GPU behind the C ABI (BASELINE.json configs 4 and 5): the tile partition of a frame
+// over the ranks of one node, and the ONE collective of the path — the per-frame gather of the composed tiles to rank 0.
+//
+// One process per GPU, one engine per process, the scene replicated (every rank builds the same engine state). The reference has
+// no counterpart (strolle renders on one device); north_star keeps the host in Rust, so the gather must be reachable through the
+// C ABI and not only from Python (`strolle_amd/distributed.py` is the torch.distributed fallback for boxes without RCCL).
+//
+// Transports:
+//   RCCL  — librccl is opened at run time (dlopen: the library stays loadable where RCCL is absent, and a process that already
+//           loaded RCCL — torch does — shares that copy instead of bringing a second one). Grouped ncclSend / ncclRecv: every
+//           peer sends its tile to rank 0 over its own xGMI link (point to point, not a ring), on a communication stream the
+//           engine owns, ordered behind the frame by an event and overlapped with the next frame's rendering.
+//   local — an in-process mailbox (several engines in ONE process, host-only or sharing one device): what the CPU tests and the
+//           single-GPU box drive; same partition, same pack / unpack, same stream ordering, no RCCL.
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include "st_engine.h"
+
+namespace st {
+
+// ------------------------------------------------------------------ partition (pure functions)
+// Default grid of `world` tiles for a landscape frame: columns x rows with columns >= rows and both as square as the count allows
+// (1: 1x1, 2: 1x2 — two row bands —, 4: 2x2, 8: 4x2, 6: 3x2, a prime p: 1 x p row bands).
+static void default_grid(uint32_t world, uint32_t* cols, uint32_t* rows) {
+    uint32_t r = 1;
+    for (uint32_t k = 1; k * k <= world; k++) if (world % k == 0u) r = k;
+    *rows = r; *cols = world / r;
+    if (world == 2u) { *cols = 1u; *rows = 2u; }   // two row bands: no column seam, contiguous sends
+}
+static uint32_t split_edge(uint32_t extent, uint32_t parts, uint32_t i, uint32_t align) {
+    if (i >= parts) return extent;
+    uint64_t e = (uint64_t)extent * i / parts;
+    e = (e + align / 2u) / align * align;
+    return (uint32_t)std::min<uint64_t>(e, extent);
+}
+int dist_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, uint32_t rank, StDistRect* owned) {
+    if (!width || !height || !world || rank >= world || !owned) return fail(ST_ERR_INVALID_ARGUMENT, "bad partition request");
+    uint32_t rows;
+    if (cols == 0u) default_grid(world, &cols, &rows);
+    else { if (world % cols != 0u) return fail(ST_ERR_INVALID_ARGUMENT, "world is not a multiple of the column count"); rows = world / cols; }
+    const uint32_t cx = rank % cols, cy = rank / cols;
+    owned->x0 = split_edge(width, cols, cx, 16u); owned->x1 = split_edge(width, cols, cx + 1u, 16u);
+    owned->y0 = split_edge(height, rows, cy, 8u); owned->y1 = split_edge(height, rows, cy + 1u, 8u);
+    if (owned->x0 >= owned->x1 || owned->y0 >= owned->y1) return fail(ST_ERR_INVALID_ARGUMENT, "the frame is too small for that many tiles");
+    return ST_OK;
+}
+int dist_window(uint32_t width, uint32_t height, const StDistRect* owned, uint32_t apron, StDistRect* window) {
+    if (!owned || !window || owned->x1 > width || owned->y1 > height) return fail(ST_ERR_INVALID_ARGUMENT, "bad window request");
+    auto down = [](uint32_t v, uint32_t a) { return v / a * a; };
+    auto up = [](uint32_t v, uint32_t a, uint32_t lim) { const uint64_t r = ((uint64_t)v + a - 1u) / a * a; return (uint32_t)std::min<uint64_t>(r, lim); };
+    window->x0 = down(owned->x0 > apron ? owned->x0 - apron : 0u, 16u);
+    window->y0 = down(owned->y0 > apron ? owned->y0 - apron : 0u, 8u);
+    window->x1 = owned->x1 >= width ? width : up(std::min<uint64_t>((uint64_t)owned->x1 + apron, width), 16u, width);
+    window->y1 = owned->y1 >= height ? height : up(std::min<uint64_t>((uint64_t)owned->y1 + apron, height), 8u, height);
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------ RCCL through dlopen
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, StDistUniqueId, int) = nullptr;   // ncclUniqueId is passed BY VALUE: a 128-byte struct
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string error;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);   // a copy the process already has (torch's) is shared, not doubled
+            if (lib) break;
+        }
+        if (!lib) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) { error = std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "?"); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) error = std::string("librccl lacks ") + n; return p; };
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        return GetUniqueId && CommInitRank && CommDestroy && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+constexpr int kNcclInt8 = 0;   // rccl.h ncclDataType_t
+
+// ---- the in-process transport: one mailbox slot per (group, sender); the sender copies its packed tile in and records an event, the
+// root waits for the event on its stream and copies out. Non-root ranks of a frame must have called st_dist_gather before the root does.
+struct LocalSlot { void* mem = nullptr; size_t capacity = 0, bytes = 0; bool device = false; int device_id = -1; hipEvent_t ready = nullptr; uint64_t seq = 0, taken = 0; };
+std::map<std::pair<uint64_t, int>, LocalSlot> g_local;
+std::mutex g_local_mutex;
+}  // namespace
+
+struct DistState {
+    int transport = 0;            // 0 none, 1 RCCL, 2 local
+    int rank = 0, world = 1;
+    void* comm = nullptr;         // ncclComm_t
+    uint64_t group = 0;           // local transport: which mailbox
+    hipStream_t stream = nullptr; // the communication stream
+    struct CamPart { StDistRect owned{}, window{}; uint32_t cols = 0, apron = 0; hipEvent_t rendered = nullptr, done = nullptr; bool pending = false; void* staging = nullptr; size_t staging_bytes = 0; };
+    std::map<uint64_t, CamPart> cams;
+};
+
+static size_t bytes_per_pixel(uint32_t format) { return format == ST_FORMAT_RGBA32F ? 16u : (format == ST_FORMAT_RGBA16F ? 8u : 4u); }
+static int rccl_fail(int code, const char* what) {
+    return fail(ST_ERR_DIST, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "RCCL error") + " (" + std::to_string(code) + ")");
+}
+
+void Engine::release_dist() {
+    if (!dist) return;
+    if (has_device) { (void)hipSetDevice(device); if (dist->stream) (void)hipStreamSynchronize(dist->stream); }
+    for (auto& kv : dist->cams) {
+        auto& p = kv.second;
+        if (p.rendered) (void)hipEventDestroy(p.rendered);
+        if (p.done) (void)hipEventDestroy(p.done);
+        if (p.staging) { if (has_device) (void)hipFree(p.staging); else free(p.staging); }
+    }
+    if (dist->transport == 1 && dist->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(dist->comm);
+    if (dist->transport == 2) {
+        std::lock_guard<std::mutex> lock(g_local_mutex);
+        auto it = g_local.find({dist->group, dist->rank});
+        if (it != g_local.end()) {
+            if (it->second.ready) (void)hipEventDestroy(it->second.ready);
+            if (it->second.mem) { if (it->second.device) (void)hipFree(it->second.mem); else free(it->second.mem); }
+            g_local.erase(it);
+        }
+    }
+    if (dist->stream) (void)hipStreamDestroy(dist->stream);
+    delete dist; dist = nullptr;
+}
+
+static int dist_begin(Engine* en, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) return fail(ST_ERR_INVALID_ARGUMENT, "bad rank / world");
+    en->release_dist();
+    en->dist = new DistState();
+    en->dist->rank = rank; en->dist->world = world;
+    if (en->has_device) { ST_HIP(hipSetDevice(en->device)); ST_HIP(hipStreamCreateWithFlags(&en->dist->stream, hipStreamNonBlocking)); }
+    return ST_OK;
+}
+
+// the tile `r` of this camera's partition, as every rank computes it
+static int rect_of(const CameraState& c, const DistState& d, const DistState::CamPart& p, int r, StDistRect* out) {
+    return dist_partition(c.desc.width, c.desc.height, (uint32_t)d.world, p.cols, (uint32_t)r, out);
+}
+
+int Engine::dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, uint32_t apron) {
+    if (!dist) return fail(ST_ERR_INVALID_ARGUMENT, "st_dist_init has not been called on this engine");
+    DistState::CamPart& p = dist->cams[handle];
+    p.cols = cols; p.apron = apron;
+    if (int rc = dist_partition(c.desc.width, c.desc.height, (uint32_t)dist->world, cols, (uint32_t)dist->rank, &p.owned)) return rc;
+    if (int rc = dist_window(c.desc.width, c.desc.height, &p.owned, apron, &p.window)) return rc;
+    c.col0 = p.window.x0; c.col1 = p.window.x1; c.row0 = p.window.y0; c.row1 = p.window.y1;
+    return ST_OK;
+}
+
+// pack / unpack on whichever side the engine lives
+static void copy_rect(Engine* en, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes, uint32_t rows, hipStream_t s) {
+    if (en->has_device) { en->L.launch_rect_copy(dst, dst_pitch, src, src_pitch, row_bytes, rows, s); return; }
+    for (uint32_t y = 0; y < rows; y++) memcpy(static_cast<char*>(dst) + (size_t)y * dst_pitch, static_cast<const char*>(src) + (size_t)y * src_pitch, row_bytes);
+}
+static int ensure_staging(Engine* en, DistState::CamPart& p, size_t bytes) {
+    if (p.staging_bytes >= bytes) return ST_OK;
+    if (p.staging) { if (en->has_device) (void)hipFree(p.staging); else free(p.staging); p.staging = nullptr; p.staging_bytes = 0; }
+    if (en->has_device) ST_HIP(hipMalloc(&p.staging, bytes)); else { p.staging = malloc(bytes); if (!p.staging) return fail(ST_ERR_DIST, "out of memory"); }
+    p.staging_bytes = bytes;
+    return ST_OK;
+}
+
+int Engine::dist_gather(uint64_t handle, CameraState& c, const void* frame, void* full, hipStream_t stream) {
+    if (!dist) return fail(ST_ERR_INVALID_ARGUMENT, "st_dist_init has not been called on this engine");
+    auto it = dist->cams.find(handle);
+    if (it == dist->cams.end()) return fail(ST_ERR_INVALID_ARGUMENT, "st_dist_set_partition has not been called for this camera");
+    DistState& d = *dist; DistState::CamPart& p = it->second;
+    const bool root = d.rank == 0;
+    if (root && !full) return fail(ST_ERR_INVALID_ARGUMENT, "rank 0 needs the destination frame");
+    if (!frame) return fail(ST_ERR_INVALID_ARGUMENT, "null frame");
+    const size_t bpp = bytes_per_pixel(c.out_format), pitch = (size_t)c.desc.width * bpp;
+    hipStream_t cs = d.stream;
+    if (has_device) {
+        ST_HIP(hipSetDevice(device));
+        if (!p.rendered) { ST_HIP(hipEventCreateWithFlags(&p.rendered, hipEventDisableTiming)); ST_HIP(hipEventCreateWithFlags(&p.done, hipEventDisableTiming)); }
+        ST_HIP(hipEventRecord(p.rendered, stream));          // the frame is composed ...
+        ST_HIP(hipStreamWaitEvent(cs, p.rendered, 0));       // ... before the communication stream touches it
+    }
+    // what this rank contributes: its own tile, contiguous when it spans the frame's width (a row band), packed otherwise
+    auto tile_bytes = [&](const StDistRect& r) { return (size_t)(r.x1 - r.x0) * (r.y1 - r.y0) * bpp; };
+    auto is_band = [&](const StDistRect& r) { return r.x0 == 0u && r.x1 == c.desc.width; };
+    auto at = [&](const void* base, const StDistRect& r) { return static_cast<const char*>(base) + (size_t)r.y0 * pitch + (size_t)r.x0 * bpp; };
+    if (d.world == 1) {
+        if (root && full != frame) copy_rect(this, const_cast<char*>(at(full, p.owned)), pitch, at(frame, p.owned), pitch, (size_t)(p.owned.x1 - p.owned.x0) * bpp, p.owned.y1 - p.owned.y0, cs);
+    } else if (!root) {
+        const void* send = at(frame, p.owned);
+        if (!is_band(p.owned)) {
+            if (int rc = ensure_staging(this, p, tile_bytes(p.owned))) return rc;
+            copy_rect(this, p.staging, (size_t)(p.owned.x1 - p.owned.x0) * bpp, at(frame, p.owned), pitch, (size_t)(p.owned.x1 - p.owned.x0) * bpp, p.owned.y1 - p.owned.y0, cs);
+            send = p.staging;
+        }
+        if (d.transport == 1) {
+            const int rc = g_rccl.Send(send, tile_bytes(p.owned), kNcclInt8, 0, d.comm, cs);
+            if (rc) return rccl_fail(rc, "ncclSend");
+        } else {
+            std::lock_guard<std::mutex> lock(g_local_mutex);
+            LocalSlot& slot = g_local[{d.group, d.rank}];
+            const size_t n = tile_bytes(p.owned);
+            if (slot.capacity < n || slot.device != has_device) {
+                if (slot.mem) { if (slot.device) (void)hipFree(slot.mem); else free(slot.mem); slot.mem = nullptr; }
+                if (has_device) { ST_HIP(hipMalloc(&slot.mem, n)); } else slot.mem = malloc(n);
+                slot.capacity = n; slot.device = has_device; slot.device_id = device;
+            }
+            if (has_device) {
+                if (!slot.ready) ST_HIP(hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming));
+                ST_HIP(hipMemcpyAsync(slot.mem, send, n, hipMemcpyDeviceToDevice, cs));
+                ST_HIP(hipEventRecord(slot.ready, cs));
+            } else memcpy(slot.mem, send, n);
+            slot.bytes = n; slot.seq++;
+        }
+    } else {
+        if (full != frame) copy_rect(this, const_cast<char*>(at(full, p.owned)), pitch, at(frame, p.owned), pitch, (size_t)(p.owned.x1 - p.owned.x0) * bpp, p.owned.y1 - p.owned.y0, cs);
+        // receive every peer's tile: straight into the frame when it is a band, through the staging area and an unpack otherwise
+        size_t need = 0;
+        std::vector<StDistRect> rects((size_t)d.world);
+        std::vector<size_t> offset((size_t)d.world, 0);
+        for (int r = 1; r < d.world; r++) {
+            if (int rc = rect_of(c, d, p, r, &rects[(size_t)r])) return rc;
+            if (!is_band(rects[(size_t)r])) { offset[(size_t)r] = need; need += (tile_bytes(rects[(size_t)r]) + 255u) & ~(size_t)255u; }
+        }
+        if (need) if (int rc = ensure_staging(this, p, need)) return rc;
+        if (d.transport == 1) {
+            int rc = g_rccl.GroupStart();
+            if (rc) return rccl_fail(rc, "ncclGroupStart");
+            for (int r = 1; r < d.world && !rc; r++) {
+                const StDistRect& q = rects[(size_t)r];
+                void* dst = is_band(q) ? const_cast<char*>(at(full, q)) : static_cast<char*>(p.staging) + offset[(size_t)r];
+                rc = g_rccl.Recv(dst, tile_bytes(q), kNcclInt8, r, d.comm, cs);
+            }
+            const int rc2 = g_rccl.GroupEnd();
+            if (rc) return rccl_fail(rc, "ncclRecv");
+            if (rc2) return rccl_fail(rc2, "ncclGroupEnd");
+        } else {
+            std::lock_guard<std::mutex> lock(g_local_mutex);
+            for (int r = 1; r < d.world; r++) {
+                const StDistRect& q = rects[(size_t)r];
+                auto sit = g_local.find({d.group, r});
+                if (sit == g_local.end() || sit->second.seq == sit->second.taken || sit->second.bytes != tile_bytes(q))
+                    return fail(ST_ERR_DIST, "local transport: rank " + std::to_string(r) + " has not handed over this frame's tile (non-root ranks call st_dist_gather first)");
+                LocalSlot& slot = sit->second;
+                void* dst = is_band(q) ? const_cast<char*>(at(full, q)) : static_cast<char*>(p.staging) + offset[(size_t)r];
+                if (has_device) {
+                    if (slot.ready) ST_HIP(hipStreamWaitEvent(cs, slot.ready, 0));
+                    ST_HIP(hipMemcpyAsync(dst, slot.mem, slot.bytes, slot.device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, cs));
+                } else memcpy(dst, slot.mem, slot.bytes);
+                slot.taken = slot.seq;
+            }
+        }
+        for (int r = 1; r < d.world; r++) {
+            const StDistRect& q = rects[(size_t)r];
+            if (!is_band(q)) copy_rect(this, const_cast<char*>(at(full, q)), pitch, static_cast<char*>(p.staging) + offset[(size_t)r], (size_t)(q.x1 - q.x0) * bpp, (size_t)(q.x1 - q.x0) * bpp, q.y1 - q.y0, cs);
+        }
+    }
+    if (has_device) { ST_HIP(hipEventRecord(p.done, cs)); p.pending = true; }
+    return ST_OK;
+}
+
+int Engine::dist_wait(uint64_t handle, hipStream_t stream, bool host) {
+    if (!dist) return ST_OK;
+    auto it = dist->cams.find(handle);
+    if (it == dist->cams.end() || !it->second.pending || !has_device) return ST_OK;
+    ST_HIP(hipSetDevice(device));
+    if (host) { ST_HIP(hipEventSynchronize(it->second.done)); it->second.pending = false; }
+    else ST_HIP(hipStreamWaitEvent(stream, it->second.done, 0));
+    return ST_OK;
+}
+
+}  // namespace st
+
+using namespace st;
+static Engine* E(StEngine* e) { return reinterpret_cast<Engine*>(e); }
+#define ST_REQUIRE(cond, msg) do { if (!(cond)) return fail(ST_ERR_INVALID_ARGUMENT, msg); } while (0)
+
+extern "C" {
+
+int st_dist_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, uint32_t rank, StDistRect* owned) { return dist_partition(width, height, world, cols, rank, owned); }
+int st_dist_window(uint32_t width, uint32_t height, const StDistRect* owned, uint32_t apron, StDistRect* window) { return dist_window(width, height, owned, apron, window); }
+
+int st_dist_unique_id(StDistUniqueId* out) {
+    ST_REQUIRE(out, "null argument");
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (!g_rccl.load()) return fail(ST_ERR_DIST, g_rccl.error);
+    const int rc = g_rccl.GetUniqueId(out);
+    return rc ? rccl_fail(rc, "ncclGetUniqueId") : ST_OK;
+}
+int st_dist_init(StEngine* e, int rank, int world, const StDistUniqueId* id) {
+    ST_REQUIRE(e && id, "null argument");
+    Engine* en = E(e);
+    if (!en->has_device) return fail(ST_ERR_NO_DEVICE, "the RCCL transport needs a device engine (st_dist_init_local is the in-process one)");
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        if (!g_rccl.load()) return fail(ST_ERR_DIST, g_rccl.error);
+    }
+    if (int rc = dist_begin(en, rank, world)) return rc;
+    en->dist->transport = 1;
+    const int rc = g_rccl.CommInitRank(&en->dist->comm, world, *id, rank);
+    if (rc) { const int out = rccl_fail(rc, "ncclCommInitRank"); en->release_dist(); return out; }
+    return ST_OK;
+}
+int st_dist_init_local(StEngine* e, int rank, int world, uint64_t group) {
+    ST_REQUIRE(e, "null engine");
+    Engine* en = E(e);
+    if (int rc = dist_begin(en, rank, world)) return rc;
+    en->dist->transport = 2; en->dist->group = group;
+    return ST_OK;
+}
+int st_dist_shutdown(StEngine* e) { ST_REQUIRE(e, "null engine"); E(e)->release_dist(); return ST_OK; }
+int st_dist_rank(StEngine* e, int* rank, int* world) {
+    ST_REQUIRE(e && rank && world, "null argument");
+    *rank = E(e)->dist ? E(e)->dist->rank : 0; *world = E(e)->dist ? E(e)->dist->world : 1;
+    return ST_OK;
+}
+int st_dist_set_partition(StEngine* e, StHandle camera, uint32_t cols, uint32_t apron, StDistRect* owned, StDistRect* window) {
+    ST_REQUIRE(e, "null engine");
+    auto it = E(e)->cameras.find(camera);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    if (int rc = E(e)->dist_set_partition(camera, *it->second, cols, apron)) return rc;
+    const DistState::CamPart& p = E(e)->dist->cams[camera];
+    if (owned) *owned = p.owned;
+    if (window) *window = p.window;
+    return ST_OK;
+}
+int st_dist_gather(StEngine* e, StHandle camera, const void* frame, void* full_on_root, void* stream) {
+    ST_REQUIRE(e, "null engine");
+    auto it = E(e)->cameras.find(camera);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    return E(e)->dist_gather(camera, *it->second, frame, full_on_root, static_cast<hipStream_t>(stream));
+}
+int st_dist_wait(StEngine* e, StHandle camera, void* stream, int host_wait) {
+    ST_REQUIRE(e, "null engine");
+    return E(e)->dist_wait(camera, static_cast<hipStream_t>(stream), host_wait != 0);
+}
+
+}  // extern "C"

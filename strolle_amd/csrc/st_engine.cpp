@@ -11,7 +11,7 @@ StTuning default_tuning() {
     StTuning t{};
     t.struct_size = sizeof(StTuning);
     t.overlap = t.fuse = t.fuse_di_head = t.fuse_spatial = t.fuse_gi_sampling = t.fuse_gi_validation = t.fuse_gi_reprojection = 1u;
-    t.fuse_wavelet = t.fuse_compose = t.preview_both = t.variance_in_reproject = t.variance_compaction = t.lean_frame = 1u;
+    t.fuse_wavelet = t.fuse_compose = t.preview_both = t.variance_in_reproject = t.lean_frame = 1u;
     t.skip_scratch_stores = t.di_head_on_main = t.alias_gi_history = 1u;
     t.tile_map = 1u; t.tile_map_denoise = 2u; t.side_priority = 0;
     t.staging = t.double_buffer = t.packed_base = 1u; t.tick_timing = 0u;
@@ -26,7 +26,7 @@ static void tuning_from_environment(StTuning& t) {
         {"ST_NO_FUSE_SPATIAL", &StTuning::fuse_spatial}, {"ST_NO_FUSE_GI_SAMPLING", &StTuning::fuse_gi_sampling},
         {"ST_NO_FUSE_GI_VALIDATION", &StTuning::fuse_gi_validation}, {"ST_NO_FUSE_GI_REPROJECTION", &StTuning::fuse_gi_reprojection},
         {"ST_NO_FUSE_WAVELET", &StTuning::fuse_wavelet}, {"ST_NO_FUSE_COMPOSE", &StTuning::fuse_compose}, {"ST_NO_PREVIEW_BOTH", &StTuning::preview_both},
-        {"ST_NO_VARIANCE_IN_REPROJECT", &StTuning::variance_in_reproject}, {"ST_NO_VARIANCE_COMPACTION", &StTuning::variance_compaction},
+        {"ST_NO_VARIANCE_IN_REPROJECT", &StTuning::variance_in_reproject},
         {"ST_KEEP_ALL_PLANES", &StTuning::lean_frame}, {"ST_KEEP_SCRATCH", &StTuning::skip_scratch_stores}, {"ST_NO_GI_ALIAS", &StTuning::alias_gi_history},
         {"ST_NO_STAGING", &StTuning::staging}, {"ST_NO_DOUBLE_BUFFER", &StTuning::double_buffer}, {"ST_NO_PACKED_BASE", &StTuning::packed_base},
         {"ST_NO_ANYHIT_FAST", &StTuning::anyhit_fast}, {"ST_NO_OCCLUDER_TABLE", &StTuning::occluder_table_log2},
@@ -84,6 +84,7 @@ void Engine::reset_profile_totals() {
 }
 
 Engine::~Engine() {
+    release_dist();
     if (!has_device) return;
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();

@@ -241,12 +241,11 @@ constexpr int kInternalPlanes = 4;  // decoded-surface twins A/B (KArgs::sn / ps
 struct CameraState {
     StCamera desc{};
     GpuCamera curr{}, prev{};
-    uint32_t frame = 0, row0 = 0, row1 = 0;
+    uint32_t frame = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0;   // [row0,row1) x [col0,col1): the window this engine renders (st_camera_set_window)
     uint32_t out_format = 0;  // StOutputFormat (camera.rs:170-175 viewport.format)
     void* slab = nullptr; size_t slab_bytes = 0;
     float4* plane[ST_BUF_COUNT + kInternalPlanes] = {};   // + the two decoded-surface twins (KArgs::sn / psn), internal only
     size_t plane_bytes[ST_BUF_COUNT + kInternalPlanes] = {};
-    uint32_t* var_compact = nullptr; uint32_t var_groups = 0, var_epoch = 0;  // KArgs::var_compact: {count, finished, epoch[G], list[G]}
     unsigned long long* tile_mask = nullptr; size_t tile_mask_tiles = 0;  // two arrays of one u64 per 8x8 tile (KArgs::tile_mask, KArgs::gi_late_mask)
     unsigned long long* counters = nullptr;  // KS_COUNT x kCounterLines x 8 u64 (one 64-B line each: {rays, traversal bytes, pad})
     unsigned long long profiled_traversal_bytes[KS_COUNT] = {};  // part of counters[..][1] already reported by st_profile_read
@@ -310,6 +309,9 @@ struct ProfileRecord { int slot; hipEvent_t start, stop; double bytes; uint32_t 
 struct Light112 { GpuLight g; };
 
 StTuning default_tuning();  // st_engine.cpp
+struct DistState;           // st_dist.cpp: rank / world, transport, per-camera partition
+int dist_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, uint32_t rank, StDistRect* owned);
+int dist_window(uint32_t width, uint32_t height, const StDistRect* owned, uint32_t apron, StDistRect* window);
 
 struct Engine {
     int device = -1;
@@ -436,6 +438,12 @@ struct Engine {
 
     Engine();
     int set_tuning(const StTuning& t);
+    // multi-GPU (st_dist.cpp)
+    DistState* dist = nullptr;
+    void release_dist();
+    int dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, uint32_t apron);
+    int dist_gather(uint64_t handle, CameraState& c, const void* frame, void* full, hipStream_t stream);
+    int dist_wait(uint64_t handle, hipStream_t stream, bool host);
     int allocate_occluder_table();
     void reset_profile_totals();
     ~Engine();

@@ -7,8 +7,7 @@ void Engine::release_camera(CameraState& c) {
     if (c.slab) (void)hipFree(c.slab);
     if (c.counters) (void)hipFree(c.counters);
     if (c.tile_mask) (void)hipFree(c.tile_mask);
-    if (c.var_compact) (void)hipFree(c.var_compact);
-    c.tile_mask = nullptr; c.var_compact = nullptr; c.var_groups = 0;
+    c.tile_mask = nullptr;
     c.slab = nullptr; c.counters = nullptr;
     if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
     for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
@@ -65,7 +64,7 @@ GpuCamera Engine::serialize_camera(const StCamera& c) {
 }
 
 int Engine::allocate_camera(CameraState& c) {
-    c.row0 = 0; c.row1 = c.desc.height;
+    c.row0 = 0; c.row1 = c.desc.height; c.col0 = 0; c.col1 = c.desc.width;
     if (!has_device) return ST_OK;
     ST_HIP(hipSetDevice(device));
     release_camera(c);
@@ -92,10 +91,6 @@ int Engine::allocate_camera(CameraState& c) {
         if (hipMalloc(reinterpret_cast<void**>(&c.tile_mask), 2 * tiles * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); c.tile_mask = nullptr; release_camera(c); return fail(ST_ERR_HIP, "hipMalloc(camera tile mask) failed"); }
         ST_HIP(hipMemset(c.tile_mask, 0, 2 * tiles * sizeof(unsigned long long)));  // [0, tiles): variance's, [tiles, 2 tiles): the GI preview's
         c.tile_mask_tiles = tiles;
-        const uint32_t groups = (((c.desc.width + 7u) / 8u + 3u) / 4u) * ((c.desc.height + 7u) / 8u);
-        if (hipMalloc(reinterpret_cast<void**>(&c.var_compact), (2 + 2 * (size_t)groups) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c.var_compact = nullptr; release_camera(c); return fail(ST_ERR_HIP, "hipMalloc(camera variance list) failed"); }
-        ST_HIP(hipMemset(c.var_compact, 0, (2 + 2 * (size_t)groups) * sizeof(uint32_t)));
-        c.var_groups = groups;
     }
     memset(c.profiled_traversal_bytes, 0, sizeof(c.profiled_traversal_bytes));
     ST_HIP(hipDeviceSynchronize());  // the clears run on the null stream; renders may use any stream
@@ -144,14 +139,15 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.gi_diff_stash = P(ST_BUF_GI_DIFF_STASH); a.gi_spec_samples = P(ST_BUF_GI_SPEC_SAMPLES);
     a.ref_hits = P(ST_BUF_REF_HITS); a.ref_rays = P(ST_BUF_REF_RAYS); a.ref_colors = P(ST_BUF_REF_COLORS);
     a.dbg_used_memory = reinterpret_cast<uint32_t*>(P(ST_BUF_DBG_USED_MEMORY));
-    a.width = c.desc.width; a.height = c.desc.height; a.row0 = c.row0; a.row1 = c.row1;
+    a.width = c.desc.width; a.height = c.desc.height; a.row0 = c.row0; a.row1 = c.row1; a.col0 = c.col0; a.col1 = c.col1;
     a.frame = c.frame;
     a.tile_map = tuning.tile_map;
 
     const double rows = (double)(c.row1 - c.row0);
+    const uint32_t cols = c.col1 - c.col0;
     auto slot_bytes = [&](int slot) {
         const KernelInfo& ki = kernel_info(slot);
-        const double units = rows * (ki.half ? (double)(((c.desc.width + 7u) / 8u / 2u) * 8u) : (double)c.desc.width);
+        const double units = rows * (ki.half ? (double)(((cols + 7u) / 8u / 2u) * 8u) : (double)cols);
         return units * ki.bytes_per_unit;
     };
     hipStream_t cur = stream;  // stream the next launches go to (the GI chain may be diverted to side_stream)
@@ -228,7 +224,6 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
         a.gi_late_mask = c.tile_mask ? c.tile_mask + c.tile_mask_tiles : nullptr; a.gi_preview_late = 0u;
         const bool gi_preview_both = tuning.preview_both && whole_graph && tuning.fuse && gi_runs && a.gi_late_mask;
         a.variance_in_reproject = (tuning.variance_in_reproject && whole_graph && tuning.fuse && tuning.fuse_wavelet && denoise && needs_di && needs_gi && any_objects && c.tile_mask) ? 1u : 0u;
-        a.var_compact = (a.variance_in_reproject && tuning.variance_compaction) ? c.var_compact : nullptr; a.var_groups = c.var_groups; a.var_epoch = ++c.var_epoch;   // one epoch per render: a group is appended once per frame
         // di_spatial's scratch records (di_diff_samples / curr_colors / stash as the reference binds them) are dead stores
         // when the fused launch is followed by resolving, denoise-reproject and the a-trous chain of the same frame
         const bool even_tiles_x = (((a.width + 7u) / 8u) & 1u) == 0u;

@@ -69,7 +69,6 @@ struct KArgs {
     // k_denoise.hip "variance in the reproject stage": the fused reproject stages store each pixel's long-history variance in
     // curr_colors.w and the DI one flags short-history pixels per 8x8 tile (bit = lane) for the variance kernel
     unsigned long long* tile_mask; uint32_t variance_in_reproject;
-    uint32_t* var_compact; uint32_t var_groups, var_epoch;  // compacted list of the 32x8 groups with short-history pixels (k_denoise.hip k_denoise_variance_compact; nullptr: full-screen variance launch)
     // k_gi.hip k_gi_preview_both: pixels whose second preview pass resamples, per 8x8 tile (bit = lane); gi_preview_late: the
     // second-pass launch serves flagged pixels only
     unsigned long long* gi_late_mask; uint32_t gi_preview_late;
@@ -105,7 +104,8 @@ struct KArgs {
     float4 *ref_hits, *ref_rays, *ref_colors;
     uint32_t* dbg_used_memory;
     unsigned long long* ray_counter;
-    uint32_t width, height, row0, row1;  // [row0,row1): rows this launch covers (multi-GPU tiling)
+    uint32_t width, height, row0, row1;  // [row0,row1) x [col0,col1): the window of the viewport this launch covers (multi-GPU row bands / 2-D tiles;
+    uint32_t col0, col1;                 // st_camera_set_rows / st_camera_set_window); pixels keep their absolute coordinates
     uint32_t frame;
     uint32_t tile_map;  // blockIdx -> tile mapping (st_device.h tile_for_thread)
 };

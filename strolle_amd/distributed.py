@@ -45,6 +45,59 @@ def render_window(height: int, band: Tuple[int, int], apron: int) -> Tuple[int, 
     return y0, y1
 
 
+def tile_for_rank(width: int, height: int, world_size: int, rank: int, cols: int = 0) -> Tuple[int, int, int, int]:
+    """(x0, y0, x1, y1) rank `rank` owns under the library's partition rule (st_dist_partition; one definition, in C): the default
+    grid is 1x1, two row bands, 2x2, 3x2, 4x2 ... (columns >= rows), tile edges on multiples of 16 pixels in x and 8 in y."""
+    from .api import dist_partition
+    return dist_partition(width, height, world_size, rank, cols)
+
+
+def tile_window(width: int, height: int, tile: Tuple[int, int, int, int], apron: int) -> Tuple[int, int, int, int]:
+    """What a rank renders: its tile widened by `apron` pixels towards its neighbours (st_dist_window)."""
+    from .api import dist_window
+    return dist_window(width, height, tile, apron)
+
+
+def tile_overhead(width: int, height: int, world_size: int, apron: int, cols: int = 0):
+    """Redundant pixels a rank renders around its tile, as a fraction of the tile: (max over ranks, mean)."""
+    fr = []
+    for r in range(world_size):
+        t = tile_for_rank(width, height, world_size, r, cols); w = tile_window(width, height, t, apron)
+        fr.append(((w[2] - w[0]) * (w[3] - w[1])) / ((t[2] - t[0]) * (t[3] - t[1])) - 1.0)
+    return max(fr), sum(fr) / len(fr)
+
+
+def gather_tiles_to_root(local_frame, full_frame, world_size: int, rank: int, cols: int = 0, dst: int = 0, group=None):
+    """torch.distributed FALLBACK of st_dist_gather (the C ABI's RCCL gather is the product path; this one serves boxes without
+    RCCL and the gloo tests): every rank sends its tile — packed, a tile is a strided view of the frame —, rank `dst` unpacks
+    each into its place in `full_frame`. One gather, the only collective."""
+    import torch
+    import torch.distributed as dist
+
+    height, width = local_frame.shape[0], local_frame.shape[1]
+    tiles = [tile_for_rank(width, height, world_size, r, cols) for r in range(world_size)]
+    x0, y0, x1, y1 = tiles[rank]
+    send = local_frame[y0:y1, x0:x1].contiguous()
+    if rank == dst:
+        recv = [torch.empty((t[3] - t[1], t[2] - t[0]) + tuple(local_frame.shape[2:]), dtype=local_frame.dtype, device=local_frame.device) for t in tiles]
+        same = all(r.shape == recv[0].shape for r in recv)
+        if same:
+            dist.gather(send, recv, dst=dst, group=group)
+        else:   # ragged tiles: point-to-point
+            ops = [dist.P2POp(dist.irecv, recv[r], r, group) for r in range(world_size) if r != dst]
+            for w in dist.batch_isend_irecv(ops): w.wait()
+            recv[dst] = send
+        for r, t in enumerate(tiles):
+            full_frame[t[1]:t[3], t[0]:t[2]] = recv[r]
+        return full_frame
+    same = all((t[3] - t[1], t[2] - t[0]) == (tiles[0][3] - tiles[0][1], tiles[0][2] - tiles[0][0]) for t in tiles)
+    if same:
+        dist.gather(send, None, dst=dst, group=group)
+    else:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, dst, group)]): w.wait()
+    return None
+
+
 def gather_frame(local_frame, height: int, width: int, world_size: int, rank: int, group=None):
     """All-gather the owned band of every rank into a full frame (torch tensors, any backend).
 

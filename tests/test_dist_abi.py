@@ -1,0 +1,124 @@
+"""Multi-GPU behind the C ABI (include/strolle_hip.h st_dist_*, strolle_amd/csrc/st_dist.cpp): the tile partition rule, the
+window (tile + apron) a rank renders, and the gather of the tiles to rank 0 — driven here through the in-process transport on
+host-only engines, i.e. without a GPU and without RCCL (same partition, same pack / unpack, same call sequence as the RCCL path)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from strolle_amd import Engine, StrolleError, scenes
+from strolle_amd.api import OutputFormat, dist_partition, dist_window
+from strolle_amd.distributed import tile_for_rank, tile_overhead, tile_window
+
+
+@pytest.mark.parametrize("size", [(3840, 2160), (1920, 1080), (640, 360), (200, 120)])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8])
+def test_partition_tiles_cover_the_frame_exactly_once(size, world):
+    w, h = size
+    cover = np.zeros((h, w), np.int32)
+    tiles = [dist_partition(w, h, world, r) for r in range(world)]
+    for x0, y0, x1, y1 in tiles:
+        assert x0 % 16 == 0 and y0 % 8 == 0 and (x1 % 16 == 0 or x1 == w) and (y1 % 8 == 0 or y1 == h)
+        cover[y0:y1, x0:x1] += 1
+    assert (cover == 1).all()
+    if world in (4, 8) and size == (3840, 2160):    # BASELINE.json configs 4 / 5: "4-tile" 2x2, "8-tile" 4x2
+        assert tiles[0] == ((0, 0, 1920, 1080) if world == 4 else (0, 0, 960, 1080))
+    if world == 2:
+        assert tiles[0][2] == w, "two ranks: row bands (contiguous sends, no column seam)"
+    # explicit column counts: row bands (cols = 1) and column strips (cols = world)
+    bands = [dist_partition(w, h, world, r, cols=1) for r in range(world)]
+    assert all(b[0] == 0 and b[2] == w for b in bands)
+
+
+def test_window_adds_the_apron_only_towards_neighbours():
+    w, h = 3840, 2160
+    t = dist_partition(w, h, 8, 1)                       # (960, 0, 1920, 1080): neighbours left, right and below
+    assert dist_window(w, h, t, 16) == (944, 0, 1936, 1096)
+    assert dist_window(w, h, t, 0) == t
+    corner = dist_partition(w, h, 8, 7)                  # bottom-right tile
+    assert dist_window(w, h, corner, 16) == (2864, 1064, 3840, 2160)
+    assert dist_window(w, h, (0, 0, w, h), 128) == (0, 0, w, h)
+    # config 5 at 8 ranks must not pay more than 8 % in redundant pixels (row bands paid 15.6 %)
+    mx, mean = tile_overhead(w, h, 8, 16)
+    assert mx <= 0.08 and mean <= 0.05, (mx, mean)
+    assert tile_overhead(w, h, 8, 16, cols=1)[0] > 0.10, "the row-band partition it replaces"
+    assert tile_for_rank(w, h, 8, 3) == dist_partition(w, h, 8, 3) and tile_window(w, h, t, 16) == dist_window(w, h, t, 16)
+
+
+def _engines(world, size, group, fmt=None):
+    out = []
+    for r in range(world):
+        e = Engine(device=-1)
+        scenes.build_cornell(e)
+        cam = e.create_camera(scenes.cornell_camera(size))
+        if fmt is not None:
+            e.set_output_format(cam, fmt)
+        e.dist_init_local(r, world, group)
+        out.append((e, cam))
+    return out
+
+
+@pytest.mark.parametrize("world,cols,fmt,dtype", [(4, 0, None, np.float32), (8, 0, None, np.float32), (2, 0, None, np.float32), (3, 0, None, np.float32),
+                                                  (4, 4, None, np.float32), (4, 0, OutputFormat.RGBA8_UNORM_SRGB, np.uint8), (6, 0, OutputFormat.RGBA16F, np.uint16)])
+def test_local_transport_gathers_tiles_to_rank_0(world, cols, fmt, dtype):
+    """Every rank hands over its tile of a frame it alone can have produced (the rank number + a position ramp); rank 0's assembled
+    frame must be tile r from rank r, bit for bit — for bands (contiguous sends), 2-D tiles (packed) and the narrower formats."""
+    w, h = 352, 200
+    ranks = _engines(world, (w, h), group=1000 + world * 16 + cols, fmt=fmt)
+    chan = 4
+    frames = []
+    yy, xx = np.mgrid[0:h, 0:w]
+    for r in range(world):
+        f = np.empty((h, w, chan), dtype)
+        base = (r * 37 + xx * 3 + yy * 5)
+        for c in range(chan):
+            f[..., c] = (base + c).astype(dtype)
+        frames.append(np.ascontiguousarray(f))
+    full = np.zeros((h, w, chan), dtype)
+    expect = np.zeros_like(full)
+    for r, (e, cam) in enumerate(ranks):
+        owned, window = e.dist_set_partition(cam, cols=cols, apron=16)
+        assert owned == dist_partition(w, h, world, r, cols) and window == dist_window(w, h, owned, 16)
+        x0, y0, x1, y1 = owned
+        expect[y0:y1, x0:x1] = frames[r][y0:y1, x0:x1]
+    for r in range(world - 1, -1, -1):     # non-root ranks first (in-process transport)
+        e, cam = ranks[r]
+        e.dist_gather(cam, frames[r].ctypes.data, full.ctypes.data if r == 0 else 0)
+    assert np.array_equal(full, expect)
+    # a second frame through the same mailbox, root assembling IN PLACE (full == its own frame)
+    for f in frames:
+        f += 1
+    expect2 = frames[0].copy()
+    for r in range(1, world):
+        x0, y0, x1, y1 = dist_partition(w, h, world, r, cols)
+        expect2[y0:y1, x0:x1] = frames[r][y0:y1, x0:x1]
+    for r in range(world - 1, -1, -1):
+        e, cam = ranks[r]
+        e.dist_gather(cam, frames[r].ctypes.data, frames[0].ctypes.data if r == 0 else 0)
+    assert np.array_equal(frames[0], expect2)
+    for e, _ in ranks:
+        e.dist_shutdown(); e.close()
+
+
+def test_gather_says_when_a_rank_is_missing_and_when_nothing_was_set_up():
+    (e0, c0), (e1, c1) = _engines(2, (64, 48), group=77)
+    buf = np.zeros((48, 64, 4), np.float32)
+    with pytest.raises(StrolleError, match="st_dist_set_partition"):
+        e0.dist_gather(c0, buf.ctypes.data, buf.ctypes.data)
+    e0.dist_set_partition(c0); e1.dist_set_partition(c1)
+    with pytest.raises(StrolleError, match="has not handed over"):
+        e0.dist_gather(c0, buf.ctypes.data, buf.ctypes.data)       # rank 1 has not sent
+    e1.dist_gather(c1, buf.ctypes.data)
+    e0.dist_gather(c0, buf.ctypes.data, buf.ctypes.data)
+    with pytest.raises(StrolleError, match="has not handed over"):
+        e0.dist_gather(c0, buf.ctypes.data, buf.ctypes.data)       # the same tile is not taken twice
+    plain = Engine(device=-1)
+    scenes.build_cornell(plain)
+    cam = plain.create_camera(scenes.cornell_camera((64, 48)))
+    with pytest.raises(StrolleError, match="st_dist_init"):
+        plain.dist_set_partition(cam)
+    with pytest.raises(StrolleError):
+        plain.set_camera_window(cam, 8, 0, 64, 48)                 # columns must sit on multiples of 16
+    plain.set_camera_window(cam, 16, 8, 48, 40)
+    for e in (e0, e1, plain):
+        e.close()
