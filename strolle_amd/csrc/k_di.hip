@@ -173,7 +173,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a_in, uint32_t s
             Ray ray = make_ray(xyz(r0), normal_decode(v2(r1.x, r1.y)));
             ray.len = r0.w;
             uint32_t used_ = 0u;
-            const bool occluded = trace_any<1>(a, ray, lane_stack(lds), &used_);
+            const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
             rays += 1u; bytes += used_;
             vis[k] = make_float4(occluded ? 0.0f : 1.0f, r1.z, r1.w, 0.0f);
         }
@@ -207,7 +207,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     float confidence;
     V3 radiance, spec_brdf;
     if (hit_some(hit)) {
-        const bool occluded = trace_any<1>(a, di_sample_ray(res.s, hit.point), lane_stack(lds), &used_);
+        const bool occluded = trace_any(a, di_sample_ray(res.s, hit.point), lane_stack(lds), &used_);
         count_rays(a, used_);
         confidence = (res.s.is_occluded == occluded) ? res.s.confidence : 0.0f;
         res.s.confidence = 1.0f;

@@ -129,7 +129,7 @@ ST_D void gi_sampling_b_cell(const KArgs& a, uint32_t seed, bool tracing, U2 pos
         if (hit_some(gi_hit)) {
             const Ray ray = light_id == kLightIdSky ? make_ray(gi_hit.point, light_dir) : light_ray_wnoise(light_get(a, light_id), wn, gi_hit.point);
             uint32_t used_now = 0u;
-            const bool occluded = trace_any<1>(a, ray, stack, &used_now);
+            const bool occluded = trace_any(a, ray, stack, &used_now);
             *used_ += used_now;
             count_rays(a, used_now);
             light_vis = occluded ? 0.0f : 1.0f;

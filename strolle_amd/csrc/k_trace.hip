@@ -115,7 +115,7 @@ __global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, 
         const uint32_t light_id = wn.sample_int() % a.light_count;
         const float light_pdf = frcp((float)a.light_count);
         const GpuLight light = light_get(a, light_id);
-        const bool occluded = trace_any<1>(a, light_ray_wnoise(light, wn, hit.point), lane_stack(lds), &used_);
+        const bool occluded = trace_any(a, light_ray_wnoise(light, wn, hit.point), lane_stack(lds), &used_);
         count_rays(a, used_);
         if (!occluded) color = color + throughput * radiance_sum(light_radiance(light, hit)) / light_pdf;
     }

@@ -27,7 +27,6 @@ int st_engine_create(int device_ordinal, StEngine** out) {
         for (int i = 0; i < 3; i++) { ST_HIP(hipMalloc(&luts[i]->ptr, lut_bytes[i])); luts[i]->capacity = lut_bytes[i]; ST_HIP(hipMemset(luts[i]->ptr, 0, lut_bytes[i])); }
         ST_HIP(hipMalloc(&e->d_byte_luts.ptr, sizeof(float) * 1024)); e->d_byte_luts.capacity = sizeof(float) * 1024;
         e->L.launch_build_byte_luts(static_cast<float*>(e->d_byte_luts.ptr), nullptr);
-        if (int rc = e->allocate_occluder_table()) return rc;
         ST_HIP(hipDeviceSynchronize());
     }
     *out = reinterpret_cast<StEngine*>(e.release());

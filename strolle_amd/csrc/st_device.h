@@ -431,12 +431,11 @@ ST_D bool trace_any_contract(const KArgs& a, const Ray& ray, SE* stack, uint32_t
 //     the dungeon's DI shadow rays (occluded rays find their occluder later) against the ~15 % of an internal step the sort costs;
 //     a wave-wide packet walk of the same rays (one node per step for all lanes, scalar fetch) visits 1.8x (DI) to 3x (GI) MORE
 //     entries than the per-lane loop executes bodies — rays of one 8x8 tile go to 4-5 different lights — and is not built.
-//   * SITE 1 (rays towards a light: DI sampling / resolving / spatial, GI sampling b): a WORLD-SPACE LAST-OCCLUDER TABLE
-//     (KArgs::occluder_table; key = hash of the ray's origin cell (1 unit) and end-point cell (1/4 unit)). The leaf entry
-//     that ended an earlier ray between the same two cells is tested first; a hit ends the ray after one entry, and whole
-//     tiles in shadow end after one step (packet_sim.py, dungeon: 0.74 of the DI shadow rays end there, loop bodies per wave
-//     / 1.6). Any leaf entry of the current stream is a legitimate occluder to test, so a stale or colliding slot costs one
-//     test and nothing else; slots are validated against the stream (inside it, a leaf entry, not AlphaMode::Blend).
+//   * a WORLD-SPACE LAST-OCCLUDER TABLE (key = hash of the ray's origin cell and end-point cell; the leaf entry that ended an earlier
+//     ray between the same two cells is tested first) was built on top of this loop and measured NEUTRAL — dungeon 1.4244 vs 1.4212
+//     ms/frame without it, DI resolving 138.4 vs 141.6 us, DI spatial 117.6 vs 115.3: packet_sim.py's 0.74 hit rate per ray holds,
+//     but a wave only ends when its last lane does, and the waves that end early were not the ones the frame waits for. It is in
+//     tools/experiments/occluder_table.inc.
 // The boolean can differ from the contract loop's only where a ray grazes a box or a triangle edge within an ulp; the fast
 // build's launch-by-launch tolerance tests (tests/test_gpu_fast_*.py) bound how often. The exact build never comes here.
 #if ST_FAST_DEVICE
@@ -462,36 +461,18 @@ ST_D bool any_triangle(const Ray& ray, V3 p0, V3 e1, V3 e2, float limit, float* 
     *u_out = u; *v_out = v;
     return !((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= limit));
 }
-// cells are hashed through the bits of floorf(): no float -> int conversion whose range the compiler could reason about
-ST_D uint32_t occluder_slot(const KArgs& a, const Ray& ray) {
-    const V3 end = ray_at(ray, ray.len);
-    const uint32_t ox = f2b(floorf(ray.origin.x)), oy = f2b(floorf(ray.origin.y)), oz = f2b(floorf(ray.origin.z));
-    const uint32_t ex = f2b(floorf(end.x * 4.0f)), ey = f2b(floorf(end.y * 4.0f)), ez = f2b(floorf(end.z * 4.0f));
-    uint32_t h = (ox >> 7) * 73856093u ^ (oy >> 7) * 19349663u ^ (oz >> 7) * 83492791u;
-    h = h * 0x9e3779b1u ^ ((ex >> 7) * 2654435761u ^ (ey >> 7) * 2654404609u ^ (ez >> 7) * 2246822519u);
-    h ^= h >> 15;
-    return h & a.occluder_mask;
-}
-template <int SITE, class SE>
+template <class SE>
 ST_D bool any_hit_fast(const KArgs& a, const Ray& ray, SE* stack) {
     if (a.bvh_len == 0u) return false;
     const float limit = ray.len;
-    uint32_t slot = 0u;
-    const bool cached = SITE != 0 && a.occluder_table != nullptr && limit < 1.0e30f;   // (a sky ray has no end point)
-    if (cached) {
-        slot = occluder_slot(a, ray);
-        const uint32_t entry = a.occluder_table[slot];
-        if (entry < (a.bvh_len >> 2)) {
-            const float4* e = bvh_entry(a.bvh, entry << 6);
-            const float4 d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3];
-            float u, v;
-            if (f2b(d0.w) != 0u && (f2b(d0.x) & 2u) == 0u && any_triangle(ray, xyz(d1), xyz(d2), xyz(d3), limit, &u, &v)) return true;
-        }
-    }
     const V3 inv = v3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
     const V3 oi = v3(-ray.origin.x * inv.x, -ray.origin.y * inv.y, -ray.origin.z * inv.z);
+    // (Loop shape: ONE loop with `continue`s and a single exit, as traverse() has it. A first version returned from inside the loop;
+    // the structurizer turned its exits into an inner and an outer loop, lanes waited for each other at the inner one's end, and the
+    // dungeon frame went 1.520 -> 1.604 ms although every body had become cheaper.)
     uint32_t ptr = 0u;
     int sp = 0;
+    bool hit = false;
     for (;;) {
         const float4* entry = bvh_entry(a.bvh, ptr);
         const float4 d0 = entry[0], d1 = entry[1], d2 = entry[2], d3 = entry[3];
@@ -506,27 +487,26 @@ ST_D bool any_hit_fast(const KArgs& a, const Ray& ray, SE* stack) {
         } else {
             const uint32_t flags = f2b(d0.x);
             float u, v;
-            if (any_triangle(ray, xyz(d1), xyz(d2), xyz(d3), limit, &u, &v)) {
-                bool found = true;
-                if (flags & 2u) {  // AlphaMode::Blend: the texel decides (exact-island fetch, as in traverse())
-                    const uint32_t tri = f2b(d0.y), material = f2b(d0.z);
-                    const GpuMaterial m = a.materials[material];
-                    const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
-                    if (bc.w < 1.0f) found = false;
-                } else if (cached) a.occluder_table[slot] = ptr >> 6;   // benign race: every value ever stored is a leaf entry of some stream
-                if (found) return true;
+            bool found = any_triangle(ray, xyz(d1), xyz(d2), xyz(d3), limit, &u, &v);
+            if (found && (flags & 2u)) {  // AlphaMode::Blend: the texel decides (exact-island fetch, as in traverse())
+                const uint32_t tri = f2b(d0.y), material = f2b(d0.z);
+                const GpuMaterial m = a.materials[material];
+                const float4 bc = sample_atlas(a, tri_uv(a, tri, u, v), m.base_color, m.base_color_texture);
+                if (bc.w < 1.0f) found = false;
             }
+            if (found) { hit = true; break; }
             if (flags & 1u) { ptr += 64u; continue; }
         }
-        if (sp > 0) { sp--; ptr = (uint32_t)stack[sp * 64] << 6; } else return false;
+        if (sp > 0) { sp--; ptr = (uint32_t)stack[sp * 64] << 6; } else break;
     }
+    return hit;
 }
 #endif
-// Ray::intersect (shadow ray). SITE 1: a ray towards a light (see above); SITE 0: everything else.
-template <int SITE = 0, class SE>
+// Ray::intersect (shadow ray)
+template <class SE>
 ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
 #if ST_FAST_DEVICE && !defined(ST_NO_ANYHIT_FAST)
-    if (!a.anyhit_contract) { *used_memory = 0u; return any_hit_fast<SITE>(a, ray, stack); }
+    if (!a.anyhit_contract) { *used_memory = 0u; return any_hit_fast(a, ray, stack); }
 #endif
     return trace_any_contract(a, ray, stack, used_memory);
 }

@@ -15,7 +15,7 @@ StTuning default_tuning() {
     t.skip_scratch_stores = t.di_head_on_main = t.alias_gi_history = 1u;
     t.tile_map = 1u; t.tile_map_denoise = 2u; t.side_priority = 0;
     t.staging = t.double_buffer = t.packed_base = 1u; t.tick_timing = 0u;
-    t.anyhit_fast = 1u; t.occluder_table_log2 = 19u; t.occluder_min_texels = 4096u;
+    t.anyhit_fast = 1u;
     t.allow_deep_bvh = 0u; t.device_bake = 1u;
     return t;
 }
@@ -29,18 +29,17 @@ static void tuning_from_environment(StTuning& t) {
         {"ST_NO_VARIANCE_IN_REPROJECT", &StTuning::variance_in_reproject},
         {"ST_KEEP_ALL_PLANES", &StTuning::lean_frame}, {"ST_KEEP_SCRATCH", &StTuning::skip_scratch_stores}, {"ST_NO_GI_ALIAS", &StTuning::alias_gi_history},
         {"ST_NO_STAGING", &StTuning::staging}, {"ST_NO_DOUBLE_BUFFER", &StTuning::double_buffer}, {"ST_NO_PACKED_BASE", &StTuning::packed_base},
-        {"ST_NO_ANYHIT_FAST", &StTuning::anyhit_fast}, {"ST_NO_OCCLUDER_TABLE", &StTuning::occluder_table_log2},
+        {"ST_NO_ANYHIT_FAST", &StTuning::anyhit_fast},
     };
     for (const Clear& c : clears) if (const char* v = getenv(c.name)) { if (atoi(v) != 0) t.*c.field = 0u; else if (t.*c.field == 0u) t.*c.field = 1u; }
     struct Value { const char* name; uint32_t StTuning::*field; };
     static const Value values[] = {
         {"ST_DI_HEAD_ON_MAIN", &StTuning::di_head_on_main}, {"ST_TILE_MAP_DENOISE", &StTuning::tile_map_denoise}, {"ST_TICK_TIMING", &StTuning::tick_timing},
-        {"ST_OCCLUDER_TABLE_LOG2", &StTuning::occluder_table_log2}, {"ST_ALLOW_DEEP_BVH", &StTuning::allow_deep_bvh}, {"ST_DEVICE_BAKE", &StTuning::device_bake},
+        {"ST_ALLOW_DEEP_BVH", &StTuning::allow_deep_bvh}, {"ST_DEVICE_BAKE", &StTuning::device_bake},
     };
     if (const char* v = getenv("ST_TILE_MAP")) t.tile_map = t.tile_map_denoise = (uint32_t)atoi(v);
     for (const Value& c : values) if (const char* v = getenv(c.name)) t.*c.field = (uint32_t)atoi(v);
     if (const char* v = getenv("ST_SIDE_PRIORITY")) t.side_priority = atoi(v);
-    if (t.occluder_table_log2 > 26u) t.occluder_table_log2 = 26u;
 }
 
 Engine::Engine() {
@@ -59,23 +58,10 @@ Engine::Engine() {
 int Engine::set_tuning(const StTuning& t) {
     if (t.struct_size != sizeof(StTuning)) return fail(ST_ERR_INVALID_ARGUMENT, "StTuning::struct_size does not match this library");
     if (t.tile_map > 2u || t.tile_map_denoise > 2u) return fail(ST_ERR_INVALID_ARGUMENT, "tile_map is 0, 1 or 2");
-    if (t.occluder_table_log2 > 26u) return fail(ST_ERR_INVALID_ARGUMENT, "occluder_table_log2 above 26");
-    const bool table_changed = t.occluder_table_log2 != tuning.occluder_table_log2;
     tuning = t;
     staging.enabled = tuning.staging != 0u;
-    if (table_changed && has_device) { ST_HIP(hipSetDevice(device)); ST_HIP(hipDeviceSynchronize()); return allocate_occluder_table(); }
     return ST_OK;
 }
-int Engine::allocate_occluder_table() {
-    d_occluder.release(); occluder_slots = 0;
-    if (!has_device || tuning.occluder_table_log2 == 0u) return ST_OK;
-    const size_t slots = (size_t)1 << tuning.occluder_table_log2;
-    ST_HIP(hipMalloc(&d_occluder.ptr, slots * sizeof(uint32_t))); d_occluder.capacity = slots * sizeof(uint32_t);
-    ST_HIP(hipMemset(d_occluder.ptr, 0xff, slots * sizeof(uint32_t)));   // 0xffffffff: no entry
-    occluder_slots = (uint32_t)slots;
-    return ST_OK;
-}
-
 void Engine::reset_profile_totals() {
     for (int i = 0; i < KS_COUNT; i++) {
         memset(&profile_totals[i], 0, sizeof(StKernelProfile));
@@ -89,7 +75,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
     for (auto& kv : cameras) release_camera(*kv.second);
-    for (DeviceArray* d : {&d_byte_luts, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky, &d_occluder}) d->release();
+    for (DeviceArray* d : {&d_byte_luts, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky}) d->release();
     for (LightSet& l : light_sets) { l.buf.release(); if (l.free_ev) (void)hipEventDestroy(l.free_ev); }
     for (SceneSet& t : sets) {
         for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed, &t.tri_geo, &t.tri_bounds, &t.entry_of_tri, &t.parent, &t.refit_local, &t.refit_items, &t.refit_batch_off}) d->release();

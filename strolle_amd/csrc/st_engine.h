@@ -390,7 +390,6 @@ struct Engine {
     bool atmosphere_initialized = false, sky_known = false; float known_sun_altitude = 0.0f;  // passes/atmosphere.rs:14-15,78-110
 
     DeviceArray d_byte_luts, d_atlas, d_blue_noise, d_transmittance, d_scattering, d_sky;
-    DeviceArray d_occluder; uint32_t occluder_slots = 0;  // world-space last-occluder table of the fast build's shadow rays (st_device.h any_hit_fast)
     // The arrays a scene change rewrites exist twice. A tick that changes the scene fills the copy no frame in flight reads,
     // on a stream of its own, while the previous frame still renders from the other one; the next frame switches over.
     // (Updating in place would have to wait for the previous frame, and the next frame's primary rays with it.)
@@ -444,7 +443,6 @@ struct Engine {
     int dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, uint32_t apron);
     int dist_gather(uint64_t handle, CameraState& c, const void* frame, void* full, hipStream_t stream);
     int dist_wait(uint64_t handle, hipStream_t stream, bool host);
-    int allocate_occluder_table();
     void reset_profile_totals();
     ~Engine();
     static void release_camera(CameraState& c);

@@ -78,7 +78,7 @@ ST_D DiReservoir di_sampling_pixel(const KArgs& a, uint32_t seed, U2 pos, const 
     if (res.m > 0.0f) {
         const float4 bn = blue_noise_read(a, pos);
         const Ray ray = light_ray_bnoise(light_get(a, res.light_id), v2(bn.x, bn.y), hit.point);
-        const bool occluded = trace_any<1>(a, ray, stack, &used_);
+        const bool occluded = trace_any(a, ray, stack, &used_);
         count_rays(a, used_);
         if (occluded) res.w = 0.0f;
         out.s.light_id = res.light_id; out.s.light_point = ray.origin; out.s.is_occluded = occluded;

@@ -117,8 +117,6 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
     a.count_bytes = count_bytes ? 1u : 0u;
     a.anyhit_contract = (count_bytes || !tuning.anyhit_fast) ? 1u : 0u;   // the reference's used_memory is the contract loop's
-    const bool use_table = occluder_slots != 0u && device_bvh_len >= tuning.occluder_min_texels;
-    a.occluder_table = use_table ? static_cast<uint32_t*>(d_occluder.ptr) : nullptr; a.occluder_mask = use_table ? occluder_slots - 1u : 0u;
     a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
     a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
     a.sun_dir[0] = sun_dir_.x; a.sun_dir[1] = sun_dir_.y; a.sun_dir[2] = sun_dir_.z;

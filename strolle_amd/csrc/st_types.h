@@ -79,9 +79,7 @@ struct KArgs {
     // ST_KEEP_ALL_PLANES=1 keeps every plane as the reference leaves it.
     uint32_t lean;
     const float4* gi_mid_src;  // kLeanGiMid, second-pass launch only: the first preview pass's input plane (nullptr: GI_RESERVOIRS_3 holds every first-pass result)
-    // any-hit rays of the fast build (st_device.h any_hit_fast): world-space last-occluder table (nullptr: off), its index mask,
-    // and the switch back to the contract loop (set while the reference's used_memory bytes are being counted, or by StTuning)
-    uint32_t* occluder_table; uint32_t occluder_mask, anyhit_contract;
+    uint32_t anyhit_contract;  // fast build: shadow rays walk the contract loop (set while the reference's used_memory bytes are counted, or by StTuning::anyhit_fast = 0)
     uint32_t count_bytes;  // st_profile_enable bit 1: kernels also sum the reference's used_memory over their rays
     uint32_t tri_slots;  // triangle records in tri_attr (upper bound of every triangle id in the BVH stream)
     float sun_altitude;

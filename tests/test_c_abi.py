@@ -469,7 +469,7 @@ def test_tuning_round_trips_and_rejects_a_foreign_struct():
     e = Engine(device=-1)
     t = e.tuning()
     assert t.struct_size == C.sizeof(type(t)) and t.overlap == 1 and t.fuse == 1 and t.tile_map == 1 and t.tile_map_denoise == 2
-    assert t.anyhit_fast == 1 and t.occluder_table_log2 == 19 and t.allow_deep_bvh == 0
+    assert t.anyhit_fast == 1 and t.allow_deep_bvh == 0
     e.set_tuning(fuse=0, tile_map=2, side_priority=-1)
     t2 = e.tuning()
     assert (t2.fuse, t2.tile_map, t2.side_priority, t2.overlap) == (0, 2, -1, 1)
