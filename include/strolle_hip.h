@@ -168,7 +168,10 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                                                level of 512-leaf subtrees: two at 208 k triangles). Same bits as ST_BVH_REFIT. */ };
 int st_set_bvh_refresh(StEngine* e, int mode);
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits);
-int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits);   /* ticks whose boxes were recomputed by k_bvh.hip (ST_BVH_REFIT_DEVICE) */
+int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits);
+/* Launches of the device bake so far and the triangles they baked (StTuning::device_bake: under ST_BVH_REFIT_DEVICE instances that only moved are
+ * baked into world space on the device from object-space meshes uploaded once; a tick then sends 132 B per moved instance). */
+int st_debug_device_bakes(StEngine* e, uint64_t* ticks, uint64_t* triangles);   /* ticks whose boxes were recomputed by k_bvh.hip (ST_BVH_REFIT_DEVICE) */
 /* Depth check of the last BVH build: the longest chain of internal nodes (= the most far-child pointers one traversal can
  * have pending) against the per-ray stack of the kernels (24 entries, strolle-gpu/src/lib.rs:76). The reference writes past
  * its stack array when a tree is deeper; this library drops the push and says so once on stderr — a scene for which

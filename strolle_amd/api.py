@@ -304,6 +304,7 @@ class _Binding:
         if has_device:
             self.debug_bvh_depth = fn("debug_bvh_depth", [vp, P(u32), P(u32)])
             self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
+            self.debug_device_bakes = fn("debug_device_bakes", [vp, P(u64), P(u64)])
             self.engine_get_tuning = fn("engine_get_tuning", [vp, P(StTuning)]); self.engine_set_tuning = fn("engine_set_tuning", [vp, P(StTuning)])
             self.debug_copy_bandwidth = fn("debug_copy_bandwidth", [vp, sz, i32, P(C.c_double)])
             self.debug_variance_flags = fn("debug_variance_flags", [vp, u64, vp, sz, P(sz)])
@@ -485,6 +486,12 @@ class EngineBase:
         out = C.c_uint64()
         self._check(self._b.debug_bvh_device_refits(self._h, C.byref(out)))
         return out.value
+
+    def device_bakes(self):
+        """(launches of the device bake, triangles they baked) so far — StTuning::device_bake."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._b.debug_device_bakes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def bvh_refits(self):
         """(rebuilds, refits) so far."""

@@ -79,6 +79,53 @@ __global__ __launch_bounds__(256) void k_bvh_refit(float4* bvh, const float4* tr
     }
 }
 
+// ---- world-space baking on the device (strolle/src/instances.rs:100-139, mesh_triangle.rs:47-86; StTuning::device_bake).
+// When instances only MOVE under ST_BVH_REFIT_DEVICE the host no longer bakes their triangles and sends 80 + 64 B for each: the
+// object-space meshes are uploaded once (24 floats per triangle: positions, normals, uvs), a tick sends one 128-B job per moved
+// instance, and this kernel writes what Engine::bake writes for the device — the hit-test record (also straight into the
+// triangle's leaf entry, which is what k_bvh_patch_leaves did), the bounds k_bvh_refit reads, and the attribute record — with
+// Engine::bake's own operations in its own order (this file's EXACT build is the one launched, whatever arithmetic the frame
+// uses: st_engine launches launchers_exact().launch_bvh_bake), so the device arrays are bit for bit the host's
+// (tests/test_gpu_parity.py test_device_bake_*). Tangents are host-only data (the reference's 144-B triangle) and are not made here.
+struct BakeJobDevice { float4 x, y, z, t, r0, r1, r2; uint32_t mesh_first, count, slot_first, xslot; };
+static_assert(sizeof(BakeJobDevice) == 128, "one bake job is 128 B");
+__global__ __launch_bounds__(256) void k_bvh_bake(const BakeJobDevice* jobs, const uint32_t* job_start, uint32_t n_jobs, uint32_t total, const float* mesh,
+                                                  float4* tri_geo, float4* tri_bounds, float4* tri_attr, float4* bvh, const uint32_t* entry_of_tri) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint32_t lo = 0u, hi = n_jobs;          // the job whose [job_start[j], job_start[j + 1]) holds i
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (job_start[mid] <= i) lo = mid; else hi = mid; }
+    const BakeJobDevice j = jobs[lo];
+    const uint32_t k = i - job_start[lo];
+    const float* m = mesh + 24u * (size_t)(j.mesh_first + k);
+    const V3 ax = xyz(j.x), ay = xyz(j.y), az = xyz(j.z), at = xyz(j.t), r0 = xyz(j.r0), r1 = xyz(j.r1), r2 = xyz(j.r2);
+    V3 p[3], n[3];
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        const V3 q = v3(m[3 * v], m[3 * v + 1], m[3 * v + 2]);
+        p[v] = ((ax * q.x) + (ay * q.y) + (az * q.z)) + at;                       // glam Affine3A::transform_point3
+        const V3 nn = v3(m[9 + 3 * v], m[9 + 3 * v + 1], m[9 + 3 * v + 2]);
+        V3 acc = r0 * nn.x; acc = r1 * nn.y + acc; acc = r2 * nn.z + acc;           // transpose(inverse) * normal, Mat4::transform_vector3 order
+        n[v] = normalize(acc);
+    }
+    const float* uv = m + 18;
+    const uint32_t slot = j.slot_first + k;
+    const float4 g0 = f4(p[0], 0.0f), g1 = f4(p[1] - p[0], 0.0f), g2 = f4(p[2] - p[0], 0.0f);
+    tri_geo[3u * slot] = g0; tri_geo[3u * slot + 1u] = g1; tri_geo[3u * slot + 2u] = g2;
+    V3 blo = v3s(kF32Max), bhi = v3s(-kF32Max);                                      // Aabb::grow: every point through min AND max
+#pragma unroll
+    for (int v = 0; v < 3; v++) { blo = vmin(blo, p[v]); bhi = vmax(bhi, p[v]); }
+    tri_bounds[2u * slot] = f4(blo, 0.0f); tri_bounds[2u * slot + 1u] = f4(bhi, 0.0f);
+    tri_attr[4u * slot] = f4(n[0], uv[0]); tri_attr[4u * slot + 1u] = f4(n[1], uv[1]); tri_attr[4u * slot + 2u] = f4(n[2], uv[2]);
+    tri_attr[4u * slot + 3u] = make_float4(uv[3], uv[4], uv[5], b2f(j.xslot));
+    const uint32_t e = entry_of_tri[slot];
+    if (e != 0xffffffffu) { bvh[4u * e + 1u] = g0; bvh[4u * e + 2u] = g1; bvh[4u * e + 3u] = g2; }
+}
+void launch_bvh_bake(const void* jobs, const uint32_t* job_start, uint32_t n_jobs, uint32_t total, const float* mesh, float4* tri_geo, float4* tri_bounds, float4* tri_attr,
+                     float4* bvh, const uint32_t* entry_of_tri, hipStream_t s) {
+    if (total) ST_KLAUNCH(k_bvh_bake, dim3((total + 255u) / 256u), dim3(256), s, static_cast<const BakeJobDevice*>(jobs), job_start, n_jobs, total, mesh, tri_geo, tri_bounds, tri_attr, bvh, entry_of_tri);
+}
+
 void launch_bvh_patch_leaves(float4* bvh, const float4* tri_geo, const uint32_t* entry_of_tri, uint32_t lo, uint32_t hi, hipStream_t s) {
     if (hi > lo) ST_KLAUNCH(k_bvh_patch_leaves, dim3((hi - lo + 255u) / 256u), dim3(256), s, bvh, tri_geo, entry_of_tri, lo, hi);
 }

@@ -38,9 +38,10 @@ int st_mesh_insert(StEngine* e, StHandle id, const StMeshTriangle* t, size_t cou
     ST_REQUIRE(e && (t || count == 0), "null argument");
     if (count == 0) return fail(ST_ERR_EMPTY_MESH, "mesh contains no triangles");
     E(e)->meshes[id].assign(t, t + count);
+    E(e)->mesh_version[id] = E(e)->next_mesh_version++;   // an instance baked from the earlier mesh of this handle is re-baked by the host
     return ST_OK;
 }
-int st_mesh_remove(StEngine* e, StHandle id) { ST_REQUIRE(e, "null engine"); E(e)->meshes.erase(id); return ST_OK; }
+int st_mesh_remove(StEngine* e, StHandle id) { ST_REQUIRE(e, "null engine"); E(e)->meshes.erase(id); E(e)->mesh_version.erase(id); return ST_OK; }
 
 int st_material_insert(StEngine* e, StHandle id, const StMaterial* m) {
     ST_REQUIRE(e && m, "null argument");
@@ -154,7 +155,7 @@ int st_instance_remove(StEngine* e, StHandle id) {
     ST_REQUIRE(e, "null engine");
     Engine* en = E(e);
     for (size_t i = 0; i < en->instances.size(); i++)
-        if (en->instances[i].id == id) { en->xslot_free.push_back(en->instances[i].xslot); en->instances.erase(en->instances.begin() + i); en->instances_dirty = true; break; }
+        if (en->instances[i].id == id) { en->xslot_free.push_back(en->instances[i].xslot); en->instances.erase(en->instances.begin() + i); en->instances_dirty = true; en->instance_removed = true; break; }
     en->drop_instance_triangles(id);
     return ST_OK;
 }
@@ -364,6 +365,7 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
     ST_REQUIRE(e, "null engine");
     Engine* en = E(e);
     const void* p; size_t bytes;
+    if ((what == 0 || what == 1 || what == 4 || (what >= 7 && what <= 13)) && en->any_host_stale()) en->bake_stale_on_host();   // instances the device moved: the host arrays catch up
     if ((what == 0 || what == 4) && en->host_stream_stale) { en->refit_stream(); en->host_stream_stale = false; }  // device refits since the host copy was current
     switch (what) {
         case 0: p = en->bvh_stream.data(); bytes = en->bvh_stream.size() * sizeof(float4); break;
@@ -424,6 +426,11 @@ int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits) {
 int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits) {
     ST_REQUIRE(e && device_refits, "null argument");
     *device_refits = E(e)->device_refits;
+    return ST_OK;
+}
+int st_debug_device_bakes(StEngine* e, uint64_t* ticks, uint64_t* triangles) {
+    ST_REQUIRE(e && ticks && triangles, "null argument");
+    *ticks = E(e)->device_bakes; *triangles = E(e)->device_baked_triangles;
     return ST_OK;
 }
 int st_debug_bvh_refresh(StEngine* e, uint64_t* primitives, uint64_t* reused) {

@@ -321,9 +321,27 @@ struct Engine {
 
     // meshes / materials / instances / triangles
     std::unordered_map<uint64_t, std::vector<StMeshTriangle>> meshes;
+    // Device bake (StTuning::device_bake; k_bvh.hip k_bvh_bake): object-space meshes live on the device too (24 floats per triangle, appended
+    // when an instance of the mesh is first moved on the device; a re-inserted mesh is a new version and is appended again).
+    std::unordered_map<uint64_t, uint64_t> mesh_version; uint64_t next_mesh_version = 1;
+    struct DeviceMeshRec { size_t first, count; uint64_t version; };
+    std::unordered_map<uint64_t, DeviceMeshRec> device_meshes;
+    std::vector<float> mesh_store_host; DeviceArray d_mesh_store; size_t mesh_store_uploaded = 0;   // floats
+    bool moved_on_device = false;      // this tick's refresh left the moved instances to the device
+    bool materials_changed_this_tick = false;
+    bool instance_removed = false;     // since the last refresh: the set of triangle slots changed, the tree will be rebuilt
+    uint64_t device_bakes = 0, device_baked_triangles = 0;
+    bool any_host_stale() const { for (const auto& i : instances) if (i.host_stale) return true; return false; }
+    void bake_stale_on_host();         // brings the host arrays up to date (rebuilds, host refits, full uploads and debug reads need them)
+
     std::vector<StMaterial> materials; std::unordered_map<uint64_t, uint32_t> material_slot; SlotRanges material_free; bool materials_dirty = false;
     std::vector<GpuMaterial> gpu_materials; std::vector<uint32_t> material_base_packed;
-    struct InstanceRec { uint64_t id, mesh, material; Affine xform, xform_inv, prev_xform; bool dirty; uint32_t xslot; };
+    struct InstanceRec {
+        uint64_t id, mesh, material; Affine xform, xform_inv, prev_xform; bool dirty; uint32_t xslot;
+        // what the triangle slots of this instance were baked from (device bake: a later change of the transform alone can be baked on the device)
+        uint64_t baked_mesh = 0, baked_mesh_version = 0; uint32_t baked_material = 0xffffffffu; bool baked = false;
+        bool host_stale = false;   // moved on the device since the host arrays (triangles, prims, tri_geo / attr / bounds) were last baked
+    };
     std::vector<InstanceRec> instances; bool instances_dirty = false;
     // per-instance transforms for primary visibility's prev_point (the reference's per-draw push constants,
     // passes/prim_raster.rs:196-230): 8 float4 per stable slot — curr_xform_inv (x, y, z axes, translation), then prev_xform.
@@ -401,6 +419,8 @@ struct Engine {
         DeviceArray tri_geo, tri_bounds, entry_of_tri, parent, refit_local, refit_items, refit_batch_off;
         uint64_t tree_version = 0;
         size_t dirty_lo = SIZE_MAX, dirty_hi = 0; bool tri_full = true;  // what this copy lacks of the host's triangle arrays
+        std::vector<uint64_t> pending_moves;   // instances moved on the device whose current transform this copy has not baked yet
+        DeviceArray bake_jobs, bake_starts;
         hipEvent_t free_ev = nullptr; bool busy = false;  // busy: frames reading this copy were enqueued since it was written; free_ev ends the last
         bool valid = false;
     };
@@ -463,6 +483,8 @@ struct Engine {
     void bake(const StMeshTriangle& t, const InstanceRec& inst, uint32_t material, size_t slot);
     struct BakeJob { const std::vector<StMeshTriangle>* mesh; const InstanceRec* inst; uint32_t material; size_t first, count; };
     bool refresh_instances();
+    void bake_jobs_on_host(const std::vector<BakeJob>& jobs, size_t total);
+    int bake_on_device(SceneSet& t, hipStream_t up, bool* pageable);
 
     uint64_t topology_of(const std::vector<uint8_t>& blend) const;
     void index_stream();

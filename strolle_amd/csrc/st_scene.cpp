@@ -127,9 +127,82 @@ void Engine::bake(const StMeshTriangle& t, const InstanceRec& inst, uint32_t mat
     tri_attr[4 * slot + 3] = make_float4(t.uvs[1][1], t.uvs[2][0], t.uvs[2][1], b2f(inst.xslot));
 }
 
+// Baking (instances.rs:100-139) writes disjoint slots and reads nothing it writes, so once every range is assigned — the arrays
+// do not move any more — large refreshes are spread over the BVH builder's worker pool in chunks.
+void Engine::bake_jobs_on_host(const std::vector<BakeJob>& jobs, size_t total) {
+    const auto tb0 = std::chrono::steady_clock::now();
+    constexpr size_t kChunk = 2048, kParallelFrom = 16384;
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads > 16u) threads = 16u;
+    if (total < kParallelFrom || threads < 2u) {
+        for (const BakeJob& j : jobs)
+            for (size_t i = 0; i < j.count; i++) bake((*j.mesh)[i], *j.inst, j.material, j.first + i);
+    } else {
+        TaskPool pool(threads);
+        for (const BakeJob& j : jobs)
+            for (size_t at = 0; at < j.count; at += kChunk) {
+                const size_t end = std::min(j.count, at + kChunk);
+                pool.push([this, j, at, end] { for (size_t i = at; i < end; i++) bake((*j.mesh)[i], *j.inst, j.material, j.first + i); });
+            }
+        pool.finish();
+    }
+    if (tuning.tick_timing) fprintf(stderr, "[bake] %zu triangles in %zu jobs: %.2f ms\n", total, jobs.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
+}
+
+// Instances the device has moved (StTuning::device_bake) are baked on the host only when the host arrays are needed again: a rebuild
+// (its primitives), a host refit or a debug read of the stream (tri_bounds), a full upload. Both device copies then receive those slots from
+// the host like any other baked range, and their lists of pending device moves are void.
+void Engine::bake_stale_on_host() {
+    std::vector<BakeJob> jobs; size_t total = 0;
+    for (auto& inst : instances) {
+        if (!inst.host_stale) continue;
+        inst.host_stale = false;
+        auto mesh = meshes.find(inst.mesh);
+        auto have = instance_triangles.find(inst.id);
+        if (mesh == meshes.end() || have == instance_triangles.end() || have->second.second - have->second.first != mesh->second.size()) continue;  // the next refresh re-bakes it as dirty
+        jobs.push_back({&mesh->second, &inst, inst.baked_material, have->second.first, mesh->second.size()});
+        total += mesh->second.size();
+        for (SceneSet& t : sets) { t.dirty_lo = std::min(t.dirty_lo, have->second.first); t.dirty_hi = std::max(t.dirty_hi, have->second.second); }
+    }
+    for (SceneSet& t : sets) t.pending_moves.clear();
+    if (!jobs.empty()) bake_jobs_on_host(jobs, total);
+}
+
 bool Engine::refresh_instances() {
+    moved_on_device = false;
     if (!instances_dirty) return false;
     instances_dirty = false;
+    // Device bake: when every dirty instance only MOVED — same mesh (and version of it), same material, its slots already assigned —
+    // under ST_BVH_REFIT_DEVICE with the tree's topology on record, the host bakes nothing: the device copies do (Engine::bake_on_device).
+    const bool removed = instance_removed; instance_removed = false;
+    if (tuning.device_bake && device_refit_possible() && have_topology && !materials_changed_this_tick && !removed) {
+        bool only_moves = true; size_t moved = 0;
+        for (const auto& inst : instances) {
+            if (!inst.dirty) continue;
+            moved++;
+            auto mv = mesh_version.find(inst.mesh);
+            auto mat = material_slot.find(inst.material);
+            auto have = instance_triangles.find(inst.id);
+            auto mesh = meshes.find(inst.mesh);
+            if (!inst.baked || mv == mesh_version.end() || mat == material_slot.end() || have == instance_triangles.end() || mesh == meshes.end() ||
+                inst.baked_mesh != inst.mesh || inst.baked_mesh_version != mv->second || inst.baked_material != mat->second ||
+                have->second.second - have->second.first != mesh->second.size()) { only_moves = false; break; }
+        }
+        if (only_moves && moved) {
+            for (auto& inst : instances) {
+                if (!inst.dirty) continue;
+                inst.dirty = false; inst.host_stale = true;
+                for (SceneSet& t : sets) if (std::find(t.pending_moves.begin(), t.pending_moves.end(), inst.id) == t.pending_moves.end()) t.pending_moves.push_back(inst.id);
+            }
+            moved_on_device = true;
+            return true;
+        }
+    }
+    // the host bakes this refresh: instances the device moved earlier and that are not dirty now must catch up first (a rebuild reads every primitive)
+    if (any_host_stale()) {
+        for (auto& inst : instances) if (inst.host_stale && inst.dirty) inst.host_stale = false;   // re-baked below anyway
+        bake_stale_on_host();
+    }
     std::vector<BakeJob> jobs; size_t total = 0;
     {   // one reallocation at most for everything this refresh appends (a scene load appends every instance)
         size_t fresh = 0;
@@ -163,27 +236,67 @@ bool Engine::refresh_instances() {
         total += count;
         for (SceneSet& t : sets) { t.dirty_lo = std::min(t.dirty_lo, b); t.dirty_hi = std::max(t.dirty_hi, e); }  // slots each device copy still has to receive
         instance_triangles[inst.id] = {b, e};
+        auto mv = mesh_version.find(inst.mesh);
+        inst.baked = true; inst.baked_mesh = inst.mesh; inst.baked_mesh_version = mv == mesh_version.end() ? 0 : mv->second; inst.baked_material = mat->second; inst.host_stale = false;
     }
-    // Baking (instances.rs:100-139) writes disjoint slots and reads nothing it writes, so once every range is assigned —
-    // the arrays do not move any more — large refreshes are spread over the BVH builder's worker pool in chunks.
-    const auto tb0 = std::chrono::steady_clock::now();
-    constexpr size_t kChunk = 2048, kParallelFrom = 16384;
-    unsigned threads = std::thread::hardware_concurrency();
-    if (threads > 16u) threads = 16u;
-    if (total < kParallelFrom || threads < 2u) {
-        for (const BakeJob& j : jobs)
-            for (size_t i = 0; i < j.count; i++) bake((*j.mesh)[i], *j.inst, j.material, j.first + i);
-    } else {
-        TaskPool pool(threads);
-        for (const BakeJob& j : jobs)
-            for (size_t at = 0; at < j.count; at += kChunk) {
-                const size_t end = std::min(j.count, at + kChunk);
-                pool.push([this, j, at, end] { for (size_t i = at; i < end; i++) bake((*j.mesh)[i], *j.inst, j.material, j.first + i); });
-            }
-        pool.finish();
-    }
-    if (tuning.tick_timing) fprintf(stderr, "[bake] %zu triangles in %zu jobs: %.2f ms\n", total, jobs.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
+    bake_jobs_on_host(jobs, total);
     return true;
+}
+
+// The device half of a tick whose instances only moved: object-space meshes this copy's pending instances need (appended to the
+// device mesh store once), one 128-B job per instance with its CURRENT transform, one launch of k_bvh_bake (which also patches the
+// leaf entries). PCIe per tick: 128 B + 4 B per moved instance (and the instance-transform table st_tick sends anyway).
+int Engine::bake_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
+    if (t.pending_moves.empty()) return ST_OK;
+    std::unordered_map<uint64_t, const InstanceRec*> by_id;
+    for (const auto& inst : instances) by_id[inst.id] = &inst;
+    struct Job { float4 x, y, z, t, r0, r1, r2; uint32_t mesh_first, count, slot_first, xslot; };
+    static_assert(sizeof(Job) == 128, "k_bvh.hip BakeJobDevice");
+    std::vector<Job> jobs; std::vector<uint32_t> starts{0u};
+    bool store_grew = false;
+    for (uint64_t id : t.pending_moves) {
+        auto it = by_id.find(id);
+        if (it == by_id.end()) continue;   // removed since: that tick rebuilt the tree and voided the lists
+        const InstanceRec& inst = *it->second;
+        auto have = instance_triangles.find(id);
+        auto mesh = meshes.find(inst.mesh);
+        if (have == instance_triangles.end() || mesh == meshes.end()) continue;
+        auto dm = device_meshes.find(inst.mesh);
+        if (dm == device_meshes.end() || dm->second.version != inst.baked_mesh_version) {
+            DeviceMeshRec rec{mesh_store_host.size() / 24u, mesh->second.size(), inst.baked_mesh_version};
+            mesh_store_host.reserve(mesh_store_host.size() + 24u * rec.count);
+            for (const StMeshTriangle& m : mesh->second) {
+                for (int v = 0; v < 3; v++) for (int c = 0; c < 3; c++) mesh_store_host.push_back(m.positions[v][c]);
+                for (int v = 0; v < 3; v++) for (int c = 0; c < 3; c++) mesh_store_host.push_back(m.normals[v][c]);
+                for (int v = 0; v < 3; v++) for (int c = 0; c < 2; c++) mesh_store_host.push_back(m.uvs[v][c]);
+            }
+            device_meshes[inst.mesh] = rec; dm = device_meshes.find(inst.mesh); store_grew = true;
+        }
+        const Affine& inv = inst.xform_inv;
+        Job j;
+        j.x = f4(inst.xform.x, 0.0f); j.y = f4(inst.xform.y, 0.0f); j.z = f4(inst.xform.z, 0.0f); j.t = f4(inst.xform.t, 0.0f);
+        j.r0 = make_float4(inv.x.x, inv.y.x, inv.z.x, 0.0f); j.r1 = make_float4(inv.x.y, inv.y.y, inv.z.y, 0.0f); j.r2 = make_float4(inv.x.z, inv.y.z, inv.z.z, 0.0f);
+        j.mesh_first = (uint32_t)dm->second.first; j.count = (uint32_t)dm->second.count; j.slot_first = (uint32_t)have->second.first; j.xslot = inst.xslot;
+        jobs.push_back(j); starts.push_back(starts.back() + j.count);
+    }
+    t.pending_moves.clear();
+    if (jobs.empty()) return ST_OK;
+    int rc;
+    if (store_grew) {
+        const size_t bytes = mesh_store_host.size() * sizeof(float);
+        if (bytes > d_mesh_store.capacity) {   // a new allocation: everything again (hipFree waits for the kernels that read the old one)
+            if ((rc = d_mesh_store.upload(mesh_store_host.data(), bytes, up, staging, pageable))) return rc;
+        } else if ((rc = d_mesh_store.upload_range(mesh_store_host.data(), mesh_store_uploaded * sizeof(float), (mesh_store_host.size() - mesh_store_uploaded) * sizeof(float), up, staging, pageable))) return rc;
+        mesh_store_uploaded = mesh_store_host.size();
+    }
+    if ((rc = t.bake_jobs.upload(jobs.data(), jobs.size() * sizeof(Job), up, staging, pageable))) return rc;
+    if ((rc = t.bake_starts.upload(starts.data(), starts.size() * sizeof(uint32_t), up, staging, pageable))) return rc;
+    // the EXACT build's kernel, whatever arithmetic the frames use: the baked arrays are the host's bits
+    launchers_exact().launch_bvh_bake(t.bake_jobs.ptr, static_cast<const uint32_t*>(t.bake_starts.ptr), (uint32_t)jobs.size(), starts.back(), static_cast<const float*>(d_mesh_store.ptr),
+                                      static_cast<float4*>(t.tri_geo.ptr), static_cast<float4*>(t.tri_bounds.ptr), static_cast<float4*>(t.tri_attr.ptr), static_cast<float4*>(t.bvh.ptr),
+                                      static_cast<const uint32_t*>(t.entry_of_tri.ptr), up);
+    device_bakes++; device_baked_triangles += starts.back();
+    return ST_OK;
 }
 
 }  // namespace st

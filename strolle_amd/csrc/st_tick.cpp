@@ -6,6 +6,7 @@ namespace st {
 // ---- tick (lib.rs:301-395)
 int Engine::tick(hipStream_t stream) {
     bool scene_changed = false;
+    materials_changed_this_tick = materials_dirty || atlas_dirty;   // a Blend flag may have changed: the tree's topology signature has to be looked at
     if (materials_dirty || atlas_dirty) { materials_dirty = false; rebuild_gpu_materials(); scene_changed = true; }
     const bool timing = tuning.tick_timing;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -21,7 +22,8 @@ int Engine::tick(hipStream_t stream) {
         std::vector<uint8_t> blend(materials.size());
         for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
         const bool refitting = bvh_refresh_mode != ST_BVH_REBUILD;
-        const uint64_t signature = refitting ? topology_of(blend) : 0;
+        // (moved_on_device: refresh_instances saw nothing but transforms change — slots, materials and Blend flags are what the last build saw)
+        const uint64_t signature = moved_on_device ? topology_signature : (refitting ? topology_of(blend) : 0);
         if (refitting && have_topology && signature == topology_signature) {
             // ST_BVH_REFIT_DEVICE: the boxes are recomputed on the device from the moved triangles' bounds (k_bvh.hip); the host's
             // copy of the stream is brought up to date only when something reads it
@@ -88,14 +90,26 @@ int Engine::tick(hipStream_t stream) {
                 if (sets[target].busy) { ST_HIP(hipStreamWaitEvent(copy_stream, sets[target].free_ev, 0)); sets[target].busy = false; }
             } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
             SceneSet& t = sets[target];
-            if (device_refit_possible() && t.valid && !t.tri_full && t.tree_version == tree_version && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4)) {
+            bool attr_sent = false;
+            const bool device_path = device_refit_possible() && t.valid && !t.tri_full && t.tree_version == tree_version && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4);
+            // a copy that cannot be brought up to date in place is sent whole, from the host's arrays: instances the device moved must be in them
+            if (!device_path && any_host_stale()) bake_stale_on_host();
+            if (device_path) {
                 // This copy holds the current tree; only boxes and moved triangles are behind. Send the records and bounds of the
                 // triangle slots baked since it was written and let the device patch its leaf entries and refit its boxes.
                 if (t.dirty_lo < t.dirty_hi) {
                     if ((rc = t.tri_geo.upload_range(tri_geo.data(), 3 * t.dirty_lo * sizeof(float4), 3 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
                     if ((rc = t.tri_bounds.upload_range(tri_bounds.data(), 2 * t.dirty_lo * sizeof(float4), 2 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
                     L.launch_bvh_patch_leaves(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_geo.ptr), static_cast<const uint32_t*>(t.entry_of_tri.ptr), (uint32_t)t.dirty_lo, (uint32_t)t.dirty_hi, up);
+                    // (their attribute records too, BEFORE the device bake below: an instance the host baked a tick ago and the device moves now must end with the device's)
+                    if (t.tri_attr.capacity >= tri_attr.size() * sizeof(float4)) {
+                        if ((rc = t.tri_attr.upload_range(tri_attr.data(), 4 * t.dirty_lo * sizeof(float4), 4 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
+                        attr_sent = true;
+                    }
                 }
+                // instances that only moved are baked HERE, from the object-space meshes (StTuning::device_bake; k_bvh.hip k_bvh_bake): this copy's
+                // hit-test records (+ leaf entries), bounds and attribute records of every instance it has not followed yet
+                if ((rc = bake_on_device(t, up, flag))) return rc;
                 for (const auto& level : refit_levels_)   // this copy holds the current tree, so the engine's work list is its own
                     L.launch_bvh_refit(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_bounds.ptr), static_cast<const uint32_t*>(t.parent.ptr), static_cast<const uint32_t*>(t.refit_local.ptr),
                                        static_cast<const uint32_t*>(t.refit_items.ptr), static_cast<const uint32_t*>(t.refit_batch_off.ptr), level.first, level.second, up);
@@ -122,7 +136,7 @@ int Engine::tick(hipStream_t stream) {
             const bool partial = t.valid && !t.tri_full && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
             if (!partial) {
                 if ((rc = t.tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), up, staging, flag))) return rc;
-            } else if (t.dirty_lo < t.dirty_hi) {
+            } else if (t.dirty_lo < t.dirty_hi && !attr_sent) {
                 if ((rc = t.tri_attr.upload_range(tri_attr.data(), 4 * t.dirty_lo * sizeof(float4), 4 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;
             }
             t.dirty_lo = SIZE_MAX; t.dirty_hi = 0; t.tri_full = false; t.valid = true;

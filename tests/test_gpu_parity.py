@@ -776,6 +776,10 @@ def test_bvh_refit_mode_renders_bit_exact(mode):
             assert_bits_equal(prod.read_scene(0), orac.read_scene(0), f"refit frame {frame}: the host's (lazily refitted) stream vs the oracle's")
     assert prod.bvh_refits() == orac.bvh_refits() == (2, 6)
     assert prod.bvh_device_refits() == (4 if mode == 2 else 0)   # refit ticks whose target copy already held the tree (the first refit after a build goes to the other copy in full)
+    if mode == 2:   # StTuning::device_bake (default on): those same ticks baked the moved instances ON THE DEVICE from their object-space meshes — the
+        # comparisons above (stream read back from the device, every plane of every frame) are therefore device bake vs host bake, bit for bit
+        launches, triangles = prod.device_bakes()
+        assert launches == 4 and triangles > 0
 
 
 @pytest.mark.gpu
@@ -799,6 +803,23 @@ def test_device_refit_of_the_dungeon_equals_the_host_refit():
         assert on_device.size > 4 * 60_000
         assert_bits_equal(on_device, on_host, f"tick {tick}: the stream on the device vs the host's refit")
     assert e.bvh_refits() == (1, 5) and e.bvh_device_refits() == 4
+    launches, triangles = e.device_bakes()
+    assert launches == 4 and triangles >= 3 * 33_000, (launches, triangles)   # every instance of the 52 k-triangle level on three of the four device ticks
+    # ... and with the device bake switched off the same sequence gives the same stream (host bake + 80 B per triangle over PCIe)
+    h = Engine(device=0)
+    scenes.build_dungeon(h, subdivide=1)
+    h.set_tuning(device_bake=0)
+    h.set_bvh_refresh(2)
+    h.tick()
+    for tick in range(5):
+        for k in range(int(npz["n_meshes"])):
+            if tick == 3 and k % 3: continue
+            x = npz[f"xform_{k}"].reshape(4, 3).T.copy(); x[:3, 3] += 0.01 * (tick + 1) * np.array([1.0, -0.5, 0.25]) * (1 + k % 5)
+            h.insert_instance(1 + k, Instance(1 + k, 1 + int(npz[f"material_{k}"]), x))
+        h.tick()
+    assert h.device_bakes() == (0, 0)
+    assert_bits_equal(h.read_scene(6), e.read_scene(6), "device bake vs host bake: the stream on the device")
+    assert_bits_equal(h.read_scene(1), e.read_scene(1), "device bake vs host bake: the host's triangles once they caught up")
 
 
 def _cornell_glb() -> bytes:

@@ -12,11 +12,14 @@ ap.add_argument("--device", type=int, default=-1)
 ap.add_argument("--subdivide", type=int, default=0)
 ap.add_argument("--ticks", type=int, default=20)
 ap.add_argument("--refit", nargs="?", const=1, default=0, type=int, help="1 = ST_BVH_REFIT (boxes refitted on the host instead of a rebuild), 2 = ST_BVH_REFIT_DEVICE (refitted by k_bvh.hip)")
+ap.add_argument("--host-bake", action="store_true", help="StTuning::device_bake = 0: moved instances are baked on the host and sent (80 + 64 B per triangle)")
 ap.add_argument("--all", action="store_true", help="move every instance per tick, not just one (stress-bvh.rs: many bodies under physics)")
 args = ap.parse_args()
 e = Engine(device=args.device)
 scenes.build_dungeon(e, subdivide=args.subdivide)
 e.set_bvh_refresh(args.refit)
+if args.host_bake:
+    e.set_tuning(device_bake=0)
 e.tick()
 npz = np.load(os.path.join(scenes.ASSETS, "dungeon.npz"))
 base = npz["xform_0"].reshape(4, 3).T.copy()
@@ -27,5 +30,6 @@ for i in range(args.ticks):
         x = npz[f"xform_{k}"].reshape(4, 3).T.copy(); x[0, 3] += 0.001 * (i + 1)
         e.insert_instance(1 + k, Instance(1 + k, 1 + int(npz[f"material_{k}"]), x))
     t = time.perf_counter(); e.tick(); ts.append(time.perf_counter() - t)
+bakes = e.device_bakes() if args.device >= 0 else (0, 0)
 tris = e.read_scene(1).nbytes // 144
-print(f"device={args.device} triangles={tris} refit={args.refit} (rebuilds, refits)={e.bvh_refits()}: tick with {'every' if args.all else 'one'} instance moved: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms")
+print(f"device={args.device} triangles={tris} refit={args.refit} (rebuilds, refits)={e.bvh_refits()}: tick with {'every' if args.all else 'one'} instance moved: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms; device bakes {bakes[0]} ({bakes[1]} triangles)")
