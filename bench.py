@@ -10,8 +10,9 @@ Scene, buffers and temporal state are resident in HBM before the timed region; t
 The kernels run in the library's default (fast-arithmetic) build; --exact selects the bit-exact build.
 
 N > 1, --scaling weak (default): the frame grows to N x (width x height) pixels (N=4 is BASELINE.json's 3840x2160 4-tile
-config), each rank renders one row band (+ apron) and the bands are gathered to rank 0 every frame (the only collective).
---scaling strong: the frame stays width x height and is split into N row bands — BASELINE.json configs 4 and 5 as written:
+config), each rank renders one tile of st_dist_partition's grid (2 ranks: row bands, 4: 2 x 2, 8: 4 x 2) + an apron, and the tiles
+are gathered to rank 0 every frame — the only collective, st_dist_gather: RCCL through the C ABI (--py-gather: torch.distributed).
+--scaling strong: the frame stays width x height and is split into N tiles — BASELINE.json configs 4 and 5 as written:
   ... bench.py --gpus 4 --scaling strong --width 3840 --height 2160 --scene cornell --mode reference     (config 4)
   ... bench.py --gpus 8 --scaling strong --width 3840 --height 2160 --scene dungeon --mode image         (config 5; N = 1, 2, 4, 8)
 Extra regions, all in the same ONE JSON line (none of them changes `value` / `ms_per_step`, which stay the static headline):
@@ -21,8 +22,8 @@ Extra regions, all in the same ONE JSON line (none of them changes `value` / `ms
                              `present` — the same K steps through the facade's present path (RGBA8 target, two buffers,
                              st_camera_present_copy to page-locked host memory, previous frame polled: `ms_per_step_with_present`).
   N > 1:                     `multi_gpu.strong_config5` — BASELINE.json config 5 as written (dungeon 3840x2160 Image, ONE frame split
-                             into N row bands + apron, gathered to rank 0), whatever --scaling the main region used; N = 4 also runs
-                             config 4 (Cornell 3840x2160 Reference, 4 bands) as `multi_gpu.strong_config4`.
+                             into N tiles + apron, gathered to rank 0), whatever --scaling the main region used; N = 4 also runs
+                             config 4 (Cornell 3840x2160 Reference, 2 x 2 tiles) as `multi_gpu.strong_config4`.
   --no-extras skips them.
 Rank 0 prints ONE JSON line.
 """
@@ -162,24 +163,21 @@ def n1_reference(key):
         return None
 
 
-def apron_overhead(height, world, apron):
-    """Redundant rows a rank renders around its band (windows are kept on 8-row tile boundaries), as a fraction of the band:
-    the largest over the ranks (an interior band) and the mean."""
-    from strolle_amd.distributed import band_for_rank, render_window
-    fr = []
-    for r in range(world):
-        b = band_for_rank(height, world, r); w = render_window(height, b, apron)
-        fr.append((w[1] - w[0]) / (b[1] - b[0]) - 1.0)
-    return {"max": round(max(fr), 4), "mean": round(sum(fr) / len(fr), 4)}
+def apron_overhead(width, height, world, apron, cols=0):
+    """Redundant pixels a rank renders around its tile (windows sit on the partition's 16 x 8 pixel grid), as a fraction of the tile:
+    the largest over the ranks and the mean."""
+    from strolle_amd.distributed import tile_overhead
+    mx, mean = tile_overhead(width, height, world, apron, cols)
+    return {"max": round(mx, 4), "mean": round(mean, 4)}
 
 
 class Job:
-    """One camera of one scene on this rank: engine, row band (+ apron), double-buffered render targets and the per-frame
-    gather of the bands to rank 0 on a communication stream."""
+    """One camera of one scene on this rank: engine, tile (+ apron), double-buffered render targets and the per-frame
+    gather of the tiles to rank 0 on a communication stream."""
 
     def __init__(self, torch, dist, args, scene, mode_name, size, world, rank, local_rank, debug_shared):
         from strolle_amd import CameraMode, Engine, scenes
-        from strolle_amd.distributed import band_for_rank, render_window
+        from strolle_amd.distributed import tile_for_rank, tile_window
         self.torch, self.dist, self.world, self.rank, self.debug_shared = torch, dist, world, rank, debug_shared
         self.scenes = scenes
         self.scene, self.mode_name = scene, mode_name
@@ -195,13 +193,27 @@ class Job:
         self.mode = mode
         self.engine.set_seed(args.seed)
         self.cam = self.engine.create_camera(self.desc)
-        self.band = band_for_rank(self.height, world, rank)
-        self.window = (0, self.height)
+        # the partition: st_dist_partition's tiles (2 ranks: row bands, 4: 2 x 2, 8: 4 x 2 — BASELINE.json's "4-tile" / "8-tile split"),
+        # each rank rendering its tile + an apron of redundant pixels in the modes whose passes read neighbours
+        self.cols = args.cols
+        self.tile = tile_for_rank(self.width, self.height, world, rank, self.cols)
+        self.band = (self.tile[1], self.tile[3])
+        self.window = (0, 0, self.width, self.height)
         self.needs_apron = mode_name in ("image", "gi_diffuse")   # Reference / heatmap pixels read nothing but their own
         self.apron = (args.apron if self.needs_apron else 0) if world > 1 else 0
+        self.c_abi_gather = world > 1 and not debug_shared and not args.py_gather
         if world > 1:
-            self.window = render_window(self.height, self.band, self.apron)
-            self.engine.set_camera_rows(self.cam, *self.window)
+            if self.c_abi_gather:
+                # the product path: RCCL through the C ABI (st_dist_*). The id travels over torch.distributed's store — plumbing, like the barrier
+                from strolle_amd.api import dist_unique_id
+                uid = [dist_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                self.engine.dist_init(rank, world, uid[0])
+                owned, self.window = self.engine.dist_set_partition(self.cam, cols=self.cols, apron=self.apron)
+                assert owned == self.tile
+            else:
+                self.window = tile_window(self.width, self.height, self.tile, self.apron)
+                self.engine.set_camera_window(self.cam, *self.window)
         self.dev = f"cuda:{local_rank}"
         # double-buffered render targets: frame i is gathered on `comm` while frame i+1 renders on `main`
         self.outs = [torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=self.dev) for _ in range(2 if world > 1 else 1)]
@@ -244,7 +256,12 @@ class Job:
         self.engine.render_camera(self.cam, out.data_ptr(), self.stream)
         if world == 1:
             return out
-        from strolle_amd.distributed import gather_bands_to_root
+        if self.c_abi_gather:
+            # st_dist_gather: grouped ncclSend / ncclRecv of the tiles on the engine's communication stream, behind this frame, under the next
+            # (rendering into outs[k] again is ordered behind its gather by the engine)
+            self.engine.dist_gather(self.cam, out.data_ptr(), self.full.data_ptr() if rank == 0 else 0, self.stream)
+            return self.full if rank == 0 else out
+        from strolle_amd.distributed import gather_tiles_to_root
         rendered = torch.cuda.Event(); rendered.record(self.main)
         self.comm.wait_event(rendered)
         with torch.cuda.stream(self.comm):
@@ -252,11 +269,11 @@ class Job:
             if self.debug_shared:
                 self.comm.synchronize()
                 host_full = torch.zeros((self.height, self.width, 4)) if rank == 0 else None
-                gather_bands_to_root(out.cpu(), host_full, self.height, world, rank)
+                gather_tiles_to_root(out.cpu(), host_full, world, rank, self.cols)
                 if rank == 0:
                     self.full.copy_(host_full)
             else:
-                gather_bands_to_root(out, self.full, self.height, world, rank)   # the only collective: bands -> rank 0 over RCCL
+                gather_tiles_to_root(out, self.full, world, rank, self.cols)   # --py-gather: the torch.distributed fallback
             done = torch.cuda.Event(enable_timing=True); done.record(self.comm)
         self.gather_events.append((g0, done))
         self.gathered[k] = done
@@ -283,8 +300,9 @@ class Job:
         return time.perf_counter() - t0, f
 
     def counted_rays(self):
-        """rays of this rank's OWN band: apron rows are redundant work and not counted"""
-        return self.engine.ray_count(self.cam) * (self.band[1] - self.band[0]) / (self.window[1] - self.window[0])
+        """rays of this rank's OWN tile: apron pixels are redundant work and not counted"""
+        own = (self.tile[2] - self.tile[0]) * (self.tile[3] - self.tile[1])
+        return self.engine.ray_count(self.cam) * own / ((self.window[2] - self.window[0]) * (self.window[3] - self.window[1]))
 
     def reduce(self, elapsed, rays):
         """max over ranks of the time, sum of the rays, every rank's ms per step"""
@@ -300,8 +318,16 @@ class Job:
         return float(tmax[0]), float(tsum[1]), [float(x[0]) for x in each]
 
     def gather_ms(self):
+        if self.c_abi_gather:
+            return self.engine.dist_gather_ms(self.cam)   # the last gather on the engine's communication stream (HIP events there)
         ev = self.gather_events
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
+
+    def gathered_bytes(self):
+        """what arrives at rank 0 per frame: every tile but its own"""
+        from strolle_amd.distributed import tile_for_rank
+        t0 = tile_for_rank(self.width, self.height, self.world, 0, self.cols)
+        return (self.width * self.height - (t0[2] - t0[0]) * (t0[3] - t0[1])) * 16
 
     def close(self):
         self.torch.cuda.synchronize()
@@ -320,13 +346,14 @@ def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scen
     elapsed, frame = job.timed_region(steps)
     elapsed, rays_total, per_rank = job.reduce(elapsed, job.counted_rays())
     finite = bool(torch.isfinite(frame).all())
-    out = {"workload": f"{scene} {size[0]}x{size[1]} mode {mode_name}, strong: one frame in {world} row bands, gathered to rank 0",
+    out = {"workload": f"{scene} {size[0]}x{size[1]} mode {mode_name}, strong: one frame in {world} tiles (st_dist_partition), gathered to rank 0",
            "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4), "Mray_per_s": round(rays_total / elapsed / 1e6, 2),
            "per_rank_ms": None if per_rank is None else [round(x / steps * 1e3, 4) for x in per_rank],
            "gather_ms": None if job.gather_ms() is None else round(job.gather_ms(), 4),
-           "gathered_bytes_per_frame": (job.height - (job.band[1] - job.band[0])) * job.width * 16,
-           "band_rows": job.band[1] - job.band[0], "apron_rows": job.apron,
-           "apron_overhead_frac": apron_overhead(job.height, world, job.apron),
+           "gathered_bytes_per_frame": job.gathered_bytes(),
+           "tile": [job.tile[2] - job.tile[0], job.tile[3] - job.tile[1]], "band_rows": job.band[1] - job.band[0], "apron_rows": job.apron,
+           "gather": "st_dist_gather (RCCL through the C ABI)" if job.c_abi_gather else "torch.distributed fallback",
+           "apron_overhead_frac": apron_overhead(job.width, job.height, world, job.apron, job.cols),
            "n1_ms_reference": n1_reference(key), "n1_ms_reference_source": "profiles/n1_reference.json (builder-run single-GPU figure, not measured by this process)",
            "frame_finite": finite}
     job.close()
@@ -347,7 +374,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--apron", type=int, default=16, help="extra rows rendered around a rank's band in Image mode (N > 1)")
+    ap.add_argument("--apron", type=int, default=16, help="extra pixels rendered around a rank's tile in Image mode (N > 1)")
+    ap.add_argument("--cols", type=int, default=0, help="N > 1: columns of the tile grid (0 = st_dist_partition's default: 2 ranks row bands, 4: 2 x 2, 8: 4 x 2; 1 = row bands)")
+    ap.add_argument("--py-gather", action="store_true", help="N > 1: gather through torch.distributed (the fallback) instead of st_dist_gather (RCCL through the C ABI)")
     ap.add_argument("--scene", choices=["cornell", "dungeon", "dungeon134k"], default="cornell",
                     help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene (level.glb + the demo's three tori); dungeon134k = the same surface subdivided twice (synthetic ~100k-triangle stand-in)")
     ap.add_argument("--mode", choices=["image", "gi_diffuse", "reference", "heatmap"], default="image")
@@ -363,7 +392,7 @@ def main():
     import torch
     import torch.distributed as dist
     from strolle_amd import CameraMode, Engine, scenes
-    from strolle_amd.distributed import band_for_rank, gather_bands_to_root, render_window, weak_scaling_frame
+    from strolle_amd.distributed import weak_scaling_frame
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -560,13 +589,14 @@ def main():
                        "per_gpu_rows": band[1] - band[0], "apron_rows": (args.apron if needs_apron else 0) if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
                        **({"DEBUG_NOT_A_RESULT": "ranks share cuda:0, gather through gloo + host copies"} if debug_shared else {}),
-                       "partition": "single GPU" if world == 1 else f"{world} row bands, per-frame RCCL gather of the RGBA32F bands to rank 0 overlapped with the next frame"},
+                       "partition": "single GPU" if world == 1 else f"{world} tiles of {job.tile[2] - job.tile[0]}x{job.tile[3] - job.tile[1]} (st_dist_partition), per-frame RCCL gather of the RGBA32F tiles to rank 0 overlapped with the next frame"},
         }
         if world > 1:
             result["multi_gpu"] = {"rccl_ranks": rccl_ranks, "backend": backend, "rccl_ranks_note": "sum of ones over an all-reduce on that backend before the first frame (nccl = RCCL on ROCm)",
                                    "per_rank_ms_per_step": per_rank_ms, "gather_ms_on_comm_stream_rank0": None if gather_ms is None else round(gather_ms, 4),
-                                   "gathered_bytes_per_frame": (height - (band[1] - band[0])) * width * 16,
-                                   "apron_overhead_frac": apron_overhead(height, world, job.apron),
+                                   "gathered_bytes_per_frame": job.gathered_bytes(), "tile": [job.tile[2] - job.tile[0], job.tile[3] - job.tile[1]],
+                                   "gather": "st_dist_gather (RCCL through the C ABI: grouped ncclSend / ncclRecv on the engine's communication stream)" if job.c_abi_gather else "torch.distributed fallback (gloo / --py-gather)",
+                                   "apron_overhead_frac": apron_overhead(width, height, world, job.apron, job.cols),
                                    "main_region": "weak scaling: NOT a BASELINE config for N > 1 (the frame grows with N); the BASELINE configs as written are strong_config5 / strong_config4 below" if args.scaling == "weak" else "strong scaling of --width x --height",
                                    "hardware_scaling_curve": "none measured by the builder (gpurun boxes have one GPU); whatever the driver's N = 1, 2, 4, 8 runs print is the first",
                                    **strong}

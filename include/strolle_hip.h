@@ -220,9 +220,12 @@ int st_dist_set_partition(StEngine* e, StHandle camera, uint32_t cols, uint32_t 
 /* `frame`: the buffer st_render_camera just composed into on `hip_stream` (full-frame sized, the camera's output format; this
  * rank's tile of it is what travels). `full_on_root`: where rank 0 assembles the frame (may be `frame` itself: its own tile is
  * then already in place); ignored on other ranks. Returns at once; the caller alternates two frame buffers so that frame N is
- * gathered while frame N+1 renders. st_dist_wait orders `hip_stream` behind the camera's last gather (host_wait != 0: blocks). */
+ * gathered while frame N+1 renders; st_render_camera into a buffer whose gather is still in flight is ordered behind that gather by the
+ * engine. st_dist_wait orders `hip_stream` behind the gather that read `frame` (NULL: every gather in flight); host_wait != 0 blocks
+ * the caller instead. st_dist_gather_ms: duration of the camera's last gather on the communication stream (blocks until it is through). */
 int st_dist_gather(StEngine* e, StHandle camera, const void* frame, void* full_on_root, void* hip_stream);
-int st_dist_wait(StEngine* e, StHandle camera, void* hip_stream, int host_wait);
+int st_dist_wait(StEngine* e, StHandle camera, const void* frame, void* hip_stream, int host_wait);
+int st_dist_gather_ms(StEngine* e, StHandle camera, float* ms);
 
 /* camera.rs:170-175 `viewport.format`: the reference renders into a texture view of that format and the hardware converts
  * on store; here the composition kernel does. RGBA32F (default, 16 B/pixel), RGBA16F (8 B, round to nearest even),

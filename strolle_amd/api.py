@@ -312,7 +312,8 @@ class _Binding:
             self.dist_init = fn("dist_init", [vp, i32, i32, P(StDistUniqueId)]); self.dist_init_local = fn("dist_init_local", [vp, i32, i32, u64])
             self.dist_shutdown = fn("dist_shutdown", [vp]); self.dist_rank = fn("dist_rank", [vp, P(i32), P(i32)])
             self.dist_set_partition = fn("dist_set_partition", [vp, u64, u32, u32, P(StDistRect), P(StDistRect)])
-            self.dist_gather = fn("dist_gather", [vp, u64, vp, vp, vp]); self.dist_wait = fn("dist_wait", [vp, u64, vp, i32])
+            self.dist_gather = fn("dist_gather", [vp, u64, vp, vp, vp]); self.dist_wait = fn("dist_wait", [vp, u64, vp, vp, i32])
+            self.dist_gather_ms = fn("dist_gather_ms", [vp, u64, P(C.c_float)])
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
         if has_device:
             self.camera_set_rows = fn("camera_set_rows", [vp, u64, u32, u32])
@@ -637,8 +638,14 @@ class Engine(EngineBase):
         """st_dist_gather: this rank's tile of `frame_ptr` travels to rank 0, which assembles the frame at `full_ptr`."""
         self._check(self._b.dist_gather(self._h, cam, frame_ptr, full_ptr or None, stream))
 
-    def dist_wait(self, cam: int, stream: int = 0, host: bool = True):
-        self._check(self._b.dist_wait(self._h, cam, stream, 1 if host else 0))
+    def dist_wait(self, cam: int, frame_ptr: int = 0, stream: int = 0, host: bool = True):
+        """st_dist_wait: behind the gather that read `frame_ptr` (0: every gather in flight); host=True blocks the caller."""
+        self._check(self._b.dist_wait(self._h, cam, frame_ptr or None, stream, 1 if host else 0))
+
+    def dist_gather_ms(self, cam: int) -> float:
+        out = C.c_float()
+        self._check(self._b.dist_gather_ms(self._h, cam, C.byref(out)))
+        return out.value
 
     def insert_device_image(self, handle: int, device_ptr: int, width: int, height: int, row_pitch_bytes: int = 0, dynamic: bool = False):
         """ImageData::Texture: RGBA8 pixels in device memory (e.g. `tensor.data_ptr()` of a [h, w, 4] uint8 CUDA tensor)."""

@@ -172,6 +172,7 @@ int st_camera_create(StEngine* e, const StCamera* c, StHandle* out) {
     const int rc = en->allocate_camera(*s);
     if (rc) return rc;
     *out = en->next_camera++;
+    s->handle = *out;
     en->cameras[*out] = std::move(s);
     return ST_OK;
 }

@@ -107,7 +107,11 @@ struct DistState {
     void* comm = nullptr;         // ncclComm_t
     uint64_t group = 0;           // local transport: which mailbox
     hipStream_t stream = nullptr; // the communication stream
-    struct CamPart { StDistRect owned{}, window{}; uint32_t cols = 0, apron = 0; hipEvent_t rendered = nullptr, done = nullptr; bool pending = false; void* staging = nullptr; size_t staging_bytes = 0; };
+    // `slots`: the gathers in flight, by the frame buffer they read (the caller alternates two): a render into a buffer whose gather has
+    // not finished is ordered behind it (Engine::dist_guard), st_dist_wait waits for one buffer's gather or for all.
+    struct Slot { const void* frame = nullptr; hipEvent_t done = nullptr, t0 = nullptr; bool pending = false; };
+    struct CamPart { StDistRect owned{}, window{}; uint32_t cols = 0, apron = 0; hipEvent_t rendered = nullptr; Slot slots[2]; uint32_t next = 0; int last = -1;
+                     void* staging = nullptr; size_t staging_bytes = 0; };
     std::map<uint64_t, CamPart> cams;
 };
 
@@ -122,7 +126,7 @@ void Engine::release_dist() {
     for (auto& kv : dist->cams) {
         auto& p = kv.second;
         if (p.rendered) (void)hipEventDestroy(p.rendered);
-        if (p.done) (void)hipEventDestroy(p.done);
+        for (auto& sl : p.slots) { if (sl.done) (void)hipEventDestroy(sl.done); if (sl.t0) (void)hipEventDestroy(sl.t0); }
         if (p.staging) { if (has_device) (void)hipFree(p.staging); else free(p.staging); }
     }
     if (dist->transport == 1 && dist->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(dist->comm);
@@ -186,11 +190,18 @@ int Engine::dist_gather(uint64_t handle, CameraState& c, const void* frame, void
     if (!frame) return fail(ST_ERR_INVALID_ARGUMENT, "null frame");
     const size_t bpp = bytes_per_pixel(c.out_format), pitch = (size_t)c.desc.width * bpp;
     hipStream_t cs = d.stream;
+    DistState::Slot* slot = nullptr;
     if (has_device) {
         ST_HIP(hipSetDevice(device));
-        if (!p.rendered) { ST_HIP(hipEventCreateWithFlags(&p.rendered, hipEventDisableTiming)); ST_HIP(hipEventCreateWithFlags(&p.done, hipEventDisableTiming)); }
+        if (!p.rendered) ST_HIP(hipEventCreateWithFlags(&p.rendered, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) if (p.slots[k].frame == frame) { slot = &p.slots[k]; p.last = k; }
+        if (!slot) { p.last = (int)(p.next & 1u); slot = &p.slots[p.last]; p.next++; }
+        if (slot->pending) { ST_HIP(hipEventSynchronize(slot->done)); slot->pending = false; }   // only when the caller runs more than two frames ahead
+        if (!slot->done) { ST_HIP(hipEventCreate(&slot->done)); ST_HIP(hipEventCreate(&slot->t0)); }   // timing enabled: st_dist_gather_ms
+        slot->frame = frame;
         ST_HIP(hipEventRecord(p.rendered, stream));          // the frame is composed ...
         ST_HIP(hipStreamWaitEvent(cs, p.rendered, 0));       // ... before the communication stream touches it
+        ST_HIP(hipEventRecord(slot->t0, cs));
     }
     // what this rank contributes: its own tile, contiguous when it spans the frame's width (a row band), packed otherwise
     auto tile_bytes = [&](const StDistRect& r) { return (size_t)(r.x1 - r.x0) * (r.y1 - r.y0) * bpp; };
@@ -267,17 +278,40 @@ int Engine::dist_gather(uint64_t handle, CameraState& c, const void* frame, void
             if (!is_band(q)) copy_rect(this, const_cast<char*>(at(full, q)), pitch, static_cast<char*>(p.staging) + offset[(size_t)r], (size_t)(q.x1 - q.x0) * bpp, (size_t)(q.x1 - q.x0) * bpp, q.y1 - q.y0, cs);
         }
     }
-    if (has_device) { ST_HIP(hipEventRecord(p.done, cs)); p.pending = true; }
+    if (has_device) { ST_HIP(hipEventRecord(slot->done, cs)); slot->pending = true; }
     return ST_OK;
 }
 
-int Engine::dist_wait(uint64_t handle, hipStream_t stream, bool host) {
-    if (!dist) return ST_OK;
+int Engine::dist_wait(uint64_t handle, const void* frame, hipStream_t stream, bool host) {
+    if (!dist || !has_device) return ST_OK;
     auto it = dist->cams.find(handle);
-    if (it == dist->cams.end() || !it->second.pending || !has_device) return ST_OK;
+    if (it == dist->cams.end()) return ST_OK;
     ST_HIP(hipSetDevice(device));
-    if (host) { ST_HIP(hipEventSynchronize(it->second.done)); it->second.pending = false; }
-    else ST_HIP(hipStreamWaitEvent(stream, it->second.done, 0));
+    for (auto& sl : it->second.slots) {
+        if (!sl.pending || (frame && sl.frame != frame)) continue;
+        if (host) { ST_HIP(hipEventSynchronize(sl.done)); sl.pending = false; }
+        else ST_HIP(hipStreamWaitEvent(stream, sl.done, 0));
+    }
+    return ST_OK;
+}
+// a composition into a buffer whose gather has not finished waits for that gather (callers that alternate two buffers never wait long)
+void Engine::dist_guard(uint64_t handle, const void* out, hipStream_t s) {
+    if (!dist || !has_device || !out) return;
+    auto it = dist->cams.find(handle);
+    if (it == dist->cams.end()) return;
+    for (auto& sl : it->second.slots) if (sl.pending && sl.frame == out) (void)hipStreamWaitEvent(s, sl.done, 0);
+}
+// duration of the camera's last gather on the communication stream (blocks until it has finished)
+int Engine::dist_gather_ms(uint64_t handle, float* ms) {
+    *ms = 0.0f;
+    if (!dist || !has_device) return ST_OK;
+    auto it = dist->cams.find(handle);
+    if (it == dist->cams.end() || it->second.last < 0) return ST_OK;
+    DistState::Slot& sl = it->second.slots[it->second.last];
+    if (!sl.done) return ST_OK;
+    ST_HIP(hipSetDevice(device));
+    ST_HIP(hipEventSynchronize(sl.done)); sl.pending = false;
+    ST_HIP(hipEventElapsedTime(ms, sl.t0, sl.done));
     return ST_OK;
 }
 
@@ -342,9 +376,10 @@ int st_dist_gather(StEngine* e, StHandle camera, const void* frame, void* full_o
     if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
     return E(e)->dist_gather(camera, *it->second, frame, full_on_root, static_cast<hipStream_t>(stream));
 }
-int st_dist_wait(StEngine* e, StHandle camera, void* stream, int host_wait) {
+int st_dist_wait(StEngine* e, StHandle camera, const void* frame, void* stream, int host_wait) {
     ST_REQUIRE(e, "null engine");
-    return E(e)->dist_wait(camera, static_cast<hipStream_t>(stream), host_wait != 0);
+    return E(e)->dist_wait(camera, frame, static_cast<hipStream_t>(stream), host_wait != 0);
 }
+int st_dist_gather_ms(StEngine* e, StHandle camera, float* ms) { ST_REQUIRE(e && ms, "null argument"); return E(e)->dist_gather_ms(camera, ms); }
 
 }  // extern "C"

@@ -241,6 +241,7 @@ constexpr int kInternalPlanes = 4;  // decoded-surface twins A/B (KArgs::sn / ps
 struct CameraState {
     StCamera desc{};
     GpuCamera curr{}, prev{};
+    uint64_t handle = 0;   // the StHandle this camera is known by (st_dist.cpp keys its partitions by it)
     uint32_t frame = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0;   // [row0,row1) x [col0,col1): the window this engine renders (st_camera_set_window)
     uint32_t out_format = 0;  // StOutputFormat (camera.rs:170-175 viewport.format)
     void* slab = nullptr; size_t slab_bytes = 0;
@@ -462,7 +463,9 @@ struct Engine {
     void release_dist();
     int dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, uint32_t apron);
     int dist_gather(uint64_t handle, CameraState& c, const void* frame, void* full, hipStream_t stream);
-    int dist_wait(uint64_t handle, hipStream_t stream, bool host);
+    int dist_wait(uint64_t handle, const void* frame, hipStream_t stream, bool host);
+    void dist_guard(uint64_t handle, const void* out, hipStream_t s);
+    int dist_gather_ms(uint64_t handle, float* ms);
     void reset_profile_totals();
     ~Engine();
     static void release_camera(CameraState& c);

@@ -347,7 +347,7 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
             } else run(KS_DENOISE_VARIANCE, ST_PASS_DENOISE_VARIANCE, [&] { L.launch_denoise_variance(a, a.di_diff_stash, a.gi_diff_stash, cur); });
             for (uint32_t nth = first; nth < 5; nth++) {
                 if (nth == 4u && compose_in_wavelet) {
-                    present_guard(c, out, cur);
+                    present_guard(c, out, cur); dist_guard(c.handle, out, cur);
                     run(KS_DENOISE_WAVELET_COMPOSE, ((uint64_t)ST_PASS_DENOISE_WAVELET_0 << nth) | ST_PASS_COMPOSITION, [&] {
                         L.launch_denoise_wavelet_compose(a, 1u << nth, (float)(1u + nth), di[in_ix[nth]], di[out_ix[nth]], gi[in_ix[nth]], gi[out_ix[nth]], mode, out, c.out_format, a.lean == 0u, cur); });
                     composed = true;
@@ -358,7 +358,7 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
         };
         auto do_compose = [&] {
             if (!out || composed) return;
-            present_guard(c, out, cur);
+            present_guard(c, out, cur); dist_guard(c.handle, out, cur);
             const float4* di_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
             const float4* gi_diff = (denoise && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;
             run(KS_COMPOSITION, ST_PASS_COMPOSITION, [&] { L.launch_composition(a, mode, di_diff, gi_diff, out, c.out_format, cur); });
@@ -428,7 +428,7 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
         }
     }
     if (out && !composed) {
-        present_guard(c, out, cur);
+        present_guard(c, out, cur); dist_guard(c.handle, out, cur);
         const bool dn = c.desc.denoise != 0u;
         const float4* di_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_DI_DIFFUSE)) ? a.di_diff_curr_colors : a.di_diff_samples;
         const float4* gi_diff = (dn && (mode == ST_MODE_IMAGE || mode == ST_MODE_GI_DIFFUSE)) ? a.gi_diff_curr_colors : a.gi_diff_samples;

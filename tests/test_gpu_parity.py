@@ -276,6 +276,93 @@ def test_row_bands_image_mode_seam_psnr(bands):
     assert value >= 40.0, value
 
 
+def _tiled_ranks(torch, build, size, mode, depth, world, cols, apron, group, camera_fn=scenes.cornell_camera, exact=True, seed=21):
+    """`world` engines on ONE device joined through the in-process transport of st_dist_* (same partition, pack / unpack and stream
+    ordering as the RCCL path): returns [(engine, camera, frame tensor, desc)]."""
+    ranks = []
+    for r in range(world):
+        e = Engine(device=0, exact=exact)
+        build(e); e.set_seed(seed)
+        desc = camera_fn(size, mode, depth=depth)
+        cam = e.create_camera(desc)
+        e.dist_init_local(r, world, group)
+        e.dist_set_partition(cam, cols=cols, apron=apron)
+        ranks.append((e, cam, torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0"), desc))
+    return ranks
+
+
+@pytest.mark.parametrize("world,cols", [(4, 0), (8, 0), (2, 0), (4, 4)])
+def test_tiles_gathered_through_the_c_abi_reproduce_the_single_gpu_frame_exactly(world, cols):
+    """BASELINE.json config 4's shape — Reference mode, 2 x 2 tiles (also 4 x 2, bands and column strips) — through st_dist_set_partition
+    + st_dist_gather on device engines: the frame rank 0 assembles equals the single-engine frame bit for bit, over 3 accumulated frames,
+    with the gather of frame N in flight while frame N+1 renders into the other buffer."""
+    torch = _torch()
+    size = (272, 200)   # tile edges that are not multiples of the frame's halves: st_dist_partition rounds them onto its 16 x 8 grid
+    single = _render_bands(torch, scenes.build_cornell, size, CameraMode.REFERENCE, 1, 3, 1, 0)
+    ranks = _tiled_ranks(torch, scenes.build_cornell, size, CameraMode.REFERENCE, 1, world, cols, 0, group=4000 + world * 8 + cols)
+    alt = [torch.zeros_like(ranks[0][2]) for _ in ranks]
+    full = [torch.zeros_like(ranks[0][2]), torch.zeros_like(ranks[0][2])]
+    stream = torch.cuda.current_stream().cuda_stream
+    for f in range(3):
+        for r in range(world - 1, -1, -1):     # in-process transport: rank 0 last
+            e, cam, out, desc = ranks[r]
+            target = out if f % 2 == 0 else alt[r]
+            e.update_camera(cam, desc); e.tick(stream)
+            e.render_camera(cam, target.data_ptr(), stream)
+            e.dist_gather(cam, target.data_ptr(), full[f % 2].data_ptr() if r == 0 else 0, stream)
+    ranks[0][0].dist_wait(ranks[0][1], host=True)
+    torch.cuda.synchronize()
+    assert_bits_equal(full[0].cpu().numpy(), single, f"{world} tiles ({cols or 'default'} columns) vs one engine")
+    assert ranks[0][0].dist_gather_ms(ranks[0][1]) >= 0.0
+    for e, *_ in ranks:
+        e.close()
+
+
+def test_image_mode_tiles_under_motion_hold_40_db_for_120_frames():
+    """VERDICT r3 item 3 / SURVEY 8(e): seams "drift through temporal history". Config 5's partition AT CONFIG 5's SIZE — 3840 x 2160
+    in 8 tiles (4 x 2) of 960 x 1080, apron 16 — against the single-engine frame over 130 frames with the light orbiting as
+    cornell.rs animates it and the camera orbiting the box: every one of the LAST 30 frames must stay within BASELINE.json's 40 dB
+    (fast build on both sides, as shipped). Measured (profiles/r04_seam_motion.txt, tools/seam_motion_sweep.py): 45.0 dB worst here,
+    59.7 dB on the moving dungeon; the apron is a property of the TILE size — the same 8 tiles on a 1280 x 720 frame (320 x 360 each)
+    give 38.3 dB with apron 16 and need 32 for 40.2 dB, which is why bench.py --apron is a flag."""
+    import math
+    from parity import psnr
+    from strolle_amd import Light
+    from strolle_amd.api import dist_partition
+    torch = _torch()
+    size, world, frames = (3840, 2160), 8, 130
+    ranks = _tiled_ranks(torch, scenes.build_cornell, size, CameraMode.IMAGE, 0, world, 0, 16, group=4100, exact=False)
+    ref = Engine(device=0)
+    scenes.build_cornell(ref); ref.set_seed(21)
+    rdesc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    rcam = ref.create_camera(rdesc)
+    rout = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    full = torch.zeros_like(rout)
+    stream = torch.cuda.current_stream().cuda_stream
+    worst = 1e9
+    for f in range(frames):
+        t = f / 60.0
+        light = Light.point((math.sin(t) / 2.0, 1.5, math.cos(t) / 2.0), 0.15, (50.0 / (4.0 * math.pi),) * 3, 20.0)
+        a = 0.1 * t
+        desc = scenes.camera_for(size, (3.2 * math.sin(a), 1.0, 3.2 * math.cos(a)), (0.0, 1.0, 0.0), CameraMode.IMAGE, True, 0)
+        for e, cam, out in [(ref, rcam, rout)] + [(e, cam, out) for e, cam, out, _ in reversed(ranks)]:
+            e.insert_light(1, light); e.update_camera(cam, desc); e.tick(stream)
+            e.render_camera(cam, out.data_ptr(), stream)
+        if f >= frames - 30:
+            for r in range(world - 1, -1, -1):
+                e, cam, out, _ = ranks[r]
+                e.dist_gather(cam, out.data_ptr(), full.data_ptr() if r == 0 else 0, stream)
+            ranks[0][0].dist_wait(ranks[0][1], host=True)
+            torch.cuda.synchronize()
+            value = psnr(np.clip(full.cpu().numpy()[..., :3], 0, 1), np.clip(rout.cpu().numpy()[..., :3], 0, 1))
+            worst = min(worst, value)
+    print(f"worst seam PSNR over the last 30 of {frames} frames (8 tiles, apron 16, light + camera moving) = {worst:.2f} dB")
+    assert worst >= 40.0, worst
+    ref.close()
+    for e, *_ in ranks:
+        e.close()
+
+
 def test_atmosphere_luts_and_daylight_bit_exact():
     """the three LUT-generation kernels (transmittance, multi-scattering, sky view) against the
     oracle, texel for texel (f16-rounded), then a daylight dungeon frame sequence that samples them."""

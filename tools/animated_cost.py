@@ -15,6 +15,7 @@ ap.add_argument("--light", action="store_true", help="move a light every frame i
 ap.add_argument("--cornell", action="store_true")
 ap.add_argument("--refit", nargs="?", const=1, default=0, type=int, help="1 = ST_BVH_REFIT (boxes refitted on the host instead of a rebuild), 2 = ST_BVH_REFIT_DEVICE (refitted by k_bvh.hip)")
 ap.add_argument("--all", action="store_true", help="move EVERY instance every frame (stress-bvh.rs: many bodies under physics)")
+ap.add_argument("--only", choices=["static", "animated"], default=None, help="run one of the two phases only (for a profiler)")
 ap.add_argument("--host-bake", action="store_true", help="StTuning::device_bake = 0")
 args = ap.parse_args()
 e = Engine(device=0)
@@ -46,7 +47,7 @@ def frame(i, animate):
     e.update_camera(cam, desc)
     t = time.perf_counter(); e.tick(stream); in_tick[0] += time.perf_counter() - t
     e.render_camera(cam, out.data_ptr(), stream)
-for animate in (False, True):
+for animate in ((False, True) if args.only is None else ((args.only == 'animated'),)):
     for i in range(12): frame(i, animate)
     torch.cuda.synchronize(); t = time.perf_counter(); in_tick[0] = 0.0
     for i in range(args.frames): frame(i, animate)
