@@ -67,6 +67,59 @@ pub const ST_FORMAT_RGBA16F: i32 = 1;
 pub const ST_FORMAT_RGBA8_UNORM_SRGB: i32 = 2;
 pub const ST_FORMAT_BGRA8_UNORM_SRGB: i32 = 3;
 
+pub const ST_ERR_BVH_TOO_DEEP: i32 = 10; // st_tick: the tree is deeper than the kernels' traversal stack (uploaded all the same)
+pub const ST_ERR_DIST: i32 = 11;
+
+/// include/strolle_hip.h StTuning: scheduling / tuning switches of one engine (get, change, set).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct StTuning {
+    pub struct_size: u32,
+    pub overlap: u32,
+    pub fuse: u32,
+    pub fuse_di_head: u32,
+    pub fuse_spatial: u32,
+    pub fuse_gi_sampling: u32,
+    pub fuse_gi_validation: u32,
+    pub fuse_gi_reprojection: u32,
+    pub fuse_wavelet: u32,
+    pub fuse_compose: u32,
+    pub preview_both: u32,
+    pub variance_in_reproject: u32,
+    pub lean_frame: u32,
+    pub skip_scratch_stores: u32,
+    pub di_head_on_main: u32,
+    pub alias_gi_history: u32,
+    pub tile_map: u32,
+    pub tile_map_denoise: u32,
+    pub side_priority: i32,
+    pub staging: u32,
+    pub double_buffer: u32,
+    pub packed_base: u32,
+    pub tick_timing: u32,
+    pub anyhit_fast: u32,
+    pub allow_deep_bvh: u32,
+    pub device_bake: u32,
+    pub _reserved: [u32; 4],
+}
+
+/// [x0, x1) x [y0, y1) in pixels (st_dist_partition / st_dist_window)
+#[repr(C)]
+#[derive(Clone, Copy, Default, PartialEq, Eq, Debug)]
+pub struct StDistRect {
+    pub x0: u32,
+    pub y0: u32,
+    pub x1: u32,
+    pub y1: u32,
+}
+
+/// ncclUniqueId: rank 0 makes one (st_dist_unique_id) and hands it to the other processes by the host's own means
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct StDistUniqueId {
+    pub internal: [c_char; 128],
+}
+
 pub enum StEngine {}
 
 extern "C" {
@@ -99,6 +152,18 @@ extern "C" {
     pub fn st_set_blue_noise(e: *mut StEngine, rgba: *const u8, bytes: usize) -> i32; // Noise::new (noise.rs:40-50)
     pub fn st_engine_set_arithmetic(e: *mut StEngine, arithmetic: i32) -> i32;
     pub fn st_set_bvh_refresh(e: *mut StEngine, mode: i32) -> i32;
+    pub fn st_engine_get_tuning(e: *mut StEngine, out: *mut StTuning) -> i32;
+    pub fn st_engine_set_tuning(e: *mut StEngine, tuning: *const StTuning) -> i32;
+    // multi-GPU behind the boundary: one process per GPU, tiles + ONE gather to rank 0 over RCCL (dist.rs)
+    pub fn st_camera_set_window(e: *mut StEngine, camera: u64, x0: u32, y0: u32, x1: u32, y1: u32) -> i32;
+    pub fn st_dist_partition(width: u32, height: u32, world: u32, cols: u32, rank: u32, owned: *mut StDistRect) -> i32;
+    pub fn st_dist_window(width: u32, height: u32, owned: *const StDistRect, apron: u32, window: *mut StDistRect) -> i32;
+    pub fn st_dist_unique_id(out: *mut StDistUniqueId) -> i32;
+    pub fn st_dist_init(e: *mut StEngine, rank: i32, world: i32, id: *const StDistUniqueId) -> i32;
+    pub fn st_dist_shutdown(e: *mut StEngine) -> i32;
+    pub fn st_dist_set_partition(e: *mut StEngine, camera: u64, cols: u32, apron: u32, owned: *mut StDistRect, window: *mut StDistRect) -> i32;
+    pub fn st_dist_gather(e: *mut StEngine, camera: u64, frame: *const c_void, full_on_root: *mut c_void, hip_stream: *mut c_void) -> i32;
+    pub fn st_dist_wait(e: *mut StEngine, camera: u64, frame: *const c_void, hip_stream: *mut c_void, host_wait: i32) -> i32;
 }
 
 // ---- the HIP runtime, as far as the staging-copy present needs it (libamdhip64)

@@ -9,7 +9,8 @@
 //!
 //! Status: written against the C ABI and the reference's call sites; the build container has no Rust toolchain, so this
 //! crate has not been compiled there. The C ABI underneath is exercised by the repository's test suites.
-mod ffi;
+pub mod dist;
+pub mod ffi;
 mod handles;
 mod present;
 mod types;
@@ -68,6 +69,7 @@ where
     texture_images: HashMap<u64, TextureImage<P>>,
     cameras: HashMap<CameraHandle, CameraSlot>,
     next_camera: usize,
+    warned_deep_bvh: bool,
 }
 
 // one owner at a time, like the reference's `&mut self` API; the raw pointers are only used through it
@@ -121,6 +123,7 @@ where
             texture_images: Default::default(),
             cameras: Default::default(),
             next_camera: 0,
+            warned_deep_bvh: false,
         }
     }
 
@@ -280,7 +283,18 @@ where
     /// Sends all changes to the GPU, renders every camera's frame on the MI355X and hands the frames to wgpu.
     pub fn tick(&mut self, device: &wgpu::Device, queue: &wgpu::Queue) {
         self.flush_texture_images(device, queue);
-        check(unsafe { ffi::st_tick(self.raw, self.stream) });
+        // a tree deeper than the kernels' traversal stack is uploaded and rendered all the same; the reference indexes past its
+        // stack there (strolle-gpu/src/lib.rs:76), this facade says so once and goes on
+        let status = unsafe { ffi::st_tick(self.raw, self.stream) };
+        if status == ffi::ST_ERR_BVH_TOO_DEEP {
+            if !self.warned_deep_bvh {
+                self.warned_deep_bvh = true;
+                let msg = unsafe { CStr::from_ptr(ffi::st_last_error()) }.to_string_lossy().into_owned();
+                warn!("strolle-hip: {msg}");
+            }
+        } else {
+            check(status);
+        }
         for slot in self.cameras.values() {
             check(unsafe { ffi::st_render_camera(self.raw, slot.raw, slot.presenter.device_frame(), self.stream) });
             slot.presenter.upload(self.raw, slot.raw, queue, self.stream);

@@ -155,11 +155,15 @@ impl Presenter {
             assert_eq!(ffi::st_camera_present_copy(engine, camera, self.device_frame[cur], self.host_frame[cur], bytes, stream), ffi::ST_OK, "st_camera_present_copy");
         }
         self.ticks.set(n + 1);
-        if n == 0 {
-            return; // nothing rendered before this tick: the view shows the cleared texture once
-        }
+        // The first frame after creation or a resize has no predecessor to show: it is presented SYNCHRONOUSLY (wait for its own copy),
+        // so the view never shows a cleared texture; from the second frame on the previous frame is presented while this one renders
+        // (one frame of latency, stated in INTEGRATION.md).
+        let prev = if n == 0 { cur } else { prev };
         let mut ready = 0;
         unsafe {
+            if n == 0 {
+                assert_eq!(ffi::st_camera_present_ready(engine, camera, self.host_frame[prev], 1, &mut ready), ffi::ST_OK, "st_camera_present_ready");
+            }
             assert_eq!(ffi::st_camera_present_ready(engine, camera, self.host_frame[prev], 0, &mut ready), ffi::ST_OK, "st_camera_present_ready");
             if ready == 0 {
                 // the application is ahead of the GPU: wait for that one copy (not for the stream)

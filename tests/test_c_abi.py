@@ -42,7 +42,7 @@ def test_rust_facade_binds_exported_symbols():
     lib, declared = load_library(), set(declared_symbols())
     assert not [s for s in bound if not hasattr(lib, s)] and not [s for s in bound if s not in declared]
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "strolle_hip.h")).read(), flags=re.S)
-    for name in ("StMeshTriangle", "StMaterial", "StLight", "StCamera"):
+    for name in ("StMeshTriangle", "StMaterial", "StLight", "StCamera", "StTuning", "StDistRect", "StDistUniqueId"):
         c_body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
         c_fields = [f.strip().split("[")[0] for decl in c_body.split(";") if decl.strip() for f in decl.strip().split(" ", 1)[1].split(",")]
         r_body = re.search(r"pub struct %s \{(.*?)\n\}" % name, ffi, re.S).group(1)
@@ -655,14 +655,16 @@ def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "strolle_hip.h"\nint main(void) {\n'
                    '  printf("%zu %zu %zu %zu %zu %zu %zu ", sizeof(StMeshTriangle), sizeof(StMaterial), sizeof(StLight), sizeof(StCamera), sizeof(StGltfOptions), sizeof(StGltfSummary), sizeof(StKernelProfile));\n'
-                   '  printf("%zu %zu %zu %zu\\n", offsetof(StMaterial, base_color_texture), offsetof(StCamera, transform), offsetof(StGltfOptions, light_radius), offsetof(StKernelProfile, algorithmic_bytes));\n'
+                   '  printf("%zu %zu %zu %zu ", offsetof(StMaterial, base_color_texture), offsetof(StCamera, transform), offsetof(StGltfOptions, light_radius), offsetof(StKernelProfile, algorithmic_bytes));\n'
+                   '  printf("%zu %zu %zu %zu %zu\\n", sizeof(StTuning), offsetof(StTuning, side_priority), offsetof(StTuning, device_bake), sizeof(StDistRect), sizeof(StDistUniqueId));\n'
                    '  return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True, text=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [C.sizeof(api.StMeshTriangle), C.sizeof(api.StMaterial), C.sizeof(api.StLight), C.sizeof(api.StCamera), C.sizeof(api.StGltfOptions), C.sizeof(api.StGltfSummary),
             C.sizeof(api.StKernelProfile), api.StMaterial.base_color_texture.offset, api.StCamera.transform.offset, api.StGltfOptions.light_radius.offset,
-            api.StKernelProfile.algorithmic_bytes.offset]
+            api.StKernelProfile.algorithmic_bytes.offset,
+            C.sizeof(api.StTuning), api.StTuning.side_priority.offset, api.StTuning.device_bake.offset, C.sizeof(api.StDistRect), C.sizeof(api.StDistUniqueId)]
     assert got == want, (got, want)
 
 
