@@ -327,6 +327,7 @@ class _Binding:
             self.camera_write_buffer = fn("camera_write_buffer", [vp, u64, i32, vp, sz])
             self.debug_set_pass_mask = fn("debug_set_pass_mask", [vp, u64]); self.debug_last_launches = fn("debug_last_launches", [vp, P(u64), sz, P(sz)])
             self.debug_keep_all_planes = fn("debug_keep_all_planes", [vp, i32])
+            self.camera_buffer_stale = fn("camera_buffer_stale", [vp, u64, i32, P(i32)])
             self.camera_present_copy = fn("camera_present_copy", [vp, u64, vp, vp, sz, vp])
             self.camera_present_ready = fn("camera_present_ready", [vp, u64, vp, i32, P(i32)])
             self.profile_enable = fn("profile_enable", [vp, i32])
@@ -436,7 +437,19 @@ class EngineBase:
         self._check(self._b.set_blue_noise(self._h, rgba.ctypes.data, rgba.nbytes))
 
     # --- read-back
-    def read_buffer(self, camera: int, buffer: Buffer) -> np.ndarray:
+    def buffer_stale(self, camera: int, buffer: Buffer) -> bool:
+        """st_camera_buffer_stale: the camera's last frame (a lean frame) left this plane unwritten."""
+        if not hasattr(self._b, "camera_buffer_stale"):
+            return False
+        out = C.c_int()
+        self._check(self._b.camera_buffer_stale(self._h, camera, int(buffer), C.byref(out)))
+        return out.value != 0
+
+    def read_buffer(self, camera: int, buffer: Buffer, strict: bool = False) -> np.ndarray:
+        """st_camera_read_buffer. strict=True refuses a plane the last frame did not write (the lean frame of the fast build,
+        include/strolle_hip.h st_debug_keep_all_planes) instead of returning an earlier launch's content."""
+        if strict and self.buffer_stale(camera, buffer):
+            raise StrolleError(f"{Buffer(int(buffer)).name} was not written by the last frame (lean frame): keep_all_planes(True) stores every plane")
         n = C.c_size_t()
         self._check(self._b.camera_read_buffer(self._h, camera, int(buffer), None, 0, C.byref(n)))
         dtype = np.uint32 if int(buffer) == int(Buffer.DBG_USED_MEMORY) else np.float32

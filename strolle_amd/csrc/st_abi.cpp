@@ -282,6 +282,23 @@ int st_camera_read_buffer(StEngine* e, StHandle h, int id, void* out, size_t cap
     ST_HIP(hipMemcpy(out, src, c.plane_bytes[id], hipMemcpyDeviceToHost));
     return ST_OK;
 }
+// Did the camera's last frame leave this plane unwritten (the lean frame, st_debug_keep_all_planes)? A read-back then returns what an
+// earlier launch or frame stored there.
+int st_camera_buffer_stale(StEngine* e, StHandle h, int id, int* stale) {
+    ST_REQUIRE(e && stale && id >= 0 && id < ST_BUF_COUNT, "bad argument");
+    auto it = E(e)->cameras.find(h);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    const CameraState& c = *it->second;
+    const uint32_t lean = c.last_lean;
+    bool s = false;
+    if (lean & kLeanPrim) s |= id == ST_BUF_VELOCITY_MAP || id == ST_BUF_PRIM_SURFACE_MAP_A || id == ST_BUF_PRIM_SURFACE_MAP_B;
+    if (lean & kLeanSamples) s |= id == ST_BUF_DI_DIFF_SAMPLES || id == ST_BUF_GI_DIFF_SAMPLES;
+    if (lean & kLeanGiRes2) s |= id == ST_BUF_GI_RESERVOIRS_2;
+    if (lean & kLeanGiMid) s |= id == ST_BUF_GI_RESERVOIRS_3;
+    if (c.last_lean_composed) s |= id == ST_BUF_DI_DIFF_CURR_COLORS || id == ST_BUF_GI_DIFF_CURR_COLORS;
+    *stale = s ? 1 : 0;
+    return ST_OK;
+}
 int st_camera_write_buffer(StEngine* e, StHandle h, int id, const void* data, size_t bytes) {
     ST_REQUIRE(e && data && id >= 0 && id < ST_BUF_COUNT, "bad buffer id");
     Engine* en = E(e);

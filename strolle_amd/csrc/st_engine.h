@@ -264,6 +264,7 @@ struct CameraState {
     // reading GI_RESERVOIRS_1 back returns GI_RESERVOIRS_0's storage (`gi_aliased`; st_camera_read_buffer), and anything
     // that could observe the difference (a pass mask, st_camera_write_buffer) first makes the copy for real
     // (`materialize_gi_history`).
+    uint32_t last_lean = 0; bool last_lean_composed = false;   // KArgs::lean of the last frame: which planes it left unwritten (st_camera_buffer_stale)
     bool gi_aliased = false;
     bool surface_map_replaced[2] = {false, false};  // st_camera_write_buffer replaced PRIM_SURFACE_MAP_A / _B: regenerate its decoded twin before the next frame
     // Present hand-over (st_camera_present_copy): composed frames leave for host memory on a stream of their own, behind the

@@ -12,12 +12,16 @@ namespace st {
 // launch goes through hipExtLaunchKernelGGL, which writes the dispatch's own start / stop timestamps into the two events — what
 // rocprofv3's kernel trace reads too. An event RECORDED between two kernels instead makes the second wait for a barrier packet
 // (3-15 us each, measured), which is how the default profiling mode times runs of launches.
-struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+// `consumed` tells the engine that a launch really took the pair (a launcher whose grid is empty enqueues nothing: its events must go
+// back to the pool unrecorded — hipEventElapsedTime on a pair no dispatch wrote fails).
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; bool consumed = false; };
 extern thread_local LaunchEvents g_launch_events;  // st_engine.cpp
 #define ST_KLAUNCH(kernel, grid, block, stream, ...)                                                                                             \
     do {                                                                                                                                         \
-        if (::st::g_launch_events.start) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ::st::g_launch_events.start, ::st::g_launch_events.stop, 0, __VA_ARGS__); \
-        else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                                                    \
+        if (::st::g_launch_events.start && !::st::g_launch_events.consumed) {                                                                    \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ::st::g_launch_events.start, ::st::g_launch_events.stop, 0, __VA_ARGS__);      \
+            ::st::g_launch_events.consumed = true;                                                                                               \
+        } else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                                                  \
     } while (0)
 
 // Kernel slots: index into the per-camera counter array (2 x u64 per slot: rays, traversal bytes) and into the

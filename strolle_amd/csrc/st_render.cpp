@@ -107,6 +107,7 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     if (rendered_before && last_render_stream != stream) mixed_render_streams = true;  // the null stream is a stream too
     last_render_stream = stream; rendered_before = true;
     const bool alt = c.frame % 2u == 1u;
+    c.last_lean = 0u; c.last_lean_composed = false;
     KArgs a{};
     a.cam = c.curr; a.prev_cam = c.prev;
     const SceneSet& scene = sets[live];
@@ -159,9 +160,11 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
         const double bytes = slot_bytes(slot);
         a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
         if (profiling && profile_kernel_events) {  // the dispatch's own timestamps (what rocprofv3's kernel trace reads)
-            g_launch_events.start = take_event(); g_launch_events.stop = take_event();
+            (void)profile_close();   // a scope the run-of-launches mode left open belongs to that mode
+            g_launch_events.start = take_event(); g_launch_events.stop = take_event(); g_launch_events.consumed = false;
             launch();
-            profile_records.push_back({slot, g_launch_events.start, g_launch_events.stop, bytes, 1u, true});
+            if (g_launch_events.consumed) profile_records.push_back({slot, g_launch_events.start, g_launch_events.stop, bytes, 1u, true});
+            else { event_pool.push_back(g_launch_events.start); event_pool.push_back(g_launch_events.stop); }   // nothing was enqueued (an empty grid)
             g_launch_events = LaunchEvents();
             return;
         }
@@ -231,8 +234,10 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
             if (tuning.fuse_gi_reprojection && tracing && even_tiles_x) a.lean |= kLeanGiRes2;
             if (gi_preview_both) a.lean |= kLeanGiMid;
         }
+        c.last_lean = a.lean; c.last_lean_composed = false;
         // frame composition rides in the last a-trous pass (k_denoise.hip k_denoise_wavelet_far<true>)
         const bool compose_in_wavelet = tuning.fuse_compose && arithmetic == ST_ARITH_FAST && whole_graph && tuning.fuse && denoise && out != nullptr && mode == ST_MODE_IMAGE && any_objects;
+        c.last_lean_composed = compose_in_wavelet && a.lean != 0u;   // the last a-trous pass's colour planes stay unwritten
         a.skip_dead_scratch = (tuning.skip_scratch_stores && whole_graph && tuning.fuse && tuning.fuse_spatial && ((((a.width + 7u) / 8u) & 1u) == 0u) && needs_di && denoise && any_objects) ? 1u : 0u;
 
         auto do_prim = [&] {

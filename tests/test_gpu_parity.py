@@ -7,7 +7,7 @@ import pytest
 
 from oracle_binding import OracleEngine
 from parity import assert_bits_equal, bits_equal_mask
-from strolle_amd import Buffer, CameraMode, Engine, OutputFormat, scenes
+from strolle_amd import Buffer, CameraMode, Engine, OutputFormat, StrolleError, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -316,6 +316,33 @@ def test_tiles_gathered_through_the_c_abi_reproduce_the_single_gpu_frame_exactly
     assert ranks[0][0].dist_gather_ms(ranks[0][1]) >= 0.0
     for e, *_ in ranks:
         e.close()
+
+
+def test_lean_frame_planes_are_flagged_stale_instead_of_read_silently():
+    """the fast build's lean frame leaves seven planes unwritten; st_camera_buffer_stale says which, and a strict read-back
+    refuses them instead of returning an earlier launch's content. With every plane kept (or in the exact build) nothing is stale."""
+    torch = _torch()
+    size = (128, 96)
+    e = Engine(device=0)
+    scenes.build_cornell(e); e.set_seed(5)
+    desc = scenes.cornell_camera(size, CameraMode.IMAGE)
+    cam = e.create_camera(desc)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    lean = (Buffer.VELOCITY_MAP, Buffer.PRIM_SURFACE_MAP_A, Buffer.DI_DIFF_SAMPLES, Buffer.GI_DIFF_SAMPLES, Buffer.DI_DIFF_CURR_COLORS, Buffer.GI_DIFF_CURR_COLORS)
+    for _ in range(3):
+        e.update_camera(cam, desc); e.tick(stream); e.render_camera(cam, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert all(e.buffer_stale(cam, b) for b in lean) and not e.buffer_stale(cam, Buffer.PRIM_GBUFFER_D0_A) and not e.buffer_stale(cam, Buffer.DI_RESERVOIRS_0)
+    with pytest.raises(StrolleError, match="lean frame"):
+        e.read_buffer(cam, Buffer.VELOCITY_MAP, strict=True)
+    e.read_buffer(cam, Buffer.VELOCITY_MAP)             # the default read still returns what is there
+    e.keep_all_planes(True)
+    e.update_camera(cam, desc); e.tick(stream); e.render_camera(cam, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert not any(e.buffer_stale(cam, Buffer(i)) for i in range(35))
+    e.read_buffer(cam, Buffer.VELOCITY_MAP, strict=True)
+    e.close()
 
 
 def test_rccl_transport_binds_and_runs_with_one_rank():
