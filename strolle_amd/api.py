@@ -20,7 +20,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libstrolle_hip.so")
+LIB_PATH = os.environ.get("STROLLE_HIP_LIB") or os.path.join(_HERE, "csrc", "libstrolle_hip.so")   # STROLLE_HIP_LIB: another build of the library (same-box A/B of two builds)
 if os.environ.get("STROLLE_HIP_LIB"):  # experiments: an alternative build of the same sources (never a different implementation)
     LIB_PATH = os.environ["STROLLE_HIP_LIB"]
 

@@ -73,13 +73,21 @@ inline bool scene_fits_lds(const KArgs&) { return false; }
 inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len <= kLdsSceneTexels; }
 #endif
 // first statement of a tracing kernel whose parameter is `a_in`: defines `a`, the arguments the body uses
+// ... and every tracing kernel stages the head of the light table in LDS (kLdsLights x 112 B = 1.75 KB per block): RIS over the lights
+// (reservoir/ephemeral.rs:14-55: up to 16 picks per pixel, each a 112-B fetch at a per-lane random index) and the resampling passes'
+// per-sample light look-ups then read LDS instead of going through the texture-address path. Lights beyond kLdsLights keep the global table.
 #define ST_SCENE_PROLOGUE                                                                                                        \
     __shared__ float4 s_scene_bvh_[LDS_SCENE ? kLdsSceneTexels : 1];                                                             \
+    __shared__ GpuLight s_lights_[kLdsLights];                                                                                   \
     KArgs a = a_in;                                                                                                              \
-    if (LDS_SCENE) {                                                                                                             \
-        for (uint32_t i_ = threadIdx.x; i_ < a_in.bvh_len; i_ += kBlockThreads) s_scene_bvh_[i_] = a_in.bvh[i_];                 \
+    {                                                                                                                            \
+        const uint32_t n_l_ = (a_in.n_lights_buf < kLdsLights ? a_in.n_lights_buf : kLdsLights) * 7u;                            \
+        for (uint32_t i_ = threadIdx.x; i_ < n_l_; i_ += kBlockThreads)                                                          \
+            reinterpret_cast<float4*>(s_lights_)[i_] = reinterpret_cast<const float4*>(a_in.lights)[i_];                         \
+        if (LDS_SCENE) for (uint32_t i_ = threadIdx.x; i_ < a_in.bvh_len; i_ += kBlockThreads) s_scene_bvh_[i_] = a_in.bvh[i_];  \
         __syncthreads();                                                                                                         \
-        a.bvh = s_scene_bvh_;                                                                                                    \
+        a.lights_lds = s_lights_;                                                                                                \
+        if (LDS_SCENE) a.bvh = s_scene_bvh_;                                                                                     \
     }
 #define ST_LAUNCH_TRACE(kernel_tmpl, half, stream, ...)                                                             \
     do {                                                                                                            \

@@ -640,7 +640,11 @@ ST_D BrdfSample layered_brdf_sample(const GBuffer& g, WhiteNoise& wn, V3 v) {
 struct LightRadiance { V3 radiance, diff_brdf, spec_brdf; };
 ST_D V3 radiance_sum(const LightRadiance& r) { return r.radiance * (r.diff_brdf + r.spec_brdf); }
 ST_D GpuLight light_zero() { GpuLight l; l.d0 = l.d1 = l.d2 = l.d3 = l.prev_d0 = l.prev_d1 = l.prev_d2 = f4z(); return l; }
-ST_D GpuLight light_get(const KArgs& a, uint32_t id) { return id < a.n_lights_buf ? a.lights[id] : light_zero(); }  // unchecked in the reference
+ST_D GpuLight light_get(const KArgs& a, uint32_t id) {  // unchecked in the reference
+    if (id >= a.n_lights_buf) return light_zero();
+    if (a.lights_lds != nullptr && id < kLdsLights) return a.lights_lds[id];   // tracing kernels: the head of the table lives in LDS
+    return a.lights[id];
+}
 ST_D GpuLight light_get_prev(const KArgs& a, uint32_t id) { GpuLight l = light_get(a, id); l.d0 = l.prev_d0; l.d1 = l.prev_d1; l.d2 = l.prev_d2; return l; }
 ST_D bool light_is_none(const GpuLight& l) { return f2b(l.d2.x) == 0u; }
 ST_D bool light_contains(const GpuLight& l, V3 p) { return distance(xyz(l.d0), p) <= l.d0.w; }

@@ -52,6 +52,7 @@ Engine::Engine() {
     tuning = default_tuning();
     tuning_from_environment(tuning);
     staging.enabled = tuning.staging != 0u;
+    if (const char* x = getenv("ST_EXP")) exp_flags = (uint32_t)strtoul(x, nullptr, 0);
     if (const char* ex = getenv("ST_EXACT")) if (atoi(ex) != 0) { arithmetic = ST_ARITH_EXACT; L = launchers_exact(); }
 }
 // st_engine_set_tuning: between frames. What cannot change under a running pipeline is re-armed here.

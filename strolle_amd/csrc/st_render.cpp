@@ -117,6 +117,7 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.transmittance_lut = static_cast<const float4*>(d_transmittance.ptr); a.sky_lut = static_cast<const float4*>(d_sky.ptr);
     a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
     a.count_bytes = count_bytes ? 1u : 0u;
+    a.exp_flags = exp_flags;
     a.anyhit_contract = (count_bytes || !tuning.anyhit_fast) ? 1u : 0u;   // the reference's used_memory is the contract loop's
     a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
     a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;

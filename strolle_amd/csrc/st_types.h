@@ -52,6 +52,7 @@ constexpr uint32_t kLeanGiMid = 8u;    // both GI preview passes in one launch: 
                                        // whose second pass does resample rebuild such a neighbour's record from the pass's input (KArgs::gi_mid_src)
 constexpr int kBvhStackSize = 24;  // strolle-gpu/src/lib.rs:76
 constexpr uint32_t kLightIdSky = 0xffffffffu;
+constexpr uint32_t kLdsLights = 16;  // lights the tracing kernels keep in LDS (k_common.h ST_SCENE_PROLOGUE)
 constexpr uint32_t kCounterLines = 256;  // ray/byte counters are spread over this many 64-B lines per kernel slot
 
 // Everything a per-pixel kernel can touch, passed by value as the kernel argument (scalar loads).
@@ -61,6 +62,7 @@ struct KArgs {
     const float4* bvh; const float4* tri_attr;
     const float4* instance_xforms;  // 8 float4 per instance slot: curr_xform_inv (3 axes + translation), prev_xform; slot = tri_attr[4 t + 3].w
     const GpuMaterial* materials; const GpuLight* lights;
+    const GpuLight* lights_lds;   // set by the tracing kernels' prologue: the first kLdsLights lights in LDS (nullptr from the host)
     const uint32_t* material_base_packed;  // per material: gbuffer_pack_base_color(base_color), valid where it has no base-colour texture
     const uchar4* atlas; const uchar4* blue_noise;
     const float* byte_luts;  // 256 sRGB->linear + 256 unorm8 values (st_device.h kLut*), generated on the device at engine creation
@@ -79,6 +81,7 @@ struct KArgs {
     // ST_KEEP_ALL_PLANES=1 keeps every plane as the reference leaves it.
     uint32_t lean;
     const float4* gi_mid_src;  // kLeanGiMid, second-pass launch only: the first preview pass's input plane (nullptr: GI_RESERVOIRS_3 holds every first-pass result)
+    uint32_t exp_flags;        // A/B switches of experiments in flight (ST_EXP in the environment; 0 in the shipped configuration)
     uint32_t anyhit_contract;  // fast build: shadow rays walk the contract loop (set while the reference's used_memory bytes are counted, or by StTuning::anyhit_fast = 0)
     uint32_t count_bytes;  // st_profile_enable bit 1: kernels also sum the reference's used_memory over their rays
     uint32_t tri_slots;  // triangle records in tri_attr (upper bound of every triangle id in the BVH stream)

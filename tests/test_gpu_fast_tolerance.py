@@ -282,3 +282,9 @@ def test_fast_build_whole_graph_switches_agree_with_the_default(switch):
     for b in planes_a:
         frac = float(lanes_outside_tolerance(planes_b[b], planes_a[b]).mean())
         assert frac <= 2e-2, f"{switch}: plane {b.name}: {frac:.2e} of the lanes outside tolerance after four frames"
+
+
+def test_report_only_is_not_set():
+    """ST_TOL_REPORT_ONLY=1 turns every threshold of this module into a report (calibration runs). A run with it set must not come out
+    green: this test fails then, so the switch cannot hide a regression in a gate."""
+    assert not REPORT_ONLY, "ST_TOL_REPORT_ONLY=1 is set: the tolerance assertions of this module were skipped — reports only, not a passing run"

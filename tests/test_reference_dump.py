@@ -255,3 +255,24 @@ def test_scene_export_covers_both_benchmark_scenes(tmp_path):
         expected = 12 + sum(8 + rec.images[h].size for h in rec.images) + 4 + want["materials"] * 56 + 4 + want["instances"] * 56 + want["triangles"] * 96 + 4 + want["lights"] * 32 + 8 + 128
         assert len(data) == expected, (scene, len(data), expected)
         assert got["instances"] == count_instances(scene)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/strolle"), reason="the reference's sources exist in the build container only")
+def test_the_reference_dump_patch_still_applies(tmp_path):
+    """tools/reference_dump/strolle_deterministic_dump.patch against the reference as it lies under /root/reference (read-only: a
+    scratch copy of the files the patch names is patched, with --dry-run first): the pin harness must stay runnable by a maintainer."""
+    import re, shutil, subprocess
+    patch = os.path.join(ROOT, "tools", "reference_dump", "strolle_deterministic_dump.patch")
+    text = open(patch).read()
+    files = sorted(set(re.findall(r"^\+\+\+ b/(\S+)", text, re.M)) | set(re.findall(r"^--- a/(\S+)", text, re.M)))
+    assert files, "the patch names no files"
+    for f in files:
+        src = os.path.join("/root/reference", f)
+        dst = tmp_path / f
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        if os.path.exists(src):
+            shutil.copy(src, dst)
+    dry = subprocess.run(["patch", "-p1", "--dry-run", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert dry.returncode == 0, dry.stdout[-2000:] + dry.stderr[-2000:]
+    real = subprocess.run(["patch", "-p1", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert real.returncode == 0 and "mod dump" in open(tmp_path / "strolle" / "src" / "lib.rs").read() and (tmp_path / "strolle" / "src" / "dump.rs").exists()
