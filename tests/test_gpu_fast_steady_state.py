@@ -128,6 +128,8 @@ def _plane_stats(got, want):
     g = got.reshape(-1, 4)[:, :3].astype(np.float64); w = want.reshape(-1, 4)[:, :3].astype(np.float64)
     ok = np.isfinite(g).all(axis=1) & np.isfinite(w).all(axis=1)
     g, w = g[ok], w[ok]
+    if not w.any() and not g.any():   # a plane the mode never writes (the DI planes under GiDiffuse): zero on both sides
+        return {"psnr": 999.0, "mean_ratio": 1.0, "nonfinite_px": int((~ok).sum())}
     peak = float(max(np.percentile(w, 99.9), 1e-6))
     return {"psnr": psnr(np.clip(g, 0, peak), np.clip(w, 0, peak), peak), "mean_ratio": float(g.mean() / max(w.mean(), 1e-30)), "nonfinite_px": int((~ok).sum())}
 
