@@ -6,14 +6,22 @@ namespace st {
 namespace ST_KNS {
 
 // Grid-stride float4 copy: the device's own streaming ceiling (read + write), what /opt/skills/guides/MI355X_MICROARCH.md quotes
-// as the achievable HBM rate (6.29 TB/s there). bench.py reports it beside torch's copy_ and beside the 8 TB/s spec figure:
-// `frac` in the roofline object is always against the spec peak.
-__global__ __launch_bounds__(256) void k_copy_float4(float4* __restrict__ dst, const float4* __restrict__ src, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+// as the achievable HBM rate (6.29 TB/s there). Four float4 per thread and iteration, nontemporal accesses, 16 blocks per CU: the best
+// of tools/copy_probe.hip's variants on this pool (6.04 TB/s; one plain float4 per thread: 4.7-5.7; torch's copy_: 5.2-5.5).
+// bench.py reports it beside the 8 TB/s spec figure: `frac` in the roofline object is always against the spec peak.
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_float4(vf4* __restrict__ dst, const vf4* __restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 1024u;
+    for (size_t i = (size_t)blockIdx.x * 1024u + threadIdx.x; i < n; i += stride) {
+        vf4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i + (size_t)u * 256u < n) v[u] = __builtin_nontemporal_load(&src[i + (size_t)u * 256u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i + (size_t)u * 256u < n) __builtin_nontemporal_store(v[u], &dst[i + (size_t)u * 256u]);
+    }
 }
 void launch_copy_float4(float4* dst, const float4* src, size_t n, uint32_t blocks, hipStream_t s) {
-    ST_KLAUNCH(k_copy_float4, dim3(blocks), dim3(256), s, dst, src, n);
+    ST_KLAUNCH(k_copy_float4, dim3(blocks), dim3(256), s, reinterpret_cast<vf4*>(dst), reinterpret_cast<const vf4*>(src), n);
 }
 
 // Rectangle copy between two pitched images in units of T (uint4 when everything is 16-byte aligned, uint32_t otherwise): packs a

@@ -252,3 +252,25 @@ for cell in (0.125, 0.25, 0.5, 1.0):
     hitc[have] = tri(ent[have], lo[sub][have], sd[sub][have], sl[sub][have])
     # cost per wave of 8x8 tiles is not defined for a random subset; report ray-level rates
     print(f"  cell {cell:5.3f}: {have.mean():.2f} of the rays find an entry, {hitc.mean():.2f} end at it ({len(table)} entries in use)")
+
+# ---- regrouping WITHIN a block: the 256 shadow rays of four horizontally adjacent tiles (one workgroup) sorted by the light they go to,
+# then cut into four waves again (an LDS shuffle of ray records + two barriers on the device) — does the per-lane loop get cheaper?
+print("block-level regrouping by light (4 adjacent tiles = 256 rays -> 4 waves):")
+tot_a = tot_b = tot_c = 0; nblk = 0
+blocks = [(ty, gx) for ty in range(H // 8) for gx in range(W // 32)]
+rng.shuffle(blocks)
+for ty, gx in blocks[:max(1, args.waves // 4)]:
+    yy, xx = np.mgrid[ty * 8:ty * 8 + 8, gx * 32:gx * 32 + 32]
+    # tile order: wave w = tile gx*4 + w
+    ids_t = [((yy[:, w * 8:(w + 1) * 8]) * W + xx[:, w * 8:(w + 1) * 8]).reshape(-1) for w in range(4)]
+    ids_t = [i[is_hit[i]] for i in ids_t]
+    allids = np.concatenate(ids_t)
+    if len(allids) < 64: continue
+    a = sum(sum(per_lane_wave(lo[i], sd[i], sl[i])[:2]) for i in ids_t if len(i))
+    order = allids[np.lexsort((allids, pick[allids]))]                      # by light, then pixel
+    b = sum(sum(per_lane_wave(lo[order[s:s + 64]], sd[order[s:s + 64]], sl[order[s:s + 64]])[:2]) for s in range(0, len(order), 64))
+    # by light, then by ray length (a proxy for traversal length known before tracing)
+    order2 = allids[np.lexsort((sl[allids], pick[allids]))]
+    c = sum(sum(per_lane_wave(lo[order2[s:s + 64]], sd[order2[s:s + 64]], sl[order2[s:s + 64]])[:2]) for s in range(0, len(order2), 64))
+    tot_a += a; tot_b += b; tot_c += c; nblk += 1
+print(f"  bodies per block: pixel tiles {tot_a / nblk:.1f}; sorted by light {tot_b / nblk:.1f} ({tot_a / tot_b:.2f}x fewer); by light then ray length {tot_c / nblk:.1f} ({tot_a / tot_c:.2f}x fewer)")
