@@ -241,7 +241,7 @@ int st_camera_set_output_format(StEngine* e, StHandle camera, int format);
  *   ST_NO_OVERLAP ST_NO_FUSE ST_NO_FUSE_DI_HEAD ST_NO_FUSE_SPATIAL ST_NO_FUSE_GI_SAMPLING ST_NO_FUSE_GI_VALIDATION
  *   ST_NO_FUSE_GI_REPROJECTION ST_NO_FUSE_WAVELET ST_NO_FUSE_COMPOSE ST_NO_PREVIEW_BOTH ST_NO_VARIANCE_IN_REPROJECT
  *   ST_KEEP_ALL_PLANES ST_KEEP_SCRATCH ST_NO_GI_ALIAS ST_NO_STAGING ST_NO_DOUBLE_BUFFER ST_NO_PACKED_BASE
- *   ST_NO_ANYHIT_FAST (=1 clears the field), ST_ALLOW_DEEP_BVH ST_DI_HEAD_ON_MAIN ST_TILE_MAP ST_TILE_MAP_DENOISE ST_SIDE_PRIORITY
+ *   ST_NO_ANYHIT_FAST ST_NO_COMPACT_BVH (=1 clears the field), ST_ALLOW_DEEP_BVH ST_DI_HEAD_ON_MAIN ST_TILE_MAP ST_TILE_MAP_DENOISE ST_SIDE_PRIORITY
  *   ST_TICK_TIMING ST_DEVICE_BAKE (= value). */
 typedef struct StTuning {
     uint32_t struct_size;
@@ -269,10 +269,12 @@ typedef struct StTuning {
     uint32_t tick_timing;           /* 1: host-side cost of a scene refresh on stderr */
     uint32_t anyhit_fast;           /* fast build: shadow rays (boolean result only, ray.rs:84-112) walk with fast arithmetic
                                      * (st_device.h any_hit_fast); 0: the contract loop. Always 0 while traversal bytes are counted */
+    uint32_t compact_bvh;           /* fast build: shadow rays walk a second, compact form of the BVH stream (48-B entries with conservative f16 child
+                                     * boxes, regenerated on the device after every change: k_bvh.hip k_bvh_compact) — 2 / 3 texels per step instead of 4 */
     uint32_t allow_deep_bvh;        /* 1: a tree deeper than the traversal stack is a warning on stderr, not ST_ERR_BVH_TOO_DEEP */
     uint32_t device_bake;           /* 1: instances are baked into world space ON THE DEVICE from object-space meshes uploaded once
                                      * (k_bvh.hip k_bvh_bake) when only transforms changed under ST_BVH_REFIT_DEVICE; 0: on the host */
-    uint32_t _reserved[4];
+    uint32_t _reserved[3];
 } StTuning;
 int st_engine_get_tuning(StEngine* e, StTuning* out);
 int st_engine_set_tuning(StEngine* e, const StTuning* tuning);

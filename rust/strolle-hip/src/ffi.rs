@@ -98,9 +98,10 @@ pub struct StTuning {
     pub packed_base: u32,
     pub tick_timing: u32,
     pub anyhit_fast: u32,
+    pub compact_bvh: u32,
     pub allow_deep_bvh: u32,
     pub device_bake: u32,
-    pub _reserved: [u32; 4],
+    pub _reserved: [u32; 3],
 }
 
 /// [x0, x1) x [y0, y1) in pixels (st_dist_partition / st_dist_window)

@@ -67,8 +67,8 @@ class StTuning(C.Structure):
                                           "fuse_gi_reprojection", "fuse_wavelet", "fuse_compose", "preview_both", "variance_in_reproject",
                                           "lean_frame", "skip_scratch_stores", "di_head_on_main", "alias_gi_history", "tile_map", "tile_map_denoise")] + \
                [("side_priority", C.c_int32)] + \
-               [(n, C.c_uint32) for n in ("staging", "double_buffer", "packed_base", "tick_timing", "anyhit_fast",
-                                          "allow_deep_bvh", "device_bake")] + [("_reserved", C.c_uint32 * 4)]
+               [(n, C.c_uint32) for n in ("staging", "double_buffer", "packed_base", "tick_timing", "anyhit_fast", "compact_bvh",
+                                          "allow_deep_bvh", "device_bake")] + [("_reserved", C.c_uint32 * 3)]
 
 
 class StKernelProfile(C.Structure):

@@ -65,8 +65,9 @@ ST_D bool owns_pixel(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.hei
 //                      fetches are the traversal's latency chain; measured -21 % on the shadow-ray pass)
 //   <false, uint16_t>  fewer than 65,536 entries (stack slots hold entry numbers = texel pointer / 4): 16-bit stack entries
 //   <false, uint32_t>  anything larger
-constexpr uint32_t kLdsSceneTexels = 448;  // 7 KiB of LDS per block: 112 entries, e.g. 56 one-triangle leaves + 55 internal nodes
 constexpr uint32_t kStack16Texels = 4u * 65536u;
+// (the compact stream's pointers carry a kind bit: entry << 1 | leaf — half as many entries fit a 16-bit slot)
+inline uint32_t stack16_limit(const KArgs& a) { return a.bvh_c ? kStack16Texels / 2u : kStack16Texels; }   // (32-bit slots cost 0.6 % of the dungeon frame, measured)
 #ifdef ST_NO_LDS_SCENE  // experiment switch (tools/ab_bench.sh): small scenes traverse through the vector L1 like large ones
 inline bool scene_fits_lds(const KArgs&) { return false; }
 #else
@@ -92,14 +93,14 @@ inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len 
 #define ST_LAUNCH_TRACE(kernel_tmpl, half, stream, ...)                                                             \
     do {                                                                                                            \
         if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL2(kernel_tmpl, true, uint16_t), half, stream, __VA_ARGS__);          \
-        else if (a.bvh_len < kStack16Texels) ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint16_t), half, stream, __VA_ARGS__);   \
+        else if (a.bvh_len < stack16_limit(a)) ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint16_t), half, stream, __VA_ARGS__);   \
         else ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint32_t), half, stream, __VA_ARGS__);                           \
     } while (0)
 // the same for kernels with one more leading bool (REPROJECT)
 #define ST_LAUNCH_TRACE_B(kernel_tmpl, flag, half, stream, ...)                                                         \
     do {                                                                                                                \
         if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL3(kernel_tmpl, true, flag, uint16_t), half, stream, __VA_ARGS__);        \
-        else if (a.bvh_len < kStack16Texels) ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint16_t), half, stream, __VA_ARGS__); \
+        else if (a.bvh_len < stack16_limit(a)) ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint16_t), half, stream, __VA_ARGS__); \
         else ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint32_t), half, stream, __VA_ARGS__);                         \
     } while (0)
 #define ST_TPL(k, t) k<t>

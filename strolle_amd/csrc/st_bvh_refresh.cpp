@@ -46,6 +46,7 @@ void Engine::expand_stream() {
         }
     }
     device_bvh_len = (uint32_t)(4 * entries);
+    device_root_is_leaf = entries != 0 && f2b(bvh_upload_[0].w) != 0u;
 }
 
 // Index arrays of the device refit, from the device form of the stream (bvh_upload_, entries of four texels): per triangle

@@ -387,9 +387,16 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, C
     return used_memory;
 }
 // Ray::trace (closest hit) with attributes resolved once, for the winning triangle.
+template <class SE> ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candidate* best);
 template <class SE>
 ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
     Candidate c; bool any;
+#if ST_FAST_DEVICE && !defined(ST_NO_ANYHIT_FAST)
+    // the fast build's closest-hit rays outside the heatmap pass (which calls traverse() itself: its integers are the contract's) walk the
+    // compact stream too when there is one: conservative boxes visit a superset of the entries, the triangle records are the same f32
+    if (a.bvh_c != nullptr) { *used_memory = 0u; any = closest_hit_compact(a, ray, stack, &c); }
+    else
+#endif
     *used_memory = traverse<false>(a, ray, kF32Max, stack, &c, &any);
     TriangleHit h;
     h.distance = c.t; h.material_id = c.material; h.point = v3s(0.0f); h.normal = v3s(0.0f); h.uv = v2(0.0f, 0.0f); h.xform_slot = 0u;
@@ -501,12 +508,112 @@ ST_D bool any_hit_fast(const KArgs& a, const Ray& ray, SE* stack) {
     }
     return hit;
 }
+// The same walk over the COMPACT stream (k_bvh.hip k_bvh_compact: 48-B entries, conservative f16 child boxes; KArgs::bvh_c): two texels
+// per internal step, three per leaf step instead of four. The slab test reads the f16 planes straight into v_fma_mix_f32
+// (f16 x f32 + f32): the narrower boxes cost no conversion. A child's kind travels with its pointer: `cur` and the stack entries are
+// (entry << 1 | is a leaf entry).
+ST_D float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+ST_D float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+template <class SE>
+ST_D bool any_hit_compact(const KArgs& a, const Ray& ray, SE* stack) {
+    if (a.bvh_len == 0u) return false;
+    const float limit = ray.len;
+    const V3 inv = v3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
+    const V3 oi = v3(-ray.origin.x * inv.x, -ray.origin.y * inv.y, -ray.origin.z * inv.z);
+    uint32_t cur = a.bvh_c_root;
+    int sp = 0;
+    bool hit = false;
+    for (;;) {
+        const bool leaf = (cur & 1u) != 0u;
+        const float4* e = bvh_entry(a.bvh_c, (cur >> 1) * 48u);
+        const float4 t0 = e[0], t1 = e[1];
+        float4 t2 = f4z();
+        if (leaf) t2 = e[2];
+        asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x));   // one round trip for the entry
+        if (!leaf) {
+            const uint32_t w0 = f2b(t0.x), w1 = f2b(t0.y), w2 = f2b(t0.z), w3 = f2b(t0.w), w4 = f2b(t1.x), w5 = f2b(t1.y), link = f2b(t1.z);
+            float near_d = any_slab(v3(half_lo(w0), half_hi(w0), half_lo(w1)), v3(half_hi(w1), half_lo(w2), half_hi(w2)), inv, oi);
+            float far_d = any_slab(v3(half_lo(w3), half_hi(w3), half_lo(w4)), v3(half_hi(w4), half_lo(w5), half_hi(w5)), inv, oi);
+            uint32_t near_ptr = (((cur >> 1) + 1u) << 1) | (link & 1u), far_ptr = ((link >> 2) << 1) | ((link >> 1) & 1u);
+            if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
+            if (far_d < limit) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)far_ptr; sp++; } }
+            if (near_d < limit) { cur = near_ptr; continue; }
+        } else {
+            const uint32_t head = f2b(t0.w);
+            float u, v;
+            bool found = any_triangle(ray, xyz(t0), xyz(t1), xyz(t2), limit, &u, &v);
+            if (found && (head & 2u)) {  // AlphaMode::Blend: the texel decides (exact-island fetch, as in traverse())
+                const GpuMaterial m = a.materials[f2b(t1.w)];
+                const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
+                if (bc.w < 1.0f) found = false;
+            }
+            if (found) { hit = true; break; }
+            if (head & 1u) { cur += 2u; continue; }   // the next entry of the run: a leaf entry too
+        }
+        if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64]; } else break;
+    }
+    return hit;
+}
+// Closest hit over the compact stream: the same loop with the cut-off following the best distance (triangle arithmetic contracted, as in
+// any_triangle; Candidate as traverse() fills it, so trace_closest resolves attributes the same way).
+template <class SE>
+ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candidate* best) {
+    best->t = kF32Max; best->tri = 0xffffffffu; best->material = 0u; best->u = 0.0f; best->v = 0.0f; best->inv_det = 1.0f;
+    if (a.bvh_len == 0u) return false;
+    const V3 inv = v3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
+    const V3 oi = v3(-ray.origin.x * inv.x, -ray.origin.y * inv.y, -ray.origin.z * inv.z);
+    uint32_t cur = a.bvh_c_root;
+    int sp = 0;
+    bool found_any = false;
+    for (;;) {
+        const bool leaf = (cur & 1u) != 0u;
+        const float4* e = bvh_entry(a.bvh_c, (cur >> 1) * 48u);
+        const float4 t0 = e[0], t1 = e[1];
+        float4 t2 = f4z();
+        if (leaf) t2 = e[2];
+        asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x));
+        if (!leaf) {
+            const uint32_t w0 = f2b(t0.x), w1 = f2b(t0.y), w2 = f2b(t0.z), w3 = f2b(t0.w), w4 = f2b(t1.x), w5 = f2b(t1.y), link = f2b(t1.z);
+            float near_d = any_slab(v3(half_lo(w0), half_hi(w0), half_lo(w1)), v3(half_hi(w1), half_lo(w2), half_hi(w2)), inv, oi);
+            float far_d = any_slab(v3(half_lo(w3), half_hi(w3), half_lo(w4)), v3(half_hi(w4), half_lo(w5), half_hi(w5)), inv, oi);
+            uint32_t near_ptr = (((cur >> 1) + 1u) << 1) | (link & 1u), far_ptr = ((link >> 2) << 1) | ((link >> 1) & 1u);
+            if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
+            if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)far_ptr; sp++; } }
+            if (near_d < best->t) { cur = near_ptr; continue; }
+        } else {
+            const uint32_t head = f2b(t0.w);
+            const V3 p0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);
+            const V3 pvec = cross(ray.dir, e2);
+            const float det = dot(e1, pvec);
+            if (!(fabsf(det) < kF32Eps)) {
+                const float inv_det = __builtin_amdgcn_rcpf(det);
+                const V3 tvec = ray.origin - p0;
+                const float u = dot(tvec, pvec) * inv_det;
+                const V3 qvec = cross(tvec, e1);
+                const float v = dot(ray.dir, qvec) * inv_det;
+                const float t = dot(e2, qvec) * inv_det;
+                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t))) {
+                    bool found = true;
+                    if (head & 2u) {
+                        const GpuMaterial m = a.materials[f2b(t1.w)];
+                        const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
+                        if (bc.w < 1.0f) found = false;
+                    }
+                    if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = head >> 2; best->material = f2b(t1.w); found_any = true; }
+                }
+            }
+            if (head & 1u) { cur += 2u; continue; }
+        }
+        if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64]; } else break;
+    }
+    return found_any;
+}
 #endif
 // Ray::intersect (shadow ray)
 template <class SE>
 ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
 #if ST_FAST_DEVICE && !defined(ST_NO_ANYHIT_FAST)
-    if (!a.anyhit_contract) { *used_memory = 0u; return any_hit_fast(a, ray, stack); }
+    if (!a.anyhit_contract) { *used_memory = 0u; return a.bvh_c != nullptr ? any_hit_compact(a, ray, stack) : any_hit_fast(a, ray, stack); }
 #endif
     return trace_any_contract(a, ray, stack, used_memory);
 }

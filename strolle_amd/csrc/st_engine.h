@@ -376,7 +376,7 @@ struct Engine {
     // serializer wrote it (far pointer remapped), a leaf entry followed by its triangle's hit-test record — so that one
     // four-texel fetch serves a traversal step of either kind. Entry k starts at texel 4 k.
     std::vector<uint32_t> expand_map_;  // scratch: offset in bvh_stream -> texel pointer in bvh_upload_ (entry starts only)
-    uint32_t device_bvh_len = 0;
+    uint32_t device_bvh_len = 0; bool device_root_is_leaf = false;
     void expand_stream();
     void index_device_tree();
     std::vector<uint8_t> internal_start_;  // scratch of measure_stack_need: 1 where an internal node begins
@@ -415,6 +415,7 @@ struct Engine {
     // (Updating in place would have to wait for the previous frame, and the next frame's primary rays with it.)
     struct SceneSet {
         DeviceArray bvh, tri_attr, xforms, materials, base_packed;
+        DeviceArray bvh_compact; uint32_t compact_entries = 0;   // k_bvh.hip k_bvh_compact: 48 B per entry, regenerated whenever `bvh` changed
         // ST_BVH_REFIT_DEVICE: what k_bvh.hip needs beside the stream — per triangle slot the hit-test record, the bounds and the
         // device entry that holds it; per entry its parent (entry << 1 | child slot); the leaf runs; an arrival counter per entry.
         // tree_version says which build of the tree these (and the stream's topology) belong to.
@@ -490,6 +491,7 @@ struct Engine {
     bool refresh_instances();
     void bake_jobs_on_host(const std::vector<BakeJob>& jobs, size_t total);
     int bake_on_device(SceneSet& t, hipStream_t up, bool* pageable);
+    int refresh_compact_stream(SceneSet& t, hipStream_t up);
 
     uint64_t topology_of(const std::vector<uint8_t>& blend) const;
     void index_stream();

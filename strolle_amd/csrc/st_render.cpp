@@ -118,6 +118,10 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.tri_slots = (uint32_t)(tri_geo.size() / 3u);
     a.count_bytes = count_bytes ? 1u : 0u;
     a.exp_flags = exp_flags;
+    // the fast build's shadow rays walk the compact stream of this scene copy when it has one (k_bvh.hip k_bvh_compact)
+    const bool compact = arithmetic == ST_ARITH_FAST && tuning.compact_bvh && tuning.anyhit_fast && !count_bytes && scene.compact_entries != 0u && scene.compact_entries * 4u == device_bvh_len;
+    a.bvh_c = compact ? static_cast<const float4*>(scene.bvh_compact.ptr) : nullptr;
+    a.bvh_c_root = (compact && device_root_is_leaf) ? 1u : 0u;
     a.anyhit_contract = (count_bytes || !tuning.anyhit_fast) ? 1u : 0u;   // the reference's used_memory is the contract loop's
     a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
     a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;

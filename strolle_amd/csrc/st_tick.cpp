@@ -132,6 +132,7 @@ int Engine::tick(hipStream_t stream) {
                     t.tree_version = tree_version;
                 }
             }
+            if ((rc = refresh_compact_stream(t, up))) return rc;   // the shadow rays' compact form follows every change of the contract stream
             // attribute records: whole the first time or after they grew, otherwise only the slots baked since this copy was written
             const bool partial = t.valid && !t.tri_full && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
             if (!partial) {
@@ -212,6 +213,22 @@ int Engine::tick(hipStream_t stream) {
             return fail(ST_ERR_BVH_TOO_DEEP, "the BVH is " + std::to_string(bvh_stack_need) + " internal nodes deep, the kernels' traversal stack holds " + std::to_string(kBvhStackSize) +
                                              " pending entries (strolle-gpu/src/lib.rs:76): pushes beyond it are dropped and geometry behind them can be missed. The scene was uploaded and renders; StTuning::allow_deep_bvh = 1 accepts this");
     }
+    return ST_OK;
+}
+
+// The compact stream (k_bvh.hip k_bvh_compact) of device copy `t`, from that copy's contract stream as it is on the device right now.
+int Engine::refresh_compact_stream(SceneSet& t, hipStream_t up) {
+    t.compact_entries = 0;
+    if (!tuning.compact_bvh || device_bvh_len <= kLdsSceneTexels) return ST_OK;   // tiny scenes live in LDS as they are
+    const uint32_t entries = device_bvh_len / 4u;
+    const size_t bytes = (size_t)entries * 48u;
+    if (bytes > t.bvh_compact.capacity) {
+        if (t.bvh_compact.ptr) ST_HIP(hipFree(t.bvh_compact.ptr));
+        t.bvh_compact.ptr = nullptr; t.bvh_compact.capacity = 0;
+        ST_HIP(hipMalloc(&t.bvh_compact.ptr, bytes + bytes / 2)); t.bvh_compact.capacity = bytes + bytes / 2;
+    }
+    launchers_exact().launch_bvh_compact(static_cast<const float4*>(t.bvh.ptr), entries, static_cast<float4*>(t.bvh_compact.ptr), up);
+    t.compact_entries = entries;
     return ST_OK;
 }
 

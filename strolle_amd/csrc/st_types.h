@@ -52,6 +52,7 @@ constexpr uint32_t kLeanGiMid = 8u;    // both GI preview passes in one launch: 
                                        // whose second pass does resample rebuild such a neighbour's record from the pass's input (KArgs::gi_mid_src)
 constexpr int kBvhStackSize = 24;  // strolle-gpu/src/lib.rs:76
 constexpr uint32_t kLightIdSky = 0xffffffffu;
+constexpr uint32_t kLdsSceneTexels = 448;  // device streams up to this many float4 are copied into LDS by the tracing kernels (7 KiB per block: 112 entries, e.g. 56 one-triangle leaves + 55 internal nodes)
 constexpr uint32_t kLdsLights = 16;  // lights the tracing kernels keep in LDS (k_common.h ST_SCENE_PROLOGUE)
 constexpr uint32_t kCounterLines = 256;  // ray/byte counters are spread over this many 64-B lines per kernel slot
 
@@ -81,6 +82,8 @@ struct KArgs {
     // ST_KEEP_ALL_PLANES=1 keeps every plane as the reference leaves it.
     uint32_t lean;
     const float4* gi_mid_src;  // kLeanGiMid, second-pass launch only: the first preview pass's input plane (nullptr: GI_RESERVOIRS_3 holds every first-pass result)
+    const float4* bvh_c;       // fast build: the compact stream the shadow rays walk (k_bvh.hip k_bvh_compact; nullptr: they walk `bvh`)
+    uint32_t bvh_c_root;       // ... its entry 0 with the kind bit (entry << 1 | is a leaf entry)
     uint32_t exp_flags;        // A/B switches of experiments in flight (ST_EXP in the environment; 0 in the shipped configuration)
     uint32_t anyhit_contract;  // fast build: shadow rays walk the contract loop (set while the reference's used_memory bytes are counted, or by StTuning::anyhit_fast = 0)
     uint32_t count_bytes;  // st_profile_enable bit 1: kernels also sum the reference's used_memory over their rays
