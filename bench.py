@@ -336,8 +336,8 @@ class Job:
 
 
 def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scene, mode_name, size, key):
-    """A BASELINE.json multi-GPU config as written — ONE frame of `size` split into `world` row bands (+ apron in Image mode),
-    bands gathered to rank 0 every frame — timed like the main region (barrier + synchronize on both sides, max over ranks)."""
+    """A BASELINE.json multi-GPU config as written — ONE frame of `size` split into `world` tiles (st_dist_partition; + apron in Image mode),
+    tiles gathered to rank 0 every frame — timed like the main region (barrier + synchronize on both sides, max over ranks)."""
     job = Job(torch, dist, args, scene, mode_name, size, world, rank, local_rank, debug_shared)
     steps = max(2, min(args.steps, 30))
     job.run(min(args.preroll, 48)); job.run(args.warmup)
