@@ -348,6 +348,10 @@ enum StPassBit {
     ST_PASS_COMPOSITION = 1u << 26, ST_PASS_BVH_HEATMAP = 1u << 27, ST_PASS_REF_TRACING = 1u << 28, ST_PASS_REF_SHADING = 1u << 29
 };
 int st_debug_set_pass_mask(StEngine* e, uint64_t mask);
+/* Measurement only (tools/pair_matrix.py): the frame's graph is built as always — every fusion of the whole frame — but only the launches
+ * whose ordinal in the frame's serial order has its bit set are enqueued, all on the caller's stream. ~0 (default): everything, as shipped.
+ * What the planes hold after a filtered frame is unspecified. */
+int st_debug_set_launch_filter(StEngine* e, uint64_t filter);
 /* The variance pass's short-history flags after the last frame (StTuning::variance_in_reproject): one 64-bit word per 8x8 tile, bit =
  * pixel of the tile — the pixels whose estimate_variance takes the 29-tap spatial branch (frame_denoising.rs:128-189). out == NULL: only
  * the tile count. (Steady state, 1080p: 8 % of the pixels on the Cornell box, 84 % in the dungeon — DI samples without confidence reset

@@ -325,7 +325,7 @@ class _Binding:
             self.decode_png = fn("decode_png", [vp, sz, vp, sz, P(u32), P(u32)])
             self.engine_set_arithmetic = fn("engine_set_arithmetic", [vp, i32]); self.engine_get_arithmetic = fn("engine_get_arithmetic", [vp, P(i32)])
             self.camera_write_buffer = fn("camera_write_buffer", [vp, u64, i32, vp, sz])
-            self.debug_set_pass_mask = fn("debug_set_pass_mask", [vp, u64]); self.debug_last_launches = fn("debug_last_launches", [vp, P(u64), sz, P(sz)])
+            self.debug_set_pass_mask = fn("debug_set_pass_mask", [vp, u64]); self.debug_set_launch_filter = fn("debug_set_launch_filter", [vp, u64]); self.debug_last_launches = fn("debug_last_launches", [vp, P(u64), sz, P(sz)])
             self.debug_keep_all_planes = fn("debug_keep_all_planes", [vp, i32])
             self.camera_buffer_stale = fn("camera_buffer_stale", [vp, u64, i32, P(i32)])
             self.camera_present_copy = fn("camera_present_copy", [vp, u64, vp, vp, sz, vp])
@@ -584,6 +584,10 @@ class Engine(EngineBase):
     def set_pass_mask(self, mask: int):
         """st_debug_set_pass_mask: bit set = that reference pass runs (PassBit)."""
         self._check(self._b.debug_set_pass_mask(self._h, mask & 0xFFFFFFFFFFFFFFFF))
+
+    def set_launch_filter(self, mask: int):
+        """st_debug_set_launch_filter: bit i set = the i-th launch of the frame's serial order is enqueued (measurement only)."""
+        self._check(self._b.debug_set_launch_filter(self._h, mask & 0xFFFFFFFFFFFFFFFF))
 
     def last_launches(self):
         """Pass bits of every launch the last render_camera considered, in launch order."""

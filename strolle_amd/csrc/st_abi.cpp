@@ -336,6 +336,11 @@ int st_debug_set_pass_mask(StEngine* e, uint64_t mask) {
     en->pass_mask = mask;
     return ST_OK;
 }
+int st_debug_set_launch_filter(StEngine* e, uint64_t filter) {
+    ST_REQUIRE(e, "null engine");
+    E(e)->launch_filter = filter;
+    return ST_OK;
+}
 int st_debug_last_launches(StEngine* e, uint64_t* out_bits, size_t capacity, size_t* count) {
     ST_REQUIRE(e && count, "null argument");
     const std::vector<uint64_t>& v = E(e)->last_launches;

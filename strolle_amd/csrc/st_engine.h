@@ -441,6 +441,7 @@ struct Engine {
     int arithmetic = ST_ARITH_FAST;
     Launchers L = launchers_fast();
     std::vector<uint64_t> last_launches;  // pass bits of every launch the last render considered (st_debug_last_launches)
+    uint64_t launch_filter = ~0ull;  // st_debug_set_launch_filter: which launches of the whole frame's graph (by their ordinal in the serial order) are enqueued (tools/pair_matrix.py)
     uint64_t pass_mask = ~0ull;  // st_debug_set_pass_mask: which reference passes a render executes (parity tests run one launch at a time)
     // Scheduling / tuning switches (include/strolle_hip.h StTuning says what each selects; st_engine.cpp holds the defaults and
     // the environment overrides). Notes that belong to the implementation:

@@ -159,9 +159,11 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     // kernel_info(slot) credits to the launch, so fusion shows up as a gain, not as a moved goalpost.
     last_launches.clear();
     bool mask_split = false;
+    uint32_t launch_ordinal = 0u;
     auto run = [&](int slot, uint64_t bits, auto&& launch) {
         if (last_launches.empty() || last_launches.back() != bits) last_launches.push_back(bits);  // a launch group is reported once
         if ((bits & pass_mask) != bits) { mask_split |= (bits & pass_mask) != 0; return; }
+        if (launch_filter != ~0ull && !((launch_filter >> (launch_ordinal++ & 63u)) & 1ull)) return;  // measurement only: the frame's state is not meaningful afterwards
         const double bytes = slot_bytes(slot);
         a.ray_counter = c.counters + kCounterWordsPerSlot * slot;
         if (profiling && profile_kernel_events) {  // the dispatch's own timestamps (what rocprofv3's kernel trace reads)
@@ -377,7 +379,7 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
 
         // per-kernel profiling runs the graph serially on `stream`: a launch's event pair then times that kernel alone,
         // not the kernels of the other stream it would share the chip with
-        if (tuning.overlap && !profiling && needs_di && needs_gi && any_objects) {
+        if (tuning.overlap && !profiling && launch_filter == ~0ull && needs_di && needs_gi && any_objects) {
             // Two streams, software-pipelined across frames: `side` carries primary visibility and the GI chain; `stream`
             // carries the DI passes (sampling + temporal resampling too, by default: measured 1.2 % on the dungeon, nothing
             // on Cornell, against running them behind primary visibility on `side`), the denoiser and composition. Events
