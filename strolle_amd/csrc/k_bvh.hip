@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void k_bvh_compact(const float4* bvh, uint32_t
     auto dn = [](float x) { return (uint32_t)__half_as_ushort(__float2half_rd(x)); };
     auto up = [](float x) { return (uint32_t)__half_as_ushort(__float2half_ru(x)); };
     uint4 t0, t1;
-    t0.x = dn(d0.x) | (dn(d0.y) << 16); t0.y = dn(d0.z) | (up(d1.x) << 16); t0.z = up(d1.y) | (up(d1.z) << 16); t0.w = dn(d2.x) | (dn(d2.y) << 16);
-    t1.x = dn(d2.z) | (up(d3.x) << 16); t1.y = up(d3.y) | (up(d3.z) << 16); t1.z = (far_entry << 2) | (right_leaf << 1) | left_leaf; t1.w = 0u;
+    // a word per axis and box: (lower bound | upper bound << 16) — st_device.h compact_slab picks the entry plane by rotating the word
+    t0.x = dn(d0.x) | (up(d1.x) << 16); t0.y = dn(d0.y) | (up(d1.y) << 16); t0.z = dn(d0.z) | (up(d1.z) << 16); t0.w = dn(d2.x) | (up(d3.x) << 16);
+    t1.x = dn(d2.y) | (up(d3.y) << 16); t1.y = dn(d2.z) | (up(d3.z) << 16); t1.z = (far_entry << 2) | (right_leaf << 1) | left_leaf; t1.w = 0u;
     out[3u * k] = make_float4(b2f(t0.x), b2f(t0.y), b2f(t0.z), b2f(t0.w));
     out[3u * k + 1u] = make_float4(b2f(t1.x), b2f(t1.y), b2f(t1.z), b2f(t1.w));
     out[3u * k + 2u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -66,8 +66,10 @@ void launch_denoise_reproject(const KArgs& a, const float4* prev_colors, const f
 
 // Short history (frame_denoising.rs:128,180-189): spatial estimate over the reference's 29-tap window — the walk starts at
 // (-2,-2) and every later row starts at -3 —, kept as is, from a window staged in LDS (`lc` = the pixel's texel, row pitch
-// `pitch`; sqrt(luma) of a staged colour rides in its w). The two signals share the arithmetic as in the wavelet pass.
-ST_D void variance_short_history(float4 csn, float4 cdi, float4 cgi, const float4* s_sn, const float4* s_di, const float4* s_gi, int lc, int pitch, float* di_var, float* gi_var) {
+// `pitch`). A tap needs its two colours only as luma and sqrt(luma): both are evaluated once per staged texel and staged as
+// one texel (direct luma, indirect luma, their square roots) — two 16-B LDS reads per tap instead of three, no luma
+// arithmetic per tap. The two signals share the arithmetic as in the wavelet pass.
+ST_D void variance_short_history(float4 csn, float4 cdi, float4 cgi, const float4* s_sn, const float4* s_l, int lc, int pitch, float* di_var, float* gi_var) {
     const V3 cn = v3(csn.x, csn.y, csn.z);
     const f2 c_sqrt_luma = mk2(fsqrt(luma(xyz(cdi))), fsqrt(luma(xyz(cgi))));
     const float leeway = csn.w * 0.2f, inv_leeway = frcp(leeway);
@@ -79,9 +81,9 @@ ST_D void variance_short_history(float4 csn, float4 cdi, float4 cgi, const float
             const int lt = lc + oy * pitch + ox;
             const float4 ssn = s_sn[lt];
             if (ssn.w == 0.0f) continue;
-            const float4 sdi = s_di[lt], sgi = s_gi[lt];
-            const f2 l = (mk2(sdi.x, sgi.x) * 0.2126f + mk2(sdi.y, sgi.y) * 0.7152f) + mk2(sdi.z, sgi.z) * 0.0722f;
-            const f2 d = c_sqrt_luma - mk2(sdi.w, sgi.w);  // = sqrt2(l), staged
+            const float4 sl = s_l[lt];
+            const f2 l = mk2(sl.x, sl.y);
+            const f2 d = c_sqrt_luma - mk2(sl.z, sl.w);
             const float diff = fabsf(ssn.w - csn.w);
             const float depth_weight = diff >= leeway ? 0.0f : 1.0f - div_by(diff, leeway, inv_leeway);
             const float normal_weight = pow64_(fmax_(dot(v3(ssn.x, ssn.y, ssn.z), cn), 0.0f));
@@ -102,8 +104,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
     // as it skips out-of-bounds and sky taps (frame_denoising.rs:135-140).
     constexpr int RW = 38, RH = 12, PITCH = 40;
     __shared__ float4 s_sn[PITCH * RH];
-    __shared__ float4 s_di[PITCH * RH];
-    __shared__ float4 s_gi[PITCH * RH];
+    __shared__ float4 s_l[PITCH * RH];
     const TileCoord tc = resolve_tile(a, false);
     const uint32_t wave = threadIdx.x >> 6;
     const U2 pos = pixel_in_tile(tc);
@@ -130,12 +131,11 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
             const int li = ry * PITCH + rx;
             if (gx >= 0 && gy >= 0 && gx < (int32_t)a.width && gy < (int32_t)a.height) {
                 const uint32_t at = (uint32_t)gy * a.width + (uint32_t)gx;
-                // sqrt(luma) of a staged texel rides in its w (the taps read x, y, z only): evaluated once per texel, not once per tap
-                float4 tdi = a.di_diff_curr_colors[at], tgi = a.gi_diff_curr_colors[at];
+                // luma and sqrt(luma) of both signals: evaluated once per staged texel, not once per tap
+                const float4 tdi = a.di_diff_curr_colors[at], tgi = a.gi_diff_curr_colors[at];
                 const f2 tl = (mk2(tdi.x, tgi.x) * 0.2126f + mk2(tdi.y, tgi.y) * 0.7152f) + mk2(tdi.z, tgi.z) * 0.0722f;
                 const f2 ts = sqrt2(tl);
-                tdi.w = ts.x; tgi.w = ts.y;
-                s_sn[li] = a.sn[at]; s_di[li] = tdi; s_gi[li] = tgi;
+                s_sn[li] = a.sn[at]; s_l[li] = make_float4(tl.x, tl.y, ts.x, ts.y);
             } else {
                 s_sn[li] = f4z();
             }
@@ -150,7 +150,7 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
         di_var = cdi_m.z - sqr(cdi_m.y);
         gi_var = cgi_m.z - sqr(cgi_m.y);
     } else {
-        variance_short_history(csn, cdi, cgi, s_sn, s_di, s_gi, ((int)(pos.y & 7u) + 2) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + 3, PITCH, &di_var, &gi_var);
+        variance_short_history(csn, cdi, cgi, s_sn, s_l, ((int)(pos.y & 7u) + 2) * PITCH + (int)(wave * 8u + (pos.x & 7u)) + 3, PITCH, &di_var, &gi_var);
     }
     di_var = fmax_(di_var, 0.0f);
     gi_var = fmax_(gi_var, 0.0f);

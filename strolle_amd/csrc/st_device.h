@@ -431,8 +431,7 @@ ST_D bool trace_any_contract(const KArgs& a, const Ray& ray, SE* stack, uint32_t
 // which switches back to the contract loop above). The fast build therefore walks shadow rays with ordinary fast arithmetic:
 //   * the slab test is two FMAs per plane pair against a precomputed -origin * inv_dir (the exact island's (b - o) * inv is a
 //     subtraction and a multiplication: 12 VALU instructions fewer per internal node). In position space the difference is
-//     one ulp of the coordinate's magnitude; a direction component of exactly 0 turns that axis' test into "no constraint"
-//     (inf - inf = NaN, which v_min / v_max drop), i.e. conservative;
+//     one ulp of the coordinate's magnitude; direction components are floored at 1e-20 in magnitude (slab_safe_dir says why);
 //   * Möller–Trumbore is contracted into FMAs and divides by v_rcp_f32 (the island's IEEE division alone is 13 instructions);
 //   * near-child-first order is KEPT: tools/packet_sim.py prices "left child first, no near/far sort" at +27 % loop bodies on
 //     the dungeon's DI shadow rays (occluded rays find their occluder later) against the ~15 % of an internal step the sort costs;
@@ -446,6 +445,12 @@ ST_D bool trace_any_contract(const KArgs& a, const Ray& ray, SE* stack, uint32_t
 // The boolean can differ from the contract loop's only where a ray grazes a box or a triangle edge within an ulp; the fast
 // build's launch-by-launch tolerance tests (tests/test_gpu_fast_*.py) bound how often. The exact build never comes here.
 #if ST_FAST_DEVICE
+// A direction component of (nearly) zero would make that axis' planes inf - inf = NaN wherever the origin and the plane have the same sign;
+// v_min / v_max return the other operand for a NaN, so the axis would either collapse to one plane (a box the ray runs inside gets rejected)
+// or constrain nothing (max3 / min3 below: measured — a handful of axis-parallel GI rays per frame walked every box along their other axes
+// and turned a 0.3 ms launch into 3 ms). A floor of 1e-20 keeps the products finite: the planes become (bound - origin) * 1e20, which
+// rejects a slab the ray runs beside and leaves one it runs inside unconstrained, as it should be.
+ST_D float slab_safe_dir(float d) { return fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d; }
 ST_D float any_slab(V3 lo, V3 hi, V3 inv, V3 oi) {
     const float ax = fmaf(lo.x, inv.x, oi.x), bx = fmaf(hi.x, inv.x, oi.x);
     const float ay = fmaf(lo.y, inv.y, oi.y), by = fmaf(hi.y, inv.y, oi.y);
@@ -472,7 +477,7 @@ template <class SE>
 ST_D bool any_hit_fast(const KArgs& a, const Ray& ray, SE* stack) {
     if (a.bvh_len == 0u) return false;
     const float limit = ray.len;
-    const V3 inv = v3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
+    const V3 inv = v3(__builtin_amdgcn_rcpf(slab_safe_dir(ray.dir.x)), __builtin_amdgcn_rcpf(slab_safe_dir(ray.dir.y)), __builtin_amdgcn_rcpf(slab_safe_dir(ray.dir.z)));
     const V3 oi = v3(-ray.origin.x * inv.x, -ray.origin.y * inv.y, -ray.origin.z * inv.z);
     // (Loop shape: ONE loop with `continue`s and a single exit, as traverse() has it. A first version returned from inside the loop;
     // the structurizer turned its exits into an inner and an outer loop, lanes waited for each other at the inner one's end, and the
@@ -514,26 +519,45 @@ ST_D bool any_hit_fast(const KArgs& a, const Ray& ray, SE* stack) {
 // (entry << 1 | is a leaf entry).
 ST_D float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
 ST_D float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+// One child box of a compact internal entry: a word per axis, (lower bound | upper bound << 16). The ray's direction sign per axis says
+// which of the two is the entry plane, so the word is rotated by 0 or 16 bits (`rot`, per ray) and its low half is the near plane, its
+// high half the far plane: no min / max per axis, max3 / min3 over the axes.
+struct RaySlabs { V3 inv, oi; uint32_t rx, ry, rz; };
+ST_D RaySlabs ray_slabs(const Ray& ray) {
+    RaySlabs r;
+    r.inv = v3(__builtin_amdgcn_rcpf(slab_safe_dir(ray.dir.x)), __builtin_amdgcn_rcpf(slab_safe_dir(ray.dir.y)), __builtin_amdgcn_rcpf(slab_safe_dir(ray.dir.z)));
+    r.oi = v3(-ray.origin.x * r.inv.x, -ray.origin.y * r.inv.y, -ray.origin.z * r.inv.z);
+    r.rx = (f2b(r.inv.x) >> 31) << 4; r.ry = (f2b(r.inv.y) >> 31) << 4; r.rz = (f2b(r.inv.z) >> 31) << 4;
+    return r;
+}
+ST_D float compact_slab(uint32_t wx, uint32_t wy, uint32_t wz, const RaySlabs& r) {
+    wx = __builtin_amdgcn_alignbit(wx, wx, r.rx); wy = __builtin_amdgcn_alignbit(wy, wy, r.ry); wz = __builtin_amdgcn_alignbit(wz, wz, r.rz);
+    const float nx = fmaf(half_lo(wx), r.inv.x, r.oi.x), fx = fmaf(half_hi(wx), r.inv.x, r.oi.x);
+    const float ny = fmaf(half_lo(wy), r.inv.y, r.oi.y), fy = fmaf(half_hi(wy), r.inv.y, r.oi.y);
+    const float nz = fmaf(half_lo(wz), r.inv.z, r.oi.z), fz = fmaf(half_hi(wz), r.inv.z, r.oi.z);
+    const float tmin = fmax_(fmax_(fmax_(nx, ny), nz), 0.0f);
+    const float tmax = fmin_(fmin_(fx, fy), fz);
+    return tmin <= tmax ? tmin : kF32Max;
+}
 template <class SE>
 ST_D bool any_hit_compact(const KArgs& a, const Ray& ray, SE* stack) {
     if (a.bvh_len == 0u) return false;
     const float limit = ray.len;
-    const V3 inv = v3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
-    const V3 oi = v3(-ray.origin.x * inv.x, -ray.origin.y * inv.y, -ray.origin.z * inv.z);
+    const RaySlabs rs = ray_slabs(ray);
     uint32_t cur = a.bvh_c_root;
     int sp = 0;
     bool hit = false;
     for (;;) {
         const bool leaf = (cur & 1u) != 0u;
-        const float4* e = bvh_entry(a.bvh_c, (cur >> 1) * 48u);
+        const float4* e = bvh_entry(a.bvh_c, __umul24(cur >> 1, 48u));   // v_mul_u32_u24: full rate, the 32-bit multiply is not
         const float4 t0 = e[0], t1 = e[1];
         float4 t2 = f4z();
         if (leaf) t2 = e[2];
         asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x));   // one round trip for the entry
         if (!leaf) {
-            const uint32_t w0 = f2b(t0.x), w1 = f2b(t0.y), w2 = f2b(t0.z), w3 = f2b(t0.w), w4 = f2b(t1.x), w5 = f2b(t1.y), link = f2b(t1.z);
-            float near_d = any_slab(v3(half_lo(w0), half_hi(w0), half_lo(w1)), v3(half_hi(w1), half_lo(w2), half_hi(w2)), inv, oi);
-            float far_d = any_slab(v3(half_lo(w3), half_hi(w3), half_lo(w4)), v3(half_hi(w4), half_lo(w5), half_hi(w5)), inv, oi);
+            const uint32_t link = f2b(t1.z);
+            float near_d = compact_slab(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs);
+            float far_d = compact_slab(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs);
             uint32_t near_ptr = (((cur >> 1) + 1u) << 1) | (link & 1u), far_ptr = ((link >> 2) << 1) | ((link >> 1) & 1u);
             if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
             if (far_d < limit) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)far_ptr; sp++; } }
@@ -560,22 +584,21 @@ template <class SE>
 ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candidate* best) {
     best->t = kF32Max; best->tri = 0xffffffffu; best->material = 0u; best->u = 0.0f; best->v = 0.0f; best->inv_det = 1.0f;
     if (a.bvh_len == 0u) return false;
-    const V3 inv = v3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
-    const V3 oi = v3(-ray.origin.x * inv.x, -ray.origin.y * inv.y, -ray.origin.z * inv.z);
+    const RaySlabs rs = ray_slabs(ray);
     uint32_t cur = a.bvh_c_root;
     int sp = 0;
     bool found_any = false;
     for (;;) {
         const bool leaf = (cur & 1u) != 0u;
-        const float4* e = bvh_entry(a.bvh_c, (cur >> 1) * 48u);
+        const float4* e = bvh_entry(a.bvh_c, __umul24(cur >> 1, 48u));   // v_mul_u32_u24: full rate, the 32-bit multiply is not
         const float4 t0 = e[0], t1 = e[1];
         float4 t2 = f4z();
         if (leaf) t2 = e[2];
         asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x));
         if (!leaf) {
-            const uint32_t w0 = f2b(t0.x), w1 = f2b(t0.y), w2 = f2b(t0.z), w3 = f2b(t0.w), w4 = f2b(t1.x), w5 = f2b(t1.y), link = f2b(t1.z);
-            float near_d = any_slab(v3(half_lo(w0), half_hi(w0), half_lo(w1)), v3(half_hi(w1), half_lo(w2), half_hi(w2)), inv, oi);
-            float far_d = any_slab(v3(half_lo(w3), half_hi(w3), half_lo(w4)), v3(half_hi(w4), half_lo(w5), half_hi(w5)), inv, oi);
+            const uint32_t link = f2b(t1.z);
+            float near_d = compact_slab(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs);
+            float far_d = compact_slab(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs);
             uint32_t near_ptr = (((cur >> 1) + 1u) << 1) | (link & 1u), far_ptr = ((link >> 2) << 1) | ((link >> 1) & 1u);
             if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
             if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)far_ptr; sp++; } }
