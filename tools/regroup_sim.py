@@ -162,3 +162,17 @@ print(f"  secondary, sorted by 16x16 direction cell + coarse origin cell: {wave_
 key3 = (morton(cell[:, 0] >> 1, cell[:, 1] >> 1, cell[:, 2] >> 1) << np.uint64(32)) | morton(dcell[:, 0], dcell[:, 1], np.zeros(len(r), np.int64))
 print(f"  secondary, sorted by origin cell, then direction cell:          {wave_stats(k2, s2, np.argsort(key3, kind='stable')):.3f}")
 print(f"  secondary, sorted by step count (upper bound):      {wave_stats(k2, s2, np.argsort(s2, kind='stable')):.3f}")
+
+# What a workgroup could do on its own (no global pass): the rays of ONE block — 256 consecutive rays of the tile order, 4 waves — exchanged
+# through LDS so that each wave takes rays of similar direction (or of similar length, the bound). Blocks of 1024 for comparison.
+def block_sorted(base_order, key_of, block):
+    out = []
+    for b in range(0, len(base_order), block):
+        r = base_order[b:b + block]
+        out.append(r[np.argsort(key_of[r], kind="stable")])
+    return np.concatenate(out)
+dir_key = morton(dcell[:, 0], dcell[:, 1], np.zeros(len(r), np.int64)).astype(np.int64)
+for block in (256, 1024):
+    print(f"  secondary, blocks of {block} rays regrouped by direction octant:   {wave_stats(k2, s2, block_sorted(tile2, octant.astype(np.int64), block)):.3f}")
+    print(f"  secondary, blocks of {block} rays regrouped by 16x16 direction cell: {wave_stats(k2, s2, block_sorted(tile2, dir_key, block)):.3f}")
+    print(f"  secondary, blocks of {block} rays regrouped by step count (bound):  {wave_stats(k2, s2, block_sorted(tile2, s2, block)):.3f}")
