@@ -205,10 +205,28 @@ class Job:
         if world > 1:
             if self.c_abi_gather:
                 # the product path: RCCL through the C ABI (st_dist_*). The id travels over torch.distributed's store — plumbing, like the barrier
+                # A rank whose transport does not come up must not leave the others waiting inside a collective: every rank reports, the
+                # ranks agree (MIN over torch.distributed), and if any failed ALL fall back to the torch.distributed gather — and the line says so.
                 from strolle_amd.api import dist_unique_id
-                uid = [dist_unique_id() if rank == 0 else None]
+                self.c_abi_error = None
+                uid = [None]
+                if rank == 0:
+                    try: uid = [dist_unique_id()]
+                    except Exception as exc: self.c_abi_error = f"st_dist_unique_id: {exc}"
                 dist.broadcast_object_list(uid, src=0)
-                self.engine.dist_init(rank, world, uid[0])
+                if uid[0] is None:
+                    self.c_abi_error = self.c_abi_error or "rank 0 could not create the RCCL id"
+                else:
+                    try: self.engine.dist_init(rank, world, uid[0])
+                    except Exception as exc: self.c_abi_error = f"st_dist_init: {exc}"
+                ok = torch.tensor([0 if self.c_abi_error else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok[0]) == 0:
+                    if not self.c_abi_error:
+                        self.engine.dist_shutdown()
+                    print(f"[bench rank {rank}] st_dist transport unavailable ({self.c_abi_error or 'another rank failed'}): torch.distributed gather instead", file=sys.stderr)
+                    self.c_abi_gather = False
+            if self.c_abi_gather:
                 owned, self.window = self.engine.dist_set_partition(self.cam, cols=self.cols, apron=self.apron)
                 assert owned == self.tile
             else:
