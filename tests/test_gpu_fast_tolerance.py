@@ -288,3 +288,35 @@ def test_report_only_is_not_set():
     """ST_TOL_REPORT_ONLY=1 turns every threshold of this module into a report (calibration runs). A run with it set must not come out
     green: this test fails then, so the switch cannot hide a regression in a gate."""
     assert not REPORT_ONLY, "ST_TOL_REPORT_ONLY=1 is set: the tolerance assertions of this module were skipped — reports only, not a passing run"
+
+
+@pytest.mark.gpu
+def test_axis_parallel_rays_walk_the_compact_stream_like_the_contract_stream():
+    """Rays with a direction component of exactly 0 (an axis-aligned camera's centre column and centre row; st_device.h slab_safe_dir):
+    on such an axis the slab planes are (bound - origin) / 0. The fast build's compact walk must still find what the contract walk of the
+    exact build finds — same triangle, same distance — and not wander (the launch stays as short as its neighbours'). 33 x 33 pixels so
+    that pixel 16 sits on the optical axis; a soup dense enough for the scene to leave LDS and use the compact stream; also with the eye on
+    a coordinate that many box planes share (0: the soup is symmetric around it), where bound - origin is 0 for whole families of planes."""
+    torch = _torch()
+    size = (33, 33)
+    for eye_xy in ((0.1, 0.2), (0.0, 0.0)):
+        engines = []
+        for exact in (False, True):
+            e = Engine(device=0, exact=exact)
+            scenes.build_random_soup(e, 3000, seed=5, n_lights=2)
+            e.set_seed(3)
+            desc = scenes.camera_for(size, (eye_xy[0], eye_xy[1], 3.0), (eye_xy[0], eye_xy[1], 0.0), CameraMode.REFERENCE, depth=0)
+            cam = e.create_camera(desc)
+            e.update_camera(cam, desc); e.tick(); e.render_camera(cam)
+            torch.cuda.synchronize()
+            engines.append((e, cam))
+        fast, exact = (e.read_buffer(c, Buffer.REF_HITS).reshape(size[1], size[0], -1) for e, c in engines)
+        # pixel 16 of 33 is at NDC 0 exactly and the camera's axes are the world's: its rays have a zero x (column 16) or y (row 16) component
+        assert np.float32(16.5) / np.float32(33.0) * np.float32(2.0) - np.float32(1.0) == 0.0
+        assert np.array_equal(np.asarray(desc.transform, np.float32)[:3, :3], np.eye(3, dtype=np.float32)), "the camera is not axis-aligned"
+        bad = lanes_outside_tolerance(fast, exact, rtol=1e-4, atol=1e-5).reshape(fast.shape).any(-1)
+        assert bad[:, 16].sum() + bad[16, :].sum() == 0, f"eye {eye_xy}: axis-parallel rays disagree at {np.argwhere(bad)[:8].tolist()}"
+        assert bad.mean() <= 2e-3, f"eye {eye_xy}: {bad.mean():.2e} of the primary hits differ between the compact and the contract walk"
+        assert np.isfinite(exact[..., 0]).sum() > 100, "the soup is not in view"
+        for e, _ in engines:
+            e.close()
