@@ -176,3 +176,19 @@ for block in (256, 1024):
     print(f"  secondary, blocks of {block} rays regrouped by direction octant:   {wave_stats(k2, s2, block_sorted(tile2, octant.astype(np.int64), block)):.3f}")
     print(f"  secondary, blocks of {block} rays regrouped by 16x16 direction cell: {wave_stats(k2, s2, block_sorted(tile2, dir_key, block)):.3f}")
     print(f"  secondary, blocks of {block} rays regrouped by step count (bound):  {wave_stats(k2, s2, block_sorted(tile2, s2, block)):.3f}")
+
+# Two dependent rays per lane (GI sampling: the bounce ray, then the shadow ray from its hit point): a wave that runs them as two loops pays
+# max(steps of ray 1) + max(steps of ray 2); a wave whose lanes each start their second ray as soon as their first is through pays
+# max(steps of ray 1 + steps of ray 2). The second ray here: another uniform-hemisphere ray, from the first one's hit point.
+h2 = t2 < 3e38
+p2 = o2 + r * t2[:, None]
+r3 = rng.normal(size=(len(sel), 3)).astype(np.float32); r3 /= np.linalg.norm(r3, axis=1, keepdims=True)
+r3[(r3 * -r).sum(1) < 0] *= -1
+r3[np.abs(r3) < 1e-9] = 1e-9
+t3, k3, s3 = traverse((p2 - r * 1e-3).astype(np.float32), r3)
+s3 = np.where(h2, s3, 0)
+two = fused = need = 0
+for w in range(0, len(tile2) - len(tile2) % 64, 64):
+    q = tile2[w:w + 64]
+    two += s2[q].max() + s3[q].max(); fused += (s2[q] + s3[q]).max(); need += (s2[q] + s3[q]).mean()
+print(f"  two dependent rays per lane: wave steps as two loops {two}, as one loop over both {fused} ({fused / two:.3f}); lane-step utilisation {need / two:.3f} -> {need / fused:.3f}")
