@@ -203,7 +203,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
     DiReservoir res = di_read(a.di_res[2], idx, n);
     ReprojectHistory history;  // fetched ahead of the shadow ray (st_passes.h)
-    if (REPROJECT) history = denoise_reproject_prefetch(a, pos, a.di_diff_prev_colors, a.di_diff_prev_moments);
+    if (REPROJECT) history = denoise_reproject_prefetch<true>(a, pos, a.di_diff_prev_colors, a.di_diff_prev_moments);
     float confidence;
     V3 radiance, spec_brdf;
     if (hit_some(hit)) {

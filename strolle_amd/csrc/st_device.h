@@ -946,6 +946,28 @@ ST_D float4 bilinear_reproject(const KArgs& a, const Reprojection& r, const floa
     if (w_sum == 0.0f) return f4z();
     return div4(s[0] * weights.x + s[1] * weights.y + s[2] * weights.z + s[3] * weights.w, w_sum);
 }
+// Two planes at once (the denoiser's colour and moment history share the reprojection): the taps of both are in flight together — one
+// round trip instead of two — and each plane's arithmetic is bilinear_reproject's, operation for operation.
+ST_D void bilinear_reproject2(const KArgs& a, const Reprojection& r, const float4* plane_a, const float4* plane_b, float4* out_a, float4* out_b) {
+    if (reprojection_is_exact(r)) { const U2 q = reprojection_prev_round(r); *out_a = tex_read(plane_a, a, q); *out_b = tex_read(plane_b, a, q); return; }
+    const float fl_x = floorf(r.prev_x), fl_y = floorf(r.prev_y), ce_x = ceilf(r.prev_x), ce_y = ceilf(r.prev_y);
+    const I2 p[4] = {i2(f2i_sat(fl_x), f2i_sat(fl_y)), i2(f2i_sat(ce_x), f2i_sat(fl_y)), i2(f2i_sat(fl_x), f2i_sat(ce_y)), i2(f2i_sat(ce_x), f2i_sat(ce_y))};
+    float4 sa[4], sb[4]; float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        sa[i] = f4z(); sb[i] = f4z(); w[i] = 0.0f;
+        if ((r.validity & (1u << i)) > 0u && p[i].x >= 0 && p[i].y >= 0) {
+            const U2 q = u2((uint32_t)p[i].x, (uint32_t)p[i].y);
+            sa[i] = tex_read(plane_a, a, q); sb[i] = tex_read(plane_b, a, q); w[i] = 1.0f;
+        }
+    }
+    const float ux = r.prev_x - truncf(r.prev_x), uy = r.prev_y - truncf(r.prev_y);  // f32::fract
+    const float4 weights = make_float4(w[0], w[1], w[2], w[3]) * make_float4((1.0f - ux) * (1.0f - uy), ux * (1.0f - uy), (1.0f - ux) * uy, ux * uy);
+    const float w_sum = (weights.x * 1.0f) + (weights.y * 1.0f) + (weights.z * 1.0f) + (weights.w * 1.0f);
+    if (w_sum == 0.0f) { *out_a = f4z(); *out_b = f4z(); return; }
+    *out_a = div4(sa[0] * weights.x + sa[1] * weights.y + sa[2] * weights.z + sa[3] * weights.w, w_sum);
+    *out_b = div4(sb[0] * weights.x + sb[1] * weights.y + sb[2] * weights.z + sb[3] * weights.w, w_sum);
+}
 
 // ------------------------------------------------------------------ reservoirs (reservoir.rs, reservoir/*.rs)
 struct DiSample { float pdf, confidence; uint32_t light_id; V3 light_point; bool is_occluded; };
@@ -1057,6 +1079,27 @@ ST_D GiReservoir gi_read_own(const float4* buf, uint32_t id, bool valid, bool wa
     }
     if (!want) return gi_empty();
     return gi_from_texels(buf[4u * id], buf[4u * id + 1u], buf[4u * id + 2u], buf[4u * id + 3u]);
+}
+// gi_read_own in two halves, so that a kernel can have the record's four loads in flight beside other loads before anything consumes them
+struct GiOwnRaw { float4 v0, v1, v2, v3; bool quad, loaded, want; };
+ST_D GiOwnRaw gi_load_own(const float4* buf, uint32_t id, bool valid, bool want) {
+    GiOwnRaw r; r.v0 = r.v1 = r.v2 = r.v3 = f4z();
+    r.want = want && valid; r.quad = quad_all(valid); r.loaded = false;
+    if (r.quad) {
+        if (!quad_any(r.want)) return r;
+        const uint32_t j = threadIdx.x & 3u, first = id - j;
+        r.v0 = buf[4u * first + j]; r.v1 = buf[4u * (first + 1u) + j]; r.v2 = buf[4u * (first + 2u) + j]; r.v3 = buf[4u * (first + 3u) + j];
+        r.loaded = true;
+        return r;
+    }
+    if (!r.want) return r;
+    r.v0 = buf[4u * id]; r.v1 = buf[4u * id + 1u]; r.v2 = buf[4u * id + 2u]; r.v3 = buf[4u * id + 3u]; r.loaded = true;
+    return r;
+}
+ST_D GiReservoir gi_finish_own(GiOwnRaw r) {
+    if (!r.loaded) return gi_empty();
+    if (r.quad) quad_transpose(r.v0, r.v1, r.v2, r.v3);
+    return r.want ? gi_from_texels(r.v0, r.v1, r.v2, r.v3) : gi_empty();
 }
 ST_D void gi_write_own(float4* buf, uint32_t id, const GiReservoir& r, bool valid, bool want) {
     want = want && valid;

@@ -11,13 +11,32 @@ namespace st {
 // two dependent round trips) BEFORE its own long latency chain (a shadow-ray traversal, a resampling loop) and consume
 // them after it: the loads do not depend on the sample. Fetching history that `sample.w <= 0` then ignores is harmless.
 struct ReprojectHistory { bool sky, have; float4 pc, pm; };
-ST_D ReprojectHistory denoise_reproject_prefetch(const KArgs& a, U2 pos, const float4* prev_colors, const float4* prev_moments) {
+// (`sky` and the pixel's reprojection texel come from the caller, who fetched them beside its other first-round loads; the colour and
+// the moment taps then travel together: the history costs one dependent round trip, not three)
+// TOGETHER: the colour and the moment taps travel as one round trip (eight texels live at once: +13 VGPRs — pays in di_resolving,
+// 134 -> 129 us on the dungeon, costs gi_preview_both a wave of occupancy, 102 -> 105 us, which therefore keeps them apart)
+template <bool TOGETHER>
+ST_D ReprojectHistory denoise_reproject_history(const KArgs& a, bool sky, float4 reprojection_texel, const float4* prev_colors, const float4* prev_moments) {
     ReprojectHistory h; h.have = false; h.pc = f4z(); h.pm = f4z();
-    h.sky = tex_read(a.sn, a, pos).w == 0.0f;
+    h.sky = sky;
     if (h.sky) return h;
-    const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, pos));
-    if (rp.confidence > 0.0f) { h.have = true; h.pc = bilinear_reproject(a, rp, prev_colors); h.pm = bilinear_reproject(a, rp, prev_moments); }
+    const Reprojection rp = reprojection_read(reprojection_texel);
+    if (rp.confidence > 0.0f) {
+        h.have = true;
+        if (TOGETHER) bilinear_reproject2(a, rp, prev_colors, prev_moments, &h.pc, &h.pm);
+        else { h.pc = bilinear_reproject(a, rp, prev_colors); h.pm = bilinear_reproject(a, rp, prev_moments); }
+    }
     return h;
+}
+template <bool TOGETHER = false>
+ST_D ReprojectHistory denoise_reproject_prefetch(const KArgs& a, U2 pos, const float4* prev_colors, const float4* prev_moments) {
+    if (TOGETHER) {
+        const float4 snt = tex_read(a.sn, a, pos), rpt = tex_read(a.reprojection, a, pos);   // both before the first branch: one round trip
+        return denoise_reproject_history<true>(a, snt.w == 0.0f, rpt, prev_colors, prev_moments);
+    }
+    const bool sky = tex_read(a.sn, a, pos).w == 0.0f;
+    if (sky) { ReprojectHistory h; h.have = false; h.pc = f4z(); h.pm = f4z(); h.sky = true; return h; }
+    return denoise_reproject_history<false>(a, false, tex_read(a.reprojection, a, pos), prev_colors, prev_moments);
 }
 // Returns true where estimate_variance will take its short-history path for this pixel (frame_denoising.rs:118-121; decided
 // by the DIRECT signal's history length, so only the DI caller's answer means anything). With KArgs::variance_in_reproject
