@@ -1080,27 +1080,6 @@ ST_D GiReservoir gi_read_own(const float4* buf, uint32_t id, bool valid, bool wa
     if (!want) return gi_empty();
     return gi_from_texels(buf[4u * id], buf[4u * id + 1u], buf[4u * id + 2u], buf[4u * id + 3u]);
 }
-// gi_read_own in two halves, so that a kernel can have the record's four loads in flight beside other loads before anything consumes them
-struct GiOwnRaw { float4 v0, v1, v2, v3; bool quad, loaded, want; };
-ST_D GiOwnRaw gi_load_own(const float4* buf, uint32_t id, bool valid, bool want) {
-    GiOwnRaw r; r.v0 = r.v1 = r.v2 = r.v3 = f4z();
-    r.want = want && valid; r.quad = quad_all(valid); r.loaded = false;
-    if (r.quad) {
-        if (!quad_any(r.want)) return r;
-        const uint32_t j = threadIdx.x & 3u, first = id - j;
-        r.v0 = buf[4u * first + j]; r.v1 = buf[4u * (first + 1u) + j]; r.v2 = buf[4u * (first + 2u) + j]; r.v3 = buf[4u * (first + 3u) + j];
-        r.loaded = true;
-        return r;
-    }
-    if (!r.want) return r;
-    r.v0 = buf[4u * id]; r.v1 = buf[4u * id + 1u]; r.v2 = buf[4u * id + 2u]; r.v3 = buf[4u * id + 3u]; r.loaded = true;
-    return r;
-}
-ST_D GiReservoir gi_finish_own(GiOwnRaw r) {
-    if (!r.loaded) return gi_empty();
-    if (r.quad) quad_transpose(r.v0, r.v1, r.v2, r.v3);
-    return r.want ? gi_from_texels(r.v0, r.v1, r.v2, r.v3) : gi_empty();
-}
 ST_D void gi_write_own(float4* buf, uint32_t id, const GiReservoir& r, bool valid, bool want) {
     want = want && valid;
     const V2 n = normal_encode(r.s.v2_normal);
