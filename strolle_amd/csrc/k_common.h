@@ -90,6 +90,15 @@ inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len 
         a.lights_lds = s_lights_;                                                                                                \
         if (LDS_SCENE) a.bvh = s_scene_bvh_;                                                                                     \
     }
+// For a kernel that decodes MANY G-buffer texels per lane (GI spatial resampling: every candidate neighbour's): the byte tables of the
+// decode (st_device.h kLut*, 4 KB) staged in LDS as well — seven per-lane table reads per decoded texel leave the texture-address path
+// (dungeon gi_spatial_fused 366 -> 335 us; in the kernels that decode one pixel the staging costs what it saves, measured).
+#define ST_SCENE_PROLOGUE_WITH_BYTE_TABLES                                                                                       \
+    __shared__ float s_byte_luts_[kByteLutFloats];                                                                               \
+    for (uint32_t i_ = threadIdx.x; i_ < kByteLutFloats / 4u; i_ += kBlockThreads)                                               \
+        reinterpret_cast<float4*>(s_byte_luts_)[i_] = reinterpret_cast<const float4*>(a_in.byte_luts)[i_];                       \
+    ST_SCENE_PROLOGUE                                                                                                            \
+    a.byte_luts = s_byte_luts_;
 #define ST_LAUNCH_TRACE(kernel_tmpl, half, stream, ...)                                                             \
     do {                                                                                                            \
         if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL2(kernel_tmpl, true, uint16_t), half, stream, __VA_ARGS__);          \

@@ -416,7 +416,7 @@ void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST
 // gi_spatial_resampling.rs pick + trace + sample for one 2x1 cell in one launch (see k_di_spatial_fused, k_di.hip)
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_gi_spatial_fused(const KArgs a_in, uint32_t seed_pick, uint32_t seed_sample) {
-    ST_SCENE_PROLOGUE
+    ST_SCENE_PROLOGUE_WITH_BYTE_TABLES
     __shared__ SE lds[kStackWords];
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
