@@ -203,7 +203,7 @@ def main():
 
     if os.path.exists(bench_path):
         shutil.copy(bench_path, os.path.join(out_dir, f"{tag}_bench.json"))
-    print("wrote", sorted(os.listdir(out_dir)))
+    print("wrote", sorted(f for f in os.listdir(out_dir) if f.startswith(tag + "_")))
 
 
 if __name__ == "__main__":
