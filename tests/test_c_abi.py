@@ -628,10 +628,10 @@ def test_random_edit_sequences_keep_host_state_equal_to_oracle(seed):
             assert prod.world() == orac.world(), f"seed {seed} step {step}: world"
 
 
-def _compile_example(out_path):
+def _compile_example(out_path, source="render_gltf.c"):
     import subprocess
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
-           os.path.join(ROOT, "examples", "render_gltf.c"), "-L", os.path.dirname(LIB_PATH), "-lstrolle_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           os.path.join(ROOT, "examples", source), "-L", os.path.dirname(LIB_PATH), "-lstrolle_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
            "-Wl,-rpath," + os.path.dirname(LIB_PATH), "-o", out_path]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
@@ -645,6 +645,7 @@ def test_header_is_c99_and_the_c_example_links(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(probe), "-o", str(tmp_path / "probe.o")],
                    check=True, capture_output=True, text=True)
     _compile_example(str(tmp_path / "render_gltf"))
+    _compile_example(str(tmp_path / "dist_tiles"), "dist_tiles.c")   # the multi-GPU host loop of INTEGRATION.md section 6, as a program
 
 
 def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):

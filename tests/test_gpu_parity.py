@@ -1018,6 +1018,23 @@ def test_c_example_renders_the_cornell_box(tmp_path):
     assert left[0] > left[1] and right[1] > right[0], (left, right)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8])
+def test_c_example_gathers_tiles_through_the_c_abi(tmp_path, world):
+    """examples/dist_tiles.c — the multi-GPU host loop (st_dist_init_local / st_dist_set_partition / st_dist_gather / st_dist_wait) from
+    plain C: `world` engines render their tiles of a Reference frame, rank 0 assembles them, and the program itself compares the result
+    with the same frame from one engine, byte for byte (exit status 0 only if none differs and the frame is lit)."""
+    import subprocess
+    from test_c_abi import _compile_example
+    glb = tmp_path / "cornell.glb"
+    glb.write_bytes(_cornell_glb())
+    exe = str(tmp_path / "dist_tiles")
+    _compile_example(exe, "dist_tiles.c")
+    run = subprocess.run([exe, str(glb), str(world), "272", "200", "3"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    assert f"{world} ranks, 3 frames" in run.stderr and " 0 of 870400 bytes differ" in run.stderr, run.stderr
+
+
 def test_profile_flags_timing_and_traversal_bytes():
     """st_profile_enable bit 0 = per-kernel event timing, bit 1 = the tracing kernels also sum the reference's `used_memory`
     over their rays (off by default: it costs a cross-lane reduction per ray). Rays are counted either way, identically."""
