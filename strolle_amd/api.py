@@ -635,7 +635,9 @@ class Engine(EngineBase):
     # ---- multi-GPU behind the boundary (include/strolle_hip.h st_dist_*)
     def dist_init(self, rank: int, world: int, unique_id: bytes):
         """RCCL transport: `unique_id` = dist_unique_id() of rank 0, handed to every rank by the caller's own means."""
-        uid = StDistUniqueId(); C.memmove(C.byref(uid), unique_id, 128)
+        if not isinstance(unique_id, (bytes, bytearray)) or len(unique_id) != 128:   # a truncated id would hang every rank in ncclCommInitRank
+            raise StrolleError(f"dist_init: the RCCL unique id has 128 bytes, got {len(unique_id) if hasattr(unique_id, '__len__') else type(unique_id).__name__}")
+        uid = StDistUniqueId(); C.memmove(C.byref(uid), bytes(unique_id), 128)
         self._check(self._b.dist_init(self._h, rank, world, C.byref(uid)))
 
     def dist_init_local(self, rank: int, world: int, group: int = 1):

@@ -195,6 +195,7 @@ int st_camera_delete(StEngine* e, StHandle h) {
     auto it = en->cameras.find(h);
     if (it == en->cameras.end()) return ST_OK;
     if (en->has_device) { ST_HIP(hipSetDevice(en->device)); ST_HIP(hipDeviceSynchronize()); Engine::release_camera(*it->second); }
+    en->dist_forget_camera(h);
     en->cameras.erase(it);
     return ST_OK;
 }

@@ -96,7 +96,10 @@ constexpr int kNcclInt8 = 0;   // rccl.h ncclDataType_t
 
 // ---- the in-process transport: one mailbox slot per (group, sender); the sender copies its packed tile in and records an event, the
 // root waits for the event on its stream and copies out. Non-root ranks of a frame must have called st_dist_gather before the root does.
-struct LocalSlot { void* mem = nullptr; size_t capacity = 0, bytes = 0; bool device = false; int device_id = -1; hipEvent_t ready = nullptr; uint64_t seq = 0, taken = 0; };
+// `consumed` orders the other direction: the root records it behind its copy-out, the sender's next hand-over waits for it before it
+// overwrites the slot (a caller with two frames in flight would otherwise hand the root a torn or next-frame tile).
+struct LocalSlot { void* mem = nullptr; size_t capacity = 0, bytes = 0; bool device = false; int device_id = -1; hipEvent_t ready = nullptr, consumed = nullptr;
+                   bool consumed_recorded = false; uint64_t seq = 0, taken = 0; };
 std::map<std::pair<uint64_t, int>, LocalSlot> g_local;
 std::mutex g_local_mutex;
 }  // namespace
@@ -110,7 +113,8 @@ struct DistState {
     // `slots`: the gathers in flight, by the frame buffer they read (the caller alternates two): a render into a buffer whose gather has
     // not finished is ordered behind it (Engine::dist_guard), st_dist_wait waits for one buffer's gather or for all.
     struct Slot { const void* frame = nullptr; hipEvent_t done = nullptr, t0 = nullptr; bool pending = false; };
-    struct CamPart { StDistRect owned{}, window{}; uint32_t cols = 0, apron = 0; hipEvent_t rendered = nullptr; Slot slots[2]; uint32_t next = 0; int last = -1;
+    struct CamPart { StDistRect owned{}, window{}; uint32_t cols = 0, apron = 0, width = 0, height = 0;   // width x height: the frame the partition was computed for
+                     hipEvent_t rendered = nullptr; Slot slots[2]; uint32_t next = 0; int last = -1;
                      void* staging = nullptr; size_t staging_bytes = 0; };
     std::map<uint64_t, CamPart> cams;
 };
@@ -120,21 +124,32 @@ static int rccl_fail(int code, const char* what) {
     return fail(ST_ERR_DIST, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "RCCL error") + " (" + std::to_string(code) + ")");
 }
 
+static void release_cam_part(Engine* en, DistState::CamPart& p) {
+    if (p.rendered) (void)hipEventDestroy(p.rendered);
+    for (auto& sl : p.slots) { if (sl.done) (void)hipEventDestroy(sl.done); if (sl.t0) (void)hipEventDestroy(sl.t0); }
+    if (p.staging) { if (en->has_device) (void)hipFree(p.staging); else free(p.staging); }
+    p = DistState::CamPart();
+}
+// st_camera_delete: the camera's partition, events and staging go with it
+void Engine::dist_forget_camera(uint64_t handle) {
+    if (!dist) return;
+    auto it = dist->cams.find(handle);
+    if (it == dist->cams.end()) return;
+    if (has_device) { (void)hipSetDevice(device); if (dist->stream) (void)hipStreamSynchronize(dist->stream); }
+    release_cam_part(this, it->second);
+    dist->cams.erase(it);
+}
 void Engine::release_dist() {
     if (!dist) return;
     if (has_device) { (void)hipSetDevice(device); if (dist->stream) (void)hipStreamSynchronize(dist->stream); }
-    for (auto& kv : dist->cams) {
-        auto& p = kv.second;
-        if (p.rendered) (void)hipEventDestroy(p.rendered);
-        for (auto& sl : p.slots) { if (sl.done) (void)hipEventDestroy(sl.done); if (sl.t0) (void)hipEventDestroy(sl.t0); }
-        if (p.staging) { if (has_device) (void)hipFree(p.staging); else free(p.staging); }
-    }
+    for (auto& kv : dist->cams) release_cam_part(this, kv.second);
     if (dist->transport == 1 && dist->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(dist->comm);
     if (dist->transport == 2) {
         std::lock_guard<std::mutex> lock(g_local_mutex);
         auto it = g_local.find({dist->group, dist->rank});
         if (it != g_local.end()) {
             if (it->second.ready) (void)hipEventDestroy(it->second.ready);
+            if (it->second.consumed) (void)hipEventDestroy(it->second.consumed);
             if (it->second.mem) { if (it->second.device) (void)hipFree(it->second.mem); else free(it->second.mem); }
             g_local.erase(it);
         }
@@ -159,10 +174,12 @@ static int rect_of(const CameraState& c, const DistState& d, const DistState::Ca
 
 int Engine::dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, uint32_t apron) {
     if (!dist) return fail(ST_ERR_INVALID_ARGUMENT, "st_dist_init has not been called on this engine");
+    // validate first: a request that fails leaves neither a zero rectangle in the map nor the camera's window changed
+    StDistRect owned{}, window{};
+    if (int rc = dist_partition(c.desc.width, c.desc.height, (uint32_t)dist->world, cols, (uint32_t)dist->rank, &owned)) return rc;
+    if (int rc = dist_window(c.desc.width, c.desc.height, &owned, apron, &window)) return rc;
     DistState::CamPart& p = dist->cams[handle];
-    p.cols = cols; p.apron = apron;
-    if (int rc = dist_partition(c.desc.width, c.desc.height, (uint32_t)dist->world, cols, (uint32_t)dist->rank, &p.owned)) return rc;
-    if (int rc = dist_window(c.desc.width, c.desc.height, &p.owned, apron, &p.window)) return rc;
+    p.cols = cols; p.apron = apron; p.owned = owned; p.window = window; p.width = c.desc.width; p.height = c.desc.height;
     c.col0 = p.window.x0; c.col1 = p.window.x1; c.row0 = p.window.y0; c.row1 = p.window.y1;
     return ST_OK;
 }
@@ -186,6 +203,13 @@ int Engine::dist_gather(uint64_t handle, CameraState& c, const void* frame, void
     if (it == dist->cams.end()) return fail(ST_ERR_INVALID_ARGUMENT, "st_dist_set_partition has not been called for this camera");
     DistState& d = *dist; DistState::CamPart& p = it->second;
     const bool root = d.rank == 0;
+    // The partition belongs to the frame size it was computed for. st_camera_update with another size rebuilds the camera's buffers and
+    // resets its window to the whole frame (allocate_camera): peers would then send the OLD tile's byte count while the root expects the
+    // NEW one's — a hung collective or a corrupt frame. Refuse until st_dist_set_partition has been called again.
+    if (p.width != c.desc.width || p.height != c.desc.height || p.owned.x0 >= p.owned.x1 || p.owned.y0 >= p.owned.y1)
+        return fail(ST_ERR_INVALID_ARGUMENT, "the camera's size changed since st_dist_set_partition: call it again before gathering");
+    if (c.col0 > p.owned.x0 || c.col1 < p.owned.x1 || c.row0 > p.owned.y0 || c.row1 < p.owned.y1)
+        return fail(ST_ERR_INVALID_ARGUMENT, "the camera's window no longer covers this rank's tile (st_camera_set_window since st_dist_set_partition)");
     if (root && !full) return fail(ST_ERR_INVALID_ARGUMENT, "rank 0 needs the destination frame");
     if (!frame) return fail(ST_ERR_INVALID_ARGUMENT, "null frame");
     const size_t bpp = bytes_per_pixel(c.out_format), pitch = (size_t)c.desc.width * bpp;
@@ -224,12 +248,14 @@ int Engine::dist_gather(uint64_t handle, CameraState& c, const void* frame, void
             LocalSlot& slot = g_local[{d.group, d.rank}];
             const size_t n = tile_bytes(p.owned);
             if (slot.capacity < n || slot.device != has_device) {
-                if (slot.mem) { if (slot.device) (void)hipFree(slot.mem); else free(slot.mem); slot.mem = nullptr; }
-                if (has_device) { ST_HIP(hipMalloc(&slot.mem, n)); } else slot.mem = malloc(n);
+                if (slot.mem) { if (slot.device) (void)hipFree(slot.mem); else free(slot.mem); slot.mem = nullptr; }   // hipFree joins the device: no read of it is left in flight
+                slot.capacity = 0; slot.consumed_recorded = false;
+                if (has_device) { ST_HIP(hipMalloc(&slot.mem, n)); } else { slot.mem = malloc(n); if (!slot.mem) return fail(ST_ERR_DIST, "out of memory"); }
                 slot.capacity = n; slot.device = has_device; slot.device_id = device;
             }
             if (has_device) {
                 if (!slot.ready) ST_HIP(hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming));
+                if (slot.consumed_recorded) ST_HIP(hipStreamWaitEvent(cs, slot.consumed, 0));   // the root's read of the previous tile comes first
                 ST_HIP(hipMemcpyAsync(slot.mem, send, n, hipMemcpyDeviceToDevice, cs));
                 ST_HIP(hipEventRecord(slot.ready, cs));
             } else memcpy(slot.mem, send, n);
@@ -269,6 +295,10 @@ int Engine::dist_gather(uint64_t handle, CameraState& c, const void* frame, void
                 if (has_device) {
                     if (slot.ready) ST_HIP(hipStreamWaitEvent(cs, slot.ready, 0));
                     ST_HIP(hipMemcpyAsync(dst, slot.mem, slot.bytes, slot.device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, cs));
+                    if (slot.device) {
+                        if (!slot.consumed) ST_HIP(hipEventCreateWithFlags(&slot.consumed, hipEventDisableTiming));
+                        ST_HIP(hipEventRecord(slot.consumed, cs)); slot.consumed_recorded = true;
+                    }
                 } else memcpy(dst, slot.mem, slot.bytes);
                 slot.taken = slot.seq;
             }

@@ -465,6 +465,7 @@ struct Engine {
     // multi-GPU (st_dist.cpp)
     DistState* dist = nullptr;
     void release_dist();
+    void dist_forget_camera(uint64_t handle);
     int dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, uint32_t apron);
     int dist_gather(uint64_t handle, CameraState& c, const void* frame, void* full, hipStream_t stream);
     int dist_wait(uint64_t handle, const void* frame, hipStream_t stream, bool host);

@@ -200,7 +200,10 @@ bool Engine::refresh_instances() {
     }
     // the host bakes this refresh: instances the device moved earlier and that are not dirty now must catch up first (a rebuild reads every primitive)
     if (any_host_stale()) {
-        for (auto& inst : instances) if (inst.host_stale && inst.dirty) inst.host_stale = false;   // re-baked below anyway
+        // re-baked below anyway — but only those whose bake job WILL be queued: an instance whose mesh or material is missing is retried at a
+        // later tick, and until then its host arrays must still count as stale (debug reads catch up through bake_stale_on_host)
+        for (auto& inst : instances)
+            if (inst.host_stale && inst.dirty && meshes.count(inst.mesh) && material_slot.count(inst.material)) inst.host_stale = false;
         bake_stale_on_host();
     }
     std::vector<BakeJob> jobs; size_t total = 0;

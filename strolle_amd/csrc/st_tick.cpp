@@ -221,6 +221,9 @@ int Engine::refresh_compact_stream(SceneSet& t, hipStream_t up) {
     t.compact_entries = 0;
     if (!tuning.compact_bvh || device_bvh_len <= kLdsSceneTexels) return ST_OK;   // tiny scenes live in LDS as they are
     const uint32_t entries = device_bvh_len / 4u;
+    // the compact walk addresses entries with v_mul_u32_u24 (st_device.h any_hit_compact): 24 bits of entry number. A larger stream (8 M+
+    // triangles) keeps compact_entries = 0 and its rays walk the contract stream with any_hit_fast / traverse
+    if (entries >= (1u << 24)) return ST_OK;
     const size_t bytes = (size_t)entries * 48u;
     if (bytes > t.bvh_compact.capacity) {
         if (t.bvh_compact.ptr) ST_HIP(hipFree(t.bvh_compact.ptr));

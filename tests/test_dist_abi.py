@@ -122,3 +122,49 @@ def test_gather_says_when_a_rank_is_missing_and_when_nothing_was_set_up():
     plain.set_camera_window(cam, 16, 8, 48, 40)
     for e in (e0, e1, plain):
         e.close()
+
+
+def test_a_partition_belongs_to_the_frame_size_it_was_computed_for():
+    """st_camera_update with a new size rebuilds the camera and resets its window, while the cached partition kept the old tile —
+    peers would send the old tile's bytes, the root expect the new one's. The gather now refuses until st_dist_set_partition is called
+    again; a failed st_dist_set_partition leaves nothing behind; st_camera_delete takes the camera's partition with it."""
+    (e0, c0), (e1, c1) = _engines(2, (64, 48), group=78)
+    buf = np.zeros((96, 128, 4), np.float32)
+    e0.dist_set_partition(c0); e1.dist_set_partition(c1)
+    e1.dist_gather(c1, buf.ctypes.data); e0.dist_gather(c0, buf.ctypes.data, buf.ctypes.data)
+    for e, c in ((e0, c0), (e1, c1)):
+        e.update_camera(c, scenes.cornell_camera((128, 96)))      # a resize: buffers rebuilt, window back to the whole frame
+    with pytest.raises(StrolleError, match="size changed"):
+        e1.dist_gather(c1, buf.ctypes.data)
+    with pytest.raises(StrolleError, match="size changed"):
+        e0.dist_gather(c0, buf.ctypes.data, buf.ctypes.data)
+    o0, _ = e0.dist_set_partition(c0); o1, _ = e1.dist_set_partition(c1)
+    assert o0 == dist_partition(128, 96, 2, 0) and o1 == dist_partition(128, 96, 2, 1)
+    e1.dist_gather(c1, buf.ctypes.data); e0.dist_gather(c0, buf.ctypes.data, buf.ctypes.data)
+    # a window that no longer covers the rank's own tile is refused too
+    e1.set_camera_window(c1, 0, 0, 128, 8)
+    with pytest.raises(StrolleError, match="window no longer covers"):
+        e1.dist_gather(c1, buf.ctypes.data)
+    # a request that fails (3 columns do not divide 2 ranks) leaves no zero rectangle a later gather would accept
+    e2 = Engine(device=-1); scenes.build_cornell(e2)
+    c2 = e2.create_camera(scenes.cornell_camera((64, 48)))
+    e2.dist_init_local(0, 2, 79)
+    with pytest.raises(StrolleError, match="multiple of the column count"):
+        e2.dist_set_partition(c2, cols=3)
+    with pytest.raises(StrolleError, match="st_dist_set_partition has not been called"):
+        e2.dist_gather(c2, buf.ctypes.data, buf.ctypes.data)
+    # deleting the camera forgets its partition: a camera that reuses nothing of it has to set its own
+    e2.dist_set_partition(c2)
+    e2.delete_camera(c2)
+    c3 = e2.create_camera(scenes.cornell_camera((64, 48)))
+    with pytest.raises(StrolleError):
+        e2.dist_gather(c3, buf.ctypes.data, buf.ctypes.data)
+    for e in (e0, e1, e2):
+        e.close()
+
+
+def test_dist_init_refuses_a_truncated_unique_id():
+    e = Engine(device=-1)
+    with pytest.raises(StrolleError, match="128 bytes"):
+        e.dist_init(0, 2, b"\x01" * 64)
+    e.close()
