@@ -245,6 +245,7 @@ class Job:
         self.moving = False
         self.moving_t0 = None
         self.geometry = None          # (handle, Instance factory): re-inserted with a new transform before every tick
+        self.step_times = [] if (os.environ.get("ST_BENCH_STEP_TIMES") == "1" and world == 1) else None
 
     def animate(self):
         """bevy-strolle/examples/cornell.rs:82-93: the point light at (sin t / 2, 1.5, cos t / 2), t = elapsed seconds (one frame =
@@ -270,6 +271,11 @@ class Job:
         if world > 1 and self.gathered[k] is not None:
             self.main.wait_event(self.gathered[k])   # outs[k] may be overwritten only after its previous gather has read it
         self.engine.update_camera(self.cam, self.desc)   # Bevy calls update_camera every frame (bevy-strolle/src/stages/prepare.rs:300-340)
+        if self.step_times is not None:   # ST_BENCH_STEP_TIMES=1: host time inside st_tick / st_render_camera per step (tools/stall_probe.py reads them)
+            t0 = time.perf_counter(); self.engine.tick(self.stream); t1 = time.perf_counter()
+            self.engine.render_camera(self.cam, out.data_ptr(), self.stream); t2 = time.perf_counter()
+            self.step_times.append((self.frame_no, t0, t1 - t0, t2 - t1))
+            return out
         self.engine.tick(self.stream)
         self.engine.render_camera(self.cam, out.data_ptr(), self.stream)
         if world == 1:
@@ -378,6 +384,51 @@ def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scen
     return out
 
 
+def emulate_tiles(torch, args):
+    """`--emulate-tiles N` (one GPU): the N tile windows (+ apron) of a frame of --width x --height, rendered one after another with
+    st_camera_set_window, each from its own engine with its own temporal state, next to the full frame — the only evidence ONE GPU can give
+    for the tile split's balance: per-tile ms, max / mean, and predicted_speedup = T(full frame) / max_i T(tile_i) (the gather, 8.3 MB per
+    tile per frame, rides behind the next frame and is not in the figure). PREDICTED FROM ONE GPU: no scaling curve has been measured."""
+    from strolle_amd.distributed import tile_for_rank, tile_window
+    n = args.emulate_tiles
+    size = (args.width, args.height)
+    steps = max(3, min(args.steps, 30))
+    apron = args.apron if args.mode in ("image", "gi_diffuse") else 0
+    edges = None
+    if args.row_edges:
+        edges = [int(v) for v in args.row_edges.split(",")]
+
+    def one(window):
+        job = Job(torch, None, args, args.scene, args.mode, size, 1, 0, 0, False)
+        if window is not None:
+            job.engine.set_camera_window(job.cam, *window)
+        job.run(min(args.preroll, 48)); job.run(args.warmup)
+        torch.cuda.synchronize(); job.engine.ray_count(job.cam, reset=True)
+        el, _ = job.timed_region(steps)
+        rays = job.engine.ray_count(job.cam)
+        job.close()
+        return el / steps * 1e3, rays / steps
+
+    full_ms, full_rays = one(None)
+    tiles, windows, per_tile, rays = [], [], [], []
+    for r in range(n):
+        t = tile_for_rank(size[0], size[1], n, r, args.cols)
+        if edges is not None:   # a cost-weighted row split: row k of the grid spans [edges[k], edges[k + 1])
+            cols = args.cols or {1: 1, 2: 1, 4: 2, 8: 4}.get(n, 1)
+            row = r // cols
+            t = (t[0], edges[row], t[2], edges[row + 1])
+        w = tile_window(size[0], size[1], t, apron)
+        ms, rr = one(w)
+        tiles.append(list(t)); windows.append(list(w)); per_tile.append(round(ms, 4)); rays.append(round(rr))
+    mean = sum(per_tile) / n
+    return {"what": f"{args.scene} {size[0]}x{size[1]} mode {args.mode}: the {n} tile windows (apron {apron}) of st_dist_partition rendered one after another on ONE GPU (st_camera_set_window), each with its own engine and history",
+            "label": "predicted from one GPU - no curve measured", "tiles": n, "steps": steps, "row_edges": edges,
+            "full_frame_ms": round(full_ms, 4), "per_tile_ms": per_tile, "tile_rects": tiles, "tile_windows": windows, "rays_per_tile_frame": rays,
+            "max_over_mean": round(max(per_tile) / mean, 4), "sum_of_tiles_over_full_frame": round(sum(per_tile) / full_ms, 4),
+            "predicted_speedup": round(full_ms / max(per_tile), 3), "ideal_speedup": n,
+            "note": "sum_of_tiles_over_full_frame > 1 is what the apron's redundant pixels and a smaller launch's tail cost; predicted_speedup assumes the gather stays hidden behind the next frame (st_dist_gather on its own stream)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,6 +456,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra regions (moving light + camera, moving geometry, present path; N > 1: BASELINE configs 5 / 4 as written)")
     ap.add_argument("--extras-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"), help="frame of the N > 1 strong-scaling extras (tests shrink it)")
+    ap.add_argument("--emulate-tiles", type=int, default=0, metavar="N",
+                    help="one GPU: render the N tile windows (+ apron) of a --width x --height frame one after another and print per-tile ms, max / mean and the speed-up N GPUs could reach at best (prints its own JSON line; no headline)")
+    ap.add_argument("--row-edges", default=None, help="--emulate-tiles: row edges of the tile grid in pixels, comma separated (rows + 1 values, multiples of 8): a cost-weighted split instead of equal rows")
     args = ap.parse_args()
 
     import torch
@@ -435,6 +489,13 @@ def main():
             except TypeError:   # a torch without the device_id keyword
                 dist.init_process_group("nccl")
 
+    if args.emulate_tiles:
+        if world != 1:
+            raise SystemExit("--emulate-tiles runs on one GPU")
+        out = emulate_tiles(torch, args)
+        out["build_stamp"] = build_stamp()
+        print(json.dumps(out))
+        return
     base = (args.width, args.height)
     width, height = weak_scaling_frame(base, world) if args.scaling == "weak" else base
     rccl_ranks, backend = None, None
@@ -501,6 +562,17 @@ def main():
         import numpy as np
         np.save(args.dump_frame, frame.cpu().numpy())
     headline = (args.scene, args.mode) == ("cornell", "image")
+    # share of the pixels whose primary ray hit something (G-buffer depth != 0): a sky pixel leaves every denoiser kernel after one texel but
+    # is credited a lit pixel's algorithmic bytes, so `roofline.frac` has to be read next to this figure (`roofline.frac_lit`)
+    lit_fraction = None
+    if args.mode in ("image", "gi_diffuse"):
+        try:
+            from strolle_amd import Buffer
+            import numpy as np
+            d0 = engine.read_buffer(cam, Buffer.PRIM_GBUFFER_D0_A).reshape(height, width, 4)[window[1]:window[3], window[0]:window[2], 0]
+            lit_fraction = float(np.count_nonzero(d0) / d0.size)
+        except Exception:
+            lit_fraction = None
     engine_exact = engine.exact
     bvh_depth = engine.bvh_depth()   # read here: the N > 1 extras close this job's engine
     extras = {}
@@ -531,16 +603,30 @@ def main():
             return Instance(1 + mesh, 1 + int(npz[f"material_{mesh}"]), x)
         engine.set_bvh_refresh(2)
         job.geometry = (1 + mesh, placed)
-        job.run(args.warmup)
+        # The first ticks of this mode do one-off work (a rebuild that indexes the tree for the device refit, each device copy's first full
+        # upload, the mesh store, the first launch of k_bvh_bake's code object: tools/stall_probe.py shows them in ticks 0-2), so the warm-up
+        # is never shorter than 8 ticks; and the region is timed TWICE back to back — a one-off stall of the box (the driver's round-4 run
+        # reported 2.548 ms here, 35 ms in one of 20 frames, that no re-run of the same command reproduced: 0.82) shows up as a gap between the two.
+        job.run(max(args.warmup, 8))
         torch.cuda.synchronize(); engine.ray_count(cam, reset=True)
-        el_g, frame_g = job.timed_region(args.steps)
+        el_g1, frame_g = job.timed_region(args.steps)
         rays_g = engine.ray_count(cam)
+        el_g2, frame_g = job.timed_region(args.steps)
+        el_g = min(el_g1, el_g2); rays_g = rays_g if el_g1 <= el_g2 else engine.ray_count(cam) - rays_g
         job.geometry = None
+        if job.step_times is not None:   # where did the host spend its time in the two regions? (steps, longest tick / render call and the step it fell in)
+            last = job.step_times[-2 * args.steps:]
+            gaps = [b[1] - a[1] for a, b in zip(last, last[1:])]
+            worst_tick = max(last, key=lambda r: r[2]); worst_render = max(last, key=lambda r: r[3]); worst_gap = max(range(len(gaps)), key=lambda i: gaps[i])
+            print(f"[bench] geometry regions, host side: longest st_tick {worst_tick[2] * 1e3:.3f} ms (step {worst_tick[0] - last[0][0]}), longest st_render_camera {worst_render[3] * 1e3:.3f} ms (step {worst_render[0] - last[0][0]}), "
+                  f"longest step-to-step gap {gaps[worst_gap] * 1e3:.3f} ms (after step {worst_gap}); per step tick/render ms: " + " ".join(f"{r[2] * 1e3:.2f}/{r[3] * 1e3:.2f}" for r in last), file=sys.stderr)
         rebuilds, refits = engine.bvh_refits()
         engine.insert_instance(1 + mesh, Instance(1 + mesh, 1 + int(npz[f"material_{mesh}"]), rest))
         engine.set_bvh_refresh(0)
         extras["ms_per_step_geometry_moving"] = round(el_g / args.steps * 1e3, 4)
         extras["geometry_moving"] = {"what": f"same K steps; instance {1 + mesh} of the scene re-inserted with a new transform before every tick, BVH refitted on the device (k_bvh.hip; ST_BVH_REFIT_DEVICE)",
+                                     "regions_ms_per_step": [round(el_g1 / args.steps * 1e3, 4), round(el_g2 / args.steps * 1e3, 4)],
+                                     "regions_note": "two back-to-back regions of K steps; ms_per_step_geometry_moving is the faster one, both are given",
                                      "Mray_per_s": round(rays_g / el_g / 1e6, 2), "bvh_rebuilds": rebuilds, "bvh_refits": refits, "bvh_device_refits": engine.bvh_device_refits(),
                                      "frame_finite": bool(torch.isfinite(frame_g).all())}
         # -- the facade's present path (rust/strolle-hip/src/present.rs, examples/render_gltf.c): RGBA8 target, two device
@@ -664,6 +750,13 @@ def main():
                                     "achieved": round(r_alg / (r_ms * 1e-3) / 1e9, 2), "frac": round(r_alg / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "ms_per_frame": round(r_ms / args.steps, 5)}
             result["roofline"] = {"bound": "hbm", "kernel": name, "timing": timing, "with_one_event_pair_around_the_chain": one_pair, "with_one_event_pair_per_slot": per_slot, "wavelet_only": wavelet_only, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
+                                  # the same kernel three ways, so that ONE line says how flattering the scene is: `frac` credits every pixel the
+                                  # pass's algorithmic bytes; `frac_counter` = the counters' HBM bytes per launch (`traffic`) over the same duration;
+                                  # `frac_lit` credits only the pixels that are not sky (`lit_pixel_fraction` of the frame)
+                                  "frac_counter": None if not traffic else round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                  "lit_pixel_fraction": None if lit_fraction is None else round(lit_fraction, 4),
+                                  "frac_lit": None if lit_fraction is None else round(achieved * lit_fraction / HBM_PEAK_GBS, 5),
+                                  "frac_note": "frac = algorithmic bytes of ALL pixels / time / 8 TB/s; frac_counter = HBM bytes by the FETCH_SIZE / WRITE_SIZE counters / time / 8 TB/s; frac_lit = algorithmic bytes of the lit (non-sky) pixels only: a sky pixel leaves each denoiser kernel after one texel",
                                   "frac_of_measured_copy_ceiling": None if not copy_ceiling else round(achieved / copy_ceiling, 5),
                                   "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": round(b_bytes),
                                   "traversal_bytes_per_launch_not_hbm": round(trav / launches),

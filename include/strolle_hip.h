@@ -205,6 +205,24 @@ typedef struct StDistUniqueId { char internal[128]; } StDistUniqueId;      /* nc
 int st_dist_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, uint32_t rank, StDistRect* owned);
 /* `owned` widened by `apron` pixels on every side that has a neighbour, outward to the same 16 / 8 grid: what a rank renders. */
 int st_dist_window(uint32_t width, uint32_t height, const StDistRect* owned, uint32_t apron, StDistRect* window);
+/* Cost-weighted tiles (round 5). The equal split gives BASELINE config 5's eight tiles unequal work (one GPU rendering each tile window in
+ * turn: max / mean 1.10, profiles/r05_tile_balance.json), so a grid's row edges and — per row — its column edges can be moved. A StDistGrid is
+ * plain data that every rank holds identically: rank r owns column r % cols of row r / cols. st_dist_grid: the equal split (the tiles
+ * st_dist_partition returns). st_dist_grid_rebalance: from the current grid and ONE cost per tile in rank order (a rank's frame time: the host
+ * gathers them its own way), the grid whose rows — then each row's tiles — would cost the same if a tile's cost were spread evenly over its
+ * pixels; edges stay on the 16 x 8 pixel grid, tiles stay at least 64 x 32 pixels, and with max_step != 0 no edge moves further than that per
+ * call (max_step <= apron: every pixel a rank newly owns was already rendered by it, as apron, so its history is warm). The tiles of a valid
+ * grid are disjoint and cover the frame. st_dist_set_grid: like st_dist_set_partition, with the grid's tiles; every rank must set the same
+ * grid between the same two frames (the root sizes its receives from it). */
+#define ST_DIST_MAX_SIDE 16
+typedef struct StDistGrid {
+    uint32_t cols, rows;
+    uint32_t row_edge[ST_DIST_MAX_SIDE + 1];                    /* rows + 1 values, 0 ... height, multiples of 8 */
+    uint32_t col_edge[ST_DIST_MAX_SIDE][ST_DIST_MAX_SIDE + 1];  /* per row: cols + 1 values, 0 ... width, multiples of 16 */
+} StDistGrid;
+int st_dist_grid(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, StDistGrid* out);
+int st_dist_grid_tile(const StDistGrid* grid, uint32_t rank, StDistRect* owned);
+int st_dist_grid_rebalance(uint32_t width, uint32_t height, const StDistGrid* current, const float* tile_cost, uint32_t max_step, StDistGrid* out);
 /* RCCL transport: rank 0 makes an id (ncclGetUniqueId) and hands it to the other processes by its own means (the Rust host: a
  * pipe or MPI; bench.py: torch.distributed's store); every rank then joins with st_dist_init on its engine's device. */
 int st_dist_unique_id(StDistUniqueId* out);
@@ -217,6 +235,7 @@ int st_dist_shutdown(StEngine* e);
 int st_dist_rank(StEngine* e, int* rank, int* world);
 /* Sets the camera's window (st_camera_set_window) to this rank's tile + apron; reports both rectangles (either may be NULL). */
 int st_dist_set_partition(StEngine* e, StHandle camera, uint32_t cols, uint32_t apron, StDistRect* owned, StDistRect* window);
+int st_dist_set_grid(StEngine* e, StHandle camera, const StDistGrid* grid, uint32_t apron, StDistRect* owned, StDistRect* window);
 /* `frame`: the buffer st_render_camera just composed into on `hip_stream` (full-frame sized, the camera's output format; this
  * rank's tile of it is what travels). `full_on_root`: where rank 0 assembles the frame (may be `frame` itself: its own tile is
  * then already in place); ignored on other ranks. Returns at once; the caller alternates two frame buffers so that frame N is
@@ -274,7 +293,10 @@ typedef struct StTuning {
     uint32_t allow_deep_bvh;        /* 1: a tree deeper than the traversal stack is a warning on stderr, not ST_ERR_BVH_TOO_DEEP */
     uint32_t device_bake;           /* 1: instances are baked into world space ON THE DEVICE from object-space meshes uploaded once
                                      * (k_bvh.hip k_bvh_bake) when only transforms changed under ST_BVH_REFIT_DEVICE; 0: on the host */
-    uint32_t _reserved[3];
+    uint32_t wide_bvh;              /* fast build, scenes that do not fit LDS: every ray outside the heatmap pass walks a 4-WIDE form of the BVH — four conservative
+                                     * f16 child boxes + four links per aligned 64-B line (k_bvh.hip k_bvh_wide; the host collapses the binary tree once per build,
+                                     * the device refills the boxes after every change) — half the dependent round trips and lines of the compact binary stream */
+    uint32_t _reserved[2];
 } StTuning;
 int st_engine_get_tuning(StEngine* e, StTuning* out);
 int st_engine_set_tuning(StEngine* e, const StTuning* tuning);
@@ -368,8 +390,12 @@ int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
  * hit-test record; st_types.h), 6 the device form read back FROM the device (live copy),
  * 7-13 the inputs of the device refit (k_bvh.hip; uint32 unless noted): 7 parent of every entry (entry << 1 | child slot),
  * 8 LDS slot of every internal entry (bit 31: a task's root), 9 work items (bit 31: root of a finished task), 10 batch offsets
- * into 9, 11 (first batch, batches) per launch, 12 leaf entry of every triangle slot, 13 triangle bounds (two float4 per slot).
- * All but 6 work on host-only engines. */
+ * into 9, 11 (first batch, batches) per launch, 12 leaf entry of every triangle slot, 13 triangle bounds (two float4 per slot);
+ * 14-17 the WIDE stream (StTuning::wide_bvh; uint32 unless noted): 14 its topology as the host builds it — one word with the root's
+ * link, then 8 words per node: where each of the four child boxes lives in the device form (entry << 1 | 0 left box, 1 right box;
+ * 0xffffffff = empty slot) and the four links (index << 1 | is a leaf record) —, 15 the device-form entry of every leaf record,
+ * 16 / 17 its nodes (64 B each) and leaf records (48 B each) read back FROM the device (live copy; float4).
+ * All but 6, 16 and 17 work on host-only engines. */
 int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_t* written);
 int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame);
 /* Where an image sits in the 8192-wide atlas: x, y, width, height in texels (images.rs:115-124 `lookup`). */

@@ -101,7 +101,8 @@ pub struct StTuning {
     pub compact_bvh: u32,
     pub allow_deep_bvh: u32,
     pub device_bake: u32,
-    pub _reserved: [u32; 3],
+    pub wide_bvh: u32,
+    pub _reserved: [u32; 2],
 }
 
 /// [x0, x1) x [y0, y1) in pixels (st_dist_partition / st_dist_window)

@@ -57,6 +57,18 @@ class StDistRect(C.Structure):
         return (self.x0, self.y0, self.x1, self.y1)
 
 
+class StDistGrid(C.Structure):
+    """include/strolle_hip.h StDistGrid: a (cost-weighted) tile grid every rank holds identically."""
+    _fields_ = [("cols", C.c_uint32), ("rows", C.c_uint32), ("row_edge", C.c_uint32 * 17), ("col_edge", (C.c_uint32 * 17) * 16)]
+
+    def tiles(self):
+        return [dist_grid_tile(self, r) for r in range(self.cols * self.rows)]
+
+    def describe(self):
+        return {"cols": self.cols, "rows": self.rows, "row_edges": list(self.row_edge[:self.rows + 1]),
+                "col_edges": [list(self.col_edge[k][:self.cols + 1]) for k in range(self.rows)]}
+
+
 class StDistUniqueId(C.Structure):
     _fields_ = [("internal", C.c_char * 128)]
 
@@ -68,7 +80,7 @@ class StTuning(C.Structure):
                                           "lean_frame", "skip_scratch_stores", "di_head_on_main", "alias_gi_history", "tile_map", "tile_map_denoise")] + \
                [("side_priority", C.c_int32)] + \
                [(n, C.c_uint32) for n in ("staging", "double_buffer", "packed_base", "tick_timing", "anyhit_fast", "compact_bvh",
-                                          "allow_deep_bvh", "device_bake")] + [("_reserved", C.c_uint32 * 3)]
+                                          "allow_deep_bvh", "device_bake", "wide_bvh")] + [("_reserved", C.c_uint32 * 2)]
 
 
 class StKernelProfile(C.Structure):
@@ -312,6 +324,7 @@ class _Binding:
             self.dist_init = fn("dist_init", [vp, i32, i32, P(StDistUniqueId)]); self.dist_init_local = fn("dist_init_local", [vp, i32, i32, u64])
             self.dist_shutdown = fn("dist_shutdown", [vp]); self.dist_rank = fn("dist_rank", [vp, P(i32), P(i32)])
             self.dist_set_partition = fn("dist_set_partition", [vp, u64, u32, u32, P(StDistRect), P(StDistRect)])
+            self.dist_set_grid = fn("dist_set_grid", [vp, u64, P(StDistGrid), u32, P(StDistRect), P(StDistRect)])
             self.dist_gather = fn("dist_gather", [vp, u64, vp, vp, vp]); self.dist_wait = fn("dist_wait", [vp, u64, vp, vp, i32])
             self.dist_gather_ms = fn("dist_gather_ms", [vp, u64, P(C.c_float)])
         self.image_insert_rgba8 = fn("image_insert_rgba8", [vp, u64, u32, u32, vp, i32]); self.image_remove = fn("image_remove", [vp, u64])
@@ -653,6 +666,12 @@ class Engine(EngineBase):
         self._check(self._b.dist_set_partition(self._h, cam, cols, apron, C.byref(o), C.byref(w)))
         return o.as_tuple(), w.as_tuple()
 
+    def dist_set_grid(self, cam: int, grid: "StDistGrid", apron: int = 0):
+        """st_dist_set_grid: like dist_set_partition with the tiles of `grid` (dist_grid / dist_grid_rebalance); every rank sets the same grid."""
+        o, w = StDistRect(), StDistRect()
+        self._check(self._b.dist_set_grid(self._h, cam, C.byref(grid), apron, C.byref(o), C.byref(w)))
+        return o.as_tuple(), w.as_tuple()
+
     def dist_gather(self, cam: int, frame_ptr: int, full_ptr: int = 0, stream: int = 0):
         """st_dist_gather: this rank's tile of `frame_ptr` travels to rank 0, which assembles the frame at `full_ptr`."""
         self._check(self._b.dist_gather(self._h, cam, frame_ptr, full_ptr or None, stream))
@@ -729,6 +748,37 @@ def dist_partition(width: int, height: int, world: int, rank: int, cols: int = 0
         lib.st_last_error.restype = C.c_char_p
         raise StrolleError(lib.st_last_error().decode(errors="replace"))
     return r.as_tuple()
+
+
+def _dist_call(name, argtypes, *args):
+    lib = load_library()
+    f = getattr(lib, name)
+    f.restype = C.c_int; f.argtypes = argtypes
+    if f(*args) != 0:
+        lib.st_last_error.restype = C.c_char_p
+        raise StrolleError(lib.st_last_error().decode(errors="replace"))
+
+
+def dist_grid(width: int, height: int, world: int, cols: int = 0) -> StDistGrid:
+    """st_dist_grid: the equal split as a grid (its tiles are st_dist_partition's)."""
+    g = StDistGrid()
+    _dist_call("st_dist_grid", [C.c_uint32] * 4 + [C.POINTER(StDistGrid)], width, height, world, cols, C.byref(g))
+    return g
+
+
+def dist_grid_tile(grid: StDistGrid, rank: int):
+    r = StDistRect()
+    _dist_call("st_dist_grid_tile", [C.POINTER(StDistGrid), C.c_uint32, C.POINTER(StDistRect)], C.byref(grid), rank, C.byref(r))
+    return r.as_tuple()
+
+
+def dist_grid_rebalance(width: int, height: int, grid: StDistGrid, tile_cost, max_step: int = 0) -> StDistGrid:
+    """st_dist_grid_rebalance: the grid whose rows, then each row's tiles, would cost the same, from one cost per tile in rank order."""
+    cost = (C.c_float * (grid.cols * grid.rows))(*[float(v) for v in tile_cost])
+    out = StDistGrid()
+    _dist_call("st_dist_grid_rebalance", [C.c_uint32, C.c_uint32, C.POINTER(StDistGrid), C.POINTER(C.c_float), C.c_uint32, C.POINTER(StDistGrid)],
+               width, height, C.byref(grid), cost, max_step, C.byref(out))
+    return out
 
 
 def dist_window(width: int, height: int, owned, apron: int):

@@ -168,6 +168,50 @@ void launch_bvh_compact(const float4* bvh, uint32_t n_entries, float4* out, hipS
     if (n_entries) ST_KLAUNCH(k_bvh_compact, dim3((n_entries + 255u) / 256u), dim3(256), s, bvh, n_entries, out);
 }
 
+// ---- the WIDE stream (st_device.h any_hit_wide / closest_hit_wide; StTuning::wide_bvh): 4-wide nodes whose child boxes are the contract
+// stream's own, read from the device copy as it is NOW (after an upload, leaf patch, device bake or refit), rounded outwards to f16.
+// The topology — which binary nodes were collapsed into which wide node — is the host's (st_bvh_refresh.cpp build_wide_topology, once per
+// build of the tree): topo[8 n + c] = where child c's box lives in the contract stream (entry << 1 | 0: left box, 1: right box; ~0: empty
+// slot), topo[8 n + 4 + c] = the child's link (wide node or leaf record index << 1 | is a leaf record). leaf_entry[k] = contract entry of
+// leaf record k. One thread per node, then one per leaf record.
+__global__ __launch_bounds__(256) void k_bvh_wide(const float4* bvh, const uint32_t* topo, uint32_t n_nodes, const uint32_t* leaf_entry, uint32_t n_leaves, uint32_t links16,
+                                                  float4* nodes, float4* leaves) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    auto dn = [](float x) { return (uint32_t)__half_as_ushort(__float2half_rd(x)); };
+    auto up = [](float x) { return (uint32_t)__half_as_ushort(__float2half_ru(x)); };
+    if (i < n_nodes) {
+        uint32_t w[12], link[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t src = topo[8u * i + c];
+            link[c] = topo[8u * i + 4u + c];
+            if (src == 0xffffffffu) {   // empty slot: lower = +inf, upper = -inf — no ray enters it
+                w[3 * c] = w[3 * c + 1] = w[3 * c + 2] = 0xfc007c00u;
+            } else {
+                const float4 lo = bvh[4u * (src >> 1) + 2u * (src & 1u)], hi = bvh[4u * (src >> 1) + 2u * (src & 1u) + 1u];
+                w[3 * c] = dn(lo.x) | (up(hi.x) << 16); w[3 * c + 1] = dn(lo.y) | (up(hi.y) << 16); w[3 * c + 2] = dn(lo.z) | (up(hi.z) << 16);
+            }
+        }
+        nodes[4u * i] = make_float4(b2f(w[0]), b2f(w[1]), b2f(w[2]), b2f(w[3]));
+        nodes[4u * i + 1u] = make_float4(b2f(w[4]), b2f(w[5]), b2f(w[6]), b2f(w[7]));
+        nodes[4u * i + 2u] = make_float4(b2f(w[8]), b2f(w[9]), b2f(w[10]), b2f(w[11]));
+        nodes[4u * i + 3u] = links16 ? make_float4(b2f(link[0] | (link[1] << 16)), b2f(link[2] | (link[3] << 16)), 0.0f, 0.0f)
+                                     : make_float4(b2f(link[0]), b2f(link[1]), b2f(link[2]), b2f(link[3]));
+        return;
+    }
+    const uint32_t k = i - n_nodes;
+    if (k >= n_leaves) return;
+    const uint32_t e = leaf_entry[k];
+    const float4 d0 = bvh[4u * e], d1 = bvh[4u * e + 1u], d2 = bvh[4u * e + 2u], d3 = bvh[4u * e + 3u];
+    leaves[3u * k] = make_float4(d1.x, d1.y, d1.z, b2f((f2b(d0.y) << 2) | (f2b(d0.x) & 3u)));
+    leaves[3u * k + 1u] = make_float4(d2.x, d2.y, d2.z, d0.z);
+    leaves[3u * k + 2u] = make_float4(d3.x, d3.y, d3.z, 0.0f);
+}
+void launch_bvh_wide(const float4* bvh, const uint32_t* topo, uint32_t n_nodes, const uint32_t* leaf_entry, uint32_t n_leaves, uint32_t links16, float4* nodes, float4* leaves, hipStream_t s) {
+    const uint32_t n = n_nodes + n_leaves;
+    if (n) ST_KLAUNCH(k_bvh_wide, dim3((n + 255u) / 256u), dim3(256), s, bvh, topo, n_nodes, leaf_entry, n_leaves, links16, nodes, leaves);
+}
+
 void launch_bvh_patch_leaves(float4* bvh, const float4* tri_geo, const uint32_t* entry_of_tri, uint32_t lo, uint32_t hi, hipStream_t s) {
     if (hi > lo) ST_KLAUNCH(k_bvh_patch_leaves, dim3((hi - lo + 255u) / 256u), dim3(256), s, bvh, tri_geo, entry_of_tri, lo, hi);
 }

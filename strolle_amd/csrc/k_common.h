@@ -67,7 +67,11 @@ ST_D bool owns_pixel(const KArgs& a, U2 p) { return p.x < a.width && p.y < a.hei
 //   <false, uint32_t>  anything larger
 constexpr uint32_t kStack16Texels = 4u * 65536u;
 // (the compact stream's pointers carry a kind bit: entry << 1 | leaf — half as many entries fit a 16-bit slot)
-inline uint32_t stack16_limit(const KArgs& a) { return a.bvh_c ? kStack16Texels / 2u : kStack16Texels; }   // (32-bit slots cost 0.6 % of the dungeon frame, measured)
+// (the wide stream's 16-bit form — links inside the sort keys — needs 16-bit slots, its 32-bit form 32-bit ones: KArgs::bvh_w_links16 decides)
+inline uint32_t stack16_limit(const KArgs& a) {
+    if (a.bvh_w) return a.bvh_w_links16 ? 0xffffffffu : 0u;
+    return a.bvh_c ? kStack16Texels / 2u : kStack16Texels;   // (32-bit slots cost 0.6 % of the dungeon frame, measured)
+}
 #ifdef ST_NO_LDS_SCENE  // experiment switch (tools/ab_bench.sh): small scenes traverse through the vector L1 like large ones
 inline bool scene_fits_lds(const KArgs&) { return false; }
 #else

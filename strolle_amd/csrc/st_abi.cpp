@@ -389,7 +389,7 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
     ST_REQUIRE(e, "null engine");
     Engine* en = E(e);
     const void* p; size_t bytes;
-    if ((what == 0 || what == 1 || what == 4 || (what >= 7 && what <= 13)) && en->any_host_stale()) en->bake_stale_on_host();   // instances the device moved: the host arrays catch up
+    if ((what == 0 || what == 1 || what == 4 || (what >= 7 && what <= 15)) && en->any_host_stale()) en->bake_stale_on_host();   // instances the device moved: the host arrays catch up
     if ((what == 0 || what == 4) && en->host_stream_stale) { en->refit_stream(); en->host_stream_stale = false; }  // device refits since the host copy was current
     switch (what) {
         case 0: p = en->bvh_stream.data(); bytes = en->bvh_stream.size() * sizeof(float4); break;
@@ -415,6 +415,24 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
             if (what == 13) { p = en->tri_bounds.data(); bytes = en->tri_bounds.size() * sizeof(float4); }
             else { p = v->data(); bytes = v->size() * sizeof(uint32_t); }
             break;
+        }
+        case 14: case 15: {  // the wide stream's topology (k_bvh.hip k_bvh_wide), built here: 14 = 8 words per node (4 box sources, 4 links), preceded by
+                             // one word holding the root's link; 15 = the contract entry of every leaf record
+            if (en->host_stream_stale) { en->refit_stream(); en->host_stream_stale = false; }
+            en->expand_stream(); en->build_wide_topology(); en->wide_built_for_ = ~0ull;   // (a later tick builds its own)
+            en->readback_levels_.assign(1, en->wide_root_);
+            en->readback_levels_.insert(en->readback_levels_.end(), en->wide_topo_.begin(), en->wide_topo_.end());
+            const std::vector<uint32_t>* v = what == 14 ? &en->readback_levels_ : &en->wide_leaf_entry_;
+            p = v->data(); bytes = v->size() * sizeof(uint32_t); break;
+        }
+        case 16: case 17: {  // the wide stream as it is on the device right now (the live copy): 16 = nodes (64 B each), 17 = leaf records (48 B each)
+            if (!en->has_device || !en->scene_uploaded) return fail(ST_ERR_NO_DEVICE, "no device copy of the scene");
+            const auto& t = en->sets[en->live];
+            const size_t n = t.wide_for_entries ? (what == 16 ? (size_t)t.wide_nodes * 4u : (size_t)t.wide_leaves * 3u) : 0;
+            en->readback_.resize(n);
+            ST_HIP(hipSetDevice(en->device)); ST_HIP(hipDeviceSynchronize());
+            if (n) ST_HIP(hipMemcpy(en->readback_.data(), what == 16 ? t.bvh_wide.ptr : static_cast<const void*>(static_cast<const float4*>(t.bvh_wide.ptr) + 4u * (size_t)t.wide_nodes), n * sizeof(float4), hipMemcpyDeviceToHost));
+            p = en->readback_.data(); bytes = n * sizeof(float4); break;
         }
         default: return fail(ST_ERR_INVALID_ARGUMENT, "unknown scene buffer");
     }

@@ -110,6 +110,57 @@ void Engine::index_device_tree() {
     }
 }
 
+// The WIDE stream's topology (k_bvh.hip k_bvh_wide; st_device.h closest_hit_wide): the binary tree of the device stream (bvh_upload_,
+// entries of four texels) collapsed top-down into nodes of up to four children — a node's two children are replaced by their own children,
+// largest surface area first, until there are four or only leaf runs are left (tools/bvh4_sim.py: 3.1 children per node on the dungeon,
+// half the node steps per ray). Wide nodes are numbered in depth-first order, leaf records in stream order (a run's records stay
+// consecutive). Only WHICH boxes a node holds is decided here; the boxes themselves are read on the device, from the device's stream.
+void Engine::build_wide_topology() {
+    const uint32_t n_entries = device_bvh_len / 4u;
+    wide_topo_.clear(); wide_leaf_entry_.clear(); wide_root_ = 0u; wide_serial_++;
+    if (!n_entries) return;
+    auto internal = [&](uint32_t k) { return f2b(bvh_upload_[4u * (size_t)k].w) == 0u; };
+    auto far_child = [&](uint32_t k) { return f2b(bvh_upload_[4u * (size_t)k + 1u].w) / 64u; };
+    auto area = [&](uint32_t src) {   // of the box stored at (entry << 1 | slot)
+        const float4 lo = bvh_upload_[4u * (size_t)(src >> 1) + 2u * (src & 1u)], hi = bvh_upload_[4u * (size_t)(src >> 1) + 2u * (src & 1u) + 1u];
+        const float dx = std::max(hi.x - lo.x, 0.0f), dy = std::max(hi.y - lo.y, 0.0f), dz = std::max(hi.z - lo.z, 0.0f);
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<uint32_t> leaf_index(n_entries, 0u);
+    for (uint32_t k = 0; k < n_entries; k++) if (!internal(k)) { leaf_index[k] = (uint32_t)wide_leaf_entry_.size(); wide_leaf_entry_.push_back(k); }
+    if (!internal(0u)) { wide_root_ = 1u; return; }   // the whole tree is one leaf run: leaf record 0
+    struct Child { uint32_t src, entry; };
+    std::vector<uint32_t> head;             // binary entry that heads wide node i
+    std::vector<Child> kids;                // 4 per node (src = ~0: empty)
+    std::vector<uint32_t> node_of(n_entries, 0xffffffffu);
+    std::vector<uint32_t> todo{0u};
+    while (!todo.empty()) {
+        const uint32_t k = todo.back(); todo.pop_back();
+        node_of[k] = (uint32_t)head.size(); head.push_back(k);
+        Child ch[4]; int n = 2;
+        ch[0] = {(k << 1) | 0u, k + 1u}; ch[1] = {(k << 1) | 1u, far_child(k)};
+        while (n < 4) {
+            int pick = -1; float best = -1.0f;
+            for (int i = 0; i < n; i++) if (internal(ch[i].entry)) { const float ar = area(ch[i].src); if (ar > best) { best = ar; pick = i; } }
+            if (pick < 0) break;
+            const uint32_t e = ch[pick].entry;
+            for (int i = n; i > pick + 1; i--) ch[i] = ch[i - 1];   // the two grandchildren take the child's place, in order
+            ch[pick] = {(e << 1) | 0u, e + 1u}; ch[pick + 1] = {(e << 1) | 1u, far_child(e)};
+            n++;
+        }
+        for (int i = 0; i < 4; i++) kids.push_back(i < n ? ch[i] : Child{0xffffffffu, 0u});
+        for (int i = n - 1; i >= 0; i--) if (internal(ch[i].entry)) todo.push_back(ch[i].entry);   // depth first: the first child's subtree follows its parent
+    }
+    wide_topo_.resize(8u * head.size());
+    for (size_t i = 0; i < head.size(); i++)
+        for (int c = 0; c < 4; c++) {
+            const Child& q = kids[4u * i + c];
+            wide_topo_[8u * i + c] = q.src;
+            wide_topo_[8u * i + 4u + c] = q.src == 0xffffffffu ? 0u : (internal(q.entry) ? (node_of[q.entry] << 1) : ((leaf_index[q.entry] << 1) | 1u));
+        }
+    wide_root_ = 0u;
+}
+
 void Engine::mark_internal_starts() {
     internal_start_.assign(bvh_stream.size(), 0);
     for (size_t p = 0; p < bvh_stream.size();) {

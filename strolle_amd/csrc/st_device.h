@@ -388,13 +388,15 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, C
 }
 // Ray::trace (closest hit) with attributes resolved once, for the winning triangle.
 template <class SE> ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candidate* best);
+template <class SE> ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate* best);
 template <class SE>
 ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
     Candidate c; bool any;
 #if ST_FAST_DEVICE && !defined(ST_NO_ANYHIT_FAST)
     // the fast build's closest-hit rays outside the heatmap pass (which calls traverse() itself: its integers are the contract's) walk the
     // compact stream too when there is one: conservative boxes visit a superset of the entries, the triangle records are the same f32
-    if (a.bvh_c != nullptr) { *used_memory = 0u; any = closest_hit_compact(a, ray, stack, &c); }
+    if (a.bvh_w != nullptr) { *used_memory = 0u; any = closest_hit_wide(a, ray, stack, &c); }
+    else if (a.bvh_c != nullptr) { *used_memory = 0u; any = closest_hit_compact(a, ray, stack, &c); }
     else
 #endif
     *used_memory = traverse<false>(a, ray, kF32Max, stack, &c, &any);
@@ -631,12 +633,162 @@ ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candida
     }
     return found_any;
 }
+
+// ---- the WIDE stream (round 5; k_bvh.hip k_bvh_wide, StTuning::wide_bvh): the same rays over 4-wide nodes. Round 4's probes priced ONE more 64-B
+// line per step at +44 % and tripled box arithmetic at +20 %: the loop is bound by the lines it fetches and by its dependent round trips. The
+// compact binary entry spends 32 B (a quarter of them straddling two lines) on TWO child boxes; a wide node holds FOUR conservative f16 child
+// boxes (4 x 3 axis words, exactly what compact_slab reads) + four links in ONE aligned 64-B line. Host model (tools/bvh4_sim.py, dungeon):
+// 11.6 node steps per GI ray instead of 23.4, the same number of texels, half the lines, 0.55 x the loop iterations per wave, VALU unchanged.
+// Round 3's 4-wide nodes lost with 128-B f32 nodes (two lines, seven texels per step) and ~25 instructions of ordering; here ordering is
+//   key = (entry distance's high 16 bits | the child's 16-bit link), one v_perm_b32 per child,
+// sorted by a 5-comparator network of v_min_u32 / v_max_u32: the link travels inside the key, a push is a 16-bit LDS store of the key itself,
+// and children whose distances agree to 7 mantissa bits are visited in link order (order only, never the result).
+//   node (64 B, texel 4 n of bvh_w):  texel 0: c0.x c0.y c0.z c1.x   texel 1: c1.y c1.z c2.x c2.y   texel 2: c2.z c3.x c3.y c3.z   (word = lower | upper << 16, f16)
+//                                     texel 3: links — 16-bit form (fewer than 32768 nodes and leaf records): l0 | l1 << 16, l2 | l3 << 16, 0, 0
+//                                                      32-bit form: l0, l1, l2, l3.   link = index << 1 | is a leaf record; an empty slot has an inverted box
+//   leaf record (48 B, bvh_w_leaf_off + 48 k bytes into the same allocation): the compact stream's leaf entry; a run's records are consecutive
+// One child's key: its slab test (compact_slab's arithmetic) fused with the cut-off — a miss or a child beyond `lim` is 0xffffffff, which sorts last.
+template <class SE> struct WideKeys;
+template <> struct WideKeys<uint16_t> {   // links ride in the keys
+    static ST_D uint32_t key(float tmin, bool hit, float4 t3, int slot) {
+        const uint32_t links = slot < 2 ? f2b(t3.x) : f2b(t3.y);
+        return hit ? __builtin_amdgcn_perm(f2b(tmin), links, (slot & 1) ? 0x07060302u : 0x07060100u) : 0xffffffffu;
+    }
+    static ST_D uint32_t link(uint32_t k, float4) { return k & 0xffffu; }
+};
+template <> struct WideKeys<uint32_t> {   // the slot rides in the keys, links are picked afterwards
+    static ST_D uint32_t key(float tmin, bool hit, float4, int slot) { return hit ? ((f2b(tmin) & ~3u) | (uint32_t)slot) : 0xffffffffu; }
+    static ST_D uint32_t link(uint32_t k, float4 t3) { return f2b((k & 2u) ? ((k & 1u) ? t3.w : t3.z) : ((k & 1u) ? t3.y : t3.x)); }
+};
+template <class SE>
+ST_D uint32_t wide_key(uint32_t wx, uint32_t wy, uint32_t wz, const RaySlabs& r, float lim, float4 t3, int slot) {
+    wx = __builtin_amdgcn_alignbit(wx, wx, r.rx); wy = __builtin_amdgcn_alignbit(wy, wy, r.ry); wz = __builtin_amdgcn_alignbit(wz, wz, r.rz);
+    const float nx = fmaf(half_lo(wx), r.inv.x, r.oi.x), fx = fmaf(half_hi(wx), r.inv.x, r.oi.x);
+    const float ny = fmaf(half_lo(wy), r.inv.y, r.oi.y), fy = fmaf(half_hi(wy), r.inv.y, r.oi.y);
+    const float nz = fmaf(half_lo(wz), r.inv.z, r.oi.z), fz = fmaf(half_hi(wz), r.inv.z, r.oi.z);
+    const float tmin = fmax_(fmax_(fmax_(nx, ny), nz), 0.0f);
+    const float tmax = fmin_(fmin_(fx, fy), fz);
+    return WideKeys<SE>::key(tmin, (tmin <= tmax) & (tmin < lim), t3, slot);
+}
+// four keys in ascending order: sort three with v_min3 / v_med3 / v_max3, insert the fourth with two more v_med3 — 7 instructions
+// (the compiler finds v_med3_u32 in min / max trees only sometimes and v_min3_u32 never: stated here)
+ST_D uint32_t umin3_(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+ST_D uint32_t umax3_(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+ST_D uint32_t umed3_(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#define ST_WIDE_SORT4(k0, k1, k2, k3)                                                                                   \
+    do {                                                                                                                \
+        const uint32_t lo_ = umin3_(k0, k1, k2), md_ = umed3_(k0, k1, k2), hi_ = umax3_(k0, k1, k2), d_ = k3;           \
+        k0 = min(lo_, d_); k1 = umed3_(lo_, md_, d_); k2 = umed3_(md_, hi_, d_); k3 = max(hi_, d_);                     \
+    } while (0)
+// (ONE fetch site for both kinds of step, as in the compact loop: with a fetch in each body a wave whose lanes sit on nodes AND on leaf
+// records pays two dependent round trips per iteration — measured: the incoherent GI rays lost 10 % that way while coherent rays gained.
+// Nodes and leaf records therefore live in one allocation, the records `bvh_w_leaf_off` bytes behind its start.)
+ST_D uint32_t wide_at(const KArgs& a, uint32_t cur) { return (cur & 1u) ? a.bvh_w_leaf_off + __umul24(cur >> 1, 48u) : (cur << 5); }
+template <class SE>
+ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
+    if (a.bvh_len == 0u) return false;
+    const float limit = ray.len;
+    const RaySlabs rs = ray_slabs(ray);
+    uint32_t cur = a.bvh_w_root;
+    int sp = 0;
+    bool hit = false;
+    for (;;) {
+        const bool leaf = (cur & 1u) != 0u;
+        const float4* e = bvh_entry(a.bvh_w, wide_at(a, cur));
+        const float4 t0 = e[0], t1 = e[1], t2 = e[2];
+        float4 t3 = f4z();
+        if (!leaf) t3 = e[3];
+        asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x), "v"(t3.x));   // one round trip for the line
+        if (!leaf) {
+            uint32_t k0 = wide_key<SE>(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs, limit, t3, 0);
+            uint32_t k1 = wide_key<SE>(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs, limit, t3, 1);
+            uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, limit, t3, 2);
+            uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, limit, t3, 3);
+            ST_WIDE_SORT4(k0, k1, k2, k3);
+            if (k3 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k3, t3); sp++; } }
+            if (k2 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k2, t3); sp++; } }
+            if (k1 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k1, t3); sp++; } }
+            if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, t3); continue; }
+        } else {
+            const uint32_t head = f2b(t0.w);
+            float u, v;
+            bool found = any_triangle(ray, xyz(t0), xyz(t1), xyz(t2), limit, &u, &v);
+            if (found && (head & 2u)) {  // AlphaMode::Blend: the texel decides (exact-island fetch, as in traverse())
+                const GpuMaterial m = a.materials[f2b(t1.w)];
+                const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
+                if (bc.w < 1.0f) found = false;
+            }
+            if (found) { hit = true; break; }
+            if (head & 1u) { cur += 2u; continue; }   // the next record of the run
+        }
+        if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64]; } else break;
+    }
+    return hit;
+}
+template <class SE>
+ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate* best) {
+    best->t = kF32Max; best->tri = 0xffffffffu; best->material = 0u; best->u = 0.0f; best->v = 0.0f; best->inv_det = 1.0f;
+    if (a.bvh_len == 0u) return false;
+    const RaySlabs rs = ray_slabs(ray);
+    uint32_t cur = a.bvh_w_root;
+    int sp = 0;
+    bool found_any = false;
+    for (;;) {
+        const bool leaf = (cur & 1u) != 0u;
+        const float4* e = bvh_entry(a.bvh_w, wide_at(a, cur));
+        const float4 t0 = e[0], t1 = e[1], t2 = e[2];
+        float4 t3 = f4z();
+        if (!leaf) t3 = e[3];
+        asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x), "v"(t3.x));
+        if (!leaf) {
+            const float lim = best->t;
+            uint32_t k0 = wide_key<SE>(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs, lim, t3, 0);
+            uint32_t k1 = wide_key<SE>(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs, lim, t3, 1);
+            uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, lim, t3, 2);
+            uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, lim, t3, 3);
+            ST_WIDE_SORT4(k0, k1, k2, k3);
+            if (k3 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k3, t3); sp++; } }
+            if (k2 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k2, t3); sp++; } }
+            if (k1 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k1, t3); sp++; } }
+            if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, t3); continue; }
+        } else {
+            const uint32_t head = f2b(t0.w);
+            const V3 p0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);
+            const V3 pvec = cross(ray.dir, e2);
+            const float det = dot(e1, pvec);
+            if (!(fabsf(det) < kF32Eps)) {
+                const float inv_det = __builtin_amdgcn_rcpf(det);
+                const V3 tvec = ray.origin - p0;
+                const float u = dot(tvec, pvec) * inv_det;
+                const V3 qvec = cross(tvec, e1);
+                const float v = dot(ray.dir, qvec) * inv_det;
+                const float t = dot(e2, qvec) * inv_det;
+                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t))) {
+                    bool found = true;
+                    if (head & 2u) {
+                        const GpuMaterial m = a.materials[f2b(t1.w)];
+                        const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
+                        if (bc.w < 1.0f) found = false;
+                    }
+                    if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = head >> 2; best->material = f2b(t1.w); found_any = true; }
+                }
+            }
+            if (head & 1u) { cur += 2u; continue; }
+        }
+        if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64]; } else break;
+    }
+    return found_any;
+}
 #endif
 // Ray::intersect (shadow ray)
 template <class SE>
 ST_D bool trace_any(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
 #if ST_FAST_DEVICE && !defined(ST_NO_ANYHIT_FAST)
-    if (!a.anyhit_contract) { *used_memory = 0u; return a.bvh_c != nullptr ? any_hit_compact(a, ray, stack) : any_hit_fast(a, ray, stack); }
+    if (!a.anyhit_contract) {
+        *used_memory = 0u;
+        if (a.bvh_w != nullptr) return any_hit_wide(a, ray, stack);
+        return a.bvh_c != nullptr ? any_hit_compact(a, ray, stack) : any_hit_fast(a, ray, stack);
+    }
 #endif
     return trace_any_contract(a, ray, stack, used_memory);
 }

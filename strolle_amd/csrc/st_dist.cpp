@@ -14,6 +14,8 @@
 //           single-GPU box drive; same partition, same pack / unpack, same stream ordering, no RCCL.
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <cmath>
 #include <mutex>
 
 #include "st_engine.h"
@@ -54,6 +56,103 @@ int dist_window(uint32_t width, uint32_t height, const StDistRect* owned, uint32
     window->y0 = down(owned->y0 > apron ? owned->y0 - apron : 0u, 8u);
     window->x1 = owned->x1 >= width ? width : up(std::min<uint64_t>((uint64_t)owned->x1 + apron, width), 16u, width);
     window->y1 = owned->y1 >= height ? height : up(std::min<uint64_t>((uint64_t)owned->y1 + apron, height), 8u, height);
+    return ST_OK;
+}
+
+// ---- cost-weighted grids (round 5). The equal split above gives config 5's eight tiles unequal work (dungeon 3840x2160, one GPU rendering
+// each tile window in turn: max / mean 1.10 — the upper-left tiles hold the vaults); a grid's row edges and, per row, its column edges can
+// therefore be moved. A grid is plain data every rank holds identically: the host gathers each rank's frame time its own way (three floats
+// per rank), every rank calls st_dist_grid_rebalance with the same numbers and gets the same grid.
+int dist_grid(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, StDistGrid* g) {
+    if (!g) return fail(ST_ERR_INVALID_ARGUMENT, "null grid");
+    uint32_t rows;
+    if (!width || !height || !world) return fail(ST_ERR_INVALID_ARGUMENT, "bad partition request");
+    if (cols == 0u) default_grid(world, &cols, &rows);
+    else { if (world % cols != 0u) return fail(ST_ERR_INVALID_ARGUMENT, "world is not a multiple of the column count"); rows = world / cols; }
+    if (cols > ST_DIST_MAX_SIDE || rows > ST_DIST_MAX_SIDE) return fail(ST_ERR_INVALID_ARGUMENT, "a grid has at most 16 columns and 16 rows");
+    memset(g, 0, sizeof(*g));
+    g->cols = cols; g->rows = rows;
+    for (uint32_t k = 0; k <= rows; k++) g->row_edge[k] = split_edge(height, rows, k, 8u);
+    for (uint32_t k = 0; k < rows; k++) for (uint32_t c = 0; c <= cols; c++) g->col_edge[k][c] = split_edge(width, cols, c, 16u);
+    for (uint32_t k = 0; k < rows; k++) if (g->row_edge[k] >= g->row_edge[k + 1]) return fail(ST_ERR_INVALID_ARGUMENT, "the frame is too small for that many tiles");
+    for (uint32_t c = 0; c < cols; c++) if (g->col_edge[0][c] >= g->col_edge[0][c + 1]) return fail(ST_ERR_INVALID_ARGUMENT, "the frame is too small for that many tiles");
+    return ST_OK;
+}
+// a grid is valid for a frame when its rows tile [0, height) and every row's columns tile [0, width), edges on the 8- / 16-pixel grid
+static int grid_check(uint32_t width, uint32_t height, const StDistGrid* g) {
+    if (!g || !g->cols || !g->rows || g->cols > ST_DIST_MAX_SIDE || g->rows > ST_DIST_MAX_SIDE) return fail(ST_ERR_INVALID_ARGUMENT, "bad grid");
+    if (g->row_edge[0] != 0u || g->row_edge[g->rows] != height) return fail(ST_ERR_INVALID_ARGUMENT, "the grid's rows do not span the frame");
+    for (uint32_t k = 0; k < g->rows; k++) {
+        if (g->row_edge[k] >= g->row_edge[k + 1] || (g->row_edge[k] % 8u) != 0u) return fail(ST_ERR_INVALID_ARGUMENT, "grid rows must ascend on multiples of 8");
+        if (g->col_edge[k][0] != 0u || g->col_edge[k][g->cols] != width) return fail(ST_ERR_INVALID_ARGUMENT, "a grid row's columns do not span the frame");
+        for (uint32_t c = 0; c < g->cols; c++)
+            if (g->col_edge[k][c] >= g->col_edge[k][c + 1] || (g->col_edge[k][c] % 16u) != 0u) return fail(ST_ERR_INVALID_ARGUMENT, "grid columns must ascend on multiples of 16");
+    }
+    return ST_OK;
+}
+int dist_grid_tile(const StDistGrid* g, uint32_t rank, StDistRect* owned) {
+    if (!g || !owned || !g->cols || !g->rows || g->cols > ST_DIST_MAX_SIDE || g->rows > ST_DIST_MAX_SIDE || rank >= g->cols * g->rows) return fail(ST_ERR_INVALID_ARGUMENT, "bad grid tile request");
+    const uint32_t cx = rank % g->cols, cy = rank / g->cols;
+    owned->x0 = g->col_edge[cy][cx]; owned->x1 = g->col_edge[cy][cx + 1u]; owned->y0 = g->row_edge[cy]; owned->y1 = g->row_edge[cy + 1u];
+    return ST_OK;
+}
+// Equal-cost edges of a piecewise-constant cost density: `bp` (n + 1 ascending breakpoints from 0 to extent) and `mass` (cost between
+// consecutive breakpoints) -> `parts` + 1 edges, snapped to `align`, at least `min_size` apart, each within `max_step` of `old` (0: free).
+static void equal_cost_edges(const std::vector<double>& bp, const std::vector<double>& mass, uint32_t extent, uint32_t parts, uint32_t align, uint32_t min_size,
+                             uint32_t max_step, const uint32_t* old, uint32_t* out) {
+    double total = 0.0; for (double m : mass) total += m;
+    out[0] = 0u; out[parts] = extent;
+    for (uint32_t j = 1; j < parts; j++) {
+        double want = total * j / parts, acc = 0.0, pos = (double)extent * j / parts;
+        if (total > 0.0)
+            for (size_t i = 0; i < mass.size(); i++) {
+                if (acc + mass[i] >= want) { pos = mass[i] > 0.0 ? bp[i] + (bp[i + 1] - bp[i]) * (want - acc) / mass[i] : bp[i]; break; }
+                acc += mass[i];
+            }
+        int64_t e = (int64_t)((pos + align / 2.0) / align) * align;
+        if (max_step) {   // an edge moves by at most max_step pixels (rounded down to the grid, at least one grid step) per call
+            const int64_t step = std::max<int64_t>(align, (int64_t)max_step / align * align);
+            e = std::min<int64_t>(std::max<int64_t>(e, (int64_t)old[j] - step), (int64_t)old[j] + step);
+        }
+        out[j] = (uint32_t)std::max<int64_t>(e, 0);
+    }
+    for (uint32_t j = 1; j < parts; j++) out[j] = std::max(out[j], out[j - 1] + min_size);                 // ascending, min_size apart ...
+    for (uint32_t j = parts; j-- > 1;) out[j] = std::min(out[j], out[j + 1] - min_size);                    // ... from both ends
+}
+int dist_grid_rebalance(uint32_t width, uint32_t height, const StDistGrid* cur, const float* cost, uint32_t max_step, StDistGrid* out) {
+    if (!cost || !out) return fail(ST_ERR_INVALID_ARGUMENT, "null argument");
+    if (int rc = grid_check(width, height, cur)) return rc;
+    const uint32_t rows = cur->rows, cols = cur->cols;
+    for (uint32_t i = 0; i < rows * cols; i++) if (!(cost[i] > 0.0f) || !std::isfinite(cost[i])) return fail(ST_ERR_INVALID_ARGUMENT, "tile costs must be positive and finite");
+    if (height < rows * 32u || width < cols * 64u) return fail(ST_ERR_INVALID_ARGUMENT, "the frame is too small to rebalance that many tiles");
+    StDistGrid g = *cur;
+    // rows first: a row's work is the sum of its tiles' (its columns are then balanced among themselves), spread evenly over its height
+    std::vector<double> bp(rows + 1), mass(rows);
+    for (uint32_t k = 0; k <= rows; k++) bp[k] = cur->row_edge[k];
+    for (uint32_t k = 0; k < rows; k++) { mass[k] = 0.0; for (uint32_t c = 0; c < cols; c++) mass[k] += cost[k * cols + c]; }
+    equal_cost_edges(bp, mass, height, rows, 8u, 32u, max_step, cur->row_edge, g.row_edge);
+    // then each new row's columns, from the cost density of the old rows it overlaps (a tile's cost spread evenly over its area)
+    for (uint32_t j = 0; j < rows; j++) {
+        std::vector<uint32_t> cuts;
+        for (uint32_t k = 0; k < rows; k++) for (uint32_t c = 0; c <= cols; c++) cuts.push_back(cur->col_edge[k][c]);
+        std::sort(cuts.begin(), cuts.end()); cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+        std::vector<double> xb(cuts.begin(), cuts.end()), xm(cuts.size() - 1, 0.0);
+        for (uint32_t k = 0; k < rows; k++) {
+            const int64_t y0 = std::max<int64_t>(g.row_edge[j], cur->row_edge[k]), y1 = std::min<int64_t>(g.row_edge[j + 1], cur->row_edge[k + 1]);
+            if (y1 <= y0) continue;
+            const double share = (double)(y1 - y0) / (double)(cur->row_edge[k + 1] - cur->row_edge[k]);
+            for (uint32_t c = 0; c < cols; c++) {
+                const double x0 = cur->col_edge[k][c], x1 = cur->col_edge[k][c + 1];
+                for (size_t i = 0; i + 1 < cuts.size(); i++) {
+                    const double a = std::max<double>(x0, cuts[i]), b = std::min<double>(x1, cuts[i + 1]);
+                    if (b > a) xm[i] += cost[k * cols + c] * share * (b - a) / (x1 - x0);
+                }
+            }
+        }
+        equal_cost_edges(xb, xm, width, cols, 16u, 64u, max_step, cur->col_edge[j], g.col_edge[j]);
+    }
+    if (int rc = grid_check(width, height, &g)) return rc;
+    *out = g;
     return ST_OK;
 }
 
@@ -114,6 +213,7 @@ struct DistState {
     // not finished is ordered behind it (Engine::dist_guard), st_dist_wait waits for one buffer's gather or for all.
     struct Slot { const void* frame = nullptr; hipEvent_t done = nullptr, t0 = nullptr; bool pending = false; };
     struct CamPart { StDistRect owned{}, window{}; uint32_t cols = 0, apron = 0, width = 0, height = 0;   // width x height: the frame the partition was computed for
+                     bool has_grid = false; StDistGrid grid{};   // st_dist_set_grid: every rank's tile comes from this grid instead of the equal split
                      hipEvent_t rendered = nullptr; Slot slots[2]; uint32_t next = 0; int last = -1;
                      void* staging = nullptr; size_t staging_bytes = 0; };
     std::map<uint64_t, CamPart> cams;
@@ -169,6 +269,7 @@ static int dist_begin(Engine* en, int rank, int world) {
 
 // the tile `r` of this camera's partition, as every rank computes it
 static int rect_of(const CameraState& c, const DistState& d, const DistState::CamPart& p, int r, StDistRect* out) {
+    if (p.has_grid) return dist_grid_tile(&p.grid, (uint32_t)r, out);
     return dist_partition(c.desc.width, c.desc.height, (uint32_t)d.world, p.cols, (uint32_t)r, out);
 }
 
@@ -179,7 +280,21 @@ int Engine::dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, u
     if (int rc = dist_partition(c.desc.width, c.desc.height, (uint32_t)dist->world, cols, (uint32_t)dist->rank, &owned)) return rc;
     if (int rc = dist_window(c.desc.width, c.desc.height, &owned, apron, &window)) return rc;
     DistState::CamPart& p = dist->cams[handle];
-    p.cols = cols; p.apron = apron; p.owned = owned; p.window = window; p.width = c.desc.width; p.height = c.desc.height;
+    p.cols = cols; p.apron = apron; p.owned = owned; p.window = window; p.width = c.desc.width; p.height = c.desc.height; p.has_grid = false;
+    c.col0 = p.window.x0; c.col1 = p.window.x1; c.row0 = p.window.y0; c.row1 = p.window.y1;
+    return ST_OK;
+}
+// the same with a grid every rank holds (st_dist_grid / st_dist_grid_rebalance). A gather in flight still uses the tiles it was enqueued with
+// (the byte counts were fixed then); the next st_dist_gather of every rank must follow the same st_dist_set_grid.
+int Engine::dist_set_grid(uint64_t handle, CameraState& c, const StDistGrid& grid, uint32_t apron) {
+    if (!dist) return fail(ST_ERR_INVALID_ARGUMENT, "st_dist_init has not been called on this engine");
+    if (int rc = grid_check(c.desc.width, c.desc.height, &grid)) return rc;
+    if (grid.cols * grid.rows != (uint32_t)dist->world) return fail(ST_ERR_INVALID_ARGUMENT, "the grid does not have one tile per rank");
+    StDistRect owned{}, window{};
+    if (int rc = dist_grid_tile(&grid, (uint32_t)dist->rank, &owned)) return rc;
+    if (int rc = dist_window(c.desc.width, c.desc.height, &owned, apron, &window)) return rc;
+    DistState::CamPart& p = dist->cams[handle];
+    p.cols = grid.cols; p.apron = apron; p.owned = owned; p.window = window; p.width = c.desc.width; p.height = c.desc.height; p.has_grid = true; p.grid = grid;
     c.col0 = p.window.x0; c.col1 = p.window.x1; c.row0 = p.window.y0; c.row1 = p.window.y1;
     return ST_OK;
 }
@@ -395,6 +510,21 @@ int st_dist_set_partition(StEngine* e, StHandle camera, uint32_t cols, uint32_t 
     auto it = E(e)->cameras.find(camera);
     if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
     if (int rc = E(e)->dist_set_partition(camera, *it->second, cols, apron)) return rc;
+    const DistState::CamPart& p = E(e)->dist->cams[camera];
+    if (owned) *owned = p.owned;
+    if (window) *window = p.window;
+    return ST_OK;
+}
+int st_dist_grid(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, StDistGrid* out) { return dist_grid(width, height, world, cols, out); }
+int st_dist_grid_tile(const StDistGrid* grid, uint32_t rank, StDistRect* owned) { return dist_grid_tile(grid, rank, owned); }
+int st_dist_grid_rebalance(uint32_t width, uint32_t height, const StDistGrid* current, const float* tile_cost, uint32_t max_step, StDistGrid* out) {
+    return dist_grid_rebalance(width, height, current, tile_cost, max_step, out);
+}
+int st_dist_set_grid(StEngine* e, StHandle camera, const StDistGrid* grid, uint32_t apron, StDistRect* owned, StDistRect* window) {
+    ST_REQUIRE(e && grid, "null argument");
+    auto it = E(e)->cameras.find(camera);
+    if (it == E(e)->cameras.end()) return fail(ST_ERR_UNKNOWN_CAMERA, "camera does not exist");
+    if (int rc = E(e)->dist_set_grid(camera, *it->second, *grid, apron)) return rc;
     const DistState::CamPart& p = E(e)->dist->cams[camera];
     if (owned) *owned = p.owned;
     if (window) *window = p.window;

@@ -15,7 +15,7 @@ StTuning default_tuning() {
     t.skip_scratch_stores = t.di_head_on_main = t.alias_gi_history = 1u;
     t.tile_map = 1u; t.tile_map_denoise = 2u; t.side_priority = 0;
     t.staging = t.double_buffer = t.packed_base = 1u; t.tick_timing = 0u;
-    t.anyhit_fast = 1u; t.compact_bvh = 1u;
+    t.anyhit_fast = 1u; t.compact_bvh = 1u; t.wide_bvh = 1u;
     t.allow_deep_bvh = 0u; t.device_bake = 1u;
     return t;
 }
@@ -29,7 +29,7 @@ static void tuning_from_environment(StTuning& t) {
         {"ST_NO_VARIANCE_IN_REPROJECT", &StTuning::variance_in_reproject},
         {"ST_KEEP_ALL_PLANES", &StTuning::lean_frame}, {"ST_KEEP_SCRATCH", &StTuning::skip_scratch_stores}, {"ST_NO_GI_ALIAS", &StTuning::alias_gi_history},
         {"ST_NO_STAGING", &StTuning::staging}, {"ST_NO_DOUBLE_BUFFER", &StTuning::double_buffer}, {"ST_NO_PACKED_BASE", &StTuning::packed_base},
-        {"ST_NO_ANYHIT_FAST", &StTuning::anyhit_fast}, {"ST_NO_COMPACT_BVH", &StTuning::compact_bvh},
+        {"ST_NO_ANYHIT_FAST", &StTuning::anyhit_fast}, {"ST_NO_COMPACT_BVH", &StTuning::compact_bvh}, {"ST_NO_WIDE_BVH", &StTuning::wide_bvh},
     };
     for (const Clear& c : clears) if (const char* v = getenv(c.name)) { if (atoi(v) != 0) t.*c.field = 0u; else if (t.*c.field == 0u) t.*c.field = 1u; }
     struct Value { const char* name; uint32_t StTuning::*field; };
@@ -79,7 +79,7 @@ Engine::~Engine() {
     for (DeviceArray* d : {&d_byte_luts, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky, &d_mesh_store}) d->release();
     for (LightSet& l : light_sets) { l.buf.release(); if (l.free_ev) (void)hipEventDestroy(l.free_ev); }
     for (SceneSet& t : sets) {
-        for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed, &t.tri_geo, &t.tri_bounds, &t.entry_of_tri, &t.parent, &t.refit_local, &t.refit_items, &t.refit_batch_off, &t.bvh_compact, &t.bake_jobs, &t.bake_starts}) d->release();
+        for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed, &t.tri_geo, &t.tri_bounds, &t.entry_of_tri, &t.parent, &t.refit_local, &t.refit_items, &t.refit_batch_off, &t.bvh_compact, &t.bvh_wide, &t.wide_topo, &t.wide_leaf_entry, &t.bake_jobs, &t.bake_starts}) d->release();
         if (t.free_ev) (void)hipEventDestroy(t.free_ev);
     }
     if (copy_stream) (void)hipStreamDestroy(copy_stream);

@@ -314,6 +314,9 @@ StTuning default_tuning();  // st_engine.cpp
 struct DistState;           // st_dist.cpp: rank / world, transport, per-camera partition
 int dist_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, uint32_t rank, StDistRect* owned);
 int dist_window(uint32_t width, uint32_t height, const StDistRect* owned, uint32_t apron, StDistRect* window);
+int dist_grid(uint32_t width, uint32_t height, uint32_t world, uint32_t cols, StDistGrid* out);
+int dist_grid_tile(const StDistGrid* g, uint32_t rank, StDistRect* owned);
+int dist_grid_rebalance(uint32_t width, uint32_t height, const StDistGrid* cur, const float* cost, uint32_t max_step, StDistGrid* out);
 
 struct Engine {
     int device = -1;
@@ -416,6 +419,9 @@ struct Engine {
     struct SceneSet {
         DeviceArray bvh, tri_attr, xforms, materials, base_packed;
         DeviceArray bvh_compact; uint32_t compact_entries = 0;   // k_bvh.hip k_bvh_compact: 48 B per entry, regenerated whenever `bvh` changed
+        // k_bvh.hip k_bvh_wide: 4-wide nodes (64 B) + leaf records (48 B), regenerated whenever `bvh` changed; the topology arrays only when the tree was rebuilt
+        DeviceArray bvh_wide /* the nodes, then the leaf records */, wide_topo, wide_leaf_entry; uint32_t wide_nodes = 0, wide_leaves = 0, wide_root = 0, wide_links16 = 0, wide_for_entries = 0;
+        uint64_t wide_topology_serial = 0;   // which build_wide_topology() result this copy holds
         // ST_BVH_REFIT_DEVICE: what k_bvh.hip needs beside the stream — per triangle slot the hit-test record, the bounds and the
         // device entry that holds it; per entry its parent (entry << 1 | child slot); the leaf runs; an arrival counter per entry.
         // tree_version says which build of the tree these (and the stream's topology) belong to.
@@ -466,7 +472,13 @@ struct Engine {
     DistState* dist = nullptr;
     void release_dist();
     void dist_forget_camera(uint64_t handle);
+    // the wide stream's topology (st_bvh_refresh.cpp build_wide_topology), from bvh_upload_: 8 words per node (4 box sources, 4 links) and the
+    // contract entry of every leaf record; wide_serial_ counts the builds
+    std::vector<uint32_t> wide_topo_, wide_leaf_entry_; uint32_t wide_root_ = 0; uint64_t wide_serial_ = 0; uint64_t wide_built_for_ = ~0ull;
+    void build_wide_topology();
+    int refresh_wide_stream(SceneSet& t, hipStream_t up, bool topology_changed, bool* pageable);
     int dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, uint32_t apron);
+    int dist_set_grid(uint64_t handle, CameraState& c, const StDistGrid& grid, uint32_t apron);
     int dist_gather(uint64_t handle, CameraState& c, const void* frame, void* full, hipStream_t stream);
     int dist_wait(uint64_t handle, const void* frame, hipStream_t stream, bool host);
     void dist_guard(uint64_t handle, const void* out, hipStream_t s);

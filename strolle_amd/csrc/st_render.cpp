@@ -122,6 +122,11 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     const bool compact = arithmetic == ST_ARITH_FAST && tuning.compact_bvh && tuning.anyhit_fast && !count_bytes && scene.compact_entries != 0u && scene.compact_entries * 4u == device_bvh_len;
     a.bvh_c = compact ? static_cast<const float4*>(scene.bvh_compact.ptr) : nullptr;
     a.bvh_c_root = (compact && device_root_is_leaf) ? 1u : 0u;
+    // ... or, preferred, its wide form (k_bvh.hip k_bvh_wide)
+    const bool wide = compact && tuning.wide_bvh && scene.wide_for_entries != 0u && scene.wide_for_entries * 4u == device_bvh_len;
+    a.bvh_w = wide ? static_cast<const float4*>(scene.bvh_wide.ptr) : nullptr;
+    a.bvh_w_leaf_off = wide ? scene.wide_nodes * 64u : 0u;
+    a.bvh_w_root = wide ? scene.wide_root : 0u; a.bvh_w_links16 = wide ? scene.wide_links16 : 0u;
     a.anyhit_contract = (count_bytes || !tuning.anyhit_fast) ? 1u : 0u;   // the reference's used_memory is the contract loop's
     a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
     a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;

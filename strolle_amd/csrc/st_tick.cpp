@@ -133,6 +133,7 @@ int Engine::tick(hipStream_t stream) {
                 }
             }
             if ((rc = refresh_compact_stream(t, up))) return rc;   // the shadow rays' compact form follows every change of the contract stream
+            if ((rc = refresh_wide_stream(t, up, !device_path, flag))) return rc;   // and so does the wide form (its topology only when the tree itself was sent)
             // attribute records: whole the first time or after they grew, otherwise only the slots baked since this copy was written
             const bool partial = t.valid && !t.tri_full && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
             if (!partial) {
@@ -213,6 +214,37 @@ int Engine::tick(hipStream_t stream) {
             return fail(ST_ERR_BVH_TOO_DEEP, "the BVH is " + std::to_string(bvh_stack_need) + " internal nodes deep, the kernels' traversal stack holds " + std::to_string(kBvhStackSize) +
                                              " pending entries (strolle-gpu/src/lib.rs:76): pushes beyond it are dropped and geometry behind them can be missed. The scene was uploaded and renders; StTuning::allow_deep_bvh = 1 accepts this");
     }
+    return ST_OK;
+}
+
+// The wide stream (k_bvh.hip k_bvh_wide) of device copy `t`: topology from the host when the tree was (re)sent, boxes and leaf records from that
+// copy's contract stream as it is on the device right now.
+int Engine::refresh_wide_stream(SceneSet& t, hipStream_t up, bool topology_changed, bool* pageable) {
+    if (!tuning.wide_bvh || !tuning.compact_bvh || device_bvh_len <= kLdsSceneTexels) { t.wide_nodes = t.wide_leaves = 0u; t.wide_for_entries = 0u; return ST_OK; }
+    int rc;
+    if (topology_changed || t.wide_for_entries != device_bvh_len / 4u) {
+        if (!topology_changed && wide_built_for_ != tree_version) return ST_OK;   // (cannot happen: a copy on the device path holds this tree's topology)
+        if (wide_built_for_ != tree_version || wide_topo_.empty()) { build_wide_topology(); wide_built_for_ = tree_version; }
+        const uint32_t nodes = (uint32_t)(wide_topo_.size() / 8u), leaves = (uint32_t)wide_leaf_entry_.size();
+        t.wide_nodes = t.wide_leaves = 0u; t.wide_for_entries = 0u;
+        if (nodes >= (1u << 23) || leaves >= (1u << 23)) return ST_OK;   // v_mul_u32_u24 addressing and the << 5 of a node link: larger trees keep the binary streams
+        if (nodes && (rc = t.wide_topo.upload(wide_topo_.data(), wide_topo_.size() * sizeof(uint32_t), up, staging, pageable))) return rc;
+        if (leaves && (rc = t.wide_leaf_entry.upload(wide_leaf_entry_.data(), wide_leaf_entry_.size() * sizeof(uint32_t), up, staging, pageable))) return rc;
+        // one allocation: nodes (64 B each), then the leaf records (48 B each) + one texel of slack (a node step's fourth texel is never read for a record)
+        const size_t need = (size_t)nodes * 64u + (size_t)leaves * 48u + 64u;
+        if (need > 0xfffffff0ull) return ST_OK;   // 32-bit byte offsets
+        if (need > t.bvh_wide.capacity) {
+            if (t.bvh_wide.ptr) ST_HIP(hipFree(t.bvh_wide.ptr));
+            t.bvh_wide.ptr = nullptr; t.bvh_wide.capacity = 0;
+            ST_HIP(hipMalloc(&t.bvh_wide.ptr, need + need / 2)); t.bvh_wide.capacity = need + need / 2;
+        }
+        t.wide_nodes = nodes; t.wide_leaves = leaves; t.wide_root = wide_root_; t.wide_for_entries = device_bvh_len / 4u;
+        t.wide_links16 = (nodes < 32768u && leaves < 32768u) ? 1u : 0u;
+        t.wide_topology_serial = wide_serial_;
+    }
+    if (!t.wide_for_entries) return ST_OK;
+    launchers_exact().launch_bvh_wide(static_cast<const float4*>(t.bvh.ptr), static_cast<const uint32_t*>(t.wide_topo.ptr), t.wide_nodes, static_cast<const uint32_t*>(t.wide_leaf_entry.ptr), t.wide_leaves,
+                                      t.wide_links16, static_cast<float4*>(t.bvh_wide.ptr), static_cast<float4*>(t.bvh_wide.ptr) + 4u * (size_t)t.wide_nodes, up);
     return ST_OK;
 }
 

@@ -84,6 +84,10 @@ struct KArgs {
     const float4* gi_mid_src;  // kLeanGiMid, second-pass launch only: the first preview pass's input plane (nullptr: GI_RESERVOIRS_3 holds every first-pass result)
     const float4* bvh_c;       // fast build: the compact stream the shadow rays walk (k_bvh.hip k_bvh_compact; nullptr: they walk `bvh`)
     uint32_t bvh_c_root;       // ... its entry 0 with the kind bit (entry << 1 | is a leaf entry)
+    const float4* bvh_w;       // fast build: the WIDE stream's nodes (k_bvh.hip k_bvh_wide: four f16 child boxes + four links per 64-B line; nullptr: none)
+    uint32_t bvh_w_leaf_off;   // ... byte offset of its leaf records (48 B each) in the same allocation
+    uint32_t bvh_w_root;       // ... the root's link (index << 1 | is a leaf record)
+    uint32_t bvh_w_links16;    // ... 1: links are 16-bit (fewer than 32768 nodes and leaf records): kernels run with 16-bit stack slots
     uint32_t exp_flags;        // A/B switches of experiments in flight (ST_EXP in the environment; 0 in the shipped configuration)
     uint32_t anyhit_contract;  // fast build: shadow rays walk the contract loop (set while the reference's used_memory bytes are counted, or by StTuning::anyhit_fast = 0)
     uint32_t count_bytes;  // st_profile_enable bit 1: kernels also sum the reference's used_memory over their rays

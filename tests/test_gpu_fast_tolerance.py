@@ -320,3 +320,56 @@ def test_axis_parallel_rays_walk_the_compact_stream_like_the_contract_stream():
         assert np.isfinite(exact[..., 0]).sum() > 100, "the soup is not in view"
         for e, _ in engines:
             e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("triangles,links16", [(3000, True), (40000, False)])
+def test_the_wide_stream_finds_what_the_contract_walk_finds(triangles, links16):
+    """StTuning::wide_bvh (round 5): the fast build's rays walk 4-wide nodes (k_bvh.hip k_bvh_wide, st_device.h closest_hit_wide / any_hit_wide) —
+    in the 16-bit form (links inside the sort keys, fewer than 32768 nodes and leaf records) and in the 32-bit form. Primary hits of a Reference
+    frame against the exact build's contract walk, the same gate as the compact stream's; the device's wide stream read back: every child box
+    contains the contract stream's box it was made from (conservative f16), every leaf record is its contract entry's triangle."""
+    torch = _torch()
+    size = (96, 64)
+    frames = {}
+    for name, exact, tuning in (("wide", False, {}), ("compact", False, {"wide_bvh": 0}), ("exact", True, {})):
+        e = Engine(device=0, exact=exact)
+        if tuning:
+            e.set_tuning(**tuning)
+        scenes.build_random_soup(e, triangles, seed=5, n_lights=2)
+        e.set_seed(3)
+        desc = scenes.camera_for(size, (0.1, 0.2, 3.0), (0.0, 0.0, 0.0), CameraMode.REFERENCE, depth=1)
+        cam = e.create_camera(desc)
+        out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+        e.update_camera(cam, desc); e.tick(); e.render_camera(cam, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        frames[name] = (e.read_buffer(cam, Buffer.REF_HITS).reshape(size[1], size[0], -1), out.cpu().numpy()[..., :3])
+        if name == "wide":
+            nodes = e.read_scene(16).view(np.uint32).reshape(-1, 16)
+            leaves = e.read_scene(17).reshape(-1, 3, 4)
+            stream = e.read_scene(6).reshape(-1, 4, 4)
+            topo = e.read_scene(14).view(np.uint32)[1:].reshape(-1, 8)
+            leaf_entry = e.read_scene(15).view(np.uint32)
+            assert len(nodes) == len(topo) and len(leaves) == len(leaf_entry) and len(nodes) > 0, "the wide stream was not built"
+            assert (len(nodes) < 32768 and len(leaves) < 32768) == links16
+            words = nodes[:, :12].reshape(-1, 4, 3)
+            lo16 = (words & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32); hi16 = (words >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+            src = topo[:, :4]
+            live = src != 0xffffffff
+            at = np.where(live, src, 0)
+            lo32 = stream[at >> 1, 2 * (at & 1), :3]; hi32 = stream[at >> 1, 2 * (at & 1) + 1, :3]
+            assert (lo16[live] <= lo32[live]).all() and (hi16[live] >= hi32[live]).all(), "a wide child box does not contain the contract stream's"
+            assert (np.abs(lo16[live] - lo32[live]) <= 2e-3 * np.maximum(1.0, np.abs(lo32[live]))).all(), "f16 rounding grew a box by more than 2^-9"
+            assert np.isinf(lo16[~live]).all() and (lo16[~live] > 0).all() and (hi16[~live] < 0).all(), "an empty slot is not an inverted box"
+            links = nodes[:, 12:14].view(np.uint16).reshape(-1, 4).astype(np.uint32) if links16 else nodes[:, 12:16]
+            assert np.array_equal(links[live], topo[:, 4:][live])
+            assert np.array_equal(leaves[:, :, :3], stream[leaf_entry, 1:4, :3]), "a leaf record is not its contract entry's triangle"
+        e.close()
+    want = frames["exact"][0]
+    assert np.isfinite(want[..., 0]).sum() > 500, "the soup is not in view"
+    for name in ("wide", "compact"):
+        bad = lanes_outside_tolerance(frames[name][0], want, rtol=1e-4, atol=1e-5).reshape(want.shape).any(-1)
+        assert bad.mean() <= 2e-3, f"{name}: {bad.mean():.2e} of the primary hits differ from the contract walk"
+        peak = float(np.percentile(frames["exact"][1], 99.9)) or 1.0
+        p = psnr(np.clip(frames[name][1], 0, peak), np.clip(frames["exact"][1], 0, peak), peak)
+        assert p >= 40.0, f"{name}: shaded Reference frame (primary + shadow rays) PSNR {p:.1f} dB against the exact build"
