@@ -232,6 +232,7 @@ class Job:
             else:
                 self.window = tile_window(self.width, self.height, self.tile, self.apron)
                 self.engine.set_camera_window(self.cam, *self.window)
+        self.grid = None              # a cost-weighted grid (Job.set_grid) instead of the equal split
         self.dev = f"cuda:{local_rank}"
         # double-buffered render targets: frame i is gathered on `comm` while frame i+1 renders on `main`
         self.outs = [torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=self.dev) for _ in range(2 if world > 1 else 1)]
@@ -246,6 +247,21 @@ class Job:
         self.moving_t0 = None
         self.geometry = None          # (handle, Instance factory): re-inserted with a new transform before every tick
         self.step_times = [] if (os.environ.get("ST_BENCH_STEP_TIMES") == "1" and world == 1) else None
+
+    def set_grid(self, grid):
+        """every rank's tile from `grid` (api.StDistGrid: st_dist_grid / st_dist_grid_rebalance) from the next frame on"""
+        from strolle_amd.api import dist_grid_tile
+        from strolle_amd.distributed import tile_window
+        self.grid = grid
+        self.tile = dist_grid_tile(grid, self.rank)
+        self.band = (self.tile[1], self.tile[3])
+        if self.c_abi_gather:
+            self.engine.dist_wait(self.cam)   # gathers in flight were sized by the old tiles
+            owned, self.window = self.engine.dist_set_grid(self.cam, grid, apron=self.apron)
+            assert owned == self.tile
+        else:
+            self.window = tile_window(self.width, self.height, self.tile, self.apron)
+            self.engine.set_camera_window(self.cam, *self.window)
 
     def animate(self):
         """bevy-strolle/examples/cornell.rs:82-93: the point light at (sin t / 2, 1.5, cos t / 2), t = elapsed seconds (one frame =
@@ -293,11 +309,11 @@ class Job:
             if self.debug_shared:
                 self.comm.synchronize()
                 host_full = torch.zeros((self.height, self.width, 4)) if rank == 0 else None
-                gather_tiles_to_root(out.cpu(), host_full, world, rank, self.cols)
+                gather_tiles_to_root(out.cpu(), host_full, world, rank, self.cols, tiles=None if self.grid is None else self.grid.tiles())
                 if rank == 0:
                     self.full.copy_(host_full)
             else:
-                gather_tiles_to_root(out, self.full, world, rank, self.cols)   # --py-gather: the torch.distributed fallback
+                gather_tiles_to_root(out, self.full, world, rank, self.cols, tiles=None if self.grid is None else self.grid.tiles())   # --py-gather: the torch.distributed fallback
             done = torch.cuda.Event(enable_timing=True); done.record(self.comm)
         self.gather_events.append((g0, done))
         self.gathered[k] = done
@@ -350,8 +366,30 @@ class Job:
     def gathered_bytes(self):
         """what arrives at rank 0 per frame: every tile but its own"""
         from strolle_amd.distributed import tile_for_rank
-        t0 = tile_for_rank(self.width, self.height, self.world, 0, self.cols)
+        t0 = tile_for_rank(self.width, self.height, self.world, 0, self.cols) if self.grid is None else self.grid.tiles()[0]
         return (self.width * self.height - (t0[2] - t0[0]) * (t0[3] - t0[1])) * 16
+
+    def balance(self, rounds, frames):
+        """Cost-weighted tiles: `rounds` times, every rank times `frames` frames of its own (no barrier inside), the ranks exchange the
+        figures (one float each over torch.distributed: plumbing), and all compute the same new grid with st_dist_grid_rebalance — edges move
+        by at most the apron per round, so every pixel a rank newly owns was rendered by it before (as apron) and has warm history.
+        Returns what happened per round."""
+        from strolle_amd.api import dist_grid, dist_grid_rebalance
+        torch, dist = self.torch, self.dist
+        log = []
+        grid = self.grid if self.grid is not None else dist_grid(self.width, self.height, self.world, self.cols)
+        on = "cpu" if self.debug_shared else self.dev
+        for _ in range(rounds):
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter(); self.run(frames); torch.cuda.synchronize()
+            mine = (time.perf_counter() - t0) / frames * 1e3
+            each = [torch.zeros(1, dtype=torch.float64, device=on) for _ in range(self.world)]
+            dist.all_gather(each, torch.tensor([mine], dtype=torch.float64, device=on))
+            ms = [float(x[0]) for x in each]
+            log.append({"per_rank_ms": [round(v, 4) for v in ms], "max_over_mean": round(max(ms) / (sum(ms) / len(ms)), 4), "grid": grid.describe()})
+            grid = dist_grid_rebalance(self.width, self.height, grid, ms, max_step=max(self.apron, 16))
+            self.set_grid(grid)
+        return log
 
     def close(self):
         self.torch.cuda.synchronize()
@@ -364,7 +402,9 @@ def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scen
     tiles gathered to rank 0 every frame — timed like the main region (barrier + synchronize on both sides, max over ranks)."""
     job = Job(torch, dist, args, scene, mode_name, size, world, rank, local_rank, debug_shared)
     steps = max(2, min(args.steps, 30))
-    job.run(min(args.preroll, 48)); job.run(args.warmup)
+    job.run(min(args.preroll, 48))
+    balance_log = job.balance(args.balance_rounds, 6) if (args.balance_rounds and job.needs_apron and world > 1) else []
+    job.run(args.warmup)
     torch.cuda.synchronize()
     job.engine.ray_count(job.cam, reset=True); job.gather_events.clear()
     elapsed, frame = job.timed_region(steps)
@@ -378,6 +418,8 @@ def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scen
            "tile": [job.tile[2] - job.tile[0], job.tile[3] - job.tile[1]], "band_rows": job.band[1] - job.band[0], "apron_rows": job.apron,
            "gather": "st_dist_gather (RCCL through the C ABI)" if job.c_abi_gather else "torch.distributed fallback",
            "apron_overhead_frac": apron_overhead(job.width, job.height, world, job.apron, job.cols),
+           "balance": {"rounds": balance_log, "final_grid": None if job.grid is None else job.grid.describe(),
+                       "what": "cost-weighted tiles (st_dist_grid_rebalance): each round every rank times 6 frames, the ranks exchange one float each, edges move by at most the apron"} if balance_log else None,
            "n1_ms_reference": n1_reference(key), "n1_ms_reference_source": "profiles/n1_reference.json (builder-run single-GPU figure, not measured by this process)",
            "frame_finite": finite}
     job.close()
@@ -394,9 +436,7 @@ def emulate_tiles(torch, args):
     size = (args.width, args.height)
     steps = max(3, min(args.steps, 30))
     apron = args.apron if args.mode in ("image", "gi_diffuse") else 0
-    edges = None
-    if args.row_edges:
-        edges = [int(v) for v in args.row_edges.split(",")]
+    from strolle_amd.api import dist_grid, dist_grid_rebalance
 
     def one(window):
         job = Job(torch, None, args, args.scene, args.mode, size, 1, 0, 0, False)
@@ -410,23 +450,26 @@ def emulate_tiles(torch, args):
         return el / steps * 1e3, rays / steps
 
     full_ms, full_rays = one(None)
-    tiles, windows, per_tile, rays = [], [], [], []
-    for r in range(n):
-        t = tile_for_rank(size[0], size[1], n, r, args.cols)
-        if edges is not None:   # a cost-weighted row split: row k of the grid spans [edges[k], edges[k + 1])
-            cols = args.cols or {1: 1, 2: 1, 4: 2, 8: 4}.get(n, 1)
-            row = r // cols
-            t = (t[0], edges[row], t[2], edges[row + 1])
-        w = tile_window(size[0], size[1], t, apron)
-        ms, rr = one(w)
-        tiles.append(list(t)); windows.append(list(w)); per_tile.append(round(ms, 4)); rays.append(round(rr))
-    mean = sum(per_tile) / n
-    return {"what": f"{args.scene} {size[0]}x{size[1]} mode {args.mode}: the {n} tile windows (apron {apron}) of st_dist_partition rendered one after another on ONE GPU (st_camera_set_window), each with its own engine and history",
-            "label": "predicted from one GPU - no curve measured", "tiles": n, "steps": steps, "row_edges": edges,
-            "full_frame_ms": round(full_ms, 4), "per_tile_ms": per_tile, "tile_rects": tiles, "tile_windows": windows, "rays_per_tile_frame": rays,
-            "max_over_mean": round(max(per_tile) / mean, 4), "sum_of_tiles_over_full_frame": round(sum(per_tile) / full_ms, 4),
-            "predicted_speedup": round(full_ms / max(per_tile), 3), "ideal_speedup": n,
-            "note": "sum_of_tiles_over_full_frame > 1 is what the apron's redundant pixels and a smaller launch's tail cost; predicted_speedup assumes the gather stays hidden behind the next frame (st_dist_gather on its own stream)"}
+    grid = dist_grid(size[0], size[1], n, args.cols)
+    rounds = []
+    for it in range(1 + (args.balance_rounds if apron else 0)):   # round 0: the equal split; then st_dist_grid_rebalance from the measured tile times
+        tiles, windows, per_tile = grid.tiles(), [], []
+        for t in tiles:
+            w = tile_window(size[0], size[1], t, apron)
+            ms, _ = one(w)
+            windows.append(list(w)); per_tile.append(round(ms, 4))
+        mean = sum(per_tile) / n
+        rounds.append({"grid": grid.describe(), "per_tile_ms": per_tile, "tile_rects": [list(t) for t in tiles], "tile_windows": windows,
+                       "max_over_mean": round(max(per_tile) / mean, 4), "sum_of_tiles_over_full_frame": round(sum(per_tile) / full_ms, 4),
+                       "predicted_speedup": round(full_ms / max(per_tile), 3)})
+        grid = dist_grid_rebalance(size[0], size[1], grid, per_tile)
+    best = max(rounds, key=lambda r: r["predicted_speedup"])
+    return {"what": f"{args.scene} {size[0]}x{size[1]} mode {args.mode}: the {n} tile windows (apron {apron}) rendered one after another on ONE GPU (st_camera_set_window), each with its own engine and history; round 0 = st_dist_partition's equal split, later rounds = st_dist_grid_rebalance from the previous round's tile times",
+            "label": "predicted from one GPU - no curve measured", "tiles": n, "steps": steps, "full_frame_ms": round(full_ms, 4), "ideal_speedup": n,
+            "equal_split": {k: rounds[0][k] for k in ("per_tile_ms", "max_over_mean", "predicted_speedup", "sum_of_tiles_over_full_frame")},
+            "balanced": {k: best[k] for k in ("per_tile_ms", "max_over_mean", "predicted_speedup", "sum_of_tiles_over_full_frame", "grid")},
+            "rounds": rounds,
+            "note": "sum_of_tiles_over_full_frame > 1 is what the apron's redundant pixels and a smaller launch's tail cost; predicted_speedup = T(full frame) / max_i T(tile_i) assumes the gather stays hidden behind the next frame (st_dist_gather on its own stream)"}
 
 
 def main():
@@ -458,7 +501,7 @@ def main():
     ap.add_argument("--extras-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"), help="frame of the N > 1 strong-scaling extras (tests shrink it)")
     ap.add_argument("--emulate-tiles", type=int, default=0, metavar="N",
                     help="one GPU: render the N tile windows (+ apron) of a --width x --height frame one after another and print per-tile ms, max / mean and the speed-up N GPUs could reach at best (prints its own JSON line; no headline)")
-    ap.add_argument("--row-edges", default=None, help="--emulate-tiles: row edges of the tile grid in pixels, comma separated (rows + 1 values, multiples of 8): a cost-weighted split instead of equal rows")
+    ap.add_argument("--balance-rounds", type=int, default=4, help="N > 1 strong-scaling extras (Image modes) and --emulate-tiles: rounds of cost-weighted tile rebalancing (st_dist_grid_rebalance) before the timed region; 0 = the equal split")
     args = ap.parse_args()
 
     import torch
@@ -689,7 +732,8 @@ def main():
                                  "dungeon134k": "SYNTHETIC: the dungeon with every triangle split into 16, same materials and lights"}[args.scene],
                        "arithmetic": "exact (bit-identical to the CPU oracle)" if engine_exact else "fast (hardware rcp/sqrt/exp/log, FMA contraction; traversal exact; tolerances in tests/test_gpu_fast_tolerance.py)",
                        "width": width, "height": height,
-                       "bvh_deepest_internal_chain": bvh_depth[0], "bvh_stack_entries": bvh_depth[1],   # deeper than the stack = dropped pushes (st_debug_bvh_depth)
+                       "bvh_deepest_internal_chain": bvh_depth[0], "bvh_stack_entries": bvh_depth[1],   # deeper than the stack = dropped pushes (st_debug_bvh_depth): the contract walks' stack is as deep as the tree needs, up to 32
+                       "dropped_pushes": "none: contract walks hold the tree's deepest chain (tests/test_c_abi.py); the wide walk keeps 24 entries and renders the same bits with 48 (tests/test_gpu_fast_tolerance.py test_the_wide_walk_drops_no_push); the oracle drops none at 24 and its deepest stack on config 3's scene is 13 (tests/test_wide_bvh.py)" if bvh_depth[0] <= bvh_depth[1] else "POSSIBLE: the tree is deeper than the 32-entry stack",
                        "per_gpu_rows": band[1] - band[0], "apron_rows": (args.apron if needs_apron else 0) if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
                        **({"DEBUG_NOT_A_RESULT": "ranks share cuda:0, gather through gloo + host copies"} if debug_shared else {}),

@@ -296,7 +296,8 @@ typedef struct StTuning {
     uint32_t wide_bvh;              /* fast build, scenes that do not fit LDS: every ray outside the heatmap pass walks a 4-WIDE form of the BVH — four conservative
                                      * f16 child boxes + four links per aligned 64-B line (k_bvh.hip k_bvh_wide; the host collapses the binary tree once per build,
                                      * the device refills the boxes after every change) — half the dependent round trips and lines of the compact binary stream */
-    uint32_t _reserved[2];
+    uint32_t wide_stack_entries;    /* pending entries per ray of the wide walk's stack: 0 = 24 (strolle-gpu/src/lib.rs:76); tests render with 48 to show that 24 drops no push */
+    uint32_t _reserved[1];
 } StTuning;
 int st_engine_get_tuning(StEngine* e, StTuning* out);
 int st_engine_set_tuning(StEngine* e, const StTuning* tuning);

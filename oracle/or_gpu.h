@@ -252,6 +252,13 @@ struct SceneView {  // what the shaders bind: triangles, bvh, materials, atlas
 };
 enum Tracing { ReturnClosest, ReturnFirst };
 static const int BVH_STACK_SIZE = 24;  // lib.rs:76
+// Test-only switches of the checker (or_debug_set_stack_limit / or_debug_stack_stats): the number of pending entries a ray may keep (24 as the
+// reference's lib.rs:76 by default; up to BVH_STACK_MAX stands for "unbounded": the deepest chain of any scene here is 26) and what the rays
+// actually needed — pushes that were dropped at the limit and the deepest stack any ray reached. Process-wide, relaxed atomics.
+static const int BVH_STACK_MAX = 64;
+static int g_or_stack_limit = BVH_STACK_SIZE;
+static unsigned long long g_or_dropped_pushes = 0;
+static int g_or_deepest_stack = 0;
 
 struct Ray {
     Vec3 origin, dir, inv_dir; float len;
@@ -305,8 +312,9 @@ struct Ray {
         size_t used_memory = 0;
         if (s.bvh_len == 0) return 0;  // deviation: empty world == miss (the reference would read an empty buffer)
         uint32_t bvh_ptr = 0;
-        uint32_t stack[BVH_STACK_SIZE];
-        int stack_ptr = 0;
+        uint32_t stack[BVH_STACK_MAX];
+        int stack_ptr = 0, deepest = 0;
+        const int limit = g_or_stack_limit;
         for (;;) {
             used_memory += 16;
             Vec4 d0 = s.bvh[bvh_ptr];
@@ -318,7 +326,10 @@ struct Ray {
                 float near_d = intersect_box(d0.xyz(), d1.xyz());
                 float far_d = intersect_box(d2.xyz(), d3.xyz());
                 if (far_d < near_d) { uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; float td = near_d; near_d = far_d; far_d = td; }
-                if (far_d < hit->distance) { if (stack_ptr < BVH_STACK_SIZE) stack[stack_ptr++] = far_ptr; }
+                if (far_d < hit->distance) {
+                    if (stack_ptr < limit) { stack[stack_ptr++] = far_ptr; if (stack_ptr > deepest) deepest = stack_ptr; }
+                    else __atomic_fetch_add(&g_or_dropped_pushes, 1ull, __ATOMIC_RELAXED);
+                }
                 if (near_d < hit->distance) { bvh_ptr = near_ptr; continue; }
             } else {
                 used_memory += sizeof(Triangle);
@@ -344,6 +355,10 @@ struct Ray {
             if (stack_ptr > 0) { stack_ptr -= 1; bvh_ptr = stack[stack_ptr]; } else break;
         }
         if (hit->is_some()) hit->point = at(hit->distance);
+        if (deepest > __atomic_load_n(&g_or_deepest_stack, __ATOMIC_RELAXED)) {   // (rare after the first rays: a max, kept with a CAS loop)
+            int seen = __atomic_load_n(&g_or_deepest_stack, __ATOMIC_RELAXED);
+            while (deepest > seen && !__atomic_compare_exchange_n(&g_or_deepest_stack, &seen, deepest, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
         return used_memory;
     }
     TriangleHit trace(const SceneView& s, size_t* used_memory = nullptr) const {  // ray.rs:55-80

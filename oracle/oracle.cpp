@@ -46,6 +46,14 @@ int or_material_remove(OrEngine* e, uint64_t id) { E(e)->remove_material(id); re
 int or_image_insert_rgba8(OrEngine* e, uint64_t id, uint32_t w, uint32_t h, const uint8_t* rgba, int /*srgb*/) { return E(e)->insert_image(id, w, h, rgba) ? 0 : 6; }
 int or_image_remove(OrEngine* e, uint64_t id) { E(e)->remove_image(id); return 0; }
 int or_debug_set_gi_neighbours(uint32_t n) { g_debug_gi_neighbours = n; return 0; }  // test-only, process-wide
+// pending entries a ray may keep (24 = the reference's; 64 stands for unbounded), and what the rays since the last reset needed
+int or_debug_set_stack_limit(int n) { if (n < 1 || n > BVH_STACK_MAX) return 1; g_or_stack_limit = n; return 0; }
+int or_debug_stack_stats(unsigned long long* dropped_pushes, int* deepest_stack, int reset) {
+    if (dropped_pushes) *dropped_pushes = __atomic_load_n(&g_or_dropped_pushes, __ATOMIC_RELAXED);
+    if (deepest_stack) *deepest_stack = __atomic_load_n(&g_or_deepest_stack, __ATOMIC_RELAXED);
+    if (reset) { __atomic_store_n(&g_or_dropped_pushes, 0ull, __ATOMIC_RELAXED); __atomic_store_n(&g_or_deepest_stack, 0, __ATOMIC_RELAXED); }
+    return 0;
+}
 int or_set_bvh_refresh(OrEngine* e, int mode) { E(e)->bvh_refit_mode = mode == 1; return (mode == 0 || mode == 1) ? 0 : 1; }
 int or_debug_bvh_refits(OrEngine* e, uint64_t* rebuilds, uint64_t* refits) { *rebuilds = E(e)->rebuilds; *refits = E(e)->refits; return 0; }
 int or_debug_image_rect(OrEngine* e, uint64_t id, uint32_t out[4]) {

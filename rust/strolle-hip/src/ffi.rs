@@ -102,7 +102,8 @@ pub struct StTuning {
     pub allow_deep_bvh: u32,
     pub device_bake: u32,
     pub wide_bvh: u32,
-    pub _reserved: [u32; 2],
+    pub wide_stack_entries: u32,
+    pub _reserved: [u32; 1],
 }
 
 /// [x0, x1) x [y0, y1) in pixels (st_dist_partition / st_dist_window)

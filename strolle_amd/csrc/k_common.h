@@ -13,7 +13,9 @@ constexpr int kBlockThreads = 256;               // 4 wavefronts, one 8x8 tile e
 #else
 #define ST_KERNEL_BOUNDS __launch_bounds__(kBlockThreads)
 #endif
-constexpr int kStackWords = 4 * kBvhStackSize * 64;  // 24 KiB of LDS per block for the traversal stacks
+// the traversal stacks of a block: dynamic LDS, [wave][entry][lane], KArgs::stack_entries x 256 slots of SE (st_device.h lane_stack)
+#define ST_STACK_LDS(SE, name) extern __shared__ __align__(16) unsigned char st_stack_lds_[]; SE* name = reinterpret_cast<SE*>(st_stack_lds_)
+inline uint32_t stack_lds_bytes(const KArgs& a, size_t slot_bytes) { return a.stack_entries * (uint32_t)kBlockThreads * (uint32_t)slot_bytes; }
 
 // The window of 8x8 tiles a launch covers: all of the viewport, or the rows / columns of st_camera_set_rows / st_camera_set_window
 // widened to tile boundaries (owns_pixel masks the rest). Half-resolution passes (2x1 checkerboard cells, `(size + 7) / 8 / (2, 1)`
@@ -105,21 +107,26 @@ inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len 
     a.byte_luts = s_byte_luts_;
 #define ST_LAUNCH_TRACE(kernel_tmpl, half, stream, ...)                                                             \
     do {                                                                                                            \
-        if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL2(kernel_tmpl, true, uint16_t), half, stream, __VA_ARGS__);          \
-        else if (a.bvh_len < stack16_limit(a)) ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint16_t), half, stream, __VA_ARGS__);   \
-        else ST_LAUNCH(ST_TPL2(kernel_tmpl, false, uint32_t), half, stream, __VA_ARGS__);                           \
+        if (scene_fits_lds(a)) ST_LAUNCH_SMEM(ST_TPL2(kernel_tmpl, true, uint16_t), half, stack_lds_bytes(a, 2), stream, __VA_ARGS__);          \
+        else if (a.bvh_len < stack16_limit(a)) ST_LAUNCH_SMEM(ST_TPL2(kernel_tmpl, false, uint16_t), half, stack_lds_bytes(a, 2), stream, __VA_ARGS__);   \
+        else ST_LAUNCH_SMEM(ST_TPL2(kernel_tmpl, false, uint32_t), half, stack_lds_bytes(a, 4), stream, __VA_ARGS__);                           \
     } while (0)
 // the same for kernels with one more leading bool (REPROJECT)
 #define ST_LAUNCH_TRACE_B(kernel_tmpl, flag, half, stream, ...)                                                         \
     do {                                                                                                                \
-        if (scene_fits_lds(a)) ST_LAUNCH(ST_TPL3(kernel_tmpl, true, flag, uint16_t), half, stream, __VA_ARGS__);        \
-        else if (a.bvh_len < stack16_limit(a)) ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint16_t), half, stream, __VA_ARGS__); \
-        else ST_LAUNCH(ST_TPL3(kernel_tmpl, false, flag, uint32_t), half, stream, __VA_ARGS__);                         \
+        if (scene_fits_lds(a)) ST_LAUNCH_SMEM(ST_TPL3(kernel_tmpl, true, flag, uint16_t), half, stack_lds_bytes(a, 2), stream, __VA_ARGS__);        \
+        else if (a.bvh_len < stack16_limit(a)) ST_LAUNCH_SMEM(ST_TPL3(kernel_tmpl, false, flag, uint16_t), half, stack_lds_bytes(a, 2), stream, __VA_ARGS__); \
+        else ST_LAUNCH_SMEM(ST_TPL3(kernel_tmpl, false, flag, uint32_t), half, stack_lds_bytes(a, 4), stream, __VA_ARGS__);                         \
     } while (0)
 #define ST_TPL(k, t) k<t>
 #define ST_TPL2(k, b, t) (k<b, t>)
 #define ST_TPL3(k, b, c, t) (k<b, c, t>)
 
+#define ST_LAUNCH_SMEM(kernel, half, smem, stream, ...)                                                          \
+    do {                                                                                                         \
+        const LaunchDims d_ = launch_dims(a, half);                                                              \
+        if (d_.blocks) ST_KLAUNCH_SMEM(kernel, dim3(d_.blocks), dim3(kBlockThreads), smem, stream, __VA_ARGS__); \
+    } while (0)
 #define ST_LAUNCH(kernel, half, stream, ...)                                                          \
     do {                                                                                              \
         const LaunchDims d_ = launch_dims(a, half);                                                   \

@@ -12,12 +12,12 @@ namespace ST_KNS {
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_di_sampling(const KArgs a_in, uint32_t seed) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
     if (!hit_some(hit)) return;
-    di_write(a.di_res[1], screen_to_idx(a, pos), di_sampling_pixel(a, seed, pos, hit, lane_stack(lds)));
+    di_write(a.di_res[1], screen_to_idx(a, pos), di_sampling_pixel(a, seed, pos, hit, lane_stack(a, lds)));
 }
 void launch_di_sampling(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_di_sampling, false, s, a, seed); }
 
@@ -37,12 +37,12 @@ void launch_di_temporal(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNC
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_di_sampling_temporal(const KArgs a_in, uint32_t seed_sampling, uint32_t seed_temporal) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Hit hit = pixel_hit(a, a.cam, a.g0, a.g1, pos);
     if (!hit_some(hit)) return;
-    di_temporal_pixel(a, seed_temporal, pos, hit, di_after_store(di_sampling_pixel(a, seed_sampling, pos, hit, lane_stack(lds))), tex_read(a.reprojection, a, pos));
+    di_temporal_pixel(a, seed_temporal, pos, hit, di_after_store(di_sampling_pixel(a, seed_sampling, pos, hit, lane_stack(a, lds))), tex_read(a.reprojection, a, pos));
 }
 void launch_di_sampling_temporal(const KArgs& a, uint32_t seed_sampling, uint32_t seed_temporal, hipStream_t s) {
     ST_LAUNCH_TRACE(k_di_sampling_temporal, false, s, a, seed_sampling, seed_temporal);
@@ -153,7 +153,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_sample(const KArgs a, uint32_t see
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a_in, uint32_t seed_pick, uint32_t seed_sample) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
     const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
@@ -173,7 +173,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_spatial_fused(const KArgs a_in, uint32_t s
             Ray ray = make_ray(xyz(r0), normal_decode(v2(r1.x, r1.y)));
             ray.len = r0.w;
             uint32_t used_ = 0u;
-            const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+            const bool occluded = trace_any(a, ray, lane_stack(a, lds), &used_);
             rays += 1u; bytes += used_;
             vis[k] = make_float4(occluded ? 0.0f : 1.0f, r1.z, r1.w, 0.0f);
         }
@@ -194,7 +194,7 @@ void launch_di_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST
 template <bool LDS_SCENE, bool REPROJECT, class SE>
 __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -207,7 +207,7 @@ __global__ ST_KERNEL_BOUNDS void k_di_resolving(const KArgs a_in) {
     float confidence;
     V3 radiance, spec_brdf;
     if (hit_some(hit)) {
-        const bool occluded = trace_any(a, di_sample_ray(res.s, hit.point), lane_stack(lds), &used_);
+        const bool occluded = trace_any(a, di_sample_ray(res.s, hit.point), lane_stack(a, lds), &used_);
         count_rays(a, used_);
         confidence = (res.s.is_occluded == occluded) ? res.s.confidence : 0.0f;
         res.s.confidence = 1.0f;

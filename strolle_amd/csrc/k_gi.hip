@@ -67,7 +67,7 @@ ST_D bool gi_sampling_a_cell(const KArgs& a, uint32_t seed, bool tracing, U2 pos
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a_in, uint32_t seed) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
@@ -77,7 +77,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_a(const KArgs a_in, uint32_t seed
     const Hit prim_hit = tracing ? pixel_hit(a, a.cam, a.g0, a.g1, pos) : hit_zero();
     const GiReservoir vres = tracing ? gi_empty() : gi_read(a.gi_res[2], screen_to_idx(a, pos), a.width * a.height);
     float4 d0, d1, d2;
-    if (!gi_sampling_a_cell(a, seed, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, &d0, &d1, &d2)) return;
+    if (!gi_sampling_a_cell(a, seed, tracing, pos, prim_hit, vres, lane_stack(a, lds), &used_, &d0, &d1, &d2)) return;
     count_rays(a, used_);
     tex_write(a.gi_d0, a, gid, d0);  // indexed by the half-resolution gid (gi_sampling_a.rs:117-121)
     tex_write(a.gi_d1, a, gid, d1);
@@ -152,7 +152,7 @@ ST_D void gi_sampling_b_cell(const KArgs& a, uint32_t seed, bool tracing, U2 pos
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
@@ -164,7 +164,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_sampling_b(const KArgs a_in, uint32_t seed
     const float4 d0 = tex_read(a.gi_d0, a, gid), d1 = tex_read(a.gi_d1, a, gid), d2 = tex_read(a.gi_d2, a, gid);
     GiReservoir vres = gi_empty();
     if (!tracing) { vres = gi_read(a.gi_res[2], screen_to_idx(a, pos), a.width * a.height); if (vres.m == 0.0f) return; }
-    gi_sampling_b_cell(a, seed, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, d0, d1, d2);
+    gi_sampling_b_cell(a, seed, tracing, pos, prim_hit, vres, lane_stack(a, lds), &used_, d0, d1, d2);
 }
 void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH_TRACE(k_gi_sampling_b, true, s, a, seed); }
 
@@ -175,7 +175,7 @@ void launch_gi_sampling_b(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAU
 template <bool LDS_SCENE, class SE>
 __global__ __launch_bounds__(kBlockThreads, 6) void k_gi_sampling_ab(const KArgs a_in, uint32_t seed_a, uint32_t seed_b, uint32_t reproject) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
@@ -198,13 +198,13 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_gi_sampling_ab(const KArgs
         } else vres = gi_read(a.gi_res[2], screen_to_idx(a, pos), n);  // a pixel without a surface: the slot gi_reprojection leaves alone
     }
     float4 d0, d1, d2;
-    if (!gi_sampling_a_cell(a, seed_a, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, &d0, &d1, &d2)) return;
+    if (!gi_sampling_a_cell(a, seed_a, tracing, pos, prim_hit, vres, lane_stack(a, lds), &used_, &d0, &d1, &d2)) return;
     count_rays(a, used_);
     tex_write(a.gi_d0, a, gid, d0);
     tex_write(a.gi_d1, a, gid, d1);
     tex_write(a.gi_d2, a, gid, d2);
     if (!hit_some(prim_hit)) return;  // validation frames: pass a re-traces a reservoir wherever one is, pass b wants a surface too
-    gi_sampling_b_cell(a, seed_b, tracing, pos, prim_hit, vres, lane_stack(lds), &used_, d0, d1, d2);
+    gi_sampling_b_cell(a, seed_b, tracing, pos, prim_hit, vres, lane_stack(a, lds), &used_, d0, d1, d2);
 }
 void launch_gi_sampling_ab(const KArgs& a, uint32_t seed_a, uint32_t seed_b, bool reproject, hipStream_t s) {
     ST_LAUNCH_TRACE(k_gi_sampling_ab, true, s, a, seed_a, seed_b, reproject ? 1u : 0u);
@@ -417,7 +417,7 @@ void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_gi_spatial_fused(const KArgs a_in, uint32_t seed_pick, uint32_t seed_sample) {
     ST_SCENE_PROLOGUE_WITH_BYTE_TABLES
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     U2 gid;
     if (!resolve_gid(a, true, &gid)) return;
     const U2 lhs_pos = resolve_checkerboard_alt(gid, a.frame / 2u);
@@ -437,7 +437,7 @@ __global__ ST_KERNEL_BOUNDS void k_gi_spatial_fused(const KArgs a_in, uint32_t s
             Ray ray = make_ray(xyz(r0), normal_decode(v2(r1.x, r1.y)));
             ray.len = r0.w;
             uint32_t used_ = 0u;
-            const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+            const bool occluded = trace_any(a, ray, lane_stack(a, lds), &used_);
             rays += 1u; bytes += used_;
             vis[k] = make_float4(occluded ? 0.0f : 1.0f, r1.z, r1.w, 0.0f);
         }

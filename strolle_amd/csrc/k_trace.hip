@@ -28,12 +28,12 @@ ST_D V3 heatmap_gradient(float progress) {
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_bvh_heatmap(const KArgs a_in) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     Candidate c; bool any;
-    const uint32_t used = traverse<false, SE>(a, camera_ray(a.cam, pos), kF32Max, lane_stack(lds), &c, &any);
+    const uint32_t used = traverse<false, SE>(a, camera_ray(a.cam, pos), kF32Max, lane_stack(a, lds), &c, &any);
     count_rays(a, used);
     a.dbg_used_memory[screen_to_idx(a, pos)] = used;
     tex_write(a.ref_colors, a, pos, f4(heatmap_gradient((float)used / 8192.0f), 1.0f));
@@ -44,7 +44,7 @@ void launch_bvh_heatmap(const KArgs& a, hipStream_t s) { ST_LAUNCH_TRACE(k_bvh_h
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a_in, uint32_t depth) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -56,7 +56,7 @@ __global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a_in, uint32_t depth)
         if (is_zero(d1)) return;
         ray = make_ray(xyz(d0), xyz(d1));
     }
-    const TriangleHit hit = trace_closest(a, ray, lane_stack(lds), &used_);
+    const TriangleHit hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
     count_rays(a, used_);
     float4 h0, h1;
     hit_pack(hit, &h0, &h1);
@@ -68,7 +68,7 @@ void launch_ref_tracing(const KArgs& a, uint32_t depth, hipStream_t s) { ST_LAUN
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, uint32_t depth) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -115,7 +115,7 @@ __global__ ST_KERNEL_BOUNDS void k_ref_shading(const KArgs a_in, uint32_t seed, 
         const uint32_t light_id = wn.sample_int() % a.light_count;
         const float light_pdf = frcp((float)a.light_count);
         const GpuLight light = light_get(a, light_id);
-        const bool occluded = trace_any(a, light_ray_wnoise(light, wn, hit.point), lane_stack(lds), &used_);
+        const bool occluded = trace_any(a, light_ray_wnoise(light, wn, hit.point), lane_stack(a, lds), &used_);
         count_rays(a, used_);
         if (!occluded) color = color + throughput * radiance_sum(light_radiance(light, hit)) / light_pdf;
     }
@@ -158,12 +158,12 @@ ST_D void frame_reprojection_pixel(const KArgs& a, U2 pos, const Surface& surfac
 template <bool LDS_SCENE, bool REPROJECT, class SE>
 __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Ray ray = camera_ray(a.cam, pos);
-    const TriangleHit hit = trace_closest(a, ray, lane_stack(lds), &used_);
+    const TriangleHit hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
     count_rays(a, used_);
     if (!hit_is_some(hit)) {  // LoadOp::Clear(TRANSPARENT)
         tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z());
@@ -228,7 +228,7 @@ void launch_frame_reprojection(const KArgs& a, hipStream_t s) { ST_LAUNCH(k_fram
 template <bool LDS_SCENE, class SE>
 __global__ ST_KERNEL_BOUNDS void k_spatial_trace(const KArgs a_in, const float4* buf_d0, const float4* buf_d1, float4* buf_d2) {
     ST_SCENE_PROLOGUE
-    __shared__ SE lds[kStackWords];
+    ST_STACK_LDS(SE, lds);
     uint32_t used_ = 0u;
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
@@ -236,7 +236,7 @@ __global__ ST_KERNEL_BOUNDS void k_spatial_trace(const KArgs a_in, const float4*
     if (is_zero(ray_d1)) { tex_write(buf_d2, a, pos, f4z()); return; }
     Ray ray = make_ray(xyz(ray_d0), normal_decode(v2(ray_d1.x, ray_d1.y)));
     ray.len = ray_d0.w;
-    const bool occluded = trace_any(a, ray, lane_stack(lds), &used_);
+    const bool occluded = trace_any(a, ray, lane_stack(a, lds), &used_);
     count_rays(a, used_);
     tex_write(buf_d2, a, pos, make_float4(occluded ? 0.0f : 1.0f, ray_d1.z, ray_d1.w, 0.0f));
 }

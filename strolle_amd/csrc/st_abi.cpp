@@ -420,7 +420,7 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
                              // one word holding the root's link; 15 = the contract entry of every leaf record
             if (en->host_stream_stale) { en->refit_stream(); en->host_stream_stale = false; }
             en->expand_stream(); en->build_wide_topology(); en->wide_built_for_ = ~0ull;   // (a later tick builds its own)
-            en->readback_levels_.assign(1, en->wide_root_);
+            en->readback_levels_.assign(1, en->wide_root_ | (en->wide_stack_need_ << 8));   // (bits 8..: the most entries a wide walk can have pending)
             en->readback_levels_.insert(en->readback_levels_.end(), en->wide_topo_.begin(), en->wide_topo_.end());
             const std::vector<uint32_t>* v = what == 14 ? &en->readback_levels_ : &en->wide_leaf_entry_;
             p = v->data(); bytes = v->size() * sizeof(uint32_t); break;
@@ -457,7 +457,7 @@ int st_set_bvh_refresh(StEngine* e, int mode) {
 }
 int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* stack_entries) {
     ST_REQUIRE(e && deepest_internal_chain && stack_entries, "null argument");
-    *deepest_internal_chain = E(e)->bvh_stack_need; *stack_entries = (uint32_t)kBvhStackSize;
+    *deepest_internal_chain = E(e)->bvh_stack_need; *stack_entries = E(e)->stack_entries;
     return ST_OK;
 }
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits) {

@@ -16,12 +16,15 @@ void Engine::measure_stack_need() {
         }
     }
     bvh_stack_need = deepest;
-    // A deeper tree is reported through st_tick's status (ST_ERR_BVH_TOO_DEEP, once per build) — or, with StTuning::allow_deep_bvh,
-    // once on stderr
-    bvh_too_deep_unreported = deepest > (uint32_t)kBvhStackSize;
+    // A ray's pending stack never holds more entries than the deepest chain of internal nodes (every node on the path pushes at most its far
+    // child): up to kBvhStackSize (24, the reference's) the launches keep the reference's stack, up to kBvhStackSizeDeep (32) they take the
+    // deep one — more LDS per block, no dropped push. Beyond that a tree is reported through st_tick's status (ST_ERR_BVH_TOO_DEEP, once per
+    // build) — or, with StTuning::allow_deep_bvh, once on stderr.
+    stack_entries = std::min<uint32_t>(std::max<uint32_t>(deepest, (uint32_t)kBvhStackSize), (uint32_t)kBvhStackSizeDeep);   // exactly what the tree needs: LDS per block decides occupancy
+    bvh_too_deep_unreported = deepest > stack_entries;
     if (bvh_too_deep_unreported && tuning.allow_deep_bvh && !bvh_depth_warned) {
         bvh_depth_warned = true;
-        fprintf(stderr, "[strolle-hip] warning: the BVH is %u internal nodes deep; traversal keeps %d pending entries per ray (as the reference does) and drops deeper ones — distant geometry may be missed. st_debug_bvh_depth reports this.\n", deepest, kBvhStackSize);
+        fprintf(stderr, "[strolle-hip] warning: the BVH is %u internal nodes deep; traversal keeps %d pending entries per ray (as the reference does) and drops deeper ones — distant geometry may be missed. st_debug_bvh_depth reports this.\n", deepest, (int)stack_entries);
     }
 }
 
@@ -117,7 +120,7 @@ void Engine::index_device_tree() {
 // consecutive). Only WHICH boxes a node holds is decided here; the boxes themselves are read on the device, from the device's stream.
 void Engine::build_wide_topology() {
     const uint32_t n_entries = device_bvh_len / 4u;
-    wide_topo_.clear(); wide_leaf_entry_.clear(); wide_root_ = 0u; wide_serial_++;
+    wide_topo_.clear(); wide_leaf_entry_.clear(); wide_root_ = 0u; wide_stack_need_ = 0u; wide_serial_++;
     if (!n_entries) return;
     auto internal = [&](uint32_t k) { return f2b(bvh_upload_[4u * (size_t)k].w) == 0u; };
     auto far_child = [&](uint32_t k) { return f2b(bvh_upload_[4u * (size_t)k + 1u].w) / 64u; };
@@ -150,6 +153,22 @@ void Engine::build_wide_topology() {
         }
         for (int i = 0; i < 4; i++) kids.push_back(i < n ? ch[i] : Child{0xffffffffu, 0u});
         for (int i = n - 1; i >= 0; i--) if (internal(ch[i].entry)) todo.push_back(ch[i].entry);   // depth first: the first child's subtree follows its parent
+    }
+    // the most entries a walk over the wide nodes can have pending: descending into one of a node's n children leaves at most n - 1 behind
+    // (children sit behind their parent in `head`, so a backward sweep sees finished children)
+    {
+        std::vector<uint32_t> need(head.size(), 0u);
+        for (size_t i = head.size(); i-- > 0;) {
+            uint32_t n = 0, below = 0;
+            for (int c = 0; c < 4; c++) {
+                const Child& q = kids[4u * i + c];
+                if (q.src == 0xffffffffu) continue;
+                n++;
+                if (internal(q.entry)) below = std::max(below, need[node_of[q.entry]]);
+            }
+            need[i] = (n ? n - 1u : 0u) + below;
+        }
+        wide_stack_need_ = head.empty() ? 0u : need[0];
     }
     wide_topo_.resize(8u * head.size());
     for (size_t i = 0; i < head.size(); i++)

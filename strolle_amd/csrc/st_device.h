@@ -51,8 +51,11 @@ ST_D U2 pixel_in_tile(TileCoord t) {
 // entry numbers (byte offset / 64): device streams of fewer than 65536 entries (Cornell: 55, dungeon: ~26 k) use 16-bit
 // stack slots, which halves the LDS footprint
 // (12 KiB per 4-wave block) and lifts the LDS cap on occupancy from 6 to 8 waves per SIMD.
+// The stack holds KArgs::stack_entries pending entries per lane: kBvhStackSize (24, strolle-gpu/src/lib.rs:76) or — when the tree's deepest chain of
+// internal nodes is longer than that (the 208 k-triangle dungeon: 26) — kBvhStackSizeDeep (32), so that no push is ever dropped. It lives in
+// DYNAMIC LDS sized at the launch (k_common.h ST_STACK_LDS / ST_LAUNCH): the 24-entry launches keep their occupancy.
 template <class SE>
-ST_D SE* lane_stack(SE* lds) { return lds + (threadIdx.x >> 6) * (kBvhStackSize * 64) + (threadIdx.x & 63u); }
+ST_D SE* lane_stack(const KArgs& a, SE* lds) { return lds + (threadIdx.x >> 6) * (a.stack_entries * 64u) + (threadIdx.x & 63u); }
 // Per-kernel counters {rays traced, the reference's `used_memory` bytes}. One returning-free atomic pair per
 // wavefront (hipcc's atomic optimizer reduces the uniform-address adds across the wave) lands on one of
 // kCounterLines 64-byte lines picked by block id: a single hot word saturates near 88 atomics/us
@@ -352,7 +355,7 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, C
             float near_d = intersect_box(ray, xyz(d0), xyz(d1));
             float far_d = intersect_box(ray, xyz(d2), xyz(d3));
             if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-            if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)(far_ptr >> 6); sp++; } }
+            if (far_d < best->t) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)(far_ptr >> 6); sp++; } }
             if (near_d < best->t) { ptr = near_ptr; continue; }
         } else {
             used_memory += 144u;
@@ -496,7 +499,7 @@ ST_D bool any_hit_fast(const KArgs& a, const Ray& ray, SE* stack) {
             float near_d = any_slab(xyz(d0), xyz(d1), inv, oi);
             float far_d = any_slab(xyz(d2), xyz(d3), inv, oi);
             if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-            if (far_d < limit) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)(far_ptr >> 6); sp++; } }
+            if (far_d < limit) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)(far_ptr >> 6); sp++; } }
             if (near_d < limit) { ptr = near_ptr; continue; }
         } else {
             const uint32_t flags = f2b(d0.x);
@@ -562,7 +565,7 @@ ST_D bool any_hit_compact(const KArgs& a, const Ray& ray, SE* stack) {
             float far_d = compact_slab(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs);
             uint32_t near_ptr = (((cur >> 1) + 1u) << 1) | (link & 1u), far_ptr = ((link >> 2) << 1) | ((link >> 1) & 1u);
             if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-            if (far_d < limit) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)far_ptr; sp++; } }
+            if (far_d < limit) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)far_ptr; sp++; } }
             if (near_d < limit) { cur = near_ptr; continue; }
         } else {
             const uint32_t head = f2b(t0.w);
@@ -603,7 +606,7 @@ ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candida
             float far_d = compact_slab(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs);
             uint32_t near_ptr = (((cur >> 1) + 1u) << 1) | (link & 1u), far_ptr = ((link >> 2) << 1) | ((link >> 1) & 1u);
             if (far_d < near_d) { const uint32_t tp = near_ptr; near_ptr = far_ptr; far_ptr = tp; const float td = near_d; near_d = far_d; far_d = td; }
-            if (far_d < best->t) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)far_ptr; sp++; } }
+            if (far_d < best->t) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)far_ptr; sp++; } }
             if (near_d < best->t) { cur = near_ptr; continue; }
         } else {
             const uint32_t head = f2b(t0.w);
@@ -705,9 +708,9 @@ ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
             uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, limit, t3, 2);
             uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, limit, t3, 3);
             ST_WIDE_SORT4(k0, k1, k2, k3);
-            if (k3 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k3, t3); sp++; } }
-            if (k2 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k2, t3); sp++; } }
-            if (k1 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k1, t3); sp++; } }
+            if (k3 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k3, t3); sp++; } }
+            if (k2 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k2, t3); sp++; } }
+            if (k1 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k1, t3); sp++; } }
             if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, t3); continue; }
         } else {
             const uint32_t head = f2b(t0.w);
@@ -747,9 +750,9 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
             uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, lim, t3, 2);
             uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, lim, t3, 3);
             ST_WIDE_SORT4(k0, k1, k2, k3);
-            if (k3 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k3, t3); sp++; } }
-            if (k2 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k2, t3); sp++; } }
-            if (k1 != 0xffffffffu) { if (sp < kBvhStackSize) { stack[sp * 64] = (SE)WideKeys<SE>::link(k1, t3); sp++; } }
+            if (k3 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k3, t3); sp++; } }
+            if (k2 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k2, t3); sp++; } }
+            if (k1 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k1, t3); sp++; } }
             if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, t3); continue; }
         } else {
             const uint32_t head = f2b(t0.w);

@@ -59,6 +59,7 @@ Engine::Engine() {
 int Engine::set_tuning(const StTuning& t) {
     if (t.struct_size != sizeof(StTuning)) return fail(ST_ERR_INVALID_ARGUMENT, "StTuning::struct_size does not match this library");
     if (t.tile_map > 2u || t.tile_map_denoise > 2u) return fail(ST_ERR_INVALID_ARGUMENT, "tile_map is 0, 1 or 2");
+    if (t.wide_stack_entries != 0u && (t.wide_stack_entries < 8u || t.wide_stack_entries > 56u)) return fail(ST_ERR_INVALID_ARGUMENT, "wide_stack_entries is 0 (default) or 8 ... 56");
     tuning = t;
     staging.enabled = tuning.staging != 0u;
     return ST_OK;

@@ -373,7 +373,8 @@ struct Engine {
     // Deepest chain of internal nodes in the uploaded stream = the most entries a traversal can have pending (every internal
     // node on the path may push its far child). The kernels' per-lane stack holds kBvhStackSize entries (strolle-gpu/src/lib.rs:76;
     // the reference indexes past the end there, here a push beyond the end is dropped): a deeper tree is reported, not hidden.
-    uint32_t bvh_stack_need = 0; bool bvh_depth_warned = false, bvh_too_deep_unreported = false;
+    // (round 5) Up to kBvhStackSizeDeep the launches take a deeper stack instead (dynamic LDS): `stack_entries` is what this tree's launches hold.
+    uint32_t bvh_stack_need = 0, stack_entries = (uint32_t)kBvhStackSize; bool bvh_depth_warned = false, bvh_too_deep_unreported = false;
     void measure_stack_need();
     // Device form of the stream (st_types.h "device BVH stream"): every entry four texels — an internal node as the
     // serializer wrote it (far pointer remapped), a leaf entry followed by its triangle's hit-test record — so that one
@@ -474,7 +475,7 @@ struct Engine {
     void dist_forget_camera(uint64_t handle);
     // the wide stream's topology (st_bvh_refresh.cpp build_wide_topology), from bvh_upload_: 8 words per node (4 box sources, 4 links) and the
     // contract entry of every leaf record; wide_serial_ counts the builds
-    std::vector<uint32_t> wide_topo_, wide_leaf_entry_; uint32_t wide_root_ = 0; uint64_t wide_serial_ = 0; uint64_t wide_built_for_ = ~0ull;
+    std::vector<uint32_t> wide_topo_, wide_leaf_entry_; uint32_t wide_root_ = 0, wide_stack_need_ = 0; uint64_t wide_serial_ = 0; uint64_t wide_built_for_ = ~0ull;
     void build_wide_topology();
     int refresh_wide_stream(SceneSet& t, hipStream_t up, bool topology_changed, bool* pageable);
     int dist_set_partition(uint64_t handle, CameraState& c, uint32_t cols, uint32_t apron);

@@ -16,13 +16,14 @@ namespace st {
 // back to the pool unrecorded — hipEventElapsedTime on a pair no dispatch wrote fails).
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; bool consumed = false; };
 extern thread_local LaunchEvents g_launch_events;  // st_engine.cpp
-#define ST_KLAUNCH(kernel, grid, block, stream, ...)                                                                                             \
+#define ST_KLAUNCH_SMEM(kernel, grid, block, smem, stream, ...)                                                                                  \
     do {                                                                                                                                         \
         if (::st::g_launch_events.start && !::st::g_launch_events.consumed) {                                                                    \
-            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ::st::g_launch_events.start, ::st::g_launch_events.stop, 0, __VA_ARGS__);      \
+            hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, ::st::g_launch_events.start, ::st::g_launch_events.stop, 0, __VA_ARGS__);   \
             ::st::g_launch_events.consumed = true;                                                                                               \
-        } else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                                                  \
+        } else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                                               \
     } while (0)
+#define ST_KLAUNCH(kernel, grid, block, stream, ...) ST_KLAUNCH_SMEM(kernel, grid, block, 0, stream, __VA_ARGS__)
 
 // Kernel slots: index into the per-camera counter array (2 x u64 per slot: rays, traversal bytes) and into the
 // profiler's table. `bytes_per_unit` = compulsory screen-space bytes one launch unit (pixel or 2x1 cell) reads +

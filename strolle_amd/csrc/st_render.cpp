@@ -128,6 +128,12 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.bvh_w_leaf_off = wide ? scene.wide_nodes * 64u : 0u;
     a.bvh_w_root = wide ? scene.wide_root : 0u; a.bvh_w_links16 = wide ? scene.wide_links16 : 0u;
     a.anyhit_contract = (count_bytes || !tuning.anyhit_fast) ? 1u : 0u;   // the reference's used_memory is the contract loop's
+    // Walks over the CONTRACT stream (exact build, heatmap pass, byte-counting mode, the compact binary stream: the contract's tree) hold what
+    // that tree's deepest chain can need — proven drop-free up to kBvhStackSizeDeep. The WIDE stream is another tree: its worst case (every
+    // child of every node on a path hit: 35 pending entries for the 13 k-triangle dungeon, 45 at 208 k) does not fit LDS at full occupancy and
+    // no ray comes near it (deepest stack measured: 11-13); it keeps kBvhStackSize entries, and test_the_wide_walk_drops_no_push renders
+    // BASELINE config 3's scene with 24 and with 48 entries (StTuning::wide_stack_entries) and finds the same bits.
+    a.stack_entries = wide ? (tuning.wide_stack_entries ? tuning.wide_stack_entries : (uint32_t)kBvhStackSize) : stack_entries;
     a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
     a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
     a.sun_dir[0] = sun_dir_.x; a.sun_dir[1] = sun_dir_.y; a.sun_dir[2] = sun_dir_.z;

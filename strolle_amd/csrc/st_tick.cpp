@@ -211,7 +211,7 @@ int Engine::tick(hipStream_t stream) {
     if (bvh_too_deep_unreported) {   // the tick did everything; the status says what the uploaded tree can cost (once per build)
         bvh_too_deep_unreported = false;
         if (!tuning.allow_deep_bvh)
-            return fail(ST_ERR_BVH_TOO_DEEP, "the BVH is " + std::to_string(bvh_stack_need) + " internal nodes deep, the kernels' traversal stack holds " + std::to_string(kBvhStackSize) +
+            return fail(ST_ERR_BVH_TOO_DEEP, "the BVH is " + std::to_string(bvh_stack_need) + " internal nodes deep, the kernels' traversal stack holds " + std::to_string(stack_entries) +
                                              " pending entries (strolle-gpu/src/lib.rs:76): pushes beyond it are dropped and geometry behind them can be missed. The scene was uploaded and renders; StTuning::allow_deep_bvh = 1 accepts this");
     }
     return ST_OK;

@@ -51,6 +51,7 @@ constexpr uint32_t kLeanGiMid = 8u;    // both GI preview passes in one launch: 
                                        // no neighbour: every pixel once the reservoirs have history) is not stored to GI_RESERVOIRS_3; the few pixels
                                        // whose second pass does resample rebuild such a neighbour's record from the pass's input (KArgs::gi_mid_src)
 constexpr int kBvhStackSize = 24;  // strolle-gpu/src/lib.rs:76
+constexpr int kBvhStackSizeDeep = 32;  // trees whose deepest chain of internal nodes exceeds kBvhStackSize (st_bvh_refresh.cpp measure_stack_need)
 constexpr uint32_t kLightIdSky = 0xffffffffu;
 constexpr uint32_t kLdsSceneTexels = 448;  // device streams up to this many float4 are copied into LDS by the tracing kernels (7 KiB per block: 112 entries, e.g. 56 one-triangle leaves + 55 internal nodes)
 constexpr uint32_t kLdsLights = 16;  // lights the tracing kernels keep in LDS (k_common.h ST_SCENE_PROLOGUE)
@@ -69,6 +70,7 @@ struct KArgs {
     const float* byte_luts;  // 256 sRGB->linear + 256 unorm8 values (st_device.h kLut*), generated on the device at engine creation
     const float4* transmittance_lut; const float4* sky_lut;
     uint32_t bvh_len, n_lights_buf, light_count, atlas_w, atlas_h;
+    uint32_t stack_entries;    // pending entries per lane of the traversal stack: kBvhStackSize, or kBvhStackSizeDeep for deeper trees (dynamic LDS, sized at the launch)
     // k_denoise.hip "variance in the reproject stage": the fused reproject stages store each pixel's long-history variance in
     // curr_colors.w and the DI one flags short-history pixels per 8x8 tile (bit = lane) for the variance kernel
     unsigned long long* tile_mask; uint32_t variance_in_reproject;

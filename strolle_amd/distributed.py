@@ -67,7 +67,7 @@ def tile_overhead(width: int, height: int, world_size: int, apron: int, cols: in
     return max(fr), sum(fr) / len(fr)
 
 
-def gather_tiles_to_root(local_frame, full_frame, world_size: int, rank: int, cols: int = 0, dst: int = 0, group=None):
+def gather_tiles_to_root(local_frame, full_frame, world_size: int, rank: int, cols: int = 0, dst: int = 0, group=None, tiles=None):
     """torch.distributed FALLBACK of st_dist_gather (the C ABI's RCCL gather is the product path; this one serves boxes without
     RCCL and the gloo tests): every rank sends its tile — packed, a tile is a strided view of the frame —, rank `dst` unpacks
     each into its place in `full_frame`. One gather, the only collective."""
@@ -75,7 +75,8 @@ def gather_tiles_to_root(local_frame, full_frame, world_size: int, rank: int, co
     import torch.distributed as dist
 
     height, width = local_frame.shape[0], local_frame.shape[1]
-    tiles = [tile_for_rank(width, height, world_size, r, cols) for r in range(world_size)]
+    if tiles is None:   # (`tiles`: every rank's tile of a cost-weighted grid, api.StDistGrid.tiles())
+        tiles = [tile_for_rank(width, height, world_size, r, cols) for r in range(world_size)]
     x0, y0, x1, y1 = tiles[rank]
     send = local_frame[y0:y1, x0:x1].contiguous()
     if rank == dst:

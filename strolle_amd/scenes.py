@@ -142,10 +142,8 @@ def build_dungeon(engine, subdivide: int = 0, tori: bool = True):
     BASELINE.json's "~100k tris" dungeon; the demo scene itself has 13,001)."""
     npz = np.load(os.path.join(ASSETS, "dungeon.npz"))
     engine.set_blue_noise(load_blue_noise())
-    if subdivide and hasattr(engine, "set_tuning"):
-        # the subdivided variants are 25 / 26 internal nodes deep, the traversal stack holds 24 pending entries: st_tick would say
-        # ST_ERR_BVH_TOO_DEEP. These synthetic scenes accept the dropped pushes and say so here.
-        engine.set_tuning(allow_deep_bvh=1)
+    # (the subdivided variants are 25 / 26 internal nodes deep: since round 5 the launches that walk the contract stream take a stack as deep as
+    # the tree needs, up to 32 entries — StTuning::allow_deep_bvh is no longer set here, no push is dropped)
     n = _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0), subdivide=subdivide)
     if tori:
         pos, nrm, uv = bevy_torus()

@@ -79,3 +79,19 @@ class OracleEngine(EngineBase):
         out = np.zeros((h, w, 4), np.float32) if compose else None
         self._check(self._b.render_camera(self._h, handle, out.ctypes.data if compose else None))
         return out
+
+
+def set_stack_limit(n: int = 24):
+    """or_debug_set_stack_limit: pending entries a ray of the oracle may keep (24 = the reference's lib.rs:76; 64 stands for unbounded). Process-wide."""
+    fn = oracle_lib().or_debug_set_stack_limit
+    fn.restype = C.c_int; fn.argtypes = [C.c_int]
+    assert fn(n) == 0, "stack limit out of range"
+
+
+def stack_stats(reset: bool = False):
+    """or_debug_stack_stats: (pushes dropped at the limit, deepest stack any ray reached) since the last reset."""
+    fn = oracle_lib().or_debug_stack_stats
+    fn.restype = C.c_int; fn.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_int), C.c_int]
+    d, s = C.c_ulonglong(), C.c_int()
+    fn(C.byref(d), C.byref(s), 1 if reset else 0)
+    return int(d.value), int(s.value)

@@ -10,7 +10,7 @@ import pytest
 
 from oracle_binding import OracleEngine
 from parity import assert_bits_equal
-from strolle_amd import Engine, Light, StrolleError, scenes
+from strolle_amd import Engine, Instance, Light, Material, Mesh, StrolleError, scenes
 from strolle_amd.api import LIB_PATH, load_library
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -433,30 +433,54 @@ def test_device_refit_work_list_reproduces_the_host_refit(scene):
 
 
 def test_bvh_depth_is_reported():
-    """st_debug_bvh_depth: the longest chain of internal nodes against the 24-entry traversal stack (strolle-gpu/src/lib.rs:76).
-    The Cornell box and the demo dungeon fit; the synthetic 208 k-triangle dungeon is deeper than the stack, which the library
-    says instead of silently dropping pushes."""
-    for build, fits in ((scenes.build_cornell, True), (scenes.build_dungeon, True), (lambda e: scenes.build_dungeon(e, subdivide=2), False)):
+    """st_debug_bvh_depth: the longest chain of internal nodes and the entries the launches' traversal stack holds for this tree — 24 as the
+    reference's (strolle-gpu/src/lib.rs:76) while that is enough (Cornell box, demo dungeon), the chain's own length up to 32 for deeper trees
+    (the synthetic 208 k-triangle dungeon: 26), so that no push is dropped."""
+    for build, want in ((scenes.build_cornell, 24), (scenes.build_dungeon, 24), (lambda e: scenes.build_dungeon(e, subdivide=2), 26)):
         e = Engine(device=-1)
         build(e); e.tick()
         depth, stack = e.bvh_depth()
-        assert stack == 24 and depth >= 5
-        assert (depth <= stack) == fits, (depth, stack)
+        assert stack == want and 5 <= depth <= stack, (depth, stack)
+        e.close()
+
+
+def _chain_scene(e, n):
+    """n triangles whose centroids grow by 8x from one to the next: nearly every binned-SAH split (12 bins) peels the largest ones off — a tree
+    that is almost a chain (coordinates stay between 2^-120 and 2^54 so that box areas stay finite floats)."""
+    e.insert_material(1, Material(base_color=(0.8, 0.8, 0.8, 1.0)))
+    pos = np.zeros((n, 3, 3), np.float32)
+    for i in range(n):
+        x = np.float32(2.0) ** (3 * i - 120)
+        pos[i] = [[x, 0, 0], [x * 1.01, 0, 0], [x, x * 0.01, 0]]
+    nrm = np.zeros_like(pos); nrm[..., 2] = 1
+    e.insert_mesh(1, Mesh(pos, nrm)); e.insert_instance(1, Instance(1, 1, np.eye(4, dtype=np.float32)[:3]))
 
 
 def test_a_tree_deeper_than_the_stack_fails_the_tick_loudly():
-    """a tree deeper than the 24-entry traversal stack drops pushes — st_tick says ST_ERR_BVH_TOO_DEEP (once per
-    build; the scene is uploaded all the same) unless StTuning::allow_deep_bvh accepts it."""
+    """the traversal stack holds what the tree's deepest chain of internal nodes can need — 24 entries as the
+    reference's (lib.rs:76), up to 32 for deeper trees (the subdivided dungeons: 25 / 26; no push is dropped and scenes.py no longer sets
+    allow_deep_bvh). Only a tree deeper than 32 drops pushes: st_tick says ST_ERR_BVH_TOO_DEEP (once per build; the scene is uploaded all the
+    same) unless StTuning::allow_deep_bvh accepts it."""
     from strolle_amd.api import ST_ERR_BVH_TOO_DEEP, StrolleError
     e = Engine(device=-1)
-    scenes.build_dungeon(e, subdivide=1)        # the builder sets allow_deep_bvh for its synthetic variants ...
-    assert e.tuning().allow_deep_bvh == 1
-    e.set_tuning(allow_deep_bvh=0)              # ... undo that: the status must come
+    scenes.build_dungeon(e, subdivide=1)
+    assert e.tuning().allow_deep_bvh == 0
+    e.tick()
+    assert e.bvh_depth() == (25, 25), "the launches take a stack as deep as this tree needs"
+    e.close()
+    e = Engine(device=-1)
+    _chain_scene(e, 46); e.tick()
+    depth, stack = e.bvh_depth()
+    assert 26 < depth <= 32 and stack == depth, (depth, stack)
+    e.close()
+    e = Engine(device=-1)
+    _chain_scene(e, 58)
     with pytest.raises(StrolleError) as err:
         e.tick()
-    assert f"status {ST_ERR_BVH_TOO_DEEP}" in str(err.value) and "25 internal nodes deep" in str(err.value)
     depth, stack = e.bvh_depth()
-    assert depth == 25 and len(e.read_scene(0)) > 0, "the tick did its work before reporting"
+    assert depth > 32 and stack == 32
+    assert f"status {ST_ERR_BVH_TOO_DEEP}" in str(err.value) and f"{depth} internal nodes deep" in str(err.value) and "holds 32" in str(err.value)
+    assert len(e.read_scene(0)) > 0, "the tick did its work before reporting"
     e.tick()                                     # reported once per build: a tick that rebuilds nothing is clean
     e.set_tuning(allow_deep_bvh=1)
     e.insert_light(99, Light.point((0.0, 1.0, 0.0), 0.1, (1.0, 1.0, 1.0), 5.0)); e.tick()

@@ -608,9 +608,16 @@ def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
     mg = out["multi_gpu"]
     assert mg["rccl_ranks"] == 2 and mg["backend"] == "gloo"   # shared-GPU debug mode gathers through gloo
     c5 = mg["strong_config5"]
-    assert c5["band_rows"] == 48 and c5["apron_rows"] == 16 and c5["frame_finite"] and c5["ms_per_step"] > 0 and c5["Mray_per_s"] > 0
-    assert len(c5["per_rank_ms"]) == 2 and c5["gather_ms"] is not None and c5["gathered_bytes_per_frame"] == 48 * 160 * 16
-    assert abs(c5["apron_overhead_frac"]["max"] - (64 / 48 - 1)) < 1e-3 and "n1_ms_reference" in c5   # 96 rows in 2 bands of 48, apron 16
+    # (round 5: the extras rebalance the tiles from the ranks' own frame times before the timed region — st_dist_grid_rebalance, four rounds,
+    # an edge moves by at most the apron per round and a band keeps at least 32 rows: rank 0's band ends somewhere in [32, 64] on the 8-row grid)
+    bal = c5["balance"]
+    assert len(bal["rounds"]) == 4 and bal["rounds"][0]["grid"]["row_edges"] == [0, 48, 96] and all(len(r["per_rank_ms"]) == 2 for r in bal["rounds"])
+    edge = bal["final_grid"]["row_edges"][1]
+    assert bal["final_grid"]["row_edges"] == [0, edge, 96] and edge % 8 == 0 and 32 <= edge <= 64
+    assert all(abs(a["grid"]["row_edges"][1] - b["grid"]["row_edges"][1]) <= 16 for a, b in zip(bal["rounds"], bal["rounds"][1:]))
+    assert c5["band_rows"] == edge and c5["apron_rows"] == 16 and c5["frame_finite"] and c5["ms_per_step"] > 0 and c5["Mray_per_s"] > 0
+    assert len(c5["per_rank_ms"]) == 2 and c5["gather_ms"] is not None and c5["gathered_bytes_per_frame"] == (96 - edge) * 160 * 16
+    assert abs(c5["apron_overhead_frac"]["max"] - (64 / 48 - 1)) < 1e-3 and "n1_ms_reference" in c5   # (of the equal split) 96 rows in 2 bands of 48, apron 16
     assert "strong_config4" not in mg   # N = 4 only
     got = np.load(dump)
     # the same 5 frames in one process

@@ -154,3 +154,38 @@ def test_a_walk_over_the_wide_topology_finds_the_brute_force_hit(name):
             hits += 1
             assert got is not None and abs(got - want) <= 1e-9 * max(1.0, abs(want)), (got, want)
     assert hits > 20, "the rays do not meet the scene"
+
+
+def test_no_ray_of_config_3s_scene_comes_near_the_24_entry_stack():
+    """BASELINE config 3's stand-in (the dungeon subdivided twice, 208 k triangles) is 26 internal nodes deep, the reference's
+    traversal stack holds 24 pending entries (strolle-gpu/src/lib.rs:76, ray.rs:176-180). The oracle counts what its rays need: no push is
+    dropped at 24, the deepest stack any ray reaches is about half of that, and rendering with an unbounded stack (64) gives the same bits —
+    heatmap integers, G-buffer, GI samples. (The product's contract walks take a 26-entry stack for this tree: test_c_abi.py.)"""
+    from oracle_binding import OracleEngine, set_stack_limit, stack_stats
+    from parity import assert_bits_equal
+    from strolle_amd import Buffer, CameraMode
+    size = (240, 136)
+    results = []
+    try:
+        for limit in (24, 64):
+            set_stack_limit(limit)
+            stack_stats(reset=True)
+            o = OracleEngine(); scenes.build_dungeon(o, subdivide=2); o.set_seed(0)
+            planes = {}
+            for mode, frames, bufs in ((CameraMode.BVH_HEATMAP, 1, (Buffer.DBG_USED_MEMORY,)),
+                                       (CameraMode.GI_DIFFUSE, 2, (Buffer.PRIM_GBUFFER_D0_A, Buffer.GI_D0, Buffer.GI_D1, Buffer.GI_RESERVOIRS_1))):
+                desc = scenes.dungeon_camera(size, mode, depth=1)
+                cam = o.create_camera(desc)
+                for _ in range(frames):
+                    o.update_camera(cam, desc); o.tick(); frame = o.render_camera(cam)
+                planes[mode.name] = [frame] + [o.read_buffer(cam, b) for b in bufs]
+            results.append((planes, stack_stats()))
+            o.close()
+    finally:
+        set_stack_limit(24)
+    (p24, (dropped24, deepest24)), (p64, (dropped64, deepest64)) = results
+    assert dropped24 == 0 and dropped64 == 0, f"{dropped24} pushes were dropped at the reference's stack size"
+    assert 8 <= deepest24 <= 16 and deepest24 == deepest64, (deepest24, deepest64)
+    for mode in p24:
+        for a, b in zip(p24[mode], p64[mode]):
+            assert_bits_equal(a, b, f"{mode}: 24-entry stack vs unbounded")
