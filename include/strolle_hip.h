@@ -165,7 +165,17 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                     ST_BVH_REFIT_DEVICE = 2 /* as ST_BVH_REFIT, but the boxes are recomputed ON THE DEVICE: st_tick sends the moved triangles'
                                                hit-test records and bounds (80 B each) instead of refitting the stream on the host and
                                                re-sending all of it; k_bvh.hip patches the leaf entries and refits the boxes bottom-up (one launch per
-                                               level of 512-leaf subtrees: two at 208 k triangles). Same bits as ST_BVH_REFIT. */ };
+                                               level of 512-leaf subtrees: two at 208 k triangles). Same bits as ST_BVH_REFIT. */,
+                    ST_BVH_BUILD_DEVICE = 3 /* (round 5) after a scene change the tree is BUILT ON THE DEVICE, straight into the wide stream the fast
+                                               build's rays walk (k_lbvh.hip: Morton codes, radix sort, the binary radix tree of Karras 2012, boxes by
+                                               range queries, collapsed into 4-wide nodes): spawning or removing an instance costs a few hundred
+                                               microseconds of device time instead of the host rebuild (26-28 ms at 208 k triangles). It is ANOTHER tree
+                                               than the reference's binned SAH — the hits are the same, traversal costs about a fifth more for
+                                               incoherent rays —, so it is used only while nothing observes the contract stream: fast arithmetic, no
+                                               BvhHeatmap camera, no byte counting. A tick that finds such an observer builds on the host as
+                                               ST_BVH_REBUILD does; a heatmap camera created later renders after the next st_tick. */ };
+/* Ticks whose tree was built on the device so far (ST_BVH_BUILD_DEVICE). */
+int st_debug_device_builds(StEngine* e, uint64_t* ticks);
 int st_set_bvh_refresh(StEngine* e, int mode);
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits);
 int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits);
@@ -393,7 +403,7 @@ int st_camera_ray_count(StEngine* e, StHandle camera, uint64_t* out, int reset);
  * 8 LDS slot of every internal entry (bit 31: a task's root), 9 work items (bit 31: root of a finished task), 10 batch offsets
  * into 9, 11 (first batch, batches) per launch, 12 leaf entry of every triangle slot, 13 triangle bounds (two float4 per slot);
  * 14-17 the WIDE stream (StTuning::wide_bvh; uint32 unless noted): 14 its topology as the host builds it — one word with the root's
- * link, then 8 words per node: where each of the four child boxes lives in the device form (entry << 1 | 0 left box, 1 right box;
+ * link in bits 0-7 and the most entries a walk over it can have pending in bits 8.., then 8 words per node: where each of the four child boxes lives in the device form (entry << 1 | 0 left box, 1 right box;
  * 0xffffffff = empty slot) and the four links (index << 1 | is a leaf record) —, 15 the device-form entry of every leaf record,
  * 16 / 17 its nodes (64 B each) and leaf records (48 B each) read back FROM the device (live copy; float4).
  * All but 6, 16 and 17 work on host-only engines. */

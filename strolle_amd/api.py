@@ -317,6 +317,7 @@ class _Binding:
             self.debug_bvh_depth = fn("debug_bvh_depth", [vp, P(u32), P(u32)])
             self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
             self.debug_device_bakes = fn("debug_device_bakes", [vp, P(u64), P(u64)])
+            self.debug_device_builds = fn("debug_device_builds", [vp, P(u64)])
             self.engine_get_tuning = fn("engine_get_tuning", [vp, P(StTuning)]); self.engine_set_tuning = fn("engine_set_tuning", [vp, P(StTuning)])
             self.debug_copy_bandwidth = fn("debug_copy_bandwidth", [vp, sz, i32, P(C.c_double)])
             self.debug_variance_flags = fn("debug_variance_flags", [vp, u64, vp, sz, P(sz)])
@@ -499,11 +500,12 @@ class EngineBase:
 
     def set_bvh_refresh(self, refit):
         """st_set_bvh_refresh: False / 0 = rebuild on every change (the reference's behaviour), True / 1 = refit while instances only
-        move, 2 = the same with the boxes recomputed on the device (ST_BVH_REFIT_DEVICE; libstrolle_hip.so only)."""
+        move, 2 = the same with the boxes recomputed on the device (ST_BVH_REFIT_DEVICE; libstrolle_hip.so only), 3 = the tree BUILT on the device
+        straight into the wide stream while nothing observes the contract stream (ST_BVH_BUILD_DEVICE; libstrolle_hip.so only)."""
         refit = int(refit)
-        if refit not in (0, 1, 2):
+        if refit not in (0, 1, 2, 3):
             raise StrolleError(f"unknown BVH refresh mode {refit}")
-        if refit == 2 and not hasattr(self._b, "debug_bvh_device_refits"):
+        if refit >= 2 and not hasattr(self._b, "debug_bvh_device_refits"):
             raise StrolleError("ST_BVH_REFIT_DEVICE is a mode of libstrolle_hip.so; this engine's library does not have it")
         self._check(self._b.set_bvh_refresh(self._h, refit))
 
@@ -513,6 +515,12 @@ class EngineBase:
         out = C.c_uint64()
         self._check(self._b.debug_bvh_device_refits(self._h, C.byref(out)))
         return out.value
+
+    def device_builds(self) -> int:
+        """ticks whose tree was built on the device so far (ST_BVH_BUILD_DEVICE)."""
+        n = C.c_uint64()
+        self._check(self._b.debug_device_builds(self._h, C.byref(n)))
+        return int(n.value)
 
     def device_bakes(self):
         """(launches of the device bake, triangles they baked) so far — StTuning::device_bake."""

@@ -1,0 +1,228 @@
+// k_lbvh.hip — a BVH built ON THE DEVICE, straight into the wide stream (st_set_bvh_refresh(ST_BVH_BUILD_DEVICE); round 5).
+//
+// The reference rebuilds its binned-SAH tree on the host whenever an instance appears or disappears (strolle/src/bvh/builder.rs:17-228,
+// bevy-strolle/examples/stress-bvh.rs:111-167); this library's host builder is the same tree bit for bit (st_bvh.h: that is what makes the
+// heatmap's `used_memory` integers the reference's) and costs 26-28 ms per spawn at 208 k triangles. The fast build's rays do not need THAT
+// tree — they owe the reference their hits, not their path (st_device.h closest_hit_wide) — so while no camera observes the contract stream
+// (no heatmap camera, fast arithmetic, no byte counting) a scene change is followed by this builder instead:
+//
+//   1. centroid bounds of the live triangle slots                                   k_lbvh_bounds      (wave reduction, one ordered-int atomic pair per wave)
+//   2. key = 30-bit Morton code of the centroid << 32 | triangle slot (unique)      k_lbvh_keys        dead slots: ~0, sorted to the end
+//   3. radix sort of the 64-bit keys                                                hipCUB DeviceRadixSort (a plain library sort)
+//   4. leaf records (48 B, sorted order = leaf index) + leaf boxes                  k_lbvh_leaves
+//   5. min / max segment tree over the sorted leaf boxes                            k_lbvh_seg_level   one launch per level, no fences
+//   6. the binary radix tree of Karras 2012 — one thread per internal node finds its range and split from the keys alone —, each
+//      node's box as a range query of the segment tree (no bottom-up pass: nothing is handed from workgroup to workgroup) k_lbvh_hierarchy
+//   7. collapse into 4-wide nodes, top-down: a wide node is headed by a binary node and takes its children's children, largest surface
+//      area first, until it has four (the rule st_bvh_refresh.cpp build_wide_topology applies to the host's tree); a wide node lives at
+//      its head's binary index, so nothing is allocated and the result does not depend on the schedule. One launch per frontier level
+//      (40: an empty frontier costs 4 us), a last launch walks whatever is deeper with a private stack per thread          k_lbvh_collapse
+//
+// Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
+// 11.6 for a GI bounce, the same number of triangle tests, deepest stack 13-14.
+#include <hip/hip_fp16.h>
+#include <hipcub/hipcub.hpp>
+#include "k_common.h"
+#include "st_lbvh.h"
+
+namespace st {
+
+namespace {
+constexpr int kT = 256;
+__device__ inline int ordered(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ inline float unordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+__device__ inline uint32_t expand10(uint32_t x) {
+    x &= 0x3ffu; x = (x | (x << 16)) & 0x30000ffu; x = (x | (x << 8)) & 0x300f00fu; x = (x | (x << 4)) & 0x30c30c3u; x = (x | (x << 2)) & 0x9249249u;
+    return x;
+}
+struct Box { float lx, ly, lz, hx, hy, hz; };
+__device__ inline Box box_empty() { return {kF32Max, kF32Max, kF32Max, -kF32Max, -kF32Max, -kF32Max}; }
+__device__ inline Box box_union(const Box& a, const Box& b) { return {fminf(a.lx, b.lx), fminf(a.ly, b.ly), fminf(a.lz, b.lz), fmaxf(a.hx, b.hx), fmaxf(a.hy, b.hy), fmaxf(a.hz, b.hz)}; }
+__device__ inline Box box_load(const float4* p) { const float4 a = p[0], b = p[1]; return {a.x, a.y, a.z, b.x, b.y, b.z}; }
+__device__ inline void box_store(float4* p, const Box& b) { p[0] = make_float4(b.lx, b.ly, b.lz, 0.0f); p[1] = make_float4(b.hx, b.hy, b.hz, 0.0f); }
+__device__ inline float box_area(const Box& b) {
+    const float dx = fmaxf(b.hx - b.lx, 0.0f), dy = fmaxf(b.hy - b.ly, 0.0f), dz = fmaxf(b.hz - b.lz, 0.0f);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void k_lbvh_init(int* bounds, uint32_t* counters) {
+    if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;             // ordered(+inf-ish): min
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;   // max
+    if (threadIdx.x == 0) { counters[0] = 1u; counters[1] = 0u; counters[2] = 0u; }   // frontier 0 = { the root }
+}
+// 1. bounds of the live triangles' centroids
+__global__ __launch_bounds__(kT) void k_lbvh_bounds(const float4* tri_bounds, const uint32_t* tri_info, uint32_t slots, int* bounds) {
+    float mn[3] = {kF32Max, kF32Max, kF32Max}, mx[3] = {-kF32Max, -kF32Max, -kF32Max};
+    for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < slots; i += gridDim.x * kT) {
+        if (!(tri_info[i] & 1u)) continue;
+        const float4 lo = tri_bounds[2u * i], hi = tri_bounds[2u * i + 1u];
+        const float c[3] = {(lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f};
+        for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], c[k]); mx[k] = fmaxf(mx[k], c[k]); }
+    }
+    for (int k = 0; k < 3; k++)   // one atomic pair per wave: min / max over its 64 lanes first
+        for (int off = 32; off >= 1; off >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], off)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off)); }
+    if ((threadIdx.x & 63u) == 0u)
+        for (int k = 0; k < 3; k++) { atomicMin(&bounds[k], ordered(mn[k])); atomicMax(&bounds[3 + k], ordered(mx[k])); }
+}
+// 2. sort keys
+__global__ __launch_bounds__(kT) void k_lbvh_keys(const float4* tri_bounds, const uint32_t* tri_info, uint32_t slots, const int* bounds, unsigned long long* keys) {
+    const uint32_t i = blockIdx.x * kT + threadIdx.x;
+    if (i >= slots) return;
+    if (!(tri_info[i] & 1u)) { keys[i] = ~0ull; return; }
+    const float4 lo = tri_bounds[2u * i], hi = tri_bounds[2u * i + 1u];
+    const float c[3] = {(lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f};
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) {
+        const float mn = unordered(bounds[k]), mx = unordered(bounds[3 + k]);
+        const float ext = mx - mn;
+        const float t = ext > 0.0f ? (c[k] - mn) / ext : 0.0f;
+        q[k] = (uint32_t)fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+    }
+    const uint32_t code = expand10(q[0]) | (expand10(q[1]) << 1) | (expand10(q[2]) << 2);
+    keys[i] = ((unsigned long long)code << 32) | i;
+}
+// 4. leaf records and leaf boxes, in sorted order; the segment tree's unused leaves are empty boxes
+__global__ __launch_bounds__(kT) void k_lbvh_leaves(const unsigned long long* keys, uint32_t n, uint32_t pow2, const float4* tri_geo, const float4* tri_bounds,
+                                                    const uint32_t* tri_info, float4* seg, float4* leaves) {
+    const uint32_t p = blockIdx.x * kT + threadIdx.x;
+    if (p >= pow2) return;
+    if (p >= n) { box_store(seg + 2u * (size_t)(pow2 + p), box_empty()); return; }
+    const uint32_t slot = (uint32_t)keys[p];
+    seg[2u * (size_t)(pow2 + p)] = tri_bounds[2u * slot]; seg[2u * (size_t)(pow2 + p) + 1u] = tri_bounds[2u * slot + 1u];
+    const uint32_t info = tri_info[slot];
+    const float4 g0 = tri_geo[3u * slot], g1 = tri_geo[3u * slot + 1u], g2 = tri_geo[3u * slot + 2u];
+    leaves[3u * p] = make_float4(g0.x, g0.y, g0.z, b2f((slot << 2) | (info & 2u)));   // bit 0 (another record of the run follows): single-triangle leaves
+    leaves[3u * p + 1u] = make_float4(g1.x, g1.y, g1.z, b2f(info >> 2));
+    leaves[3u * p + 2u] = make_float4(g2.x, g2.y, g2.z, 0.0f);
+}
+// 5. one level of the segment tree: nodes [first, first + count)
+__global__ __launch_bounds__(kT) void k_lbvh_seg_level(float4* seg, uint32_t first, uint32_t count) {
+    const uint32_t i = blockIdx.x * kT + threadIdx.x;
+    if (i >= count) return;
+    const size_t k = first + i;
+    box_store(seg + 2u * k, box_union(box_load(seg + 4u * k), box_load(seg + 4u * k + 2u)));
+}
+__device__ inline Box seg_query(const float4* seg, uint32_t pow2, uint32_t first, uint32_t last) {
+    Box b = box_empty();
+    for (uint32_t l = first + pow2, r = last + pow2 + 1u; l < r; l >>= 1, r >>= 1) {
+        if (l & 1u) { b = box_union(b, box_load(seg + 2u * (size_t)l)); l++; }
+        if (r & 1u) { r--; b = box_union(b, box_load(seg + 2u * (size_t)r)); }
+    }
+    return b;
+}
+// 6. Karras 2012: internal node i of the binary radix tree over n sorted, unique keys. children[i] = (left, right) as links (index << 1 | is a
+// leaf), node_box[i] = the box of its range.
+__device__ inline int lb_delta(const unsigned long long* keys, int n, int i, int j) { return (j < 0 || j >= n) ? -1 : __clzll((long long)(keys[i] ^ keys[j])); }
+__global__ __launch_bounds__(kT) void k_lbvh_hierarchy(const unsigned long long* keys, uint32_t n_, uint32_t pow2, const float4* seg, uint2* children, float4* node_box) {
+    const int n = (int)n_, i = (int)(blockIdx.x * kT + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = lb_delta(keys, n, i, i + 1) - lb_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = lb_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lb_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1) if (lb_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lb_delta(keys, n, i, j);
+    int s = 0, t = l;
+    do { t = (t + 1) >> 1; if (lb_delta(keys, n, i, i + (s + t) * d) > dnode) s += t; } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int first = i < j ? i : j, last = i < j ? j : i;
+    const uint32_t left = first == gamma ? ((uint32_t)gamma << 1) | 1u : (uint32_t)gamma << 1;
+    const uint32_t right = last == gamma + 1 ? ((uint32_t)(gamma + 1) << 1) | 1u : (uint32_t)(gamma + 1) << 1;
+    children[i] = make_uint2(left, right);
+    box_store(node_box + 2u * (size_t)i, seg_query(seg, pow2, (uint32_t)first, (uint32_t)last));
+}
+// 7. one wide node, headed by binary node `b`: written at node index b; its internal children are returned in `next` (their count in *n_next)
+__device__ inline Box lb_child_box(uint32_t link, const float4* seg, uint32_t pow2, const float4* node_box) {
+    return (link & 1u) ? box_load(seg + 2u * (size_t)(pow2 + (link >> 1))) : box_load(node_box + 2u * (size_t)(link >> 1));
+}
+__device__ inline void lb_emit(uint32_t b, const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
+                               uint32_t* next, int* n_next) {
+    uint32_t link[4]; Box box[4]; int n = 2;
+    const uint2 c = children[b];
+    link[0] = c.x; link[1] = c.y;
+    box[0] = lb_child_box(c.x, seg, pow2, node_box); box[1] = lb_child_box(c.y, seg, pow2, node_box);
+    while (n < 4) {
+        int pick = -1; float best = -1.0f;
+        for (int i = 0; i < n; i++) if (!(link[i] & 1u)) { const float ar = box_area(box[i]); if (ar > best) { best = ar; pick = i; } }
+        if (pick < 0) break;
+        const uint2 g = children[link[pick] >> 1];
+        for (int i = n; i > pick + 1; i--) { link[i] = link[i - 1]; box[i] = box[i - 1]; }
+        link[pick] = g.x; link[pick + 1] = g.y;
+        box[pick] = lb_child_box(g.x, seg, pow2, node_box); box[pick + 1] = lb_child_box(g.y, seg, pow2, node_box);
+        n++;
+    }
+    auto dn = [](float x) { return (uint32_t)__half_as_ushort(__float2half_rd(x)); };
+    auto up = [](float x) { return (uint32_t)__half_as_ushort(__float2half_ru(x)); };
+    uint32_t w[12], l[4];
+    *n_next = 0;
+    for (int i = 0; i < 4; i++) {
+        if (i >= n) { w[3 * i] = w[3 * i + 1] = w[3 * i + 2] = 0xfc007c00u; l[i] = 0u; continue; }
+        w[3 * i] = dn(box[i].lx) | (up(box[i].hx) << 16); w[3 * i + 1] = dn(box[i].ly) | (up(box[i].hy) << 16); w[3 * i + 2] = dn(box[i].lz) | (up(box[i].hz) << 16);
+        l[i] = link[i];
+        if (!(link[i] & 1u)) next[(*n_next)++] = link[i] >> 1;
+    }
+    float4* out = nodes + 4u * (size_t)b;
+    out[0] = make_float4(b2f(w[0]), b2f(w[1]), b2f(w[2]), b2f(w[3]));
+    out[1] = make_float4(b2f(w[4]), b2f(w[5]), b2f(w[6]), b2f(w[7]));
+    out[2] = make_float4(b2f(w[8]), b2f(w[9]), b2f(w[10]), b2f(w[11]));
+    out[3] = links16 ? make_float4(b2f(l[0] | (l[1] << 16)), b2f(l[2] | (l[3] << 16)), 0.0f, 0.0f) : make_float4(b2f(l[0]), b2f(l[1]), b2f(l[2]), b2f(l[3]));
+}
+// one frontier level (counters rotate: in = level % 3, out = (level + 1) % 3, (level + 2) % 3 is cleared for the level after); with
+// `finish` every thread walks the whole subtree of each of its items instead of handing its children on
+__global__ __launch_bounds__(kT) void k_lbvh_collapse(const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
+                                                      const uint32_t* frontier_in, uint32_t* frontier_out, uint32_t* counters, uint32_t level, uint32_t finish) {
+    const uint32_t count = counters[level % 3u];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[(level + 2u) % 3u] = 0u;
+    for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
+        uint32_t next[4]; int n_next;
+        const uint32_t head = level == 0u ? 0u : frontier_in[i];
+        if (!finish) {
+            lb_emit(head, children, node_box, seg, pow2, links16, nodes, next, &n_next);
+            if (n_next) { const uint32_t at = atomicAdd(&counters[(level + 1u) % 3u], (uint32_t)n_next); for (int k = 0; k < n_next; k++) frontier_out[at + k] = next[k]; }
+        } else {
+            uint32_t stack[96]; int sp = 0;   // a path of the binary tree is at most 64 + 32 nodes long (64-bit keys, 32-bit tie-break inside them)
+            stack[sp++] = head;
+            while (sp > 0) {
+                lb_emit(stack[--sp], children, node_box, seg, pow2, links16, nodes, next, &n_next);
+                for (int k = 0; k < n_next && sp < 96; k++) stack[sp++] = next[k];
+            }
+        }
+    }
+}
+}  // namespace
+
+size_t lbvh_sort_temp_bytes(uint32_t slots) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)slots, 0, 64, (hipStream_t) nullptr);
+    return bytes;
+}
+uint32_t lbvh_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
+
+int lbvh_build(const LbvhArgs& a, hipStream_t s) {
+    if (a.live < 2u) return -1;   // the caller keeps the host path for a scene of fewer than two triangles
+    const uint32_t pow2 = lbvh_pow2(a.live);
+    auto grid = [](uint32_t n) { return dim3((n + kT - 1) / kT); };
+    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, a.bounds, a.counters);
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((a.slots + kT - 1) / kT, 2048u)), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds);
+    hipLaunchKernelGGL(k_lbvh_keys, grid(a.slots), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds, a.keys_in);
+    size_t temp = a.sort_temp_bytes;
+    if (hipcub::DeviceRadixSort::SortKeys(a.sort_temp, temp, a.keys_in, a.keys_out, (int)a.slots, 0, 64, s) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_lbvh_leaves, grid(pow2), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.tri_geo, a.tri_bounds, a.tri_info, a.seg, a.leaves);
+    for (uint32_t count = pow2 >> 1; count >= 1u; count >>= 1) hipLaunchKernelGGL(k_lbvh_seg_level, grid(count), dim3(kT), 0, s, a.seg, count, count);
+    hipLaunchKernelGGL(k_lbvh_hierarchy, grid(a.live - 1u), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.seg, a.children, a.node_box);
+    // frontier levels before the finishing launch. Measured at 208 k triangles: with 8 levels the finishing launch — single threads walking deep,
+    // narrow subtrees one dependent load after the other — took 8 ms of a 9-ms build; the tree's wide levels are few dozen, a launch over an
+    // empty frontier costs 4 us.
+    constexpr uint32_t kLevels = 40;
+    for (uint32_t level = 0; level <= kLevels; level++) {
+        const uint32_t* in = (level & 1u) ? a.frontier_b : a.frontier_a;   // level 0 reads no frontier: its one item is the root
+        uint32_t* out = (level & 1u) ? a.frontier_a : a.frontier_b;
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min<uint32_t>((a.live + kT - 1) / kT, 1024u)), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes,
+                           in, out, a.counters, level, level == kLevels ? 1u : 0u);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace st

@@ -390,6 +390,7 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
     Engine* en = E(e);
     const void* p; size_t bytes;
     if ((what == 0 || what == 1 || what == 4 || (what >= 7 && what <= 15)) && en->any_host_stale()) en->bake_stale_on_host();   // instances the device moved: the host arrays catch up
+    if (en->host_tree_stale && (what == 0 || what == 4 || (what >= 7 && what <= 15))) en->rebuild_host_tree(false);   // ST_BVH_BUILD_DEVICE left the host's tree behind
     if ((what == 0 || what == 4) && en->host_stream_stale) { en->refit_stream(); en->host_stream_stale = false; }  // device refits since the host copy was current
     switch (what) {
         case 0: p = en->bvh_stream.data(); bytes = en->bvh_stream.size() * sizeof(float4); break;
@@ -428,7 +429,7 @@ int st_debug_read_scene(StEngine* e, int what, void* out, size_t capacity, size_
         case 16: case 17: {  // the wide stream as it is on the device right now (the live copy): 16 = nodes (64 B each), 17 = leaf records (48 B each)
             if (!en->has_device || !en->scene_uploaded) return fail(ST_ERR_NO_DEVICE, "no device copy of the scene");
             const auto& t = en->sets[en->live];
-            const size_t n = t.wide_for_entries ? (what == 16 ? (size_t)t.wide_nodes * 4u : (size_t)t.wide_leaves * 3u) : 0;
+            const size_t n = (t.wide_for_entries || t.device_built) ? (what == 16 ? (size_t)t.wide_nodes * 4u : (size_t)t.wide_leaves * 3u) : 0;
             en->readback_.resize(n);
             ST_HIP(hipSetDevice(en->device)); ST_HIP(hipDeviceSynchronize());
             if (n) ST_HIP(hipMemcpy(en->readback_.data(), what == 16 ? t.bvh_wide.ptr : static_cast<const void*>(static_cast<const float4*>(t.bvh_wide.ptr) + 4u * (size_t)t.wide_nodes), n * sizeof(float4), hipMemcpyDeviceToHost));
@@ -450,11 +451,12 @@ int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame) {
 
 int st_set_bvh_refresh(StEngine* e, int mode) {
     ST_REQUIRE(e, "null engine");
-    ST_REQUIRE(mode == ST_BVH_REBUILD || mode == ST_BVH_REFIT || mode == ST_BVH_REFIT_DEVICE, "unknown refresh mode");
+    ST_REQUIRE(mode == ST_BVH_REBUILD || mode == ST_BVH_REFIT || mode == ST_BVH_REFIT_DEVICE || mode == ST_BVH_BUILD_DEVICE, "unknown refresh mode");
     Engine* en = E(e);
     if (en->bvh_refresh_mode != mode) { en->bvh_refresh_mode = mode; en->have_topology = false; }
     return ST_OK;
 }
+int st_debug_device_builds(StEngine* e, uint64_t* ticks) { ST_REQUIRE(e && ticks, "null argument"); *ticks = E(e)->device_builds; return ST_OK; }
 int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* stack_entries) {
     ST_REQUIRE(e && deepest_internal_chain && stack_entries, "null argument");
     *deepest_internal_chain = E(e)->bvh_stack_need; *stack_entries = E(e)->stack_entries;

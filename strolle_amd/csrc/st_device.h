@@ -693,7 +693,8 @@ ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
     const float limit = ray.len;
     const RaySlabs rs = ray_slabs(ray);
     uint32_t cur = a.bvh_w_root;
-    int sp = 0;
+    SE* top = stack;                                             // the stack pointer is the LDS address itself: a push / pop is one add, no index -> address step
+    const SE* const stack_end = stack + a.stack_entries * 64u;
     bool hit = false;
     for (;;) {
         const bool leaf = (cur & 1u) != 0u;
@@ -708,9 +709,9 @@ ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
             uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, limit, t3, 2);
             uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, limit, t3, 3);
             ST_WIDE_SORT4(k0, k1, k2, k3);
-            if (k3 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k3, t3); sp++; } }
-            if (k2 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k2, t3); sp++; } }
-            if (k1 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k1, t3); sp++; } }
+            if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, t3); top += 64; } }
+            if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, t3); top += 64; } }
+            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, t3); top += 64; } }
             if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, t3); continue; }
         } else {
             const uint32_t head = f2b(t0.w);
@@ -724,7 +725,7 @@ ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
             if (found) { hit = true; break; }
             if (head & 1u) { cur += 2u; continue; }   // the next record of the run
         }
-        if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64]; } else break;
+        if (top > stack) { top -= 64; cur = (uint32_t)*top; } else break;
     }
     return hit;
 }
@@ -734,7 +735,8 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
     if (a.bvh_len == 0u) return false;
     const RaySlabs rs = ray_slabs(ray);
     uint32_t cur = a.bvh_w_root;
-    int sp = 0;
+    SE* top = stack;                                             // the stack pointer is the LDS address itself: a push / pop is one add, no index -> address step
+    const SE* const stack_end = stack + a.stack_entries * 64u;
     bool found_any = false;
     for (;;) {
         const bool leaf = (cur & 1u) != 0u;
@@ -750,9 +752,9 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
             uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, lim, t3, 2);
             uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, lim, t3, 3);
             ST_WIDE_SORT4(k0, k1, k2, k3);
-            if (k3 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k3, t3); sp++; } }
-            if (k2 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k2, t3); sp++; } }
-            if (k1 != 0xffffffffu) { if (sp < (int)a.stack_entries) { stack[sp * 64] = (SE)WideKeys<SE>::link(k1, t3); sp++; } }
+            if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, t3); top += 64; } }
+            if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, t3); top += 64; } }
+            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, t3); top += 64; } }
             if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, t3); continue; }
         } else {
             const uint32_t head = f2b(t0.w);
@@ -778,7 +780,7 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
             }
             if (head & 1u) { cur += 2u; continue; }
         }
-        if (sp > 0) { sp--; cur = (uint32_t)stack[sp * 64]; } else break;
+        if (top > stack) { top -= 64; cur = (uint32_t)*top; } else break;
     }
     return found_any;
 }

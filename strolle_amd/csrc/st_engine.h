@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/strolle_hip.h"
+#include "st_lbvh.h"
 #include "st_atlas.h"
 #include "st_bvh.h"
 #include "st_kernels.h"
@@ -423,6 +424,10 @@ struct Engine {
         // k_bvh.hip k_bvh_wide: 4-wide nodes (64 B) + leaf records (48 B), regenerated whenever `bvh` changed; the topology arrays only when the tree was rebuilt
         DeviceArray bvh_wide /* the nodes, then the leaf records */, wide_topo, wide_leaf_entry; uint32_t wide_nodes = 0, wide_leaves = 0, wide_root = 0, wide_links16 = 0, wide_for_entries = 0;
         uint64_t wide_topology_serial = 0;   // which build_wide_topology() result this copy holds
+        // ST_BVH_BUILD_DEVICE (k_lbvh.hip): this copy's wide stream was built on the device from its own triangle arrays; `bvh` (the contract
+        // stream) is then stale and no launch may read it. lb_live: live triangles of that build. The rest is the builder's scratch.
+        bool device_built = false; uint32_t lb_live = 0;
+        DeviceArray tri_info, lb_keys_a, lb_keys_b, lb_temp, lb_seg, lb_children, lb_node_box, lb_front_a, lb_front_b, lb_small;
         // ST_BVH_REFIT_DEVICE: what k_bvh.hip needs beside the stream — per triangle slot the hit-test record, the bounds and the
         // device entry that holds it; per entry its parent (entry << 1 | child slot); the leaf runs; an arrival counter per entry.
         // tree_version says which build of the tree these (and the stream's topology) belong to.
@@ -516,6 +521,13 @@ struct Engine {
     // One thread: at 134 k triangles the sweep is about a millisecond, less than starting a worker pool for it would buy back.
     void refit_stream() { refit_span(0, bvh_stream.size()); }
     bool device_refit_possible() const { return bvh_refresh_mode == ST_BVH_REFIT_DEVICE && has_device; }
+    // ST_BVH_BUILD_DEVICE: the tree of a changed scene is built on the device (k_lbvh.hip) while nothing observes the contract stream
+    bool host_tree_stale = false;    // the host's binned-SAH tree (bvh_stream and everything derived from it) is behind the scene
+    uint64_t device_builds = 0;
+    std::vector<uint32_t> tri_info_;
+    bool device_build_possible() const;
+    int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);
+    void rebuild_host_tree(bool timing);
 
     int tick(hipStream_t stream);
 

@@ -1,0 +1,26 @@
+// st_lbvh.h — interface of the device BVH builder (k_lbvh.hip): built once into the library, whatever arithmetic the frames use.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace st {
+
+// Everything is device memory the caller owns. tri_info: one word per triangle slot — bit 0 the slot is live, bit 1 its material is
+// AlphaMode::Blend, bits 2.. its material slot. Output: `nodes` (64 B per node, node index = the head's index in the binary radix tree:
+// live - 1 slots, sparsely used; the root is node 0) and `leaves` (48 B per record, sorted order), in the wide stream's format
+// (st_device.h closest_hit_wide). Scratch: keys_in / keys_out (8 B x slots), sort_temp (lbvh_sort_temp_bytes(slots)), seg
+// (2 x lbvh_pow2(live) boxes of 32 B), children (8 B x live), node_box (32 B x live), frontier_a / frontier_b (4 B x live), bounds (6 ints),
+// counters (3 words).
+struct LbvhArgs {
+    const float4* tri_geo; const float4* tri_bounds; const uint32_t* tri_info;
+    uint32_t slots, live, links16;
+    float4* nodes; float4* leaves;
+    unsigned long long* keys_in; unsigned long long* keys_out; void* sort_temp; size_t sort_temp_bytes;
+    float4* seg; uint2* children; float4* node_box; uint32_t* frontier_a; uint32_t* frontier_b; int* bounds; uint32_t* counters;
+};
+size_t lbvh_sort_temp_bytes(uint32_t slots);
+uint32_t lbvh_pow2(uint32_t n);
+int lbvh_build(const LbvhArgs& args, hipStream_t stream);   // 0, or negative: -1 fewer than two live triangles, -2 the sort failed, -3 a launch failed
+
+}  // namespace st

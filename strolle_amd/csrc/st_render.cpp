@@ -123,7 +123,12 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.bvh_c = compact ? static_cast<const float4*>(scene.bvh_compact.ptr) : nullptr;
     a.bvh_c_root = (compact && device_root_is_leaf) ? 1u : 0u;
     // ... or, preferred, its wide form (k_bvh.hip k_bvh_wide)
-    const bool wide = compact && tuning.wide_bvh && scene.wide_for_entries != 0u && scene.wide_for_entries * 4u == device_bvh_len;
+    // (ST_BVH_BUILD_DEVICE: this copy's wide stream was built on the device and its contract stream is stale — every ray must walk the wide stream)
+    const bool contract_observer = arithmetic != ST_ARITH_FAST || !tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes || c.desc.mode == ST_MODE_BVH_HEATMAP;
+    if (scene.device_built && contract_observer)
+        return fail(ST_ERR_INVALID_ARGUMENT, "the live scene copy's tree was built on the device (ST_BVH_BUILD_DEVICE) and this frame needs the contract stream (heatmap camera, exact arithmetic, "
+                                             "byte counting or a switched-off wide stream): st_tick builds it on the host once it sees the observer");
+    const bool wide = scene.device_built || (compact && tuning.wide_bvh && scene.wide_for_entries != 0u && scene.wide_for_entries * 4u == device_bvh_len);
     a.bvh_w = wide ? static_cast<const float4*>(scene.bvh_wide.ptr) : nullptr;
     a.bvh_w_leaf_off = wide ? scene.wide_nodes * 64u : 0u;
     a.bvh_w_root = wide ? scene.wide_root : 0u; a.bvh_w_links16 = wide ? scene.wide_links16 : 0u;
@@ -134,7 +139,8 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     // no ray comes near it (deepest stack measured: 11-13); it keeps kBvhStackSize entries, and test_the_wide_walk_drops_no_push renders
     // BASELINE config 3's scene with 24 and with 48 entries (StTuning::wide_stack_entries) and finds the same bits.
     a.stack_entries = wide ? (tuning.wide_stack_entries ? tuning.wide_stack_entries : (uint32_t)kBvhStackSize) : stack_entries;
-    a.bvh_len = device_bvh_len; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
+    a.bvh_len = scene.device_built ? 0x40000000u : device_bvh_len;   // (device-built: no contract stream; any value that is neither "empty" nor "fits LDS")
+    if (scene.device_built) a.bvh = nullptr; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
     a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;
     a.sun_dir[0] = sun_dir_.x; a.sun_dir[1] = sun_dir_.y; a.sun_dir[2] = sun_dir_.z;
     auto P = [&](int id) { return c.plane[id]; };

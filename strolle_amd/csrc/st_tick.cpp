@@ -3,6 +3,84 @@
 
 namespace st {
 
+// The host's binned-SAH tree of the scene as it is now (st_bvh.h: the reference's tree, with unchanged subtrees reused) and its flattened stream.
+void Engine::rebuild_host_tree(bool timing) {
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    if (any_host_stale()) bake_stale_on_host();
+    std::vector<uint8_t> blend(materials.size());
+    for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
+    const auto t1 = now();
+    bvh.begin_refresh();  // keeps the previous tree: unchanged subtrees are copied, not rebuilt (same result as a fresh build)
+    for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
+    const auto t2 = now();
+    bvh.run();
+    const auto t3 = now();
+    bvh.flatten(blend, bvh_stream);
+    const auto t4 = now();
+    rebuilds++; tree_version++; host_stream_stale = false; host_tree_stale = false;
+    mark_internal_starts(); measure_stack_need();
+    have_topology = false;
+    if (timing) fprintf(stderr, "[st_tick] gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles, %zu reused)\n", ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size(), bvh.reused_primitives());
+}
+// ST_BVH_BUILD_DEVICE applies while nothing observes the contract stream: the fast build's rays walk the wide stream (StTuning::wide_bvh and
+// what it rests on), no camera draws the heatmap, the reference's traversal bytes are not being counted — and there is a scene to sort.
+bool Engine::device_build_possible() const {
+    if (bvh_refresh_mode != ST_BVH_BUILD_DEVICE || !has_device || arithmetic != ST_ARITH_FAST) return false;
+    if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes) return false;
+    for (const auto& kv : cameras) if (kv.second->desc.mode == ST_MODE_BVH_HEATMAP) return false;
+    size_t live = 0;
+    for (uint8_t a : prim_alive) live += a;
+    return live >= 2u && prims.size() < (1u << 23);
+}
+// This device copy's triangle arrays brought up to date, then k_lbvh.hip builds its wide stream from them.
+int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
+    int rc;
+    const size_t slots = prims.size();
+    tri_info_.resize(slots);
+    uint32_t live = 0;
+    for (size_t i = 0; i < slots; i++) {
+        const uint32_t mat = prims[i].material_id;
+        const uint32_t blend = mat < materials.size() && materials[mat].alpha_mode == 1u ? 2u : 0u;
+        tri_info_[i] = (prim_alive[i] ? 1u : 0u) | blend | (mat << 2);
+        live += prim_alive[i] ? 1u : 0u;
+    }
+    const bool whole = !t.valid || t.tri_full || t.tri_geo.capacity < tri_geo.size() * sizeof(float4) || t.tri_bounds.capacity < tri_bounds.size() * sizeof(float4);
+    if (whole) {
+        if ((rc = t.tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), up, staging, pageable))) return rc;
+        if ((rc = t.tri_bounds.upload(tri_bounds.data(), tri_bounds.size() * sizeof(float4), up, staging, pageable))) return rc;
+    } else if (t.dirty_lo < t.dirty_hi) {
+        if ((rc = t.tri_geo.upload_range(tri_geo.data(), 3 * t.dirty_lo * sizeof(float4), 3 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, pageable))) return rc;
+        if ((rc = t.tri_bounds.upload_range(tri_bounds.data(), 2 * t.dirty_lo * sizeof(float4), 2 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, pageable))) return rc;
+    }
+    if ((rc = t.tri_info.upload(tri_info_.data(), slots * sizeof(uint32_t), up, staging, pageable))) return rc;
+    const uint32_t pow2 = lbvh_pow2(live);
+    const size_t temp = lbvh_sort_temp_bytes((uint32_t)slots);
+    auto need = [&](DeviceArray& d, size_t bytes) -> int {   // scratch: grown with headroom, never shrunk
+        if (bytes <= d.capacity) return ST_OK;
+        if (d.ptr) ST_HIP(hipFree(d.ptr));
+        d.ptr = nullptr; d.capacity = 0;
+        ST_HIP(hipMalloc(&d.ptr, bytes + bytes / 4)); d.capacity = bytes + bytes / 4;
+        return ST_OK;
+    };
+    if ((rc = need(t.lb_keys_a, slots * 8u)) || (rc = need(t.lb_keys_b, slots * 8u)) || (rc = need(t.lb_temp, std::max<size_t>(temp, 16u))) || (rc = need(t.lb_seg, (size_t)pow2 * 2u * 32u)) ||
+        (rc = need(t.lb_children, (size_t)live * 8u)) || (rc = need(t.lb_node_box, (size_t)live * 32u)) || (rc = need(t.lb_front_a, (size_t)live * 4u)) ||
+        (rc = need(t.lb_front_b, (size_t)live * 4u)) || (rc = need(t.lb_small, 64u)) || (rc = need(t.bvh_wide, (size_t)(live - 1u) * 64u + (size_t)live * 48u + 64u))) return rc;
+    LbvhArgs a{};
+    a.tri_geo = static_cast<const float4*>(t.tri_geo.ptr); a.tri_bounds = static_cast<const float4*>(t.tri_bounds.ptr); a.tri_info = static_cast<const uint32_t*>(t.tri_info.ptr);
+    a.slots = (uint32_t)slots; a.live = live; a.links16 = live < 32768u ? 1u : 0u;
+    a.nodes = static_cast<float4*>(t.bvh_wide.ptr); a.leaves = a.nodes + 4u * (size_t)(live - 1u);
+    a.keys_in = static_cast<unsigned long long*>(t.lb_keys_a.ptr); a.keys_out = static_cast<unsigned long long*>(t.lb_keys_b.ptr);
+    a.sort_temp = t.lb_temp.ptr; a.sort_temp_bytes = temp;
+    a.seg = static_cast<float4*>(t.lb_seg.ptr); a.children = static_cast<uint2*>(t.lb_children.ptr); a.node_box = static_cast<float4*>(t.lb_node_box.ptr);
+    a.frontier_a = static_cast<uint32_t*>(t.lb_front_a.ptr); a.frontier_b = static_cast<uint32_t*>(t.lb_front_b.ptr);
+    a.bounds = static_cast<int*>(t.lb_small.ptr); a.counters = static_cast<uint32_t*>(t.lb_small.ptr) + 8;
+    if (lbvh_build(a, up) != 0) return fail(ST_ERR_HIP, "the device BVH build failed to launch");
+    t.device_built = true; t.lb_live = live;
+    t.wide_nodes = live - 1u; t.wide_leaves = live; t.wide_root = 0u; t.wide_links16 = a.links16; t.wide_for_entries = 0u; t.compact_entries = 0u;
+    return ST_OK;
+}
+
 // ---- tick (lib.rs:301-395)
 int Engine::tick(hipStream_t stream) {
     bool scene_changed = false;
@@ -12,37 +90,36 @@ int Engine::tick(hipStream_t stream) {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();
-    if (refresh_instances()) {
+    const bool instances_changed = refresh_instances();
+    if (instances_changed) {
         for (const auto& inst : instances) {
             float4* x = instance_xforms.data() + 8u * inst.xslot;
             const Affine* src[2] = {&inst.xform_inv, &inst.prev_xform};
             for (int k = 0; k < 2; k++) { x[4 * k] = f4(src[k]->x, 0.0f); x[4 * k + 1] = f4(src[k]->y, 0.0f); x[4 * k + 2] = f4(src[k]->z, 0.0f); x[4 * k + 3] = f4(src[k]->t, 0.0f); }
         }
+    }
+    // ST_BVH_BUILD_DEVICE: while nothing observes the contract stream the changed scene's tree is built on the device (below, per device copy)
+    // and the host's tree falls behind; the first tick that finds an observer brings it up to date like any rebuild.
+    const bool build_on_device_now = device_build_possible();
+    if (instances_changed && build_on_device_now) {
+        host_tree_stale = true; device_builds++; scene_changed = true;
+        if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, tree: on the device\n", ms(t0, now()));
+    } else if (instances_changed || (host_tree_stale && !build_on_device_now)) {
         const auto t1 = now();
         std::vector<uint8_t> blend(materials.size());
         for (size_t i = 0; i < materials.size(); i++) blend[i] = materials[i].alpha_mode == 1u;
-        const bool refitting = bvh_refresh_mode != ST_BVH_REBUILD;
+        const bool refitting = bvh_refresh_mode == ST_BVH_REFIT || bvh_refresh_mode == ST_BVH_REFIT_DEVICE;
         // (moved_on_device: refresh_instances saw nothing but transforms change — slots, materials and Blend flags are what the last build saw)
         const uint64_t signature = moved_on_device ? topology_signature : (refitting ? topology_of(blend) : 0);
-        if (refitting && have_topology && signature == topology_signature) {
+        if (refitting && have_topology && !host_tree_stale && signature == topology_signature) {
             // ST_BVH_REFIT_DEVICE: the boxes are recomputed on the device from the moved triangles' bounds (k_bvh.hip); the host's
             // copy of the stream is brought up to date only when something reads it
             if (device_refit_possible()) host_stream_stale = true; else refit_stream();
             refits++;
             if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, refit %.2f ms (%zu internal nodes)\n", ms(t0, t1), ms(t1, now()), internal_positions.size());
         } else {
-            bvh.begin_refresh();  // keeps the previous tree: unchanged subtrees are copied, not rebuilt (same result as a fresh build)
-            for (size_t i = 0; i < prims.size(); i++) if (prim_alive[i]) bvh.prims.push_back(prims[i]);
-            const auto t2 = now();
-            bvh.run();
-            const auto t3 = now();
-            bvh.flatten(blend, bvh_stream);
-            const auto t4 = now();
-            rebuilds++; tree_version++; host_stream_stale = false;
-            mark_internal_starts(); measure_stack_need();
-            have_topology = false;
+            rebuild_host_tree(timing);
             if (refitting) { index_stream(); topology_signature = signature; have_topology = true; }
-            if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, gather %.2f ms, bvh build %.2f ms, flatten %.2f ms (%zu triangles, %zu reused)\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), bvh.prims.size(), bvh.reused_primitives());
         }
         scene_changed = true;
     }
@@ -91,7 +168,11 @@ int Engine::tick(hipStream_t stream) {
             } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
             SceneSet& t = sets[target];
             bool attr_sent = false;
-            const bool device_path = device_refit_possible() && t.valid && !t.tri_full && t.tree_version == tree_version && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4);
+            if (build_on_device_now) {
+                if (any_host_stale()) bake_stale_on_host();
+                if ((rc = build_on_device(t, up, flag))) return rc;
+            } else t.device_built = false;
+            const bool device_path = !build_on_device_now && device_refit_possible() && t.valid && !t.tri_full && t.tree_version == tree_version && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4);
             // a copy that cannot be brought up to date in place is sent whole, from the host's arrays: instances the device moved must be in them
             if (!device_path && any_host_stale()) bake_stale_on_host();
             if (device_path) {
@@ -114,7 +195,7 @@ int Engine::tick(hipStream_t stream) {
                     L.launch_bvh_refit(static_cast<float4*>(t.bvh.ptr), static_cast<const float4*>(t.tri_bounds.ptr), static_cast<const uint32_t*>(t.parent.ptr), static_cast<const uint32_t*>(t.refit_local.ptr),
                                        static_cast<const uint32_t*>(t.refit_items.ptr), static_cast<const uint32_t*>(t.refit_batch_off.ptr), level.first, level.second, up);
                 device_refits++;
-            } else {
+            } else if (!build_on_device_now) {
                 if (host_stream_stale) { refit_stream(); host_stream_stale = false; }
                 expand_stream();
                 // traversal pointers are 32-bit BYTE offsets into the device stream (64 B per entry) and stack slots hold entry numbers
@@ -132,8 +213,10 @@ int Engine::tick(hipStream_t stream) {
                     t.tree_version = tree_version;
                 }
             }
-            if ((rc = refresh_compact_stream(t, up))) return rc;   // the shadow rays' compact form follows every change of the contract stream
-            if ((rc = refresh_wide_stream(t, up, !device_path, flag))) return rc;   // and so does the wide form (its topology only when the tree itself was sent)
+            if (!build_on_device_now) {
+                if ((rc = refresh_compact_stream(t, up))) return rc;   // the shadow rays' compact form follows every change of the contract stream
+                if ((rc = refresh_wide_stream(t, up, !device_path, flag))) return rc;   // and so does the wide form (its topology only when the tree itself was sent)
+            }
             // attribute records: whole the first time or after they grew, otherwise only the slots baked since this copy was written
             const bool partial = t.valid && !t.tri_full && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
             if (!partial) {
@@ -146,7 +229,7 @@ int Engine::tick(hipStream_t stream) {
             if ((rc = t.materials.upload(gpu_materials.data(), gpu_materials.size() * sizeof(GpuMaterial), up, staging, flag))) return rc;
             if ((rc = t.base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), up, staging, flag))) return rc;
             if (other_copy) copied_now = true;
-            live = target; live_bvh_texels = device_bvh_len;
+            live = target; live_bvh_texels = build_on_device_now ? 0u : device_bvh_len;
             scene_uploaded = true;
             scene_changed = !other_copy;  // in-place uploads count as work on the caller's stream below
         }

@@ -26,8 +26,8 @@ import numpy as np
 import pytest
 
 from oracle_binding import OracleEngine
-from parity import psnr
-from strolle_amd import Buffer, CameraMode, Engine, PassBit, scenes
+from parity import assert_bits_equal, psnr
+from strolle_amd import Buffer, CameraMode, Engine, Instance, Mesh, PassBit, StrolleError, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -402,3 +402,69 @@ def test_the_wide_walk_drops_no_push():
             e.close()
         for name, a, b in zip(["composed frame"] + [x.name for x in bufs], *runs):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"subdivide {sub}: {name} differs between a 24- and a 48-entry stack: a push was dropped"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subdivide", [0, 2])
+def test_a_tree_built_on_the_device_finds_the_same_hits(subdivide):
+    """ST_BVH_BUILD_DEVICE (k_lbvh.hip): after a scene change the fast build's tree is built on the device — Morton sort, Karras'
+    binary radix tree, 4-wide collapse — instead of the host's binned SAH. Another tree, the same hits: primary hits and the shaded Reference
+    frame against an engine that rebuilds on the host, after the first build, after spawning an instance and after removing one (the
+    stress-bvh.rs situation); 16-bit links at 13 k triangles, 32-bit links at 208 k. The host tree is not touched meanwhile, and comes back — bit for
+    bit the reference's, heatmap integers included — at the first tick that finds a heatmap camera."""
+    torch = _torch()
+    size = (192, 112)
+    host, dev = Engine(device=0, exact=False), Engine(device=0, exact=False)
+    dev.set_bvh_refresh(3)
+    rng = np.random.default_rng(2)
+    pos = (rng.uniform(-0.3, 0.3, (200, 1, 3)) + rng.uniform(-0.05, 0.05, (200, 3, 3))).astype(np.float32)
+    nrm = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
+    blob = Mesh(pos, np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32))
+    cams = []
+    for e in (host, dev):
+        scenes.build_dungeon(e, subdivide=subdivide); e.set_seed(9)
+        e.insert_mesh(7777, blob)
+        desc = scenes.dungeon_camera(size, CameraMode.REFERENCE, depth=1)
+        cams.append((e, e.create_camera(desc), desc))
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+
+    def frame(e, cam, desc):
+        e.update_camera(cam, desc); e.tick(); e.render_camera(cam, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return e.read_buffer(cam, Buffer.REF_HITS).reshape(size[1], size[0], -1).copy(), out.cpu().numpy()[..., :3].copy()
+
+    def compare(what):
+        (h_hits, h_img), (d_hits, d_img) = (frame(*c) for c in cams)
+        bad = lanes_outside_tolerance(d_hits, h_hits, rtol=1e-4, atol=1e-5).reshape(h_hits.shape).any(-1)
+        assert np.isfinite(h_hits[..., 0]).sum() > 2000, "the scene is not in view"
+        assert bad.mean() <= 2e-3, f"{what}: {bad.mean():.2e} of the primary hits differ between the device-built and the host-built tree"
+        peak = float(np.percentile(h_img, 99.9)) or 1.0
+        p = psnr(np.clip(d_img, 0, peak), np.clip(h_img, 0, peak), peak)
+        assert p >= 40.0, f"{what}: shaded Reference frame PSNR {p:.1f} dB"
+
+    compare("first build")
+    assert dev.device_builds() == 1 and dev.bvh_refits()[0] == 0, "the host tree was built although nothing observes it"
+    nodes = dev.read_scene(16)
+    assert len(nodes) > 0, "the device-built wide stream is not live"
+    place = np.eye(4, dtype=np.float32)[:3].copy(); place[:, 3] = (-5.75, 0.6, -18.2)
+    for e, _, _ in cams:
+        e.insert_instance(7777, Instance(7777, 2, place))       # spawn: in front of the camera
+    compare("after a spawn")
+    for e, _, _ in cams:
+        e.remove_instance(7777)
+    compare("after a despawn")
+    assert dev.device_builds() == 3 and dev.bvh_refits()[0] == 0
+    assert host.bvh_refits()[0] == 3
+    # a heatmap camera needs the contract stream: refused until a tick has seen it, then the reference's tree is back bit for bit
+    hm_desc = scenes.dungeon_camera(size, CameraMode.BVH_HEATMAP)
+    hm_dev, hm_host = dev.create_camera(hm_desc), host.create_camera(hm_desc)
+    with pytest.raises(StrolleError, match="ST_BVH_BUILD_DEVICE"):
+        dev.render_camera(hm_dev, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for e, c in ((dev, hm_dev), (host, hm_host)):
+        e.update_camera(c, hm_desc); e.tick(); e.render_camera(c, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert dev.bvh_refits()[0] == 1, "the tick that found the heatmap camera rebuilds on the host"
+    assert np.array_equal(dev.read_buffer(hm_dev, Buffer.DBG_USED_MEMORY), host.read_buffer(hm_host, Buffer.DBG_USED_MEMORY))
+    assert_bits_equal(dev.read_scene(0), host.read_scene(0), "the host tree after device builds")
+    for e, _, _ in cams:
+        e.close()

@@ -23,7 +23,7 @@ def _scene(name):
     topo = e.read_scene(14).view(np.uint32)
     leaf_entry = e.read_scene(15).view(np.uint32)
     e.close()
-    return stream, int(topo[0]), topo[1:].reshape(-1, 8), leaf_entry
+    return stream, int(topo[0]) & 0xff, topo[1:].reshape(-1, 8), leaf_entry   # (bits 8.. of the first word: the walk's worst-case pending entries)
 
 
 @pytest.mark.parametrize("name", ["cornell", "soup", "dungeon"])
