@@ -6,12 +6,15 @@
 //!
 //! ```ignore
 //! let id = if rank == 0 { let id = dist::unique_id()?; share(&id); id } else { receive() };
-//! let mut node = dist::Node::join(&mut engine, rank, world, &id)?;
+//! // SAFETY: `engine` is declared before `node`, so `node` is dropped first (its Drop calls st_dist_shutdown on the engine's handle)
+//! let mut node = unsafe { dist::Node::join(engine.raw_handle(), rank, world, &id)? };
 //! let (owned, window) = node.partition(camera, 0 /* default grid */, 16 /* apron */)?;
 //! loop {
 //!     engine.tick(..); engine.render_into(camera, frames[k]);          // composes only `window`
 //!     node.gather(camera, frames[k], if rank == 0 { full } else { null_mut() })?;   // returns at once; overlaps frame N+1
 //!     k ^= 1;
+//!     // every few frames: all ranks exchange their frame times and move the tile edges (cost-weighted grid)
+//!     // let (grid2, owned, window) = node.rebalance(camera, w, h, &grid, &frame_ms_of_all_ranks, 16, 16)?;
 //! }
 //! ```
 use crate::ffi;
@@ -50,7 +53,11 @@ pub struct Node {
 
 impl Node {
     /// joins the RCCL communicator on the engine's device
-    pub fn join(engine: *mut ffi::StEngine, rank: i32, world: i32, id: &ffi::StDistUniqueId) -> Result<Self, DistError> {
+    ///
+    /// # Safety
+    /// `engine` must be a live engine handle and must outlive this `Node`: `Drop` calls `st_dist_shutdown` on it (declare the `Node` AFTER
+    /// the engine wrapper, so that it is dropped first).
+    pub unsafe fn join(engine: *mut ffi::StEngine, rank: i32, world: i32, id: &ffi::StDistUniqueId) -> Result<Self, DistError> {
         check(unsafe { ffi::st_dist_init(engine, rank, world, id) })?;
         Ok(Self { engine, rank, world })
     }
@@ -59,6 +66,18 @@ impl Node {
         let (mut o, mut w) = (ffi::StDistRect::default(), ffi::StDistRect::default());
         check(unsafe { ffi::st_dist_set_partition(self.engine, camera, cols, apron, &mut o, &mut w) })?;
         Ok((o, w))
+    }
+    /// Cost-weighted tiles: from every rank's frame time (one f32 per rank, gathered by the host's own means, the same on every rank) the
+    /// grid whose tiles would cost the same, edges moved by at most `max_step` pixels (<= the apron keeps every newly owned pixel's history
+    /// warm); this rank's tile of it becomes the camera's window. `current`: st_dist_grid's equal split the first time, then what this returned.
+    pub fn rebalance(&mut self, camera: u64, width: u32, height: u32, current: &ffi::StDistGrid, frame_ms: &[f32], apron: u32, max_step: u32)
+        -> Result<(ffi::StDistGrid, ffi::StDistRect, ffi::StDistRect), DistError> {
+        assert_eq!(frame_ms.len() as u32, current.cols * current.rows);
+        let mut next = *current;
+        check(unsafe { ffi::st_dist_grid_rebalance(width, height, current, frame_ms.as_ptr(), max_step, &mut next) })?;
+        let (mut o, mut w) = (ffi::StDistRect::default(), ffi::StDistRect::default());
+        check(unsafe { ffi::st_dist_set_grid(self.engine, camera, &next, apron, &mut o, &mut w) })?;
+        Ok((next, o, w))
     }
     /// `frame`: the device buffer the frame was just composed into on `stream`; `full`: rank 0's assembled frame (may be `frame`)
     pub fn gather(&mut self, camera: u64, frame: *const c_void, full: *mut c_void, stream: ffi::hipStream_t) -> Result<(), DistError> {

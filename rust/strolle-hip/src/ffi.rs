@@ -107,6 +107,16 @@ pub struct StTuning {
 }
 
 /// [x0, x1) x [y0, y1) in pixels (st_dist_partition / st_dist_window)
+/// A (cost-weighted) tile grid every rank holds identically (st_dist_grid / st_dist_grid_rebalance / st_dist_set_grid)
+#[repr(C)]
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+pub struct StDistGrid {
+    pub cols: u32,
+    pub rows: u32,
+    pub row_edge: [u32; 17],
+    pub col_edge: [[u32; 17]; 16],
+}
+
 #[repr(C)]
 #[derive(Clone, Copy, Default, PartialEq, Eq, Debug)]
 pub struct StDistRect {
@@ -154,7 +164,8 @@ extern "C" {
     pub fn st_set_seed(e: *mut StEngine, seed: u64) -> i32;
     pub fn st_set_blue_noise(e: *mut StEngine, rgba: *const u8, bytes: usize) -> i32; // Noise::new (noise.rs:40-50)
     pub fn st_engine_set_arithmetic(e: *mut StEngine, arithmetic: i32) -> i32;
-    pub fn st_set_bvh_refresh(e: *mut StEngine, mode: i32) -> i32;
+    pub fn st_set_bvh_refresh(e: *mut StEngine, mode: i32) -> i32; // 0 rebuild, 1 refit, 2 refit on the device, 3 build on the device (ST_BVH_BUILD_DEVICE)
+    pub fn st_debug_device_builds(e: *mut StEngine, ticks: *mut u64) -> i32;
     pub fn st_engine_get_tuning(e: *mut StEngine, out: *mut StTuning) -> i32;
     pub fn st_engine_set_tuning(e: *mut StEngine, tuning: *const StTuning) -> i32;
     // multi-GPU behind the boundary: one process per GPU, tiles + ONE gather to rank 0 over RCCL (dist.rs)
@@ -165,6 +176,10 @@ extern "C" {
     pub fn st_dist_init(e: *mut StEngine, rank: i32, world: i32, id: *const StDistUniqueId) -> i32;
     pub fn st_dist_shutdown(e: *mut StEngine) -> i32;
     pub fn st_dist_set_partition(e: *mut StEngine, camera: u64, cols: u32, apron: u32, owned: *mut StDistRect, window: *mut StDistRect) -> i32;
+    pub fn st_dist_grid(width: u32, height: u32, world: u32, cols: u32, out: *mut StDistGrid) -> i32;
+    pub fn st_dist_grid_tile(grid: *const StDistGrid, rank: u32, owned: *mut StDistRect) -> i32;
+    pub fn st_dist_grid_rebalance(width: u32, height: u32, current: *const StDistGrid, tile_cost: *const f32, max_step: u32, out: *mut StDistGrid) -> i32;
+    pub fn st_dist_set_grid(e: *mut StEngine, camera: u64, grid: *const StDistGrid, apron: u32, owned: *mut StDistRect, window: *mut StDistRect) -> i32;
     pub fn st_dist_gather(e: *mut StEngine, camera: u64, frame: *const c_void, full_on_root: *mut c_void, hip_stream: *mut c_void) -> i32;
     pub fn st_dist_wait(e: *mut StEngine, camera: u64, frame: *const c_void, hip_stream: *mut c_void, host_wait: i32) -> i32;
 }

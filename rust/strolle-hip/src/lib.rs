@@ -340,6 +340,11 @@ where
         }
     }
 
+    /// The library's engine handle, for the multi-GPU layer (`dist::Node::join`); valid while this `Engine` lives.
+    pub fn raw_handle(&mut self) -> *mut ffi::StEngine {
+        self.raw
+    }
+
     /// Not part of the reference's API: selects the bit-exact build of the kernels (for parity work).
     pub fn set_exact_arithmetic(&mut self, exact: bool) {
         check(unsafe { ffi::st_engine_set_arithmetic(self.raw, exact as i32) });
@@ -349,6 +354,12 @@ where
     /// (ST_BVH_REFIT_DEVICE = 2: st_tick sends the moved triangles only; same bits as the host refit).
     pub fn set_bvh_refit(&mut self, refit: bool) {
         check(unsafe { ffi::st_set_bvh_refresh(self.raw, if refit { 2 } else { 0 }) });
+    }
+
+    /// Not part of the reference's API: after a scene change build the tree ON THE DEVICE (ST_BVH_BUILD_DEVICE = 3: a spawn costs about a
+    /// millisecond instead of the host rebuild) while nothing observes the contract stream — no BvhHeatmap camera, fast arithmetic.
+    pub fn set_bvh_build_on_device(&mut self, on_device: bool) {
+        check(unsafe { ffi::st_set_bvh_refresh(self.raw, if on_device { 3 } else { 0 }) });
     }
 }
 

@@ -42,7 +42,7 @@ def test_rust_facade_binds_exported_symbols():
     lib, declared = load_library(), set(declared_symbols())
     assert not [s for s in bound if not hasattr(lib, s)] and not [s for s in bound if s not in declared]
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "strolle_hip.h")).read(), flags=re.S)
-    for name in ("StMeshTriangle", "StMaterial", "StLight", "StCamera", "StTuning", "StDistRect", "StDistUniqueId"):
+    for name in ("StMeshTriangle", "StMaterial", "StLight", "StCamera", "StTuning", "StDistRect", "StDistUniqueId", "StDistGrid"):
         c_body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
         c_fields = [f.strip().split("[")[0] for decl in c_body.split(";") if decl.strip() for f in decl.strip().split(" ", 1)[1].split(",")]
         r_body = re.search(r"pub struct %s \{(.*?)\n\}" % name, ffi, re.S).group(1)
@@ -693,3 +693,19 @@ def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):
     assert got == want, (got, want)
 
 
+
+
+def test_device_build_mode_without_a_device_builds_on_the_host():
+    """ST_BVH_BUILD_DEVICE needs a device copy of the scene and nothing that observes the contract stream; a host-only engine has neither, so the
+    mode falls back to the reference's rebuild: same stream, same refresh counts, no device builds."""
+    a, b = Engine(device=-1), Engine(device=-1)
+    b.set_bvh_refresh(3)
+    for e in (a, b):
+        scenes.build_cornell(e); e.tick()
+        e.insert_light(77, Light.point((0.0, 1.0, 0.0), 0.1, (1.0, 1.0, 1.0), 5.0)); e.tick()
+    assert_bits_equal(a.read_scene(0), b.read_scene(0), "BVH stream, ST_BVH_BUILD_DEVICE on a host-only engine")
+    assert a.bvh_refits() == b.bvh_refits() and b.device_builds() == 0
+    with pytest.raises(StrolleError):
+        b.set_bvh_refresh(4)
+    for e in (a, b):
+        e.close()
