@@ -41,8 +41,9 @@ enum StStatus {
     ST_ERR_IO = 7,               /* scene ingest: a file could not be read */
     ST_ERR_PARSE = 8,            /* scene ingest: malformed glTF / GLB / PNG; st_last_error() says where */
     ST_ERR_UNSUPPORTED = 9,      /* scene ingest: valid file using something this loader does not read (JPEG, Draco, ...) */
-    ST_ERR_BVH_TOO_DEEP = 10,    /* st_tick: the tree's deepest chain of internal nodes exceeds the kernels' 24-entry traversal stack
-                                  * (strolle-gpu/src/lib.rs:76; the reference indexes past its stack array there). The scene IS uploaded and
+    ST_ERR_BVH_TOO_DEEP = 10,    /* st_tick: the tree's deepest chain of internal nodes exceeds the deepest traversal stack the kernels take
+                                  * (24 entries as strolle-gpu/src/lib.rs:76 — the reference indexes past its stack array beyond that —, grown
+                                  * to the chain's own length for deeper trees, up to 32). The scene IS uploaded and
                                   * renders — pushes beyond the stack are dropped, so geometry behind them can be missed — but the tick
                                   * says so instead of returning ST_OK; StTuning::allow_deep_bvh = 1 turns the status back into a warning */
     ST_ERR_DIST = 11             /* st_dist_*: the collective transport failed (RCCL status in st_last_error()) */
@@ -183,9 +184,10 @@ int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits);
  * baked into world space on the device from object-space meshes uploaded once; a tick then sends 132 B per moved instance). */
 int st_debug_device_bakes(StEngine* e, uint64_t* ticks, uint64_t* triangles);   /* ticks whose boxes were recomputed by k_bvh.hip (ST_BVH_REFIT_DEVICE) */
 /* Depth check of the last BVH build: the longest chain of internal nodes (= the most far-child pointers one traversal can
- * have pending) against the per-ray stack of the kernels (24 entries, strolle-gpu/src/lib.rs:76). The reference writes past
- * its stack array when a tree is deeper; this library drops the push and says so once on stderr — a scene for which
- * *deepest_internal_chain > *stack_entries can miss geometry behind the dropped subtrees. */
+ * have pending) against the per-ray stack the launches that walk this tree take: 24 entries (strolle-gpu/src/lib.rs:76) while that is
+ * enough, the chain's own length for a deeper tree, up to 32 (dynamic LDS). The reference writes past its stack array when a tree is
+ * deeper than 24; this library drops a push only beyond 32 and says so — a scene for which *deepest_internal_chain > *stack_entries can
+ * miss geometry behind the dropped subtrees. */
 int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* stack_entries);
 
 /* Deterministic seeds: every pass draws seed = pass_seed(base, frame, pass_id) instead of

@@ -3,7 +3,7 @@
 # workload that fits one GPU the bench line + every rocprofv3 pass (tools/gpu_profile_workload.sh). Summarised afterwards, locally, by
 #   for k in cornell_1920x1080_image dungeon_1920x1080_image dungeon_3840x2160_image dungeon134k_1920x1080_gi_diffuse; do python tools/summarize_profiles.py r04 --key $k; done
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 python -c 'import __graft_entry__ as g; g.build()' || exit 1
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; head -c 400 gpurun_out/${TAG}_bench.json; echo
 bash tools/gpu_profile_workload.sh cornell_1920x1080_image
