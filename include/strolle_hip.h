@@ -309,7 +309,8 @@ typedef struct StTuning {
                                      * f16 child boxes + four links per aligned 64-B line (k_bvh.hip k_bvh_wide; the host collapses the binary tree once per build,
                                      * the device refills the boxes after every change) — half the dependent round trips and lines of the compact binary stream */
     uint32_t wide_stack_entries;    /* pending entries per ray of the wide walk's stack: 0 = 24 (strolle-gpu/src/lib.rs:76); tests render with 48 to show that 24 drops no push */
-    uint32_t _reserved[1];
+    uint32_t primary_packets;       /* with the wide stream: primary visibility walks it as ONE packet per wave — uniform node pointer and stack, scalar node
+                                     * fetches, per-lane box and triangle tests, ballots decide the descent (st_device.h closest_hit_packet) */
 } StTuning;
 int st_engine_get_tuning(StEngine* e, StTuning* out);
 int st_engine_set_tuning(StEngine* e, const StTuning* tuning);

@@ -103,7 +103,7 @@ pub struct StTuning {
     pub device_bake: u32,
     pub wide_bvh: u32,
     pub wide_stack_entries: u32,
-    pub _reserved: [u32; 1],
+    pub primary_packets: u32,
 }
 
 /// [x0, x1) x [y0, y1) in pixels (st_dist_partition / st_dist_window)

@@ -80,7 +80,7 @@ class StTuning(C.Structure):
                                           "lean_frame", "skip_scratch_stores", "di_head_on_main", "alias_gi_history", "tile_map", "tile_map_denoise")] + \
                [("side_priority", C.c_int32)] + \
                [(n, C.c_uint32) for n in ("staging", "double_buffer", "packed_base", "tick_timing", "anyhit_fast", "compact_bvh",
-                                          "allow_deep_bvh", "device_bake", "wide_bvh", "wide_stack_entries")] + [("_reserved", C.c_uint32 * 1)]
+                                          "allow_deep_bvh", "device_bake", "wide_bvh", "wide_stack_entries", "primary_packets")]
 
 
 class StKernelProfile(C.Structure):

@@ -163,7 +163,15 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const Ray ray = camera_ray(a.cam, pos);
-    const TriangleHit hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
+    TriangleHit hit;
+#if ST_FAST_DEVICE
+    if (!LDS_SCENE && a.bvh_w != nullptr && a.primary_packets) {   // the tile's 64 primary rays as one packet over the wide stream
+        Candidate c;
+        const bool any = closest_hit_packet(a, ray, &c);
+        hit = closest_resolve(a, ray, c, any);
+    } else
+#endif
+    hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
     count_rays(a, used_);
     if (!hit_is_some(hit)) {  // LoadOp::Clear(TRANSPARENT)
         tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z());

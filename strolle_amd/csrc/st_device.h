@@ -392,6 +392,7 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, C
 // Ray::trace (closest hit) with attributes resolved once, for the winning triangle.
 template <class SE> ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candidate* best);
 template <class SE> ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate* best);
+ST_D TriangleHit closest_resolve(const KArgs& a, const Ray& ray, const Candidate& c, bool any);
 template <class SE>
 ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
     Candidate c; bool any;
@@ -403,6 +404,10 @@ ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32
     else
 #endif
     *used_memory = traverse<false>(a, ray, kF32Max, stack, &c, &any);
+    return closest_resolve(a, ray, c, any);
+}
+// the winning triangle's attributes (normal, uv, instance slot), fetched once
+ST_D TriangleHit closest_resolve(const KArgs& a, const Ray& ray, const Candidate& c, bool any) {
     TriangleHit h;
     h.distance = c.t; h.material_id = c.material; h.point = v3s(0.0f); h.normal = v3s(0.0f); h.uv = v2(0.0f, 0.0f); h.xform_slot = 0u;
     if (any) {
@@ -781,6 +786,93 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
             if (head & 1u) { cur += 2u; continue; }
         }
         if (top > stack) { top -= 64; cur = (uint32_t)*top; } else break;
+    }
+    return found_any;
+}
+
+// ---- A WAVE-WIDE PACKET over the wide stream, for coherent rays (round 5: primary visibility; StTuning::primary_packets). The 64 primary rays of
+// an 8 x 8 tile walk nearly the same nodes (host model, dungeon: 13.9 node steps per ray, 15.0 for the tile's longest ray, 15.7 in the UNION of the
+// tile's paths), yet in the per-lane loop every lane fetches its own node, sorts its own keys and keeps its own stack: ~89 VALU instructions and
+// four vector loads per node step. Here the WAVE walks the union: `cur` and the stack are uniform, a node is fetched ONCE with scalar loads
+// (64 B through the scalar cache: no vector memory instruction in the loop), every lane tests the node's four boxes against its own ray — the
+// box words arrive as scalar operands —, v_cmp's result IS the ballot, a child is entered when any lane hits it, children are ordered by the
+// distances of the first lane that hits each, and the stack is ONE VGPR indexed by lane (v_writelane / v_readlane with a uniform stack pointer:
+// 64 entries). A lane that missed a node misses its children too (their boxes lie inside it), so no per-entry lane mask is kept. Leaf records
+// are scalar loads as well; the triangle test is each lane's own. Lanes that have left the kernel are simply inactive: ballots skip them.
+// Results: each lane's closest hit — the same triangle as the per-lane walk finds, except where two triangles tie.
+typedef const __attribute__((address_space(4))) uint32_t* ScalarWords;
+ST_D uint32_t wave_uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+// lane `lane` of `reg` = `value` (both uniform); v_writelane_b32 ignores EXEC. (This clang has the readlane builtin but no writelane one.)
+ST_D uint32_t wave_writelane(uint32_t reg, uint32_t value, uint32_t lane) {
+    // (two different SGPR operands would break the one-SGPR constant-bus rule of gfx9 VALU instructions: the lane select goes through M0)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(wave_uniform(value)), "s"(wave_uniform(lane)) : "m0");
+    return reg;
+}
+// (A software-pipelined form — the nearest child's line fetched before the others are pushed, a leaf step's successor before its triangle is
+// tested, keys sorted by a branch-free min / max network with the slot in their low bits — measured SLOWER on the same box: prim_visibility
+// 119 -> 132 us on the dungeon, 150 -> 173 at 208 k triangles, 440 -> 485 at 3840 x 2160: sixteen more live SGPRs for the second line spill, and
+// scalar loads return out of order, so every wait for an OLD line also waits for the prefetched one. The simple loop below is the one kept.)
+ST_D bool closest_hit_packet(const KArgs& a, const Ray& ray, Candidate* best) {
+    best->t = kF32Max; best->tri = 0xffffffffu; best->material = 0u; best->u = 0.0f; best->v = 0.0f; best->inv_det = 1.0f;
+    if (a.bvh_len == 0u) return false;
+    const RaySlabs rs = ray_slabs(ray);
+    const ScalarWords base = (ScalarWords)(a.bvh_w);
+    const uint32_t leaf_words = a.bvh_w_leaf_off >> 2;
+    uint32_t cur = a.bvh_w_root;          // uniform
+    uint32_t stack = 0u;                  // lane k of this VGPR = stack entry k
+    uint32_t sp = 0u;                     // uniform
+    bool found_any = false;
+    for (;;) {
+        if (!(cur & 1u)) {
+            const ScalarWords n = base + (size_t)cur * 8u;   // node index = cur >> 1, 16 words each
+            const uint32_t w0 = n[0], w1 = n[1], w2 = n[2], w3 = n[3], w4 = n[4], w5 = n[5], w6 = n[6], w7 = n[7], w8 = n[8], w9 = n[9], w10 = n[10], w11 = n[11];
+            const uint32_t x0 = n[12], x1 = n[13], x2 = n[14], x3 = n[15];
+            uint32_t l0, l1, l2, l3;
+            if (a.bvh_w_links16) { l0 = x0 & 0xffffu; l1 = x0 >> 16; l2 = x1 & 0xffffu; l3 = x1 >> 16; } else { l0 = x0; l1 = x1; l2 = x2; l3 = x3; }
+            const float lim = best->t;
+            const float t0 = compact_slab(w0, w1, w2, rs), t1 = compact_slab(w3, w4, w5, rs), t2 = compact_slab(w6, w7, w8, rs), t3 = compact_slab(w9, w10, w11, rs);
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(t0 < lim), m1 = __builtin_amdgcn_ballot_w64(t1 < lim), m2 = __builtin_amdgcn_ballot_w64(t2 < lim),
+                                     m3 = __builtin_amdgcn_ballot_w64(t3 < lim);
+            // keys: the entry distance of the first lane that hits the child (bits of a non-negative float order as integers), ~0 when no lane does
+            uint32_t k0 = m0 ? (uint32_t)__builtin_amdgcn_readlane((int)f2b(t0), (int)__builtin_ctzll(m0)) : 0xffffffffu;
+            uint32_t k1 = m1 ? (uint32_t)__builtin_amdgcn_readlane((int)f2b(t1), (int)__builtin_ctzll(m1)) : 0xffffffffu;
+            uint32_t k2 = m2 ? (uint32_t)__builtin_amdgcn_readlane((int)f2b(t2), (int)__builtin_ctzll(m2)) : 0xffffffffu;
+            uint32_t k3 = m3 ? (uint32_t)__builtin_amdgcn_readlane((int)f2b(t3), (int)__builtin_ctzll(m3)) : 0xffffffffu;
+            // a 5-comparator network on (key, link) pairs: uniform values, scalar unit
+#define ST_PKT_CSWAP(ka, la, kb, lb) do { if (kb < ka) { const uint32_t tk_ = ka; ka = kb; kb = tk_; const uint32_t tl_ = la; la = lb; lb = tl_; } } while (0)
+            ST_PKT_CSWAP(k0, l0, k1, l1); ST_PKT_CSWAP(k2, l2, k3, l3); ST_PKT_CSWAP(k0, l0, k2, l2); ST_PKT_CSWAP(k1, l1, k3, l3); ST_PKT_CSWAP(k1, l1, k2, l2);
+#undef ST_PKT_CSWAP
+            if (k3 != 0xffffffffu && sp < 64u) { stack = wave_writelane(stack, l3, sp); sp++; }
+            if (k2 != 0xffffffffu && sp < 64u) { stack = wave_writelane(stack, l2, sp); sp++; }
+            if (k1 != 0xffffffffu && sp < 64u) { stack = wave_writelane(stack, l1, sp); sp++; }
+            if (k0 != 0xffffffffu) { cur = l0; continue; }
+        } else {
+            const ScalarWords r = base + leaf_words + (size_t)(cur >> 1) * 12u;
+            const V3 p0 = v3(b2f(r[0]), b2f(r[1]), b2f(r[2])), e1 = v3(b2f(r[4]), b2f(r[5]), b2f(r[6])), e2 = v3(b2f(r[8]), b2f(r[9]), b2f(r[10]));
+            const uint32_t head = r[3], material = r[7];
+            const V3 pvec = cross(ray.dir, e2);
+            const float det = dot(e1, pvec);
+            if (!(fabsf(det) < kF32Eps)) {
+                const float inv_det = __builtin_amdgcn_rcpf(det);
+                const V3 tvec = ray.origin - p0;
+                const float u = dot(tvec, pvec) * inv_det;
+                const V3 qvec = cross(tvec, e1);
+                const float v = dot(ray.dir, qvec) * inv_det;
+                const float t = dot(e2, qvec) * inv_det;
+                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t))) {
+                    bool found = true;
+                    if (head & 2u) {
+                        const GpuMaterial m = a.materials[material];
+                        const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
+                        if (bc.w < 1.0f) found = false;
+                    }
+                    if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = head >> 2; best->material = material; found_any = true; }
+                }
+            }
+            if (head & 1u) { cur += 2u; continue; }
+        }
+        if (sp == 0u) break;
+        sp--; cur = (uint32_t)__builtin_amdgcn_readlane((int)stack, (int)sp);
     }
     return found_any;
 }

@@ -15,7 +15,7 @@ StTuning default_tuning() {
     t.skip_scratch_stores = t.di_head_on_main = t.alias_gi_history = 1u;
     t.tile_map = 1u; t.tile_map_denoise = 2u; t.side_priority = 0;
     t.staging = t.double_buffer = t.packed_base = 1u; t.tick_timing = 0u;
-    t.anyhit_fast = 1u; t.compact_bvh = 1u; t.wide_bvh = 1u;
+    t.anyhit_fast = 1u; t.compact_bvh = 1u; t.wide_bvh = 1u; t.primary_packets = 1u;
     t.allow_deep_bvh = 0u; t.device_bake = 1u;
     return t;
 }
@@ -29,7 +29,7 @@ static void tuning_from_environment(StTuning& t) {
         {"ST_NO_VARIANCE_IN_REPROJECT", &StTuning::variance_in_reproject},
         {"ST_KEEP_ALL_PLANES", &StTuning::lean_frame}, {"ST_KEEP_SCRATCH", &StTuning::skip_scratch_stores}, {"ST_NO_GI_ALIAS", &StTuning::alias_gi_history},
         {"ST_NO_STAGING", &StTuning::staging}, {"ST_NO_DOUBLE_BUFFER", &StTuning::double_buffer}, {"ST_NO_PACKED_BASE", &StTuning::packed_base},
-        {"ST_NO_ANYHIT_FAST", &StTuning::anyhit_fast}, {"ST_NO_COMPACT_BVH", &StTuning::compact_bvh}, {"ST_NO_WIDE_BVH", &StTuning::wide_bvh},
+        {"ST_NO_ANYHIT_FAST", &StTuning::anyhit_fast}, {"ST_NO_COMPACT_BVH", &StTuning::compact_bvh}, {"ST_NO_WIDE_BVH", &StTuning::wide_bvh}, {"ST_NO_PRIMARY_PACKETS", &StTuning::primary_packets},
     };
     for (const Clear& c : clears) if (const char* v = getenv(c.name)) { if (atoi(v) != 0) t.*c.field = 0u; else if (t.*c.field == 0u) t.*c.field = 1u; }
     struct Value { const char* name; uint32_t StTuning::*field; };

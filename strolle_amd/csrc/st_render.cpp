@@ -132,6 +132,7 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.bvh_w = wide ? static_cast<const float4*>(scene.bvh_wide.ptr) : nullptr;
     a.bvh_w_leaf_off = wide ? scene.wide_nodes * 64u : 0u;
     a.bvh_w_root = wide ? scene.wide_root : 0u; a.bvh_w_links16 = wide ? scene.wide_links16 : 0u;
+    a.primary_packets = wide && tuning.primary_packets ? 1u : 0u;
     a.anyhit_contract = (count_bytes || !tuning.anyhit_fast) ? 1u : 0u;   // the reference's used_memory is the contract loop's
     // Walks over the CONTRACT stream (exact build, heatmap pass, byte-counting mode, the compact binary stream: the contract's tree) hold what
     // that tree's deepest chain can need — proven drop-free up to kBvhStackSizeDeep. The WIDE stream is another tree: its worst case (every
