@@ -653,30 +653,35 @@ ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candida
 // and children whose distances agree to 7 mantissa bits are visited in link order (order only, never the result).
 //   node (64 B, texel 4 n of bvh_w):  texel 0: c0.x c0.y c0.z c1.x   texel 1: c1.y c1.z c2.x c2.y   texel 2: c2.z c3.x c3.y c3.z   (word = lower | upper << 16, f16)
 //                                     texel 3: links — 16-bit form (fewer than 32768 nodes and leaf records): l0 | l1 << 16, l2 | l3 << 16, 0, 0
-//                                                      32-bit form: l0, l1, l2, l3.   link = index << 1 | is a leaf record; an empty slot has an inverted box
+//                                                      32-bit form: l0, l1, l2, l3 (the key then keeps the link in its low 17 ... 24 bits — as many as the tree's
+//                                                      largest link needs — and the distance's leading bits above them: one v_and_or_b32 per child).
+//                                                      link = index << 1 | is a leaf record; an empty slot has an inverted box
 //   leaf record (48 B, bvh_w_leaf_off + 48 k bytes into the same allocation): the compact stream's leaf entry; a run's records are consecutive
 // One child's key: its slab test (compact_slab's arithmetic) fused with the cut-off — a miss or a child beyond `lim` is 0xffffffff, which sorts last.
 template <class SE> struct WideKeys;
 template <> struct WideKeys<uint16_t> {   // links ride in the keys
-    static ST_D uint32_t key(float tmin, bool hit, float4 t3, int slot) {
+    static ST_D uint32_t key(float tmin, bool hit, float4 t3, int slot, uint32_t) {
         const uint32_t links = slot < 2 ? f2b(t3.x) : f2b(t3.y);
         return hit ? __builtin_amdgcn_perm(f2b(tmin), links, (slot & 1) ? 0x07060302u : 0x07060100u) : 0xffffffffu;
     }
-    static ST_D uint32_t link(uint32_t k, float4) { return k & 0xffffu; }
+    static ST_D uint32_t link(uint32_t k, uint32_t) { return k & 0xffffu; }
 };
-template <> struct WideKeys<uint32_t> {   // the slot rides in the keys, links are picked afterwards
-    static ST_D uint32_t key(float tmin, bool hit, float4, int slot) { return hit ? ((f2b(tmin) & ~3u) | (uint32_t)slot) : 0xffffffffu; }
-    static ST_D uint32_t link(uint32_t k, float4 t3) { return f2b((k & 2u) ? ((k & 1u) ? t3.w : t3.z) : ((k & 1u) ? t3.y : t3.x)); }
+template <> struct WideKeys<uint32_t> {   // the link rides in the key's low KArgs::bvh_w_link_bits bits (17 ... 24), the distance keeps what is left above them
+    static ST_D uint32_t key(float tmin, bool hit, float4 t3, int slot, uint32_t mask) {
+        const uint32_t link = f2b(slot == 0 ? t3.x : (slot == 1 ? t3.y : (slot == 2 ? t3.z : t3.w)));
+        return hit ? ((f2b(tmin) & ~mask) | link) : 0xffffffffu;   // v_and_or_b32
+    }
+    static ST_D uint32_t link(uint32_t k, uint32_t mask) { return k & mask; }
 };
 template <class SE>
-ST_D uint32_t wide_key(uint32_t wx, uint32_t wy, uint32_t wz, const RaySlabs& r, float lim, float4 t3, int slot) {
+ST_D uint32_t wide_key(uint32_t wx, uint32_t wy, uint32_t wz, const RaySlabs& r, float lim, float4 t3, int slot, uint32_t mask) {
     wx = __builtin_amdgcn_alignbit(wx, wx, r.rx); wy = __builtin_amdgcn_alignbit(wy, wy, r.ry); wz = __builtin_amdgcn_alignbit(wz, wz, r.rz);
     const float nx = fmaf(half_lo(wx), r.inv.x, r.oi.x), fx = fmaf(half_hi(wx), r.inv.x, r.oi.x);
     const float ny = fmaf(half_lo(wy), r.inv.y, r.oi.y), fy = fmaf(half_hi(wy), r.inv.y, r.oi.y);
     const float nz = fmaf(half_lo(wz), r.inv.z, r.oi.z), fz = fmaf(half_hi(wz), r.inv.z, r.oi.z);
     const float tmin = fmax_(fmax_(fmax_(nx, ny), nz), 0.0f);
     const float tmax = fmin_(fmin_(fx, fy), fz);
-    return WideKeys<SE>::key(tmin, (tmin <= tmax) & (tmin < lim), t3, slot);
+    return WideKeys<SE>::key(tmin, (tmin <= tmax) & (tmin < lim), t3, slot, mask);
 }
 // four keys in ascending order: sort three with v_min3 / v_med3 / v_max3, insert the fourth with two more v_med3 — 7 instructions
 // (the compiler finds v_med3_u32 in min / max trees only sometimes and v_min3_u32 never: stated here)
@@ -709,15 +714,15 @@ ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
         if (!leaf) t3 = e[3];
         asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x), "v"(t3.x));   // one round trip for the line
         if (!leaf) {
-            uint32_t k0 = wide_key<SE>(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs, limit, t3, 0);
-            uint32_t k1 = wide_key<SE>(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs, limit, t3, 1);
-            uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, limit, t3, 2);
-            uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, limit, t3, 3);
+            uint32_t k0 = wide_key<SE>(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs, limit, t3, 0, a.bvh_w_link_mask);
+            uint32_t k1 = wide_key<SE>(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs, limit, t3, 1, a.bvh_w_link_mask);
+            uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, limit, t3, 2, a.bvh_w_link_mask);
+            uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, limit, t3, 3, a.bvh_w_link_mask);
             ST_WIDE_SORT4(k0, k1, k2, k3);
-            if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, t3); top += 64; } }
-            if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, t3); top += 64; } }
-            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, t3); top += 64; } }
-            if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, t3); continue; }
+            if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, a.bvh_w_link_mask); top += 64; } }
+            if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, a.bvh_w_link_mask); top += 64; } }
+            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, a.bvh_w_link_mask); top += 64; } }
+            if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, a.bvh_w_link_mask); continue; }
         } else {
             const uint32_t head = f2b(t0.w);
             float u, v;
@@ -752,15 +757,15 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
         asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x), "v"(t3.x));
         if (!leaf) {
             const float lim = best->t;
-            uint32_t k0 = wide_key<SE>(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs, lim, t3, 0);
-            uint32_t k1 = wide_key<SE>(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs, lim, t3, 1);
-            uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, lim, t3, 2);
-            uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, lim, t3, 3);
+            uint32_t k0 = wide_key<SE>(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs, lim, t3, 0, a.bvh_w_link_mask);
+            uint32_t k1 = wide_key<SE>(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs, lim, t3, 1, a.bvh_w_link_mask);
+            uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, lim, t3, 2, a.bvh_w_link_mask);
+            uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, lim, t3, 3, a.bvh_w_link_mask);
             ST_WIDE_SORT4(k0, k1, k2, k3);
-            if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, t3); top += 64; } }
-            if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, t3); top += 64; } }
-            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, t3); top += 64; } }
-            if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, t3); continue; }
+            if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, a.bvh_w_link_mask); top += 64; } }
+            if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, a.bvh_w_link_mask); top += 64; } }
+            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, a.bvh_w_link_mask); top += 64; } }
+            if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, a.bvh_w_link_mask); continue; }
         } else {
             const uint32_t head = f2b(t0.w);
             const V3 p0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);

@@ -133,6 +133,12 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.bvh_w_leaf_off = wide ? scene.wide_nodes * 64u : 0u;
     a.bvh_w_root = wide ? scene.wide_root : 0u; a.bvh_w_links16 = wide ? scene.wide_links16 : 0u;
     a.primary_packets = wide && tuning.primary_packets ? 1u : 0u;
+    {   // the largest link of this stream: (max(nodes, leaf records) - 1) << 1 | 1
+        uint32_t bits = 16u;
+        const uint32_t top = std::max(scene.wide_nodes, scene.wide_leaves);
+        while (bits < 31u && (1ull << bits) <= (unsigned long long)top * 2ull + 1ull) bits++;
+        a.bvh_w_link_mask = (1u << bits) - 1u;
+    }
     a.anyhit_contract = (count_bytes || !tuning.anyhit_fast) ? 1u : 0u;   // the reference's used_memory is the contract loop's
     // Walks over the CONTRACT stream (exact build, heatmap pass, byte-counting mode, the compact binary stream: the contract's tree) hold what
     // that tree's deepest chain can need — proven drop-free up to kBvhStackSizeDeep. The WIDE stream is another tree: its worst case (every

@@ -90,6 +90,7 @@ struct KArgs {
     uint32_t bvh_w_leaf_off;   // ... byte offset of its leaf records (48 B each) in the same allocation
     uint32_t bvh_w_root;       // ... the root's link (index << 1 | is a leaf record)
     uint32_t primary_packets;  // ... 1: primary visibility walks it as ONE packet per wave (st_device.h closest_hit_packet; StTuning::primary_packets)
+    uint32_t bvh_w_link_mask;  // ... 32-bit form: (1 << bits) - 1, bits = what the largest link needs (the sort key keeps the link there)
     uint32_t bvh_w_links16;    // ... 1: links are 16-bit (fewer than 32768 nodes and leaf records): kernels run with 16-bit stack slots
     uint32_t exp_flags;        // A/B switches of experiments in flight (ST_EXP in the environment; 0 in the shipped configuration)
     uint32_t anyhit_contract;  // fast build: shadow rays walk the contract loop (set while the reference's used_memory bytes are counted, or by StTuning::anyhit_fast = 0)
