@@ -162,7 +162,6 @@ __global__ ST_KERNEL_BOUNDS void k_denoise_variance(const KArgs a, float4* di_ou
     di_out[center] = f4(xyz(cdi), di_var);
     gi_out[center] = f4(xyz(cgi), gi_var);
 }
-void launch_denoise_variance(const KArgs& a, float4* di_out, float4* gi_out, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a, di_out, gi_out); }
 
 // ---------------------------------------------------------------- frame_denoising.rs:219-361 (five à-trous passes)
 // Measured (rocprofv3, MI355X): the LDS-staged passes run at 70-75 % of their VALU issue time and within 10-30 % of the
@@ -288,6 +287,9 @@ inline uint32_t wavelet_blocks(const KArgs& a, uint32_t block_w = kWvW) {
 }
 // the pixel belongs to this launch's window (the LDS passes address pixels as signed block offsets)
 ST_D bool wavelet_owns(const KArgs& a, int32_t px, int32_t py) { return px >= 0 && py >= 0 && owns_pixel(a, u2((uint32_t)px, (uint32_t)py)); }
+
+void launch_denoise_variance(const KArgs& a, float4* di_out, float4* gi_out, hipStream_t s) { ST_LAUNCH(k_denoise_variance, false, s, a, di_out, gi_out); }
+
 // stages the (kWvW + 2 HALO) x (kWvH + 2 HALO) window around the block into LDS (row pitch P texels)
 template <int HALO, int P, int BW = kWvW>
 ST_D void wavelet_stage(const KArgs& a, const WaveletBlock& blk, const float4* di_in, const float4* gi_in, float4* s_sn, float4* s_di, float4* s_gi) {
