@@ -387,7 +387,11 @@ class Job:
             dist.all_gather(each, torch.tensor([mine], dtype=torch.float64, device=on))
             ms = [float(x[0]) for x in each]
             log.append({"per_rank_ms": [round(v, 4) for v in ms], "max_over_mean": round(max(ms) / (sum(ms) / len(ms)), 4), "grid": grid.describe()})
-            grid = dist_grid_rebalance(self.width, self.height, grid, ms, max_step=max(self.apron, 16))
+            try:
+                grid = dist_grid_rebalance(self.width, self.height, grid, ms, max_step=max(self.apron, 16))
+            except Exception as exc:   # a frame too small to move its edges (every rank gets the same answer: the inputs are the same)
+                log[-1]["stopped"] = str(exc)
+                break
             self.set_grid(grid)
         return log
 
