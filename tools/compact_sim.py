@@ -9,7 +9,8 @@ walked over the wide tree with the product's rules; each ray's sequence of node 
              they fit fewer waves than hold them, repacks them densely into the first waves through LDS; emptied waves sleep at the barrier. A repack
              costs every live ray its state through LDS (C_SWAP VALU-equivalents per wave that takes part) and the barrier pair
 
-and prints issue work per workgroup (VALU-equivalents summed over the waves that are awake), the lane utilisation of both, and the ratio.
+Also printed: for the PRIMARY rays of each 8 x 8 tile, node steps per ray, of the tile's longest ray, and in the union of the tile's paths — what a
+wave-wide packet visits. Then issue work per workgroup (VALU-equivalents summed over the waves that are awake), the lane utilisation of both, and the ratio.
 
   python tools/compact_sim.py [--scene dungeon] [--size 128 64] [--k 8]
 """
@@ -38,10 +39,11 @@ topo = e.read_scene(14).view(np.uint32)[1:].reshape(-1, 8); leaf_entry = e.read_
 e.close()
 F = 3.4e38
 
-def walk(o, d, limit=F, any_hit=False):
+def walk(o, d, limit=F, any_hit=False, ids=None):
     inv = 1.0 / d
     kinds = []; stack = []; best = limit; found = None; cur = 0
     while True:
+        if ids is not None: ids.append(cur)
         if not cur & 1:
             kinds.append(0); hits = []
             for s, l in zip(topo[cur >> 1, :4], topo[cur >> 1, 4:]):
@@ -72,15 +74,19 @@ right = np.cross(fwd, [0, 1, 0]); right /= np.linalg.norm(right); up = np.cross(
 rng = np.random.default_rng(args.seed)
 def fix(v): v = v.copy(); v[np.abs(v) < 1e-9] = 1e-9; return v
 groups = {"GI bounce (closest)": [], "shadow from the bounce hit (any)": []}
+union = {"node_mean": 0.0, "node_max": 0, "node_union": 0, "leaf_max": 0, "leaf_union": 0, "tiles": 0}   # primary rays per 8 x 8 tile: what a wave-wide packet would visit
 for ty in range(0, H, 8):
     for tx in range(0, W, 32):
         rays = {k: [] for k in groups}
         for w in range(4):
+            tile_ids, per_node, per_leaf = set(), [], []
             for y in range(ty, ty + 8):
                 for x in range(tx + 8 * w, tx + 8 * w + 8):
                     px = ((x + .5) / W * 2 - 1) * tan * (W / H); py = (1 - (y + .5) / H * 2) * tan
                     d = fix((fwd + px * right + py * up) / np.linalg.norm(fwd + px * right + py * up))
-                    t, _ = walk(eye, d)
+                    ids = []
+                    t, _ = walk(eye, d, ids=ids)
+                    tile_ids |= set(ids); per_node.append(sum(1 for i in ids if not i & 1)); per_leaf.append(sum(1 for i in ids if i & 1))
                     k1 = k2 = []
                     if t is not None:
                         p = eye + d * t; n = -d; r = rng.normal(size=3); r /= np.linalg.norm(r)
@@ -91,6 +97,8 @@ for ty in range(0, H, 8):
                             p2 = o2 + r * t2 - r * 1e-3; l = p + np.array((0.0, 0.4, 0.0)); dl = l - p2; dist = np.linalg.norm(dl)
                             if dist > 1e-4: _, k2 = walk(p2, fix(dl / dist), limit=dist, any_hit=True)
                     rays["GI bounce (closest)"].append(k1); rays["shadow from the bounce hit (any)"].append(k2)
+            union["node_mean"] += float(np.mean(per_node)); union["node_max"] += max(per_node); union["node_union"] += sum(1 for i in tile_ids if not i & 1)
+            union["leaf_max"] += max(per_leaf); union["leaf_union"] += sum(1 for i in tile_ids if i & 1); union["tiles"] += 1
         for k in groups: groups[k].append(rays[k])
 
 def replay(block, K):
@@ -120,6 +128,9 @@ def replay(block, K):
         it += 1
     return work, useful / 64.0
 
+n = union["tiles"]
+print(f"primary rays per 8 x 8 tile (what a wave-wide packet walks, st_device.h closest_hit_packet): node steps {union['node_mean'] / n:.1f} per ray, {union['node_max'] / n:.1f} for the tile's longest ray, "
+      f"{union['node_union'] / n:.1f} in the UNION of the tile's paths; leaf records {union['leaf_max'] / n:.1f} (longest ray) / {union['leaf_union'] / n:.1f} (union)")
 for name, blocks in groups.items():
     base = [replay(b, 0) for b in blocks]
     w0 = sum(x[0] for x in base); u0 = sum(x[1] for x in base)
