@@ -328,16 +328,28 @@ class Job:
     def timed_region(self, steps):
         """EXACTLY `steps` steps between barrier + synchronize on both sides."""
         torch = self.torch
-        if self.world > 1:
-            self.dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        f = self.run(steps)
-        torch.cuda.synchronize()
-        if self.world > 1:
-            self.dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, f
+        # The interpreter's cyclic garbage collector stays out of the timed region (as timeit does it): a full collection of this process (torch +
+        # numpy loaded) takes 35-47 ms, and one of them landing in a 16-ms region is what the driver's round-4 run reported as 2.548 ms per step for
+        # the moving-geometry region — found with rocprofv3 --hip-trace (tools/gpu_stall_trace.sh): a 42-ms idle gap of the device with NO HIP call
+        # in flight, between one frame's last kernel and the next tick's first copy.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            if self.world > 1:
+                self.dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            f = self.run(steps)
+            torch.cuda.synchronize()
+            if self.world > 1:
+                self.dist.barrier()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, f
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def counted_rays(self):
         """rays of this rank's OWN tile: apron pixels are redundant work and not counted"""
@@ -652,8 +664,8 @@ def main():
         job.geometry = (1 + mesh, placed)
         # The first ticks of this mode do one-off work (a rebuild that indexes the tree for the device refit, each device copy's first full
         # upload, the mesh store, the first launch of k_bvh_bake's code object: tools/stall_probe.py shows them in ticks 0-2), so the warm-up
-        # is never shorter than 8 ticks; and the region is timed TWICE back to back — a one-off stall of the box (the driver's round-4 run
-        # reported 2.548 ms here, 35 ms in one of 20 frames, that no re-run of the same command reproduced: 0.82) shows up as a gap between the two.
+        # is never shorter than 8 ticks; and the region is timed TWICE back to back, both figures in the line. (The driver's round-4 run
+        # reported 2.548 ms here: a 35-ms garbage collection of the interpreter inside the region — Job.timed_region keeps the collector out now.)
         job.run(max(args.warmup, 8))
         torch.cuda.synchronize(); engine.ray_count(cam, reset=True)
         el_g1, frame_g = job.timed_region(args.steps)
