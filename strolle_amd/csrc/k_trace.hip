@@ -56,7 +56,15 @@ __global__ ST_KERNEL_BOUNDS void k_ref_tracing(const KArgs a_in, uint32_t depth)
         if (is_zero(d1)) return;
         ray = make_ray(xyz(d0), xyz(d1));
     }
-    const TriangleHit hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
+    TriangleHit hit;
+#if ST_FAST_DEVICE
+    if (!LDS_SCENE && depth == 0u && a.bvh_w != nullptr && a.primary_packets) {   // camera rays: one packet per wave (depth is uniform: the branch is)
+        Candidate c;
+        const bool any = closest_hit_packet(a, ray, &c);
+        hit = closest_resolve(a, ray, c, any);
+    } else
+#endif
+    hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
     count_rays(a, used_);
     float4 h0, h1;
     hit_pack(hit, &h0, &h1);
