@@ -815,7 +815,7 @@ ST_D uint32_t wave_writelane(uint32_t reg, uint32_t value, uint32_t lane) {
 }
 // (The same walk over the LDS-resident CONTRACT stream of the Cornell box — uniform pointer, LDS broadcast reads, the exact island's box and
 // triangle tests per lane — was built too: prim_visibility 59.3 -> 58.0 us, inside the noise of the frame, and the whole-frame steady-state test
-// no longer passed (ties between a quad's two triangles resolve in packet order, not in the oracle's). Not kept: the Cornell box keeps its
+// no longer passed (ties between a quad's two triangles resolve in packet order, not in the per-lane walk's). Not kept: the Cornell box keeps its
 // per-lane contract walk.)
 // (A software-pipelined form — the nearest child's line fetched before the others are pushed, a leaf step's successor before its triangle is
 // tested, keys sorted by a branch-free min / max network with the slot in their low bits — measured SLOWER on the same box: prim_visibility
