@@ -119,8 +119,10 @@ __global__ __launch_bounds__(256) void k_bvh_bake(const BakeJobDevice* jobs, con
     tri_bounds[2u * slot] = f4(blo, 0.0f); tri_bounds[2u * slot + 1u] = f4(bhi, 0.0f);
     tri_attr[4u * slot] = f4(n[0], uv[0]); tri_attr[4u * slot + 1u] = f4(n[1], uv[1]); tri_attr[4u * slot + 2u] = f4(n[2], uv[2]);
     tri_attr[4u * slot + 3u] = make_float4(uv[3], uv[4], uv[5], b2f(j.xslot));
-    const uint32_t e = entry_of_tri[slot];
-    if (e != 0xffffffffu) { bvh[4u * e + 1u] = g0; bvh[4u * e + 2u] = g1; bvh[4u * e + 3u] = g2; }
+    if (entry_of_tri != nullptr) {   // (nullptr: ST_BVH_BUILD_DEVICE — there is no contract stream to patch, the tree is rebuilt from tri_geo / tri_bounds right after)
+        const uint32_t e = entry_of_tri[slot];
+        if (e != 0xffffffffu) { bvh[4u * e + 1u] = g0; bvh[4u * e + 2u] = g1; bvh[4u * e + 3u] = g2; }
+    }
 }
 void launch_bvh_bake(const void* jobs, const uint32_t* job_start, uint32_t n_jobs, uint32_t total, const float* mesh, float4* tri_geo, float4* tri_bounds, float4* tri_attr,
                      float4* bvh, const uint32_t* entry_of_tri, hipStream_t s) {

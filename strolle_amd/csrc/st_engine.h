@@ -426,7 +426,7 @@ struct Engine {
         uint64_t wide_topology_serial = 0;   // which build_wide_topology() result this copy holds
         // ST_BVH_BUILD_DEVICE (k_lbvh.hip): this copy's wide stream was built on the device from its own triangle arrays; `bvh` (the contract
         // stream) is then stale and no launch may read it. lb_live: live triangles of that build. The rest is the builder's scratch.
-        bool device_built = false; uint32_t lb_live = 0;
+        bool device_built = false; uint32_t lb_live = 0; uint64_t tri_info_serial = 0;
         DeviceArray tri_info, lb_keys_a, lb_keys_b, lb_temp, lb_seg, lb_children, lb_node_box, lb_front_a, lb_front_b, lb_small;
         // ST_BVH_REFIT_DEVICE: what k_bvh.hip needs beside the stream — per triangle slot the hit-test record, the bounds and the
         // device entry that holds it; per entry its parent (entry << 1 | child slot); the leaf runs; an arrival counter per entry.
@@ -524,7 +524,7 @@ struct Engine {
     // ST_BVH_BUILD_DEVICE: the tree of a changed scene is built on the device (k_lbvh.hip) while nothing observes the contract stream
     bool host_tree_stale = false;    // the host's binned-SAH tree (bvh_stream and everything derived from it) is behind the scene
     uint64_t device_builds = 0;
-    std::vector<uint32_t> tri_info_;
+    std::vector<uint32_t> tri_info_; uint32_t tri_info_live_ = 0; uint64_t tri_info_serial_ = 1, tri_info_built_for_ = 0;   // per slot: live | Blend << 1 | material << 2; the serial counts what can change it
     bool device_build_possible() const;
     int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);
     void rebuild_host_tree(bool timing);

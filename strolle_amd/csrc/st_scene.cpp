@@ -175,7 +175,9 @@ bool Engine::refresh_instances() {
     // Device bake: when every dirty instance only MOVED — same mesh (and version of it), same material, its slots already assigned —
     // under ST_BVH_REFIT_DEVICE with the tree's topology on record, the host bakes nothing: the device copies do (Engine::bake_on_device).
     const bool removed = instance_removed; instance_removed = false;
-    if (tuning.device_bake && device_refit_possible() && have_topology && !materials_changed_this_tick && !removed) {
+    // (ST_BVH_BUILD_DEVICE: the same, with the tree rebuilt on the device from the device-baked arrays instead of refitted)
+    const bool build_mode = device_build_possible() && scene_uploaded;
+    if (tuning.device_bake && ((device_refit_possible() && have_topology) || build_mode) && !materials_changed_this_tick && !removed) {
         bool only_moves = true; size_t moved = 0;
         for (const auto& inst : instances) {
             if (!inst.dirty) continue;
@@ -297,7 +299,7 @@ int Engine::bake_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
     // the EXACT build's kernel, whatever arithmetic the frames use: the baked arrays are the host's bits
     launchers_exact().launch_bvh_bake(t.bake_jobs.ptr, static_cast<const uint32_t*>(t.bake_starts.ptr), (uint32_t)jobs.size(), starts.back(), static_cast<const float*>(d_mesh_store.ptr),
                                       static_cast<float4*>(t.tri_geo.ptr), static_cast<float4*>(t.tri_bounds.ptr), static_cast<float4*>(t.tri_attr.ptr), static_cast<float4*>(t.bvh.ptr),
-                                      static_cast<const uint32_t*>(t.entry_of_tri.ptr), up);
+                                      t.device_built ? nullptr : static_cast<const uint32_t*>(t.entry_of_tri.ptr), up);
     device_bakes++; device_baked_triangles += starts.back();
     return ST_OK;
 }

@@ -37,14 +37,18 @@ bool Engine::device_build_possible() const {
 int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
     int rc;
     const size_t slots = prims.size();
-    tri_info_.resize(slots);
-    uint32_t live = 0;
-    for (size_t i = 0; i < slots; i++) {
-        const uint32_t mat = prims[i].material_id;
-        const uint32_t blend = mat < materials.size() && materials[mat].alpha_mode == 1u ? 2u : 0u;
-        tri_info_[i] = (prim_alive[i] ? 1u : 0u) | blend | (mat << 2);
-        live += prim_alive[i] ? 1u : 0u;
+    if (tri_info_built_for_ != tri_info_serial_ || tri_info_.size() != slots) {   // (a tick in which instances only moved changes none of this)
+        tri_info_.resize(slots);
+        tri_info_live_ = 0;
+        for (size_t i = 0; i < slots; i++) {
+            const uint32_t mat = prims[i].material_id;
+            const uint32_t blend = mat < materials.size() && materials[mat].alpha_mode == 1u ? 2u : 0u;
+            tri_info_[i] = (prim_alive[i] ? 1u : 0u) | blend | (mat << 2);
+            tri_info_live_ += prim_alive[i] ? 1u : 0u;
+        }
+        tri_info_built_for_ = tri_info_serial_;
     }
+    const uint32_t live = tri_info_live_;
     const bool whole = !t.valid || t.tri_full || t.tri_geo.capacity < tri_geo.size() * sizeof(float4) || t.tri_bounds.capacity < tri_bounds.size() * sizeof(float4);
     if (whole) {
         if ((rc = t.tri_geo.upload(tri_geo.data(), tri_geo.size() * sizeof(float4), up, staging, pageable))) return rc;
@@ -53,7 +57,19 @@ int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
         if ((rc = t.tri_geo.upload_range(tri_geo.data(), 3 * t.dirty_lo * sizeof(float4), 3 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, pageable))) return rc;
         if ((rc = t.tri_bounds.upload_range(tri_bounds.data(), 2 * t.dirty_lo * sizeof(float4), 2 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, pageable))) return rc;
     }
-    if ((rc = t.tri_info.upload(tri_info_.data(), slots * sizeof(uint32_t), up, staging, pageable))) return rc;
+    // attribute records of the same slots, BEFORE the device bake below (an instance the host baked a tick ago and the device moves now must end with the device's)
+    if (whole || t.tri_attr.capacity < tri_attr.size() * sizeof(float4)) {
+        if ((rc = t.tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), up, staging, pageable))) return rc;
+    } else if (t.dirty_lo < t.dirty_hi) {
+        if ((rc = t.tri_attr.upload_range(tri_attr.data(), 4 * t.dirty_lo * sizeof(float4), 4 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, pageable))) return rc;
+    }
+    if (t.tri_info_serial != tri_info_serial_ || t.tri_info.capacity < slots * sizeof(uint32_t)) {
+        if ((rc = t.tri_info.upload(tri_info_.data(), slots * sizeof(uint32_t), up, staging, pageable))) return rc;
+        t.tri_info_serial = tri_info_serial_;
+    }
+    // instances that only moved are baked HERE from the object-space meshes (StTuning::device_bake, k_bvh.hip k_bvh_bake): the host bakes nothing for them
+    t.device_built = true;   // (bake_on_device: no contract stream to patch on this copy)
+    if ((rc = bake_on_device(t, up, pageable))) return rc;
     const uint32_t pow2 = lbvh_pow2(live);
     const size_t temp = lbvh_sort_temp_bytes((uint32_t)slots);
     auto need = [&](DeviceArray& d, size_t bytes) -> int {   // scratch: grown with headroom, never shrunk
@@ -100,6 +116,7 @@ int Engine::tick(hipStream_t stream) {
     }
     // ST_BVH_BUILD_DEVICE: while nothing observes the contract stream the changed scene's tree is built on the device (below, per device copy)
     // and the host's tree falls behind; the first tick that finds an observer brings it up to date like any rebuild.
+    if ((instances_changed && !moved_on_device) || materials_changed_this_tick) tri_info_serial_++;   // slots, liveness, materials or Blend flags may have changed
     const bool build_on_device_now = device_build_possible();
     if (instances_changed && build_on_device_now) {
         host_tree_stale = true; device_builds++; scene_changed = true;
@@ -168,13 +185,15 @@ int Engine::tick(hipStream_t stream) {
             } else if (mixed_render_streams) ST_HIP(hipDeviceSynchronize());  // cameras render on several streams: no single event ends their reads
             SceneSet& t = sets[target];
             bool attr_sent = false;
+            bool attr_done = false;
             if (build_on_device_now) {
-                if (any_host_stale()) bake_stale_on_host();
+                // (instances the device moved stay stale on the host: this copy's pending list re-bakes them on the device even after a whole upload)
                 if ((rc = build_on_device(t, up, flag))) return rc;
+                attr_done = true;
             } else t.device_built = false;
             const bool device_path = !build_on_device_now && device_refit_possible() && t.valid && !t.tri_full && t.tree_version == tree_version && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4);
             // a copy that cannot be brought up to date in place is sent whole, from the host's arrays: instances the device moved must be in them
-            if (!device_path && any_host_stale()) bake_stale_on_host();
+            if (!device_path && !build_on_device_now && any_host_stale()) bake_stale_on_host();
             if (device_path) {
                 // This copy holds the current tree; only boxes and moved triangles are behind. Send the records and bounds of the
                 // triangle slots baked since it was written and let the device patch its leaf entries and refit its boxes.
@@ -219,7 +238,8 @@ int Engine::tick(hipStream_t stream) {
             }
             // attribute records: whole the first time or after they grew, otherwise only the slots baked since this copy was written
             const bool partial = t.valid && !t.tri_full && t.tri_attr.capacity >= tri_attr.size() * sizeof(float4);
-            if (!partial) {
+            if (attr_done) {
+            } else if (!partial) {
                 if ((rc = t.tri_attr.upload(tri_attr.data(), tri_attr.size() * sizeof(float4), up, staging, flag))) return rc;
             } else if (t.dirty_lo < t.dirty_hi && !attr_sent) {
                 if ((rc = t.tri_attr.upload_range(tri_attr.data(), 4 * t.dirty_lo * sizeof(float4), 4 * (t.dirty_hi - t.dirty_lo) * sizeof(float4), up, staging, flag))) return rc;

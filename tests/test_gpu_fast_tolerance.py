@@ -450,11 +450,18 @@ def test_a_tree_built_on_the_device_finds_the_same_hits(subdivide):
     for e, _, _ in cams:
         e.insert_instance(7777, Instance(7777, 2, place))       # spawn: in front of the camera
     compare("after a spawn")
+    # moves only: the device bakes the moved instance from its object-space mesh (StTuning::device_bake) and rebuilds; the host bakes nothing
+    for step in range(1, 4):
+        moved = place.copy(); moved[0, 3] += 0.1 * step; moved[1, 3] += 0.05 * step
+        for e, _, _ in cams:
+            e.insert_instance(7777, Instance(7777, 2, moved))
+        compare(f"after move {step}")
+    assert dev.device_bakes()[0] == 3, "the moved instance was not baked on the device"
     for e, _, _ in cams:
         e.remove_instance(7777)
     compare("after a despawn")
-    assert dev.device_builds() == 3 and dev.bvh_refits()[0] == 0
-    assert host.bvh_refits()[0] == 3
+    assert dev.device_builds() == 6 and dev.bvh_refits()[0] == 0
+    assert host.bvh_refits()[0] == 6
     # a heatmap camera needs the contract stream: refused until a tick has seen it, then the reference's tree is back bit for bit
     hm_desc = scenes.dungeon_camera(size, CameraMode.BVH_HEATMAP)
     hm_dev, hm_host = dev.create_camera(hm_desc), host.create_camera(hm_desc)
