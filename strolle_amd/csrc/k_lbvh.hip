@@ -10,13 +10,14 @@
 //   2. key = 30-bit Morton code of the centroid << 32 | triangle slot (unique)      k_lbvh_keys        dead slots: ~0, sorted to the end
 //   3. radix sort of the 64-bit keys                                                hipCUB DeviceRadixSort (a plain library sort)
 //   4. leaf records (48 B, sorted order = leaf index) + leaf boxes                  k_lbvh_leaves
-//   5. min / max segment tree over the sorted leaf boxes                            k_lbvh_seg_level   one launch per level, no fences
+//   5. min / max segment tree over the sorted leaf boxes                            k_lbvh_seg_levels  nine levels per launch, no fences
 //   6. the binary radix tree of Karras 2012 — one thread per internal node finds its range and split from the keys alone —, each
 //      node's box as a range query of the segment tree (no bottom-up pass: nothing is handed from workgroup to workgroup) k_lbvh_hierarchy
 //   7. collapse into 4-wide nodes, top-down: a wide node is headed by a binary node and takes its children's children, largest surface
 //      area first, until it has four (the rule st_bvh_refresh.cpp build_wide_topology applies to the host's tree); a wide node lives at
-//      its head's binary index, so nothing is allocated and the result does not depend on the schedule. One launch per frontier level
-//      (40: an empty frontier costs 4 us), a last launch walks whatever is deeper with a private stack per thread          k_lbvh_collapse
+//      its head's binary index, so nothing is allocated and the result does not depend on the schedule. One launch per WIDE frontier level;
+//      a run of narrow levels (the first five or six, and the long tail) is one workgroup's loop through LDS inside one launch; a last
+//      launch walks whatever is deeper with a private stack per thread                                                    k_lbvh_collapse
 //
 // Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
 // 11.6 for a GI bounce, the same number of triangle tests, deepest stack 13-14.
@@ -45,13 +46,17 @@ __device__ inline float box_area(const Box& b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ void k_lbvh_init(int* bounds, uint32_t* counters) {
+__global__ void k_lbvh_init(int* bounds, uint32_t* counters, uint32_t* frontier_a) {
     if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;             // ordered(+inf-ish): min
     else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;   // max
-    if (threadIdx.x == 0) { counters[0] = 1u; counters[1] = 0u; counters[2] = 0u; }   // frontier 0 = { the root }
+    if (threadIdx.x == 0) { counters[0] = 1u; counters[1] = 0u; counters[2] = 0u; frontier_a[0] = 0u; }   // the first collapse launch's frontier = { the root }
 }
-// 1. bounds of the live triangles' centroids
+// 1. bounds of the live triangles' centroids. One ordered-int atomic pair per axis and WORKGROUP, from at most kBoundsBlocks workgroups: with one
+// pair per wave of a launch that covered the slots once (3,252 waves at 208 k triangles = 19,500 atomics on one cache line) this kernel took
+// 34-225 us depending on the box — the largest single item of the build (profiles/r05_lbvh_kernel_stats.txt).
+constexpr uint32_t kBoundsBlocks = 256;
 __global__ __launch_bounds__(kT) void k_lbvh_bounds(const float4* tri_bounds, const uint32_t* tri_info, uint32_t slots, int* bounds) {
+    __shared__ float s_mn[3][kT / 64], s_mx[3][kT / 64];
     float mn[3] = {kF32Max, kF32Max, kF32Max}, mx[3] = {-kF32Max, -kF32Max, -kF32Max};
     for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < slots; i += gridDim.x * kT) {
         if (!(tri_info[i] & 1u)) continue;
@@ -59,10 +64,17 @@ __global__ __launch_bounds__(kT) void k_lbvh_bounds(const float4* tri_bounds, co
         const float c[3] = {(lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f};
         for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], c[k]); mx[k] = fmaxf(mx[k], c[k]); }
     }
-    for (int k = 0; k < 3; k++)   // one atomic pair per wave: min / max over its 64 lanes first
+    for (int k = 0; k < 3; k++)
         for (int off = 32; off >= 1; off >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], off)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off)); }
     if ((threadIdx.x & 63u) == 0u)
-        for (int k = 0; k < 3; k++) { atomicMin(&bounds[k], ordered(mn[k])); atomicMax(&bounds[3 + k], ordered(mx[k])); }
+        for (int k = 0; k < 3; k++) { s_mn[k][threadIdx.x >> 6] = mn[k]; s_mx[k][threadIdx.x >> 6] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        const int k = (int)threadIdx.x;
+        float lo = s_mn[k][0], hi = s_mx[k][0];
+        for (int w = 1; w < kT / 64; w++) { lo = fminf(lo, s_mn[k][w]); hi = fmaxf(hi, s_mx[k][w]); }
+        atomicMin(&bounds[k], ordered(lo)); atomicMax(&bounds[3 + k], ordered(hi));
+    }
 }
 // 2. sort keys
 __global__ __launch_bounds__(kT) void k_lbvh_keys(const float4* tri_bounds, const uint32_t* tri_info, uint32_t slots, const int* bounds, unsigned long long* keys) {
@@ -95,12 +107,23 @@ __global__ __launch_bounds__(kT) void k_lbvh_leaves(const unsigned long long* ke
     leaves[3u * p + 1u] = make_float4(g1.x, g1.y, g1.z, b2f(info >> 2));
     leaves[3u * p + 2u] = make_float4(g2.x, g2.y, g2.z, 0.0f);
 }
-// 5. one level of the segment tree: nodes [first, first + count)
-__global__ __launch_bounds__(kT) void k_lbvh_seg_level(float4* seg, uint32_t first, uint32_t count) {
-    const uint32_t i = blockIdx.x * kT + threadIdx.x;
-    if (i >= count) return;
-    const size_t k = first + i;
-    box_store(seg + 2u * k, box_union(box_load(seg + 4u * k), box_load(seg + 4u * k + 2u)));
+// 5. the segment tree, up to log2(kT) + 1 levels per launch: workgroup b computes its min(count0, kT) nodes of the level that has `count0` nodes from
+// their children in global memory and every ancestor those nodes have among themselves from LDS (208 k triangles: 18 levels, 2 launches)
+__global__ __launch_bounds__(kT) void k_lbvh_seg_levels(float4* seg, uint32_t count0) {
+    __shared__ Box s_box[2 * kT];   // the workgroup's subtree as a heap: its bottom level at [width, 2 * width)
+    const uint32_t t = threadIdx.x, width = count0 < (uint32_t)kT ? count0 : (uint32_t)kT, groups = count0 / width;
+    if (t < width) {
+        const size_t k = (size_t)count0 + blockIdx.x * width + t;
+        const Box b = box_union(box_load(seg + 4u * k), box_load(seg + 4u * k + 2u));
+        s_box[width + t] = b; box_store(seg + 2u * k, b);
+    }
+    for (uint32_t w = width >> 1; w >= 1u; w >>= 1) {
+        __syncthreads();
+        if (t < w) {
+            const Box b = box_union(s_box[2u * (w + t)], s_box[2u * (w + t) + 1u]);
+            s_box[w + t] = b; box_store(seg + 2u * ((size_t)groups * w + blockIdx.x * w + t), b);   // the level of groups * w nodes starts at node groups * w
+        }
+    }
 }
 __device__ inline Box seg_query(const float4* seg, uint32_t pow2, uint32_t first, uint32_t last) {
     Box b = box_empty();
@@ -139,57 +162,114 @@ __device__ inline Box lb_child_box(uint32_t link, const float4* seg, uint32_t po
 }
 __device__ inline void lb_emit(uint32_t b, const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
                                uint32_t* next, int* n_next) {
+    // (four slots addressed by compile-time indices only: with run-time indices — the first version shifted the slots to keep the children in
+    // the binary tree's order — the arrays lived in scratch memory, 112 B per lane, and every access was a round trip through the vector L1)
     uint32_t link[4]; Box box[4]; int n = 2;
     const uint2 c = children[b];
-    link[0] = c.x; link[1] = c.y;
-    box[0] = lb_child_box(c.x, seg, pow2, node_box); box[1] = lb_child_box(c.y, seg, pow2, node_box);
-    while (n < 4) {
-        int pick = -1; float best = -1.0f;
-        for (int i = 0; i < n; i++) if (!(link[i] & 1u)) { const float ar = box_area(box[i]); if (ar > best) { best = ar; pick = i; } }
+    link[0] = c.x; link[1] = c.y; link[2] = link[3] = 1u;
+    box[0] = lb_child_box(c.x, seg, pow2, node_box); box[1] = lb_child_box(c.y, seg, pow2, node_box); box[2] = box[3] = box_empty();
+#pragma unroll
+    for (int round = 0; round < 2; round++) {   // the internal child of the largest surface area gives way to its two children: one in its slot, one in the next free slot
+        int pick = -1; float best = -1.0f; uint32_t pick_link = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < n && !(link[i] & 1u)) { const float ar = box_area(box[i]); if (ar > best) { best = ar; pick = i; pick_link = link[i]; } }
         if (pick < 0) break;
-        const uint2 g = children[link[pick] >> 1];
-        for (int i = n; i > pick + 1; i--) { link[i] = link[i - 1]; box[i] = box[i - 1]; }
-        link[pick] = g.x; link[pick + 1] = g.y;
-        box[pick] = lb_child_box(g.x, seg, pow2, node_box); box[pick + 1] = lb_child_box(g.y, seg, pow2, node_box);
+        const uint2 g = children[pick_link >> 1];
+        const Box bx = lb_child_box(g.x, seg, pow2, node_box), by = lb_child_box(g.y, seg, pow2, node_box);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i == pick) { link[i] = g.x; box[i] = bx; }
+            if (i == n) { link[i] = g.y; box[i] = by; }
+        }
         n++;
     }
     auto dn = [](float x) { return (uint32_t)__half_as_ushort(__float2half_rd(x)); };
     auto up = [](float x) { return (uint32_t)__half_as_ushort(__float2half_ru(x)); };
     uint32_t w[12], l[4];
-    *n_next = 0;
+    int heads = 0;
+#pragma unroll
     for (int i = 0; i < 4; i++) {
         if (i >= n) { w[3 * i] = w[3 * i + 1] = w[3 * i + 2] = 0xfc007c00u; l[i] = 0u; continue; }
         w[3 * i] = dn(box[i].lx) | (up(box[i].hx) << 16); w[3 * i + 1] = dn(box[i].ly) | (up(box[i].hy) << 16); w[3 * i + 2] = dn(box[i].lz) | (up(box[i].hz) << 16);
         l[i] = link[i];
-        if (!(link[i] & 1u)) next[(*n_next)++] = link[i] >> 1;
+        if (!(link[i] & 1u)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (j == heads) next[j] = link[i] >> 1;
+            heads++;
+        }
     }
+    *n_next = heads;
     float4* out = nodes + 4u * (size_t)b;
     out[0] = make_float4(b2f(w[0]), b2f(w[1]), b2f(w[2]), b2f(w[3]));
     out[1] = make_float4(b2f(w[4]), b2f(w[5]), b2f(w[6]), b2f(w[7]));
     out[2] = make_float4(b2f(w[8]), b2f(w[9]), b2f(w[10]), b2f(w[11]));
     out[3] = links16 ? make_float4(b2f(l[0] | (l[1] << 16)), b2f(l[2] | (l[3] << 16)), 0.0f, 0.0f) : make_float4(b2f(l[0]), b2f(l[1]), b2f(l[2]), b2f(l[3]));
 }
-// one frontier level (counters rotate: in = level % 3, out = (level + 1) % 3, (level + 2) % 3 is cleared for the level after); with
-// `finish` every thread walks the whole subtree of each of its items instead of handing its children on
+// One collapse launch. Launch k reads the frontier front[k & 1] of counters[k % 3] heads, appends the next one to front[(k + 1) & 1] counting in
+// counters[(k + 1) % 3], and clears counters[(k + 2) % 3] for the launch after: nothing a launch reads is written by it, whatever order its
+// workgroups run in. A frontier of more than kSmallIn heads is one level for the whole grid. A smaller one is workgroup 0's alone, and it keeps
+// going — frontier after frontier through LDS, a barrier between them instead of a launch — until a frontier outgrows it, or none is left: the
+// tree's first five or six levels and its long tail of narrow ones (dozens at 208 k triangles) cost two launches, not one each.
+// With `finish` every thread walks the whole subtree of each of its heads instead of handing its children on.
+constexpr uint32_t kSmallIn = 1024u, kSmallCap = 4u * kSmallIn, kSmallRounds = 96u;
 __global__ __launch_bounds__(kT) void k_lbvh_collapse(const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
-                                                      const uint32_t* frontier_in, uint32_t* frontier_out, uint32_t* counters, uint32_t level, uint32_t finish) {
-    const uint32_t count = counters[level % 3u];
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[(level + 2u) % 3u] = 0u;
-    for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
-        uint32_t next[4]; int n_next;
-        const uint32_t head = level == 0u ? 0u : frontier_in[i];
-        if (!finish) {
-            lb_emit(head, children, node_box, seg, pow2, links16, nodes, next, &n_next);
-            if (n_next) { const uint32_t at = atomicAdd(&counters[(level + 1u) % 3u], (uint32_t)n_next); for (int k = 0; k < n_next; k++) frontier_out[at + k] = next[k]; }
-        } else {
+                                                      uint32_t* frontier_a, uint32_t* frontier_b, uint32_t* counters, uint32_t launch, uint32_t finish) {
+    __shared__ uint32_t s_front[2][kSmallCap];
+    __shared__ uint32_t s_n[2];
+    uint32_t count = counters[launch % 3u];
+    uint32_t* next_count = &counters[(launch + 1u) % 3u];
+    const uint32_t* frontier_in = (launch & 1u) ? frontier_b : frontier_a;
+    uint32_t* frontier_out = (launch & 1u) ? frontier_a : frontier_b;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[(launch + 2u) % 3u] = 0u;
+    uint32_t next[4]; int n_next;
+    if (finish) {
+        for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
             uint32_t stack[96]; int sp = 0;   // a path of the binary tree is at most 64 + 32 nodes long (64-bit keys, 32-bit tie-break inside them)
-            stack[sp++] = head;
+            stack[sp++] = frontier_in[i];
             while (sp > 0) {
                 lb_emit(stack[--sp], children, node_box, seg, pow2, links16, nodes, next, &n_next);
-                for (int k = 0; k < n_next && sp < 96; k++) stack[sp++] = next[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (k < n_next && sp < 96) stack[sp++] = next[k];
             }
         }
+        return;
     }
+    if (count > kSmallIn) {
+        for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
+            lb_emit(frontier_in[i], children, node_box, seg, pow2, links16, nodes, next, &n_next);
+            if (n_next) {
+                const uint32_t at = atomicAdd(next_count, (uint32_t)n_next);
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (k < n_next) frontier_out[at + k] = next[k];
+            }
+        }
+        return;
+    }
+    if (blockIdx.x != 0 || count == 0u) return;   // (an empty frontier: *next_count stays 0)
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < count; i += kT) s_front[0][i] = frontier_in[i];
+    if (t < 2u) s_n[t] = 0u;
+    __syncthreads();
+    uint32_t cur = 0u;
+    for (uint32_t round = 0; round < kSmallRounds; round++) {
+        for (uint32_t i = t; i < count; i += kT) {
+            lb_emit(s_front[cur][i], children, node_box, seg, pow2, links16, nodes, next, &n_next);
+            if (n_next) {
+                const uint32_t at = atomicAdd(&s_n[cur ^ 1u], (uint32_t)n_next);
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (k < n_next) s_front[cur ^ 1u][at + k] = next[k];
+            }
+        }
+        __syncthreads();
+        cur ^= 1u; count = s_n[cur];
+        __syncthreads();
+        if (t == 0u) s_n[cur ^ 1u] = 0u;
+        __syncthreads();
+        if (count == 0u || count > kSmallIn) break;
+    }
+    for (uint32_t i = t; i < count; i += kT) frontier_out[i] = s_front[cur][i];   // what is left (more than kSmallIn heads, or kSmallRounds used up) is the next launch's
+    if (t == 0u) *next_count = count;
 }
 }  // namespace
 
@@ -204,24 +284,29 @@ int lbvh_build(const LbvhArgs& a, hipStream_t s) {
     if (a.live < 2u) return -1;   // the caller keeps the host path for a scene of fewer than two triangles
     const uint32_t pow2 = lbvh_pow2(a.live);
     auto grid = [](uint32_t n) { return dim3((n + kT - 1) / kT); };
-    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, a.bounds, a.counters);
-    hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((a.slots + kT - 1) / kT, 2048u)), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds);
+    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, a.bounds, a.counters, a.frontier_a);
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((a.slots + kT - 1) / kT, kBoundsBlocks)), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds);
     hipLaunchKernelGGL(k_lbvh_keys, grid(a.slots), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds, a.keys_in);
     size_t temp = a.sort_temp_bytes;
     if (hipcub::DeviceRadixSort::SortKeys(a.sort_temp, temp, a.keys_in, a.keys_out, (int)a.slots, 0, 64, s) != hipSuccess) return -2;
     hipLaunchKernelGGL(k_lbvh_leaves, grid(pow2), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.tri_geo, a.tri_bounds, a.tri_info, a.seg, a.leaves);
-    for (uint32_t count = pow2 >> 1; count >= 1u; count >>= 1) hipLaunchKernelGGL(k_lbvh_seg_level, grid(count), dim3(kT), 0, s, a.seg, count, count);
-    hipLaunchKernelGGL(k_lbvh_hierarchy, grid(a.live - 1u), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.seg, a.children, a.node_box);
-    // frontier levels before the finishing launch. Measured at 208 k triangles: with 8 levels the finishing launch — single threads walking deep,
-    // narrow subtrees one dependent load after the other — took 8 ms of a 9-ms build; the tree's wide levels are few dozen, a launch over an
-    // empty frontier costs 4 us.
-    constexpr uint32_t kLevels = 40;
-    for (uint32_t level = 0; level <= kLevels; level++) {
-        const uint32_t* in = (level & 1u) ? a.frontier_b : a.frontier_a;   // level 0 reads no frontier: its one item is the root
-        uint32_t* out = (level & 1u) ? a.frontier_a : a.frontier_b;
-        hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min<uint32_t>((a.live + kT - 1) / kT, 1024u)), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes,
-                           in, out, a.counters, level, level == kLevels ? 1u : 0u);
+    for (uint32_t count = pow2 >> 1; count >= 1u;) {
+        const uint32_t width = std::min<uint32_t>(count, (uint32_t)kT), groups = count / width;   // after this launch: every level down to the one of `groups` nodes
+        hipLaunchKernelGGL(k_lbvh_seg_levels, dim3(groups), dim3(kT), 0, s, a.seg, count);
+        count = groups >> 1;
     }
+    hipLaunchKernelGGL(k_lbvh_hierarchy, grid(a.live - 1u), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.seg, a.children, a.node_box);
+    // Collapse launches before the finishing one: one per wide level of the tree (about log4 of the leaves), the two runs of narrow levels, and
+    // six to spare for an LBVH's imbalance — a launch over an empty frontier costs 5 us (208 k triangles: 11 of the 17 have work: the top run
+    // 70 us, nine wide levels of 10-14 us, the tail run 37 us). Whatever is still open after them — nothing, at the sizes measured — is the
+    // finishing launch's: single threads walking subtrees one dependent load after the other (with only 8 levels before it, that launch took
+    // 8 ms of a 9-ms build at 208 k triangles).
+    uint32_t wide_levels = 1;
+    while (wide_levels < 16u && (1ull << (2u * wide_levels)) < a.live) wide_levels++;
+    const uint32_t launches = wide_levels + 8u;
+    for (uint32_t launch = 0; launch <= launches; launch++)
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min<uint32_t>((a.live + kT - 1) / kT, 1024u)), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes,
+                           a.frontier_a, a.frontier_b, a.counters, launch, launch == launches ? 1u : 0u);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

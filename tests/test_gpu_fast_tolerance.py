@@ -27,7 +27,7 @@ import pytest
 
 from oracle_binding import OracleEngine
 from parity import assert_bits_equal, psnr
-from strolle_amd import Buffer, CameraMode, Engine, Instance, Mesh, PassBit, StrolleError, scenes
+from strolle_amd import Buffer, CameraMode, Engine, Instance, Light, Material, Mesh, PassBit, StrolleError, Sun, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -475,6 +475,46 @@ def test_a_tree_built_on_the_device_finds_the_same_hits(subdivide):
     assert_bits_equal(dev.read_scene(0), host.read_scene(0), "the host tree after device builds")
     for e, _, _ in cams:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_triangles", [1, 2, 3, 5, 33, 257, 1025, 4099])
+def test_small_trees_built_on_the_device(n_triangles):
+    """The device builder's small ends: a segment tree of fewer nodes than one workgroup's width (k_lbvh_seg_levels with count0 < 256, down to ONE
+    node), a collapse whose every frontier is workgroup 0's loop through LDS, triangle counts one past a power of two (the segment tree's padding
+    leaves), 4,099 triangles (the first frontier that outgrows the loop); one triangle: no tree to build, the host's path stays (k_lbvh.hip
+    lbvh_build -1). Primary hits against an engine that builds on the host."""
+    torch = _torch()
+    size = (160, 96)
+    rng = np.random.default_rng(100 + n_triangles)
+    c = rng.uniform(-0.8, 0.8, (n_triangles, 1, 3)).astype(np.float32)
+    pos = (c + rng.uniform(-0.4, 0.4, (n_triangles, 3, 3))).astype(np.float32)
+    nrm = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
+    mesh = Mesh(pos, np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32))
+    place = np.eye(4, dtype=np.float32)[:3].copy(); place[:, 3] = (0.0, 1.0, 0.0)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    hits = []
+    for mode in (0, 3):
+        e = Engine(device=0, exact=False)
+        e.set_bvh_refresh(mode)
+        e.set_blue_noise(scenes.load_blue_noise())
+        e.insert_material(1, Material(base_color=[0.8, 0.7, 0.6, 1.0]))
+        e.insert_mesh(1, mesh); e.insert_instance(1, Instance(1, 1, place))
+        e.insert_light(1, Light.point([0.0, 1.0, 3.0], 0.1, [1.0, 1.0, 1.0], 20.0))
+        e.update_sun(Sun(azimuth=0.0, altitude=-1.0))
+        desc = scenes.cornell_camera(size, CameraMode.REFERENCE, depth=0)   # REF_HITS: the primary hits
+        cam = e.create_camera(desc)
+        e.update_camera(cam, desc); e.tick(); e.render_camera(cam, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        hits.append(e.read_buffer(cam, Buffer.REF_HITS).reshape(size[1], size[0], -1).copy())
+        if mode == 3:
+            assert e.device_builds() == (1 if n_triangles >= 2 else 0)
+            assert e.bvh_refits()[0] == (0 if n_triangles >= 2 else 1), "one triangle: the host builds"
+        e.close()
+    seen = int((np.isfinite(hits[0][..., :3]).all(-1) & (np.abs(hits[0][..., :3]).sum(-1) > 0)).sum())
+    assert seen >= 20, f"the triangles are not in view ({seen} pixels)"
+    bad = lanes_outside_tolerance(hits[1], hits[0], rtol=1e-4, atol=1e-5).reshape(hits[0].shape).any(-1)
+    assert bad.mean() <= 2e-3, f"{n_triangles} triangles: {bad.mean():.2e} of the primary hits differ between the device-built and the host-built tree"
 
 
 @pytest.mark.gpu
