@@ -172,11 +172,15 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                                                range queries, collapsed into 4-wide nodes): spawning or removing an instance costs a few hundred
                                                microseconds of device time instead of the host rebuild (26-28 ms at 208 k triangles). It is ANOTHER tree
                                                than the reference's binned SAH — the hits are the same, traversal costs about a fifth more for
-                                               incoherent rays —, so it is used only while nothing observes the contract stream: fast arithmetic, no
+                                               incoherent rays —, so it is used only while nothing observes the contract stream (a tick in which
+                                               instances only MOVED refits that tree: st_debug_device_tree_refits): fast arithmetic, no
                                                BvhHeatmap camera, no byte counting. A tick that finds such an observer builds on the host as
                                                ST_BVH_REBUILD does; a heatmap camera created later renders after the next st_tick. */ };
 /* Ticks whose tree was built on the device so far (ST_BVH_BUILD_DEVICE). */
 int st_debug_device_builds(StEngine* e, uint64_t* ticks);
+/* Ticks of that mode in which instances only moved and the device-built tree was REFITTED instead (same shape, every box recomputed: 5 launches
+   against 42; at most 15 in a row, then the next change rebuilds; ST_NO_DEVICE_TREE_REFIT=1 in the environment rebuilds always). */
+int st_debug_device_tree_refits(StEngine* e, uint64_t* ticks);
 int st_set_bvh_refresh(StEngine* e, int mode);
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits);
 int st_debug_bvh_device_refits(StEngine* e, uint64_t* device_refits);

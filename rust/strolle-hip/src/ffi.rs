@@ -166,6 +166,7 @@ extern "C" {
     pub fn st_engine_set_arithmetic(e: *mut StEngine, arithmetic: i32) -> i32;
     pub fn st_set_bvh_refresh(e: *mut StEngine, mode: i32) -> i32; // 0 rebuild, 1 refit, 2 refit on the device, 3 build on the device (ST_BVH_BUILD_DEVICE)
     pub fn st_debug_device_builds(e: *mut StEngine, ticks: *mut u64) -> i32;
+    pub fn st_debug_device_tree_refits(e: *mut StEngine, ticks: *mut u64) -> i32;
     pub fn st_engine_get_tuning(e: *mut StEngine, out: *mut StTuning) -> i32;
     pub fn st_engine_set_tuning(e: *mut StEngine, tuning: *const StTuning) -> i32;
     // multi-GPU behind the boundary: one process per GPU, tiles + ONE gather to rank 0 over RCCL (dist.rs)

@@ -318,6 +318,7 @@ class _Binding:
             self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
             self.debug_device_bakes = fn("debug_device_bakes", [vp, P(u64), P(u64)])
             self.debug_device_builds = fn("debug_device_builds", [vp, P(u64)])
+            self.debug_device_tree_refits = fn("debug_device_tree_refits", [vp, P(u64)])
             self.engine_get_tuning = fn("engine_get_tuning", [vp, P(StTuning)]); self.engine_set_tuning = fn("engine_set_tuning", [vp, P(StTuning)])
             self.debug_copy_bandwidth = fn("debug_copy_bandwidth", [vp, sz, i32, P(C.c_double)])
             self.debug_variance_flags = fn("debug_variance_flags", [vp, u64, vp, sz, P(sz)])
@@ -520,6 +521,12 @@ class EngineBase:
         """ticks whose tree was built on the device so far (ST_BVH_BUILD_DEVICE)."""
         n = C.c_uint64()
         self._check(self._b.debug_device_builds(self._h, C.byref(n)))
+        return int(n.value)
+
+    def device_tree_refits(self) -> int:
+        """ticks of ST_BVH_BUILD_DEVICE in which instances only moved and the device-built tree was refitted instead of rebuilt."""
+        n = C.c_uint64()
+        self._check(self._b.debug_device_tree_refits(self._h, C.byref(n)))
         return int(n.value)
 
     def device_bakes(self):

@@ -271,6 +271,31 @@ __global__ __launch_bounds__(kT) void k_lbvh_collapse(const uint2* children, con
     for (uint32_t i = t; i < count; i += kT) frontier_out[i] = s_front[cur][i];   // what is left (more than kSmallIn heads, or kSmallRounds used up) is the next launch's
     if (t == 0u) *next_count = count;
 }
+// REFIT (lbvh_refit): triangles moved, nothing else changed — the sorted order, the binary tree and the wide nodes' links stay, the boxes follow. Every
+// slot of the node array that heads a wide node (its link words are not all zero: lbvh_build clears the array first; no child's link is 0, the root's)
+// gets its children's boxes again from the recomputed node boxes / segment-tree leaves.
+__global__ __launch_bounds__(kT) void k_lbvh_refit_nodes(const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes, uint32_t n_nodes) {
+    const uint32_t b = blockIdx.x * kT + threadIdx.x;
+    if (b >= n_nodes) return;
+    float4* out = nodes + 4u * (size_t)b;
+    const float4 lw = out[3];
+    uint32_t l[4];
+    if (links16) { l[0] = f2b(lw.x) & 0xffffu; l[1] = f2b(lw.x) >> 16; l[2] = f2b(lw.y) & 0xffffu; l[3] = f2b(lw.y) >> 16; }
+    else { l[0] = f2b(lw.x); l[1] = f2b(lw.y); l[2] = f2b(lw.z); l[3] = f2b(lw.w); }
+    if ((l[0] | l[1] | l[2] | l[3]) == 0u) return;
+    auto dn = [](float x) { return (uint32_t)__half_as_ushort(__float2half_rd(x)); };
+    auto up = [](float x) { return (uint32_t)__half_as_ushort(__float2half_ru(x)); };
+    uint32_t w[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (l[i] == 0u) { w[3 * i] = w[3 * i + 1] = w[3 * i + 2] = 0xfc007c00u; continue; }
+        const Box bx = lb_child_box(l[i], seg, pow2, node_box);
+        w[3 * i] = dn(bx.lx) | (up(bx.hx) << 16); w[3 * i + 1] = dn(bx.ly) | (up(bx.hy) << 16); w[3 * i + 2] = dn(bx.lz) | (up(bx.hz) << 16);
+    }
+    out[0] = make_float4(b2f(w[0]), b2f(w[1]), b2f(w[2]), b2f(w[3]));
+    out[1] = make_float4(b2f(w[4]), b2f(w[5]), b2f(w[6]), b2f(w[7]));
+    out[2] = make_float4(b2f(w[8]), b2f(w[9]), b2f(w[10]), b2f(w[11]));
+}
 }  // namespace
 
 size_t lbvh_sort_temp_bytes(uint32_t slots) {
@@ -301,12 +326,30 @@ int lbvh_build(const LbvhArgs& a, hipStream_t s) {
     // 70 us, nine wide levels of 10-14 us, the tail run 37 us). Whatever is still open after them — nothing, at the sizes measured — is the
     // finishing launch's: single threads walking subtrees one dependent load after the other (with only 8 levels before it, that launch took
     // 8 ms of a 9-ms build at 208 k triangles).
+    if (hipMemsetAsync(a.nodes, 0, (size_t)(a.live - 1u) * 64u, s) != hipSuccess) return -3;   // a slot no wide node is written to stays all zero: lbvh_refit tells the heads by that
     uint32_t wide_levels = 1;
     while (wide_levels < 16u && (1ull << (2u * wide_levels)) < a.live) wide_levels++;
     const uint32_t launches = wide_levels + 8u;
     for (uint32_t launch = 0; launch <= launches; launch++)
         hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min<uint32_t>((a.live + kT - 1) / kT, 1024u)), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes,
                            a.frontier_a, a.frontier_b, a.counters, launch, launch == launches ? 1u : 0u);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// The same arguments as the build that made the tree (keys_out, children and nodes are READ: they must still hold what that build left), after the
+// triangles' records and bounds changed in place: leaf records and boxes, the segment tree, the binary nodes' boxes, the wide nodes' boxes. 5 launches.
+int lbvh_refit(const LbvhArgs& a, hipStream_t s) {
+    if (a.live < 2u) return -1;
+    const uint32_t pow2 = lbvh_pow2(a.live);
+    auto grid = [](uint32_t n) { return dim3((n + kT - 1) / kT); };
+    hipLaunchKernelGGL(k_lbvh_leaves, grid(pow2), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.tri_geo, a.tri_bounds, a.tri_info, a.seg, a.leaves);
+    for (uint32_t count = pow2 >> 1; count >= 1u;) {
+        const uint32_t width = std::min<uint32_t>(count, (uint32_t)kT), groups = count / width;
+        hipLaunchKernelGGL(k_lbvh_seg_levels, dim3(groups), dim3(kT), 0, s, a.seg, count);
+        count = groups >> 1;
+    }
+    hipLaunchKernelGGL(k_lbvh_hierarchy, grid(a.live - 1u), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.seg, a.children, a.node_box);   // (the children come out as they were)
+    hipLaunchKernelGGL(k_lbvh_refit_nodes, grid(a.live - 1u), dim3(kT), 0, s, a.node_box, a.seg, pow2, a.links16, a.nodes, a.live - 1u);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -457,6 +457,7 @@ int st_set_bvh_refresh(StEngine* e, int mode) {
     return ST_OK;
 }
 int st_debug_device_builds(StEngine* e, uint64_t* ticks) { ST_REQUIRE(e && ticks, "null argument"); *ticks = E(e)->device_builds; return ST_OK; }
+int st_debug_device_tree_refits(StEngine* e, uint64_t* ticks) { ST_REQUIRE(e && ticks, "null argument"); *ticks = E(e)->device_tree_refits; return ST_OK; }
 int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* stack_entries) {
     ST_REQUIRE(e && deepest_internal_chain && stack_entries, "null argument");
     *deepest_internal_chain = E(e)->bvh_stack_need; *stack_entries = E(e)->stack_entries;

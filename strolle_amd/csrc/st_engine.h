@@ -427,6 +427,7 @@ struct Engine {
         // ST_BVH_BUILD_DEVICE (k_lbvh.hip): this copy's wide stream was built on the device from its own triangle arrays; `bvh` (the contract
         // stream) is then stale and no launch may read it. lb_live: live triangles of that build. The rest is the builder's scratch.
         bool device_built = false; uint32_t lb_live = 0; uint64_t tri_info_serial = 0;
+        uint64_t lb_serial = ~0ull; uint32_t lb_slots = 0;   // tri_info_serial_ / triangle slots of the copy's last device BUILD (a refit needs both unchanged)
         DeviceArray tri_info, lb_keys_a, lb_keys_b, lb_temp, lb_seg, lb_children, lb_node_box, lb_front_a, lb_front_b, lb_small;
         // ST_BVH_REFIT_DEVICE: what k_bvh.hip needs beside the stream — per triangle slot the hit-test record, the bounds and the
         // device entry that holds it; per entry its parent (entry << 1 | child slot); the leaf runs; an arrival counter per entry.
@@ -523,7 +524,8 @@ struct Engine {
     bool device_refit_possible() const { return bvh_refresh_mode == ST_BVH_REFIT_DEVICE && has_device; }
     // ST_BVH_BUILD_DEVICE: the tree of a changed scene is built on the device (k_lbvh.hip) while nothing observes the contract stream
     bool host_tree_stale = false;    // the host's binned-SAH tree (bvh_stream and everything derived from it) is behind the scene
-    uint64_t device_builds = 0;
+    uint64_t device_builds = 0, device_tree_refits = 0;   // ticks answered by a device build / by a refit of the device-built tree (moves only)
+    bool device_tree_refit_now = false; uint32_t device_refits_since_build = 0;
     std::vector<uint32_t> tri_info_; uint32_t tri_info_live_ = 0; uint64_t tri_info_serial_ = 1, tri_info_built_for_ = 0;   // per slot: live | Blend << 1 | material << 2; the serial counts what can change it
     bool device_build_possible() const;
     int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);

@@ -22,5 +22,8 @@ struct LbvhArgs {
 size_t lbvh_sort_temp_bytes(uint32_t slots);
 uint32_t lbvh_pow2(uint32_t n);
 int lbvh_build(const LbvhArgs& args, hipStream_t stream);   // 0, or negative: -1 fewer than two live triangles, -2 the sort failed, -3 a launch failed
+// After a build with the same arguments whose scratch (keys_out, children) and output are untouched: the triangles moved (tri_geo / tri_bounds changed in
+// place, the same slots live): leaf records and every box again, the topology as it was.
+int lbvh_refit(const LbvhArgs& args, hipStream_t stream);
 
 }  // namespace st

@@ -1,7 +1,10 @@
 // st_tick.cpp — host engine of libstrolle_hip.so: Engine::tick (lib.rs:301-395): refresh of the stores + uploads. See st_engine.h.
 #include "st_engine.h"
 
+#include <cstdlib>
 namespace st {
+
+constexpr uint32_t kDeviceRefitsPerBuild = 15;   // ST_BVH_BUILD_DEVICE: moves-only ticks answered by a refit of the device-built tree between two builds
 
 // The host's binned-SAH tree of the scene as it is now (st_bvh.h: the reference's tree, with unchanged subtrees reused) and its flattened stream.
 void Engine::rebuild_host_tree(bool timing) {
@@ -68,6 +71,7 @@ int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
         t.tri_info_serial = tri_info_serial_;
     }
     // instances that only moved are baked HERE from the object-space meshes (StTuning::device_bake, k_bvh.hip k_bvh_bake): the host bakes nothing for them
+    const bool refit_tree = device_tree_refit_now && t.device_built && t.lb_live == live && t.lb_serial == tri_info_serial_ && t.lb_slots == (uint32_t)slots && live >= 2u;
     t.device_built = true;   // (bake_on_device: no contract stream to patch on this copy)
     if ((rc = bake_on_device(t, up, pageable))) return rc;
     const uint32_t pow2 = lbvh_pow2(live);
@@ -91,8 +95,10 @@ int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
     a.seg = static_cast<float4*>(t.lb_seg.ptr); a.children = static_cast<uint2*>(t.lb_children.ptr); a.node_box = static_cast<float4*>(t.lb_node_box.ptr);
     a.frontier_a = static_cast<uint32_t*>(t.lb_front_a.ptr); a.frontier_b = static_cast<uint32_t*>(t.lb_front_b.ptr);
     a.bounds = static_cast<int*>(t.lb_small.ptr); a.counters = static_cast<uint32_t*>(t.lb_small.ptr) + 8;
+    // moves only, on a copy whose last build saw these very slots: the tree keeps its shape, every box follows (k_lbvh.hip lbvh_refit: 5 launches against 42)
+    if (refit_tree) { if (lbvh_refit(a, up) != 0) return fail(ST_ERR_HIP, "the device BVH refit failed to launch"); return ST_OK; }
     if (lbvh_build(a, up) != 0) return fail(ST_ERR_HIP, "the device BVH build failed to launch");
-    t.device_built = true; t.lb_live = live;
+    t.device_built = true; t.lb_live = live; t.lb_serial = tri_info_serial_; t.lb_slots = (uint32_t)slots;
     t.wide_nodes = live - 1u; t.wide_leaves = live; t.wide_root = 0u; t.wide_links16 = a.links16; t.wide_for_entries = 0u; t.compact_entries = 0u;
     return ST_OK;
 }
@@ -118,8 +124,14 @@ int Engine::tick(hipStream_t stream) {
     // and the host's tree falls behind; the first tick that finds an observer brings it up to date like any rebuild.
     if ((instances_changed && !moved_on_device) || materials_changed_this_tick) tri_info_serial_++;   // slots, liveness, materials or Blend flags may have changed
     const bool build_on_device_now = device_build_possible();
+    device_tree_refit_now = false;
     if (instances_changed && build_on_device_now) {
-        host_tree_stale = true; device_builds++; scene_changed = true;
+        // instances only moved (refresh_instances left them to the device's bake): the device-built tree is refitted, not rebuilt — at most
+        // kDeviceRefitsPerBuild times in a row, then a rebuild restores the tree's quality (it costs 0.3 ms more at 208 k triangles)
+        static const bool no_refit = getenv("ST_NO_DEVICE_TREE_REFIT") != nullptr;
+        device_tree_refit_now = moved_on_device && !materials_changed_this_tick && !no_refit && device_builds > 0 && device_refits_since_build < kDeviceRefitsPerBuild;
+        if (device_tree_refit_now) { device_tree_refits++; device_refits_since_build++; } else { device_builds++; device_refits_since_build = 0; }
+        host_tree_stale = true; scene_changed = true;
         if (timing) fprintf(stderr, "[st_tick] bake %.2f ms, tree: on the device\n", ms(t0, now()));
     } else if (instances_changed || (host_tree_stale && !build_on_device_now)) {
         const auto t1 = now();

@@ -20,6 +20,7 @@ selects another sample and the two histories diverge pixel by pixel (chaotically
    time-averaged images agree to PSNR >= 40 dB and 1 % in mean radiance.
 """
 import json
+import math
 import os
 
 import numpy as np
@@ -450,17 +451,18 @@ def test_a_tree_built_on_the_device_finds_the_same_hits(subdivide):
     for e, _, _ in cams:
         e.insert_instance(7777, Instance(7777, 2, place))       # spawn: in front of the camera
     compare("after a spawn")
-    # moves only: the device bakes the moved instance from its object-space mesh (StTuning::device_bake) and rebuilds; the host bakes nothing
+    # moves only: the device bakes the moved instance from its object-space mesh (StTuning::device_bake) and refits its tree; the host bakes nothing
     for step in range(1, 4):
         moved = place.copy(); moved[0, 3] += 0.1 * step; moved[1, 3] += 0.05 * step
         for e, _, _ in cams:
             e.insert_instance(7777, Instance(7777, 2, moved))
         compare(f"after move {step}")
     assert dev.device_bakes()[0] == 3, "the moved instance was not baked on the device"
+    assert dev.device_tree_refits() == 3 and dev.device_builds() == 2, "ticks in which instances only move refit the device-built tree (k_lbvh.hip lbvh_refit)"
     for e, _, _ in cams:
         e.remove_instance(7777)
     compare("after a despawn")
-    assert dev.device_builds() == 6 and dev.bvh_refits()[0] == 0
+    assert dev.device_builds() == 3 and dev.device_tree_refits() == 3 and dev.bvh_refits()[0] == 0
     assert host.bvh_refits()[0] == 6
     # a heatmap camera needs the contract stream: refused until a tick has seen it, then the reference's tree is back bit for bit
     hm_desc = scenes.dungeon_camera(size, CameraMode.BVH_HEATMAP)
@@ -474,6 +476,50 @@ def test_a_tree_built_on_the_device_finds_the_same_hits(subdivide):
     assert np.array_equal(dev.read_buffer(hm_dev, Buffer.DBG_USED_MEMORY), host.read_buffer(hm_host, Buffer.DBG_USED_MEMORY))
     assert_bits_equal(dev.read_scene(0), host.read_scene(0), "the host tree after device builds")
     for e, _, _ in cams:
+        e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_triangles", [700, 40000])
+def test_a_device_built_tree_is_refitted_while_instances_only_move(n_triangles):
+    """ST_BVH_BUILD_DEVICE, moves only (k_lbvh.hip lbvh_refit): the sorted order, the binary radix tree and the wide nodes' links stay, leaf records and every
+    box are recomputed — 5 launches against a build's 42. Eighteen ticks in which all four instances of a triangle soup move, further and further from where
+    the tree was built: the primary hits stay those of an engine that rebuilds on the host every tick; at most 15 refits in a row, the 16th change
+    rebuilds; with 16- and 32-bit links."""
+    torch = _torch()
+    size = (160, 96)
+    out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+    engines = []
+    for mode in (0, 3):
+        e = Engine(device=0, exact=False)
+        e.set_bvh_refresh(mode)
+        scenes.build_random_soup(e, n_triangles, seed=11)
+        desc = scenes.cornell_camera(size, CameraMode.REFERENCE, depth=0)
+        engines.append((e, e.create_camera(desc), desc))
+
+    def hits_of(e, cam, desc):
+        e.update_camera(cam, desc); e.tick(); e.render_camera(cam, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return e.read_buffer(cam, Buffer.REF_HITS).reshape(size[1], size[0], -1).copy()
+
+    def compare(what):
+        h, d = (hits_of(*x) for x in engines)
+        bad = lanes_outside_tolerance(d, h, rtol=1e-4, atol=1e-5).reshape(h.shape).any(-1)
+        assert bad.mean() <= 2e-3, f"{what}: {bad.mean():.2e} of the primary hits differ between the refitted device tree and the host's rebuild"
+
+    compare("first build")
+    dev = engines[1][0]
+    assert dev.device_builds() == 1 and dev.device_tree_refits() == 0
+    for step in range(1, 19):
+        for e, _, _ in engines:
+            for i in range(4):
+                ang = 0.3 * i + 0.07 * step
+                x = np.array([[math.cos(ang), 0, math.sin(ang), 0.05 * step * (i - 1.5)], [0, 1, 0, 1.0 + 0.03 * step], [-math.sin(ang), 0, math.cos(ang), -0.04 * step * i]], np.float32)
+                e.insert_instance(1 + i, Instance(1 + i, 1 + i, x))
+        compare(f"move {step}")
+    assert dev.device_builds() == 2 and dev.device_tree_refits() == 17, (dev.device_builds(), dev.device_tree_refits())
+    assert dev.device_bakes()[0] >= 18, "the moved instances were not baked on the device"
+    for e, _, _ in engines:
         e.close()
 
 

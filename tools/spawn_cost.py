@@ -56,5 +56,5 @@ for mode in (0, 3):
     after = (time.perf_counter() - t0) / 30 * 1e3
     print(f"refresh mode {mode} ({'host rebuild' if mode == 0 else 'device build'}), subdivide {args.subdivide}: steady frame {steady:.3f} ms before / {after:.3f} ms after the changes | "
           f"spawn / despawn: st_tick {np.median(ticks):.2f} ms on the host (max {max(ticks):.2f}), tick until its device work is through {np.median(idles):.2f} ms (max {max(idles):.2f}), the first frame after it {np.median(first):.2f} ms | "
-          f"host rebuilds {e.bvh_refits()[0]}, device builds {e.device_builds()}, finite {bool(torch.isfinite(out).all())}")
+          f"host rebuilds {e.bvh_refits()[0]}, device builds {e.device_builds()} (+ {e.device_tree_refits()} refits), finite {bool(torch.isfinite(out).all())}")
     e.close()

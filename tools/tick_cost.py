@@ -37,4 +37,4 @@ for i in range(args.ticks):
     if args.sync: torch.cuda.synchronize(); ds.append(time.perf_counter() - t)
 bakes = e.device_bakes() if args.device >= 0 else (0, 0)
 tris = e.read_scene(1).nbytes // 144
-print(f"device={args.device} triangles={tris} refit={args.refit} (rebuilds, refits)={e.bvh_refits()}: tick with {'every' if args.all else 'one'} instance moved: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms; device bakes {bakes[0]} ({bakes[1]} triangles)" + (f"; until the device is through: median {np.median(ds)*1e3:.2f} ms" if ds else "") + (f"; device builds {e.device_builds()}" if args.device >= 0 else ""))
+print(f"device={args.device} triangles={tris} refit={args.refit} (rebuilds, refits)={e.bvh_refits()}: tick with {'every' if args.all else 'one'} instance moved: median {np.median(ts)*1e3:.2f} ms, min {min(ts)*1e3:.2f} ms; device bakes {bakes[0]} ({bakes[1]} triangles)" + (f"; until the device is through: median {np.median(ds)*1e3:.2f} ms" if ds else "") + (f"; device builds {e.device_builds()}, refits of the device-built tree {e.device_tree_refits()}" if args.device >= 0 else ""))
