@@ -526,6 +526,8 @@ struct Engine {
     bool host_tree_stale = false;    // the host's binned-SAH tree (bvh_stream and everything derived from it) is behind the scene
     uint64_t device_builds = 0, device_tree_refits = 0;   // ticks answered by a device build / by a refit of the device-built tree (moves only)
     bool device_tree_refit_now = false; uint32_t device_refits_since_build = 0;
+    size_t info_dirty_lo_ = SIZE_MAX, info_dirty_hi_ = 0; bool info_full_ = true;   // slots whose word may have changed since tri_info_ was listed (spawned, removed); everything (materials changed)
+    void mark_info_dirty(size_t b, size_t e) { info_dirty_lo_ = std::min(info_dirty_lo_, b); info_dirty_hi_ = std::max(info_dirty_hi_, e); }
     std::vector<uint32_t> tri_info_; uint32_t tri_info_live_ = 0; uint64_t tri_info_serial_ = 1, tri_info_built_for_ = 0;   // per slot: live | Blend << 1 | material << 2; the serial counts what can change it
     bool device_build_possible() const;
     int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);

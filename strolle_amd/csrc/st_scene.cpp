@@ -91,6 +91,7 @@ void Engine::drop_instance_triangles(uint64_t id) {
     if (it == instance_triangles.end()) return;
     triangle_free.give(it->second.first, it->second.second);
     for (size_t i = it->second.first; i < it->second.second; i++) prim_alive[i] = 0;
+    mark_info_dirty(it->second.first, it->second.second);
     instance_triangles.erase(it);
 }
 
@@ -240,6 +241,7 @@ bool Engine::refresh_instances() {
         jobs.push_back({&mesh->second, &inst, mat->second, b, count});
         total += count;
         for (SceneSet& t : sets) { t.dirty_lo = std::min(t.dirty_lo, b); t.dirty_hi = std::max(t.dirty_hi, e); }  // slots each device copy still has to receive
+        mark_info_dirty(b, e);
         instance_triangles[inst.id] = {b, e};
         auto mv = mesh_version.find(inst.mesh);
         inst.baked = true; inst.baked_mesh = inst.mesh; inst.baked_mesh_version = mv == mesh_version.end() ? 0 : mv->second; inst.baked_material = mat->second; inst.host_stale = false;
