@@ -355,6 +355,7 @@ struct Engine {
     std::vector<float4> instance_xforms; std::vector<uint32_t> xslot_free;
     std::map<uint64_t, std::pair<size_t, size_t>> instance_triangles; SlotRanges triangle_free;
     std::vector<HostTriangle> triangles; std::vector<BuildPrim> prims; std::vector<uint8_t> prim_alive;
+    size_t live_prims_ = 0;   // how many of prim_alive are set (kept by refresh_instances / drop_instance_triangles: device_build_possible asks every tick)
     std::vector<float4> tri_geo, tri_attr, tri_bounds, bvh_stream, bvh_upload_;  // tri_bounds: (lo, hi) per triangle slot (device refit)
     BvhBuild bvh;
     bool scene_uploaded = false;

@@ -90,7 +90,7 @@ void Engine::drop_instance_triangles(uint64_t id) {
     auto it = instance_triangles.find(id);
     if (it == instance_triangles.end()) return;
     triangle_free.give(it->second.first, it->second.second);
-    for (size_t i = it->second.first; i < it->second.second; i++) prim_alive[i] = 0;
+    for (size_t i = it->second.first; i < it->second.second; i++) { live_prims_ -= prim_alive[i]; prim_alive[i] = 0; }
     mark_info_dirty(it->second.first, it->second.second);
     instance_triangles.erase(it);
 }
@@ -242,6 +242,7 @@ bool Engine::refresh_instances() {
         total += count;
         for (SceneSet& t : sets) { t.dirty_lo = std::min(t.dirty_lo, b); t.dirty_hi = std::max(t.dirty_hi, e); }  // slots each device copy still has to receive
         mark_info_dirty(b, e);
+        if (have == instance_triangles.end()) live_prims_ += count;   // (the bake below sets prim_alive for the whole range)
         instance_triangles[inst.id] = {b, e};
         auto mv = mesh_version.find(inst.mesh);
         inst.baked = true; inst.baked_mesh = inst.mesh; inst.baked_mesh_version = mv == mesh_version.end() ? 0 : mv->second; inst.baked_material = mat->second; inst.host_stale = false;

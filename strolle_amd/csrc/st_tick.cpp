@@ -32,9 +32,7 @@ bool Engine::device_build_possible() const {
     if (bvh_refresh_mode != ST_BVH_BUILD_DEVICE || !has_device || arithmetic != ST_ARITH_FAST) return false;
     if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes) return false;
     for (const auto& kv : cameras) if (kv.second->desc.mode == ST_MODE_BVH_HEATMAP) return false;
-    size_t live = 0;
-    for (uint8_t a : prim_alive) live += a;
-    return live >= 2u && prims.size() < (1u << 23);
+    return live_prims_ >= 2u && prims.size() < (1u << 23);
 }
 // This device copy's triangle arrays brought up to date, then k_lbvh.hip builds its wide stream from them.
 int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
@@ -54,6 +52,7 @@ int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
             tri_info_.resize(slots);
             tri_info_live_ = 0;
             for (size_t i = 0; i < slots; i++) { tri_info_[i] = word(i); tri_info_live_ += tri_info_[i] & 1u; }
+            live_prims_ = tri_info_live_;
         } else {   // only the slots an instance took or gave back since the last listing (208 k slots: the full listing was 0.25-0.35 ms of a 0.45-ms tick)
             for (size_t i = info_dirty_lo_; i < std::min(info_dirty_hi_, slots); i++) { const uint32_t w = word(i); tri_info_live_ += (w & 1u) - (tri_info_[i] & 1u); tri_info_[i] = w; }
         }
