@@ -6,7 +6,7 @@
 // tree — they owe the reference their hits, not their path (st_device.h closest_hit_wide) — so while no camera observes the contract stream
 // (no heatmap camera, fast arithmetic, no byte counting) a scene change is followed by this builder instead:
 //
-//   1. centroid bounds of the live triangle slots                                   k_lbvh_bounds      (wave reduction, one ordered-int atomic pair per wave)
+//   1. centroid bounds of the live triangle slots                                   k_lbvh_bounds      (wave, then workgroup reduction: one ordered-int atomic pair per workgroup)
 //   2. key = 30-bit Morton code of the centroid << 32 | triangle slot (unique)      k_lbvh_keys        dead slots: ~0, sorted to the end
 //   3. radix sort of the 64-bit keys                                                hipCUB DeviceRadixSort (a plain library sort)
 //   4. leaf records (48 B, sorted order = leaf index) + leaf boxes                  k_lbvh_leaves
@@ -19,7 +19,10 @@
 //      a run of narrow levels (the first five or six, and the long tail) is one workgroup's loop through LDS inside one launch; a last
 //      launch walks whatever is deeper with a private stack per thread                                                    k_lbvh_collapse
 //
-// Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
+//   R. instances only moved: steps 4-6 again over the SAME sorted order, then every wide node's box words from its links           lbvh_refit
+//      (5 launches against the build's 42; st_tick.cpp: at most 15 refits between two builds)
+//
+// 208 k triangles, one build: 0.34 ms of device time (profiles/r05_lbvh_kernel_stats.txt). Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
 // 11.6 for a GI bounce, the same number of triangle tests, deepest stack 13-14.
 #include <hip/hip_fp16.h>
 #include <hipcub/hipcub.hpp>

@@ -11,7 +11,7 @@ namespace st {
 // live - 1 slots, sparsely used; the root is node 0) and `leaves` (48 B per record, sorted order), in the wide stream's format
 // (st_device.h closest_hit_wide). Scratch: keys_in / keys_out (8 B x slots), sort_temp (lbvh_sort_temp_bytes(slots)), seg
 // (2 x lbvh_pow2(live) boxes of 32 B), children (8 B x live), node_box (32 B x live), frontier_a / frontier_b (4 B x live), bounds (6 ints),
-// counters (3 words).
+// counters (3 words: the collapse's frontier counts, rotating by launch).
 struct LbvhArgs {
     const float4* tri_geo; const float4* tri_bounds; const uint32_t* tri_info;
     uint32_t slots, live, links16;
