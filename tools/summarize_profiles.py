@@ -193,8 +193,9 @@ def main():
                 if not m.get("SQ_WAVES"):
                     continue
                 wc = m["SQ_WAVE_CYCLES"]
-                # a plain wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md; packed-f32 and
-                # transcendental ones longer, so this is a lower bound); 1024 SIMDs
+                # a plain wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md): a LOWER bound, and a loose one —
+                # tools/ubench/valu_rate.hip measures 2.3 cycles only for fma / mul / add / mov / and / or / xor and 4.1 for min / max / cmp / cndmask /
+                # cvt / fma_mix / alignbit / perm / shifts / med3, which is what a traversal step is made of (DESIGN.md "What a VALU instruction costs"); 1024 SIMDs
                 floor_us = m["SQ_INSTS_VALU"] * 2.0 / 1024.0 / 2400.0
                 rows.append([k, int(m["SQ_WAVES"]), round(m["SQ_INSTS_VALU"] / m["SQ_WAVES"]), round(m["SQ_ACTIVE_INST_VALU"] / wc, 3),
                              round(m["SQ_WAIT_ANY"] / wc, 3), round(m["SQ_WAIT_INST_ANY"] / wc, 3), round(m["SQ_ACTIVE_INST_ANY"] / wc, 3), round(floor_us, 1)] + list(lane.get(k, ("", "", "", ""))))
