@@ -157,7 +157,7 @@ int st_camera_present_ready(StEngine* e, StHandle camera, const void* dst_host, 
 
 /* ---- NEW seams (no counterpart in the reference) */
 /* BVH refresh policy for scenes that change every frame (examples/stress-bvh.rs).
- * ST_BVH_REBUILD (default) is the reference's behaviour: every change rebuilds the tree — with unchanged subtrees
+ * ST_BVH_REBUILD is the reference's behaviour: every change rebuilds the tree — with unchanged subtrees
  * reused, builder.rs:183-301 — and the result is the tree a from-scratch build gives. ST_BVH_REFIT keeps the tree
  * while instances only move (same triangles, same materials, same Blend flags) and recomputes its boxes bottom-up,
  * which costs a fraction of a rebuild; traversal stays correct, `used_memory` and the tree's quality follow the old
@@ -175,7 +175,13 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                                                incoherent rays —, so it is used only while nothing observes the contract stream (a tick in which
                                                instances only MOVED refits that tree: st_debug_device_tree_refits): fast arithmetic, no
                                                BvhHeatmap camera, no byte counting. A tick that finds such an observer builds on the host as
-                                               ST_BVH_REBUILD does; a heatmap camera created later renders after the next st_tick. */ };
+                                               ST_BVH_REBUILD does; a heatmap camera created later renders after the next st_tick. */,
+                    ST_BVH_AUTO = 4         /* (round 6) THE DEFAULT. The first tree of an engine is built on the host as ST_BVH_REBUILD builds it — the
+                                               reference's binned SAH, paid once while the scene loads; every later change (spawn, despawn, move) is
+                                               answered as ST_BVH_BUILD_DEVICE answers it, under the same conditions, so that a default engine no longer
+                                               stalls for tens of milliseconds per spawn. Scenes whose stream fits the kernels' LDS copy (at most 112
+                                               entries: the Cornell box), host-only engines, the exact build and observed contract streams behave as
+                                               under ST_BVH_REBUILD. */ };
 /* Ticks whose tree was built on the device so far (ST_BVH_BUILD_DEVICE). */
 int st_debug_device_builds(StEngine* e, uint64_t* ticks);
 /* Ticks of that mode in which instances only moved and the device-built tree was REFITTED instead (same shape, every box recomputed: 5 launches
@@ -193,6 +199,13 @@ int st_debug_device_bakes(StEngine* e, uint64_t* ticks, uint64_t* triangles);   
  * deeper than 24; this library drops a push only beyond 32 and says so — a scene for which *deepest_internal_chain > *stack_entries can
  * miss geometry behind the dropped subtrees. */
 int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* stack_entries);
+/* The WIDE stream (StTuning::wide_bvh) is another tree than the contract stream and its walks keep StTuning::wide_stack_entries (0 = 24) pending
+ * entries per ray — every scene measured needs 11-14. A walk that does find its stack full drops the push (geometry behind it can be missed) and
+ * sets a sticky word the engine owns; the next st_tick that sees it re-arms every later launch with a deeper stack (24 -> 32 -> 48 -> 56 entries;
+ * the primary rays' packet walk, 64 entries in one register, is replaced by the per-lane walk) and returns ST_ERR_BVH_TOO_DEEP once
+ * (StTuning::allow_deep_bvh = 1: a warning on stderr instead). *overflows: ticks that found a word set; *wide_stack_entries: what the wide walks
+ * hold now; *packets_off: 1 once the packet walk overflowed. */
+int st_debug_walk_overflow(StEngine* e, uint64_t* overflows, uint32_t* wide_stack_entries, uint32_t* packets_off);
 
 /* Deterministic seeds: every pass draws seed = pass_seed(base, frame, pass_id) instead of
  * rand::thread_rng() (camera_controller.rs:189-194; passes/ref_*.rs:49-59). */

@@ -315,6 +315,7 @@ class _Binding:
         self.set_bvh_refresh = fn("set_bvh_refresh", [vp, i32]); self.debug_bvh_refits = fn("debug_bvh_refits", [vp, P(u64), P(u64)])
         if has_device:
             self.debug_bvh_depth = fn("debug_bvh_depth", [vp, P(u32), P(u32)])
+            self.debug_walk_overflow = fn("debug_walk_overflow", [vp, P(u64), P(u32), P(u32)])
             self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
             self.debug_device_bakes = fn("debug_device_bakes", [vp, P(u64), P(u64)])
             self.debug_device_builds = fn("debug_device_builds", [vp, P(u64)])
@@ -502,9 +503,10 @@ class EngineBase:
     def set_bvh_refresh(self, refit):
         """st_set_bvh_refresh: False / 0 = rebuild on every change (the reference's behaviour), True / 1 = refit while instances only
         move, 2 = the same with the boxes recomputed on the device (ST_BVH_REFIT_DEVICE; libstrolle_hip.so only), 3 = the tree BUILT on the device
-        straight into the wide stream while nothing observes the contract stream (ST_BVH_BUILD_DEVICE; libstrolle_hip.so only)."""
+        straight into the wide stream while nothing observes the contract stream (ST_BVH_BUILD_DEVICE; libstrolle_hip.so only), 4 = the library's default
+        (ST_BVH_AUTO: the first tree on the host, every later change as mode 3)."""
         refit = int(refit)
-        if refit not in (0, 1, 2, 3):
+        if refit not in (0, 1, 2, 3, 4):
             raise StrolleError(f"unknown BVH refresh mode {refit}")
         if refit >= 2 and not hasattr(self._b, "debug_bvh_device_refits"):
             raise StrolleError("ST_BVH_REFIT_DEVICE is a mode of libstrolle_hip.so; this engine's library does not have it")
@@ -548,6 +550,12 @@ class EngineBase:
         a, b = C.c_uint32(), C.c_uint32()
         self._check(self._b.debug_bvh_depth(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def walk_overflow(self):
+        """(ticks that found a wide walk's overflow word set, entries the wide walks' stack holds now, 1 once the packet walk overflowed) — st_debug_walk_overflow."""
+        n, entries, off = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        self._check(self._b.debug_walk_overflow(self._h, C.byref(n), C.byref(entries), C.byref(off)))
+        return n.value, entries.value, off.value
 
     def image_rect(self, handle: int):
         """(x, y, w, h) of an image in the atlas, in texels."""

@@ -414,8 +414,9 @@ __global__ ST_KERNEL_BOUNDS void k_gi_spatial_sample(const KArgs a, uint32_t see
 void launch_gi_spatial_sample(const KArgs& a, uint32_t seed, hipStream_t s) { ST_LAUNCH(k_gi_spatial_sample, true, s, a, seed); }
 
 // gi_spatial_resampling.rs pick + trace + sample for one 2x1 cell in one launch (see k_di_spatial_fused, k_di.hip)
+// (5 waves per SIMD = 96 VGPRs: the allocator's free choice crossed to 97 — 4 waves — when the wide walk's overflow report went in; the loop is the one that waits, wait_any 0.49)
 template <bool LDS_SCENE, class SE>
-__global__ ST_KERNEL_BOUNDS void k_gi_spatial_fused(const KArgs a_in, uint32_t seed_pick, uint32_t seed_sample) {
+__global__ __launch_bounds__(kBlockThreads, 5) void k_gi_spatial_fused(const KArgs a_in, uint32_t seed_pick, uint32_t seed_sample) {
     ST_SCENE_PROLOGUE_WITH_BYTE_TABLES
     ST_STACK_LDS(SE, lds);
     U2 gid;

@@ -26,6 +26,13 @@ int st_engine_create(int device_ordinal, StEngine** out) {
         DeviceArray* luts[3] = {&e->d_transmittance, &e->d_scattering, &e->d_sky};
         for (int i = 0; i < 3; i++) { ST_HIP(hipMalloc(&luts[i]->ptr, lut_bytes[i])); luts[i]->capacity = lut_bytes[i]; ST_HIP(hipMemset(luts[i]->ptr, 0, lut_bytes[i])); }
         ST_HIP(hipMalloc(&e->d_byte_luts.ptr, sizeof(float) * 1024)); e->d_byte_luts.capacity = sizeof(float) * 1024;
+        {   // the wide walks' overflow words (st_engine.h walk_flags_host): page-locked, mapped, written by a kernel only when a push is dropped
+            void* host = nullptr; void* dev = nullptr;
+            ST_HIP(hipHostMalloc(&host, 64, hipHostMallocMapped));
+            memset(host, 0, 64);
+            ST_HIP(hipHostGetDevicePointer(&dev, host, 0));
+            e->walk_flags_host = static_cast<volatile uint32_t*>(host); e->walk_flags_dev = static_cast<uint32_t*>(dev);
+        }
         e->L.launch_build_byte_luts(static_cast<float*>(e->d_byte_luts.ptr), nullptr);
         ST_HIP(hipDeviceSynchronize());
     }
@@ -451,7 +458,7 @@ int st_debug_world(StEngine* e, uint32_t* light_count, uint32_t* next_frame) {
 
 int st_set_bvh_refresh(StEngine* e, int mode) {
     ST_REQUIRE(e, "null engine");
-    ST_REQUIRE(mode == ST_BVH_REBUILD || mode == ST_BVH_REFIT || mode == ST_BVH_REFIT_DEVICE || mode == ST_BVH_BUILD_DEVICE, "unknown refresh mode");
+    ST_REQUIRE(mode == ST_BVH_REBUILD || mode == ST_BVH_REFIT || mode == ST_BVH_REFIT_DEVICE || mode == ST_BVH_BUILD_DEVICE || mode == ST_BVH_AUTO, "unknown refresh mode");
     Engine* en = E(e);
     if (en->bvh_refresh_mode != mode) { en->bvh_refresh_mode = mode; en->have_topology = false; }
     return ST_OK;
@@ -461,6 +468,15 @@ int st_debug_device_tree_refits(StEngine* e, uint64_t* ticks) { ST_REQUIRE(e && 
 int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* stack_entries) {
     ST_REQUIRE(e && deepest_internal_chain && stack_entries, "null argument");
     *deepest_internal_chain = E(e)->bvh_stack_need; *stack_entries = E(e)->stack_entries;
+    return ST_OK;
+}
+int st_debug_walk_overflow(StEngine* e, uint64_t* overflows, uint32_t* wide_stack_entries, uint32_t* packets_off) {
+    ST_REQUIRE(e && overflows && wide_stack_entries && packets_off, "null argument");
+    if (E(e)->has_device && E(e)->walk_flags_host) {   // frames still in flight count too: wait for them, then look (the next st_tick reports what is found here)
+        ST_HIP(hipSetDevice(E(e)->device)); ST_HIP(hipDeviceSynchronize());
+        if ((E(e)->walk_flags_host[0] | E(e)->walk_flags_host[1]) != 0u) E(e)->note_walk_overflow();
+    }
+    *overflows = E(e)->walk_overflows; *wide_stack_entries = E(e)->wide_stack_entries_now(); *packets_off = E(e)->packets_overflowed ? 1u : 0u;
     return ST_OK;
 }
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits) {

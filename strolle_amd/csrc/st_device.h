@@ -696,6 +696,13 @@ ST_D uint32_t umed3_(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_me
 // (ONE fetch site for both kinds of step, as in the compact loop: with a fetch in each body a wave whose lanes sit on nodes AND on leaf
 // records pays two dependent round trips per iteration — measured: the incoherent GI rays lost 10 % that way while coherent rays gained.
 // Nodes and leaf records therefore live in one allocation, the records `bvh_w_leaf_off` bytes behind its start.)
+// A push the stack has no room for is DROPPED (the subtree behind it is never visited: geometry can be missed) — and reported: the keys are sorted, so
+// whenever a node pushes at all its LAST push is k1's, and if any of its pushes found the stack full that one did too. One `else` per node step, never
+// taken on any scene measured (deepest stack 11-14 of 24), sets a sticky word of page-locked host memory the engine owns (KArgs::walk_flags:
+// a plain store of 1, no atomic — word 0: a per-lane walk, word 1: the primary rays' packet); the next st_tick that sees it re-arms the launches with a
+// deeper stack (the packet: hands primary visibility back to the per-lane walk) and returns ST_ERR_BVH_TOO_DEEP once (st_tick.cpp).
+constexpr uint32_t kWalkOverflowLane = 0u, kWalkOverflowPacket = 1u;
+ST_D void wide_walk_overflowed(const KArgs& a, uint32_t word) { if (a.walk_flags) a.walk_flags[word] = 1u; }
 ST_D uint32_t wide_at(const KArgs& a, uint32_t cur) { return (cur & 1u) ? a.bvh_w_leaf_off + __umul24(cur >> 1, 48u) : (cur << 5); }
 template <class SE>
 ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
@@ -721,7 +728,7 @@ ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
             ST_WIDE_SORT4(k0, k1, k2, k3);
             if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, a.bvh_w_link_mask); top += 64; } }
             if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, a.bvh_w_link_mask); top += 64; } }
-            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, a.bvh_w_link_mask); top += 64; } }
+            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, a.bvh_w_link_mask); top += 64; } else wide_walk_overflowed(a, kWalkOverflowLane); }
             if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, a.bvh_w_link_mask); continue; }
         } else {
             const uint32_t head = f2b(t0.w);
@@ -764,7 +771,7 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
             ST_WIDE_SORT4(k0, k1, k2, k3);
             if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, a.bvh_w_link_mask); top += 64; } }
             if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, a.bvh_w_link_mask); top += 64; } }
-            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, a.bvh_w_link_mask); top += 64; } }
+            if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, a.bvh_w_link_mask); top += 64; } else wide_walk_overflowed(a, kWalkOverflowLane); }
             if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, a.bvh_w_link_mask); continue; }
         } else {
             const uint32_t head = f2b(t0.w);
@@ -853,7 +860,7 @@ ST_D bool closest_hit_packet(const KArgs& a, const Ray& ray, Candidate* best) {
 #undef ST_PKT_CSWAP
             if (k3 != 0xffffffffu && sp < 64u) { stack = wave_writelane(stack, l3, sp); sp++; }
             if (k2 != 0xffffffffu && sp < 64u) { stack = wave_writelane(stack, l2, sp); sp++; }
-            if (k1 != 0xffffffffu && sp < 64u) { stack = wave_writelane(stack, l1, sp); sp++; }
+            if (k1 != 0xffffffffu) { if (sp < 64u) { stack = wave_writelane(stack, l1, sp); sp++; } else wide_walk_overflowed(a, kWalkOverflowPacket); }
             if (k0 != 0xffffffffu) { cur = l0; continue; }
         } else {
             const ScalarWords r = base + leaf_words + (size_t)(cur >> 1) * 12u;

@@ -60,9 +60,22 @@ int Engine::set_tuning(const StTuning& t) {
     if (t.struct_size != sizeof(StTuning)) return fail(ST_ERR_INVALID_ARGUMENT, "StTuning::struct_size does not match this library");
     if (t.tile_map > 2u || t.tile_map_denoise > 2u) return fail(ST_ERR_INVALID_ARGUMENT, "tile_map is 0, 1 or 2");
     if (t.wide_stack_entries != 0u && (t.wide_stack_entries < 8u || t.wide_stack_entries > 56u)) return fail(ST_ERR_INVALID_ARGUMENT, "wide_stack_entries is 0 (default) or 8 ... 56");
+    if (t.wide_stack_entries != tuning.wide_stack_entries) wide_stack_rearmed = 0u;   // the caller's figure stands until a walk overflows it
     tuning = t;
     staging.enabled = tuning.staging != 0u;
     return ST_OK;
+}
+// st_tick found a wide walk's overflow word set (st_device.h wide_walk_overflowed): see st_engine.h walk_flags_host
+void Engine::note_walk_overflow() {
+    const bool lane = walk_flags_host[0] != 0u, packet = walk_flags_host[1] != 0u;
+    walk_flags_host[0] = 0u; walk_flags_host[1] = 0u;   // (a frame still in flight may set them again: the next tick sees that)
+    if (!lane && !packet) return;
+    walk_overflows++; walk_overflow_unreported = true;
+    if (packet) packets_overflowed = true;
+    if (lane) {
+        const uint32_t now = wide_stack_entries_now();
+        wide_stack_rearmed = now < 32u ? 32u : (now < 48u ? 48u : 56u);   // 56: what 64 KB of dynamic LDS hold with 32-bit slots
+    }
 }
 void Engine::reset_profile_totals() {
     for (int i = 0; i < KS_COUNT; i++) {
@@ -88,6 +101,7 @@ Engine::~Engine() {
     for (auto& r : profile_records) { if (r.owns_start) (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (auto e : event_pool) (void)hipEventDestroy(e);
     if (ev_tick) (void)hipEventDestroy(ev_tick);
+    if (walk_flags_host) (void)hipHostFree(const_cast<uint32_t*>(walk_flags_host));
     staging.release();
 }
 

@@ -361,7 +361,7 @@ struct Engine {
     bool scene_uploaded = false;
     // BVH refresh policy (st_set_bvh_refresh). Refit: while the set of (triangle slot, material) pairs and the Blend flags
     // are what the last build saw — i.e. instances only moved — keep the tree and recompute the boxes bottom-up.
-    int bvh_refresh_mode = ST_BVH_REBUILD;
+    int bvh_refresh_mode = ST_BVH_AUTO;   // (host-only engines, the exact build and observed contract streams: what ST_BVH_REBUILD does)
     bool have_topology = false; uint64_t topology_signature = 0;
     std::vector<uint32_t> internal_positions;  // stream offsets of the internal nodes, ascending (parents before children)
     uint64_t refits = 0, rebuilds = 0;
@@ -530,6 +530,17 @@ struct Engine {
     size_t info_dirty_lo_ = SIZE_MAX, info_dirty_hi_ = 0; bool info_full_ = true;   // slots whose word may have changed since tri_info_ was listed (spawned, removed); everything (materials changed)
     void mark_info_dirty(size_t b, size_t e) { info_dirty_lo_ = std::min(info_dirty_lo_, b); info_dirty_hi_ = std::max(info_dirty_hi_, e); }
     std::vector<uint32_t> tri_info_; uint32_t tri_info_live_ = 0; uint64_t tri_info_serial_ = 1, tri_info_built_for_ = 0;   // per slot: live | Blend << 1 | material << 2; the serial counts what can change it
+    // A wide walk that found its stack full drops the push and says so in one of two sticky words of page-locked host memory (st_device.h
+    // wide_walk_overflowed; KArgs::walk_flags). st_tick reads them: a per-lane walk's overflow re-arms every later launch with a deeper stack
+    // (24 -> 32 -> 48 -> 56 entries: dynamic LDS, fewer waves per SIMD), the packet's (64 entries, one VGPR) hands primary visibility back to the
+    // per-lane walk; either way that tick returns ST_ERR_BVH_TOO_DEEP once (StTuning::allow_deep_bvh: a line on stderr) — the frames rendered in
+    // between may have missed geometry behind the dropped subtrees.
+    volatile uint32_t* walk_flags_host = nullptr; uint32_t* walk_flags_dev = nullptr;
+    uint32_t wide_stack_rearmed = 0u;   // 0: StTuning::wide_stack_entries (0 = 24) as set; otherwise the entries an overflow re-armed the wide walks with
+    bool packets_overflowed = false;    // the packet walk overflowed once on this engine: primary rays keep the per-lane walk
+    uint64_t walk_overflows = 0; bool walk_overflow_unreported = false;
+    uint32_t wide_stack_entries_now() const { return wide_stack_rearmed ? wide_stack_rearmed : (tuning.wide_stack_entries ? tuning.wide_stack_entries : (uint32_t)kBvhStackSize); }
+    void note_walk_overflow();
     bool device_build_possible() const;
     int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);
     void rebuild_host_tree(bool timing);

@@ -132,7 +132,8 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     a.bvh_w = wide ? static_cast<const float4*>(scene.bvh_wide.ptr) : nullptr;
     a.bvh_w_leaf_off = wide ? scene.wide_nodes * 64u : 0u;
     a.bvh_w_root = wide ? scene.wide_root : 0u; a.bvh_w_links16 = wide ? scene.wide_links16 : 0u;
-    a.primary_packets = wide && tuning.primary_packets ? 1u : 0u;
+    a.primary_packets = wide && tuning.primary_packets && !packets_overflowed ? 1u : 0u;
+    a.walk_flags = walk_flags_dev;
     {   // the largest link of this stream: (max(nodes, leaf records) - 1) << 1 | 1
         uint32_t bits = 16u;
         const uint32_t top = std::max(scene.wide_nodes, scene.wide_leaves);
@@ -145,7 +146,8 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     // child of every node on a path hit: 35 pending entries for the 13 k-triangle dungeon, 45 at 208 k) does not fit LDS at full occupancy and
     // no ray comes near it (deepest stack measured: 11-13); it keeps kBvhStackSize entries, and test_the_wide_walk_drops_no_push renders
     // BASELINE config 3's scene with 24 and with 48 entries (StTuning::wide_stack_entries) and finds the same bits.
-    a.stack_entries = wide ? (tuning.wide_stack_entries ? tuning.wide_stack_entries : (uint32_t)kBvhStackSize) : stack_entries;
+    // A walk that does find the stack full says so (KArgs::walk_flags) and the next st_tick re-arms the launches with a deeper one (st_engine.h walk_flags_host).
+    a.stack_entries = wide ? wide_stack_entries_now() : stack_entries;
     a.bvh_len = scene.device_built ? 0x40000000u : device_bvh_len;   // (device-built: no contract stream; any value that is neither "empty" nor "fits LDS")
     if (scene.device_built) a.bvh = nullptr; a.n_lights_buf = (uint32_t)gpu_lights.size(); a.light_count = light_count;
     a.atlas_w = atlas_w; a.atlas_h = atlas_h; a.sun_altitude = sun_altitude;

@@ -28,8 +28,12 @@ void Engine::rebuild_host_tree(bool timing) {
 }
 // ST_BVH_BUILD_DEVICE applies while nothing observes the contract stream: the fast build's rays walk the wide stream (StTuning::wide_bvh and
 // what it rests on), no camera draws the heatmap, the reference's traversal bytes are not being counted — and there is a scene to sort.
+// ST_BVH_AUTO (the default since round 6): the FIRST tree of an engine is the host's — the reference's binned SAH, the better tree, paid once while a scene
+// loads — and every CHANGE after it (spawn, despawn, move) goes to the device under the same conditions; scenes whose contract stream fits LDS
+// (k_common.h scene_fits_lds: the Cornell box) keep the host's tree, which their kernels walk from LDS with the exact closest-hit loop.
 bool Engine::device_build_possible() const {
-    if (bvh_refresh_mode != ST_BVH_BUILD_DEVICE || !has_device || arithmetic != ST_ARITH_FAST) return false;
+    const bool automatic = bvh_refresh_mode == ST_BVH_AUTO && scene_uploaded && live_prims_ > kLdsSceneTexels / 4u;   // (a leaf entry per triangle: more than 112 of them never fit)
+    if (!(bvh_refresh_mode == ST_BVH_BUILD_DEVICE || automatic) || !has_device || arithmetic != ST_ARITH_FAST) return false;
     if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes) return false;
     for (const auto& kv : cameras) if (kv.second->desc.mode == ST_MODE_BVH_HEATMAP) return false;
     return live_prims_ >= 2u && prims.size() < (1u << 23);
@@ -168,6 +172,11 @@ int Engine::tick(hipStream_t stream) {
             if (refitting) { index_stream(); topology_signature = signature; have_topology = true; }
         }
         scene_changed = true;
+    } else if (scene_uploaded && sets[live].device_built && !build_on_device_now) {
+        // Nothing changed, the host's tree is current (a debug read rebuilt it) — but the live device copy still holds a device-built tree and no contract
+        // stream, and an observer has appeared (heatmap camera, exact arithmetic, byte counting): the host's streams are uploaded now, so that the render
+        // after THIS tick finds them (include/strolle_hip.h ST_BVH_BUILD_DEVICE: "a heatmap camera created later renders after the next st_tick").
+        scene_changed = true;
     }
     light_count = next_light_id;
     {   // World::sun_dir (world.rs:18-24)
@@ -187,6 +196,7 @@ int Engine::tick(hipStream_t stream) {
     snapshot_lights();
     if (has_device) {
         ST_HIP(hipSetDevice(device));
+        if (walk_flags_host && (walk_flags_host[0] | walk_flags_host[1]) != 0u) note_walk_overflow();   // a wide walk of an earlier frame dropped a push
         // Uploads of an earlier tick that no render has waited for yet stay pending until their event has completed: a
         // tick that uploads nothing must not make a later render on another stream forget them.
         if (tick_work_in_flight && hipEventQuery(ev_tick) == hipSuccess) tick_work_in_flight = false;
@@ -219,6 +229,8 @@ int Engine::tick(hipStream_t stream) {
                 // (instances the device moved stay stale on the host: this copy's pending list re-bakes them on the device even after a whole upload)
                 if ((rc = build_on_device(t, up, flag))) return rc;
                 attr_done = true;
+                host_tree_stale = true;   // whatever made this tick upload (a material edit, too): the live copy's tree is no longer the host's
+                t.tree_version = 0;       // ... and this copy's contract stream and refit arrays belong to no host tree any more
             } else t.device_built = false;
             const bool device_path = !build_on_device_now && device_refit_possible() && t.valid && !t.tri_full && t.tree_version == tree_version && t.tri_geo.capacity >= tri_geo.size() * sizeof(float4);
             // a copy that cannot be brought up to date in place is sent whole, from the host's arrays: instances the device moved must be in them
@@ -340,6 +352,14 @@ int Engine::tick(hipStream_t stream) {
     atlas_dirty = false;
     for (auto& kv : cameras) kv.second->frame = frame;  // CameraController::flush
     frame += 1;
+    if (walk_overflow_unreported) {   // likewise: the tick did everything, later frames walk with the deeper stack
+        walk_overflow_unreported = false;
+        const std::string msg = "a traversal of the wide BVH stream found its stack full and DROPPED a push: frames rendered so far may have missed geometry behind the dropped subtrees. "
+                                "Later frames walk with " + std::to_string(wide_stack_entries_now()) + " pending entries per ray" + (packets_overflowed ? " and primary rays with the per-lane walk instead of the packet walk" : "") +
+                                " (st_debug_walk_overflow); StTuning::allow_deep_bvh = 1 turns this status into a warning";
+        if (!tuning.allow_deep_bvh) return fail(ST_ERR_BVH_TOO_DEEP, msg);
+        fprintf(stderr, "[strolle-hip] warning: %s\n", msg.c_str());
+    }
     if (bvh_too_deep_unreported) {   // the tick did everything; the status says what the uploaded tree can cost (once per build)
         bvh_too_deep_unreported = false;
         if (!tuning.allow_deep_bvh)

@@ -210,3 +210,32 @@ def build_random_soup(engine, n_triangles: int, seed: int = 0, n_lights: int = 3
     for i in range(n_lights):
         engine.insert_light(1 + i, Light.point(rng.uniform(-1.5, 1.5, 3).tolist(), 0.1, rng.uniform(0.5, 2.0, 3).tolist(), 20.0))
     engine.update_sun(Sun(azimuth=0.0, altitude=-1.0))
+
+
+def build_sliver_bundle(engine, n_triangles: int = 20000, seed: int = 5):
+    """ADVERSARIAL for a traversal stack (tests of the wide walk's overflow report): n long slivers, each from one corner of a thin box
+    (2 x 0.04 x 0.04) to the opposite one, so that every triangle's bounding box is nearly the whole bundle. A ray along the bundle's axis meets
+    (almost) every node's every child box and hardly any triangle: the 4-wide walk has to keep three siblings pending per level —
+    27 entries at 20,000 slivers (host model: tests/test_wide_bvh.py), more than the reference's 24 (strolle-gpu/src/lib.rs:76) — while the
+    binary contract tree stays 26 internal nodes deep (within the 32 its walks can hold)."""
+    rng = np.random.default_rng(seed)
+    engine.set_blue_noise(load_blue_noise())
+    engine.insert_material(1, Material(base_color=(0.8, 0.8, 0.8, 1.0)))
+    n = n_triangles
+    j = lambda s: rng.uniform(-s, s, n)
+    pos = np.zeros((n, 3, 3), np.float32)
+    pos[:, 0] = np.stack([-1.0 + j(0.3), -0.02 + j(0.004), -0.02 + j(0.004)], 1)
+    pos[:, 1] = np.stack([1.0 + j(0.3), 0.02 + j(0.004), 0.02 + j(0.004)], 1)
+    pos[:, 2] = pos[:, 0] + np.stack([j(0.05), j(0.0005), j(0.0005)], 1)
+    nrm = np.zeros_like(pos); nrm[..., 2] = 1
+    engine.insert_mesh(1, Mesh(pos, nrm))
+    engine.insert_instance(1, Instance(1, 1, np.eye(4, dtype=np.float32)[:3]))
+    engine.insert_light(1, Light.point((-3.0, 0.5, 0.5), 0.1, (5.0, 5.0, 5.0), 20.0))
+    engine.update_sun(Sun(azimuth=0.0, altitude=-1.0))
+
+
+def sliver_bundle_camera(size, mode=CameraMode.REFERENCE, depth=0) -> Camera:
+    """looks down the bundle's axis from outside it (narrow view: the bundle fills the frame's centre)"""
+    w, h = size
+    return Camera(mode=mode, denoise=True, depth=depth, size=(w, h), transform=look_at_transform((-3.0, 0.012, -0.012), (0.0, 0.012, -0.012)),
+                  projection=perspective_infinite_reverse_rh(math.pi / 60.0, w / h, 0.1))

@@ -705,7 +705,10 @@ def test_device_build_mode_without_a_device_builds_on_the_host():
         e.insert_light(77, Light.point((0.0, 1.0, 0.0), 0.1, (1.0, 1.0, 1.0), 5.0)); e.tick()
     assert_bits_equal(a.read_scene(0), b.read_scene(0), "BVH stream, ST_BVH_BUILD_DEVICE on a host-only engine")
     assert a.bvh_refits() == b.bvh_refits() and b.device_builds() == 0
+    b.set_bvh_refresh(4)   # ST_BVH_AUTO, the default: on a host-only engine what ST_BVH_REBUILD does
+    b.insert_light(78, Light.point((0.0, 1.2, 0.0), 0.1, (1.0, 1.0, 1.0), 5.0)); b.tick()
+    assert b.device_builds() == 0
     with pytest.raises(StrolleError):
-        b.set_bvh_refresh(4)
+        b.set_bvh_refresh(5)
     for e in (a, b):
         e.close()

@@ -140,17 +140,31 @@ _SCENES = {"cornell": (scenes.build_cornell, scenes.cornell_camera), "dungeon": 
 _runs = {}
 
 
-def _run(scene, size, plan, moving=False, mode=CameraMode.IMAGE):
+def _spawned_instance_xform(frame):
+    """the fourth torus of the `spawned` runs: half the demo's scale, in front of the camera, turning and drifting a little every frame"""
+    import math
+    a = 1.0 + 0.07 * frame
+    c, s_ = 0.25 * math.cos(a), 0.25 * math.sin(a)
+    return np.array([[c, -s_, 0.0, -5.75 + 0.01 * frame], [s_, c, 0.0, 0.45], [0.0, 0.0, 0.25, -19.0]], np.float32)
+
+
+def _run(scene, size, plan, moving=False, mode=CameraMode.IMAGE, tree="host"):
     """One oracle run of max(plan) frames; frame f (the ENGINE's frame number, which starts at 1 and decides the GI schedule:
     f % 6 < 4 tracing — even f samples, odd f resamples spatially —, else validation) is checked as plan[f] says ("launches" /
     "whole" / "whole_keep"); other frames only advance the oracle. Returns {"launches": [...], "whole": [...]} of report rows; cached per (scene, size)."""
-    key = (scene, size, moving, int(mode))
+    key = (scene, size, moving, int(mode), tree)
     if key in _runs:
         return _runs[key]
     torch = _torch()
     build, camera_fn = _SCENES[scene]
     prod, orac = Engine(device=0, exact=False), OracleEngine()
     assert not prod.exact
+    # tree: "host" — a static scene, the host's binned-SAH tree (the reference's, and under the default ST_BVH_AUTO the first tree of every engine);
+    #       "device" — st_set_bvh_refresh(ST_BVH_BUILD_DEVICE) before the scene exists: the FIRST tree is k_lbvh.hip's already;
+    #       "spawned" — the default mode: host tree first, then an instance appears at frame 2 (a device BUILD) and moves at every later
+    #                   frame (device REFITS of that tree, a rebuild after 15) — the oracle rebuilds its SAH tree every time.
+    if tree == "device":
+        prod.set_bvh_refresh(3)
     for e in (prod, orac):
         build(e); e.set_seed(0)
     desc = camera_fn(size, mode)
@@ -183,6 +197,10 @@ def _run(scene, size, plan, moving=False, mode=CameraMode.IMAGE):
             desc = scenes.camera_for(size, (3.2 * math.sin(0.1 * t), 1.0, 3.2 * math.cos(0.1 * t)), (0.0, 1.0, 0.0), CameraMode.IMAGE)
             for e in (prod, orac):
                 e.insert_light(1, Light.point((math.sin(t) / 2.0, 1.5, math.cos(t) / 2.0), 0.15, (50.0 / (4.0 * math.pi),) * 3, 20.0))
+        if tree == "spawned" and frame >= 2:
+            from strolle_amd import Instance
+            for e in (prod, orac):
+                e.insert_instance(5900, Instance(5000, 5001, _spawned_instance_xform(frame)))
         for e, c in ((prod, cp), (orac, co)):
             e.update_camera(c, desc)
         prod.tick(); orac.tick()
@@ -239,9 +257,11 @@ def _run(scene, size, plan, moving=False, mode=CameraMode.IMAGE):
             lit = want[Buffer.PRIM_SURFACE_MAP_A if frame % 2 == 0 else Buffer.PRIM_SURFACE_MAP_B].reshape(-1, 4)[:, 2] != 0
             report.setdefault("state", []).append({"frame": frame, "gi_m_median": float(np.median(m[lit])) if lit.any() else None,
                                                   "history_median": float(np.median(want[Buffer.DI_DIFF_MOMENTS_A if frame % 2 == 0 else Buffer.DI_DIFF_MOMENTS_B].reshape(-1, 4)[:, 0][lit])) if lit.any() else None})
+    report["tree"] = {"device_builds": prod.device_builds(), "device_tree_refits": prod.device_tree_refits(), "walk_overflow": list(prod.walk_overflow())}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"fast_steady_{scene}{'_moving' if moving else ''}{'' if mode == CameraMode.IMAGE else '_' + mode.name.lower()}_{size[0]}x{size[1]}.json"), "w") as f:
-        json.dump({"scene": scene, "size": size, "plan": {str(k): v for k, v in plan.items()}, "rtol": RTOL, "atol": ATOL,
+    suffix = {"host": "", "device": "_devtree", "spawned": "_spawned"}[tree]
+    with open(os.path.join(ROOT, "gpurun_out", f"fast_steady_{scene}{'_moving' if moving else ''}{'' if mode == CameraMode.IMAGE else '_' + mode.name.lower()}_{size[0]}x{size[1]}{suffix}.json"), "w") as f:
+        json.dump({"scene": scene, "size": size, "tree": tree, "tree_counters": report["tree"], "plan": {str(k): v for k, v in plan.items()}, "rtol": RTOL, "atol": ATOL,
                    "launch_rows_with_outliers": sorted(report["launches"], key=lambda r: -r["bad_fraction"])[:60],
                    "whole_frame_rows": report["whole"], "state": report.get("state", [])}, f, indent=1)
     prod.close(); orac.close()
@@ -304,6 +324,44 @@ def test_fast_whole_frame_single_step_config3_as_written():
     rep = _run("dungeon134k", (1920, 1080), PLAN_CONFIG3, mode=CameraMode.GI_DIFFUSE)
     assert {r["frame"] for r in rep["whole"]} == set(PLAN_CONFIG3)
     _check_whole_rows(rep["whole"], "dungeon134k 1080p gi_diffuse")
+
+
+def _no_walk_overflowed(rep, what):
+    assert rep["tree"]["walk_overflow"][0] == 0, f"{what}: a wide walk found its stack full (st_debug_walk_overflow: {rep['tree']['walk_overflow']})"
+
+
+def test_fast_whole_frame_single_step_dungeon_1080p_device_built_tree():
+    """the tree k_lbvh.hip builds is held against the ORACLE, under the same profiles/gates.json limits as the host's tree — whole
+    unmasked frames of every GI schedule from the oracle's own state, ReSTIR + SVGF, not only primary hits against the product's own host tree."""
+    rep = _run("dungeon", (1920, 1080), PLAN_DUNGEON_1080P, tree="device")
+    assert rep["tree"]["device_builds"] >= 1, "the first tree was not built on the device"
+    _check_whole_rows(rep["whole"], "dungeon 1080p, device-built tree")
+    _no_walk_overflowed(rep, "dungeon 1080p, device-built tree")
+
+
+def test_fast_whole_frame_single_step_config3_device_built_tree():
+    """... and BASELINE config 3 as written (208 k triangles, 32-bit links, GiDiffuse) on the device-built tree."""
+    rep = _run("dungeon134k", (1920, 1080), PLAN_CONFIG3, mode=CameraMode.GI_DIFFUSE, tree="device")
+    assert rep["tree"]["device_builds"] >= 1
+    _check_whole_rows(rep["whole"], "dungeon134k 1080p gi_diffuse, device-built tree")
+    _no_walk_overflowed(rep, "config 3, device-built tree")
+
+
+def test_fast_whole_frames_after_a_spawn_and_refits_in_the_default_mode():
+    """The DEFAULT refresh mode (ST_BVH_AUTO): the host builds the first tree, an instance that appears at frame 2 is answered by a device build, its
+    motion at every later frame by refits of that tree (15 in a row, then a rebuild) — while the oracle rebuilds the reference's SAH tree every frame.
+    Whole unmasked frames 13 / 14 / 15 / 17 from the oracle's state, same gates."""
+    rep = _run("dungeon", (1920, 1080), PLAN_DUNGEON_1080P, tree="spawned")
+    assert rep["tree"]["device_builds"] >= 1 and rep["tree"]["device_tree_refits"] >= 10, rep["tree"]
+    _check_whole_rows(rep["whole"], "dungeon 1080p, spawn + refits")
+    _no_walk_overflowed(rep, "dungeon 1080p, spawn + refits")
+
+
+def test_no_wide_walk_overflows_on_the_baseline_configs():
+    """configs 2 / 3 / 5 never set the wide walks' overflow word (st_debug_walk_overflow) — read from the runs above."""
+    for args, kw in ((("cornell", (1920, 1080), PLAN_1080P), {}), (("dungeon", (1920, 1080), PLAN_DUNGEON_1080P), {}),
+                     (("dungeon134k", (1920, 1080), PLAN_CONFIG3), {"mode": CameraMode.GI_DIFFUSE}), (("dungeon", (3840, 2160), PLAN_DUNGEON_4K), {})):
+        _no_walk_overflowed(_run(*args, **kw), f"{args[0]} {args[1]}")
 
 
 def test_fast_whole_frame_single_step_dungeon_4k():

@@ -151,7 +151,8 @@ def test_heatmap_integers_bit_exact_in_the_fast_build(scene, size):
     prod.close(); orac.close()
 
 
-@pytest.mark.parametrize("scene,size,depth", [("cornell", (640, 360), 1), ("dungeon", (480, 270), 1), ("soup", (320, 200), 2)])
+# (the last row: BASELINE config 4's size and sample count — Cornell 3840x2160, 4 spp —, the size bench.py's strong_config4 / --scene cornell --mode reference TIMES)
+@pytest.mark.parametrize("scene,size,depth", [("cornell", (640, 360), 1), ("dungeon", (480, 270), 1), ("soup", (320, 200), 2), ("cornell", (3840, 2160), 1)])
 def test_reference_mode_psnr(scene, size, depth):
     """north_star: 'Output matches the reference wgpu path's reference path-tracer mode within a stated per-channel float
     tolerance (same RNG seed) ... image PSNR >= 40 dB'. Stated tolerance: per channel |got - want| <= 1e-3 + 1e-3 |want| on
@@ -406,6 +407,58 @@ def test_the_wide_walk_drops_no_push():
 
 
 @pytest.mark.gpu
+def test_a_wide_walk_that_overflows_its_stack_says_so_and_rearms():
+    """VERDICT r5 item 1b / ADVICE r5: the wide walk keeps 24 pending entries (StTuning::wide_stack_entries) whatever the tree; a push that finds the
+    stack full used to be dropped with ST_OK. Now the walk sets a sticky word (st_device.h wide_walk_overflowed), the next st_tick re-arms every
+    later launch with a deeper stack (24 -> 32 -> 48 -> 56) and returns ST_ERR_BVH_TOO_DEEP once (st_debug_walk_overflow reads the state).
+    (a) the sliver bundle (scenes.build_sliver_bundle; 27 pending entries by the host model, tests/test_wide_bvh.py) with the default 24;
+    (b) the demo dungeon with an 8-entry stack forced through StTuning. After the re-arm the hits are the exact build's contract walk's."""
+    from strolle_amd.api import ST_ERR_BVH_TOO_DEEP
+    torch = _torch()
+    stream = torch.cuda.current_stream().cuda_stream
+    for what, build, camera, size, entries0, allow in (("sliver bundle", scenes.build_sliver_bundle, scenes.sliver_bundle_camera, (96, 96), 0, False),
+                                                      ("dungeon, 8 entries", scenes.build_dungeon, lambda s: scenes.dungeon_camera(s, CameraMode.REFERENCE, depth=0), (192, 112), 8, False),
+                                                      ("dungeon, 8 entries, allow_deep_bvh", scenes.build_dungeon, lambda s: scenes.dungeon_camera(s, CameraMode.REFERENCE, depth=0), (192, 112), 8, True)):
+        out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
+        e = Engine(device=0, exact=False)
+        e.set_tuning(wide_stack_entries=entries0, allow_deep_bvh=1 if allow else 0)
+        build(e); e.set_seed(1)
+        desc = camera(size)
+        cam = e.create_camera(desc)
+        e.update_camera(cam, desc); e.tick()
+        assert e.walk_overflow() == (0, entries0 or 24, 0), what
+        seen, history = 0, []
+        for _ in range(5):
+            e.render_camera(cam, out.data_ptr(), stream)
+            n, entries, packets_off = e.walk_overflow()
+            history.append((n, entries))
+            if n == seen:
+                break                                  # this frame dropped nothing: the stack is deep enough now
+            seen = n
+            e.update_camera(cam, desc)
+            if allow:
+                e.tick()                               # a warning on stderr instead of the status
+            else:
+                with pytest.raises(StrolleError) as err:
+                    e.tick()
+                assert f"status {ST_ERR_BVH_TOO_DEEP}" in str(err.value) and "DROPPED a push" in str(err.value), str(err.value)
+            e.update_camera(cam, desc); e.tick()       # reported once: the next tick is clean
+        assert seen >= 1, f"{what}: no overflow was reported ({history})"
+        assert history[-1][1] in (32, 48, 56) and history[-1][0] == seen, f"{what}: {history}"
+        hits = e.read_buffer(cam, Buffer.REF_HITS).reshape(size[1], size[0], -1).copy()
+        e.close()
+        x = Engine(device=0, exact=True)
+        build(x); x.set_seed(1)
+        cx = x.create_camera(desc)
+        x.update_camera(cx, desc); x.tick(); x.render_camera(cx, out.data_ptr(), stream); torch.cuda.synchronize()
+        want = x.read_buffer(cx, Buffer.REF_HITS).reshape(size[1], size[0], -1)
+        x.close()
+        assert np.isfinite(want[..., 0]).sum() > 200, f"{what}: the scene is not in view"
+        bad = lanes_outside_tolerance(hits, want, rtol=1e-4, atol=1e-5).reshape(want.shape).any(-1)
+        assert bad.mean() <= 4e-3, f"{what}: {bad.mean():.2e} of the primary hits differ from the contract walk after the re-arm ({history})"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("subdivide", [0, 2])
 def test_a_tree_built_on_the_device_finds_the_same_hits(subdivide):
     """ST_BVH_BUILD_DEVICE (k_lbvh.hip): after a scene change the fast build's tree is built on the device — Morton sort, Karras'
@@ -416,6 +469,7 @@ def test_a_tree_built_on_the_device_finds_the_same_hits(subdivide):
     torch = _torch()
     size = (192, 112)
     host, dev = Engine(device=0, exact=False), Engine(device=0, exact=False)
+    host.set_bvh_refresh(0)   # (the default, ST_BVH_AUTO, would answer the spawn below on the device too)
     dev.set_bvh_refresh(3)
     rng = np.random.default_rng(2)
     pos = (rng.uniform(-0.3, 0.3, (200, 1, 3)) + rng.uniform(-0.05, 0.05, (200, 3, 3))).astype(np.float32)

@@ -83,8 +83,9 @@ def _f16_out(lo, hi):
     return lo16.astype(np.float64), hi16.astype(np.float64)
 
 
-def _walk(S, SU, topo, leaf_entry, o, d):
-    """closest hit over the wide topology with conservative f16 boxes, nearest child first; returns (t, triangle) or (None, None)"""
+def _walk(S, SU, topo, leaf_entry, o, d, deepest=None):
+    """closest hit over the wide topology with conservative f16 boxes, nearest child first; returns (t, triangle) or (None, None);
+    deepest: a one-element list that receives the most entries the stack held"""
     inv = 1.0 / d
     best, tri = F32MAX, None
     stack, cur = [], 0
@@ -105,6 +106,8 @@ def _walk(S, SU, topo, leaf_entry, o, d):
             hits.sort()
             if hits:
                 stack += [h[1] for h in reversed(hits[1:])]
+                if deepest is not None:
+                    deepest[0] = max(deepest[0], len(stack))
                 cur = hits[0][1]
                 continue
         else:
@@ -189,3 +192,23 @@ def test_no_ray_of_config_3s_scene_comes_near_the_24_entry_stack():
     for mode in p24:
         for a, b in zip(p24[mode], p64[mode]):
             assert_bits_equal(a, b, f"{mode}: 24-entry stack vs unbounded")
+
+
+def test_the_sliver_bundle_needs_more_than_24_pending_entries():
+    """scenes.build_sliver_bundle is what the GPU test of the wide walk's overflow report renders (test_gpu_fast_tolerance.py): here the host model
+    shows that it IS adversarial — a ray down the bundle's axis keeps more than the reference's 24 entries (strolle-gpu/src/lib.rs:76) pending in the
+    4-wide walk — while the binary contract tree stays within what its own walks hold (at most 32: no ST_ERR_BVH_TOO_DEEP from the tree itself)."""
+    e = Engine(device=-1)
+    scenes.build_sliver_bundle(e)
+    e.tick()
+    depth, stack = e.bvh_depth()
+    assert 24 <= depth <= 32 and stack == depth, (depth, stack)
+    S = e.read_scene(4).reshape(-1, 4, 4)
+    topo = e.read_scene(14).view(np.uint32)
+    leaf_entry = e.read_scene(15).view(np.uint32)
+    e.close()
+    assert (int(topo[0]) >> 8) > 24, "the topology's own worst case fits the stack"
+    deepest = [0]
+    d = np.array([1.0, 1e-6, 1e-6]); d /= np.linalg.norm(d)
+    _walk(S, S.view(np.uint32), topo[1:].reshape(-1, 8), leaf_entry, np.array([-3.0, 0.012, -0.012]), d, deepest)
+    assert deepest[0] > 24, f"the axis ray keeps only {deepest[0]} entries pending"
