@@ -315,7 +315,8 @@ class _Binding:
         self.set_bvh_refresh = fn("set_bvh_refresh", [vp, i32]); self.debug_bvh_refits = fn("debug_bvh_refits", [vp, P(u64), P(u64)])
         if has_device:
             self.debug_bvh_depth = fn("debug_bvh_depth", [vp, P(u32), P(u32)])
-            self.debug_walk_overflow = fn("debug_walk_overflow", [vp, P(u64), P(u32), P(u32)])
+            if hasattr(lib, prefix + "debug_walk_overflow"):   # (round 6; a round-5 library loaded for a same-box A/B has none)
+                self.debug_walk_overflow = fn("debug_walk_overflow", [vp, P(u64), P(u32), P(u32)])
             self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
             self.debug_device_bakes = fn("debug_device_bakes", [vp, P(u64), P(u64)])
             self.debug_device_builds = fn("debug_device_builds", [vp, P(u64)])
