@@ -107,6 +107,8 @@ typedef struct StCamera {
 int st_engine_create(int device_ordinal, StEngine** out);
 void st_engine_destroy(StEngine* e);
 const char* st_last_error(void);
+/* The commit libstrolle_hip.so was built from ("<hash>" or "<hash>+dirty"; "unknown" for a build outside a git tree): a property of the binary. */
+const char* st_build_commit(void);
 
 /* ---- scene: insert_xxx / remove_xxx (lib.rs:161-246) */
 int st_mesh_insert(StEngine* e, StHandle id, const StMeshTriangle* triangles, size_t count);   /* lib.rs:161 */

@@ -139,6 +139,7 @@ extern "C" {
     pub fn st_engine_create(device_ordinal: i32, out: *mut *mut StEngine) -> i32; // Engine::new
     pub fn st_engine_destroy(e: *mut StEngine); // Drop
     pub fn st_last_error() -> *const c_char;
+    pub fn st_build_commit() -> *const c_char;
     pub fn st_mesh_insert(e: *mut StEngine, id: u64, triangles: *const StMeshTriangle, count: usize) -> i32; // insert_mesh
     pub fn st_mesh_remove(e: *mut StEngine, id: u64) -> i32; // remove_mesh
     pub fn st_material_insert(e: *mut StEngine, id: u64, material: *const StMaterial) -> i32; // insert_material

@@ -589,6 +589,15 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     return _lib_cache[path]
 
 
+def library_build_commit(path: str = LIB_PATH) -> Optional[str]:
+    """st_build_commit(): the commit compiled into the library that is loaded (None: a library older than round 6)."""
+    lib = load_library(path)
+    if not hasattr(lib, "st_build_commit"):
+        return None
+    lib.st_build_commit.restype = C.c_char_p
+    return lib.st_build_commit().decode(errors="replace")
+
+
 class Engine(EngineBase):
     """MI355X engine. device >= 0: HIP ordinal; device = -1: host-only (scene + BVH logic, no rendering)."""
 

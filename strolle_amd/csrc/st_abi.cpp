@@ -9,6 +9,14 @@ static Engine* E(StEngine* e) { return reinterpret_cast<Engine*>(e); }
 extern "C" {
 
 const char* st_last_error(void) { return g_last_error.c_str(); }
+// the commit this library was built from (csrc/Makefile writes st_build_commit.inc; "+dirty": the kernel / host sources differed from that commit)
+#if __has_include("st_build_commit.inc")
+#include "st_build_commit.inc"
+#endif
+#ifndef ST_BUILD_COMMIT
+#define ST_BUILD_COMMIT "unknown"
+#endif
+const char* st_build_commit(void) { return ST_BUILD_COMMIT; }
 // st_gltf.cpp reports through the same thread-local message
 extern "C" int st_internal_fail(int status, const char* message) { return fail(status, message ? message : ""); }
 

@@ -20,9 +20,14 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "fast_steady_*.jso
     filtered = [r for r in rows if "psnr" in r]
     discrete = [r for r in rows if "psnr" not in r]
     rep = {}
-    if d.get("launch_rows_with_outliers") is not None:
-        worst = max([r["bad_fraction"] for r in d["launch_rows_with_outliers"]] + [0.0])
+    # the launch-by-launch loop runs only on frames the plan marks "launches": a report whose plan has none did not run it ("not run", not "0.0")
+    if "launches" in (d.get("plan") or {}).values():
+        worst = max([r["bad_fraction"] for r in d.get("launch_rows_with_outliers") or []] + [0.0])
         rep["BAD_FRACTION_LAUNCH"] = {"worst": worst, "limit": gates["BAD_FRACTION_LAUNCH"], "used": round(worst / gates["BAD_FRACTION_LAUNCH"], 3)}
+    else:
+        rep["BAD_FRACTION_LAUNCH"] = {"worst": "not run", "limit": gates["BAD_FRACTION_LAUNCH"], "used": "not run"}
+    if d.get("tree_counters"):
+        rep["tree"] = {"tree": d.get("tree"), **d["tree_counters"]}
     if discrete:
         w = max(discrete, key=lambda r: r["bad_fraction"])
         rep["BAD_FRACTION_FRAME_DISCRETE"] = {"worst": w["bad_fraction"], "plane": w["plane"], "frame": w["frame"], "limit": gates["BAD_FRACTION_FRAME_DISCRETE"],

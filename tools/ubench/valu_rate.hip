@@ -119,6 +119,25 @@ __global__ __launch_bounds__(256) void k_cmp_then_cnd_s(float* out, float seed) 
     }
     if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f) out[threadIdx.x] = a0;
 }
+// packed fp32 (VOP3P on 64-bit register pairs): two multiply-adds per lane and instruction — does it issue at the full rate? (if it
+// does, Moeller-Trumbore's cross / dot pairs are candidates)
+typedef float float2v __attribute__((ext_vector_type(2)));
+#define KERNEL_PK(name, ASM)                                                                                                \
+    __global__ __launch_bounds__(256) void name(float* out, float seed) {                                                  \
+        float2v a0 = {seed + threadIdx.x, seed}, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f, a4 = a0 + 4.0f, a5 = a0 + 5.0f, a6 = a0 + 6.0f, a7 = a0 + 7.0f; \
+        float2v b = {seed * 0.5f, seed * 0.75f}, c = {seed * 0.25f, seed * 0.125f};                                        \
+        for (int i = 0; i < kIters; i++) {                                                                                 \
+            asm volatile(ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%4) ASM(%5) ASM(%6) ASM(%7) ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%4) ASM(%5) ASM(%6) ASM(%7) \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));                 \
+        }                                                                                                                  \
+        const float2v t = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                                           \
+        if (t.x + t.y == 12345.678f) out[threadIdx.x] = a0.x;                                                              \
+    }
+#define A_PKFMA_F32(r) "v_pk_fma_f32 " #r ", " #r ", %8, %9\n"
+#define A_PKMUL_F32(r) "v_pk_mul_f32 " #r ", " #r ", %8\n"
+#define A_PKADD_F32(r) "v_pk_add_f32 " #r ", " #r ", %8\n"
+KERNEL_PK(k_pkfma_f32, A_PKFMA_F32) KERNEL_PK(k_pkmul_f32, A_PKMUL_F32) KERNEL_PK(k_pkadd_f32, A_PKADD_F32)
+
 int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
@@ -131,6 +150,7 @@ int main() {
                                {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo},
                                {"v_cndmask_b32 (sgpr pair)", k_cnds}, {"v_cndmask_b32 (dst not a source)", k_cndother}, {"v_cmp + v_cndmask pair (per 2)", k_cmpcnd}, {"v_max3_f32", k_max3}, {"v_add_f32", k_add}, {"v_sub_f32", k_sub},
                                {"v_and_b32", k_and}, {"v_or_b32", k_or}, {"v_xor_b32", k_xor}, {"v_lshl_add_u32", k_lshladd}, {"v_add3_u32", k_add3}, {"v_mad_u32_u24", k_mad24}, {"v_bfe_u32", k_bfe}, {"v_fmac_f32", k_fmac}, {"v_min_f32", k_min},
+                               {"v_pk_fma_f32 (2 fp32 lanes per instruction)", k_pkfma_f32}, {"v_pk_mul_f32", k_pkmul_f32}, {"v_pk_add_f32", k_pkadd_f32},
                                {"1 v_cmp -> vcc, 15 v_cndmask reading vcc", k_cmp_then_cnd}, {"1 v_cmp -> s[10:11], 15 v_cndmask reading it", k_cmp_then_cnd_s}, {"1 v_cmp -> vcc, 15 v_cndmask_e64 reading vcc", k_cmp_then_cnd_e64}, {"1 v_cmp -> vcc, s_nop 4, 15 v_cndmask reading vcc", k_cmp_then_cnd_nop}};
     printf("%s: %d CUs, clock %0.0f MHz (reported); 8 waves per SIMD, %d instructions per wave\n", p.gcnArchName, cus, mhz, kIters * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
