@@ -415,11 +415,11 @@ class Job:
         self.outs = []; self.full = None
 
 
-def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scene, mode_name, size, key):
+def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scene, mode_name, size, key, steps=None, profile=False):
     """A BASELINE.json multi-GPU config as written — ONE frame of `size` split into `world` tiles (st_dist_partition; + apron in Image mode),
     tiles gathered to rank 0 every frame — timed like the main region (barrier + synchronize on both sides, max over ranks)."""
     job = Job(torch, dist, args, scene, mode_name, size, world, rank, local_rank, debug_shared)
-    steps = max(2, min(args.steps, 30))
+    steps = max(2, min(args.steps, 30)) if steps is None else steps   # (as the line's main region: EXACTLY the K steps asked for)
     job.run(min(args.preroll, 48))
     balance_log = job.balance(args.balance_rounds, 6) if (args.balance_rounds and job.needs_apron and world > 1) else []
     job.run(args.warmup)
@@ -439,7 +439,35 @@ def strong_config(torch, dist, args, world, rank, local_rank, debug_shared, scen
            "balance": {"rounds": balance_log, "final_grid": None if job.grid is None else job.grid.describe(),
                        "what": "cost-weighted tiles (st_dist_grid_rebalance): each round every rank times 6 frames, the ranks exchange one float each, edges move by at most the apron"} if balance_log else None,
            "n1_ms_reference": n1_reference(key), "n1_ms_reference_source": "profiles/n1_reference.json (builder-run single-GPU figure, not measured by this process)",
+           "rays_per_frame": round(rays_total / steps), "width": size[0], "height": size[1],
            "frame_finite": finite}
+    if profile and not args.no_profile:
+        # this rank's launches of the same K steps again with per-kernel events (as the N = 1 line's regions 2 / 2b / 2c): the `roofline` object of a
+        # line whose main region is this config is then this config's own dominant kernel (on rank 0's tile), not the headline scene's
+        eng = job.engine
+        eng.profile_enable(1); eng.profile_read(reset=True)
+        el_p, _ = job.timed_region(steps)
+        prof = eng.profile_read(reset=True)
+        eng.profile_enable(1 | 4); eng.profile_read(reset=True); job.timed_region(steps)
+        grouped = [q for q in eng.profile_read(reset=True) if q["name"].startswith("a-trous chain")]
+        eng.profile_enable(1 | 8); eng.profile_read(reset=True); job.timed_region(steps)
+        kernel_events = {q["name"]: q for q in eng.profile_read(reset=True)}
+        eng.profile_enable(0)
+        for q in prof:
+            q["traversal_bytes"] = 0.0   # (the traversal-byte region is the headline line's; B bytes only here)
+        lit = None
+        try:
+            import numpy as np
+            from strolle_amd import Buffer
+            w = job.window
+            d0 = eng.read_buffer(job.cam, Buffer.PRIM_GBUFFER_D0_A).reshape(size[1], size[0], 4)[w[1]:w[3], w[0]:w[2], 0]
+            lit = float(np.count_nonzero(d0) / d0.size)
+        except Exception:
+            lit = None
+        out["_profile"] = {"prof": prof, "grouped": grouped, "kernel_events": kernel_events, "profiled_ms": el_p / steps * 1e3, "lit_fraction": lit}
+    n1 = out["n1_ms_reference"]
+    out["speedup_vs_n1"] = round(n1 / out["ms_per_step"], 3) if (isinstance(n1, (int, float)) and n1 > 0 and tuple(size) == (3840, 2160)) else None
+    out["speedup_vs_n1_note"] = "n1_ms_reference / ms_per_step — the N = 1 figure is profiles/n1_reference.json's (one MI355X, builder-run), not this run's; null when the frame is not the config's 3840x2160" 
     job.close()
     return out
 
@@ -510,7 +538,10 @@ def main():
     ap.add_argument("--scene", choices=["cornell", "dungeon", "dungeon134k"], default="cornell",
                     help="cornell = the headline workload; dungeon = BASELINE.json config 3's scene (level.glb + the demo's three tori); dungeon134k = the same surface subdivided twice (synthetic ~100k-triangle stand-in)")
     ap.add_argument("--mode", choices=["image", "gi_diffuse", "reference", "heatmap"], default="image")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak = the frame grows with N (per-GPU work fixed), strong = the frame stays --width x --height")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: weak = the frame grows with N (per-GPU work fixed), strong = the frame stays --width x --height. Left out with the default workload "
+                         "(the driver's command), the N > 1 line IS BASELINE.json's config 5 — dungeon 3840x2160 Image, ONE frame in N cost-balanced tiles, strong — "
+                         "and the weak region rides along under multi_gpu.weak_scaling_extra")
     ap.add_argument("--exact", action="store_true", help="run the bit-exact build of the kernels (ST_ARITH_EXACT) instead of the default fast build")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last (gathered) frame as .npy — tests compare it with a single-GPU render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -557,6 +588,11 @@ def main():
         out["build_stamp"] = build_stamp()
         print(json.dumps(out))
         return
+    # The driver's N > 1 command (no --scaling, the default workload): the line's value / ms_per_step / config.workload are BASELINE.json config 5 as
+    # written — the north_star's scaling curve (strong: the frame is fixed, N tiles) — and the weak region below is demoted to an extra. N = 1 stays the headline.
+    config5_main = world > 1 and args.scaling is None and (args.scene, args.mode, args.width, args.height) == ("cornell", "image", 1920, 1080)
+    if args.scaling is None:
+        args.scaling = "weak"
     base = (args.width, args.height)
     width, height = weak_scaling_frame(base, world) if args.scaling == "weak" else base
     rccl_ranks, backend = None, None
@@ -727,13 +763,14 @@ def main():
                              "host_frame_nonzero": bool(host8[(args.steps - 1) & 1].any()), "host_frame_equals_device_frame": arrived}
         del dev8, host8
     strong = {}
-    if not args.no_extras and world > 1:
+    if world > 1 and (config5_main or not args.no_extras):
         job.close()
         ex = tuple(args.extras_size)
-        strong["strong_config5"] = strong_config(torch, dist, args, world, rank, local_rank, debug_shared, "dungeon", "image", ex, "config5_dungeon_3840x2160_image_ms")
-        if world == 4:
+        strong["strong_config5"] = strong_config(torch, dist, args, world, rank, local_rank, debug_shared, "dungeon", "image", ex, "config5_dungeon_3840x2160_image_ms",
+                                                 steps=args.steps if config5_main else None, profile=config5_main)
+        if world == 4 and not args.no_extras:
             strong["strong_config4"] = strong_config(torch, dist, args, world, rank, local_rank, debug_shared, "cornell", "reference", ex, "config4_cornell_3840x2160_reference_ms")
-    copy_own, copy_torch = measure_copy_ceiling(torch, dev, None if (not args.no_extras and world > 1) else engine) if (rank == 0 and not debug_shared) else (None, None)
+    copy_own, copy_torch = measure_copy_ceiling(torch, dev, None if strong else engine) if (rank == 0 and not debug_shared) else (None, None)
     copy_ceiling = max([c for c in (copy_own, copy_torch) if c], default=None)
     key = workload_key(args.scene, width, height, args.mode)
 
@@ -767,6 +804,32 @@ def main():
                                    "hardware_scaling_curve": "none measured by the builder (gpurun boxes have one GPU); whatever the driver's N = 1, 2, 4, 8 runs print is the first",
                                    **strong}
         result.update(extras)
+        if config5_main:
+            # the N > 1 line of the driver's command: BASELINE.json config 5 as written is the line; what the main region above measured (weak scaling of
+            # the headline workload: N x 1080p Cornell) moves under multi_gpu.weak_scaling_extra
+            c5 = strong["strong_config5"]
+            mg = result["multi_gpu"]
+            mg["weak_scaling_extra"] = {"what": "the headline workload grown to N x 1920x1080 pixels, one tile per rank + apron, gathered to rank 0 (NOT a BASELINE config for N > 1)",
+                                        "value_Mray_per_s": result["value"], "ms_per_step": result["ms_per_step"], "workload": result["config"]["workload"],
+                                        "width": width, "height": height, "rays_per_frame": result["config"]["rays_per_frame"], "per_rank_ms_per_step": mg.pop("per_rank_ms_per_step"),
+                                        "gather_ms_on_comm_stream_rank0": mg.pop("gather_ms_on_comm_stream_rank0"), "gathered_bytes_per_frame": mg.pop("gathered_bytes_per_frame"),
+                                        "tile": mg.pop("tile"), "apron_overhead_frac": mg.pop("apron_overhead_frac"), "partition": result["config"]["partition"]}
+            mg["main_region"] = "strong_config5: BASELINE.json config 5 as written (strong scaling) — value / ms_per_step / config of this line are its figures"
+            result["value"], result["ms_per_step"], result["scaling"] = c5["Mray_per_s"], c5["ms_per_step"], "strong"
+            result["speedup_vs_n1"] = c5["speedup_vs_n1"]
+            result["speedup_vs_n1_note"] = c5["speedup_vs_n1_note"] + "; a prediction from one GPU exists (profiles/r05_tile_balance.json: 5.98x equal split, 6.63x balanced at N = 8) — predicted from one GPU, no curve measured by the builder"
+            result["config"].update({"workload": f"BASELINE.json config 5: dungeon {c5['width']}x{c5['height']}, CameraMode::Image{{denoise:true}} (ReSTIR DI+GI + SVGF), ONE frame in {world} cost-balanced tiles "
+                                                 f"(st_dist_grid_rebalance) + apron {c5['apron_rows']}, tiles gathered to rank 0 by st_dist_gather (RCCL ncclSend / ncclRecv through the C ABI)",
+                                     "scene": scenes.DUNGEON_DESCRIPTION, "width": c5["width"], "height": c5["height"], "rays_per_frame": c5["rays_per_frame"], "frame_finite": c5["frame_finite"],
+                                     "per_gpu_rows": c5["band_rows"], "apron_rows": c5["apron_rows"],
+                                     "partition": f"{world} tiles, final grid {None if not c5.get('balance') else c5['balance']['final_grid']}, gather: {c5['gather']}"})
+            for k in ("bvh_deepest_internal_chain", "bvh_stack_entries", "dropped_pushes"):   # (those describe the headline scene's tree)
+                result["config"].pop(k, None)
+            # the per-kernel table and the roofline object below: this config's own launches on rank 0's tile (strong_config's profile regions), not the weak region's
+            pr = c5.pop("_profile", None)
+            prof, grouped, kernel_events, profiled_ms, lit_fraction = (pr["prof"], pr["grouped"], pr["kernel_events"], pr["profiled_ms"], pr["lit_fraction"]) if pr else ([], [], {}, None, None)
+            key = f"config5_dungeon_{c5['width']}x{c5['height']}_image_tile_1_of_{world}"   # (no counter summary exists for a tile: roofline.traffic is null)
+            ms = c5["ms_per_step"]
         result["build_stamp"] = build_stamp()
         if copy_ceiling is not None:
             result["hbm_copy_ceiling_GBps_measured"] = round(copy_ceiling, 1)

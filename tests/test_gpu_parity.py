@@ -632,6 +632,34 @@ def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
     assert_bits_equal(got, frame.cpu().numpy(), "gathered two-band frame vs single-process frame")
 
 
+def test_bench_n_gt_1_line_is_config_5_strong(tmp_path):
+    """with the driver's N > 1 command (no --scaling, the default workload) the ONE JSON line IS BASELINE.json's config 5 as
+    written — dungeon Image, one frame in N cost-balanced tiles, strong scaling: value / ms_per_step / config.workload / scaling / speedup_vs_n1 —
+    and the weak region (N x 1080p Cornell) rides along under multi_gpu.weak_scaling_extra. Two processes sharing cuda:0 (gloo gather), config 5
+    shrunk to 160x96 through --extras-size."""
+    import json, os, subprocess, sys
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ST_BENCH_DEBUG_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--preroll", "0", "--extras-size", "160", "96"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    mg = out["multi_gpu"]; c5 = mg["strong_config5"]
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3 and c5["steps"] == 3
+    assert out["value"] == c5["Mray_per_s"] > 0 and out["ms_per_step"] == c5["ms_per_step"] > 0
+    assert "config 5" in out["config"]["workload"] and "dungeon 160x96" in out["config"]["workload"] and (out["config"]["width"], out["config"]["height"]) == (160, 96)
+    assert out["speedup_vs_n1"] is None and "profiles/n1_reference.json" in out["speedup_vs_n1_note"]   # (not the config's 3840x2160: no N = 1 figure applies)
+    assert "cpu_baseline" not in out and "_profile" not in c5
+    weak = mg["weak_scaling_extra"]
+    assert (weak["width"], weak["height"]) == (1920, 2160) and weak["value_Mray_per_s"] > 0 and len(weak["per_rank_ms_per_step"]) == 2 and "Cornell" in weak["workload"]
+    assert mg["rccl_ranks"] == 2 and "strong_config5" in mg["main_region"]
+    # the roofline object is this config's own dominant kernel on rank 0's tile
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["traffic"] is None and out["roofline"]["achieved"] > 0
+    assert "kernels" in out and out["config"]["frame_finite"]
+
+
 def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
     """bench.py --scaling strong (BASELINE.json configs 4 and 5 as written: the frame keeps its size, ranks split it): the
     gathered Reference frame equals the single-process frame of the same size bit for bit, and the JSON carries the per-rank
