@@ -51,6 +51,15 @@ ST_D TileCoord resolve_tile(const KArgs& a, bool half_x) {
     tc.x += w.tx0; tc.y += w.ty0;
     return tc;
 }
+// ... for workgroup number `b` of the one-workgroup-per-four-tiles launch (a kernel whose workgroups take two of those: k_gi_sampling_ab_pool)
+ST_D bool resolve_gid_of_block(const KArgs& a, bool half_x, uint32_t b, U2* gid) {
+    const TileWindow w = tile_window(a, half_x);
+    TileCoord tc = tile_for_block(b, w.tx1 - w.tx0, w.ty1 - w.ty0, a.tile_map);
+    tc.x += w.tx0; tc.y += w.ty0;
+    if (!tc.valid) return false;
+    *gid = pixel_in_tile(tc);
+    return true;
+}
 // Resolves this thread's `global_invocation_id` (gid). Returns false for lanes outside the dispatch.
 ST_D bool resolve_gid(const KArgs& a, bool half_x, U2* gid) {
     const TileCoord tc = resolve_tile(a, half_x);

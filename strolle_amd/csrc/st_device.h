@@ -18,10 +18,11 @@ struct TileCoord { uint32_t x, y; bool valid; };
 // map_mode 0: XCD-banded (each XCD owns a contiguous band of tile rows); 1: hardware order (block b -> XCD b % 8,
 // consecutive blocks are horizontal neighbours); 2: XCD-banded in chunks of 4 tile rows (locality for short taps,
 // balance for spatially clustered slow paths).
-ST_D TileCoord tile_for_thread(uint32_t tiles_x, uint32_t tiles_y, uint32_t map_mode) {
+// (`b`: the workgroup's number in the launch that covers the window with one workgroup per four tiles — blockIdx.x, or a number a kernel whose
+// workgroups each take several of those derives from it)
+ST_D TileCoord tile_for_block(uint32_t b, uint32_t tiles_x, uint32_t tiles_y, uint32_t map_mode) {
     const uint32_t groups_x = (tiles_x + 3u) >> 2;              // blocks per tile row
     const uint32_t n_blocks = groups_x * tiles_y;
-    const uint32_t b = blockIdx.x;
     uint32_t lin = b;
     if (map_mode == 0u) {
         const uint32_t q = n_blocks >> 3, r = n_blocks & 7u;    // bijective XCD remap (handles n % 8 != 0)
@@ -40,9 +41,10 @@ ST_D TileCoord tile_for_thread(uint32_t tiles_x, uint32_t tiles_y, uint32_t map_
     TileCoord t;
     t.y = lin / groups_x;
     t.x = (lin - t.y * groups_x) * 4u + wave;
-    t.valid = t.x < tiles_x && t.y < tiles_y;
+    t.valid = b < n_blocks && t.x < tiles_x && t.y < tiles_y;
     return t;
 }
+ST_D TileCoord tile_for_thread(uint32_t tiles_x, uint32_t tiles_y, uint32_t map_mode) { return tile_for_block(blockIdx.x, tiles_x, tiles_y, map_mode); }
 ST_D U2 pixel_in_tile(TileCoord t) {
     const uint32_t lane = threadIdx.x & 63u;
     return u2(t.x * 8u + (lane & 7u), t.y * 8u + (lane >> 3));
@@ -800,6 +802,103 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
         if (top > stack) { top -= 64; cur = (uint32_t)*top; } else break;
     }
     return found_any;
+}
+
+// ---- LANE REFILL for incoherent closest-hit rays (round 6; north_star's "wavefront ballot / prefix-sum ray compaction"). The GI bounce
+// rays of a wave end at very different lengths (lane utilisation 0.50 in k_gi_sampling_ab): here a workgroup's rays live in an LDS pool — two rays per
+// lane, 32 B each — and the lanes work through it: a lane whose ray has ended goes idle, and once kPoolRefillAt lanes of the wave are idle they take
+// the next rays of the pool together — ONE ballot, the rank of each idle lane among the idle (v_mbcnt), ONE ds_add_rtn_u32 on the workgroup's counter
+// per refill. Results go back into the ray's own pool slot. The walk per ray is closest_hit_wide's, step for step (same keys, same order, same
+// triangle arithmetic): which LANE traces a ray changes, not what the ray finds — the exact suite does not come here, the fast build's gates hold it.
+//   slot in : [0] = (origin.xyz, -)   [1] = (dir.xyz, valid != 0)
+//   slot out: [0] = (t, u, v, inv_det)   [1] = (triangle, material, found != 0, -)
+template <class SE>
+ST_D void closest_hit_wide_pool(const KArgs& a, float4* pool, uint32_t n_slots, uint32_t* next, SE* stack, uint32_t refill_at) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const SE* const stack_end = stack + a.stack_entries * 64u;
+    bool active = false, exhausted = n_slots == 0u || a.bvh_len == 0u;
+    uint32_t slot = 0u, cur = 0u;
+    SE* top = stack;
+    Ray ray = zero_ray(); RaySlabs rs = ray_slabs(ray);
+    Candidate best; best.t = kF32Max; best.tri = 0xffffffffu; best.material = 0u; best.u = 0.0f; best.v = 0.0f; best.inv_det = 1.0f;
+    bool found_any = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u && exhausted) break;
+        if (!exhausted && n_idle >= refill_at) {
+            const uint32_t first = (uint32_t)__ffsll((long long)idle) - 1u;
+            uint32_t base = 0u;
+            if (lane == first) base = atomicAdd(next, n_idle);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+            if (!active) {
+                const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (idx < n_slots) {
+                    const float4 r0 = pool[2u * idx], r1 = pool[2u * idx + 1u];
+                    if (f2b(r1.w) != 0u) {
+                        slot = idx;
+                        ray.origin = xyz(r0); ray.dir = xyz(r1);
+                        rs = ray_slabs(ray);
+                        best.t = kF32Max; best.tri = 0xffffffffu; best.material = 0u; best.u = 0.0f; best.v = 0.0f; best.inv_det = 1.0f;
+                        found_any = false; cur = a.bvh_w_root; top = stack; active = true;
+                    }
+                }
+            }
+            exhausted = base + n_idle >= n_slots;   // uniform: the pool has handed out its last slot
+        }
+        if (active) {
+            bool pop = true;
+            const bool leaf = (cur & 1u) != 0u;
+            const float4* e = bvh_entry(a.bvh_w, wide_at(a, cur));
+            const float4 t0 = e[0], t1 = e[1], t2 = e[2];
+            float4 t3 = f4z();
+            if (!leaf) t3 = e[3];
+            asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x), "v"(t3.x));
+            if (!leaf) {
+                const float lim = best.t;
+                uint32_t k0 = wide_key<SE>(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs, lim, t3, 0, a.bvh_w_link_mask);
+                uint32_t k1 = wide_key<SE>(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs, lim, t3, 1, a.bvh_w_link_mask);
+                uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, lim, t3, 2, a.bvh_w_link_mask);
+                uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, lim, t3, 3, a.bvh_w_link_mask);
+                ST_WIDE_SORT4(k0, k1, k2, k3);
+                if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, a.bvh_w_link_mask); top += 64; } }
+                if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, a.bvh_w_link_mask); top += 64; } }
+                if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, a.bvh_w_link_mask); top += 64; } else wide_walk_overflowed(a, kWalkOverflowLane); }
+                if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, a.bvh_w_link_mask); pop = false; }
+            } else {
+                const uint32_t head = f2b(t0.w);
+                const V3 p0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);
+                const V3 pvec = cross(ray.dir, e2);
+                const float det = dot(e1, pvec);
+                if (!(fabsf(det) < kF32Eps)) {
+                    const float inv_det = __builtin_amdgcn_rcpf(det);
+                    const V3 tvec = ray.origin - p0;
+                    const float u = dot(tvec, pvec) * inv_det;
+                    const V3 qvec = cross(tvec, e1);
+                    const float v = dot(ray.dir, qvec) * inv_det;
+                    const float t = dot(e2, qvec) * inv_det;
+                    if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best.t))) {
+                        bool found = true;
+                        if (head & 2u) {
+                            const GpuMaterial m = a.materials[f2b(t1.w)];
+                            const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
+                            if (bc.w < 1.0f) found = false;
+                        }
+                        if (found) { best.t = t; best.u = u; best.v = v; best.inv_det = inv_det; best.tri = head >> 2; best.material = f2b(t1.w); found_any = true; }
+                    }
+                }
+                if (head & 1u) { cur += 2u; pop = false; }
+            }
+            if (pop) {
+                if (top > stack) { top -= 64; cur = (uint32_t)*top; }
+                else {
+                    pool[2u * slot] = make_float4(best.t, best.u, best.v, best.inv_det);
+                    pool[2u * slot + 1u] = make_float4(b2f(best.tri), b2f(best.material), b2f(found_any ? 1u : 0u), 0.0f);
+                    active = false;
+                }
+            }
+        }
+    }
 }
 
 // ---- A WAVE-WIDE PACKET over the wide stream, for coherent rays (round 5: primary visibility; StTuning::primary_packets). The 64 primary rays of
