@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_gi_sampling_ab(const KArgs
     if (!hit_some(prim_hit)) return;  // validation frames: pass a re-traces a reservoir wherever one is, pass b wants a surface too
     gi_sampling_b_cell(a, seed_b, tracing, pos, prim_hit, vres, lane_stack(a, lds), &used_, d0, d1, d2);
 }
-#if ST_FAST_DEVICE
+#if defined(ST_FAST_MATH)
 // ---- the same launch with LANE REFILL for the bounce rays (st_device.h closest_hit_wide_pool; KArgs::exp_flags bit kExpGiPool while it is
 // being measured). A workgroup takes TWO of the plain kernel's workgroups' cells — 512 cells, two per lane:
 //   phase 1  per cell: the pixel's surface, the bounce ray (gi_sampling_a_ray) -> a 32-B slot of the workgroup's LDS pool; the lane keeps (dir, pdf)
@@ -268,7 +268,9 @@ __global__ __launch_bounds__(kBlockThreads, 5) void k_gi_sampling_ab_pool(const 
         if (k == 0u) kept0 = keep; else kept1 = keep;
     }
     __syncthreads();
+#if ST_FAST_DEVICE   // (st_device.h defines the walk for the device pass of the fast build only; the host pass needs this kernel's stub)
     closest_hit_wide_pool<SE>(a, s_pool, 2u * kBlockThreads, &s_next, lane_stack(a, lds), pool_refill_at(a));
+#endif
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < 2u; k++) {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kBlockThreads, 5) void k_gi_sampling_ab_pool(const 
 }
 #endif
 void launch_gi_sampling_ab(const KArgs& a, uint32_t seed_a, uint32_t seed_b, bool reproject, hipStream_t s) {
-#if ST_FAST_DEVICE
+#if defined(ST_FAST_MATH)
     if ((a.exp_flags & (kExpGiPool | kExpGiPoolSplit)) && a.bvh_w != nullptr && !a.anyhit_contract && !scene_fits_lds(a)) {
         const LaunchDims d_ = launch_dims(a, true);
         if (!d_.blocks) return;

@@ -8,7 +8,9 @@
 //
 //   1. centroid bounds of the live triangle slots                                   k_lbvh_bounds      (wave, then workgroup reduction: one ordered-int atomic pair per workgroup)
 //   2. key = 30-bit Morton code of the centroid << 32 | triangle slot (unique)      k_lbvh_keys        dead slots: ~0, sorted to the end
-//   3. radix sort of the 64-bit keys                                                hipCUB DeviceRadixSort (a plain library sort)
+//   3. radix sort                                                                   hipCUB DeviceRadixSort::SortPairs over the 31-bit (code | dead) keys with the slot as value: 4 passes
+//      (round 5 sorted the 64-bit keys: 8 passes, 0.10 of the build's 0.34 ms); the sort is stable and its input in slot order, so the order is the same,
+//      and k_lbvh_compose rebuilds the 64-bit keys afterwards
 //   4. leaf records (48 B, sorted order = leaf index) + leaf boxes                  k_lbvh_leaves
 //   5. min / max segment tree over the sorted leaf boxes                            k_lbvh_seg_levels  nine levels per launch, no fences
 //   6. the binary radix tree of Karras 2012 — one thread per internal node finds its range and split from the keys alone —, each
@@ -52,7 +54,7 @@ __device__ inline float box_area(const Box& b) {
 __global__ void k_lbvh_init(int* bounds, uint32_t* counters, uint32_t* frontier_a) {
     if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;             // ordered(+inf-ish): min
     else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;   // max
-    if (threadIdx.x == 0) { counters[0] = 1u; counters[1] = 0u; counters[2] = 0u; frontier_a[0] = 0u; }   // the first collapse launch's frontier = { the root }
+    if (threadIdx.x == 0) { counters[0] = 1u; counters[1] = 0u; counters[2] = 0u; counters[3] = 0u; frontier_a[0] = 0u; }   // the first collapse launch's frontier = { the root }
 }
 // 1. bounds of the live triangles' centroids. One ordered-int atomic pair per axis and WORKGROUP, from at most kBoundsBlocks workgroups: with one
 // pair per wave of a launch that covered the slots once (3,252 waves at 208 k triangles = 19,500 atomics on one cache line) this kernel took
@@ -80,10 +82,12 @@ __global__ __launch_bounds__(kT) void k_lbvh_bounds(const float4* tri_bounds, co
     }
 }
 // 2. sort keys
-__global__ __launch_bounds__(kT) void k_lbvh_keys(const float4* tri_bounds, const uint32_t* tri_info, uint32_t slots, const int* bounds, unsigned long long* keys) {
+constexpr uint32_t kDeadCode = 0x40000000u;   // above every 30-bit Morton code: dead slots sort to the end (31 key bits)
+__global__ __launch_bounds__(kT) void k_lbvh_keys(const float4* tri_bounds, const uint32_t* tri_info, uint32_t slots, const int* bounds, uint32_t* codes, uint32_t* slot_of) {
     const uint32_t i = blockIdx.x * kT + threadIdx.x;
     if (i >= slots) return;
-    if (!(tri_info[i] & 1u)) { keys[i] = ~0ull; return; }
+    slot_of[i] = i;
+    if (!(tri_info[i] & 1u)) { codes[i] = kDeadCode; return; }
     const float4 lo = tri_bounds[2u * i], hi = tri_bounds[2u * i + 1u];
     const float c[3] = {(lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f};
     uint32_t q[3];
@@ -93,8 +97,12 @@ __global__ __launch_bounds__(kT) void k_lbvh_keys(const float4* tri_bounds, cons
         const float t = ext > 0.0f ? (c[k] - mn) / ext : 0.0f;
         q[k] = (uint32_t)fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
     }
-    const uint32_t code = expand10(q[0]) | (expand10(q[1]) << 1) | (expand10(q[2]) << 2);
-    keys[i] = ((unsigned long long)code << 32) | i;
+    codes[i] = expand10(q[0]) | (expand10(q[1]) << 1) | (expand10(q[2]) << 2);
+}
+// 3b. the 64-bit keys the hierarchy's tie-breaks want, from the sorted (code, slot) pairs: unique, and ascending because the sort is stable
+__global__ __launch_bounds__(kT) void k_lbvh_compose(const uint32_t* codes, const uint32_t* slot_of, uint32_t slots, unsigned long long* keys) {
+    const uint32_t i = blockIdx.x * kT + threadIdx.x;
+    if (i < slots) keys[i] = codes[i] == kDeadCode ? ~0ull : (((unsigned long long)codes[i] << 32) | slot_of[i]);
 }
 // 4. leaf records and leaf boxes, in sorted order; the segment tree's unused leaves are empty boxes
 __global__ __launch_bounds__(kT) void k_lbvh_leaves(const unsigned long long* keys, uint32_t n, uint32_t pow2, const float4* tri_geo, const float4* tri_bounds,
@@ -216,8 +224,32 @@ __device__ inline void lb_emit(uint32_t b, const uint2* children, const float4* 
 // tree's first five or six levels and its long tail of narrow ones (dozens at 208 k triangles) cost two launches, not one each.
 // With `finish` every thread walks the whole subtree of each of its heads instead of handing its children on.
 constexpr uint32_t kSmallIn = 1024u, kSmallCap = 4u * kSmallIn, kSmallRounds = 96u;
+// The finishing launch — a kernel of its own since round 6, so that the collapse launches carry no scratch memory (its private stack was 400 B per lane
+// of EVERY collapse launch): every thread walks the whole subtree of each head still open. The binary tree is at most 64 + 32 levels deep and a 4-wide
+// DFS keeps up to three siblings pending per level, so a private stack cannot be proven sufficient: when it is full the subtree is NOT built and the
+// launch says so (counters[3], *flags_host) — st_tick.cpp then rebuilds on the host instead of rendering a tree with holes.
+constexpr int kFinishStack = 96;
+__global__ __launch_bounds__(kT) void k_lbvh_collapse_finish(const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
+                                                             const uint32_t* frontier_a, const uint32_t* frontier_b, uint32_t* counters, uint32_t launch, uint32_t* flags_host) {
+    const uint32_t count = counters[launch % 3u];
+    const uint32_t* frontier_in = (launch & 1u) ? frontier_b : frontier_a;
+    uint32_t next[4]; int n_next;
+    for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
+        uint32_t stack[kFinishStack]; int sp = 0;
+        stack[sp++] = frontier_in[i];
+        while (sp > 0) {
+            lb_emit(stack[--sp], children, node_box, seg, pow2, links16, nodes, next, &n_next);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < n_next) {
+                    if (sp < kFinishStack) stack[sp++] = next[k];
+                    else { counters[3] = 1u; if (flags_host) flags_host[0] = 1u; }
+                }
+        }
+    }
+}
 __global__ __launch_bounds__(kT) void k_lbvh_collapse(const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
-                                                      uint32_t* frontier_a, uint32_t* frontier_b, uint32_t* counters, uint32_t launch, uint32_t finish) {
+                                                      uint32_t* frontier_a, uint32_t* frontier_b, uint32_t* counters, uint32_t launch) {
     __shared__ uint32_t s_front[2][kSmallCap];
     __shared__ uint32_t s_n[2];
     uint32_t count = counters[launch % 3u];
@@ -226,18 +258,6 @@ __global__ __launch_bounds__(kT) void k_lbvh_collapse(const uint2* children, con
     uint32_t* frontier_out = (launch & 1u) ? frontier_a : frontier_b;
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[(launch + 2u) % 3u] = 0u;
     uint32_t next[4]; int n_next;
-    if (finish) {
-        for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
-            uint32_t stack[96]; int sp = 0;   // a path of the binary tree is at most 64 + 32 nodes long (64-bit keys, 32-bit tie-break inside them)
-            stack[sp++] = frontier_in[i];
-            while (sp > 0) {
-                lb_emit(stack[--sp], children, node_box, seg, pow2, links16, nodes, next, &n_next);
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (k < n_next && sp < 96) stack[sp++] = next[k];
-            }
-        }
-        return;
-    }
     if (count > kSmallIn) {
         for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
             lb_emit(frontier_in[i], children, node_box, seg, pow2, links16, nodes, next, &n_next);
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(kT) void k_lbvh_refit_nodes(const float4* node_box,
 
 size_t lbvh_sort_temp_bytes(uint32_t slots) {
     size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)slots, 0, 64, (hipStream_t) nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)slots, 0, 31, (hipStream_t) nullptr);
     return bytes;
 }
 uint32_t lbvh_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
@@ -314,9 +334,14 @@ int lbvh_build(const LbvhArgs& a, hipStream_t s) {
     auto grid = [](uint32_t n) { return dim3((n + kT - 1) / kT); };
     hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, a.bounds, a.counters, a.frontier_a);
     hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((a.slots + kT - 1) / kT, kBoundsBlocks)), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds);
-    hipLaunchKernelGGL(k_lbvh_keys, grid(a.slots), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds, a.keys_in);
+    // (code, slot) pairs: unsorted in keys_out's memory, sorted into keys_in's, the composed 64-bit keys back in keys_out (what the hierarchy and every
+    // later refit read)
+    uint32_t* codes_in = reinterpret_cast<uint32_t*>(a.keys_out); uint32_t* slots_in = codes_in + a.slots;
+    uint32_t* codes_out = reinterpret_cast<uint32_t*>(a.keys_in); uint32_t* slots_out = codes_out + a.slots;
+    hipLaunchKernelGGL(k_lbvh_keys, grid(a.slots), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds, codes_in, slots_in);
     size_t temp = a.sort_temp_bytes;
-    if (hipcub::DeviceRadixSort::SortKeys(a.sort_temp, temp, a.keys_in, a.keys_out, (int)a.slots, 0, 64, s) != hipSuccess) return -2;
+    if (hipcub::DeviceRadixSort::SortPairs(a.sort_temp, temp, codes_in, codes_out, slots_in, slots_out, (int)a.slots, 0, 31, s) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_lbvh_compose, grid(a.slots), dim3(kT), 0, s, codes_out, slots_out, a.slots, a.keys_out);
     hipLaunchKernelGGL(k_lbvh_leaves, grid(pow2), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.tri_geo, a.tri_bounds, a.tri_info, a.seg, a.leaves);
     for (uint32_t count = pow2 >> 1; count >= 1u;) {
         const uint32_t width = std::min<uint32_t>(count, (uint32_t)kT), groups = count / width;   // after this launch: every level down to the one of `groups` nodes
@@ -333,9 +358,11 @@ int lbvh_build(const LbvhArgs& a, hipStream_t s) {
     uint32_t wide_levels = 1;
     while (wide_levels < 16u && (1ull << (2u * wide_levels)) < a.live) wide_levels++;
     const uint32_t launches = wide_levels + 8u;
-    for (uint32_t launch = 0; launch <= launches; launch++)
+    for (uint32_t launch = 0; launch < launches; launch++)
         hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min<uint32_t>((a.live + kT - 1) / kT, 1024u)), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes,
-                           a.frontier_a, a.frontier_b, a.counters, launch, launch == launches ? 1u : 0u);
+                           a.frontier_a, a.frontier_b, a.counters, launch);
+    hipLaunchKernelGGL(k_lbvh_collapse_finish, dim3(std::min<uint32_t>((a.live + kT - 1) / kT, 1024u)), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes,
+                       a.frontier_a, a.frontier_b, a.counters, launches, a.flags_host);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -543,6 +543,8 @@ struct Engine {
     void note_walk_overflow();
     bool device_build_possible() const;
     int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);
+    int reserve_device_builder(SceneSet& t, size_t slots, uint32_t live);
+    bool device_builder_failed = false;   // k_lbvh.hip's finishing launch dropped subtrees once (walk_flags_host[2]): this engine builds on the host from then on
     void rebuild_host_tree(bool timing);
 
     int tick(hipStream_t stream);

@@ -217,9 +217,11 @@ bool Engine::refresh_instances() {
             auto mesh = meshes.find(inst.mesh);
             if (mesh != meshes.end()) fresh += mesh->second.size();
         }
-        if (fresh) {
-            const size_t want = triangles.size() + fresh;
-            triangles.reserve(want); prims.reserve(want); prim_alive.reserve(want); tri_geo.reserve(3 * want); tri_attr.reserve(4 * want);
+        if (fresh && triangles.size() + fresh > triangles.capacity()) {
+            // (geometric: reserve(size + fresh) at EVERY spawn reallocated and copied all five arrays — 60 MB at 208 k triangles, 7 ms of a spawn tick
+            // that otherwise costs 0.2 ms, profiles/r06_spawn_cost.txt — although the free list usually serves the new instance)
+            const size_t want = std::max(triangles.size() + fresh, triangles.capacity() + triangles.capacity() / 2);
+            triangles.reserve(want); prims.reserve(want); prim_alive.reserve(want); tri_geo.reserve(3 * want); tri_attr.reserve(4 * want); tri_bounds.reserve(2 * want);
         }
     }
     for (auto& inst : instances) {

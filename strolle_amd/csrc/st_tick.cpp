@@ -34,9 +34,29 @@ void Engine::rebuild_host_tree(bool timing) {
 bool Engine::device_build_possible() const {
     const bool automatic = bvh_refresh_mode == ST_BVH_AUTO && scene_uploaded && live_prims_ > kLdsSceneTexels / 4u;   // (a leaf entry per triangle: more than 112 of them never fit)
     if (!(bvh_refresh_mode == ST_BVH_BUILD_DEVICE || automatic) || !has_device || arithmetic != ST_ARITH_FAST) return false;
-    if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes) return false;
+    if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes || device_builder_failed) return false;
     for (const auto& kv : cameras) if (kv.second->desc.mode == ST_MODE_BVH_HEATMAP) return false;
     return live_prims_ >= 2u && prims.size() < (1u << 23);
+}
+// The device builder's scratch and output arrays of one scene copy, for `slots` triangle slots of which `live` are live: grown with headroom, never shrunk.
+// Also called ahead of time (tick, after the first upload of an engine whose later changes will be answered on the device): a spawn tick then allocates
+// nothing (round 5: the first device build of each copy took 5-15 ms, all of it hipMalloc).
+int Engine::reserve_device_builder(SceneSet& t, size_t slots, uint32_t live) {
+    if (live < 2u) return ST_OK;
+    const uint32_t pow2 = lbvh_pow2(live);
+    const size_t temp = lbvh_sort_temp_bytes((uint32_t)slots);
+    auto need = [&](DeviceArray& d, size_t bytes) -> int {
+        if (bytes <= d.capacity) return ST_OK;
+        if (d.ptr) ST_HIP(hipFree(d.ptr));
+        d.ptr = nullptr; d.capacity = 0;
+        ST_HIP(hipMalloc(&d.ptr, bytes + bytes / 4)); d.capacity = bytes + bytes / 4;
+        return ST_OK;
+    };
+    int rc;
+    if ((rc = need(t.lb_keys_a, slots * 8u)) || (rc = need(t.lb_keys_b, slots * 8u)) || (rc = need(t.lb_temp, std::max<size_t>(temp + temp / 4, 16u))) || (rc = need(t.lb_seg, (size_t)pow2 * 2u * 32u)) ||
+        (rc = need(t.lb_children, (size_t)live * 8u)) || (rc = need(t.lb_node_box, (size_t)live * 32u)) || (rc = need(t.lb_front_a, (size_t)live * 4u)) ||
+        (rc = need(t.lb_front_b, (size_t)live * 4u)) || (rc = need(t.lb_small, 64u)) || (rc = need(t.bvh_wide, (size_t)(live - 1u) * 64u + (size_t)live * 48u + 64u))) return rc;
+    return ST_OK;
 }
 // This device copy's triangle arrays brought up to date, then k_lbvh.hip builds its wide stream from them.
 int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
@@ -91,17 +111,9 @@ int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
     const auto t3 = now();
     const uint32_t pow2 = lbvh_pow2(live);
     const size_t temp = lbvh_sort_temp_bytes((uint32_t)slots);
-    auto need = [&](DeviceArray& d, size_t bytes) -> int {   // scratch: grown with headroom, never shrunk
-        if (bytes <= d.capacity) return ST_OK;
-        if (d.ptr) ST_HIP(hipFree(d.ptr));
-        d.ptr = nullptr; d.capacity = 0;
-        ST_HIP(hipMalloc(&d.ptr, bytes + bytes / 4)); d.capacity = bytes + bytes / 4;
-        return ST_OK;
-    };
-    if ((rc = need(t.lb_keys_a, slots * 8u)) || (rc = need(t.lb_keys_b, slots * 8u)) || (rc = need(t.lb_temp, std::max<size_t>(temp, 16u))) || (rc = need(t.lb_seg, (size_t)pow2 * 2u * 32u)) ||
-        (rc = need(t.lb_children, (size_t)live * 8u)) || (rc = need(t.lb_node_box, (size_t)live * 32u)) || (rc = need(t.lb_front_a, (size_t)live * 4u)) ||
-        (rc = need(t.lb_front_b, (size_t)live * 4u)) || (rc = need(t.lb_small, 64u)) || (rc = need(t.bvh_wide, (size_t)(live - 1u) * 64u + (size_t)live * 48u + 64u))) return rc;
+    if ((rc = reserve_device_builder(t, slots, live))) return rc;
     LbvhArgs a{};
+    a.flags_host = walk_flags_dev ? walk_flags_dev + 2 : nullptr;   // (word 2 of the engine's sticky words: the finishing launch left subtrees unbuilt)
     a.tri_geo = static_cast<const float4*>(t.tri_geo.ptr); a.tri_bounds = static_cast<const float4*>(t.tri_bounds.ptr); a.tri_info = static_cast<const uint32_t*>(t.tri_info.ptr);
     a.slots = (uint32_t)slots; a.live = live; a.links16 = live < 32768u ? 1u : 0u;
     a.nodes = static_cast<float4*>(t.bvh_wide.ptr); a.leaves = a.nodes + 4u * (size_t)(live - 1u);
@@ -144,6 +156,14 @@ int Engine::tick(hipStream_t stream) {
     // and the host's tree falls behind; the first tick that finds an observer brings it up to date like any rebuild.
     if (materials_changed_this_tick) info_full_ = true;   // a Blend flag may have changed under any slot
     if ((instances_changed && !moved_on_device) || materials_changed_this_tick) tri_info_serial_++;   // slots, liveness, materials or Blend flags may have changed
+    if (walk_flags_host && walk_flags_host[2] != 0u) {
+        // the device builder's finishing launch ran out of its private stack (k_lbvh.hip k_lbvh_collapse_finish): the tree it left has holes. This engine
+        // goes back to the host's builder for good; this very tick rebuilds (host_tree_stale) and uploads the host's streams.
+        walk_flags_host[2] = 0u;
+        device_builder_failed = true;
+        fprintf(stderr, "[strolle-hip] warning: the device BVH builder could not finish a tree (subtrees deeper than its finishing launch's stack): frames since that build may have missed geometry; "
+                        "this engine rebuilds on the host from now on\n");
+    }
     const bool build_on_device_now = device_build_possible();
     device_tree_refit_now = false;
     if (instances_changed && build_on_device_now) {
@@ -291,6 +311,14 @@ int Engine::tick(hipStream_t stream) {
             if ((rc = t.base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), up, staging, flag))) return rc;
             if (other_copy) copied_now = true;
             live = target; live_bvh_texels = build_on_device_now ? 0u : device_bvh_len;
+            if (!scene_uploaded && !build_on_device_now && (bvh_refresh_mode == ST_BVH_AUTO || bvh_refresh_mode == ST_BVH_BUILD_DEVICE) && arithmetic == ST_ARITH_FAST &&
+                tuning.wide_bvh && live_prims_ > kLdsSceneTexels / 4u && prims.size() < (1u << 23)) {
+                // later changes of this scene go to the device builder: its arrays — and the triangle arrays its builds read — are allocated NOW, while the
+                // scene loads, for both copies (a failure here is not an error: the build allocates what it finds missing)
+                for (SceneSet& c : sets) {
+                    if (reserve_device_builder(c, prims.size() + prims.size() / 8u, (uint32_t)std::min<size_t>(live_prims_ + live_prims_ / 8u, prims.size() + prims.size() / 8u)) != ST_OK) { (void)hipGetLastError(); break; }
+                }
+            }
             scene_uploaded = true;
             scene_changed = !other_copy;  // in-place uploads count as work on the caller's stream below
         }

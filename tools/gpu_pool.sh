@@ -24,4 +24,3 @@ unset ST_EXP ST_NO_FUSE_GI_VALIDATION
 bash tools/gpu_counters.sh dungeon 2>&1 | grep -v amdgpu.ids | sed 's/^/plain: /' | tee gpurun_out/r6_pool_counters.txt
 ST_EXP=0x100 bash tools/gpu_counters.sh dungeon 2>&1 | grep -v amdgpu.ids | sed 's/^/pool16: /' | tee -a gpurun_out/r6_pool_counters.txt
 ST_EXP=0x200 ST_NO_FUSE_GI_VALIDATION=1 bash tools/gpu_counters.sh dungeon 2>&1 | grep -v amdgpu.ids | sed 's/^/split16: /' | tee -a gpurun_out/r6_pool_counters.txt
-bash tools/gpu_valu_rate.sh 2>&1 | tail -12
