@@ -132,7 +132,12 @@ struct WhiteNoise {
         const float phi = 2.0f * kPi * sample();
         V3 t, b;
         any_orthonormal_pair(normal, &t, &b);
-        float sp_, cp_; sincos_(phi, &sp_, &cp_);
+        float sp_, cp_;
+#if defined(ST_ABL_HEMI_POLY)
+        sincos_poly_(phi, &sp_, &cp_);
+#else
+        sincos_(phi, &sp_, &cp_);
+#endif
         return (t * cp_ + b * sp_) * sin_theta + normal * cos_theta;
     }
 };
@@ -457,6 +462,11 @@ ST_D bool trace_any_contract(const KArgs& a, const Ray& ray, SE* stack, uint32_t
 // The boolean can differ from the contract loop's only where a ray grazes a box or a triangle edge within an ulp; the fast
 // build's launch-by-launch tolerance tests (tests/test_gpu_fast_*.py) bound how often. The exact build never comes here.
 #if ST_FAST_DEVICE
+#if defined(ST_ABL_MT_DIV)
+#define ST_MT_RCP(det) (1.0f / (det))                  // (ablation build: Moeller-Trumbore divides by an IEEE reciprocal)
+#else
+#define ST_MT_RCP(det) __builtin_amdgcn_rcpf(det)
+#endif
 // A direction component of (nearly) zero would make that axis' planes inf - inf = NaN wherever the origin and the plane have the same sign;
 // v_min / v_max return the other operand for a NaN, so the axis would either collapse to one plane (a box the ray runs inside gets rejected)
 // or constrain nothing (max3 / min3 below: measured — a handful of axis-parallel GI rays per frame walked every box along their other axes
@@ -476,7 +486,7 @@ ST_D bool any_triangle(const Ray& ray, V3 p0, V3 e1, V3 e2, float limit, float* 
     const V3 pvec = cross(ray.dir, e2);
     const float det = dot(e1, pvec);
     if (fabsf(det) < kF32Eps) return false;
-    const float inv_det = __builtin_amdgcn_rcpf(det);
+    const float inv_det = ST_MT_RCP(det);
     const V3 tvec = ray.origin - p0;
     const float u = dot(tvec, pvec) * inv_det;
     const V3 qvec = cross(tvec, e1);
@@ -621,7 +631,7 @@ ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candida
             const V3 pvec = cross(ray.dir, e2);
             const float det = dot(e1, pvec);
             if (!(fabsf(det) < kF32Eps)) {
-                const float inv_det = __builtin_amdgcn_rcpf(det);
+                const float inv_det = ST_MT_RCP(det);
                 const V3 tvec = ray.origin - p0;
                 const float u = dot(tvec, pvec) * inv_det;
                 const V3 qvec = cross(tvec, e1);
@@ -781,7 +791,7 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
             const V3 pvec = cross(ray.dir, e2);
             const float det = dot(e1, pvec);
             if (!(fabsf(det) < kF32Eps)) {
-                const float inv_det = __builtin_amdgcn_rcpf(det);
+                const float inv_det = ST_MT_RCP(det);
                 const V3 tvec = ray.origin - p0;
                 const float u = dot(tvec, pvec) * inv_det;
                 const V3 qvec = cross(tvec, e1);
@@ -871,7 +881,7 @@ ST_D void closest_hit_wide_pool(const KArgs& a, float4* pool, uint32_t n_slots, 
                 const V3 pvec = cross(ray.dir, e2);
                 const float det = dot(e1, pvec);
                 if (!(fabsf(det) < kF32Eps)) {
-                    const float inv_det = __builtin_amdgcn_rcpf(det);
+                    const float inv_det = ST_MT_RCP(det);
                     const V3 tvec = ray.origin - p0;
                     const float u = dot(tvec, pvec) * inv_det;
                     const V3 qvec = cross(tvec, e1);
@@ -968,7 +978,7 @@ ST_D bool closest_hit_packet(const KArgs& a, const Ray& ray, Candidate* best) {
             const V3 pvec = cross(ray.dir, e2);
             const float det = dot(e1, pvec);
             if (!(fabsf(det) < kF32Eps)) {
-                const float inv_det = __builtin_amdgcn_rcpf(det);
+                const float inv_det = ST_MT_RCP(det);
                 const V3 tvec = ray.origin - p0;
                 const float u = dot(tvec, pvec) * inv_det;
                 const V3 qvec = cross(tvec, e1);
@@ -1371,13 +1381,15 @@ ST_D Ray di_sample_ray(const DiSample& s, V3 hit_point) {
 struct GiSample { float pdf; uint32_t rng; V3 radiance, v1_point, v2_point, v2_normal; };
 struct GiReservoir { GiSample s; float m, w, confidence; };
 ST_D GiReservoir gi_empty() { GiReservoir r; r.s.pdf = 0.0f; r.s.rng = 0u; r.s.radiance = r.s.v1_point = r.s.v2_point = r.s.v2_normal = v3s(0.0f); r.m = 0.0f; r.w = 0.0f; r.confidence = 0.0f; return r; }
-ST_D GiReservoir gi_read(const float4* buf, uint32_t id, uint32_t count) {
-    if (id >= count) return gi_empty();
-    const float4 d0 = buf[4u * id], d1 = buf[4u * id + 1u], d2 = buf[4u * id + 2u], d3 = buf[4u * id + 3u];
+ST_D GiReservoir gi_from_texels(float4 d0, float4 d1, float4 d2, float4 d3) {
     GiReservoir r;
     r.s.pdf = d2.w; r.s.rng = f2b(d3.w); r.s.radiance = xyz(d0); r.s.v1_point = xyz(d1); r.s.v2_point = xyz(d2); r.s.v2_normal = normal_decode(v2(d3.x, d3.y));
     r.m = d0.w; r.w = d1.w; r.confidence = d3.z;
     return r;
+}
+ST_D GiReservoir gi_read(const float4* buf, uint32_t id, uint32_t count) {
+    if (id >= count) return gi_empty();
+    return gi_from_texels(buf[4u * id], buf[4u * id + 1u], buf[4u * id + 2u], buf[4u * id + 3u]);
 }
 ST_D void gi_write(float4* buf, uint32_t id, const GiReservoir& r) {
     buf[4u * id] = f4(r.s.radiance, r.m);
@@ -1423,12 +1435,6 @@ ST_D void quad_transpose(float4& v0, float4& v1, float4& v2, float4& v3) {
         const float4 ra = quad_dpp<0x4E>(sel4(b1, v0, v2)), rb = quad_dpp<0x4E>(sel4(b1, v1, v3));
         if (b1) { v0 = ra; v1 = rb; } else { v2 = ra; v3 = rb; }
     }
-}
-ST_D GiReservoir gi_from_texels(float4 d0, float4 d1, float4 d2, float4 d3) {
-    GiReservoir r;
-    r.s.pdf = d2.w; r.s.rng = f2b(d3.w); r.s.radiance = xyz(d0); r.s.v1_point = xyz(d1); r.s.v2_point = xyz(d2); r.s.v2_normal = normal_decode(v2(d3.x, d3.y));
-    r.m = d0.w; r.w = d1.w; r.confidence = d3.z;
-    return r;
 }
 // The reservoir of this lane's own pixel. `valid`: `id` is a pixel of this launch (lanes of a quad then hold consecutive
 // ids); `want`: this lane needs the record (a lane that does not still helps move its neighbours').

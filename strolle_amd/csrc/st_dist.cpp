@@ -117,7 +117,17 @@ static void equal_cost_edges(const std::vector<double>& bp, const std::vector<do
         out[j] = (uint32_t)std::max<int64_t>(e, 0);
     }
     for (uint32_t j = 1; j < parts; j++) out[j] = std::max(out[j], out[j - 1] + min_size);                 // ascending, min_size apart ...
-    for (uint32_t j = parts; j-- > 1;) out[j] = std::min(out[j], out[j + 1] - min_size);                    // ... from both ends
+    // ... from both ends — and still ON THE GRID: the frame's far edge need not be a multiple of `align` (1080 rows, a 1000-pixel-wide frame), so the
+    // back-to-front clamp rounds down (out[parts] - min_size landed off the 8 / 16 grid and grid_check refused the result)
+    for (uint32_t j = parts; j-- > 1;) out[j] = std::min(out[j], (out[j + 1] - min_size) / align * align);
+    // The clamps above may have carried an edge further than max_step from where it was, which would hand a rank pixels it never rendered (cold
+    // history at the seam): when that happens, or the edges no longer ascend, the old edges stand for this call (they are a valid grid).
+    bool keep_old = false;
+    for (uint32_t j = 1; j < parts && old; j++) {
+        const int64_t step = max_step ? std::max<int64_t>(align, (int64_t)max_step / align * align) : (int64_t)extent;
+        if (std::llabs((int64_t)out[j] - (int64_t)old[j]) > step || out[j] <= out[j - 1] || out[j] >= out[j + 1]) keep_old = true;
+    }
+    if (keep_old) for (uint32_t j = 1; j < parts; j++) out[j] = old[j];
 }
 int dist_grid_rebalance(uint32_t width, uint32_t height, const StDistGrid* cur, const float* cost, uint32_t max_step, StDistGrid* out) {
     if (!cost || !out) return fail(ST_ERR_INVALID_ARGUMENT, "null argument");

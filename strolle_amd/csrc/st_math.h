@@ -111,7 +111,7 @@ ST_HD void sincos_poly_(float x, float* s_out, float* c_out) {
     *s_out = s; *c_out = c;
 }
 ST_HD void sincos_(float x, float* s_out, float* c_out) {
-#if ST_FAST_DEVICE
+#if ST_FAST_DEVICE && !defined(ST_ABL_SINCOS_POLY)   // (ST_ABL_*: build variants of tools/abl_build.sh — which fast-math substitution spends the tolerance gates? DESIGN.md section 2.2)
     const float turns = x * 0.15915494309189535f;  // v_sin_f32 / v_cos_f32 take revolutions (valid to +-256 turns)
     *s_out = __builtin_amdgcn_sinf(turns); *c_out = __builtin_amdgcn_cosf(turns);
 #else

@@ -224,6 +224,29 @@ def test_rebalancing_moves_work_away_from_the_expensive_tiles():
         dist_grid_rebalance(w, h, g, [1.0] * 7 + [0.0])
 
 
+def test_rebalancing_a_frame_whose_edge_is_off_the_grid_stays_on_the_grid():
+    """a frame 1000 pixels wide (not a multiple of 16) or 1084 rows high (not a multiple of 8) whose cost sits at the far edge pushes the
+    rebalanced edges against the minimum tile size; the back-to-front clamp used to land off the 16 x 8 grid (extent - min_size) and the result was refused.
+    Every edge stays on the grid, tiles keep their minimum size, limited steps stay limited."""
+    for (w, h, world, cols) in ((1000, 540, 8, 4), (1920, 1084, 8, 1), (1000, 1084, 6, 3)):
+        g = dist_grid(w, h, world, cols)
+        rows = world // (cols or 1)
+        for it in range(8):
+            cost = [1.0] * world
+            cost[-1] = 60.0                                     # nearly all work in the last tile: edges crowd towards the far corner
+            for r in range(rows):
+                cost[r * g.cols + g.cols - 1] = max(cost[r * g.cols + g.cols - 1], 30.0)
+            before = g.describe()
+            g = dist_grid_rebalance(w, h, g, cost, max_step=0 if it >= 4 else 16)
+            d = g.describe()
+            assert _covers_exactly_once(g.tiles(), w, h), d
+            assert all(e % 8 == 0 for e in d["row_edges"][:-1]) and all(e % 16 == 0 for row in d["col_edges"] for e in row[:-1]), d
+            assert all(y1 - y0 >= 32 and x1 - x0 >= 64 for x0, y0, x1, y1 in g.tiles()), d
+            if it < 4:
+                assert max(abs(x - y) for x, y in zip(before["row_edges"], d["row_edges"])) <= 16
+                assert max(abs(x - y) for ra, rb in zip(before["col_edges"], d["col_edges"]) for x, y in zip(ra, rb)) <= 16
+
+
 def test_a_weighted_grid_gathers_like_the_equal_split():
     """st_dist_set_grid through the in-process transport: 4 ranks, a lopsided grid; rank 0's frame is tile r from rank r, bit for bit. A grid
     with the wrong tile count or edges off the pixel grid is refused."""
