@@ -293,6 +293,15 @@ int Engine::tick(hipStream_t stream) {
                     t.tree_version = tree_version;
                 }
             }
+            if (!scene_uploaded && !build_on_device_now && (bvh_refresh_mode == ST_BVH_AUTO || bvh_refresh_mode == ST_BVH_BUILD_DEVICE) && arithmetic == ST_ARITH_FAST &&
+                tuning.wide_bvh && live_prims_ > kLdsSceneTexels / 4u && prims.size() < (1u << 23)) {
+                // later changes of this scene go to the device builder: its arrays are allocated NOW, while the scene loads, for both copies — BEFORE the
+                // wide stream of this copy is written below (its allocation is one of them: growing it afterwards would throw the stream away: round 6's
+                // first version did, and rendered an empty world). A failure here is not an error: the build allocates what it finds missing.
+                for (SceneSet& c : sets) {
+                    if (reserve_device_builder(c, prims.size() + prims.size() / 8u, (uint32_t)std::min<size_t>(live_prims_ + live_prims_ / 8u, prims.size() + prims.size() / 8u)) != ST_OK) { (void)hipGetLastError(); break; }
+                }
+            }
             if (!build_on_device_now) {
                 if ((rc = refresh_compact_stream(t, up))) return rc;   // the shadow rays' compact form follows every change of the contract stream
                 if ((rc = refresh_wide_stream(t, up, !device_path, flag))) return rc;   // and so does the wide form (its topology only when the tree itself was sent)
@@ -311,14 +320,6 @@ int Engine::tick(hipStream_t stream) {
             if ((rc = t.base_packed.upload(material_base_packed.data(), material_base_packed.size() * sizeof(uint32_t), up, staging, flag))) return rc;
             if (other_copy) copied_now = true;
             live = target; live_bvh_texels = build_on_device_now ? 0u : device_bvh_len;
-            if (!scene_uploaded && !build_on_device_now && (bvh_refresh_mode == ST_BVH_AUTO || bvh_refresh_mode == ST_BVH_BUILD_DEVICE) && arithmetic == ST_ARITH_FAST &&
-                tuning.wide_bvh && live_prims_ > kLdsSceneTexels / 4u && prims.size() < (1u << 23)) {
-                // later changes of this scene go to the device builder: its arrays — and the triangle arrays its builds read — are allocated NOW, while the
-                // scene loads, for both copies (a failure here is not an error: the build allocates what it finds missing)
-                for (SceneSet& c : sets) {
-                    if (reserve_device_builder(c, prims.size() + prims.size() / 8u, (uint32_t)std::min<size_t>(live_prims_ + live_prims_ / 8u, prims.size() + prims.size() / 8u)) != ST_OK) { (void)hipGetLastError(); break; }
-                }
-            }
             scene_uploaded = true;
             scene_changed = !other_copy;  // in-place uploads count as work on the caller's stream below
         }

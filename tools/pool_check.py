@@ -35,6 +35,8 @@ def run(exp, extra_env):
         torch.cuda.synchronize()
         frames.append([e.read_buffer(cam, b).copy() for b in PLANES] + [out.cpu().numpy().copy()])
     rays = e.ray_count(cam)
+    lit = float(np.count_nonzero(e.read_buffer(cam, Buffer.PRIM_GBUFFER_D0_A).reshape(-1, 4)[:, 0]) / (W * H))
+    assert lit > 0.9, f"only {lit:.2f} of the primary rays hit the dungeon: the scene on the device is broken"
     e.close()
     return frames, rays
 
