@@ -12,7 +12,7 @@ d = json.loads(sys.stdin.read()); k = d.get('kernels', {})
 print('$1: %.4f ms | ' % d['ms_per_step'] + ' '.join('%s %.1f' % (n[:22], k[n].get('us_per_launch_kernel_events', k[n]['us_per_launch'])) for n in k if n.startswith('gi_sampling') or n.startswith('gi_spatial') or n.startswith('prim')))"; }
 for round in 1 2; do for w in dungeon dungeon134k:gi_diffuse; do
   IFS=: read scene mode <<< "$w"
-  for v in "base::" "pool16:0x100:" "pool8:0x2100:" "pool32:0x8100:" "pool48:0xc100:" "base_nv::1" "split16:0x200:1" "split32:0x8200:1"; do
+  for v in "base::" "pool16:0x100:" "pool32:0x8100:" "base_nv::1" "split16:0x200:1"; do
     IFS=: read name exp nv <<< "$v"
     unset ST_EXP ST_NO_FUSE_GI_VALIDATION
     [ -n "$exp" ] && export ST_EXP=$exp
