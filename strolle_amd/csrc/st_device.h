@@ -430,6 +430,21 @@ ST_D TriangleHit closest_resolve(const KArgs& a, const Ray& ray, const Candidate
 }
 // glam Affine3A::transform_point3 with the transform stored as 4 float4 (x, y, z axes, translation)
 ST_D V3 affine_point(const float4* m, V3 p) { return ((xyz(m[0]) * p.x) + (xyz(m[1]) * p.y) + (xyz(m[2]) * p.z)) + xyz(m[3]); }
+// Triangle::hit's accept / reject and (t, u, v, 1 / det) for a hit-test record (p0, e1, e2), in the island's arithmetic: what traverse() computes for a leaf
+// entry, for walks over OTHER streams that owe the contract walk's bits (the wide stream of a scene that lives in LDS: closest_hit_wide)
+ST_D bool triangle_hit_exact(const Ray& ray, V3 p0, V3 e1, V3 e2, float limit, float* t_out, float* u_out, float* v_out, float* inv_det_out) {
+    const V3 pvec = xe::cross(ray.dir, e2);
+    const float det = xe::dot(e1, pvec);
+    if (fabsf(det) < kF32Eps) return false;
+    const float inv_det = 1.0f / det;
+    const V3 tvec = xe::sub(ray.origin, p0);
+    const float u = xe::dot(tvec, pvec) * inv_det;
+    const V3 qvec = xe::cross(tvec, e1);
+    const float v = xe::dot(ray.dir, qvec) * inv_det;
+    const float t = xe::dot(e2, qvec) * inv_det;
+    *t_out = t; *u_out = u; *v_out = v; *inv_det_out = inv_det;
+    return !((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= limit));
+}
 // Ray::intersect (shadow ray) as the contract states it: the reference's visiting order, arithmetic and `used_memory` count
 template <class SE>
 ST_D bool trace_any_contract(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
@@ -788,24 +803,27 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
         } else {
             const uint32_t head = f2b(t0.w);
             const V3 p0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);
-            const V3 pvec = cross(ray.dir, e2);
-            const float det = dot(e1, pvec);
-            if (!(fabsf(det) < kF32Eps)) {
-                const float inv_det = ST_MT_RCP(det);
+            float t, u, v, inv_det;
+            bool found;
+            if (a.bvh_w_exact_leaf) found = triangle_hit_exact(ray, p0, e1, e2, best->t, &t, &u, &v, &inv_det);   // (a scene that lives in LDS: a constant per kernel, k_common.h ST_SCENE_PROLOGUE)
+            else {
+                const V3 pvec = cross(ray.dir, e2);
+                const float det = dot(e1, pvec);
+                inv_det = ST_MT_RCP(det);
                 const V3 tvec = ray.origin - p0;
-                const float u = dot(tvec, pvec) * inv_det;
+                u = dot(tvec, pvec) * inv_det;
                 const V3 qvec = cross(tvec, e1);
-                const float v = dot(ray.dir, qvec) * inv_det;
-                const float t = dot(e2, qvec) * inv_det;
-                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t))) {
-                    bool found = true;
-                    if (head & 2u) {
-                        const GpuMaterial m = a.materials[f2b(t1.w)];
-                        const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
-                        if (bc.w < 1.0f) found = false;
-                    }
-                    if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = head >> 2; best->material = f2b(t1.w); found_any = true; }
+                v = dot(ray.dir, qvec) * inv_det;
+                t = dot(e2, qvec) * inv_det;
+                found = !(fabsf(det) < kF32Eps) & !((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t));
+            }
+            if (found) {
+                if (head & 2u) {
+                    const GpuMaterial m = a.materials[f2b(t1.w)];
+                    const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
+                    if (bc.w < 1.0f) found = false;
                 }
+                if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = head >> 2; best->material = f2b(t1.w); found_any = true; }
             }
             if (head & 1u) { cur += 2u; continue; }
         }

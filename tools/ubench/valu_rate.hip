@@ -137,6 +137,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #define A_PKMUL_F32(r) "v_pk_mul_f32 " #r ", " #r ", %8\n"
 #define A_PKADD_F32(r) "v_pk_add_f32 " #r ", " #r ", %8\n"
 KERNEL_PK(k_pkfma_f32, A_PKFMA_F32) KERNEL_PK(k_pkmul_f32, A_PKMUL_F32) KERNEL_PK(k_pkadd_f32, A_PKADD_F32)
+// the 64-bit address add the compiler emits for plane[idx] (one per global access whose offset is not provably 32-bit)
+#define A_LSHLADD64(r) "v_lshl_add_u64 " #r ", " #r ", 4, %8\n"
+KERNEL_PK(k_lshladd64, A_LSHLADD64)
 
 int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
@@ -150,7 +153,7 @@ int main() {
                                {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo},
                                {"v_cndmask_b32 (sgpr pair)", k_cnds}, {"v_cndmask_b32 (dst not a source)", k_cndother}, {"v_cmp + v_cndmask pair (per 2)", k_cmpcnd}, {"v_max3_f32", k_max3}, {"v_add_f32", k_add}, {"v_sub_f32", k_sub},
                                {"v_and_b32", k_and}, {"v_or_b32", k_or}, {"v_xor_b32", k_xor}, {"v_lshl_add_u32", k_lshladd}, {"v_add3_u32", k_add3}, {"v_mad_u32_u24", k_mad24}, {"v_bfe_u32", k_bfe}, {"v_fmac_f32", k_fmac}, {"v_min_f32", k_min},
-                               {"v_pk_fma_f32 (2 fp32 lanes per instruction)", k_pkfma_f32}, {"v_pk_mul_f32", k_pkmul_f32}, {"v_pk_add_f32", k_pkadd_f32},
+                               {"v_pk_fma_f32 (2 fp32 lanes per instruction)", k_pkfma_f32}, {"v_pk_mul_f32", k_pkmul_f32}, {"v_pk_add_f32", k_pkadd_f32}, {"v_lshl_add_u64 (64-bit address add)", k_lshladd64},
                                {"1 v_cmp -> vcc, 15 v_cndmask reading vcc", k_cmp_then_cnd}, {"1 v_cmp -> s[10:11], 15 v_cndmask reading it", k_cmp_then_cnd_s}, {"1 v_cmp -> vcc, 15 v_cndmask_e64 reading vcc", k_cmp_then_cnd_e64}, {"1 v_cmp -> vcc, s_nop 4, 15 v_cndmask reading vcc", k_cmp_then_cnd_nop}};
     printf("%s: %d CUs, clock %0.0f MHz (reported); 8 waves per SIMD, %d instructions per wave\n", p.gcnArchName, cus, mhz, kIters * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
