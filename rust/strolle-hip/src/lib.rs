@@ -351,15 +351,22 @@ where
     }
 
     /// Not part of the reference's API: refit the BVH instead of rebuilding it while instances only move — on the device
-    /// (ST_BVH_REFIT_DEVICE = 2: st_tick sends the moved triangles only; same bits as the host refit).
+    /// (ST_BVH_REFIT_DEVICE = 2: st_tick sends the moved triangles only; same bits as the host refit). `false` goes back to the library's
+    /// default (ST_BVH_AUTO = 4: the first tree on the host, every later change answered on the device while nothing observes the contract stream).
     pub fn set_bvh_refit(&mut self, refit: bool) {
-        check(unsafe { ffi::st_set_bvh_refresh(self.raw, if refit { 2 } else { 0 }) });
+        check(unsafe { ffi::st_set_bvh_refresh(self.raw, if refit { 2 } else { 4 }) });
     }
 
-    /// Not part of the reference's API: after a scene change build the tree ON THE DEVICE (ST_BVH_BUILD_DEVICE = 3: a spawn costs about a
-    /// millisecond instead of the host rebuild) while nothing observes the contract stream — no BvhHeatmap camera, fast arithmetic.
+    /// Not part of the reference's API: build EVERY tree on the device, the first one too (ST_BVH_BUILD_DEVICE = 3: a spawn costs about half a
+    /// millisecond instead of the host rebuild) while nothing observes the contract stream — no BvhHeatmap camera, fast arithmetic. `false`: the default.
     pub fn set_bvh_build_on_device(&mut self, on_device: bool) {
-        check(unsafe { ffi::st_set_bvh_refresh(self.raw, if on_device { 3 } else { 0 }) });
+        check(unsafe { ffi::st_set_bvh_refresh(self.raw, if on_device { 3 } else { 4 }) });
+    }
+
+    /// Not part of the reference's API: the reference's own behaviour — every scene change rebuilds the binned-SAH tree on the host
+    /// (ST_BVH_REBUILD = 0; tens of milliseconds per spawn at 200 k triangles). The library's default is ST_BVH_AUTO.
+    pub fn set_bvh_rebuild_on_host(&mut self) {
+        check(unsafe { ffi::st_set_bvh_refresh(self.raw, 0) });
     }
 }
 

@@ -32,7 +32,8 @@ ST_D bool frame_is_gi_tracing(uint32_t frame) { return frame % 6u < 4u; }  // fr
 // `prim_hit`: pixel_hit() of the cell's pixel (tracing frames: pass a samples its BRDF; pass b needs it on every frame);
 // `vres`: the reprojected reservoir of validation frames (both passes re-trace / re-shade its sample).
 // Pass a: what it stores in gi_d0..2 — false when the pass leaves early (nothing stored, stale texels stay, as in the reference).
-// ... in two halves, so that the trace between them can be somebody else's (k_gi_sampling_ab_pool): the cell's bounce ray, and what the pass stores for its hit
+// ... in two halves — the cell's bounce ray, and what the pass stores for its hit — so that the trace between them can be somebody else's (round 6's lane-refill
+// pool, measured and archived: tools/experiments/gi_sampling_pool.inc)
 ST_D bool gi_sampling_a_ray(uint32_t seed, bool tracing, U2 pos, const Hit& prim_hit, const GiReservoir& vres, Ray* gi_ray, float* gi_ray_pdf) {
     if (tracing) {
         WhiteNoise wn = white_noise(seed, pos);
@@ -215,106 +216,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void k_gi_sampling_ab(const KArgs
     if (!hit_some(prim_hit)) return;  // validation frames: pass a re-traces a reservoir wherever one is, pass b wants a surface too
     gi_sampling_b_cell(a, seed_b, tracing, pos, prim_hit, vres, lane_stack(a, lds), &used_, d0, d1, d2);
 }
-#if defined(ST_FAST_MATH)
-// ---- the same launch with LANE REFILL for the bounce rays (st_device.h closest_hit_wide_pool; KArgs::exp_flags bit kExpGiPool while it is
-// being measured). A workgroup takes TWO of the plain kernel's workgroups' cells — 512 cells, two per lane:
-//   phase 1  per cell: the pixel's surface, the bounce ray (gi_sampling_a_ray) -> a 32-B slot of the workgroup's LDS pool; the lane keeps (dir, pdf)
-//   phase 2  the workgroup's 256 lanes walk the pool's rays over the wide stream, idle lanes refilling in groups; hits go back into the slots
-//   phase 3  per cell: the surface again (two texels, cache-served), pass a's shading of the hit, its three stores, and pass b as in the plain kernel
-//            (its shadow ray per lane, as before)
-// LDS: 16 KB pool + the stacks (12 KB with 16-bit links) + the lights: 5 workgroups per CU.
-constexpr uint32_t kExpGiPool = 0x100u;
-constexpr uint32_t kExpGiPoolSplit = 0x200u;   // ... with pass b as its own launch afterwards (k_gi_sampling_b): the pooled launch then fits 80 VGPRs without a spill
-// a wave refills once this many of its lanes are idle: 16 unless KArgs::exp_flags bits 12-15 say otherwise (x 4)
-ST_D uint32_t pool_refill_at(const KArgs& a) { const uint32_t q = (a.exp_flags >> 12) & 15u; return q ? q * 4u : 16u; }
-ST_D bool gi_pool_cell(const KArgs& a, uint32_t block, bool tracing, uint32_t reproject, U2* gid, U2* pos, Hit* prim_hit, GiReservoir* vres) {
-    if (!resolve_gid_of_block(a, true, block, gid)) return false;
-    *pos = tracing ? resolve_checkerboard(*gid, a.frame / 2u) : resolve_checkerboard(*gid, a.frame);
-    if (!owns_pixel(a, *pos)) return false;
-    *prim_hit = pixel_hit(a, a.cam, a.g0, a.g1, *pos);
-    *vres = gi_empty();
-    if (!tracing) {   // (as k_gi_sampling_ab)
-        const uint32_t n = a.width * a.height;
-        if (reproject && hit_some(*prim_hit)) {
-            GiReservoir r = gi_empty();
-            const Reprojection rp = reprojection_read(tex_read(a.reprojection, a, *pos));
-            if (rp.confidence > 0.0f) r = gi_read(a.gi_res[0], screen_to_idx(a, reprojection_prev_round(rp)), n);
-            r.confidence = 1.0f;
-            r.s.v1_point = prim_hit->point;
-            *vres = gi_after_store(r);
-        } else *vres = gi_read(a.gi_res[2], screen_to_idx(a, *pos), n);
-    }
-    return true;
-}
-template <bool LDS_SCENE, bool WITH_B, class SE>
-__global__ __launch_bounds__(kBlockThreads, 5) void k_gi_sampling_ab_pool(const KArgs a_in, uint32_t seed_a, uint32_t seed_b, uint32_t reproject) {
-    ST_SCENE_PROLOGUE
-    ST_STACK_LDS(SE, lds);
-    __shared__ float4 s_pool[2 * 2 * kBlockThreads];
-    __shared__ uint32_t s_next;
-    const bool tracing = frame_is_gi_tracing(a.frame);
-    float4 kept0 = f4z(), kept1 = f4z();      // (bounce direction, its pdf) of the lane's two cells; .w < 0: the cell has no ray
-    if (threadIdx.x == 0u) s_next = 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < 2u; k++) {
-        U2 gid, pos; Hit prim_hit; GiReservoir vres;
-        Ray r = zero_ray(); float pdf = 0.0f;
-        bool has = false;
-        if (gi_pool_cell(a, 2u * blockIdx.x + k, tracing, reproject, &gid, &pos, &prim_hit, &vres)) has = gi_sampling_a_ray(seed_a, tracing, pos, prim_hit, vres, &r, &pdf);
-        const uint32_t slot = k * kBlockThreads + threadIdx.x;
-        s_pool[2u * slot] = f4(r.origin, 0.0f);
-        s_pool[2u * slot + 1u] = f4(r.dir, b2f(has ? 1u : 0u));
-        const float4 keep = f4(r.dir, has ? pdf : -1.0f);
-        if (k == 0u) kept0 = keep; else kept1 = keep;
-    }
-    __syncthreads();
-#if ST_FAST_DEVICE   // (st_device.h defines the walk for the device pass of the fast build only; the host pass needs this kernel's stub)
-    closest_hit_wide_pool<SE>(a, s_pool, 2u * kBlockThreads, &s_next, lane_stack(a, lds), pool_refill_at(a));
-#endif
-    __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < 2u; k++) {
-        const float4 keep = k == 0u ? kept0 : kept1;
-        if (keep.w < 0.0f) continue;   // (a pdf is never negative)
-        U2 gid, pos; Hit prim_hit; GiReservoir vres;
-        (void)gi_pool_cell(a, 2u * blockIdx.x + k, tracing, reproject, &gid, &pos, &prim_hit, &vres);
-        const uint32_t slot = k * kBlockThreads + threadIdx.x;
-        const float4 h0 = s_pool[2u * slot], h1 = s_pool[2u * slot + 1u];
-        Candidate c; c.t = h0.x; c.u = h0.y; c.v = h0.z; c.inv_det = h0.w; c.tri = f2b(h1.x); c.material = f2b(h1.y);
-        const Ray gi_ray = make_ray(tracing ? prim_hit.point : vres.s.v1_point, xyz(keep));
-        const TriangleHit gi_hit = closest_resolve(a, gi_ray, c, f2b(h1.z) != 0u);
-        float4 d0, d1, d2;
-        gi_sampling_a_shade(a, gi_ray, keep.w, gi_hit, &d0, &d1, &d2);
-        count_rays(a, 0u);
-        tex_write(a.gi_d0, a, gid, d0);
-        tex_write(a.gi_d1, a, gid, d1);
-        tex_write(a.gi_d2, a, gid, d2);
-        if (!hit_some(prim_hit)) continue;
-        uint32_t used_ = 0u;
-        if (WITH_B) gi_sampling_b_cell(a, seed_b, tracing, pos, prim_hit, vres, lane_stack(a, lds), &used_, d0, d1, d2);
-    }
-}
-#endif
 void launch_gi_sampling_ab(const KArgs& a, uint32_t seed_a, uint32_t seed_b, bool reproject, hipStream_t s) {
-#if defined(ST_FAST_MATH)
-    if ((a.exp_flags & (kExpGiPool | kExpGiPoolSplit)) && a.bvh_w != nullptr && !a.anyhit_contract && !scene_fits_lds(a)) {
-        const LaunchDims d_ = launch_dims(a, true);
-        if (!d_.blocks) return;
-        const dim3 grid((d_.blocks + 1u) / 2u), block(kBlockThreads);
-        const bool split = (a.exp_flags & kExpGiPoolSplit) != 0u, s16 = a.bvh_len < stack16_limit(a);
-        const uint32_t smem = stack_lds_bytes(a, s16 ? 2 : 4), rp = reproject ? 1u : 0u;
-        if (split) {
-            if (s16) ST_KLAUNCH_SMEM((k_gi_sampling_ab_pool<false, false, uint16_t>), grid, block, smem, s, a, seed_a, seed_b, rp);
-            else ST_KLAUNCH_SMEM((k_gi_sampling_ab_pool<false, false, uint32_t>), grid, block, smem, s, a, seed_a, seed_b, rp);
-            // (pass b reads the reprojected reservoir of validation frames from gi_res[2]: this variant is measured on frames where `reproject` is 0 or tracing)
-            launch_gi_sampling_b(a, seed_b, s);
-        } else {
-            if (s16) ST_KLAUNCH_SMEM((k_gi_sampling_ab_pool<false, true, uint16_t>), grid, block, smem, s, a, seed_a, seed_b, rp);
-            else ST_KLAUNCH_SMEM((k_gi_sampling_ab_pool<false, true, uint32_t>), grid, block, smem, s, a, seed_a, seed_b, rp);
-        }
-        return;
-    }
-#endif
     ST_LAUNCH_TRACE(k_gi_sampling_ab, true, s, a, seed_a, seed_b, reproject ? 1u : 0u);
 }
 

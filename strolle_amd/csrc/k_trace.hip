@@ -173,13 +173,18 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
     const Ray ray = camera_ray(a.cam, pos);
     TriangleHit hit;
 #if ST_FAST_DEVICE
-    if (!LDS_SCENE && a.bvh_w != nullptr && a.primary_packets) {   // the tile's 64 primary rays as one packet over the wide stream
-        Candidate c;
-        const bool any = closest_hit_packet(a, ray, &c);
-        hit = closest_resolve(a, ray, c, any);
-    } else
-#endif
+    // PRIMARY hits are exact in the fast build too (round 6): Triangle::hit, the attribute interpolation and the normal's octahedral code in the island's
+    // arithmetic (st_device.h closest_resolve_exact says why: the sign of a decoded normal's z decides every hemisphere sample's tangent frame)
+    if (a.bvh_w != nullptr) a.bvh_w_exact_leaf = 1u;
+    Candidate c; bool any;
+    if (!LDS_SCENE && a.bvh_w != nullptr && a.primary_packets) any = closest_hit_packet(a, ray, &c);   // the tile's 64 primary rays as one packet over the wide stream
+    else if (a.bvh_w != nullptr) any = closest_hit_wide(a, ray, lane_stack(a, lds), &c);
+    else if (a.bvh_c != nullptr) any = closest_hit_compact(a, ray, lane_stack(a, lds), &c);
+    else used_ = traverse<false>(a, ray, kF32Max, lane_stack(a, lds), &c, &any);
+    hit = closest_resolve_exact(a, ray, c, any);
+#else
     hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
+#endif
     count_rays(a, used_);
     if (!hit_is_some(hit)) {  // LoadOp::Clear(TRANSPARENT)
         tex_write(a.g0, a, pos, f4z()); tex_write(a.g1, a, pos, f4z());
@@ -200,9 +205,14 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
     g.depth = distance(ray.origin, hit.point);
     float4 d0, d1;
     gbuffer_pack_bits(g, (a.material_base_packed && is_zero(material.base_color_texture)) ? a.material_base_packed[hit.material_id] : gbuffer_pack_base_color(g.base_color), &d0, &d1);
+#if ST_FAST_DEVICE
+    const V2 en = normal_encode_exact(hit.normal);
+    d0.y = en.x; d0.z = en.y;
+#else
+    const V2 en = normal_encode(hit.normal);
+#endif
     tex_write(a.g0, a, pos, d0);
     tex_write(a.g1, a, pos, d1);
-    const V2 en = normal_encode(hit.normal);
     const bool lean = REPROJECT && (a.lean & kLeanPrim) != 0u;
     if (!lean) tex_write(a.sm, a, pos, make_float4(en.x, en.y, g.depth, material.roughness));
     tex_write(a.sn, a, pos, f4(normal_decode(en), g.depth));

@@ -445,6 +445,34 @@ ST_D bool triangle_hit_exact(const Ray& ray, V3 p0, V3 e1, V3 e2, float limit, f
     *t_out = t; *u_out = u; *v_out = v; *inv_det_out = inv_det;
     return !((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= limit));
 }
+// closest_resolve() and normal_encode() in the island's arithmetic, for PRIMARY hits (k_trace.hip k_prim_visibility; round 6). glam's
+// Vec3::any_orthonormal_pair — behind every hemisphere sample (noise/white.rs:73-81) — branches on the SIGN of normal.z, and a wall whose normal lies in
+// the xy-plane decodes to z = +-(an ulp): the fast build's last-bit differences in the G-buffer's encoded normal flipped that sign on 0.2 % of the
+// dungeon's pixels, each flip a completely different bounce direction — the largest single consumer of the fast build's tolerance gates
+// (profiles/r06_gate_headroom.json). With the primary hit's (u, v) from triangle_hit_exact and these two, the encoded normal is the oracle's bit for bit
+// wherever the same triangle wins.
+ST_D TriangleHit closest_resolve_exact(const KArgs& a, const Ray& ray, const Candidate& c, bool any) {
+    TriangleHit h;
+    h.distance = c.t; h.material_id = c.material; h.point = v3s(0.0f); h.normal = v3s(0.0f); h.uv = v2(0.0f, 0.0f); h.xform_slot = 0u;
+    if (any) {
+        const float4 q0 = a.tri_attr[4u * c.tri], q1 = a.tri_attr[4u * c.tri + 1u], q2 = a.tri_attr[4u * c.tri + 2u], q3 = a.tri_attr[4u * c.tri + 3u];
+        const V3 n = xe::add(xe::add(xe::scale(xyz(q1), c.u), xe::scale(xyz(q2), c.v)), xe::scale(xyz(q0), (1.0f - c.u) - c.v));
+        h.normal = xe::scale(xe::normalize(n), copysignf(1.0f, c.inv_det));
+        const float u0x = q0.w, u0y = q1.w, u1x = q2.w, u1y = q3.x, u2x = q3.y, u2y = q3.z;
+        h.uv = v2((u0x + (u1x - u0x) * c.u) + (u2x - u0x) * c.v, (u0y + (u1y - u0y) * c.u) + (u2y - u0y) * c.v);
+        h.xform_slot = f2b(q3.w);
+    }
+    if (hit_is_some(h)) h.point = xe::add(ray.origin, xe::scale(ray.dir, h.distance));
+    return h;
+}
+ST_D V2 normal_encode_exact(V3 n) {  // normal.rs:9-24
+    const float s = (fabsf(n.x) + fabsf(n.y)) + fabsf(n.z);
+    n = v3(n.x / s, n.y / s, n.z / s);
+    V2 r;
+    if (n.z >= 0.0f) r = v2(n.x, n.y);
+    else r = v2(copysignf(1.0f - fabsf(n.y), n.x), copysignf(1.0f - fabsf(n.x), n.y));
+    return v2(r.x * 0.5f + 0.5f, r.y * 0.5f + 0.5f);
+}
 // Ray::intersect (shadow ray) as the contract states it: the reference's visiting order, arithmetic and `used_memory` count
 template <class SE>
 ST_D bool trace_any_contract(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
@@ -832,103 +860,6 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
     return found_any;
 }
 
-// ---- LANE REFILL for incoherent closest-hit rays (round 6; north_star's "wavefront ballot / prefix-sum ray compaction"). The GI bounce
-// rays of a wave end at very different lengths (lane utilisation 0.50 in k_gi_sampling_ab): here a workgroup's rays live in an LDS pool — two rays per
-// lane, 32 B each — and the lanes work through it: a lane whose ray has ended goes idle, and once kPoolRefillAt lanes of the wave are idle they take
-// the next rays of the pool together — ONE ballot, the rank of each idle lane among the idle (v_mbcnt), ONE ds_add_rtn_u32 on the workgroup's counter
-// per refill. Results go back into the ray's own pool slot. The walk per ray is closest_hit_wide's, step for step (same keys, same order, same
-// triangle arithmetic): which LANE traces a ray changes, not what the ray finds — the exact suite does not come here, the fast build's gates hold it.
-//   slot in : [0] = (origin.xyz, -)   [1] = (dir.xyz, valid != 0)
-//   slot out: [0] = (t, u, v, inv_det)   [1] = (triangle, material, found != 0, -)
-template <class SE>
-ST_D void closest_hit_wide_pool(const KArgs& a, float4* pool, uint32_t n_slots, uint32_t* next, SE* stack, uint32_t refill_at) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const SE* const stack_end = stack + a.stack_entries * 64u;
-    bool active = false, exhausted = n_slots == 0u || a.bvh_len == 0u;
-    uint32_t slot = 0u, cur = 0u;
-    SE* top = stack;
-    Ray ray = zero_ray(); RaySlabs rs = ray_slabs(ray);
-    Candidate best; best.t = kF32Max; best.tri = 0xffffffffu; best.material = 0u; best.u = 0.0f; best.v = 0.0f; best.inv_det = 1.0f;
-    bool found_any = false;
-    for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (n_idle == 64u && exhausted) break;
-        if (!exhausted && n_idle >= refill_at) {
-            const uint32_t first = (uint32_t)__ffsll((long long)idle) - 1u;
-            uint32_t base = 0u;
-            if (lane == first) base = atomicAdd(next, n_idle);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
-            if (!active) {
-                const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                if (idx < n_slots) {
-                    const float4 r0 = pool[2u * idx], r1 = pool[2u * idx + 1u];
-                    if (f2b(r1.w) != 0u) {
-                        slot = idx;
-                        ray.origin = xyz(r0); ray.dir = xyz(r1);
-                        rs = ray_slabs(ray);
-                        best.t = kF32Max; best.tri = 0xffffffffu; best.material = 0u; best.u = 0.0f; best.v = 0.0f; best.inv_det = 1.0f;
-                        found_any = false; cur = a.bvh_w_root; top = stack; active = true;
-                    }
-                }
-            }
-            exhausted = base + n_idle >= n_slots;   // uniform: the pool has handed out its last slot
-        }
-        if (active) {
-            bool pop = true;
-            const bool leaf = (cur & 1u) != 0u;
-            const float4* e = bvh_entry(a.bvh_w, wide_at(a, cur));
-            const float4 t0 = e[0], t1 = e[1], t2 = e[2];
-            float4 t3 = f4z();
-            if (!leaf) t3 = e[3];
-            asm volatile("" :: "v"(t0.x), "v"(t1.x), "v"(t2.x), "v"(t3.x));
-            if (!leaf) {
-                const float lim = best.t;
-                uint32_t k0 = wide_key<SE>(f2b(t0.x), f2b(t0.y), f2b(t0.z), rs, lim, t3, 0, a.bvh_w_link_mask);
-                uint32_t k1 = wide_key<SE>(f2b(t0.w), f2b(t1.x), f2b(t1.y), rs, lim, t3, 1, a.bvh_w_link_mask);
-                uint32_t k2 = wide_key<SE>(f2b(t1.z), f2b(t1.w), f2b(t2.x), rs, lim, t3, 2, a.bvh_w_link_mask);
-                uint32_t k3 = wide_key<SE>(f2b(t2.y), f2b(t2.z), f2b(t2.w), rs, lim, t3, 3, a.bvh_w_link_mask);
-                ST_WIDE_SORT4(k0, k1, k2, k3);
-                if (k3 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k3, a.bvh_w_link_mask); top += 64; } }
-                if (k2 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k2, a.bvh_w_link_mask); top += 64; } }
-                if (k1 != 0xffffffffu) { if (top < stack_end) { *top = (SE)WideKeys<SE>::link(k1, a.bvh_w_link_mask); top += 64; } else wide_walk_overflowed(a, kWalkOverflowLane); }
-                if (k0 != 0xffffffffu) { cur = WideKeys<SE>::link(k0, a.bvh_w_link_mask); pop = false; }
-            } else {
-                const uint32_t head = f2b(t0.w);
-                const V3 p0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);
-                const V3 pvec = cross(ray.dir, e2);
-                const float det = dot(e1, pvec);
-                if (!(fabsf(det) < kF32Eps)) {
-                    const float inv_det = ST_MT_RCP(det);
-                    const V3 tvec = ray.origin - p0;
-                    const float u = dot(tvec, pvec) * inv_det;
-                    const V3 qvec = cross(tvec, e1);
-                    const float v = dot(ray.dir, qvec) * inv_det;
-                    const float t = dot(e2, qvec) * inv_det;
-                    if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best.t))) {
-                        bool found = true;
-                        if (head & 2u) {
-                            const GpuMaterial m = a.materials[f2b(t1.w)];
-                            const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
-                            if (bc.w < 1.0f) found = false;
-                        }
-                        if (found) { best.t = t; best.u = u; best.v = v; best.inv_det = inv_det; best.tri = head >> 2; best.material = f2b(t1.w); found_any = true; }
-                    }
-                }
-                if (head & 1u) { cur += 2u; pop = false; }
-            }
-            if (pop) {
-                if (top > stack) { top -= 64; cur = (uint32_t)*top; }
-                else {
-                    pool[2u * slot] = make_float4(best.t, best.u, best.v, best.inv_det);
-                    pool[2u * slot + 1u] = make_float4(b2f(best.tri), b2f(best.material), b2f(found_any ? 1u : 0u), 0.0f);
-                    active = false;
-                }
-            }
-        }
-    }
-}
-
 // ---- A WAVE-WIDE PACKET over the wide stream, for coherent rays (round 5: primary visibility; StTuning::primary_packets). The 64 primary rays of
 // an 8 x 8 tile walk nearly the same nodes (host model, dungeon: 13.9 node steps per ray, 15.0 for the tile's longest ray, 15.7 in the UNION of the
 // tile's paths), yet in the per-lane loop every lane fetches its own node, sorts its own keys and keeps its own stack: ~89 VALU instructions and
@@ -993,24 +924,17 @@ ST_D bool closest_hit_packet(const KArgs& a, const Ray& ray, Candidate* best) {
             const ScalarWords r = base + leaf_words + (size_t)(cur >> 1) * 12u;
             const V3 p0 = v3(b2f(r[0]), b2f(r[1]), b2f(r[2])), e1 = v3(b2f(r[4]), b2f(r[5]), b2f(r[6])), e2 = v3(b2f(r[8]), b2f(r[9]), b2f(r[10]));
             const uint32_t head = r[3], material = r[7];
-            const V3 pvec = cross(ray.dir, e2);
-            const float det = dot(e1, pvec);
-            if (!(fabsf(det) < kF32Eps)) {
-                const float inv_det = ST_MT_RCP(det);
-                const V3 tvec = ray.origin - p0;
-                const float u = dot(tvec, pvec) * inv_det;
-                const V3 qvec = cross(tvec, e1);
-                const float v = dot(ray.dir, qvec) * inv_det;
-                const float t = dot(e2, qvec) * inv_det;
-                if (!((u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t <= 0.0f) | (t >= best->t))) {
-                    bool found = true;
-                    if (head & 2u) {
-                        const GpuMaterial m = a.materials[material];
-                        const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
-                        if (bc.w < 1.0f) found = false;
-                    }
-                    if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = head >> 2; best->material = material; found_any = true; }
+            // (the island's Triangle::hit: primary hits carry the oracle's (t, u, v) bit for bit — see closest_resolve_exact; 12 more VALU instructions per
+            // record than the contracted form with v_rcp_f32, three to five records per ray)
+            float t, u, v, inv_det;
+            if (triangle_hit_exact(ray, p0, e1, e2, best->t, &t, &u, &v, &inv_det)) {
+                bool found = true;
+                if (head & 2u) {
+                    const GpuMaterial m = a.materials[material];
+                    const float4 bc = sample_atlas(a, tri_uv(a, head >> 2, u, v), m.base_color, m.base_color_texture);
+                    if (bc.w < 1.0f) found = false;
                 }
+                if (found) { best->t = t; best->u = u; best->v = v; best->inv_det = inv_det; best->tri = head >> 2; best->material = material; found_any = true; }
             }
             if (head & 1u) { cur += 2u; continue; }
         }

@@ -4,8 +4,6 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
-timeout 600 python tools/pool_check.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6_pool_check.txt
-timeout 600 python tools/pool_check.py --subdivide 2 --frames 4 2>&1 | grep -v amdgpu.ids | sed 's/^/208k: /' | tee -a gpurun_out/r6_pool_check.txt
 line() { python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); k = d.get('kernels', {})
