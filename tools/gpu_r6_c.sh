@@ -5,7 +5,10 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
-bash tools/gpu_ab_w.sh cornell dungeon 2>&1 | tee gpurun_out/r6c_ab.txt
+# the fast build's whole-frame gates with the primary hits exact: headroom before / after by tools/gate_headroom.py
+timeout 1800 python -m pytest tests/test_gpu_fast_steady_state.py -q -m gpu 2>&1 | tail -6 | tee gpurun_out/r6c_steady.txt
+timeout 900 python -m pytest tests/test_gpu_fast_tolerance.py tests/test_gpu_parity.py -q -m gpu -x -k "packets or wide_stream or heatmap or reference_mode_psnr or every_launch or config_2 or cornell" 2>&1 | tail -5 | tee -a gpurun_out/r6c_steady.txt
+bash tools/gpu_ab_w.sh cornell dungeon dungeon134k:gi_diffuse 2>&1 | tee gpurun_out/r6c_ab.txt
 line() { python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); k = d.get('kernels', {})
