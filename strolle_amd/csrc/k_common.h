@@ -100,14 +100,10 @@ inline bool scene_fits_lds(const KArgs& a) { return a.bvh_len > 0u && a.bvh_len 
         const uint32_t n_l_ = (a_in.n_lights_buf < kLdsLights ? a_in.n_lights_buf : kLdsLights) * 7u;                            \
         for (uint32_t i_ = threadIdx.x; i_ < n_l_; i_ += kBlockThreads)                                                          \
             reinterpret_cast<float4*>(s_lights_)[i_] = reinterpret_cast<const float4*>(a_in.lights)[i_];                         \
-        /* a scene that fits LDS: its WIDE stream when the host built one for it (round 6: KArgs::bvh_w + bvh_w_bytes), else the contract stream */ \
-        const bool wide_lds_ = LDS_SCENE && a_in.bvh_w != nullptr && a_in.bvh_w_bytes != 0u;                                      \
-        if (LDS_SCENE && wide_lds_) for (uint32_t i_ = threadIdx.x; i_ < a_in.bvh_w_bytes / 16u; i_ += kBlockThreads) s_scene_bvh_[i_] = a_in.bvh_w[i_]; \
-        if (LDS_SCENE && !wide_lds_) for (uint32_t i_ = threadIdx.x; i_ < a_in.bvh_len; i_ += kBlockThreads) s_scene_bvh_[i_] = a_in.bvh[i_];  \
+        if (LDS_SCENE) for (uint32_t i_ = threadIdx.x; i_ < a_in.bvh_len; i_ += kBlockThreads) s_scene_bvh_[i_] = a_in.bvh[i_];  \
         __syncthreads();                                                                                                         \
         a.lights_lds = s_lights_;                                                                                                \
-        a.bvh_w_exact_leaf = 0u;                                                                                                 \
-        if (LDS_SCENE) { if (wide_lds_) { a.bvh_w = s_scene_bvh_; a.bvh_w_exact_leaf = 1u; } else a.bvh = s_scene_bvh_; }        \
+        if (LDS_SCENE) a.bvh = s_scene_bvh_;                                                                                     \
     }
 // For a kernel that decodes MANY G-buffer texels per lane (GI spatial resampling: every candidate neighbour's): the byte tables of the
 // decode (st_device.h kLut*, 4 KB) staged in LDS as well — seven per-lane table reads per decoded texel leave the texture-address path

@@ -416,9 +416,6 @@ struct ComposeArgs { void* out; uint32_t format, camera_mode, keep_colours; };
 #ifndef ST_FAR_COMPOSE_WAVES
 #define ST_FAR_COMPOSE_WAVES 5  // the six floats composition carries through the gather rounds do not fit the 80 registers of 6 waves per SIMD without spilling
 #endif
-// Texel `idx` of a 16-B plane through a 32-BIT byte offset (a plane is smaller than 4 GiB: 2^28 pixels): `plane[idx]` costs a 64-bit v_lshl_add_u64 per
-// access — 27 gathers per pixel here —, this form one 32-bit shift per TAP and the loads take (scalar base, 32-bit vector offset).
-ST_D float4 far_texel(const float4* plane, uint32_t byte_off) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(plane) + byte_off); }
 template <bool COMPOSE>
 __global__ __launch_bounds__(kBlockThreads, COMPOSE ? ST_FAR_COMPOSE_WAVES : 6) void k_denoise_wavelet_far(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out, const ComposeArgs co) {
     U2 pos;
@@ -453,12 +450,12 @@ __global__ __launch_bounds__(kBlockThreads, COMPOSE ? ST_FAR_COMPOSE_WAVES : 6) 
             const int k = t < 4 ? t : t + 1, ox = k % 3 - 1, oy = k / 3 - 1;
             const I2 sp = i2((int32_t)pos.x + jitter.x + ox * (int32_t)stride, (int32_t)pos.y + jitter.y + oy * (int32_t)stride);
             const bool inside = contains_i(a, sp);
-            at[t] = (inside ? (uint32_t)sp.y * a.width + (uint32_t)sp.x : center) << 4;  // (byte offset) an out-of-bounds tap reads the centre and is masked below
-            ssn[t] = far_texel(a.sn, at[t]);
+            at[t] = inside ? (uint32_t)sp.y * a.width + (uint32_t)sp.x : center;  // an out-of-bounds tap reads the centre and is masked below
+            ssn[t] = a.sn[at[t]];
             if (!inside) ssn[t].w = 0.0f;
         }
 #pragma unroll
-        for (int t = 0; t < 8; t++) if (!wavelet_shared(c, ssn[t], &dw[t], &nw[t])) { dw[t] = 0.0f; nw[t] = 0.0f; at[t] = center << 4; }  // a dead tap re-reads the centre's line
+        for (int t = 0; t < 8; t++) if (!wavelet_shared(c, ssn[t], &dw[t], &nw[t])) { dw[t] = 0.0f; nw[t] = 0.0f; at[t] = center; }  // a dead tap re-reads the centre's line
     }
     __builtin_amdgcn_sched_barrier(0);
     float4 res_di;
@@ -466,7 +463,7 @@ __global__ __launch_bounds__(kBlockThreads, COMPOSE ? ST_FAR_COMPOSE_WAVES : 6) 
         WaveletSignal sg = signal_begin(cdi, 2.5f, 0.5f);
         float4 tap[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) tap[t] = far_texel(di_in, at[t]);
+        for (int t = 0; t < 8; t++) tap[t] = di_in[at[t]];
 #pragma unroll
         for (int t = 0; t < 8; t++) if (dw[t] != 0.0f) signal_tap(sg, tap[t], dw[t], nw[t]);
         res_di = signal_end(sg);
@@ -477,7 +474,7 @@ __global__ __launch_bounds__(kBlockThreads, COMPOSE ? ST_FAR_COMPOSE_WAVES : 6) 
         WaveletSignal sg = signal_begin(gi_in[center], 1.0f, 0.0f);
         float4 tap[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) tap[t] = far_texel(gi_in, at[t]);
+        for (int t = 0; t < 8; t++) tap[t] = gi_in[at[t]];
 #pragma unroll
         for (int t = 0; t < 8; t++) if (dw[t] != 0.0f) signal_tap(sg, tap[t], dw[t], nw[t]);
         const float4 res_gi = signal_end(sg);

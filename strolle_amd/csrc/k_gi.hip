@@ -493,20 +493,6 @@ ST_D GiReservoir gi_mid_value(const KArgs& a, uint32_t seed, const float4* mid, 
     const PreviewPass p = gi_preview_pass_if_alone(seed, pos, gi_read(a.gi_mid_src, idx, n));
     return p.max_samples == 0u ? gi_after_store(p.r) : gi_read(mid, idx, n);
 }
-// SPECULATE (the launch that serves the flagged pixels of k_gi_preview_both): that launch is as long as ONE pixel's chain of dependent loads — eight taps of
-// (surface texel -> input-plane record -> first-pass record), 17 us of its 20 — and nearly all of its lanes have left: bytes are free, round trips are not.
-// A tap's three addresses are known as soon as its position is drawn, so its loads are issued TOGETHER, before the surface tests say whether the records
-// will be used: one round trip per tap instead of three. The values, the tests and their order are unchanged.
-// gi_mid_value with both of its records fetched in one round trip (the launch that serves the flagged pixels: see SPECULATE below)
-ST_D GiReservoir gi_mid_value_both(const KArgs& a, uint32_t seed, const float4* mid, U2 pos, uint32_t idx) {
-    float4 q[8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { q[k] = mid[4u * idx + k]; q[4 + k] = a.gi_mid_src[4u * idx + k]; }
-    asm volatile("" :: "v"(q[0].x), "v"(q[1].x), "v"(q[2].x), "v"(q[3].x), "v"(q[4].x), "v"(q[5].x), "v"(q[6].x), "v"(q[7].x));
-    const PreviewPass p = gi_preview_pass_if_alone(seed, pos, gi_from_texels(q[4], q[5], q[6], q[7]));
-    return p.max_samples == 0u ? gi_after_store(p.r) : gi_from_texels(q[0], q[1], q[2], q[3]);
-}
-template <bool SPECULATE = false>
 ST_D PreviewPass gi_preview_pass(const KArgs& a, uint32_t seed, uint32_t nth, const float4* in, U2 center_pos, bool center_some, const GiReservoir& center,
                                  Hit center_hit, bool hit_ready) {
     PreviewPass o; o.r = gi_empty(); o.keep_stored = false; o.max_samples = 0u;
@@ -528,26 +514,15 @@ ST_D PreviewPass gi_preview_pass(const KArgs& a, uint32_t seed, uint32_t nth, co
         const V2 disk = wn.sample_disk();
         const U2 sample_pos = camera_contain(a, as_i2(as_v2(center_pos) + disk * max_radius));
         if (sample_pos.x == center_pos.x && sample_pos.y == center_pos.y) { o.keep_stored = true; break; }  // sic: `return`, not `continue`
-        const uint32_t sample_idx = screen_to_idx(a, sample_pos);
-        const float4 sn_texel = tex_read(a.sn, a, sample_pos);
-        float4 q[8];   // SPECULATE: the tap's record in `in` (q[0..3]) and, in the lean frame's second pass, in the first pass's input plane (q[4..7])
-        const bool two_planes = nth != 0u && a.gi_mid_src != nullptr;
-        if (SPECULATE) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) { q[k] = in[4u * sample_idx + k]; q[4 + k] = two_planes ? a.gi_mid_src[4u * sample_idx + k] : f4z(); }
-            asm volatile("" :: "v"(sn_texel.x), "v"(q[0].x), "v"(q[1].x), "v"(q[2].x), "v"(q[3].x), "v"(q[4].x), "v"(q[5].x), "v"(q[6].x), "v"(q[7].x));   // one round trip for the nine loads
-        }
-        const Surface ss = surface_decoded(sn_texel);
+        const Surface ss = surface_decoded(tex_read(a.sn, a, sample_pos));
         if (ss.depth == 0.0f) continue;
         if (fabsf(ss.depth - center_hit.g.depth) > 0.25f * center_hit.g.depth) continue;
         if (dot(ss.normal, center_hit.g.normal) < 0.5f) continue;
-        GiReservoir s;
-        if (SPECULATE) {
-            if (two_planes) {   // gi_mid_value with both records already here
-                const PreviewPass alone = gi_preview_pass_if_alone(seed, sample_pos, gi_from_texels(q[4], q[5], q[6], q[7]));
-                s = alone.max_samples == 0u ? gi_after_store(alone.r) : gi_from_texels(q[0], q[1], q[2], q[3]);
-            } else s = gi_from_texels(q[0], q[1], q[2], q[3]);
-        } else s = two_planes ? gi_mid_value(a, seed, in, sample_pos, sample_idx, n) : gi_read(in, sample_idx, n);
+        const uint32_t sample_idx = screen_to_idx(a, sample_pos);
+        // (Measured and not kept, round 6: in the launch that serves the flagged pixels, a tap's three records — surface texel, input-plane record, first-pass
+        // record — fetched TOGETHER before the surface tests, one round trip instead of three: 17.0 -> 19.4 us on Cornell, 17.3 -> 18.7 on the dungeon
+        // (profiles/r06_ab_vs_r05.txt against r06_ab_exact_primary.txt rows A): most taps of a flagged pixel fail the surface tests after ONE load, and now waited for nine.)
+        const GiReservoir s = (nth != 0u && a.gi_mid_src) ? gi_mid_value(a, seed, in, sample_pos, sample_idx, n) : gi_read(in, sample_idx, n);
         if (s.m == 0.0f) continue;
         const float sample_pdf = gi_pdf(s.s, center_hit);
         float sample_jacobian = gi_jacobian(s.s, center_hit.point);
@@ -591,10 +566,9 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
     ReprojectHistory history;  // fetched ahead of the resampling loop (st_passes.h)
     if (RESOLVE && reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
     GiReservoir center;
-    if (RESOLVE && a.gi_mid_src) center = center_some ? (a.gi_preview_late ? gi_mid_value_both(a, seed, in, center_pos, center_idx) : gi_mid_value(a, seed, in, center_pos, center_idx, n)) : gi_empty();  // lean frame: see gi_mid_value
+    if (RESOLVE && a.gi_mid_src) center = center_some ? gi_mid_value(a, seed, in, center_pos, center_idx, n) : gi_empty();  // lean frame: see gi_mid_value
     else center = gi_read_own(in, center_idx, true, center_some);  // quad-transposed (st_device.h): before the branch
-    const PreviewPass pass = (RESOLVE && a.gi_preview_late) ? gi_preview_pass<true>(a, seed, nth, in, center_pos, center_some, center, center_hit, RESOLVE)
-                                                            : gi_preview_pass<false>(a, seed, nth, in, center_pos, center_some, center, center_hit, RESOLVE);
+    const PreviewPass pass = gi_preview_pass(a, seed, nth, in, center_pos, center_some, center, center_hit, RESOLVE);
     GiReservoir main_ = pass.r;
     if (!RESOLVE) {
         gi_write_own(out, center_idx, main_, true, !pass.keep_stored);

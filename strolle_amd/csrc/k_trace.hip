@@ -175,10 +175,9 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
 #if ST_FAST_DEVICE
     // PRIMARY hits are exact in the fast build too (round 6): Triangle::hit, the attribute interpolation and the normal's octahedral code in the island's
     // arithmetic (st_device.h closest_resolve_exact says why: the sign of a decoded normal's z decides every hemisphere sample's tangent frame)
-    if (a.bvh_w != nullptr) a.bvh_w_exact_leaf = 1u;
     Candidate c; bool any;
     if (!LDS_SCENE && a.bvh_w != nullptr && a.primary_packets) any = closest_hit_packet(a, ray, &c);   // the tile's 64 primary rays as one packet over the wide stream
-    else if (a.bvh_w != nullptr) any = closest_hit_wide(a, ray, lane_stack(a, lds), &c);
+    else if (a.bvh_w != nullptr) any = closest_hit_wide<SE, true>(a, ray, lane_stack(a, lds), &c);
     else if (a.bvh_c != nullptr) any = closest_hit_compact(a, ray, lane_stack(a, lds), &c);
     else used_ = traverse<false>(a, ray, kF32Max, lane_stack(a, lds), &c, &any);
     hit = closest_resolve_exact(a, ray, c, any);

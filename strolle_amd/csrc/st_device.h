@@ -398,7 +398,7 @@ ST_D uint32_t traverse(const KArgs& a, const Ray& ray, float max_t, SE* stack, C
 }
 // Ray::trace (closest hit) with attributes resolved once, for the winning triangle.
 template <class SE> ST_D bool closest_hit_compact(const KArgs& a, const Ray& ray, SE* stack, Candidate* best);
-template <class SE> ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate* best);
+template <class SE, bool EXACT_LEAF = false> ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate* best);
 ST_D TriangleHit closest_resolve(const KArgs& a, const Ray& ray, const Candidate& c, bool any);
 template <class SE>
 ST_D TriangleHit trace_closest(const KArgs& a, const Ray& ray, SE* stack, uint32_t* used_memory) {
@@ -431,7 +431,7 @@ ST_D TriangleHit closest_resolve(const KArgs& a, const Ray& ray, const Candidate
 // glam Affine3A::transform_point3 with the transform stored as 4 float4 (x, y, z axes, translation)
 ST_D V3 affine_point(const float4* m, V3 p) { return ((xyz(m[0]) * p.x) + (xyz(m[1]) * p.y) + (xyz(m[2]) * p.z)) + xyz(m[3]); }
 // Triangle::hit's accept / reject and (t, u, v, 1 / det) for a hit-test record (p0, e1, e2), in the island's arithmetic: what traverse() computes for a leaf
-// entry, for walks over OTHER streams that owe the contract walk's bits (the wide stream of a scene that lives in LDS: closest_hit_wide)
+// entry, for walks over OTHER streams that owe the contract walk's bits (primary rays over the wide stream: closest_hit_wide<SE, true>, closest_hit_packet)
 ST_D bool triangle_hit_exact(const Ray& ray, V3 p0, V3 e1, V3 e2, float limit, float* t_out, float* u_out, float* v_out, float* inv_det_out) {
     const V3 pvec = xe::cross(ray.dir, e2);
     const float det = xe::dot(e1, pvec);
@@ -801,7 +801,8 @@ ST_D bool any_hit_wide(const KArgs& a, const Ray& ray, SE* stack) {
     }
     return hit;
 }
-template <class SE>
+// EXACT_LEAF (primary rays, round 6): leaf records are tested with the exact island's Triangle::hit — (t, u, v) bit-identical to the contract walk's for the same triangle
+template <class SE, bool EXACT_LEAF>
 ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate* best) {
     best->t = kF32Max; best->tri = 0xffffffffu; best->material = 0u; best->u = 0.0f; best->v = 0.0f; best->inv_det = 1.0f;
     if (a.bvh_len == 0u) return false;
@@ -833,7 +834,7 @@ ST_D bool closest_hit_wide(const KArgs& a, const Ray& ray, SE* stack, Candidate*
             const V3 p0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);
             float t, u, v, inv_det;
             bool found;
-            if (a.bvh_w_exact_leaf) found = triangle_hit_exact(ray, p0, e1, e2, best->t, &t, &u, &v, &inv_det);   // (a scene that lives in LDS: a constant per kernel, k_common.h ST_SCENE_PROLOGUE)
+            if (EXACT_LEAF) found = triangle_hit_exact(ray, p0, e1, e2, best->t, &t, &u, &v, &inv_det);
             else {
                 const V3 pvec = cross(ray.dir, e2);
                 const float det = dot(e1, pvec);

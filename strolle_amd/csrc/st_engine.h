@@ -466,7 +466,6 @@ struct Engine {
     //    fabric (algorithmic: 174 MB) and takes 61 instead of 56 us on its own.
     //  * tile_map = 1 measured best on MI355X with the current kernels (2 was, before the LDS-staged denoiser).
     StTuning tuning;
-    static constexpr uint32_t kExpWideLds = 0x400u;   // ST_EXP bit: scenes that fit LDS walk their WIDE stream from LDS (exact leaf test) instead of the contract stream
     uint32_t exp_flags = 0;   // KArgs::exp_flags (ST_EXP): same-box A/B of an experiment before it is kept or archived
     bool profiling = false;       // st_profile_enable bit 0: per-kernel event timing (serial execution)
     bool count_bytes = false;     // st_profile_enable bit 1: traversal-byte counters

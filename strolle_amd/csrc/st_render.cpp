@@ -128,15 +128,11 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
     if (scene.device_built && contract_observer)
         return fail(ST_ERR_INVALID_ARGUMENT, "the live scene copy's tree was built on the device (ST_BVH_BUILD_DEVICE) and this frame needs the contract stream (heatmap camera, exact arithmetic, "
                                              "byte counting or a switched-off wide stream): st_tick builds it on the host once it sees the observer");
-    // (a scene that fits LDS has no compact stream; its wide stream — built only behind kExpWideLds — is walked from LDS, per lane, with the exact leaf test)
-    const bool wide_lds = !contract_observer && (exp_flags & kExpWideLds) && device_bvh_len != 0u && device_bvh_len <= kLdsSceneTexels && scene.wide_for_entries != 0u &&
-                          scene.wide_for_entries * 4u == device_bvh_len && (size_t)scene.wide_nodes * 64u + (size_t)scene.wide_leaves * 48u <= (size_t)kLdsSceneTexels * 16u;
-    const bool wide = scene.device_built || (compact && tuning.wide_bvh && scene.wide_for_entries != 0u && scene.wide_for_entries * 4u == device_bvh_len) || wide_lds;
+    const bool wide = scene.device_built || (compact && tuning.wide_bvh && scene.wide_for_entries != 0u && scene.wide_for_entries * 4u == device_bvh_len);
     a.bvh_w = wide ? static_cast<const float4*>(scene.bvh_wide.ptr) : nullptr;
     a.bvh_w_leaf_off = wide ? scene.wide_nodes * 64u : 0u;
     a.bvh_w_root = wide ? scene.wide_root : 0u; a.bvh_w_links16 = wide ? scene.wide_links16 : 0u;
-    a.primary_packets = wide && !wide_lds && tuning.primary_packets && !packets_overflowed ? 1u : 0u;   // (the packet walk fetches with scalar loads: not from LDS)
-    a.bvh_w_bytes = wide_lds ? scene.wide_nodes * 64u + scene.wide_leaves * 48u : 0u;
+    a.primary_packets = wide && tuning.primary_packets && !packets_overflowed ? 1u : 0u;
     a.walk_flags = walk_flags_dev;
     {   // the largest link of this stream: (max(nodes, leaf records) - 1) << 1 | 1
         uint32_t bits = 16u;

@@ -401,10 +401,7 @@ int Engine::tick(hipStream_t stream) {
 // The wide stream (k_bvh.hip k_bvh_wide) of device copy `t`: topology from the host when the tree was (re)sent, boxes and leaf records from that
 // copy's contract stream as it is on the device right now.
 int Engine::refresh_wide_stream(SceneSet& t, hipStream_t up, bool topology_changed, bool* pageable) {
-    // (scenes that fit LDS: their tracing kernels walk the contract stream from LDS — or, round 6, behind ST_EXP bit kExpWideLds while it is measured, the WIDE
-    // stream from LDS with the exact island's triangle test: k_common.h ST_SCENE_PROLOGUE)
-    const bool lds_scene = device_bvh_len <= kLdsSceneTexels;
-    if (!tuning.wide_bvh || !tuning.compact_bvh || (lds_scene && !(exp_flags & kExpWideLds))) { t.wide_nodes = t.wide_leaves = 0u; t.wide_for_entries = 0u; return ST_OK; }
+    if (!tuning.wide_bvh || !tuning.compact_bvh || device_bvh_len <= kLdsSceneTexels) { t.wide_nodes = t.wide_leaves = 0u; t.wide_for_entries = 0u; return ST_OK; }
     int rc;
     if (topology_changed || t.wide_for_entries != device_bvh_len / 4u) {
         if (!topology_changed && wide_built_for_ != tree_version) return ST_OK;   // (cannot happen: a copy on the device path holds this tree's topology)

@@ -91,8 +91,6 @@ struct KArgs {
     uint32_t bvh_w_root;       // ... the root's link (index << 1 | is a leaf record)
     uint32_t primary_packets;  // ... 1: primary visibility walks it as ONE packet per wave (st_device.h closest_hit_packet; StTuning::primary_packets)
     uint32_t bvh_w_link_mask;  // ... 32-bit form: (1 << bits) - 1, bits = what the largest link needs (the sort key keeps the link there)
-    uint32_t bvh_w_bytes;      // ... nodes + leaf records in bytes: tracing kernels of a scene that fits LDS copy THAT into LDS instead of the contract stream (round 6)
-    uint32_t bvh_w_exact_leaf; // ... set by those kernels' prologue: leaf records are tested with the exact island's arithmetic (closest hits bit-identical to the contract walk's, ties aside)
     uint32_t bvh_w_links16;    // ... 1: links are 16-bit (fewer than 32768 nodes and leaf records): kernels run with 16-bit stack slots
     uint32_t* walk_flags;      // ... two sticky words in page-locked host memory: [0] a per-lane wide walk, [1] the packet walk found its stack full and DROPPED a push (st_device.h wide_walk_overflowed; st_tick.cpp reads them)
     uint32_t exp_flags;        // A/B switches of experiments in flight (ST_EXP in the environment; 0 in the shipped configuration)
