@@ -449,7 +449,7 @@ ST_D bool triangle_hit_exact(const Ray& ray, V3 p0, V3 e1, V3 e2, float limit, f
 // Vec3::any_orthonormal_pair — behind every hemisphere sample (noise/white.rs:73-81) — branches on the SIGN of normal.z, and a wall whose normal lies in
 // the xy-plane decodes to z = +-(an ulp): the fast build's last-bit differences in the G-buffer's encoded normal flipped that sign on 0.2 % of the
 // dungeon's pixels, each flip a completely different bounce direction — the largest single consumer of the fast build's tolerance gates
-// (profiles/r06_gate_headroom.json). With the primary hit's (u, v) from triangle_hit_exact and these two, the encoded normal is the oracle's bit for bit
+// (profiles/r06_gate_headroom.json). With the primary hit's (u, v) from triangle_hit_exact and these two, the encoded normal is the CPU restatement's bit for bit
 // wherever the same triangle wins.
 ST_D TriangleHit closest_resolve_exact(const KArgs& a, const Ray& ray, const Candidate& c, bool any) {
     TriangleHit h;
@@ -925,7 +925,7 @@ ST_D bool closest_hit_packet(const KArgs& a, const Ray& ray, Candidate* best) {
             const ScalarWords r = base + leaf_words + (size_t)(cur >> 1) * 12u;
             const V3 p0 = v3(b2f(r[0]), b2f(r[1]), b2f(r[2])), e1 = v3(b2f(r[4]), b2f(r[5]), b2f(r[6])), e2 = v3(b2f(r[8]), b2f(r[9]), b2f(r[10]));
             const uint32_t head = r[3], material = r[7];
-            // (the island's Triangle::hit: primary hits carry the oracle's (t, u, v) bit for bit — see closest_resolve_exact; 12 more VALU instructions per
+            // (the island's Triangle::hit: primary hits carry the CPU restatement's (t, u, v) bit for bit — see closest_resolve_exact; 12 more VALU instructions per
             // record than the contracted form with v_rcp_f32, three to five records per ray)
             float t, u, v, inv_det;
             if (triangle_hit_exact(ray, p0, e1, e2, best->t, &t, &u, &v, &inv_det)) {
