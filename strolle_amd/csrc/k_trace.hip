@@ -175,12 +175,17 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
 #if ST_FAST_DEVICE
     // PRIMARY hits are exact in the fast build too (round 6): Triangle::hit, the attribute interpolation and the normal's octahedral code in the island's
     // arithmetic (st_device.h closest_resolve_exact says why: the sign of a decoded normal's z decides every hemisphere sample's tangent frame)
-    Candidate c; bool any;
-    if (!LDS_SCENE && a.bvh_w != nullptr && a.primary_packets) any = closest_hit_packet(a, ray, &c);   // the tile's 64 primary rays as one packet over the wide stream
-    else if (a.bvh_w != nullptr) any = closest_hit_wide<SE, true>(a, ray, lane_stack(a, lds), &c);
-    else if (a.bvh_c != nullptr) any = closest_hit_compact(a, ray, lane_stack(a, lds), &c);
-    else used_ = traverse<false>(a, ray, kF32Max, lane_stack(a, lds), &c, &any);
-    hit = closest_resolve_exact(a, ray, c, any);
+    // (a scene that lives in LDS — the Cornell box — keeps round 5's path: its contract walk is the island's already, its gates have 17 dB to spare, and the
+    // exact interpolation + octahedral code would cost its headline 2-3 us per frame)
+    if (LDS_SCENE) hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
+    else {
+        Candidate c; bool any;
+        if (a.bvh_w != nullptr && a.primary_packets) any = closest_hit_packet(a, ray, &c);   // the tile's 64 primary rays as one packet over the wide stream
+        else if (a.bvh_w != nullptr) any = closest_hit_wide<SE, true>(a, ray, lane_stack(a, lds), &c);
+        else if (a.bvh_c != nullptr) any = closest_hit_compact(a, ray, lane_stack(a, lds), &c);
+        else used_ = traverse<false>(a, ray, kF32Max, lane_stack(a, lds), &c, &any);
+        hit = closest_resolve_exact(a, ray, c, any);
+    }
 #else
     hit = trace_closest(a, ray, lane_stack(a, lds), &used_);
 #endif
@@ -205,7 +210,7 @@ __global__ ST_KERNEL_BOUNDS void k_prim_visibility(const KArgs a_in) {
     float4 d0, d1;
     gbuffer_pack_bits(g, (a.material_base_packed && is_zero(material.base_color_texture)) ? a.material_base_packed[hit.material_id] : gbuffer_pack_base_color(g.base_color), &d0, &d1);
 #if ST_FAST_DEVICE
-    const V2 en = normal_encode_exact(hit.normal);
+    const V2 en = LDS_SCENE ? normal_encode(hit.normal) : normal_encode_exact(hit.normal);
     d0.y = en.x; d0.z = en.y;
 #else
     const V2 en = normal_encode(hit.normal);

@@ -20,3 +20,4 @@ tail -1 gpurun_out/tiles_config4_4.json | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print('config4 tiles', d['tiles'], 'full', d['full_frame_ms'], d['equal_split']['per_tile_ms'], d['equal_split']['max_over_mean'], d['equal_split']['predicted_speedup'])"
 (timeout 600 python tools/spawn_cost.py --subdivide 2 --refresh 0 4 3; timeout 600 python tools/spawn_cost.py --subdivide 0 --refresh 0 4 3) 2>/dev/null | grep "refresh mode" | tee gpurun_out/r06_spawn_cost.txt
+bash tools/gpu_lbvh_profile.sh 2>&1 | tail -45
