@@ -298,6 +298,10 @@ int Engine::tick(hipStream_t stream) {
                 // later changes of this scene go to the device builder: its arrays are allocated NOW, while the scene loads, for both copies — BEFORE the
                 // wide stream of this copy is written below (its allocation is one of them: growing it afterwards would throw the stream away: round 6's
                 // first version did, and rendered an empty world). A failure here is not an error: the build allocates what it finds missing.
+                {   // ... and the host's triangle arrays get the same headroom now, so that the first spawn does not reallocate and copy them (60 MB at 208 k triangles: 7 ms)
+                    const size_t want = triangles.size() + triangles.size() / 8u;
+                    triangles.reserve(want); prims.reserve(want); prim_alive.reserve(want); tri_geo.reserve(3 * want); tri_attr.reserve(4 * want); tri_bounds.reserve(2 * want);
+                }
                 for (SceneSet& c : sets) {
                     if (reserve_device_builder(c, prims.size() + prims.size() / 8u, (uint32_t)std::min<size_t>(live_prims_ + live_prims_ / 8u, prims.size() + prims.size() / 8u)) != ST_OK) { (void)hipGetLastError(); break; }
                 }
