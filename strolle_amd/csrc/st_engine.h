@@ -255,7 +255,6 @@ struct CameraState {
     // passes behind frame N's are per camera, so cameras rendered on different caller streams never wait on — or race
     // with — each other's frames.
     hipStream_t side_stream = nullptr;
-    hipStream_t main_masked = nullptr; hipEvent_t ev_main_in = nullptr, ev_main_out = nullptr;   // (ST_SIDE_CUS experiment, st_render.cpp: the caller's stream's share of the frame on a CU-masked stream of the engine's own)
     hipEvent_t ev_di_head = nullptr, ev_gi_done = nullptr, ev_prim_ok = nullptr, ev_frame_done = nullptr, ev_setup = nullptr;
     bool have_prev_frame_events = false;
     // GI history hand-over without the copy. gi_resolving ends every frame by copying the frame's source reservoirs into

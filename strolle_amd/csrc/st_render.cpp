@@ -10,9 +10,6 @@ void Engine::release_camera(CameraState& c) {
     c.tile_mask = nullptr;
     c.slab = nullptr; c.counters = nullptr;
     if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
-    if (c.main_masked) (void)hipStreamDestroy(c.main_masked);
-    for (hipEvent_t* e : {&c.ev_main_in, &c.ev_main_out}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
-    c.main_masked = nullptr;
     for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
     c.side_stream = nullptr; c.have_prev_frame_events = false;
     if (c.present_stream) { (void)hipStreamSynchronize(c.present_stream); (void)hipStreamDestroy(c.present_stream); c.present_stream = nullptr; }
@@ -423,32 +420,9 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
                 int least = 0, greatest = 0;
                 (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
                 const int priority = tuning.side_priority > 0 ? greatest : (tuning.side_priority < 0 ? least : 0);
-                // EXPERIMENT (round 6, ST_SIDE_CUS=<n> [ST_SIDE_CU_LAYOUT=0|1] [ST_MAIN_COMPLEMENT=1]): the two streams' kernels do not share a CU's LDS, wave
-                // slots and L1 well (co-run efficiency G = 1.1, "What the two streams can and cannot buy") — give each its own CUs instead: the side stream n of
-                // the device's CUs (hipExtStreamCreateWithCUMask), optionally the caller's share of the frame the others (on a masked stream of the engine's own,
-                // joined to the caller's stream by events at both ends).
-                static const int side_cus = getenv("ST_SIDE_CUS") ? atoi(getenv("ST_SIDE_CUS")) : 0;
-                static const int cu_layout = getenv("ST_SIDE_CU_LAYOUT") ? atoi(getenv("ST_SIDE_CU_LAYOUT")) : 0;
-                static const bool main_complement = getenv("ST_MAIN_COMPLEMENT") != nullptr && atoi(getenv("ST_MAIN_COMPLEMENT")) != 0;
-                hipDeviceProp_t prop; ST_HIP(hipGetDeviceProperties(&prop, device));
-                const int total = prop.multiProcessorCount;
-                if (side_cus > 0 && side_cus < total) {
-                    std::vector<uint32_t> side((size_t)(total + 31) / 32, 0u), rest((size_t)(total + 31) / 32, 0u);
-                    for (int i = 0; i < total; i++) {
-                        const bool to_side = cu_layout == 0 ? i < side_cus : ((long long)(i + 1) * side_cus / total) != ((long long)i * side_cus / total);   // contiguous, or spread evenly
-                        (to_side ? side : rest)[(size_t)i / 32] |= 1u << (i % 32);
-                    }
-                    ST_HIP(hipExtStreamCreateWithCUMask(&c.side_stream, (uint32_t)side.size(), side.data()));
-                    if (main_complement) {
-                        ST_HIP(hipExtStreamCreateWithCUMask(&c.main_masked, (uint32_t)rest.size(), rest.data()));
-                        for (hipEvent_t* e : {&c.ev_main_in, &c.ev_main_out}) ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-                    }
-                } else
                 ST_HIP(hipStreamCreateWithPriority(&c.side_stream, hipStreamNonBlocking, priority));
                 for (hipEvent_t* e : {&c.ev_di_head, &c.ev_gi_done, &c.ev_prim_ok, &c.ev_frame_done, &c.ev_setup}) ST_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
             }
-            hipStream_t main_s = stream;
-            if (c.main_masked) { ST_HIP(hipEventRecord(c.ev_main_in, stream)); ST_HIP(hipStreamWaitEvent(c.main_masked, c.ev_main_in, 0)); main_s = c.main_masked; }
             // LUT generation issued on `stream` in this call must precede the side stream's consumers. (Do NOT do this
             // unconditionally: an event recorded on `stream` here completes only after frame N's denoiser, which would
             // serialise prim(N+1) behind it. Uploads in st_tick are followed by a host-side stream sync.)
@@ -466,20 +440,19 @@ int Engine::render(CameraState& c, void* out, hipStream_t stream) {
             if (c.have_prev_frame_events) ST_HIP(hipStreamWaitEvent(c.side_stream, c.ev_frame_done, 0));
             do_gi_tail();
             ST_HIP(hipEventRecord(c.ev_gi_done, c.side_stream));
-            cur = main_s;
-            ST_HIP(hipStreamWaitEvent(main_s, c.ev_di_head, 0));
+            cur = stream;
+            ST_HIP(hipStreamWaitEvent(stream, c.ev_di_head, 0));
             if (tuning.di_head_on_main) do_di_head();
             do_di_tail();
             // stand-alone denoise reprojection kernels (unfused path) still read the reprojection map: prim(N+1) may
             // only start once they are through
             const bool reproject_later = denoise && !tuning.fuse;
-            if (!reproject_later) ST_HIP(hipEventRecord(c.ev_prim_ok, main_s));
-            ST_HIP(hipStreamWaitEvent(main_s, c.ev_gi_done, 0));
+            if (!reproject_later) ST_HIP(hipEventRecord(c.ev_prim_ok, stream));
+            ST_HIP(hipStreamWaitEvent(stream, c.ev_gi_done, 0));
             do_denoise();
-            if (reproject_later) ST_HIP(hipEventRecord(c.ev_prim_ok, main_s));
+            if (reproject_later) ST_HIP(hipEventRecord(c.ev_prim_ok, stream));
             do_compose();
-            ST_HIP(hipEventRecord(c.ev_frame_done, main_s));
-            if (c.main_masked) { ST_HIP(hipEventRecord(c.ev_main_out, main_s)); ST_HIP(hipStreamWaitEvent(stream, c.ev_main_out, 0)); cur = stream; }
+            ST_HIP(hipEventRecord(c.ev_frame_done, stream));
             c.have_prev_frame_events = true;
         } else {
             do_prim();
