@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Round 6, archived experiment: the ST_EXP bits below exist only with tools/experiments/gi_sampling_pool.inc applied to the tree.)
 # On the GPU box: the lane-refill pool for the GI bounce rays (ST_EXP 0x100 fused / 0x200 split; bits 12-15: refill threshold / 4) — same bits as the
 # plain launch? what do the launches cost? lane utilisation by the SQ counters. -> gpurun_out/r6_pool_*.txt
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
