@@ -584,25 +584,17 @@ __global__ ST_KERNEL_BOUNDS void k_gi_preview(const KArgs a, uint32_t seed, uint
 // gi_res[3] and a second decode of the G-buffer go away. The first pass's result is stored for every pixel as always (a
 // neighbour's second pass may draw it); pixels whose second pass does resample — or whose first pass hit the early `return`
 // — are flagged per tile and served by k_gi_preview<true> afterwards, when every first-pass result is in memory.
-// W6 (round 6; VERDICT r5 item 6 "more waves or fewer round trips"): the kernel waits (wait_any 0.78) at 93 VGPRs = 5 waves per SIMD, and asking the allocator
-// for 6 spilled (round 5: 32 B, slower). Two live ranges make the difference: the decoded Hit (23 registers, decoded before the two passes, needed after them) and
-// the denoiser's history texels (fetched ahead of the passes to hide their round trip). With the second G-buffer texel requested early but DECODED after the passes
-// (a pixel whose first pass does draw neighbours decodes it there: gi_preview_pass, hit_ready = false) and the history fetched after them, the kernel fits 80
-// VGPRs — 6 waves — without a spill: one round trip more per wave, one wave more per SIMD to hide it under.
-template <bool W6>
-__global__ __launch_bounds__(kBlockThreads, W6 ? 6 : 1) void k_gi_preview_both(const KArgs a, uint32_t seed, const float4* in, float4* mid, uint32_t source, uint32_t reproject) {
+__global__ ST_KERNEL_BOUNDS void k_gi_preview_both(const KArgs a, uint32_t seed, const float4* in, float4* mid, uint32_t source, uint32_t reproject) {
     U2 center_pos;
     if (!resolve_gid(a, false, &center_pos) || !owns_pixel(a, center_pos)) return;
     const uint32_t center_idx = screen_to_idx(a, center_pos);
     const float4 center_g0 = tex_read(a.g0, a, center_pos);
     const bool center_some = center_g0.x != 0.0f;
-    float4 center_g1 = f4z();
-    Hit center_hit = hit_zero();
-    if (W6) center_g1 = tex_read(a.g1, a, center_pos); else center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
+    const Hit center_hit = pixel_hit(a, a.cam, a.g0, a.g1, center_pos);
     ReprojectHistory history;
-    if (!W6 && reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
+    if (reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
     const GiReservoir center0 = gi_read_own(in, center_idx, true, center_some);
-    const PreviewPass first = gi_preview_pass(a, seed, 0u, in, center_pos, center_some, center0, center_hit, !W6);
+    const PreviewPass first = gi_preview_pass(a, seed, 0u, in, center_pos, center_some, center0, center_hit, true);
     // lean frame: a result that is the plain normalisation of the input needs no slot (gi_mid_value rebuilds it where it is read)
     gi_write_own(mid, center_idx, first.r, true, !first.keep_stored && !((a.lean & kLeanGiMid) && (!center_some || first.max_samples == 0u)));
     // second pass, if it is the neighbour-free kind: its `center` is what gi_read would return for the record just stored
@@ -615,10 +607,6 @@ __global__ __launch_bounds__(kBlockThreads, W6 ? 6 : 1) void k_gi_preview_both(c
     const unsigned long long flagged = __ballot(late), active = __ballot(true);
     if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)active) - 1u) a.gi_late_mask[gi_late_index(a, center_pos)] = flagged;
     if (late) return;
-    if (W6) {
-        center_hit = hit_make(camera_ray_shading(a.cam, center_pos), gbuffer_unpack(a, center_g0, center_g1));   // = pixel_hit(): the same texels, decoded here
-        if (reproject) history = denoise_reproject_prefetch(a, center_pos, a.gi_diff_prev_colors, a.gi_diff_prev_moments);
-    }
     const float4 diff = gi_resolve_pixel(a, center_pos, center_idx, center_hit, second.r, source, reproject != 0u);
     if (reproject) denoise_reproject_finish(a, center_pos, diff, history, a.gi_diff_curr_colors, a.gi_diff_moments);
 }
@@ -629,8 +617,7 @@ void launch_gi_preview_resolve(const KArgs& a, uint32_t seed, uint32_t nth, cons
     ST_LAUNCH(k_gi_preview<true>, false, s, a, seed, nth, in, a.gi_res[0], source, reproject ? 1u : 0u);
 }
 void launch_gi_preview_both(const KArgs& a, uint32_t seed, const float4* in, float4* mid, uint32_t source, bool reproject, hipStream_t s) {
-    if (a.exp_flags & 0x800u) ST_LAUNCH(k_gi_preview_both<true>, false, s, a, seed, in, mid, source, reproject ? 1u : 0u);   // (ST_EXP bit while it is measured)
-    else ST_LAUNCH(k_gi_preview_both<false>, false, s, a, seed, in, mid, source, reproject ? 1u : 0u);
+    ST_LAUNCH(k_gi_preview_both, false, s, a, seed, in, mid, source, reproject ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------- gi_resolving.rs:3-67
