@@ -416,12 +416,8 @@ struct ComposeArgs { void* out; uint32_t format, camera_mode, keep_colours; };
 #ifndef ST_FAR_COMPOSE_WAVES
 #define ST_FAR_COMPOSE_WAVES 5  // the six floats composition carries through the gather rounds do not fit the 80 registers of 6 waves per SIMD without spilling
 #endif
-// LATE (round 6, ST_EXP bit 0x1000 while it is measured): composition's three texels are requested with the INDIRECT signal's gathers — the last of the three
-// rounds — instead of with the centre texels: their six floats are then not carried through the first two rounds, and the kernel fits 76 VGPRs = 6 waves per SIMD
-// without a spill (83 / 5 waves otherwise; round 3 had tried them at the very END, behind the last round: a dependent chain with nothing to overlap, 119 us
-// against 85 — here they share the last round's trip).
-template <bool COMPOSE, bool LATE = false>
-__global__ __launch_bounds__(kBlockThreads, (COMPOSE && !LATE) ? ST_FAR_COMPOSE_WAVES : 6) void k_denoise_wavelet_far(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out, const ComposeArgs co) {
+template <bool COMPOSE>
+__global__ __launch_bounds__(kBlockThreads, COMPOSE ? ST_FAR_COMPOSE_WAVES : 6) void k_denoise_wavelet_far(const KArgs a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out, const ComposeArgs co) {
     U2 pos;
     if (!resolve_gid(a, false, &pos) || !owns_pixel(a, pos)) return;
     const uint32_t center = pos.y * a.width + pos.x;
@@ -434,7 +430,7 @@ __global__ __launch_bounds__(kBlockThreads, (COMPOSE && !LATE) ? ST_FAR_COMPOSE_
         return;
     }
     V3 c_base = v3s(0.0f), c_add = v3s(0.0f);
-    if (COMPOSE && !LATE) {
+    if (COMPOSE) {
         const float4 g1 = a.g1[center], ds = a.di_spec_samples[center], gs = a.gi_spec_samples[center];
         const uint32_t w1 = f2b(g1.w);
         const float* lut = a.byte_luts;
@@ -479,13 +475,6 @@ __global__ __launch_bounds__(kBlockThreads, (COMPOSE && !LATE) ? ST_FAR_COMPOSE_
         float4 tap[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) tap[t] = gi_in[at[t]];
-        if (COMPOSE && LATE) {
-            const float4 g1 = a.g1[center], ds = a.di_spec_samples[center], gs = a.gi_spec_samples[center];
-            const uint32_t w1 = f2b(g1.w);
-            const float* lut = a.byte_luts;
-            c_base = v3(lut[kLutGamma8 + (w1 & 0xffu)], lut[kLutGamma8 + ((w1 >> 8) & 0xffu)], lut[kLutGamma8 + ((w1 >> 16) & 0xffu)]);
-            c_add = xyz(g1) + xyz(ds) + xyz(gs);
-        }
 #pragma unroll
         for (int t = 0; t < 8; t++) if (dw[t] != 0.0f) signal_tap(sg, tap[t], dw[t], nw[t]);
         const float4 res_gi = signal_end(sg);
@@ -506,8 +495,7 @@ void launch_denoise_wavelet(const KArgs& a, uint32_t stride, float strength, con
 // a gather pass (stride 8 or 16) with frame_composition.rs appended (the last pass of the chain)
 void launch_denoise_wavelet_compose(const KArgs& a, uint32_t stride, float strength, const float4* di_in, float4* di_out, const float4* gi_in, float4* gi_out,
                                     uint32_t camera_mode, void* out, uint32_t format, bool keep_colours, hipStream_t s) {
-    if (a.exp_flags & 0x1000u) ST_LAUNCH((k_denoise_wavelet_far<true, true>), false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, ComposeArgs{out, format, camera_mode, keep_colours ? 1u : 0u});
-    else ST_LAUNCH((k_denoise_wavelet_far<true, false>), false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, ComposeArgs{out, format, camera_mode, keep_colours ? 1u : 0u});
+    ST_LAUNCH(k_denoise_wavelet_far<true>, false, s, a, stride, strength, di_in, di_out, gi_in, gi_out, ComposeArgs{out, format, camera_mode, keep_colours ? 1u : 0u});
 }
 void launch_denoise_wavelet_12(const KArgs& a, float strength0, float strength1, const float4* di_in, float4* di_mid, float4* di_out, const float4* gi_in,
                                float4* gi_mid, float4* gi_out, hipStream_t s) {
