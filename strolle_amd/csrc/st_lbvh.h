@@ -13,9 +13,9 @@ namespace st {
 // (2 x lbvh_pow2(live) boxes of 32 B), children (8 B x live), node_box (32 B x live), frontier_a / frontier_b (4 B x live), bounds (6 ints),
 // counters (4 words: the collapse's frontier counts, rotating by launch; [3] != 0: the finishing launch ran out of its private stack and LEFT SUBTREES
 // UNBUILT — `flags_host`, if not null, is a page-locked word the same launch sets then: the caller must not use the tree).
-// The sort (round 6): 31-bit keys — the 30-bit Morton code, 0x40000000 for a dead slot — with the slot as value, hipCUB SortPairs, 4 passes instead of the
-// 8 a 64-bit key takes; the sort is stable and the input is in slot order, so the order is the one (code << 32 | slot) gives, and those 64-bit keys are
-// composed afterwards for the hierarchy's tie-breaks: the tree is bit for bit the one round 5's sort produced.
+// The sort (round 6): 31-bit keys — the 30-bit Morton code, 0x40000000 for a dead slot — with the slot as value (hipCUB SortPairs); the sort is stable and the
+// input is in slot order, so the order is the one (code << 32 | slot) gives, and those 64-bit keys are composed afterwards for the hierarchy's tie-breaks: the
+// tree is bit for bit the one round 5's 64-bit sort produced.
 struct LbvhArgs {
     const float4* tri_geo; const float4* tri_bounds; const uint32_t* tri_info;
     uint32_t slots, live, links16;
