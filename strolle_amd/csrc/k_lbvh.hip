@@ -27,7 +27,7 @@
 // 208 k triangles, one build: 0.34 ms of device time (profiles/r05_lbvh_kernel_stats.txt). Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
 // 11.6 for a GI bounce, the same number of triangle tests, deepest stack 13-14.
 #include <hip/hip_fp16.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "k_common.h"
 #include "st_lbvh.h"
 
@@ -51,10 +51,9 @@ __device__ inline float box_area(const Box& b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ void k_lbvh_init(int* bounds, uint32_t* counters, uint32_t* frontier_a) {
+__global__ void k_lbvh_init(int* bounds) {
     if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;             // ordered(+inf-ish): min
     else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;   // max
-    if (threadIdx.x == 0) { counters[0] = 1u; counters[1] = 0u; counters[2] = 0u; counters[3] = 0u; frontier_a[0] = 0u; }   // the first collapse launch's frontier = { the root }
 }
 // 1. bounds of the live triangles' centroids. One ordered-int atomic pair per axis and WORKGROUP, from at most kBoundsBlocks workgroups: with one
 // pair per wave of a launch that covered the slots once (3,252 waves at 208 k triangles = 19,500 atomics on one cache line) this kernel took
@@ -167,12 +166,11 @@ __global__ __launch_bounds__(kT) void k_lbvh_hierarchy(const unsigned long long*
     children[i] = make_uint2(left, right);
     box_store(node_box + 2u * (size_t)i, seg_query(seg, pow2, (uint32_t)first, (uint32_t)last));
 }
-// 7. one wide node, headed by binary node `b`: written at node index b; its internal children are returned in `next` (their count in *n_next)
+// 7. one wide node, headed by binary node `b`: written at node index b
 __device__ inline Box lb_child_box(uint32_t link, const float4* seg, uint32_t pow2, const float4* node_box) {
     return (link & 1u) ? box_load(seg + 2u * (size_t)(pow2 + (link >> 1))) : box_load(node_box + 2u * (size_t)(link >> 1));
 }
-__device__ inline void lb_emit(uint32_t b, const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
-                               uint32_t* next, int* n_next) {
+__device__ inline void lb_emit(uint32_t b, const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes) {
     // (four slots addressed by compile-time indices only: with run-time indices — the first version shifted the slots to keep the children in
     // the binary tree's order — the arrays lived in scratch memory, 112 B per lane, and every access was a round trip through the vector L1)
     uint32_t link[4]; Box box[4]; int n = 2;
@@ -198,105 +196,30 @@ __device__ inline void lb_emit(uint32_t b, const uint2* children, const float4* 
     auto dn = [](float x) { return (uint32_t)__half_as_ushort(__float2half_rd(x)); };
     auto up = [](float x) { return (uint32_t)__half_as_ushort(__float2half_ru(x)); };
     uint32_t w[12], l[4];
-    int heads = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (i >= n) { w[3 * i] = w[3 * i + 1] = w[3 * i + 2] = 0xfc007c00u; l[i] = 0u; continue; }
         w[3 * i] = dn(box[i].lx) | (up(box[i].hx) << 16); w[3 * i + 1] = dn(box[i].ly) | (up(box[i].hy) << 16); w[3 * i + 2] = dn(box[i].lz) | (up(box[i].hz) << 16);
         l[i] = link[i];
-        if (!(link[i] & 1u)) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (j == heads) next[j] = link[i] >> 1;
-            heads++;
-        }
     }
-    *n_next = heads;
     float4* out = nodes + 4u * (size_t)b;
     out[0] = make_float4(b2f(w[0]), b2f(w[1]), b2f(w[2]), b2f(w[3]));
     out[1] = make_float4(b2f(w[4]), b2f(w[5]), b2f(w[6]), b2f(w[7]));
     out[2] = make_float4(b2f(w[8]), b2f(w[9]), b2f(w[10]), b2f(w[11]));
     out[3] = links16 ? make_float4(b2f(l[0] | (l[1] << 16)), b2f(l[2] | (l[3] << 16)), 0.0f, 0.0f) : make_float4(b2f(l[0]), b2f(l[1]), b2f(l[2]), b2f(l[3]));
 }
-// One collapse launch. Launch k reads the frontier front[k & 1] of counters[k % 3] heads, appends the next one to front[(k + 1) & 1] counting in
-// counters[(k + 1) % 3], and clears counters[(k + 2) % 3] for the launch after: nothing a launch reads is written by it, whatever order its
-// workgroups run in. A frontier of more than kSmallIn heads is one level for the whole grid. A smaller one is workgroup 0's alone, and it keeps
-// going — frontier after frontier through LDS, a barrier between them instead of a launch — until a frontier outgrows it, or none is left: the
-// tree's first five or six levels and its long tail of narrow ones (dozens at 208 k triangles) cost two launches, not one each.
-// With `finish` every thread walks the whole subtree of each of its heads instead of handing its children on.
-constexpr uint32_t kSmallIn = 1024u, kSmallCap = 4u * kSmallIn, kSmallRounds = 96u;
-// The finishing launch — a kernel of its own since round 6, so that the collapse launches carry no scratch memory (its private stack was 400 B per lane
-// of EVERY collapse launch): every thread walks the whole subtree of each head still open. The binary tree is at most 64 + 32 levels deep and a 4-wide
-// DFS keeps up to three siblings pending per level, so a private stack cannot be proven sufficient: when it is full the subtree is NOT built and the
-// launch says so (counters[3], *flags_host) — st_tick.cpp then rebuilds on the host instead of rendering a tree with holes.
-constexpr int kFinishStack = 96;
-__global__ __launch_bounds__(kT) void k_lbvh_collapse_finish(const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
-                                                             const uint32_t* frontier_a, const uint32_t* frontier_b, uint32_t* counters, uint32_t launch, uint32_t* flags_host) {
-    const uint32_t count = counters[launch % 3u];
-    const uint32_t* frontier_in = (launch & 1u) ? frontier_b : frontier_a;
-    uint32_t next[4]; int n_next;
-    for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
-        uint32_t stack[kFinishStack]; int sp = 0;
-        stack[sp++] = frontier_in[i];
-        while (sp > 0) {
-            lb_emit(stack[--sp], children, node_box, seg, pow2, links16, nodes, next, &n_next);
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (k < n_next) {
-                    if (sp < kFinishStack) stack[sp++] = next[k];
-                    else { counters[3] = 1u; if (flags_host) flags_host[0] = 1u; }
-                }
-        }
-    }
-}
-__global__ __launch_bounds__(kT) void k_lbvh_collapse(const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes,
-                                                      uint32_t* frontier_a, uint32_t* frontier_b, uint32_t* counters, uint32_t launch) {
-    __shared__ uint32_t s_front[2][kSmallCap];
-    __shared__ uint32_t s_n[2];
-    uint32_t count = counters[launch % 3u];
-    uint32_t* next_count = &counters[(launch + 1u) % 3u];
-    const uint32_t* frontier_in = (launch & 1u) ? frontier_b : frontier_a;
-    uint32_t* frontier_out = (launch & 1u) ? frontier_a : frontier_b;
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[(launch + 2u) % 3u] = 0u;
-    uint32_t next[4]; int n_next;
-    if (count > kSmallIn) {
-        for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
-            lb_emit(frontier_in[i], children, node_box, seg, pow2, links16, nodes, next, &n_next);
-            if (n_next) {
-                const uint32_t at = atomicAdd(next_count, (uint32_t)n_next);
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (k < n_next) frontier_out[at + k] = next[k];
-            }
-        }
-        return;
-    }
-    if (blockIdx.x != 0 || count == 0u) return;   // (an empty frontier: *next_count stays 0)
-    const uint32_t t = threadIdx.x;
-    for (uint32_t i = t; i < count; i += kT) s_front[0][i] = frontier_in[i];
-    if (t < 2u) s_n[t] = 0u;
-    __syncthreads();
-    uint32_t cur = 0u;
-    for (uint32_t round = 0; round < kSmallRounds; round++) {
-        for (uint32_t i = t; i < count; i += kT) {
-            lb_emit(s_front[cur][i], children, node_box, seg, pow2, links16, nodes, next, &n_next);
-            if (n_next) {
-                const uint32_t at = atomicAdd(&s_n[cur ^ 1u], (uint32_t)n_next);
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (k < n_next) s_front[cur ^ 1u][at + k] = next[k];
-            }
-        }
-        __syncthreads();
-        cur ^= 1u; count = s_n[cur];
-        __syncthreads();
-        if (t == 0u) s_n[cur ^ 1u] = 0u;
-        __syncthreads();
-        if (count == 0u || count > kSmallIn) break;
-    }
-    for (uint32_t i = t; i < count; i += kT) frontier_out[i] = s_front[cur][i];   // what is left (more than kSmallIn heads, or kSmallRounds used up) is the next launch's
-    if (t == 0u) *next_count = count;
+// The collapse, in ONE launch (round 6, late): EVERY binary node writes the wide node it would head. Which binary nodes DO head a wide node is only known
+// from the top down (the root does; a wide node's internal children do) — rounds 5 and 6 walked that frontier level by level: 14 launches, 158 us of the
+// 368-us build at 208 k triangles, a finishing launch with a private stack that could overflow. But a walk only ever follows links from the root: a wide
+// node at a slot no link points to is never read, so nobody needs to know which slots those are. Two thirds of the launch's nodes are written for nothing
+// (13 MB instead of 4.4 at 208 k triangles); it has no dependency between its threads, no frontier arrays, no counters, no stack, nothing that can fail.
+__global__ __launch_bounds__(kT) void k_lbvh_wide_nodes(const uint2* children, const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes, uint32_t n_nodes) {
+    const uint32_t b = blockIdx.x * kT + threadIdx.x;
+    if (b < n_nodes) lb_emit(b, children, node_box, seg, pow2, links16, nodes);
 }
 // REFIT (lbvh_refit): triangles moved, nothing else changed — the sorted order, the binary tree and the wide nodes' links stay, the boxes follow. Every
-// slot of the node array that heads a wide node (its link words are not all zero: lbvh_build clears the array first; no child's link is 0, the root's)
-// gets its children's boxes again from the recomputed node boxes / segment-tree leaves.
+// slot of the node array (every one holds a wide node since k_lbvh_wide_nodes writes them all; empty child slots have link 0, the root's, which no child
+// has) gets its children's boxes again from the recomputed node boxes / segment-tree leaves.
 __global__ __launch_bounds__(kT) void k_lbvh_refit_nodes(const float4* node_box, const float4* seg, uint32_t pow2, uint32_t links16, float4* nodes, uint32_t n_nodes) {
     const uint32_t b = blockIdx.x * kT + threadIdx.x;
     if (b >= n_nodes) return;
@@ -305,7 +228,6 @@ __global__ __launch_bounds__(kT) void k_lbvh_refit_nodes(const float4* node_box,
     uint32_t l[4];
     if (links16) { l[0] = f2b(lw.x) & 0xffffu; l[1] = f2b(lw.x) >> 16; l[2] = f2b(lw.y) & 0xffffu; l[3] = f2b(lw.y) >> 16; }
     else { l[0] = f2b(lw.x); l[1] = f2b(lw.y); l[2] = f2b(lw.z); l[3] = f2b(lw.w); }
-    if ((l[0] | l[1] | l[2] | l[3]) == 0u) return;
     auto dn = [](float x) { return (uint32_t)__half_as_ushort(__float2half_rd(x)); };
     auto up = [](float x) { return (uint32_t)__half_as_ushort(__float2half_ru(x)); };
     uint32_t w[12];
@@ -321,18 +243,32 @@ __global__ __launch_bounds__(kT) void k_lbvh_refit_nodes(const float4* node_box,
 }
 }  // namespace
 
+// The sort: rocPRIM's default configuration, which below 1 M keys is its merge sort — one block sort and two launches per doubling of the sorted runs:
+// 17 launches, 110 us of launch latency, at 208 k keys. Two replacements were built and measured in round 6, both giving the same order, both slower:
+// the library's onesweep radix sort (radix_sort_config<..., MergeSortLimit = 8192>: 6 launches, but 23-29 us per pass and 10-20 us of memsets between
+// them: 163 us; profiles/r06_lbvh_onesweep.txt) and an own bucket-and-rank form (3 launches; 540 us on the dungeon, whose slot order and tori make its
+// atomics collide and its buckets huge; tools/experiments/lbvh_bucket_sort.inc, profiles/r06_lbvh_bucket_sort.txt).
 size_t lbvh_sort_temp_bytes(uint32_t slots) {
     size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)slots, 0, 31, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)slots, 0u, 31u, (hipStream_t) nullptr);
     return bytes;
 }
 uint32_t lbvh_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
+
+// Ahead of the first build (st_tick.cpp, while the scene loads): this file's code object on the device — 5 ms of the first spawn's tick otherwise
+// (profiles/r06_spawn_ticks.txt: "build launches 5.095 ms" against 0.15 for every later one). `bounds`: the six ints every build initialises itself.
+void lbvh_warm(int* bounds, hipStream_t s) {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_lbvh_wide_nodes));
+    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, bounds);
+    (void)hipGetLastError();
+}
 
 int lbvh_build(const LbvhArgs& a, hipStream_t s) {
     if (a.live < 2u) return -1;   // the caller keeps the host path for a scene of fewer than two triangles
     const uint32_t pow2 = lbvh_pow2(a.live);
     auto grid = [](uint32_t n) { return dim3((n + kT - 1) / kT); };
-    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, a.bounds, a.counters, a.frontier_a);
+    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, a.bounds);
     hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((a.slots + kT - 1) / kT, kBoundsBlocks)), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds);
     // (code, slot) pairs: unsorted in keys_out's memory, sorted into keys_in's, the composed 64-bit keys back in keys_out (what the hierarchy and every
     // later refit read)
@@ -340,7 +276,7 @@ int lbvh_build(const LbvhArgs& a, hipStream_t s) {
     uint32_t* codes_out = reinterpret_cast<uint32_t*>(a.keys_in); uint32_t* slots_out = codes_out + a.slots;
     hipLaunchKernelGGL(k_lbvh_keys, grid(a.slots), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds, codes_in, slots_in);
     size_t temp = a.sort_temp_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(a.sort_temp, temp, codes_in, codes_out, slots_in, slots_out, (int)a.slots, 0, 31, s) != hipSuccess) return -2;
+    if (rocprim::radix_sort_pairs(a.sort_temp, temp, codes_in, codes_out, slots_in, slots_out, (size_t)a.slots, 0u, 31u, s) != hipSuccess) return -2;
     hipLaunchKernelGGL(k_lbvh_compose, grid(a.slots), dim3(kT), 0, s, codes_out, slots_out, a.slots, a.keys_out);
     hipLaunchKernelGGL(k_lbvh_leaves, grid(pow2), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.tri_geo, a.tri_bounds, a.tri_info, a.seg, a.leaves);
     for (uint32_t count = pow2 >> 1; count >= 1u;) {
@@ -349,20 +285,7 @@ int lbvh_build(const LbvhArgs& a, hipStream_t s) {
         count = groups >> 1;
     }
     hipLaunchKernelGGL(k_lbvh_hierarchy, grid(a.live - 1u), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.seg, a.children, a.node_box);
-    // Collapse launches before the finishing one: one per wide level of the tree (about log4 of the leaves), the two runs of narrow levels, and
-    // six to spare for an LBVH's imbalance — a launch over an empty frontier costs 5 us (208 k triangles: 11 of the 17 have work: the top run
-    // 70 us, nine wide levels of 10-14 us, the tail run 37 us). Whatever is still open after them — nothing, at the sizes measured — is the
-    // finishing launch's: single threads walking subtrees one dependent load after the other (with only 8 levels before it, that launch took
-    // 8 ms of a 9-ms build at 208 k triangles).
-    if (hipMemsetAsync(a.nodes, 0, (size_t)(a.live - 1u) * 64u, s) != hipSuccess) return -3;   // a slot no wide node is written to stays all zero: lbvh_refit tells the heads by that
-    uint32_t wide_levels = 1;
-    while (wide_levels < 16u && (1ull << (2u * wide_levels)) < a.live) wide_levels++;
-    const uint32_t launches = wide_levels + 8u;
-    for (uint32_t launch = 0; launch < launches; launch++)
-        hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min<uint32_t>((a.live + kT - 1) / kT, 1024u)), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes,
-                           a.frontier_a, a.frontier_b, a.counters, launch);
-    hipLaunchKernelGGL(k_lbvh_collapse_finish, dim3(std::min<uint32_t>((a.live + kT - 1) / kT, 1024u)), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes,
-                       a.frontier_a, a.frontier_b, a.counters, launches, a.flags_host);
+    hipLaunchKernelGGL(k_lbvh_wide_nodes, grid(a.live - 1u), dim3(kT), 0, s, a.children, a.node_box, a.seg, pow2, a.links16, a.nodes, a.live - 1u);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

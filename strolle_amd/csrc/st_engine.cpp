@@ -93,7 +93,7 @@ Engine::~Engine() {
     for (DeviceArray* d : {&d_byte_luts, &d_atlas, &d_blue_noise, &d_transmittance, &d_scattering, &d_sky, &d_mesh_store}) d->release();
     for (LightSet& l : light_sets) { l.buf.release(); if (l.free_ev) (void)hipEventDestroy(l.free_ev); }
     for (SceneSet& t : sets) {
-        for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed, &t.tri_geo, &t.tri_bounds, &t.entry_of_tri, &t.parent, &t.refit_local, &t.refit_items, &t.refit_batch_off, &t.bvh_compact, &t.tri_info, &t.lb_keys_a, &t.lb_keys_b, &t.lb_temp, &t.lb_seg, &t.lb_children, &t.lb_node_box, &t.lb_front_a, &t.lb_front_b, &t.lb_small, &t.bvh_wide, &t.wide_topo, &t.wide_leaf_entry, &t.bake_jobs, &t.bake_starts}) d->release();
+        for (DeviceArray* d : {&t.bvh, &t.tri_attr, &t.xforms, &t.materials, &t.base_packed, &t.tri_geo, &t.tri_bounds, &t.entry_of_tri, &t.parent, &t.refit_local, &t.refit_items, &t.refit_batch_off, &t.bvh_compact, &t.tri_info, &t.lb_keys_a, &t.lb_keys_b, &t.lb_temp, &t.lb_seg, &t.lb_children, &t.lb_node_box, &t.lb_small, &t.bvh_wide, &t.wide_topo, &t.wide_leaf_entry, &t.bake_jobs, &t.bake_starts}) d->release();
         if (t.free_ev) (void)hipEventDestroy(t.free_ev);
     }
     if (copy_stream) (void)hipStreamDestroy(copy_stream);

@@ -429,7 +429,7 @@ struct Engine {
         // stream) is then stale and no launch may read it. lb_live: live triangles of that build. The rest is the builder's scratch.
         bool device_built = false; uint32_t lb_live = 0; uint64_t tri_info_serial = 0;
         uint64_t lb_serial = ~0ull; uint32_t lb_slots = 0;   // tri_info_serial_ / triangle slots of the copy's last device BUILD (a refit needs both unchanged)
-        DeviceArray tri_info, lb_keys_a, lb_keys_b, lb_temp, lb_seg, lb_children, lb_node_box, lb_front_a, lb_front_b, lb_small;
+        DeviceArray tri_info, lb_keys_a, lb_keys_b, lb_temp, lb_seg, lb_children, lb_node_box, lb_small;
         // ST_BVH_REFIT_DEVICE: what k_bvh.hip needs beside the stream — per triangle slot the hit-test record, the bounds and the
         // device entry that holds it; per entry its parent (entry << 1 | child slot); the leaf runs; an arrival counter per entry.
         // tree_version says which build of the tree these (and the stream's topology) belong to.
@@ -544,7 +544,6 @@ struct Engine {
     bool device_build_possible() const;
     int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);
     int reserve_device_builder(SceneSet& t, size_t slots, uint32_t live);
-    bool device_builder_failed = false;   // k_lbvh.hip's finishing launch dropped subtrees once (walk_flags_host[2]): this engine builds on the host from then on
     void rebuild_host_tree(bool timing);
 
     int tick(hipStream_t stream);

@@ -34,7 +34,7 @@ void Engine::rebuild_host_tree(bool timing) {
 bool Engine::device_build_possible() const {
     const bool automatic = bvh_refresh_mode == ST_BVH_AUTO && scene_uploaded && live_prims_ > kLdsSceneTexels / 4u;   // (a leaf entry per triangle: more than 112 of them never fit)
     if (!(bvh_refresh_mode == ST_BVH_BUILD_DEVICE || automatic) || !has_device || arithmetic != ST_ARITH_FAST) return false;
-    if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes || device_builder_failed) return false;
+    if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes) return false;
     for (const auto& kv : cameras) if (kv.second->desc.mode == ST_MODE_BVH_HEATMAP) return false;
     return live_prims_ >= 2u && prims.size() < (1u << 23);
 }
@@ -54,8 +54,8 @@ int Engine::reserve_device_builder(SceneSet& t, size_t slots, uint32_t live) {
     };
     int rc;
     if ((rc = need(t.lb_keys_a, slots * 8u)) || (rc = need(t.lb_keys_b, slots * 8u)) || (rc = need(t.lb_temp, std::max<size_t>(temp + temp / 4, 16u))) || (rc = need(t.lb_seg, (size_t)pow2 * 2u * 32u)) ||
-        (rc = need(t.lb_children, (size_t)live * 8u)) || (rc = need(t.lb_node_box, (size_t)live * 32u)) || (rc = need(t.lb_front_a, (size_t)live * 4u)) ||
-        (rc = need(t.lb_front_b, (size_t)live * 4u)) || (rc = need(t.lb_small, 64u)) || (rc = need(t.bvh_wide, (size_t)(live - 1u) * 64u + (size_t)live * 48u + 64u))) return rc;
+        (rc = need(t.lb_children, (size_t)live * 8u)) || (rc = need(t.lb_node_box, (size_t)live * 32u)) ||
+        (rc = need(t.lb_small, 64u)) || (rc = need(t.bvh_wide, (size_t)(live - 1u) * 64u + (size_t)live * 48u + 64u))) return rc;
     return ST_OK;
 }
 // This device copy's triangle arrays brought up to date, then k_lbvh.hip builds its wide stream from them.
@@ -113,15 +113,13 @@ int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
     const size_t temp = lbvh_sort_temp_bytes((uint32_t)slots);
     if ((rc = reserve_device_builder(t, slots, live))) return rc;
     LbvhArgs a{};
-    a.flags_host = walk_flags_dev ? walk_flags_dev + 2 : nullptr;   // (word 2 of the engine's sticky words: the finishing launch left subtrees unbuilt)
     a.tri_geo = static_cast<const float4*>(t.tri_geo.ptr); a.tri_bounds = static_cast<const float4*>(t.tri_bounds.ptr); a.tri_info = static_cast<const uint32_t*>(t.tri_info.ptr);
     a.slots = (uint32_t)slots; a.live = live; a.links16 = live < 32768u ? 1u : 0u;
     a.nodes = static_cast<float4*>(t.bvh_wide.ptr); a.leaves = a.nodes + 4u * (size_t)(live - 1u);
     a.keys_in = static_cast<unsigned long long*>(t.lb_keys_a.ptr); a.keys_out = static_cast<unsigned long long*>(t.lb_keys_b.ptr);
     a.sort_temp = t.lb_temp.ptr; a.sort_temp_bytes = temp;
     a.seg = static_cast<float4*>(t.lb_seg.ptr); a.children = static_cast<uint2*>(t.lb_children.ptr); a.node_box = static_cast<float4*>(t.lb_node_box.ptr);
-    a.frontier_a = static_cast<uint32_t*>(t.lb_front_a.ptr); a.frontier_b = static_cast<uint32_t*>(t.lb_front_b.ptr);
-    a.bounds = static_cast<int*>(t.lb_small.ptr); a.counters = static_cast<uint32_t*>(t.lb_small.ptr) + 8;
+    a.bounds = static_cast<int*>(t.lb_small.ptr);
     // moves only, on a copy whose last build saw these very slots: the tree keeps its shape, every box follows (k_lbvh.hip lbvh_refit: 5 launches against 42)
     if (refit_tree) {
         if (lbvh_refit(a, up) != 0) return fail(ST_ERR_HIP, "the device BVH refit failed to launch");
@@ -156,14 +154,6 @@ int Engine::tick(hipStream_t stream) {
     // and the host's tree falls behind; the first tick that finds an observer brings it up to date like any rebuild.
     if (materials_changed_this_tick) info_full_ = true;   // a Blend flag may have changed under any slot
     if ((instances_changed && !moved_on_device) || materials_changed_this_tick) tri_info_serial_++;   // slots, liveness, materials or Blend flags may have changed
-    if (walk_flags_host && walk_flags_host[2] != 0u) {
-        // the device builder's finishing launch ran out of its private stack (k_lbvh.hip k_lbvh_collapse_finish): the tree it left has holes. This engine
-        // goes back to the host's builder for good; this very tick rebuilds (host_tree_stale) and uploads the host's streams.
-        walk_flags_host[2] = 0u;
-        device_builder_failed = true;
-        fprintf(stderr, "[strolle-hip] warning: the device BVH builder could not finish a tree (subtrees deeper than its finishing launch's stack): frames since that build may have missed geometry; "
-                        "this engine rebuilds on the host from now on\n");
-    }
     const bool build_on_device_now = device_build_possible();
     device_tree_refit_now = false;
     if (instances_changed && build_on_device_now) {
@@ -302,9 +292,11 @@ int Engine::tick(hipStream_t stream) {
                     const size_t want = triangles.size() + triangles.size() / 8u;
                     triangles.reserve(want); prims.reserve(want); prim_alive.reserve(want); tri_geo.reserve(3 * want); tri_attr.reserve(4 * want); tri_bounds.reserve(2 * want);
                 }
+                bool reserved = true;
                 for (SceneSet& c : sets) {
-                    if (reserve_device_builder(c, prims.size() + prims.size() / 8u, (uint32_t)std::min<size_t>(live_prims_ + live_prims_ / 8u, prims.size() + prims.size() / 8u)) != ST_OK) { (void)hipGetLastError(); break; }
+                    if (reserve_device_builder(c, prims.size() + prims.size() / 8u, (uint32_t)std::min<size_t>(live_prims_ + live_prims_ / 8u, prims.size() + prims.size() / 8u)) != ST_OK) { (void)hipGetLastError(); reserved = false; break; }
                 }
+                if (reserved && sets[0].lb_small.ptr) lbvh_warm(static_cast<int*>(sets[0].lb_small.ptr), up);   // ... and the builder's code object is on the device before the first spawn
             }
             if (!build_on_device_now) {
                 if ((rc = refresh_compact_stream(t, up))) return rc;   // the shadow rays' compact form follows every change of the contract stream
