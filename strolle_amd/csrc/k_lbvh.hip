@@ -8,23 +8,23 @@
 //
 //   1. centroid bounds of the live triangle slots                                   k_lbvh_bounds      (wave, then workgroup reduction: one ordered-int atomic pair per workgroup)
 //   2. key = 30-bit Morton code of the centroid << 32 | triangle slot (unique)      k_lbvh_keys        dead slots: ~0, sorted to the end
-//   3. radix sort                                                                   hipCUB DeviceRadixSort::SortPairs over the 31-bit (code | dead) keys with the slot as value
+//   3. radix sort                                                                   rocPRIM radix_sort_pairs over the 31-bit (code | dead) keys with the slot as value
 //      (round 5 sorted 64-bit keys); the sort is stable and its input in slot order, so the order is the same, and k_lbvh_compose rebuilds the 64-bit keys
-//      afterwards. Half the key bytes — and, measured, no faster: at 208 k keys the library runs the same 17 launches of 5-6 us either way (0.11 ms, launch-bound)
+//      afterwards. Half the key bytes — and, measured, no faster: at 208 k keys the library runs the same 17 launches of 5-6 us either way (0.10 ms, launch-bound;
+//      lbvh_sort_temp_bytes: the two replacements that were tried)
 //   4. leaf records (48 B, sorted order = leaf index) + leaf boxes                  k_lbvh_leaves
 //   5. min / max segment tree over the sorted leaf boxes                            k_lbvh_seg_levels  nine levels per launch, no fences
 //   6. the binary radix tree of Karras 2012 — one thread per internal node finds its range and split from the keys alone —, each
 //      node's box as a range query of the segment tree (no bottom-up pass: nothing is handed from workgroup to workgroup) k_lbvh_hierarchy
-//   7. collapse into 4-wide nodes, top-down: a wide node is headed by a binary node and takes its children's children, largest surface
-//      area first, until it has four (the rule st_bvh_refresh.cpp build_wide_topology applies to the host's tree); a wide node lives at
-//      its head's binary index, so nothing is allocated and the result does not depend on the schedule. One launch per WIDE frontier level;
-//      a run of narrow levels (the first five or six, and the long tail) is one workgroup's loop through LDS inside one launch; a last
-//      launch walks whatever is deeper with a private stack per thread                                                    k_lbvh_collapse
+//   7. 4-wide nodes: a wide node is headed by a binary node and takes its children's children, largest surface area first, until it has
+//      four (the rule st_bvh_refresh.cpp build_wide_topology applies to the host's tree); it lives at its head's binary index, so nothing
+//      is allocated and the result does not depend on the schedule. ONE launch: every binary node writes the node it would head, and the
+//      links decide which of them a walk reaches (rounds 5-6: a frontier walk, 14 launches)                             k_lbvh_wide_nodes
 //
 //   R. instances only moved: steps 4-6 again over the SAME sorted order, then every wide node's box words from its links           lbvh_refit
-//      (5 launches against the build's 42; st_tick.cpp: at most 15 refits between two builds)
+//      (5 launches against the build's 26; st_tick.cpp: at most 15 refits between two builds)
 //
-// 208 k triangles, one build: 0.34 ms of device time (profiles/r05_lbvh_kernel_stats.txt). Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
+// 208 k triangles, one build: 0.18 ms of device time (profiles/r06_lbvh_kernel_stats_one_launch.txt; round 5: 0.34). Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
 // 11.6 for a GI bounce, the same number of triangle tests, deepest stack 13-14.
 #include <hip/hip_fp16.h>
 #include <rocprim/device/device_radix_sort.hpp>

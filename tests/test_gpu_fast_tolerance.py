@@ -581,8 +581,8 @@ def test_a_device_built_tree_is_refitted_while_instances_only_move(n_triangles):
 @pytest.mark.parametrize("n_triangles", [1, 2, 3, 5, 33, 257, 1025, 4099])
 def test_small_trees_built_on_the_device(n_triangles):
     """The device builder's small ends: a segment tree of fewer nodes than one workgroup's width (k_lbvh_seg_levels with count0 < 256, down to ONE
-    node), a collapse whose every frontier is workgroup 0's loop through LDS, triangle counts one past a power of two (the segment tree's padding
-    leaves), 4,099 triangles (the first frontier that outgrows the loop); one triangle: no tree to build, the host's path stays (k_lbvh.hip
+    node), triangle counts one past a power of two (the segment tree's padding leaves), a two-triangle tree whose only node has two leaf children;
+    one triangle: no tree to build, the host's path stays (k_lbvh.hip
     lbvh_build -1). Primary hits against an engine that builds on the host."""
     torch = _torch()
     size = (160, 96)
