@@ -32,7 +32,11 @@ void Engine::rebuild_host_tree(bool timing) {
 // loads — and every CHANGE after it (spawn, despawn, move) goes to the device under the same conditions; scenes whose contract stream fits LDS
 // (k_common.h scene_fits_lds: the Cornell box) keep the host's tree, which their kernels walk from LDS with the exact closest-hit loop.
 bool Engine::device_build_possible() const {
-    const bool automatic = bvh_refresh_mode == ST_BVH_AUTO && scene_uploaded && live_prims_ > kLdsSceneTexels / 4u;   // (a leaf entry per triangle: more than 112 of them never fit)
+    // ST_BVH_AUTO: a scene that fits LDS keeps its contract stream there (a leaf entry per triangle: more than 112 of them never fit); a larger one sends its
+    // CHANGES to the device builder and, from kAutoDeviceFirstTriangles on, its first tree too: measured (tools/tree_choice.py, profiles/r06_tree_choice.txt), the
+    // steady frame over the device's tree against the host's binned-SAH tree is 1.03x at 13 k triangles and 1.06x at 52 k, but 0.84-0.89x at 134 k and 0.93-0.97x
+    // at 208 k (the SAH tree's leaf runs cost the wide walk a step per triangle), and the first tick of a 208 k-triangle scene is 16 ms instead of 73.
+    const bool automatic = bvh_refresh_mode == ST_BVH_AUTO && (scene_uploaded || live_prims_ >= kAutoDeviceFirstTriangles) && live_prims_ > kLdsSceneTexels / 4u;
     if (!(bvh_refresh_mode == ST_BVH_BUILD_DEVICE || automatic) || !has_device || arithmetic != ST_ARITH_FAST) return false;
     if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes) return false;
     for (const auto& kv : cameras) if (kv.second->desc.mode == ST_MODE_BVH_HEATMAP) return false;
@@ -235,6 +239,21 @@ int Engine::tick(hipStream_t stream) {
             SceneSet& t = sets[target];
             bool attr_sent = false;
             bool attr_done = false;
+            if (!scene_uploaded && (bvh_refresh_mode == ST_BVH_AUTO || bvh_refresh_mode == ST_BVH_BUILD_DEVICE) && arithmetic == ST_ARITH_FAST &&
+                tuning.wide_bvh && live_prims_ > kLdsSceneTexels / 4u && prims.size() < (1u << 23)) {
+                // this scene's changes (and, for a large scene, its first tree: device_build_possible) go to the device builder: its arrays are allocated NOW, while the
+                // scene loads, for both copies — BEFORE the wide stream of this copy is written below (its allocation is one of them: growing it afterwards would throw the stream away: round 6's
+                // first version did, and rendered an empty world). A failure here is not an error: the build allocates what it finds missing.
+                {   // ... and the host's triangle arrays get the same headroom now, so that the first spawn does not reallocate and copy them (60 MB at 208 k triangles: 7 ms)
+                    const size_t want = triangles.size() + triangles.size() / 8u;
+                    triangles.reserve(want); prims.reserve(want); prim_alive.reserve(want); tri_geo.reserve(3 * want); tri_attr.reserve(4 * want); tri_bounds.reserve(2 * want);
+                }
+                bool reserved = true;
+                for (SceneSet& c : sets) {
+                    if (reserve_device_builder(c, prims.size() + prims.size() / 8u, (uint32_t)std::min<size_t>(live_prims_ + live_prims_ / 8u, prims.size() + prims.size() / 8u)) != ST_OK) { (void)hipGetLastError(); reserved = false; break; }
+                }
+                if (reserved && !build_on_device_now && sets[0].lb_small.ptr) lbvh_warm(static_cast<int*>(sets[0].lb_small.ptr), up);   // ... and the builder's code object is on the device before the first spawn
+            }
             if (build_on_device_now) {
                 // (instances the device moved stay stale on the host: this copy's pending list re-bakes them on the device even after a whole upload)
                 if ((rc = build_on_device(t, up, flag))) return rc;
@@ -282,21 +301,6 @@ int Engine::tick(hipStream_t stream) {
                     if ((rc = t.refit_batch_off.upload(refit_batch_off_.data(), refit_batch_off_.size() * sizeof(uint32_t), up, staging, flag))) return rc;
                     t.tree_version = tree_version;
                 }
-            }
-            if (!scene_uploaded && !build_on_device_now && (bvh_refresh_mode == ST_BVH_AUTO || bvh_refresh_mode == ST_BVH_BUILD_DEVICE) && arithmetic == ST_ARITH_FAST &&
-                tuning.wide_bvh && live_prims_ > kLdsSceneTexels / 4u && prims.size() < (1u << 23)) {
-                // later changes of this scene go to the device builder: its arrays are allocated NOW, while the scene loads, for both copies — BEFORE the
-                // wide stream of this copy is written below (its allocation is one of them: growing it afterwards would throw the stream away: round 6's
-                // first version did, and rendered an empty world). A failure here is not an error: the build allocates what it finds missing.
-                {   // ... and the host's triangle arrays get the same headroom now, so that the first spawn does not reallocate and copy them (60 MB at 208 k triangles: 7 ms)
-                    const size_t want = triangles.size() + triangles.size() / 8u;
-                    triangles.reserve(want); prims.reserve(want); prim_alive.reserve(want); tri_geo.reserve(3 * want); tri_attr.reserve(4 * want); tri_bounds.reserve(2 * want);
-                }
-                bool reserved = true;
-                for (SceneSet& c : sets) {
-                    if (reserve_device_builder(c, prims.size() + prims.size() / 8u, (uint32_t)std::min<size_t>(live_prims_ + live_prims_ / 8u, prims.size() + prims.size() / 8u)) != ST_OK) { (void)hipGetLastError(); reserved = false; break; }
-                }
-                if (reserved && sets[0].lb_small.ptr) lbvh_warm(static_cast<int*>(sets[0].lb_small.ptr), up);   // ... and the builder's code object is on the device before the first spawn
             }
             if (!build_on_device_now) {
                 if ((rc = refresh_compact_stream(t, up))) return rc;   // the shadow rays' compact form follows every change of the contract stream

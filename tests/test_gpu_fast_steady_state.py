@@ -160,11 +160,16 @@ def _run(scene, size, plan, moving=False, mode=CameraMode.IMAGE, tree="host"):
     prod, orac = Engine(device=0, exact=False), OracleEngine()
     assert not prod.exact
     # tree: "host" — a static scene, the host's binned-SAH tree (the reference's, and under the default ST_BVH_AUTO the first tree of every engine);
-    #       "device" — st_set_bvh_refresh(ST_BVH_BUILD_DEVICE) before the scene exists: the FIRST tree is k_lbvh.hip's already;
+    #       "device" — the FIRST tree is k_lbvh.hip's already (st_set_bvh_refresh(ST_BVH_BUILD_DEVICE) before the scene exists; the default for large scenes);
     #       "spawned" — the default mode: host tree first, then an instance appears at frame 2 (a device BUILD) and moves at every later
     #                   frame (device REFITS of that tree, a rebuild after 15) — the oracle rebuilds its SAH tree every time.
-    if tree == "device":
+    # Since late round 6 ST_BVH_AUTO builds the FIRST tree of a scene of 100,000 triangles or more on the device too (st_tick.cpp device_build_possible;
+    # profiles/r06_tree_choice.txt): for "dungeon134k" (208 k triangles) "device" IS the default mode and "host" asks for the host's tree explicitly.
+    big = scene == "dungeon134k"
+    if tree == "device" and not big:
         prod.set_bvh_refresh(3)
+    if tree == "host" and big:
+        prod.set_bvh_refresh(0)
     for e in (prod, orac):
         build(e); e.set_seed(0)
     desc = camera_fn(size, mode)
@@ -321,7 +326,9 @@ def test_fast_whole_frame_single_step_config3_as_written():
     """BASELINE.json config 3 AS WRITTEN (VERDICT r3 missing #3): the ~100 k-triangle dungeon — here the synthetic 208 k-triangle one,
     26 internal nodes deep, 32-bit traversal stacks — in CameraMode::GiDiffuse{denoise} at 1920x1080, the FAST build (what
     `bench.py --scene dungeon134k --mode gi_diffuse` times): whole unmasked frames of the three GI schedules from the oracle's state."""
-    rep = _run("dungeon134k", (1920, 1080), PLAN_CONFIG3, mode=CameraMode.GI_DIFFUSE)
+    # (208 k triangles: the default mode's first tree is the device builder's since late round 6 — that IS what the bench times)
+    rep = _run("dungeon134k", (1920, 1080), PLAN_CONFIG3, mode=CameraMode.GI_DIFFUSE, tree="device")
+    assert rep["tree"]["device_builds"] >= 1, "ST_BVH_AUTO did not build the 208 k-triangle scene's first tree on the device"
     assert {r["frame"] for r in rep["whole"]} == set(PLAN_CONFIG3)
     _check_whole_rows(rep["whole"], "dungeon134k 1080p gi_diffuse")
 
@@ -339,12 +346,13 @@ def test_fast_whole_frame_single_step_dungeon_1080p_device_built_tree():
     _no_walk_overflowed(rep, "dungeon 1080p, device-built tree")
 
 
-def test_fast_whole_frame_single_step_config3_device_built_tree():
-    """... and BASELINE config 3 as written (208 k triangles, 32-bit links, GiDiffuse) on the device-built tree."""
-    rep = _run("dungeon134k", (1920, 1080), PLAN_CONFIG3, mode=CameraMode.GI_DIFFUSE, tree="device")
-    assert rep["tree"]["device_builds"] >= 1
-    _check_whole_rows(rep["whole"], "dungeon134k 1080p gi_diffuse, device-built tree")
-    _no_walk_overflowed(rep, "config 3, device-built tree")
+def test_fast_whole_frame_single_step_config3_host_tree():
+    """... and BASELINE config 3 on the HOST's binned-SAH tree (st_set_bvh_refresh(ST_BVH_REBUILD): the reference's tree, what every scene got by default
+    until late round 6 and what a heatmap camera or the exact build still gets)."""
+    rep = _run("dungeon134k", (1920, 1080), PLAN_CONFIG3, mode=CameraMode.GI_DIFFUSE, tree="host")
+    assert rep["tree"]["device_builds"] == 0
+    _check_whole_rows(rep["whole"], "dungeon134k 1080p gi_diffuse, host tree")
+    _no_walk_overflowed(rep, "config 3, host tree")
 
 
 def test_fast_whole_frames_after_a_spawn_and_refits_in_the_default_mode():
@@ -360,6 +368,7 @@ def test_fast_whole_frames_after_a_spawn_and_refits_in_the_default_mode():
 def test_no_wide_walk_overflows_on_the_baseline_configs():
     """configs 2 / 3 / 5 never set the wide walks' overflow word (st_debug_walk_overflow) — read from the runs above."""
     for args, kw in ((("cornell", (1920, 1080), PLAN_1080P), {}), (("dungeon", (1920, 1080), PLAN_DUNGEON_1080P), {}),
+                     (("dungeon134k", (1920, 1080), PLAN_CONFIG3), {"mode": CameraMode.GI_DIFFUSE, "tree": "device"}),
                      (("dungeon134k", (1920, 1080), PLAN_CONFIG3), {"mode": CameraMode.GI_DIFFUSE}), (("dungeon", (3840, 2160), PLAN_DUNGEON_4K), {})):
         _no_walk_overflowed(_run(*args, **kw), f"{args[0]} {args[1]}")
 
