@@ -671,6 +671,8 @@ def main():
         except Exception:
             lit_fraction = None
     engine_exact = engine.exact
+    bvh_tree = ("device builder (k_lbvh.hip: LBVH, 4-wide; ST_BVH_AUTO's first tree from 100,000 triangles on)" if engine.device_builds() > 0
+                else "host, binned SAH (the reference's tree: strolle/src/bvh/builder.rs)")   # which tree the timed frames walked — read BEFORE bvh_depth(), a debug read that rebuilds a stale host tree
     bvh_depth = engine.bvh_depth()   # read here: the N > 1 extras close this job's engine
     extras = {}
     if not args.no_extras and world == 1 and headline:
@@ -787,7 +789,8 @@ def main():
                                  "dungeon134k": "SYNTHETIC: the dungeon with every triangle split into 16, same materials and lights"}[args.scene],
                        "arithmetic": "exact (bit-identical to the CPU oracle)" if engine_exact else "fast (hardware rcp/sqrt/exp/log, FMA contraction; traversal exact; tolerances in tests/test_gpu_fast_tolerance.py)",
                        "width": width, "height": height,
-                       "bvh_deepest_internal_chain": bvh_depth[0], "bvh_stack_entries": bvh_depth[1],   # deeper than the stack = dropped pushes (st_debug_bvh_depth): the contract walks' stack is as deep as the tree needs, up to 32
+                       "bvh_tree": bvh_tree,
+                       "bvh_deepest_internal_chain": bvh_depth[0], "bvh_stack_entries": bvh_depth[1],   # (of the HOST's tree) deeper than the stack = dropped pushes (st_debug_bvh_depth): the contract walks' stack is as deep as the tree needs, up to 32
                        "dropped_pushes": "none: contract walks hold the tree's deepest chain (tests/test_c_abi.py); the wide walk keeps 24 entries and renders the same bits with 48 (tests/test_gpu_fast_tolerance.py test_the_wide_walk_drops_no_push); the oracle drops none at 24 and its deepest stack on config 3's scene is 13 (tests/test_wide_bvh.py)" if bvh_depth[0] <= bvh_depth[1] else "POSSIBLE: the tree is deeper than the 32-entry stack",
                        "per_gpu_rows": band[1] - band[0], "apron_rows": (args.apron if needs_apron else 0) if world > 1 else 0,
                        "rays_per_frame": round(rays_total / args.steps), "frame_finite": finite,
