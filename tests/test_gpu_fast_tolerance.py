@@ -578,6 +578,78 @@ def test_a_device_built_tree_is_refitted_while_instances_only_move(n_triangles):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["soup", "dungeon", "dungeon208k"])
+def test_every_triangle_hangs_exactly_once_from_the_root_of_a_device_built_tree(scene):
+    """The device builder writes a wide node at EVERY binary node's slot in one launch (k_lbvh.hip k_lbvh_wide_nodes) and lets the links decide which of
+    them a walk reaches. Read back and walked here from node 0, link by link (16-bit links: soup, dungeon; 32-bit: 208 k triangles): every leaf record — one
+    per live triangle — is reached exactly ONCE, no node twice, about a third of the slots at all; a leaf child's box (conservative f16) holds its
+    triangle's three vertices, a node child's box holds every box of that node. After a spawn (a second build) the same."""
+    _torch()
+    e = Engine(device=0, exact=False)
+    e.set_bvh_refresh(3)
+    if scene == "soup": scenes.build_random_soup(e, 3000, seed=7)
+    else: scenes.build_dungeon(e, subdivide=2 if scene == "dungeon208k" else 0)
+    rng = np.random.default_rng(3)
+    pos = (rng.uniform(-0.3, 0.3, (200, 1, 3)) + rng.uniform(-0.05, 0.05, (200, 3, 3))).astype(np.float32)
+    nrm = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
+    e.insert_mesh(7777, Mesh(pos, np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32)))
+
+    def check(what, builds):
+        e.tick()
+        assert e.device_builds() == builds and e.bvh_refits()[0] == 0
+        nodes = e.read_scene(16).view(np.uint32).reshape(-1, 16)
+        leaves = e.read_scene(17).reshape(-1, 3, 4)
+        live = len(leaves)
+        assert len(nodes) == live - 1 and live >= 3000
+        links16 = live < 32768
+        lw = nodes[:, 12:16]
+        links = np.stack([lw[:, 0] & 0xffff, lw[:, 0] >> 16, lw[:, 1] & 0xffff, lw[:, 1] >> 16], 1) if links16 else lw
+        boxes = nodes[:, :12].reshape(-1, 4, 3)
+        lo = (boxes & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32); hi = (boxes >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+        node_seen, leaf_seen = np.zeros(len(nodes), np.int64), np.zeros(live, np.int64)
+        frontier = np.array([0], np.int64); node_seen[0] = 1
+        levels = 0
+        while len(frontier):
+            l = links[frontier]                                   # [n, 4]
+            used = l != 0
+            assert (used.sum(1) >= 2).all(), f"{what}: a reached wide node with fewer than two children"
+            is_leaf = used & ((l & 1) == 1)
+            is_node = used & ((l & 1) == 0)
+            idx = (l >> 1).astype(np.int64)
+            np.add.at(leaf_seen, idx[is_leaf], 1)
+            # a leaf child's box holds its triangle (p0, p0 + e1, p0 + e2 of the 48-B record)
+            rec = leaves[idx[is_leaf]]
+            p0, e1, e2 = rec[:, 0, :3], rec[:, 1, :3], rec[:, 2, :3]
+            verts = np.stack([p0, p0 + e1, p0 + e2], 1)
+            blo, bhi = lo[frontier][is_leaf], hi[frontier][is_leaf]
+            eps = 1e-4 * np.maximum(1.0, np.abs(verts).max())
+            assert (verts.min(1) >= blo - eps).all() and (verts.max(1) <= bhi + eps).all(), f"{what}: a leaf child's box does not hold its triangle"
+            # a node child's box holds every box of that node
+            kids = idx[is_node]
+            klo, khi = lo[kids], hi[kids]
+            kused = (links[kids] != 0)[..., None]
+            plo, phi = lo[frontier][is_node][:, None, :], hi[frontier][is_node][:, None, :]
+            assert (np.where(kused, klo >= plo, True)).all() and (np.where(kused, khi <= phi, True)).all(), f"{what}: a node child's box does not hold that node's boxes"
+            np.add.at(node_seen, kids, 1)
+            frontier = kids
+            levels += 1
+            assert levels < 200
+        assert (leaf_seen == 1).all(), f"{what}: {int((leaf_seen == 0).sum())} triangles are not reachable from the root, {int((leaf_seen > 1).sum())} more than once"
+        assert node_seen.max() == 1, f"{what}: a wide node is linked twice"
+        reached = float(node_seen.mean())
+        assert 0.2 <= reached <= 0.6, f"{what}: {reached:.2f} of the node slots are reached"
+        slots = (leaves[:, 0, 3].view(np.uint32) >> 2)
+        assert len(np.unique(slots)) == live, f"{what}: a triangle slot hangs from two leaf records"
+        return live
+
+    before = check(f"{scene}, first build", 1)
+    place = np.eye(4, dtype=np.float32)[:3].copy(); place[:, 3] = (0.0, 0.5, 0.0)
+    e.insert_instance(7000, Instance(7777, 1, place))
+    assert check(f"{scene}, after a spawn", 2) == before + 200
+    e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_triangles", [1, 2, 3, 5, 33, 257, 1025, 4099])
 def test_small_trees_built_on_the_device(n_triangles):
     """The device builder's small ends: a segment tree of fewer nodes than one workgroup's width (k_lbvh_seg_levels with count0 < 256, down to ONE
