@@ -622,8 +622,9 @@ def test_every_triangle_hangs_exactly_once_from_the_root_of_a_device_built_tree(
             p0, e1, e2 = rec[:, 0, :3], rec[:, 1, :3], rec[:, 2, :3]
             verts = np.stack([p0, p0 + e1, p0 + e2], 1)
             blo, bhi = lo[frontier][is_leaf], hi[frontier][is_leaf]
-            eps = 1e-4 * np.maximum(1.0, np.abs(verts).max())
-            assert (verts.min(1) >= blo - eps).all() and (verts.max(1) <= bhi + eps).all(), f"{what}: a leaf child's box does not hold its triangle"
+            if len(verts):
+                eps = 1e-4 * np.maximum(1.0, np.abs(verts).max())
+                assert (verts.min(1) >= blo - eps).all() and (verts.max(1) <= bhi + eps).all(), f"{what}: a leaf child's box does not hold its triangle"
             # a node child's box holds every box of that node
             kids = idx[is_node]
             klo, khi = lo[kids], hi[kids]
