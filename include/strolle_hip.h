@@ -178,11 +178,11 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                                                instances only MOVED refits that tree: st_debug_device_tree_refits): fast arithmetic, no
                                                BvhHeatmap camera, no byte counting. A tick that finds such an observer builds on the host as
                                                ST_BVH_REBUILD does; a heatmap camera created later renders after the next st_tick. */,
-                    ST_BVH_AUTO = 4         /* (round 6) THE DEFAULT. The first tree of a scene of fewer than 100,000 triangles is built on the host as
+                    ST_BVH_AUTO = 4         /* (round 6) THE DEFAULT. The first tree of a scene of fewer than 120,000 triangles is built on the host as
                                                ST_BVH_REBUILD builds it — the reference's binned SAH, the better tree at that size (frames 3-6 % faster
                                                at 13 k - 52 k triangles), paid once while the scene loads; every later change (spawn, despawn, move) is
                                                answered as ST_BVH_BUILD_DEVICE answers it, under the same conditions, so that a default engine no longer
-                                               stalls for tens of milliseconds per spawn. A scene of 100,000 triangles or more gets its FIRST tree from
+                                               stalls for tens of milliseconds per spawn. A scene of 120,000 triangles or more gets its FIRST tree from
                                                the device builder too: measured, frames over it are 3-16 % faster there than over the host's tree, and
                                                the first tick of a 208 k-triangle scene takes 16 ms instead of 73 (profiles/r06_tree_choice.txt).
                                                Scenes whose stream fits the kernels' LDS copy (at most 112

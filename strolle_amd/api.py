@@ -505,7 +505,7 @@ class EngineBase:
         """st_set_bvh_refresh: False / 0 = rebuild on every change (the reference's behaviour), True / 1 = refit while instances only
         move, 2 = the same with the boxes recomputed on the device (ST_BVH_REFIT_DEVICE; libstrolle_hip.so only), 3 = the tree BUILT on the device
         straight into the wide stream while nothing observes the contract stream (ST_BVH_BUILD_DEVICE; libstrolle_hip.so only), 4 = the library's default
-        (ST_BVH_AUTO: the first tree on the host below 100,000 triangles, every later change — and a larger scene's first tree — as mode 3)."""
+        (ST_BVH_AUTO: the first tree on the host below 120,000 triangles, every later change — and a larger scene's first tree — as mode 3)."""
         refit = int(refit)
         if refit not in (0, 1, 2, 3, 4):
             raise StrolleError(f"unknown BVH refresh mode {refit}")

@@ -133,7 +133,7 @@ DUNGEON_TORI = [(-0.5, 0.33, -5.5), (-11.0, 0.33, 28.0), (-11.5, 0.33, 13.5)]   
 DUNGEON_DESCRIPTION = "dungeon: level.glb (8,393 triangles, 45 textured materials) + the demo's three emissive Bevy tori (3 x 1,536 triangles) = 13,001 triangles, 7 light slots"
 
 
-def build_dungeon(engine, subdivide: int = 0, tori: bool = True):
+def build_dungeon(engine, subdivide: int = 0, tori: bool = True, tori_subdivide=None):
     """demo.rs:155-218: level.glb, six point lights, the three emissive tori (`shape::Torus::default()`, scale 0.5, rotated
     1 rad about Z; material base colour sRGB (0.9, 0.6, 0.3), emissive 10 x that, then — like every material of the scene —
     reflectance 0 and perceptual roughness 1, demo.rs:254-258), sun below the horizon. The spot light has intensity 0 and
@@ -147,8 +147,8 @@ def build_dungeon(engine, subdivide: int = 0, tori: bool = True):
     n = _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0), subdivide=subdivide)
     if tori:
         pos, nrm, uv = bevy_torus()
-        if subdivide:
-            pos, nrm, uv = _subdivide(pos, nrm, uv, subdivide)
+        if subdivide if tori_subdivide is None else tori_subdivide:   # (tori_subdivide: measurement scenes whose tori are split more or less often than the level)
+            pos, nrm, uv = _subdivide(pos, nrm, uv, subdivide if tori_subdivide is None else tori_subdivide)
         mesh_handle, first = 5000, 5001
         engine.insert_mesh(mesh_handle, Mesh(pos, nrm, uv))
         srgb = (0.9, 0.6, 0.3)

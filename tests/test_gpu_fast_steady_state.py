@@ -163,7 +163,7 @@ def _run(scene, size, plan, moving=False, mode=CameraMode.IMAGE, tree="host"):
     #       "device" — the FIRST tree is k_lbvh.hip's already (st_set_bvh_refresh(ST_BVH_BUILD_DEVICE) before the scene exists; the default for large scenes);
     #       "spawned" — the default mode: host tree first, then an instance appears at frame 2 (a device BUILD) and moves at every later
     #                   frame (device REFITS of that tree, a rebuild after 15) — the oracle rebuilds its SAH tree every time.
-    # Since late round 6 ST_BVH_AUTO builds the FIRST tree of a scene of 100,000 triangles or more on the device too (st_tick.cpp device_build_possible;
+    # Since late round 6 ST_BVH_AUTO builds the FIRST tree of a scene of 120,000 triangles or more on the device too (st_tick.cpp device_build_possible;
     # profiles/r06_tree_choice.txt): for "dungeon134k" (208 k triangles) "device" IS the default mode and "host" asks for the host's tree explicitly.
     big = scene == "dungeon134k"
     if tree == "device" and not big:

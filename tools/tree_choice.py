@@ -13,7 +13,9 @@ from strolle_amd import CameraMode, Engine, scenes
 
 def steady(subdivide, tori, mode, size, refresh):
     e = Engine(device=0); e.set_bvh_refresh(refresh)
-    scenes.build_dungeon(e, subdivide=subdivide, tori=tori); e.set_seed(1)
+    if isinstance(tori, int) and not isinstance(tori, bool): scenes.build_dungeon(e, subdivide=subdivide, tori=True, tori_subdivide=tori)   # (the tori split `tori` times)
+    else: scenes.build_dungeon(e, subdivide=subdivide, tori=tori)
+    e.set_seed(1)
     desc = scenes.dungeon_camera(size, mode, depth=1)
     cam = e.create_camera(desc)
     out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
@@ -33,10 +35,12 @@ def steady(subdivide, tori, mode, size, refresh):
     e.close()
     return best, t_load, builds
 
+extra = [("107 k (level x4, tori x16)", 1, 2, CameraMode.IMAGE, (1920, 1080)), ("139 k (level x16, tori x1)", 2, 0, CameraMode.IMAGE, (1920, 1080))]   # TREE_CHOICE_EXTRA=1
 cases = [("13 k", 0, True, CameraMode.IMAGE, (1920, 1080)), ("52 k", 1, True, CameraMode.IMAGE, (1920, 1080)), ("134 k (no tori)", 2, False, CameraMode.IMAGE, (1920, 1080)),
          ("134 k (no tori)", 2, False, CameraMode.GI_DIFFUSE, (1920, 1080)), ("208 k", 2, True, CameraMode.IMAGE, (1920, 1080)), ("208 k", 2, True, CameraMode.GI_DIFFUSE, (1920, 1080)),
          ("208 k", 2, True, CameraMode.IMAGE, (3840, 2160))]
-for name, sub, tori, mode, size in cases:
+
+for name, sub, tori, mode, size in (extra if os.environ.get('TREE_CHOICE_EXTRA') else cases):
     rows = {0: [], 3: []}; loads = {0: [], 3: []}
     for _ in range(args.rounds):
         for refresh in (0, 3):
