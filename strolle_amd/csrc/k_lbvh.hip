@@ -243,14 +243,17 @@ __global__ __launch_bounds__(kT) void k_lbvh_refit_nodes(const float4* node_box,
 }
 }  // namespace
 
-// The sort: rocPRIM's default configuration, which below 1 M keys is its merge sort — one block sort and two launches per doubling of the sorted runs:
-// 17 launches, 110 us of launch latency, at 208 k keys. Two replacements were built and measured in round 6, both giving the same order, both slower:
+// The sort: rocPRIM's radix_sort_pairs, which below 1 M keys is its merge sort — one block sort and two launches per doubling of the sorted runs: with the
+// default configuration (runs of 1,024) 17 launches, 99-110 us of launch latency, at 208 k keys; LbvhSort block-sorts runs of 4,096 (1,024 threads x 4 keys):
+// 13 launches, 82 us — the block sort 9 -> 18 us, four merge launches of 5 us fewer; runs of 8,192: 11 launches but a 30-us block sort, 95 us
+// (profiles/r06_lbvh_sort_config.txt). Two replacements were built and measured in round 6, both giving the same order, both slower:
 // the library's onesweep radix sort (radix_sort_config<..., MergeSortLimit = 8192>: 6 launches, but 23-29 us per pass and 10-20 us of memsets between
 // them: 163 us; profiles/r06_lbvh_onesweep.txt) and an own bucket-and-rank form (3 launches; 540 us on the dungeon, whose slot order and tori make its
 // atomics collide and its buckets huge; tools/experiments/lbvh_bucket_sort.inc, profiles/r06_lbvh_bucket_sort.txt).
+using LbvhSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512u, 1024u, 4u>, rocprim::default_config>;
 size_t lbvh_sort_temp_bytes(uint32_t slots) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)slots, 0u, 31u, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs<LbvhSort>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)slots, 0u, 31u, (hipStream_t) nullptr);
     return bytes;
 }
 uint32_t lbvh_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
@@ -276,7 +279,7 @@ int lbvh_build(const LbvhArgs& a, hipStream_t s) {
     uint32_t* codes_out = reinterpret_cast<uint32_t*>(a.keys_in); uint32_t* slots_out = codes_out + a.slots;
     hipLaunchKernelGGL(k_lbvh_keys, grid(a.slots), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds, codes_in, slots_in);
     size_t temp = a.sort_temp_bytes;
-    if (rocprim::radix_sort_pairs(a.sort_temp, temp, codes_in, codes_out, slots_in, slots_out, (size_t)a.slots, 0u, 31u, s) != hipSuccess) return -2;
+    if (rocprim::radix_sort_pairs<LbvhSort>(a.sort_temp, temp, codes_in, codes_out, slots_in, slots_out, (size_t)a.slots, 0u, 31u, s) != hipSuccess) return -2;
     hipLaunchKernelGGL(k_lbvh_compose, grid(a.slots), dim3(kT), 0, s, codes_out, slots_out, a.slots, a.keys_out);
     hipLaunchKernelGGL(k_lbvh_leaves, grid(pow2), dim3(kT), 0, s, a.keys_out, a.live, pow2, a.tri_geo, a.tri_bounds, a.tri_info, a.seg, a.leaves);
     for (uint32_t count = pow2 >> 1; count >= 1u;) {
