@@ -191,7 +191,7 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
 /* Ticks whose tree was built on the device so far (ST_BVH_BUILD_DEVICE). */
 int st_debug_device_builds(StEngine* e, uint64_t* ticks);
 /* Ticks of that mode in which instances only moved and the device-built tree was REFITTED instead (same shape, every box recomputed: 5 launches
-   against 26; at most 15 in a row, then the next change rebuilds; ST_NO_DEVICE_TREE_REFIT=1 in the environment rebuilds always). */
+   against 22; at most 15 in a row, then the next change rebuilds; ST_NO_DEVICE_TREE_REFIT=1 in the environment rebuilds always). */
 int st_debug_device_tree_refits(StEngine* e, uint64_t* ticks);
 int st_set_bvh_refresh(StEngine* e, int mode);
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits);

@@ -22,9 +22,9 @@
 //      links decide which of them a walk reaches (rounds 5-6: a frontier walk, 14 launches)                             k_lbvh_wide_nodes
 //
 //   R. instances only moved: steps 4-6 again over the SAME sorted order, then every wide node's box words from its links           lbvh_refit
-//      (5 launches against the build's 26; st_tick.cpp: at most 15 refits between two builds)
+//      (5 launches against the build's 22; st_tick.cpp: at most 15 refits between two builds)
 //
-// 208 k triangles, one build: 0.18 ms of device time (profiles/r06_lbvh_kernel_stats_one_launch.txt; round 5: 0.34). Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
+// 208 k triangles, one build: 0.17 ms of device time (profiles/r06_lbvh_kernel_stats_one_launch.txt, r06_lbvh_sort_config.txt; round 5: 0.34). Host model (tools/bvh4_sim.py's rays over this tree, dungeon): 13.8 node steps per primary ray against the SAH tree's 13.6, 14.3 against
 // 11.6 for a GI bounce, the same number of triangle tests, deepest stack 13-14.
 #include <hip/hip_fp16.h>
 #include <rocprim/device/device_radix_sort.hpp>

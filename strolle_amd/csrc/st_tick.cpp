@@ -124,7 +124,7 @@ int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
     a.sort_temp = t.lb_temp.ptr; a.sort_temp_bytes = temp;
     a.seg = static_cast<float4*>(t.lb_seg.ptr); a.children = static_cast<uint2*>(t.lb_children.ptr); a.node_box = static_cast<float4*>(t.lb_node_box.ptr);
     a.bounds = static_cast<int*>(t.lb_small.ptr);
-    // moves only, on a copy whose last build saw these very slots: the tree keeps its shape, every box follows (k_lbvh.hip lbvh_refit: 5 launches against 26)
+    // moves only, on a copy whose last build saw these very slots: the tree keeps its shape, every box follows (k_lbvh.hip lbvh_refit: 5 launches against 22)
     if (refit_tree) {
         if (lbvh_refit(a, up) != 0) return fail(ST_ERR_HIP, "the device BVH refit failed to launch");
         if (timing) fprintf(stderr, "[st_tick] device tree refit: slot words %.3f ms, uploads %.3f, bake launches %.3f, refit launches %.3f\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
