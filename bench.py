@@ -671,7 +671,7 @@ def main():
         except Exception:
             lit_fraction = None
     engine_exact = engine.exact
-    bvh_tree = ("device builder (k_lbvh.hip: LBVH, 4-wide; ST_BVH_AUTO's first tree from 120,000 triangles on)" if engine.device_builds() > 0
+    bvh_tree = ("device builder (k_lbvh.hip: LBVH, 4-wide; ST_BVH_AUTO picked it: the host's tree hangs long leaf runs on large faces, st_debug_auto_tree)" if engine.device_builds() > 0
                 else "host, binned SAH (the reference's tree: strolle/src/bvh/builder.rs)")   # which tree the timed frames walked — read BEFORE bvh_depth(), a debug read that rebuilds a stale host tree
     bvh_depth = engine.bvh_depth()   # read here: the N > 1 extras close this job's engine
     extras = {}

@@ -178,13 +178,14 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                                                instances only MOVED refits that tree: st_debug_device_tree_refits): fast arithmetic, no
                                                BvhHeatmap camera, no byte counting. A tick that finds such an observer builds on the host as
                                                ST_BVH_REBUILD does; a heatmap camera created later renders after the next st_tick. */,
-                    ST_BVH_AUTO = 4         /* (round 6) THE DEFAULT. The first tree of a scene of fewer than 120,000 triangles is built on the host as
-                                               ST_BVH_REBUILD builds it — the reference's binned SAH, the better tree at that size (frames 3-6 % faster
-                                               at 13 k - 52 k triangles), paid once while the scene loads; every later change (spawn, despawn, move) is
+                    ST_BVH_AUTO = 4         /* (round 6) THE DEFAULT. The first tree of a scene is built on the host as ST_BVH_REBUILD builds it — the
+                                               reference's binned SAH, paid once while the scene loads; every later change (spawn, despawn, move) is
                                                answered as ST_BVH_BUILD_DEVICE answers it, under the same conditions, so that a default engine no longer
-                                               stalls for tens of milliseconds per spawn. A scene of 120,000 triangles or more gets its FIRST tree from
-                                               the device builder too: measured, frames over it are 3-16 % faster there than over the host's tree, and
-                                               the first tick of a 208 k-triangle scene takes 16 ms instead of 73 (profiles/r06_tree_choice.txt).
+                                               stalls for tens of milliseconds per spawn. The host's first tree is MEASURED (st_debug_auto_tree: the
+                                               surface-area-weighted mean length of its leaf runs): above 3.8 — long runs of coplanar triangles on large
+                                               faces, a step of the wide walk each — the device builder's tree is used from that very tick on; over 17
+                                               scenes of 13 k - 537 k triangles that is exactly where it renders faster (3-16 %), and everywhere else the
+                                               host's tree is 3-13 % faster and stays (profiles/r06_tree_choice*.txt).
                                                Scenes whose stream fits the kernels' LDS copy (at most 112
                                                entries: the Cornell box), host-only engines, the exact build and observed contract streams behave as
                                                under ST_BVH_REBUILD. */ };
@@ -212,6 +213,10 @@ int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* 
  * (StTuning::allow_deep_bvh = 1: a warning on stderr instead). *overflows: ticks that found a word set; *wide_stack_entries: what the wide walks
  * hold now; *packets_off: 1 once the packet walk overflowed. */
 int st_debug_walk_overflow(StEngine* e, uint64_t* overflows, uint32_t* wide_stack_entries, uint32_t* packets_off);
+/* What ST_BVH_AUTO's choice of a scene's first tree rests on. *leaf_run_weight: the surface-area-weighted mean length of the leaf runs of the host's
+ * last binned-SAH build (1 = every leaf holds one triangle); *first_tree_on_device: 1 when that weight exceeded 3.8 at the scene's first tick and the
+ * device builder's tree was used from that tick on (measured: profiles/r06_tree_choice*.txt). */
+int st_debug_auto_tree(StEngine* e, float* leaf_run_weight, uint32_t* first_tree_on_device);
 
 /* Deterministic seeds: every pass draws seed = pass_seed(base, frame, pass_id) instead of
  * rand::thread_rng() (camera_controller.rs:189-194; passes/ref_*.rs:49-59). */

@@ -165,8 +165,9 @@ extern "C" {
     pub fn st_set_seed(e: *mut StEngine, seed: u64) -> i32;
     pub fn st_set_blue_noise(e: *mut StEngine, rgba: *const u8, bytes: usize) -> i32; // Noise::new (noise.rs:40-50)
     pub fn st_engine_set_arithmetic(e: *mut StEngine, arithmetic: i32) -> i32;
-    pub fn st_set_bvh_refresh(e: *mut StEngine, mode: i32) -> i32; // 0 rebuild, 1 refit, 2 refit on the device, 3 build on the device (ST_BVH_BUILD_DEVICE), 4 the default (ST_BVH_AUTO: first tree on the host below 120,000 triangles, changes on the device)
+    pub fn st_set_bvh_refresh(e: *mut StEngine, mode: i32) -> i32; // 0 rebuild, 1 refit, 2 refit on the device, 3 build on the device (ST_BVH_BUILD_DEVICE), 4 the default (ST_BVH_AUTO: first tree on the host unless its leaf runs are long, changes on the device)
     pub fn st_debug_walk_overflow(e: *mut StEngine, overflows: *mut u64, wide_stack_entries: *mut u32, packets_off: *mut u32) -> i32;
+    pub fn st_debug_auto_tree(e: *mut StEngine, leaf_run_weight: *mut f32, first_tree_on_device: *mut u32) -> i32;
     pub fn st_debug_device_builds(e: *mut StEngine, ticks: *mut u64) -> i32;
     pub fn st_debug_device_tree_refits(e: *mut StEngine, ticks: *mut u64) -> i32;
     pub fn st_engine_get_tuning(e: *mut StEngine, out: *mut StTuning) -> i32;

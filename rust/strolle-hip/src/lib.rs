@@ -352,7 +352,7 @@ where
 
     /// Not part of the reference's API: refit the BVH instead of rebuilding it while instances only move — on the device
     /// (ST_BVH_REFIT_DEVICE = 2: st_tick sends the moved triangles only; same bits as the host refit). `false` goes back to the library's
-    /// default (ST_BVH_AUTO = 4: the first tree on the host below 120,000 triangles, every later change answered on the device while nothing observes the contract stream).
+    /// default (ST_BVH_AUTO = 4: the first tree on the host unless it hangs long leaf runs on large faces (then the device builder's), every later change answered on the device while nothing observes the contract stream).
     pub fn set_bvh_refit(&mut self, refit: bool) {
         check(unsafe { ffi::st_set_bvh_refresh(self.raw, if refit { 2 } else { 4 }) });
     }

@@ -319,6 +319,8 @@ class _Binding:
                 self.debug_walk_overflow = fn("debug_walk_overflow", [vp, P(u64), P(u32), P(u32)])
             self.debug_bvh_device_refits = fn("debug_bvh_device_refits", [vp, P(u64)])
             self.debug_device_bakes = fn("debug_device_bakes", [vp, P(u64), P(u64)])
+            if hasattr(lib, prefix + "debug_auto_tree"):   # (round 6, late)
+                self.debug_auto_tree = fn("debug_auto_tree", [vp, P(C.c_float), P(u32)])
             self.debug_device_builds = fn("debug_device_builds", [vp, P(u64)])
             self.debug_device_tree_refits = fn("debug_device_tree_refits", [vp, P(u64)])
             self.engine_get_tuning = fn("engine_get_tuning", [vp, P(StTuning)]); self.engine_set_tuning = fn("engine_set_tuning", [vp, P(StTuning)])
@@ -505,7 +507,7 @@ class EngineBase:
         """st_set_bvh_refresh: False / 0 = rebuild on every change (the reference's behaviour), True / 1 = refit while instances only
         move, 2 = the same with the boxes recomputed on the device (ST_BVH_REFIT_DEVICE; libstrolle_hip.so only), 3 = the tree BUILT on the device
         straight into the wide stream while nothing observes the contract stream (ST_BVH_BUILD_DEVICE; libstrolle_hip.so only), 4 = the library's default
-        (ST_BVH_AUTO: the first tree on the host below 120,000 triangles, every later change — and a larger scene's first tree — as mode 3)."""
+        (ST_BVH_AUTO: the first tree on the host — unless it hangs long leaf runs on large faces (auto_tree()), then the device builder's —, every later change as mode 3)."""
         refit = int(refit)
         if refit not in (0, 1, 2, 3, 4):
             raise StrolleError(f"unknown BVH refresh mode {refit}")
@@ -557,6 +559,12 @@ class EngineBase:
         n, entries, off = C.c_uint64(), C.c_uint32(), C.c_uint32()
         self._check(self._b.debug_walk_overflow(self._h, C.byref(n), C.byref(entries), C.byref(off)))
         return n.value, entries.value, off.value
+
+    def auto_tree(self):
+        """(surface-area-weighted mean leaf-run length of the host's last tree, True when ST_BVH_AUTO gave this scene's first tree to the device builder) — st_debug_auto_tree."""
+        w, d = C.c_float(), C.c_uint32()
+        self._check(self._b.debug_auto_tree(self._h, C.byref(w), C.byref(d)))
+        return float(w.value), bool(d.value)
 
     def image_rect(self, handle: int):
         """(x, y, w, h) of an image in the atlas, in texels."""

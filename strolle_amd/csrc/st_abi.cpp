@@ -487,6 +487,11 @@ int st_debug_walk_overflow(StEngine* e, uint64_t* overflows, uint32_t* wide_stac
     *overflows = E(e)->walk_overflows; *wide_stack_entries = E(e)->wide_stack_entries_now(); *packets_off = E(e)->packets_overflowed ? 1u : 0u;
     return ST_OK;
 }
+int st_debug_auto_tree(StEngine* e, float* leaf_run_weight, uint32_t* first_tree_on_device) {
+    ST_REQUIRE(e && leaf_run_weight && first_tree_on_device, "null argument");
+    *leaf_run_weight = E(e)->host_leaf_run_weight; *first_tree_on_device = E(e)->auto_first_on_device ? 1u : 0u;
+    return ST_OK;
+}
 int st_debug_bvh_refits(StEngine* e, uint64_t* rebuilds, uint64_t* refits) {
     ST_REQUIRE(e && rebuilds && refits, "null argument");
     *rebuilds = E(e)->rebuilds; *refits = E(e)->refits;

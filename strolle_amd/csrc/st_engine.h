@@ -541,7 +541,10 @@ struct Engine {
     uint64_t walk_overflows = 0; bool walk_overflow_unreported = false;
     uint32_t wide_stack_entries_now() const { return wide_stack_rearmed ? wide_stack_rearmed : (tuning.wide_stack_entries ? tuning.wide_stack_entries : (uint32_t)kBvhStackSize); }
     void note_walk_overflow();
-    static constexpr uint32_t kAutoDeviceFirstTriangles = 120000u;   // ST_BVH_AUTO: from this many live triangles on, the first tree is the device builder's too (st_tick.cpp device_build_possible)
+    // ST_BVH_AUTO's choice of a scene's FIRST tree (st_tick.cpp device_build_possible): host_leaf_run_weight = the surface-area-weighted mean length of the host
+    // tree's leaf runs (rebuild_host_tree); above kAutoLeafRunLimit the device builder's tree renders faster (profiles/r06_tree_choice*.txt)
+    static constexpr float kAutoLeafRunLimit = 3.8f;
+    float host_leaf_run_weight = 1.0f; bool auto_first_on_device = false;
     bool device_build_possible() const;
     int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);
     int reserve_device_builder(SceneSet& t, size_t slots, uint32_t live);

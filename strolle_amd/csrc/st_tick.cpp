@@ -21,6 +21,18 @@ void Engine::rebuild_host_tree(bool timing) {
     const auto t3 = now();
     bvh.flatten(blend, bvh_stream);
     const auto t4 = now();
+    {   // what ST_BVH_AUTO's choice of the first tree rests on (device_build_possible): the surface-area-weighted mean length of this tree's leaf runs
+        double weighted = 0.0, area = 0.0;
+        std::vector<uint32_t> todo;
+        if (!bvh.nodes.empty() && !bvh.prims.empty()) todo.push_back(0u);
+        while (!todo.empty()) {
+            const auto& n = bvh.nodes[todo.back()]; todo.pop_back();
+            if (n.internal) { todo.push_back(n.left); todo.push_back(n.right); continue; }
+            const double a = (double)n.bounds.half_area();
+            if (a > 0.0 && a < 1e300) { weighted += a * (double)(n.end - n.begin); area += a; }
+        }
+        host_leaf_run_weight = area > 0.0 ? (float)(weighted / area) : 1.0f;
+    }
     rebuilds++; tree_version++; host_stream_stale = false; host_tree_stale = false;
     mark_internal_starts(); measure_stack_need();
     have_topology = false;
@@ -33,10 +45,13 @@ void Engine::rebuild_host_tree(bool timing) {
 // (k_common.h scene_fits_lds: the Cornell box) keep the host's tree, which their kernels walk from LDS with the exact closest-hit loop.
 bool Engine::device_build_possible() const {
     // ST_BVH_AUTO: a scene that fits LDS keeps its contract stream there (a leaf entry per triangle: more than 112 of them never fit); a larger one sends its
-    // CHANGES to the device builder and, from kAutoDeviceFirstTriangles on, its first tree too: measured (tools/tree_choice.py, profiles/r06_tree_choice.txt), the
-    // steady frame over the device's tree against the host's binned-SAH tree is 1.03x at 13 k triangles and 1.06x at 52 k, but 0.84-0.89x at 134 k and 0.93-0.97x
-    // at 208 k (the SAH tree's leaf runs cost the wide walk a step per triangle), and the first tick of a 208 k-triangle scene is 16 ms instead of 73.
-    const bool automatic = bvh_refresh_mode == ST_BVH_AUTO && (scene_uploaded || live_prims_ >= kAutoDeviceFirstTriangles) && live_prims_ > kLdsSceneTexels / 4u;
+    // CHANGES to the device builder — and its FIRST tree too when the host's tree, built first, turns out to hang long leaf runs on large faces
+    // (auto_first_on_device: tick() sets it when rebuild_host_tree measured host_leaf_run_weight > kAutoLeafRunLimit). Measured on 17 scenes of 13 k to 537 k
+    // triangles (tools/tree_choice.py, profiles/r06_tree_choice*.txt): wherever that weight is 3.0 or less the frames over the host's binned-SAH tree are 3-13 %
+    // faster than over the device's LBVH; at 3.7 they tie; at 4.2-4.5 (the dungeon with its level split x16: runs of up to 140 coplanar triangles, a wide
+    // walk's step each) the device's tree is 3-16 % faster. A triangle COUNT does not separate them: 16 instanced copies of the level (139 k triangles,
+    // weight 1.8) render 9-13 % faster on the host's tree, the x16-split level (134 k, weight 4.5) 11-16 % faster on the device's.
+    const bool automatic = bvh_refresh_mode == ST_BVH_AUTO && (scene_uploaded || auto_first_on_device) && live_prims_ > kLdsSceneTexels / 4u;
     if (!(bvh_refresh_mode == ST_BVH_BUILD_DEVICE || automatic) || !has_device || arithmetic != ST_ARITH_FAST) return false;
     if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes) return false;
     for (const auto& kv : cameras) if (kv.second->desc.mode == ST_MODE_BVH_HEATMAP) return false;
@@ -158,7 +173,7 @@ int Engine::tick(hipStream_t stream) {
     // and the host's tree falls behind; the first tick that finds an observer brings it up to date like any rebuild.
     if (materials_changed_this_tick) info_full_ = true;   // a Blend flag may have changed under any slot
     if ((instances_changed && !moved_on_device) || materials_changed_this_tick) tri_info_serial_++;   // slots, liveness, materials or Blend flags may have changed
-    const bool build_on_device_now = device_build_possible();
+    bool build_on_device_now = device_build_possible();
     device_tree_refit_now = false;
     if (instances_changed && build_on_device_now) {
         // instances only moved (refresh_instances left them to the device's bake): the device-built tree is refitted, not rebuilt — at most
@@ -184,6 +199,11 @@ int Engine::tick(hipStream_t stream) {
         } else {
             rebuild_host_tree(timing);
             if (refitting) { index_stream(); topology_signature = signature; have_topology = true; }
+            if (!scene_uploaded && bvh_refresh_mode == ST_BVH_AUTO) {
+                // the first tree of this scene: the host's, unless it hangs long leaf runs on large faces — then the device builder's, from this very tick on
+                auto_first_on_device = host_leaf_run_weight > kAutoLeafRunLimit;
+                if (auto_first_on_device && device_build_possible()) { build_on_device_now = true; device_builds++; device_refits_since_build = 0; }
+            }
         }
         scene_changed = true;
     } else if (scene_uploaded && sets[live].device_built && !build_on_device_now) {

@@ -35,7 +35,7 @@ def _subdivide(pos, nrm, uv, levels: int):
     return pos, nrm, uv
 
 
-def _insert_gltf(engine, npz, material_overrides=None, first_handle=1, subdivide: int = 0):
+def _insert_gltf(engine, npz, material_overrides=None, first_handle=1, subdivide: int = 0, subdivide_meshes=None):
     n_mat = len(npz["material_metallic"])
     n_img = int(npz["n_images"]) if "n_images" in npz else 0
     for i in range(n_img):
@@ -57,7 +57,7 @@ def _insert_gltf(engine, npz, material_overrides=None, first_handle=1, subdivide
     n = int(npz["n_meshes"])
     for i in range(n):
         pos, nrm, uv = npz[f"positions_{i}"], npz[f"normals_{i}"], npz[f"uvs_{i}"]
-        if subdivide:
+        if subdivide and (subdivide_meshes is None or i in subdivide_meshes):
             n_tri = len(np.asarray(pos).reshape(-1, 3, 3))
             pos, nrm, uv = _subdivide(np.asarray(pos, np.float32).reshape(n_tri, 3, 3), np.asarray(nrm, np.float32).reshape(n_tri, 3, 3),
                                       np.asarray(uv, np.float32).reshape(n_tri, 3, 2), subdivide)
@@ -133,7 +133,7 @@ DUNGEON_TORI = [(-0.5, 0.33, -5.5), (-11.0, 0.33, 28.0), (-11.5, 0.33, 13.5)]   
 DUNGEON_DESCRIPTION = "dungeon: level.glb (8,393 triangles, 45 textured materials) + the demo's three emissive Bevy tori (3 x 1,536 triangles) = 13,001 triangles, 7 light slots"
 
 
-def build_dungeon(engine, subdivide: int = 0, tori: bool = True, tori_subdivide=None):
+def build_dungeon(engine, subdivide: int = 0, tori: bool = True, tori_subdivide=None, subdivide_meshes=None, copies: int = 1):
     """demo.rs:155-218: level.glb, six point lights, the three emissive tori (`shape::Torus::default()`, scale 0.5, rotated
     1 rad about Z; material base colour sRGB (0.9, 0.6, 0.3), emissive 10 x that, then — like every material of the scene —
     reflectance 0 and perceptual roughness 1, demo.rs:254-258), sun below the horizon. The spot light has intensity 0 and
@@ -144,7 +144,12 @@ def build_dungeon(engine, subdivide: int = 0, tori: bool = True, tori_subdivide=
     engine.set_blue_noise(load_blue_noise())
     # (the subdivided variants are 25 / 26 internal nodes deep: since round 5 the launches that walk the contract stream take a stack as deep as
     # the tree needs, up to 32 entries — StTuning::allow_deep_bvh is no longer set here, no push is dropped)
-    n = _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0), subdivide=subdivide)
+    n = _insert_gltf(engine, npz, material_overrides=dict(reflectance=0.0, perceptual_roughness=1.0), subdivide=subdivide, subdivide_meshes=subdivide_meshes)   # (subdivide_meshes: measurement scenes in which only some of the level's 45 meshes are split)
+    for c in range(1, copies):   # (measurement scenes: the level instanced again on a 4-wide grid of 50 x 100 m cells — a LARGE scene that is not a subdivided small one)
+        for i in range(n):
+            x = npz[f"xform_{i}"].reshape(4, 3).T.copy()
+            x[0, 3] += 50.0 * (c % 4); x[2, 3] += 100.0 * (c // 4)
+            engine.insert_instance(20000 + 100 * c + i, Instance(1 + i, 1 + int(npz[f"material_{i}"]), x))
     if tori:
         pos, nrm, uv = bevy_torus()
         if subdivide if tori_subdivide is None else tori_subdivide:   # (tori_subdivide: measurement scenes whose tori are split more or less often than the level)
