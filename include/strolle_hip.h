@@ -182,7 +182,7 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                                                reference's binned SAH, paid once while the scene loads; every later change (spawn, despawn, move) is
                                                answered as ST_BVH_BUILD_DEVICE answers it, under the same conditions, so that a default engine no longer
                                                stalls for tens of milliseconds per spawn. The host's first tree is MEASURED (st_debug_auto_tree: the
-                                               surface-area-weighted mean length of its leaf runs): above 3.8 — long runs of coplanar triangles on large
+                                               surface-area-weighted mean length of its leaf runs): above 3.4 — long runs of coplanar triangles on large
                                                faces, a step of the wide walk each — the device builder's tree is used from that very tick on; over 17
                                                scenes of 13 k - 537 k triangles that is exactly where it renders faster (3-16 %), and everywhere else the
                                                host's tree is 3-13 % faster and stays (profiles/r06_tree_choice*.txt).
@@ -214,7 +214,7 @@ int st_debug_bvh_depth(StEngine* e, uint32_t* deepest_internal_chain, uint32_t* 
  * hold now; *packets_off: 1 once the packet walk overflowed. */
 int st_debug_walk_overflow(StEngine* e, uint64_t* overflows, uint32_t* wide_stack_entries, uint32_t* packets_off);
 /* What ST_BVH_AUTO's choice of a scene's first tree rests on. *leaf_run_weight: the surface-area-weighted mean length of the leaf runs of the host's
- * last binned-SAH build (1 = every leaf holds one triangle); *first_tree_on_device: 1 when that weight exceeded 3.8 at the scene's first tick and the
+ * last binned-SAH build (1 = every leaf holds one triangle); *first_tree_on_device: 1 when that weight exceeded 3.4 at the scene's first tick and the
  * device builder's tree was used from that tick on (measured: profiles/r06_tree_choice*.txt). */
 int st_debug_auto_tree(StEngine* e, float* leaf_run_weight, uint32_t* first_tree_on_device);
 

@@ -543,7 +543,7 @@ struct Engine {
     void note_walk_overflow();
     // ST_BVH_AUTO's choice of a scene's FIRST tree (st_tick.cpp device_build_possible): host_leaf_run_weight = the surface-area-weighted mean length of the host
     // tree's leaf runs (rebuild_host_tree); above kAutoLeafRunLimit the device builder's tree renders faster (profiles/r06_tree_choice*.txt)
-    static constexpr float kAutoLeafRunLimit = 3.8f;
+    static constexpr float kAutoLeafRunLimit = 3.4f;
     float host_leaf_run_weight = 1.0f; bool auto_first_on_device = false;
     bool device_build_possible() const;
     int build_on_device(SceneSet& t, hipStream_t up, bool* pageable);

@@ -579,7 +579,7 @@ def test_a_device_built_tree_is_refitted_while_instances_only_move(n_triangles):
 
 @pytest.mark.gpu
 def test_the_default_refresh_mode_picks_a_scenes_first_tree_by_the_host_trees_leaf_runs():
-    """ST_BVH_AUTO: the host builds the first tree; when that tree hangs long leaf runs on large faces (st_debug_auto_tree: weight > 3.8) the device builder's tree
+    """ST_BVH_AUTO: the host builds the first tree; when that tree hangs long leaf runs on large faces (st_debug_auto_tree: weight > 3.4) the device builder's tree
     is used from that very tick on — measured 3-16 % faster there, 3-13 % slower everywhere else (tools/tree_choice.py, profiles/r06_tree_choice*.txt). The
     triangle count does not decide: 16 instanced copies of the level (139 k triangles) stay on the host's tree, the level split x16 (208 k with its tori) does not."""
     _torch()
@@ -588,7 +588,7 @@ def test_the_default_refresh_mode_picks_a_scenes_first_tree_by_the_host_trees_le
         e = Engine(device=0, exact=False)
         build(e); e.tick()
         weight, on_device = e.auto_tree()
-        assert on_device == device_first and (weight > 3.8) == device_first, f"{what}: weight {weight}"
+        assert on_device == device_first and (weight > 3.4) == device_first, f"{what}: weight {weight}"
         assert e.bvh_refits()[0] == 1, f"{what}: the host builds the first tree either way"
         assert e.device_builds() == (1 if device_first else 0), f"{what}: {e.device_builds()} device builds"
         assert (len(e.read_scene(16)) > 0), f"{what}: no wide stream"

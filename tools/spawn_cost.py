@@ -55,7 +55,7 @@ for mode in args.refresh:
         frames(6); torch.cuda.synchronize()
     t0 = time.perf_counter(); frames(30); torch.cuda.synchronize()
     after = (time.perf_counter() - t0) / 30 * 1e3
-    print(f"refresh mode {mode} ({ {0: 'host rebuild', 3: 'device build', 4: 'auto: changes on the device, the first tree too when the host tree's leaf runs are long'}.get(mode, '?') }), subdivide {args.subdivide}: steady frame {steady:.3f} ms before / {after:.3f} ms after the changes | "
+    print(f"refresh mode {mode} ({ {0: 'host rebuild', 3: 'device build', 4: 'auto: changes on the device, the first tree too when the leaf runs of the host tree are long'}.get(mode, '?') }), subdivide {args.subdivide}: steady frame {steady:.3f} ms before / {after:.3f} ms after the changes | "
           f"spawn / despawn: st_tick {np.median(ticks):.2f} ms on the host (max {max(ticks):.2f}), tick until its device work is through {np.median(idles):.2f} ms (max {max(idles):.2f}), the first frame after it {np.median(first):.2f} ms | "
           f"host rebuilds {e.bvh_refits()[0]}, device builds {e.device_builds()} (+ {e.device_tree_refits()} refits), finite {bool(torch.isfinite(out).all())}")
     e.close()
