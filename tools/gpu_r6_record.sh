@@ -8,3 +8,4 @@ timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/r06_gpu_suite_full.tx
 grep -E "passed|failed|error" gpurun_out/r06_gpu_suite_full.txt | tail -5 | tee gpurun_out/r06_gpu_suite.txt
 timeout 600 python tools/frame_hash.py 2>/dev/null | grep -E "^(cornell|dungeon)" | tee gpurun_out/r06_frame_hashes.txt
 timeout 600 python bench.py 2>/dev/null | tail -1 | tee gpurun_out/r06_bench_final.json
+for sub in 2 0; do timeout 300 python tools/spawn_cost.py --subdivide $sub --refresh 4 2>/dev/null | tail -1 | cut -c1-420; done | tee gpurun_out/r06_spawn_cost_auto_first.txt
