@@ -603,7 +603,7 @@ def test_every_triangle_hangs_exactly_once_from_the_root_of_a_device_built_tree(
     """The device builder writes a wide node at EVERY binary node's slot in one launch (k_lbvh.hip k_lbvh_wide_nodes) and lets the links decide which of
     them a walk reaches. Read back and walked here from node 0, link by link (16-bit links: soup, dungeon; 32-bit: 208 k triangles): every leaf record — one
     per live triangle — is reached exactly ONCE, no node twice, about a third of the slots at all; a leaf child's box (conservative f16) holds its
-    triangle's three vertices, a node child's box holds every box of that node. After a spawn (a second build) the same."""
+    triangle's three vertices, a node child's box holds every box of that node. After a spawn (a second build) and after a move (a refit of that tree) the same."""
     _torch()
     e = Engine(device=0, exact=False)
     e.set_bvh_refresh(3)
@@ -614,9 +614,9 @@ def test_every_triangle_hangs_exactly_once_from_the_root_of_a_device_built_tree(
     nrm = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
     e.insert_mesh(7777, Mesh(pos, np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32)))
 
-    def check(what, builds):
+    def check(what, builds, refits=0):
         e.tick()
-        assert e.device_builds() == builds and e.bvh_refits()[0] == 0
+        assert e.device_builds() == builds and e.device_tree_refits() == refits and e.bvh_refits()[0] == 0
         nodes = e.read_scene(16).view(np.uint32).reshape(-1, 16)
         leaves = e.read_scene(17).reshape(-1, 3, 4)
         live = len(leaves)
@@ -667,6 +667,10 @@ def test_every_triangle_hangs_exactly_once_from_the_root_of_a_device_built_tree(
     place = np.eye(4, dtype=np.float32)[:3].copy(); place[:, 3] = (0.0, 0.5, 0.0)
     e.insert_instance(7000, Instance(7777, 1, place))
     assert check(f"{scene}, after a spawn", 2) == before + 200
+    # the instance only moves: the device bakes it and REFITS the tree (k_lbvh_refit_nodes over every slot) — same links, every box again
+    moved = place.copy(); moved[0, 3] += 0.35; moved[1, 3] += 0.2
+    e.insert_instance(7000, Instance(7777, 1, moved))
+    assert check(f"{scene}, after a move (refit)", 2, refits=1) == before + 200
     e.close()
 
 
