@@ -10,6 +10,7 @@ import argparse, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser(); ap.add_argument("--ticks", type=int, default=1500); ap.add_argument("--subdivide", type=int, default=0); ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--observers", action="store_true", help="every ~100 ticks a BvhHeatmap camera appears for two ticks (the host's tree comes back, then the device's again)")
 args = ap.parse_args()
 import torch
 from strolle_amd import Buffer, CameraMode, Engine, Instance, Mesh, scenes
@@ -47,6 +48,7 @@ stream = torch.cuda.current_stream().cuda_stream
 alive = {}
 next_handle = 7000
 base = None
+observers = 0
 for tick in range(args.ticks):
     r = rng.random()
     if r < 0.25 and len(alive) < 40:
@@ -58,6 +60,17 @@ for tick in range(args.ticks):
         for h in list(alive)[: rng.integers(1, len(alive) + 1)]:
             p = tuple(np.add(alive[h], rng.uniform(-0.05, 0.05, 3))); alive[h] = p
             e.insert_instance(h, Instance(7777, 2, place_at(p)))
+    if args.observers and tick % 97 == 60:
+        hdesc = scenes.dungeon_camera((160, 96), CameraMode.BVH_HEATMAP)
+        hcam = e.create_camera(hdesc); hout = torch.zeros((96, 160, 4), dtype=torch.float32, device="cuda:0")
+        before = e.bvh_refits()[0]
+        for _ in range(2):
+            e.update_camera(hcam, hdesc); e.update_camera(cam, desc); e.tick(stream)
+            e.render_camera(hcam, hout.data_ptr(), stream); e.render_camera(cam, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(hout).all()) and float(hout.abs().sum()) > 0.0, f"tick {tick}: the heatmap is empty"
+        assert e.bvh_refits()[0] >= before
+        e.delete_camera(hcam); observers += 1
     e.update_camera(cam, desc); e.tick(stream); e.render_camera(cam, out.data_ptr(), stream)
     if tick % 50 == 49 or tick == args.ticks - 1:
         torch.cuda.synchronize()
@@ -68,7 +81,7 @@ for tick in range(args.ticks):
             if base is None: base = live - 200 * len(alive)
             assert live == base + 200 * len(alive), f"tick {tick}: {live} leaf records for {len(alive)} instances"
             assert bad == 0 and twice == 1, f"tick {tick}: {bad} triangles not reached exactly once, a node linked {twice} times"
-print(f"{args.ticks} ticks: {e.device_builds()} device builds, {e.device_tree_refits()} refits, {e.bvh_refits()[0]} host rebuilds, {len(alive)} instances alive, {e.walk_overflow()[0]} overflows", flush=True)
+print(f"{args.ticks} ticks{f' ({observers} heatmap observers came and went)' if args.observers else ''}: {e.device_builds()} device builds, {e.device_tree_refits()} refits, {e.bvh_refits()[0]} host rebuilds, {len(alive)} instances alive, {e.walk_overflow()[0]} overflows", flush=True)
 # the final scene on the host's tree: the same primary hits
 ref_desc = scenes.dungeon_camera(size, CameraMode.REFERENCE, depth=0)
 hits = []
