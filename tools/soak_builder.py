@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser(); ap.add_argument("--ticks", type=int, default=150
 ap.add_argument("--observers", action="store_true", help="every ~100 ticks a BvhHeatmap camera appears for two ticks (the host's tree comes back, then the device's again)")
 args = ap.parse_args()
 import torch
-from strolle_amd import Buffer, CameraMode, Engine, Instance, Mesh, scenes
+from strolle_amd import Buffer, CameraMode, Engine, Instance, Material, Mesh, scenes
 
 rng = np.random.default_rng(args.seed)
 pos = (rng.uniform(-0.3, 0.3, (200, 1, 3)) + rng.uniform(-0.05, 0.05, (200, 3, 3))).astype(np.float32)
@@ -41,6 +41,7 @@ def reachable(e):
 
 e = Engine(device=0)
 scenes.build_dungeon(e, subdivide=args.subdivide); e.set_seed(1); e.insert_mesh(7777, blob)
+e.insert_material(9000, Material(base_color=[0.8, 0.3, 0.2, 1.0]))   # the blobs' own material: edited at random below (a materials-only tick rebuilds on the device too)
 desc = scenes.dungeon_camera(size, CameraMode.IMAGE, depth=1)
 cam = e.create_camera(desc)
 out = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda:0")
@@ -49,17 +50,20 @@ alive = {}
 next_handle = 7000
 base = None
 observers = 0
+edits = 0
 for tick in range(args.ticks):
     r = rng.random()
     if r < 0.25 and len(alive) < 40:
         p = (-5.75 + rng.uniform(-2, 2), rng.uniform(0.2, 1.5), -18.2 + rng.uniform(-3, 1)); alive[next_handle] = p
-        e.insert_instance(next_handle, Instance(7777, 2, place_at(p))); next_handle += 1
+        e.insert_instance(next_handle, Instance(7777, 9000, place_at(p))); next_handle += 1
     elif r < 0.45 and alive:
         h = list(alive)[rng.integers(len(alive))]; e.remove_instance(h); del alive[h]
     elif r < 0.9 and alive:
         for h in list(alive)[: rng.integers(1, len(alive) + 1)]:
             p = tuple(np.add(alive[h], rng.uniform(-0.05, 0.05, 3))); alive[h] = p
-            e.insert_instance(h, Instance(7777, 2, place_at(p)))
+            e.insert_instance(h, Instance(7777, 9000, place_at(p)))
+    elif r < 0.95:
+        e.insert_material(9000, Material(base_color=rng.uniform(0.1, 0.9, 3).tolist() + [1.0], perceptual_roughness=float(rng.uniform(0.2, 1.0)))); edits += 1
     if args.observers and tick % 97 == 60:
         hdesc = scenes.dungeon_camera((160, 96), CameraMode.BVH_HEATMAP)
         hcam = e.create_camera(hdesc); hout = torch.zeros((96, 160, 4), dtype=torch.float32, device="cuda:0")
@@ -81,14 +85,14 @@ for tick in range(args.ticks):
             if base is None: base = live - 200 * len(alive)
             assert live == base + 200 * len(alive), f"tick {tick}: {live} leaf records for {len(alive)} instances"
             assert bad == 0 and twice == 1, f"tick {tick}: {bad} triangles not reached exactly once, a node linked {twice} times"
-print(f"{args.ticks} ticks{f' ({observers} heatmap observers came and went)' if args.observers else ''}: {e.device_builds()} device builds, {e.device_tree_refits()} refits, {e.bvh_refits()[0]} host rebuilds, {len(alive)} instances alive, {e.walk_overflow()[0]} overflows", flush=True)
+print(f"{args.ticks} ticks{f' ({observers} heatmap observers came and went)' if args.observers else ''}: {e.device_builds()} device builds, {e.device_tree_refits()} refits, {e.bvh_refits()[0]} host rebuilds, {len(alive)} instances alive, {edits} material edits, {e.walk_overflow()[0]} overflows", flush=True)
 # the final scene on the host's tree: the same primary hits
 ref_desc = scenes.dungeon_camera(size, CameraMode.REFERENCE, depth=0)
 hits = []
 for eng, fresh in ((e, False), (Engine(device=0), True)):
     if fresh:
-        eng.set_bvh_refresh(0); scenes.build_dungeon(eng, subdivide=args.subdivide); eng.set_seed(1); eng.insert_mesh(7777, blob)
-        for h, p in alive.items(): eng.insert_instance(h, Instance(7777, 2, place_at(p)))
+        eng.set_bvh_refresh(0); scenes.build_dungeon(eng, subdivide=args.subdivide); eng.set_seed(1); eng.insert_mesh(7777, blob); eng.insert_material(9000, Material(base_color=[0.8, 0.3, 0.2, 1.0]))
+        for h, p in alive.items(): eng.insert_instance(h, Instance(7777, 9000, place_at(p)))
     c = eng.create_camera(ref_desc)
     eng.update_camera(c, ref_desc); eng.tick(stream); eng.render_camera(c, out.data_ptr(), stream); torch.cuda.synchronize()
     hits.append(eng.read_buffer(c, Buffer.REF_HITS).reshape(size[1], size[0], -1).copy())
