@@ -675,6 +675,20 @@ def test_every_triangle_hangs_exactly_once_from_the_root_of_a_device_built_tree(
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("subdivide,ticks", [(0, 400), (2, 150)])
+def test_the_default_refresh_mode_under_churn(subdivide, ticks):
+    """tools/soak_builder.py: the dungeon renders in the default refresh mode while instances of a small mesh appear, disappear and move at random, their
+    material is edited and a BvhHeatmap camera comes and goes (device builds, refits, the host's tree back and the device's again, both scene copies
+    alternating). Every 50 ticks the device's wide tree is read back and walked — every live triangle exactly once, no node twice —, frames are finite, no
+    walk overflows; at the end the primary hits equal those of an engine that builds the same final scene on the host. (Longer runs: profiles/r06_soak_builder.txt.)"""
+    import subprocess, sys
+    _torch()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_builder.py"), "--ticks", str(ticks), "--subdivide", str(subdivide), "--seed", "5", "--observers"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "soak ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_triangles", [1, 2, 3, 5, 33, 257, 1025, 4099])
 def test_small_trees_built_on_the_device(n_triangles):
     """The device builder's small ends: a segment tree of fewer nodes than one workgroup's width (k_lbvh_seg_levels with count0 < 256, down to ONE
