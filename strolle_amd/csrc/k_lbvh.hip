@@ -82,18 +82,21 @@ __global__ __launch_bounds__(kT) void k_lbvh_bounds(const float4* tri_bounds, co
 }
 // 2. sort keys
 constexpr uint32_t kDeadCode = 0x40000000u;   // above every 30-bit Morton code: dead slots sort to the end (31 key bits)
-__global__ __launch_bounds__(kT) void k_lbvh_keys(const float4* tri_bounds, const uint32_t* tri_info, uint32_t slots, const int* bounds, uint32_t* codes, uint32_t* slot_of) {
+__global__ __launch_bounds__(kT) void k_lbvh_keys(const float4* tri_bounds, const uint32_t* tri_info, uint32_t slots, const int* bounds, uint32_t* codes, uint32_t* slot_of, float cell_aspect) {
     const uint32_t i = blockIdx.x * kT + threadIdx.x;
     if (i >= slots) return;
     slot_of[i] = i;
     if (!(tri_info[i] & 1u)) { codes[i] = kDeadCode; return; }
     const float4 lo = tri_bounds[2u * i], hi = tri_bounds[2u * i + 1u];
     const float c[3] = {(lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f};
+    // Morton cells of bounded aspect (round 6, late; st_lbvh.h kLbvhCellAspect): an axis is quantised by its own extent but never finer than cell_aspect x the largest one.
+    // With each axis stretched to 1,024 cells of its own (rounds 5-6) a wide, low scene got every third split along its thin axis — slabs cut where they are thinnest.
+    float largest = 0.0f;
+    for (int k = 0; k < 3; k++) largest = fmaxf(largest, unordered(bounds[3 + k]) - unordered(bounds[k]));
     uint32_t q[3];
     for (int k = 0; k < 3; k++) {
-        const float mn = unordered(bounds[k]), mx = unordered(bounds[3 + k]);
-        const float ext = mx - mn;
-        const float t = ext > 0.0f ? (c[k] - mn) / ext : 0.0f;
+        const float ext = fmaxf(unordered(bounds[3 + k]) - unordered(bounds[k]), largest * cell_aspect);   // cell_aspect 1: cubic cells; 0: every axis its own 1,024
+        const float t = ext > 0.0f ? (c[k] - unordered(bounds[k])) / ext : 0.0f;
         q[k] = (uint32_t)fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
     }
     codes[i] = expand10(q[0]) | (expand10(q[1]) << 1) | (expand10(q[2]) << 2);
@@ -277,7 +280,7 @@ int lbvh_build(const LbvhArgs& a, hipStream_t s) {
     // later refit read)
     uint32_t* codes_in = reinterpret_cast<uint32_t*>(a.keys_out); uint32_t* slots_in = codes_in + a.slots;
     uint32_t* codes_out = reinterpret_cast<uint32_t*>(a.keys_in); uint32_t* slots_out = codes_out + a.slots;
-    hipLaunchKernelGGL(k_lbvh_keys, grid(a.slots), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds, codes_in, slots_in);
+    hipLaunchKernelGGL(k_lbvh_keys, grid(a.slots), dim3(kT), 0, s, a.tri_bounds, a.tri_info, a.slots, a.bounds, codes_in, slots_in, a.cell_aspect);
     size_t temp = a.sort_temp_bytes;
     if (rocprim::radix_sort_pairs<LbvhSort>(a.sort_temp, temp, codes_in, codes_out, slots_in, slots_out, (size_t)a.slots, 0u, 31u, s) != hipSuccess) return -2;
     hipLaunchKernelGGL(k_lbvh_compose, grid(a.slots), dim3(kT), 0, s, codes_out, slots_out, a.slots, a.keys_out);

@@ -19,10 +19,16 @@ namespace st {
 struct LbvhArgs {
     const float4* tri_geo; const float4* tri_bounds; const uint32_t* tri_info;
     uint32_t slots, live, links16;
+    float cell_aspect;   // Morton cells: an axis is quantised by max(its own extent, cell_aspect x the largest extent) — 1: cubic cells, 0: 1,024 cells of its own per axis
     float4* nodes; float4* leaves;
     unsigned long long* keys_in; unsigned long long* keys_out; void* sort_temp; size_t sort_temp_bytes;
     float4* seg; uint2* children; float4* node_box; int* bounds;
 };
+// LbvhArgs::cell_aspect as shipped: no Morton cell more than 8 times as long along one axis as along another. Measured (tools/cell_aspect.py, profiles/r06_lbvh_cell_aspect.txt:
+// nine scenes of 13 k - 537 k triangles, steady frame over the device-built tree): with every axis its own 1,024 cells (0; rounds 5-6) a wide, low scene — 16 copies of the
+// dungeon's level side by side: 194 x 7.6 x 392 m — is sliced along its thin axis and renders 7-18 % slower than with 0.125; cubic cells (1) cost the plain dungeon 2-4 %.
+// 0.125 is within 1.4 % of the best of {0, 0.125, 0.25, 0.5, 1} on average (0: 5.4 %, 1: 3.0 %). ST_LBVH_CELL_ASPECT in the environment overrides it (measurements).
+constexpr float kLbvhCellAspect = 0.125f;
 size_t lbvh_sort_temp_bytes(uint32_t slots);
 uint32_t lbvh_pow2(uint32_t n);
 void lbvh_warm(int* bounds, hipStream_t stream);   // before the first build: the builder's code object on the device (bounds: the six ints of LbvhArgs::bounds)

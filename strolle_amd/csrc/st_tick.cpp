@@ -134,6 +134,7 @@ int Engine::build_on_device(SceneSet& t, hipStream_t up, bool* pageable) {
     LbvhArgs a{};
     a.tri_geo = static_cast<const float4*>(t.tri_geo.ptr); a.tri_bounds = static_cast<const float4*>(t.tri_bounds.ptr); a.tri_info = static_cast<const uint32_t*>(t.tri_info.ptr);
     a.slots = (uint32_t)slots; a.live = live; a.links16 = live < 32768u ? 1u : 0u;
+    { static const char* v = getenv("ST_LBVH_CELL_ASPECT"); a.cell_aspect = v ? (float)atof(v) : kLbvhCellAspect; }
     a.nodes = static_cast<float4*>(t.bvh_wide.ptr); a.leaves = a.nodes + 4u * (size_t)(live - 1u);
     a.keys_in = static_cast<unsigned long long*>(t.lb_keys_a.ptr); a.keys_out = static_cast<unsigned long long*>(t.lb_keys_b.ptr);
     a.sort_temp = t.lb_temp.ptr; a.sort_temp_bytes = temp;
