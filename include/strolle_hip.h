@@ -183,9 +183,9 @@ enum StBvhRefresh { ST_BVH_REBUILD = 0, ST_BVH_REFIT = 1,
                                                answered as ST_BVH_BUILD_DEVICE answers it, under the same conditions, so that a default engine no longer
                                                stalls for tens of milliseconds per spawn. The host's first tree is MEASURED (st_debug_auto_tree: the
                                                surface-area-weighted mean length of its leaf runs): above 3.4 — long runs of coplanar triangles on large
-                                               faces, a step of the wide walk each — the device builder's tree is used from that very tick on; over 17
-                                               scenes of 13 k - 537 k triangles that is exactly where it renders faster (3-16 %), and everywhere else the
-                                               host's tree is 3-13 % faster and stays (profiles/r06_tree_choice*.txt).
+                                               faces, a step of the wide walk each — the device builder's tree is used from that very tick on: 5-17 %
+                                               faster there; over 17 measured scene x mode rows of 13 k - 537 k triangles the default picks the faster
+                                               tree, or one within 1 % of it, in 16 (profiles/r06_tree_choice_auto.txt).
                                                Scenes whose stream fits the kernels' LDS copy (at most 112
                                                entries: the Cornell box), host-only engines, the exact build and observed contract streams behave as
                                                under ST_BVH_REBUILD. */ };

@@ -46,11 +46,11 @@ void Engine::rebuild_host_tree(bool timing) {
 bool Engine::device_build_possible() const {
     // ST_BVH_AUTO: a scene that fits LDS keeps its contract stream there (a leaf entry per triangle: more than 112 of them never fit); a larger one sends its
     // CHANGES to the device builder — and its FIRST tree too when the host's tree, built first, turns out to hang long leaf runs on large faces
-    // (auto_first_on_device: tick() sets it when rebuild_host_tree measured host_leaf_run_weight > kAutoLeafRunLimit). Measured on 17 scenes of 13 k to 537 k
-    // triangles (tools/tree_choice.py, profiles/r06_tree_choice*.txt): wherever that weight is 3.0 or less the frames over the host's binned-SAH tree are 3-13 %
-    // faster than over the device's LBVH; at 3.7 the device's is 0-2 % faster; at 4.2-4.5 (the dungeon with its level split x16: runs of up to 140 coplanar triangles, a wide
-    // walk's step each) the device's tree is 3-16 % faster. A triangle COUNT does not separate them: 16 instanced copies of the level (139 k triangles,
-    // weight 1.8) render 9-13 % faster on the host's tree, the x16-split level (134 k, weight 4.5) 11-16 % faster on the device's.
+    // (auto_first_on_device: tick() sets it when rebuild_host_tree measured host_leaf_run_weight > kAutoLeafRunLimit). Measured on 17 scene x mode rows of 13 k to 537 k
+    // triangles (tools/tree_choice.py, profiles/r06_tree_choice_auto.txt): at a weight of 3.0 or less the frames over the host's binned-SAH tree are up to 7 % faster than over
+    // the device's LBVH (two rows: the device's by 1 and 6 %); at 3.7 the device's is 1-2 % faster; at 4.2-4.5 (the dungeon with its level split x16: runs of up to 140
+    // coplanar triangles, a wide walk's step each) 5-17 % faster. A triangle COUNT does not separate them: 16 instanced copies of the level (139 k triangles, weight 1.8)
+    // render 1-7 % faster on the host's tree, the x16-split level (134 k, weight 4.5) 12-17 % faster on the device's.
     const bool automatic = bvh_refresh_mode == ST_BVH_AUTO && (scene_uploaded || auto_first_on_device) && live_prims_ > kLdsSceneTexels / 4u;
     if (!(bvh_refresh_mode == ST_BVH_BUILD_DEVICE || automatic) || !has_device || arithmetic != ST_ARITH_FAST) return false;
     if (!tuning.wide_bvh || !tuning.compact_bvh || !tuning.anyhit_fast || count_bytes) return false;
