@@ -7,7 +7,7 @@
 // (no heatmap camera, fast arithmetic, no byte counting) a scene change is followed by this builder instead:
 //
 //   1. centroid bounds of the live triangle slots                                   k_lbvh_bounds      (wave, then workgroup reduction: one ordered-int atomic pair per workgroup)
-//   2. key = 30-bit Morton code of the centroid << 32 | triangle slot (unique)      k_lbvh_keys        dead slots: ~0, sorted to the end
+//   2. key = 30-bit Morton code of the centroid << 32 | triangle slot (unique)      k_lbvh_keys        dead slots: ~0, sorted to the end; cells of bounded aspect (kLbvhCellAspect)
 //   3. radix sort                                                                   rocPRIM radix_sort_pairs over the 31-bit (code | dead) keys with the slot as value
 //      (round 5 sorted 64-bit keys); the sort is stable and its input in slot order, so the order is the same, and k_lbvh_compose rebuilds the 64-bit keys
 //      afterwards. Half the key bytes — and, measured, no faster: at 208 k keys the library runs the same 17 launches of 5-6 us either way (0.10 ms, launch-bound;
